@@ -1,0 +1,169 @@
+"""Generate the golden fixtures by running the REFERENCE's own functions.
+
+Run in the build container only (needs /root/reference and torch CPU):
+
+    python tests/golden/make_golden.py
+
+It imports ``ssds.modeling.layers.box`` / ``.decoder`` of the reference *unmodified*
+(ShuangXieIrene/ssds.pytorch v1.5), feeds them the seeded inputs of ``cases.py`` and
+stores the outputs under ``tests/golden/*.npz``.  The fixtures travel to the GPU box;
+the reference does not.  Nothing in the test-suite imports this file.
+"""
+import os
+import sys
+import warnings
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, "/root/reference")
+warnings.filterwarnings("ignore")
+
+import cases  # noqa: E402
+from ssds.modeling.layers import box as rbox  # noqa: E402  (the reference)
+from ssds.modeling.layers.decoder import Decoder as RDecoder  # noqa: E402
+
+torch.set_num_threads(1)
+F32 = np.float32
+
+
+def ref_gen(stride, ratios, scales):
+    return rbox.generate_anchors(stride, list(ratios), list(scales)).numpy()
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def gen_anchors():
+    out = {}
+    specs = {
+        "s8_a6": (8, [1, 2, 0.5], [2.0, 2.828]),
+        "s32_a9": (32, [1, 2, 0.5], [2.0, 4.0, 8.0]),
+        "s15_a6": (15, [1, 2, 0.5], [2.0, 2.828]),
+        "s100_a6": (100, [1, 2, 0.5], [2.0, 2.828]),
+        "s300_a6": (300, [1, 2, 0.5], [2.0, 2.828]),
+        "s16_a4": (16, [1, 3], [1.5, 2.5]),
+        "s64_a1": (64, [0.33], [1.0]),
+        "s7_a3": (7, [1, 2, 0.5], [1.26]),
+    }
+    for k, (s, r, sc) in specs.items():
+        out[k] = ref_gen(s, r, sc)
+        out[k + "_spec"] = np.array([s, len(r), len(sc)] + list(r) + list(sc), np.float64)
+    save("anchors", **out)
+
+
+def gen_codec():
+    rs = np.random.RandomState(5)
+    anchors = np.concatenate([ref_gen(16, [1, 2, 0.5], [2.0, 2.828])] * 20, 0)
+    anchors = anchors + np.repeat(rs.randint(0, 30, (anchors.shape[0], 1)) * 16.0, 4, 1).astype(F32)
+    xy = rs.random_sample((anchors.shape[0], 2)) * 400
+    wh = rs.random_sample((anchors.shape[0], 2)) * 100 + 1
+    boxes = np.concatenate([xy, xy + wh], 1).astype(F32)
+    deltas = rbox.box2delta(t(boxes), t(anchors)).numpy()
+    d2 = (rs.standard_normal(anchors.shape) * 0.5).astype(F32)
+    back = rbox.delta2box(t(d2), t(anchors), [32, 20], 16).numpy()
+    save("codec", anchors=anchors, boxes=boxes, deltas=deltas, d2=d2, back=back)
+
+
+def gen_decode():
+    out = {}
+    # the hand-checkable KAT of SURVEY section 4
+    conf = np.zeros((1, 2, 2, 2), F32)
+    conf[0, 1, 0, 1] = 0.9
+    conf[0, 0, 1, 0] = 0.6
+    loc = np.zeros((1, 4, 2, 2), F32)
+    anc = np.array([[-4, -4, 11, 11]], F32)
+    for rescore in (False, True):
+        s, b, c = rbox.decode(t(conf), t(loc), 8, 0.05, 10, t(anc), rescore)
+        out["kat_r%d_scores" % rescore] = s.numpy()
+        out["kat_r%d_boxes" % rescore] = b.numpy()
+        out["kat_r%d_classes" % rescore] = c.numpy()
+    for name in cases.DECODE_CASES:
+        d = cases.decode_inputs(name)
+        anchors = cases.anchors_for(d["A"], d["stride"], ref_gen)
+        s, b, c = rbox.decode(
+            t(d["cls"]), t(d["box"]), d["stride"], d["thr"], d["top_n"], t(anchors), d["rescore"]
+        )
+        s, b, c = s.numpy(), b.numpy(), c.numpy()
+        out[name + "_scores"], out[name + "_boxes"], out[name + "_classes"] = s, b, c
+        out[name + "_crc"] = cases.checksum(d["cls"], d["box"], anchors)
+        print("decode", name, "filled", (s != 0).sum(1))
+    save("decode", **out)
+
+
+def gen_nms():
+    out = {}
+    s, b, c = rbox.nms(
+        t(np.array([[0.9, 0.8, 0.5]], F32)),
+        t(np.array([[[0, 0, 10, 10], [0, 0, 10, 10], [20, 20, 30, 30]]], F32)),
+        t(np.zeros((1, 3), F32)), 0.5, 3, True,
+    )
+    out["kat_scores"], out["kat_boxes"], out["kat_classes"] = s.numpy(), b.numpy(), c.numpy()
+    for name in cases.NMS_CASES:
+        d = cases.nms_inputs(name)
+        s, b, c = rbox.nms(t(d["scores"]), t(d["boxes"]), t(d["classes"]), d["thr"], d["ndet"], d["diou"])
+        s, b, c = s.numpy(), b.numpy(), c.numpy()
+        out[name + "_scores"], out[name + "_boxes"], out[name + "_classes"] = s, b, c
+        out[name + "_crc"] = cases.checksum(d["scores"], d["boxes"], d["classes"])
+        print("nms", name, "kept", (s > 0).sum(1))
+    save("nms", **out)
+
+
+def gen_decoder():
+    out = {}
+    for name in cases.DECODER_CASES:
+        d = cases.decoder_inputs(name, ref_gen)
+        dec = RDecoder(d["thr"], d["nms"], d["top_n"], d["per_level"], d["rescore"], d["diou"])
+        anchors = OrderedDict((k, t(v)) for k, v in d["anchors"].items())
+        loc = [t(x) for x in d["loc"]]
+        conf = [t(x) for x in d["conf"]]
+        # intermediate (concatenated per-level decode) + final
+        decoded = [
+            rbox.decode(c, l, stride, dec.conf_threshold, dec.top_n_per_level, anchor, rescore=dec.rescore)
+            for l, c, (stride, anchor) in zip(loc, conf, anchors.items())
+        ]
+        decoded = [torch.cat(ts, 1) for ts in zip(*decoded)]
+        pos = decoded[0][decoded[0] > 0]
+        assert pos.unique().numel() == pos.numel(), "tie in rescored scores; change the seed"
+        s, b, c = dec(loc, conf, anchors)
+        out[name + "_mid_scores"] = decoded[0].numpy()
+        out[name + "_mid_boxes"] = decoded[1].numpy()
+        out[name + "_mid_classes"] = decoded[2].numpy()
+        out[name + "_scores"], out[name + "_boxes"], out[name + "_classes"] = s.numpy(), b.numpy(), c.numpy()
+        out[name + "_crc"] = cases.checksum(*d["loc"], *d["conf"])
+        print("decoder", name, "kept", (s.numpy() > 0).sum(1))
+    save("decoder", **out)
+
+
+def gen_match():
+    out = {}
+    for name in cases.MATCH_CASES:
+        d = cases.match_inputs(name, ref_gen)
+        anchors = OrderedDict([(d["stride"], t(d["anchors"]))])
+        ct, bt, dp = rbox.extract_targets(
+            t(d["targets"]), anchors, d["C"], d["stride"], d["size"], list(map(float, d["match"])), d["radius"]
+        )
+        out[name + "_cls"], out[name + "_box"], out[name + "_depth"] = (
+            ct.numpy().astype(np.uint8), bt.numpy(), dp.numpy())
+        out[name + "_crc"] = cases.checksum(d["targets"], d["anchors"])
+        print("match", name, "fg", int((dp > 0).sum()), "ignore", int((dp < 0).sum()), "shape", tuple(ct.shape))
+    save("match", **out)
+
+
+if __name__ == "__main__":
+    gen_anchors()
+    gen_codec()
+    gen_decode()
+    gen_nms()
+    gen_decoder()
+    gen_match()
