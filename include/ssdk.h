@@ -1,0 +1,131 @@
+/*
+ * ssdk.h -- C-ABI of the MI355X-native detection hot path of ssds.pytorch.
+ *
+ * The reference (ShuangXieIrene/ssds.pytorch v1.5) is pure Python; the only native interface it
+ * names is the phantom plugin `ssds._C` that it imports but never ships:
+ *     ssds/modeling/layers/box.py:3-4        from ssds._C import decode / nms   (commented out)
+ *     ssds/modeling/layers/box.py:419-421    decode_cuda(cls_head, box_head, anchors.view(-1).tolist(),
+ *                                                        stride, threshold, top_n)
+ *     ssds/modeling/layers/box.py:483-485    nms_cuda(scores, boxes, classes, nms, ndetections)
+ *     ssds/utils/export.py:134-153           ssds._C (TensorRT; out of scope)
+ * This header is what a maintainer's `ssds._C` (ctypes / pybind stub) binds.
+ * Every entry point below cites the Python function it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  `stream` is a hipStream_t passed as void*.
+ *   - the caller owns every buffer (inputs, outputs, workspace); kernels never allocate, never
+ *     synchronise, and fully write their outputs (zero padding included), so every call is
+ *     hipGraph-capturable on the caller's stream.
+ *   - return value: 0 = ok, negative = error (SSDK_E_*); text via ssdk_last_error() (thread local).
+ *   - head tensors are NCHW contiguous, channel = a*C + c (conf) / a*4 + k (loc), exactly the layout
+ *     the reference's heads produce (ssd.py:68-70); base pointers must be 16-byte aligned.
+ *   - tie order (unspecified in the reference's topk/sort): score descending, flat index ascending.
+ *   - all box arithmetic is IEEE fp32 in the reference's operation order without FMA contraction,
+ *     inputs of any dtype are upcast to fp32 first; outputs are always fp32 (box.py:430-432).
+ */
+#ifndef SSDK_H_
+#define SSDK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSDK_VERSION 100 /* 0.1.0 */
+
+#define SSDK_MAX_LEVELS 8    /* feature-map levels per decode_nms call            */
+#define SSDK_MAX_ANCHORS 16  /* anchors per location (A)                          */
+#define SSDK_MAX_TOPN 1024   /* top_n per level (box.decode) / candidates kept    */
+#define SSDK_MAX_NDET 1024   /* ndetections (box.nms)                             */
+#define SSDK_MAX_NMS_N 8192  /* candidates per image entering nms                 */
+#define SSDK_MAX_GT 256      /* ground-truth rows per image (extract_targets)     */
+
+enum {
+  SSDK_OK = 0,
+  SSDK_E_BADARG = -1,    /* null / misaligned pointer, size out of range          */
+  SSDK_E_WORKSPACE = -2, /* workspace too small (see *_workspace_bytes)           */
+  SSDK_E_LAUNCH = -3,    /* HIP launch error                                      */
+  SSDK_E_NODEVICE = -4   /* no HIP device / wrong architecture                    */
+};
+
+typedef enum { SSDK_F32 = 0, SSDK_BF16 = 1, SSDK_F16 = 2 } ssdk_dtype;
+typedef enum {
+  SSDK_ACT_NONE = 0,
+  SSDK_ACT_RELU = 1,
+  SSDK_ACT_RELU6 = 2,
+  SSDK_ACT_SILU = 3,
+  SSDK_ACT_SIGMOID = 4
+} ssdk_act;
+
+/* One feature-map level of the multibox head (decoder.py:36-47 zips loc, conf, anchors.items()). */
+typedef struct ssdk_level {
+  const void* cls; /* device, [B, A*C, H, W] scores (sigmoid probabilities in eval, ssd.py:72-73) */
+  const void* box; /* device, [B, A*4, H, W] deltas                                               */
+  int32_t A, C, H, W;
+  int32_t stride;                       /* key of the anchors OrderedDict (model_builder.py:41)  */
+  float anchors[SSDK_MAX_ANCHORS * 4];  /* host values, generate_anchors(stride, ...) ltrb       */
+} ssdk_level;
+
+int ssdk_version(void);
+const char* ssdk_last_error(void);
+
+/* Device facts the host side needs for roofline accounting (bench.py). Returns 0 / SSDK_E_NODEVICE. */
+int ssdk_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes, char* arch, int arch_len);
+
+/* box.py:46-58 generate_anchors(stride, ratio_vals, scales_vals) -> out[nr*ns*4] (HOST memory, fp32).
+ * Ordering: scale-major, ratio-minor.  Pure host function (runs once per model/image size). */
+int ssdk_generate_anchors(int stride, const float* ratios, int nr, const float* scales, int ns,
+                          float* out);
+
+/* box.py:408-477 decode(all_cls_head, all_box_head, stride, threshold, top_n, anchors, rescore)
+ * for ONE level.  Replaces the phantom ssds._C.decode (box.py:419-421), extended by `rescore` and
+ * a dtype.  scores[B*top_n], boxes[B*top_n*4], classes[B*top_n] device fp32, zero padded. */
+size_t ssdk_decode_workspace_bytes(const ssdk_level* levels, int L, int B, int dtype, int top_n);
+int ssdk_decode(const ssdk_level* level, int B, int dtype, float threshold, int top_n, int rescore,
+                float* scores, float* boxes, float* classes, void* workspace,
+                size_t workspace_bytes, void* stream);
+
+/* box.py:480-546 nms(all_scores, all_boxes, all_classes, nms, ndetections, using_diou).
+ * Replaces the phantom ssds._C.nms (box.py:483-485), extended by `using_diou`.
+ * in: scores[B*N], boxes[B*N*4], classes[B*N]; out: [B*ndet], [B*ndet*4], [B*ndet]; device fp32. */
+size_t ssdk_nms_workspace_bytes(int B, int N, int ndetections);
+int ssdk_nms(const float* scores, const float* boxes, const float* classes, int B, int N,
+             float nms_threshold, int ndetections, int using_diou, float* out_scores,
+             float* out_boxes, float* out_classes, void* workspace, size_t workspace_bytes,
+             void* stream);
+
+/* decoder.py:25-49 Decoder.__call__: decode every level -> concat -> nms, as <=3 launches.
+ * mid_* (optional, may be NULL): the concatenated per-level decode output [B, L*top_n(,4)] that the
+ * reference materialises with torch.cat (decoder.py:48); when NULL it lives in the workspace. */
+size_t ssdk_decode_nms_workspace_bytes(const ssdk_level* levels, int L, int B, int dtype,
+                                       int top_n_per_level, int ndetections);
+int ssdk_decode_nms(const ssdk_level* levels, int L, int B, int dtype, float threshold,
+                    int top_n_per_level, int rescore, float nms_threshold, int ndetections,
+                    int using_diou, float* out_scores, float* out_boxes, float* out_classes,
+                    float* mid_scores, float* mid_boxes, float* mid_classes, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* box.py:362-405 extract_targets + box.py:116-226 snap_to_anchors_by_iou for ONE level and the whole
+ * batch in one launch.  targets[B*G*5] device fp32 (x, y, w, h, label), rows with label <= -1 are
+ * padding (box.py:375).  anchors[A*4] HOST fp32.  Outputs device fp32, fully written:
+ * cls_target[B,A,C,H,W], box_target[B,A,4,H,W], depth[B,A,1,H,W]. */
+int ssdk_match_targets(const float* targets, int B, int G, const float* anchors, int A, int C, int H,
+                       int W, int stride, float match_threshold, float unmatch_threshold,
+                       float center_sampling_radius, float* cls_target, float* box_target,
+                       float* depth, void* stream);
+
+/* basic_layers.py:28-57 (Conv+BN+ReLU blocks) and ssd.py:100-103 / fpn.py:10-18 (head convs) as one
+ * fused implicit-GEMM on MFMA: y = act(conv(x, w) * scale[c] + bias[c]).
+ * x [N,Cin,H,W] NCHW (dtype), w [Cout,Cin,kh,kw] (dtype), scale/bias [Cout] fp32 (folded BN; scale may
+ * be NULL = 1), y [N,Cout,Ho,Wo] NCHW (out_dtype).  kh=kw in {1,3}, stride in {1,2}, pad = k/2. */
+size_t ssdk_conv_workspace_bytes(int N, int Cin, int H, int W, int Cout, int k, int stride, int dtype);
+int ssdk_conv_bn_act(const void* x, const void* w, const float* scale, const float* bias, int N,
+                     int Cin, int H, int W, int Cout, int k, int stride, int act, int dtype,
+                     int out_dtype, void* y, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSDK_H_ */

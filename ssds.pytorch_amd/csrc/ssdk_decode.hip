@@ -1,0 +1,475 @@
+// ssdk_decode.hip -- threshold + exact top-k + box decode + centre rescoring on gfx950.
+//
+// Replaces box.decode (reference ssds/modeling/layers/box.py:408-477), which the reference runs as
+// ~25 ATen launches per (image, level) with nonzero() host syncs.  Here:
+//
+//   scan_kernel<DT>     ONE pass over the conf tensor (the HBM-bound part: 2 B/score in bf16).  Each
+//                       workgroup streams a "unit" (tiles_per_unit x 256 x 16 B) of one (image, level)
+//                       with 16-byte coalesced loads, 4 loads in flight per lane, and keeps the exact
+//                       top-K of what it has seen in LDS (TopK stream, ssdk_select.h).  It emits <=K
+//                       64-bit keys (score bits | ~flat index) per unit.
+//   level_kernel        per (image, level): merges the units' keys (same streaming top-K), sorts the
+//                       K winners, gathers their 4 deltas, applies delta2box (box.py:74-87) and the
+//                       centre rescoring (box.py:464-471) in the reference's fp32 operation order and
+//                       writes the zero-padded [B, top_n] outputs (box.py:430-432, 473-475).
+//
+// Algorithmic HBM bytes: the conf tensor once + 4 deltas per winner + outputs.
+#include "ssdk_common.h"
+#include "ssdk_select.h"
+
+namespace ssdk {
+
+constexpr int kScanThreads = 256;
+constexpr u32 kCap = 4096;         // LDS candidate slots per workgroup
+constexpr int kPrefetch = 4;       // 16-byte loads in flight per lane
+
+struct ScanLevel {
+  const void* cls;
+  u32 n;          // A*C*H*W scores per image
+  u32 units;      // units per image for this level
+  u32 unit_base;  // first unit id of this level inside an image
+  u32 pad;
+};
+struct ScanParams {
+  ScanLevel lv[SSDK_MAX_LEVELS];
+  int L;
+  u32 units_per_image;
+  u32 tiles_per_unit;
+  u32 K;
+  float thr;
+  u64* cand;      // [B][units_per_image][K]
+  u32* cand_cnt;  // [B][units_per_image]
+};
+
+struct LevelDesc {
+  const void* box;
+  int A, C, H, W, stride;
+  u32 units, unit_base;
+  float anchors[SSDK_MAX_ANCHORS * 4];
+};
+struct LevelParams {
+  LevelDesc lv[SSDK_MAX_LEVELS];
+  int L, dtype, rescore;
+  u32 units_per_image, K;
+  u32 out_stride;  // L*K
+  const u64* cand;
+  const u32* cand_cnt;
+  float* scores;
+  float* boxes;
+  float* classes;
+};
+
+struct LevelLds {  // per-workgroup copy of the level geometry (per-lane indexed anchors live in LDS)
+  const void* box;
+  int A, C, H, W, stride;
+  u32 units, unit_base, pad;
+  float anchors[SSDK_MAX_ANCHORS * 4];
+};
+
+__host__ __device__ inline size_t lds_bytes_for(u32 K) {
+  return (size_t)kCap * 8 + (size_t)((K + 1) & ~1u) * 8 + sizeof(SelScratch) + sizeof(StreamCtl) +
+         sizeof(LevelLds);
+}
+
+template <int DT, int E>
+__device__ __forceinline__ void scan_elems(const u32x4& v, u32 idx0, u32 n, float cut, u32 cut_idx,
+                                           u64* buf, StreamCtl* ctl, u32 limit, u32 tile) {
+  if constexpr (E < DType<DT>::vec) {
+    const float s = vec_elem<DT, E>(v);
+    const u32 idx = idx0 + E;  // wraps to a huge value for the (masked) head elements
+    const bool pass = (idx < n) & ((s > cut) | ((s == cut) & (idx < cut_idx)));
+    stream_append(buf, ctl, limit, tile, pass, make_key(s, idx));
+    scan_elems<DT, E + 1>(v, idx0, n, cut, cut_idx, buf, ctl, limit, tile);
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) {
+  constexpr int NT = kScanThreads;
+  constexpr int VEC = DType<DT>::vec;
+  constexpr int ES = DType<DT>::size;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64* buf = reinterpret_cast<u64*>(smem);
+  u64* sel = buf + kCap;
+  SelScratch* ss = reinterpret_cast<SelScratch*>(sel + ((p.K + 1) & ~1u));
+  StreamCtl* ctl = reinterpret_cast<StreamCtl*>(ss + 1);
+
+  const u32 tid = threadIdx.x;
+  const u32 b = blockIdx.x / p.units_per_image;
+  const u32 u = blockIdx.x % p.units_per_image;
+  u32 n = p.lv[0].n, ubase = 0;
+  const void* cls = p.lv[0].cls;
+#pragma unroll
+  for (int i = 1; i < SSDK_MAX_LEVELS; ++i)
+    if (i < p.L && u >= p.lv[i].unit_base) {
+      n = p.lv[i].n;
+      ubase = p.lv[i].unit_base;
+      cls = p.lv[i].cls;
+    }
+  const u32 uu = u - ubase;
+
+  // image b of this level starts at byte b*n*ES; loads are 16-byte aligned vectors, `head` elements
+  // of the first vector belong to the previous image and are masked by the index test.
+  const unsigned char* base = (const unsigned char*)cls + (size_t)b * n * ES;
+  const u32 head = (u32)((uintptr_t)base & 15u) / ES;
+  const unsigned char* abase = base - (size_t)head * ES;
+  const u32 nvec_full = (head + n) / VEC;        // complete vectors
+  const u32 tail = (head + n) % VEC;             // elements in the last partial vector
+  const u32 vec0 = uu * p.tiles_per_unit * NT;   // first vector of this unit
+  const u32 nvec = nvec_full + (tail ? 1u : 0u);
+  u32 ntiles = 0;
+  if (vec0 < nvec) {
+    ntiles = (nvec - vec0 + NT - 1) / NT;
+    if (ntiles > p.tiles_per_unit) ntiles = p.tiles_per_unit;
+  }
+
+  if (tid == 0) {
+    ctl->cnt = 0;
+    ctl->flag[0] = 0;
+    ctl->flag[1] = 0;
+  }
+  __syncthreads();
+
+  const u32 K = p.K;
+  const u32 limit = kCap - NT * VEC;
+  float cut = p.thr;
+  u32 cut_idx = 0xffffffffu;
+
+  auto load_vec = [&](u32 t) -> u32x4 {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    const u32 vi = vec0 + t * NT + tid;
+    if (t < ntiles) {
+      if (vi < nvec_full) {
+        v = *reinterpret_cast<const u32x4*>(abase + (size_t)vi * 16);
+      } else if (vi == nvec_full && tail) {  // last partial vector: never read past the tensor
+        const unsigned char* q = abase + (size_t)vi * 16;
+        u32 w[4] = {0u, 0u, 0u, 0u};
+        for (u32 e = 0; e < tail; ++e) {
+          if constexpr (ES == 4) w[e] = ((const u32*)q)[e];
+          else w[e >> 1] |= (u32)((const u16*)q)[e] << ((e & 1) * 16);
+        }
+        v = u32x4{w[0], w[1], w[2], w[3]};
+      }
+    }
+    return v;
+  };
+
+  u32x4 pf[kPrefetch];
+#pragma unroll
+  for (int i = 0; i < kPrefetch; ++i) pf[i] = load_vec(i);
+
+  for (u32 t0 = 0; t0 < ntiles; t0 += kPrefetch) {
+#pragma unroll
+    for (int i = 0; i < kPrefetch; ++i) {
+      const u32 t = t0 + i;
+      if (t < ntiles) {  // workgroup-uniform
+        const u32x4 v = pf[i];
+        pf[i] = load_vec(t + kPrefetch);
+        const u32 idx0 = (vec0 + t * NT + tid) * VEC - head;
+        scan_elems<DT, 0>(v, idx0, n, cut, cut_idx, buf, ctl, limit, t);
+        u64 T;
+        if (stream_finish_tile<NT>(buf, sel, ss, ctl, t, K, &T)) {
+          cut = key_score(T);
+          cut_idx = key_index(T);
+        }
+      }
+    }
+  }
+
+  const u32 cnt = stream_finalize<NT>(buf, sel, ss, ctl, K);
+  u64* out = p.cand + ((size_t)b * p.units_per_image + u) * K;
+  for (u32 i = tid; i < K; i += NT) out[i] = (i < cnt) ? buf[i] : 0ull;
+  if (tid == 0) p.cand_cnt[(size_t)b * p.units_per_image + u] = cnt;
+}
+
+// box.py:74-87 delta2box + box.py:459-471 for one winner; fp32, reference operation order.
+__device__ __forceinline__ void decode_one(const LevelLds& d, int dtype, int rescore, u32 b, u32 idx,
+                                           float score, float* o_score, float* o_box, float* o_cls) {
+  const u32 W = d.W, H = d.H, C = d.C;
+  const u32 x = idx % W;
+  const u32 y = (idx / W) % H;
+  const u32 c = (idx / W / H) % C;   // box.py:448
+  const u32 a = idx / C / H / W;     // box.py:454
+  const size_t hw = (size_t)H * W;
+  const size_t boff = ((size_t)b * d.A * 4 + (size_t)a * 4) * hw + (size_t)y * W + x;
+  const float d0 = load_as_f32(d.box, boff, dtype);
+  const float d1 = load_as_f32(d.box, boff + hw, dtype);
+  const float d2 = load_as_f32(d.box, boff + 2 * hw, dtype);
+  const float d3 = load_as_f32(d.box, boff + 3 * hw, dtype);
+  const float fs = (float)d.stride;
+  const float g0 = (float)x * fs + d.anchors[a * 4 + 0];  // box.py:459-462
+  const float g1 = (float)y * fs + d.anchors[a * 4 + 1];
+  const float g2 = (float)x * fs + d.anchors[a * 4 + 2];
+  const float g3 = (float)y * fs + d.anchors[a * 4 + 3];
+  const float aw = g2 - g0 + 1.0f, ah = g3 - g1 + 1.0f;  // box.py:77
+  const float cx = g0 + 0.5f * aw, cy = g1 + 0.5f * ah;  // box.py:78
+  const float pcx = d0 * aw + cx, pcy = d1 * ah + cy;    // box.py:79
+  const float pw = expf(d2) * aw;                       // box.py:80
+  const float ph = expf(d3) * ah;
+  const float Mx = (float)W * fs - 1.0f, My = (float)H * fs - 1.0f;  // box.py:83
+  const float x1 = tmax(0.0f, tmin(pcx - 0.5f * pw, Mx));           // box.py:84-87
+  const float y1 = tmax(0.0f, tmin(pcy - 0.5f * ph, My));
+  const float x2 = tmax(0.0f, tmin(pcx + 0.5f * pw - 1.0f, Mx));
+  const float y2 = tmax(0.0f, tmin(pcy + 0.5f * ph - 1.0f, My));
+  float s = score;
+  if (rescore) {  // box.py:464-471
+    const float gcx = (g0 + g2) / 2.0f, gcy = (g1 + g3) / 2.0f;
+    const float ltx = fabsf(gcx - x1), lty = fabsf(gcy - y1);
+    const float rbx = fabsf(x2 - gcx), rby = fabsf(y2 - gcy);
+    const float rx = tmin(ltx, rbx) / tmax(ltx, rbx);
+    const float ry = tmin(lty, rby) / tmax(lty, rby);
+    s = s * sqrtf(rx * ry);
+  }
+  *o_score = s;
+  o_box[0] = x1;
+  o_box[1] = y1;
+  o_box[2] = x2;
+  o_box[3] = y2;
+  *o_cls = (float)c;
+}
+
+constexpr int kLevelThreads = 256;
+
+__global__ __launch_bounds__(kLevelThreads) void level_kernel(const LevelParams p) {
+  constexpr int NT = kLevelThreads;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64* buf = reinterpret_cast<u64*>(smem);
+  u64* sel = buf + kCap;
+  SelScratch* ss = reinterpret_cast<SelScratch*>(sel + ((p.K + 1) & ~1u));
+  StreamCtl* ctl = reinterpret_cast<StreamCtl*>(ss + 1);
+
+  LevelLds* dl = reinterpret_cast<LevelLds*>(ctl + 1);
+
+  const u32 tid = threadIdx.x;
+  const u32 l = blockIdx.x, b = blockIdx.y;
+#pragma unroll
+  for (int i = 0; i < SSDK_MAX_LEVELS; ++i)
+    if (i == (int)l) {
+      if (tid == 0) {
+        dl->box = p.lv[i].box;
+        dl->A = p.lv[i].A;
+        dl->C = p.lv[i].C;
+        dl->H = p.lv[i].H;
+        dl->W = p.lv[i].W;
+        dl->stride = p.lv[i].stride;
+        dl->units = p.lv[i].units;
+        dl->unit_base = p.lv[i].unit_base;
+      }
+      if (tid < SSDK_MAX_ANCHORS * 4) dl->anchors[tid] = p.lv[i].anchors[tid];
+    }
+  __syncthreads();
+  const LevelLds& d = *dl;
+  const u32 K = p.K;
+  const u64* src = p.cand + ((size_t)b * p.units_per_image + d.unit_base) * K;
+  u32 n;
+  if (d.units == 1) {  // the scan kernel already produced the exact top-K of this (image, level)
+    n = p.cand_cnt[(size_t)b * p.units_per_image + d.unit_base];
+    for (u32 i = tid; i < n; i += NT) buf[i] = src[i];
+    __syncthreads();
+  } else {
+    if (tid == 0) {
+      ctl->cnt = 0;
+      ctl->flag[0] = 0;
+      ctl->flag[1] = 0;
+    }
+    __syncthreads();
+    const u32 total = d.units * K;
+    constexpr u32 PER = 4, TILE = NT * PER;
+    const u32 limit = kCap - TILE;
+    u64 cutkey = 0;
+    const u32 ntiles = (total + TILE - 1) / TILE;
+    for (u32 t = 0; t < ntiles; ++t) {
+      u64 k[PER];
+#pragma unroll
+      for (u32 j = 0; j < PER; ++j) {
+        const u32 i = t * TILE + j * NT + tid;
+        k[j] = (i < total) ? src[i] : 0ull;
+      }
+#pragma unroll
+      for (u32 j = 0; j < PER; ++j) stream_append(buf, ctl, limit, t, k[j] > cutkey, k[j]);
+      u64 T;
+      if (stream_finish_tile<NT>(buf, sel, ss, ctl, t, K, &T)) cutkey = T;
+    }
+    n = stream_finalize<NT>(buf, sel, ss, ctl, K);
+    __syncthreads();
+  }
+
+  // sort the winners: descending key == (score desc, index asc)  (torch.topk sorted=True, box.py:446)
+  u32 M = 2;
+  while (M < n) M <<= 1;
+  for (u32 i = n + tid; i < M; i += NT) buf[i] = 0ull;
+  __syncthreads();
+  wg_bitonic_sort_desc<NT>(buf, M);
+
+  float* so = p.scores + (size_t)b * p.out_stride + (size_t)l * K;
+  float* bo = p.boxes + ((size_t)b * p.out_stride + (size_t)l * K) * 4;
+  float* co = p.classes + (size_t)b * p.out_stride + (size_t)l * K;
+  for (u32 i = tid; i < K; i += NT) {
+    float s = 0.f, c = 0.f, bx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+      const u64 key = buf[i];
+      decode_one(d, p.dtype, p.rescore, b, key_index(key), key_score(key), &s, bx, &c);
+    }
+    so[i] = s;
+    co[i] = c;
+    *reinterpret_cast<float4*>(bo + (size_t)i * 4) = make_float4(bx[0], bx[1], bx[2], bx[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct DecodePlan {
+  u32 tiles_per_unit, units_per_image;
+  u32 units[SSDK_MAX_LEVELS], unit_base[SSDK_MAX_LEVELS], n[SSDK_MAX_LEVELS];
+  size_t cand_bytes, cnt_bytes;
+};
+
+static int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+static int make_plan(const ssdk_level* lv, int L, int B, int dtype, int K, DecodePlan* pl) {
+  if (!lv || L < 1 || L > SSDK_MAX_LEVELS || B < 1) {
+    set_error("decode: need 1 <= L <= %d levels and B >= 1 (L=%d, B=%d)", SSDK_MAX_LEVELS, L, B);
+    return SSDK_E_BADARG;
+  }
+  if (K < 1 || K > SSDK_MAX_TOPN) {
+    set_error("decode: top_n=%d outside [1, %d]", K, SSDK_MAX_TOPN);
+    return SSDK_E_BADARG;
+  }
+  if (dtype != SSDK_F32 && dtype != SSDK_BF16 && dtype != SSDK_F16) {
+    set_error("decode: unknown dtype %d", dtype);
+    return SSDK_E_BADARG;
+  }
+  const u32 vec = dtype == SSDK_F32 ? 4 : 8;
+  const u32 tile = kScanThreads * vec;
+  unsigned long long tiles_total = 0;
+  for (int l = 0; l < L; ++l) {
+    const ssdk_level& v = lv[l];
+    if (v.A < 1 || v.A > SSDK_MAX_ANCHORS || v.C < 1 || v.H < 1 || v.W < 1) {
+      set_error("decode: level %d has bad dims A=%d C=%d H=%d W=%d", l, v.A, v.C, v.H, v.W);
+      return SSDK_E_BADARG;
+    }
+    const unsigned long long n = (unsigned long long)v.A * v.C * v.H * v.W;
+    if (n >= (1ull << 31)) {
+      set_error("decode: level %d has %llu scores per image (limit 2^31)", l, n);
+      return SSDK_E_BADARG;
+    }
+    pl->n[l] = (u32)n;
+    tiles_total += (n + vec + tile - 1) / tile;
+  }
+  // unit size: enough workgroups to fill 256 CUs x 4 resident, but units as large as possible so that
+  // the per-unit prune/select and the K keys written per unit amortise.
+  int tpu = env_int("SSDK_TILES_PER_UNIT", 0);
+  if (tpu <= 0) {
+    const unsigned long long target_wgs = (unsigned long long)env_int("SSDK_TARGET_WGS", 1024);
+    unsigned long long t = (tiles_total * (unsigned long long)B + target_wgs - 1) / target_wgs;
+    tpu = (int)(t < 4 ? 4 : (t > 64 ? 64 : t));
+  }
+  pl->tiles_per_unit = (u32)tpu;
+  u32 base = 0;
+  for (int l = 0; l < L; ++l) {
+    const u32 tiles = (u32)(((unsigned long long)pl->n[l] + vec + tile - 1) / tile);
+    pl->units[l] = (tiles + tpu - 1) / tpu;
+    pl->unit_base[l] = base;
+    base += pl->units[l];
+  }
+  pl->units_per_image = base;
+  pl->cand_bytes = (size_t)B * base * K * sizeof(u64);
+  pl->cnt_bytes = (((size_t)B * base * sizeof(u32)) + 255) & ~(size_t)255;
+  return SSDK_OK;
+}
+
+static int launch_decode(const ssdk_level* lv, int L, int B, int dtype, float thr, int K, int rescore,
+                         float* scores, float* boxes, float* classes, void* ws, size_t ws_bytes,
+                         hipStream_t stream) {
+  DecodePlan pl;
+  int rc = make_plan(lv, L, B, dtype, K, &pl);
+  if (rc) return rc;
+  if (!scores || !boxes || !classes) {
+    set_error("decode: null output pointer");
+    return SSDK_E_BADARG;
+  }
+  if (!ws || ws_bytes < pl.cand_bytes + pl.cnt_bytes || ((uintptr_t)ws & 15)) {
+    set_error("decode: workspace too small or misaligned (%zu < %zu)", ws_bytes, pl.cand_bytes + pl.cnt_bytes);
+    return SSDK_E_WORKSPACE;
+  }
+  ScanParams sp;
+  LevelParams lp;
+  memset(&sp, 0, sizeof(sp));
+  memset(&lp, 0, sizeof(lp));
+  for (int l = 0; l < L; ++l) {
+    if (!lv[l].cls || !lv[l].box || ((uintptr_t)lv[l].cls & 15)) {
+      set_error("decode: level %d has a null or non-16-byte-aligned head pointer", l);
+      return SSDK_E_BADARG;
+    }
+    sp.lv[l].cls = lv[l].cls;
+    sp.lv[l].n = pl.n[l];
+    sp.lv[l].units = pl.units[l];
+    sp.lv[l].unit_base = pl.unit_base[l];
+    lp.lv[l].box = lv[l].box;
+    lp.lv[l].A = lv[l].A;
+    lp.lv[l].C = lv[l].C;
+    lp.lv[l].H = lv[l].H;
+    lp.lv[l].W = lv[l].W;
+    lp.lv[l].stride = lv[l].stride;
+    lp.lv[l].units = pl.units[l];
+    lp.lv[l].unit_base = pl.unit_base[l];
+    memcpy(lp.lv[l].anchors, lv[l].anchors, sizeof(float) * 4 * lv[l].A);
+  }
+  sp.L = L;
+  sp.units_per_image = pl.units_per_image;
+  sp.tiles_per_unit = pl.tiles_per_unit;
+  sp.K = (u32)K;
+  sp.thr = thr;
+  sp.cand = (u64*)ws;
+  sp.cand_cnt = (u32*)((char*)ws + pl.cand_bytes);
+  lp.L = L;
+  lp.dtype = dtype;
+  lp.rescore = rescore;
+  lp.units_per_image = pl.units_per_image;
+  lp.K = (u32)K;
+  lp.out_stride = (u32)(L * K);
+  lp.cand = sp.cand;
+  lp.cand_cnt = sp.cand_cnt;
+  lp.scores = scores;
+  lp.boxes = boxes;
+  lp.classes = classes;
+
+  const size_t lds = lds_bytes_for((u32)K);
+  const dim3 grid((unsigned)(B * pl.units_per_image));
+  if (dtype == SSDK_F32) hipLaunchKernelGGL(scan_kernel<SSDK_F32>, grid, dim3(kScanThreads), lds, stream, sp);
+  else if (dtype == SSDK_BF16) hipLaunchKernelGGL(scan_kernel<SSDK_BF16>, grid, dim3(kScanThreads), lds, stream, sp);
+  else hipLaunchKernelGGL(scan_kernel<SSDK_F16>, grid, dim3(kScanThreads), lds, stream, sp);
+  rc = check_launch("scan_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(level_kernel, dim3((unsigned)L, (unsigned)B), dim3(kLevelThreads), lds, stream, lp);
+  return check_launch("level_kernel");
+}
+
+// shared with ssdk_nms.hip (fused decode_nms entry point lives there)
+size_t decode_ws_bytes(const ssdk_level* lv, int L, int B, int dtype, int K) {
+  DecodePlan pl;
+  if (make_plan(lv, L, B, dtype, K, &pl)) return 0;
+  return pl.cand_bytes + pl.cnt_bytes;
+}
+int decode_levels(const ssdk_level* lv, int L, int B, int dtype, float thr, int K, int rescore,
+                  float* scores, float* boxes, float* classes, void* ws, size_t ws_bytes, void* stream) {
+  return launch_decode(lv, L, B, dtype, thr, K, rescore, scores, boxes, classes, ws, ws_bytes,
+                       (hipStream_t)stream);
+}
+
+}  // namespace ssdk
+
+extern "C" size_t ssdk_decode_workspace_bytes(const ssdk_level* levels, int L, int B, int dtype, int top_n) {
+  return ssdk::decode_ws_bytes(levels, L, B, dtype, top_n);
+}
+
+extern "C" int ssdk_decode(const ssdk_level* level, int B, int dtype, float threshold, int top_n,
+                           int rescore, float* scores, float* boxes, float* classes, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  return ssdk::decode_levels(level, 1, B, dtype, threshold, top_n, rescore, scores, boxes, classes,
+                             workspace, workspace_bytes, stream);
+}

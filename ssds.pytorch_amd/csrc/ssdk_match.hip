@@ -1,0 +1,180 @@
+// ssdk_match.hip -- ground-truth <-> anchor matching, box encoding and one-hot targets on gfx950.
+//
+// Replaces box.extract_targets + box.snap_to_anchors_by_iou (reference box.py:362-405, 116-226): the
+// reference loops over the B images in Python and issues ~35 ATen ops per (image, level), building
+// [A*W*H, G] temporaries.  Here the whole batch of one level is ONE launch: a thread owns one grid
+// anchor (a, y, x), walks the image's valid ground-truth rows (staged in LDS, order preserved so that
+// the first maximum wins like torch.max on CPU), and writes its column of the three target tensors.
+// Write-bound: (A*C + A*4 + A)*H*W*4 bytes per image.
+#include "ssdk_common.h"
+
+namespace ssdk {
+
+constexpr int kMatchThreads = 256;
+
+struct MatchParams {
+  const float* targets;  // [B, G, 5]
+  int G, A, C, H, W, stride;
+  float hi, lo, radius_px;  // radius_px = float(stride * radius); 0 = off
+  int use_radius;
+  float anchors[SSDK_MAX_ANCHORS * 4];
+  float* cls_target;  // [B, A, C, H, W]
+  float* box_target;  // [B, A, 4, H, W]
+  float* depth;       // [B, A, 1, H, W]
+};
+
+struct GtRow {
+  float x1, y1, x2, y2, area, label, pad0, pad1;
+};
+
+__global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams p) {
+  __shared__ GtRow gt[SSDK_MAX_GT];
+  __shared__ float s_anchor[SSDK_MAX_ANCHORS * 4];
+  __shared__ u32 wcnt[kMatchThreads / 64];
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u32 b = blockIdx.y;
+  const int G = p.G;
+
+  // stage + compact the valid rows (label > -1, box.py:375), order preserved
+  if (tid < SSDK_MAX_ANCHORS * 4) s_anchor[tid] = p.anchors[tid];
+  float r[5] = {0.f, 0.f, 0.f, 0.f, -1.f};
+  bool valid = false;
+  if ((int)tid < G) {
+    const float* t = p.targets + ((size_t)b * G + tid) * 5;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) r[k] = t[k];
+    valid = r[4] > -1.0f;
+  }
+  const u64 m = __ballot(valid);
+  if (lane == 0) wcnt[wave] = (u32)__popcll(m);
+  __syncthreads();
+  u32 off = 0, ng = 0;
+#pragma unroll
+  for (int w = 0; w < kMatchThreads / 64; ++w) {
+    if (w < (int)wave) off += wcnt[w];
+    ng += wcnt[w];
+  }
+  if (valid) {
+    GtRow g;
+    g.x1 = r[0];
+    g.y1 = r[1];
+    g.x2 = r[0] + r[2] - 1.0f;  // box.py:162
+    g.y2 = r[1] + r[3] - 1.0f;
+    g.area = (g.x2 - g.x1 + 1.0f) * (g.y2 - g.y1 + 1.0f);  // box.py:166
+    g.label = r[4];
+    g.pad0 = g.pad1 = 0.f;
+    gt[off + mbcnt(m)] = g;
+  }
+  __syncthreads();
+
+  const u32 HW = (u32)(p.H * p.W);
+  const u32 total = (u32)p.A * HW;
+  const u32 t = blockIdx.x * kMatchThreads + tid;
+  if (t >= total) return;
+  const u32 a = t / HW;
+  const u32 yx = t % HW;
+  const u32 iy = yx / (u32)p.W, ix = yx % (u32)p.W;
+
+  float* cls_o = p.cls_target + (((size_t)b * p.A + a) * p.C) * HW + yx;
+  float* box_o = p.box_target + (((size_t)b * p.A + a) * 4) * HW + yx;
+  float* dep_o = p.depth + ((size_t)b * p.A + a) * HW + yx;
+
+  if (ng == 0) {  // box.py:133-146
+    for (int c = 0; c < p.C; ++c) cls_o[(size_t)c * HW] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) box_o[(size_t)k * HW] = 0.f;
+    dep_o[0] = 0.f;
+    return;
+  }
+
+  const float fx = (float)(ix * (u32)p.stride), fy = (float)(iy * (u32)p.stride);  // box.py:151-156
+  const float ax1 = fx + s_anchor[a * 4 + 0], ay1 = fy + s_anchor[a * 4 + 1];     // box.py:157-159
+  const float ax2 = fx + s_anchor[a * 4 + 2], ay2 = fy + s_anchor[a * 4 + 3];
+  const float aarea = (ax2 - ax1 + 1.0f) * (ay2 - ay1 + 1.0f);                    // box.py:167
+
+  float best = 0.f;
+  u32 bi = 0;
+  bool inside = false;
+  const float apx = fx + (float)(p.stride / 2), apy = fy + (float)(p.stride / 2);  // box.py:185
+  for (u32 g = 0; g < ng; ++g) {
+    const GtRow q = gt[g];
+    const float x1 = tmax(ax1, q.x1), y1 = tmax(ay1, q.y1);  // box.py:163-165
+    const float x2 = tmin(ax2, q.x2), y2 = tmin(ay2, q.y2);
+    float w = x2 - x1 + 1.0f, h = y2 - y1 + 1.0f;
+    w = (w < 0.f) ? 0.f : w;
+    h = (h < 0.f) ? 0.f : h;
+    const float inter = w * h;
+    const float ov = inter / (aarea + q.area - inter);  // box.py:168 (no epsilon)
+    if (g == 0 || ov > best) {  // box.py:171: first maximum wins
+      best = ov;
+      bi = g;
+    }
+    if (p.use_radius) {  // box.py:90-113 get_sample_region
+      const float cx = (q.x1 + q.x2) / 2.0f, cy = (q.y1 + q.y2) / 2.0f;
+      const float lx = apx - tmax(cx - p.radius_px, q.x1), ly = apy - tmax(cy - p.radius_px, q.y1);
+      const float rx = tmin(cx + p.radius_px, q.x2) - apx, ry = tmin(cy + p.radius_px, q.y2) - apy;
+      const float mn = tmin(tmin(lx, ly), tmin(rx, ry));
+      inside = inside || (mn > 0.f);
+    }
+  }
+  const GtRow q = gt[bi];
+  // box.py:61-71 box2delta(boxes[indices], anchors)
+  const float aw = ax2 - ax1 + 1.0f, ah = ay2 - ay1 + 1.0f;
+  const float acx = ax1 + 0.5f * aw, acy = ay1 + 0.5f * ah;
+  const float bw = q.x2 - q.x1 + 1.0f, bh = q.y2 - q.y1 + 1.0f;
+  const float bcx = q.x1 + 0.5f * bw, bcy = q.y1 + 0.5f * bh;
+  box_o[0] = (bcx - acx) / aw;
+  box_o[(size_t)HW] = (bcy - acy) / ah;
+  box_o[(size_t)2 * HW] = logf(bw / aw);
+  box_o[(size_t)3 * HW] = logf(bh / ah);
+
+  float dep = -1.0f;  // box.py:177-182
+  if (best < p.lo) dep = 0.f;
+  if (best >= p.hi) dep = q.label + 1.0f;
+  if (p.use_radius) dep = tmin(dep, inside ? 1.0f : 0.f);  // box.py:191
+  dep_o[0] = dep;
+
+  // box.py:195-207: one-hot at the matched label unless background (overlap < unmatch threshold)
+  const int lab = (best < p.lo) ? p.C : (int)(long long)q.label;
+  for (int c = 0; c < p.C; ++c) cls_o[(size_t)c * HW] = (c == lab) ? 1.0f : 0.f;
+}
+
+}  // namespace ssdk
+
+extern "C" int ssdk_match_targets(const float* targets, int B, int G, const float* anchors, int A, int C,
+                                  int H, int W, int stride, float match_threshold, float unmatch_threshold,
+                                  float center_sampling_radius, float* cls_target, float* box_target,
+                                  float* depth, void* stream) {
+  using namespace ssdk;
+  if (!targets || !anchors || !cls_target || !box_target || !depth) {
+    set_error("match_targets: null pointer");
+    return SSDK_E_BADARG;
+  }
+  if (B < 1 || G < 0 || G > SSDK_MAX_GT || A < 1 || A > SSDK_MAX_ANCHORS || C < 1 || H < 1 || W < 1 ||
+      stride < 1) {
+    set_error("match_targets: bad dims B=%d G=%d (<=%d) A=%d (<=%d) C=%d H=%d W=%d stride=%d", B, G,
+              SSDK_MAX_GT, A, SSDK_MAX_ANCHORS, C, H, W, stride);
+    return SSDK_E_BADARG;
+  }
+  MatchParams p;
+  memset(&p, 0, sizeof(p));
+  p.targets = targets;
+  p.G = G;
+  p.A = A;
+  p.C = C;
+  p.H = H;
+  p.W = W;
+  p.stride = stride;
+  p.hi = match_threshold;
+  p.lo = unmatch_threshold;
+  p.use_radius = center_sampling_radius > 0.f;
+  p.radius_px = (float)((double)stride * (double)center_sampling_radius);
+  memcpy(p.anchors, anchors, sizeof(float) * 4 * A);
+  p.cls_target = cls_target;
+  p.box_target = box_target;
+  p.depth = depth;
+  const unsigned total = (unsigned)A * H * W;
+  dim3 grid((total + kMatchThreads - 1) / kMatchThreads, (unsigned)B);
+  hipLaunchKernelGGL(match_kernel, grid, dim3(kMatchThreads), 0, (hipStream_t)stream, p);
+  return check_launch("match_kernel");
+}

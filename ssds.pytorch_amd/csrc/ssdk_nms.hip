@@ -1,0 +1,267 @@
+// ssdk_nms.hip -- greedy class-aware (D)IoU NMS on gfx950, one workgroup per image.
+//
+// Replaces box.nms (reference ssds/modeling/layers/box.py:480-546): per image `nonzero, sort` and then
+// up to `ndetections` dependent iterations of ~20 tiny ATen ops with 5 host syncs each.
+//
+// The reference's loop is the standard greedy NMS in score order, truncated to the first `ndetections`
+// survivors.  Here: all waves build 64-bit keys (score bits | ~position) for the
+// candidates with score > 0 (box.py:496; NaN drops out too) and bitonic-sort them in LDS (box.py:505,
+// stable order contract); then ONE wave walks the sorted list in blocks of 64 candidates:
+//   1. every lane tests its candidate against the survivors kept so far (skipping, wave-uniformly,
+//      survivors whose class no lane shares),
+//   2. the block is resolved in order with a scalar loop over its 64 lanes (readlane pivot),
+//   3. the block's survivors are appended to the kept list and written straight to the output.
+// IoU / DIoU arithmetic follows box.py:518-533 in fp32 without FMA contraction (+1 pixel convention,
+// eps 1e-7, DIoU penalty = squared TOP-LEFT corner distance / squared outer diagonal), so keep sets are
+// bit-exact with the CPU reference.
+#include "ssdk_common.h"
+#include "ssdk_select.h"
+
+namespace ssdk {
+
+// decode side (ssdk_decode.hip)
+size_t decode_ws_bytes(const ssdk_level* lv, int L, int B, int dtype, int K);
+int decode_levels(const ssdk_level* lv, int L, int B, int dtype, float thr, int K, int rescore,
+                  float* scores, float* boxes, float* classes, void* ws, size_t ws_bytes, void* stream);
+
+constexpr int kNmsThreads = 256;
+
+struct NmsParams {
+  const float* scores;
+  const float* boxes;
+  const float* classes;
+  int N, ndet, diou;
+  float thr;
+  float* out_scores;
+  float* out_boxes;
+  float* out_classes;
+};
+
+// suppression test of candidate (box b, area ab) by pivot (box p, area ap): returns true when the
+// candidate must be dropped, i.e. NOT (iou <= thr)   (box.py:518-533)
+__device__ __forceinline__ bool suppressed_by(const float4 b, float ab, const float4 p, float ap,
+                                              float thr, int diou) {
+  const float ix1 = tmax(b.x, p.x), iy1 = tmax(b.y, p.y);
+  const float ix2 = tmin(b.z, p.z), iy2 = tmin(b.w, p.w);
+  float w = ix2 - ix1 + 1.0f, h = iy2 - iy1 + 1.0f;
+  w = (w < 0.0f) ? 0.0f : w;  // clamp(0) keeps NaN like torch
+  h = (h < 0.0f) ? 0.0f : h;
+  const float inter = w * h;
+  float iou = inter / (ab + ap - inter + 1e-7f);
+  if (diou) {
+    const float ox1 = tmin(b.x, p.x), oy1 = tmin(b.y, p.y);
+    const float ox2 = tmax(b.z, p.z), oy2 = tmax(b.w, p.w);
+    const float dx = b.x - p.x, dy = b.y - p.y;
+    const float inter_diag = dx * dx + dy * dy;
+    const float ow = ox2 - ox1, oh = oy2 - oy1;
+    const float outer_diag = (ow * ow + oh * oh) + 1e-7f;
+    float v = iou - inter_diag / outer_diag;
+    v = (v < -1.0f) ? -1.0f : ((v > 1.0f) ? 1.0f : v);
+    iou = v;
+  }
+  return !(iou <= thr);
+}
+
+__global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
+  constexpr int NT = kNmsThreads;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const u32 tid = threadIdx.x, lane = tid & 63u;
+  const u32 b = blockIdx.x;
+  const u32 N = (u32)p.N;
+  u32 M = 64;
+  while (M < N) M <<= 1;
+  u64* keys = reinterpret_cast<u64*>(smem);                       // M
+  float4* kbox = reinterpret_cast<float4*>(keys + M);              // ndet
+  float* karea = reinterpret_cast<float*>(kbox + p.ndet);          // ndet
+  float* kcls = karea + p.ndet;                                    // ndet
+  u32* ctl = reinterpret_cast<u32*>(kcls + p.ndet);                // [0] = nvalid
+
+  const float* sc = p.scores + (size_t)b * N;
+  const float4* bx = reinterpret_cast<const float4*>(p.boxes) + (size_t)b * N;
+  const float* cl = p.classes + (size_t)b * N;
+
+  if (tid == 0) ctl[0] = 0;
+  __syncthreads();
+  u32 local = 0;
+  for (u32 i = tid; i < M; i += NT) {
+    u64 k = 0;
+    if (i < N) {
+      const float s = sc[i];
+      if (s > 0.0f) {  // box.py:496
+        k = make_key(s, i);
+        ++local;
+      }
+    }
+    keys[i] = k;
+  }
+  atomicAdd(&ctl[0], local);
+  __syncthreads();
+  const u32 nvalid = ctl[0];
+  wg_bitonic_sort_desc<NT>(keys, M);  // box.py:505
+
+  if (tid >= 64) return;  // the greedy walk is one wave; everything below is wave-synchronous
+
+  const u32 ndet = (u32)p.ndet;
+  float* os = p.out_scores + (size_t)b * ndet;
+  float4* ob = reinterpret_cast<float4*>(p.out_boxes) + (size_t)b * ndet;
+  float* oc = p.out_classes + (size_t)b * ndet;
+  const float thr = p.thr;
+  const int diou = p.diou;
+
+  u32 nk = 0;
+  for (u32 base = 0; base < nvalid && nk < ndet; base += 64) {
+    const u32 i = base + lane;
+    const bool valid = i < nvalid;
+    float score = 0.f, cls = -1.f, area = 0.f;
+    float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+      const u64 k = keys[i];
+      const u32 pos = key_index(k);
+      score = key_score(k);
+      box = bx[pos];
+      cls = cl[pos];
+      area = (box.z - box.x + 1.0f) * (box.w - box.y + 1.0f);  // box.py:507
+    }
+    bool alive = valid;
+    // 1. against the survivors kept so far
+    for (u32 k = 0; k < nk; ++k) {
+      const float ck = kcls[k];
+      if (__ballot(alive && cls == ck) == 0ull) continue;
+      const bool sup = (cls == ck) && suppressed_by(box, area, kbox[k], karea[k], thr, diou);
+      alive = alive && !sup;
+    }
+    // 2. inside the block, in order
+    u64 am = __ballot(alive);
+    u32 kept_here = 0;
+    for (u32 j = 0; j < 64; ++j) {
+      if (!((am >> j) & 1ull)) continue;
+      if (nk + kept_here >= ndet) {  // truncated to ndetections survivors (box.py:512)
+        am &= (1ull << j) - 1ull;
+        break;
+      }
+      ++kept_here;
+      const float cj = __shfl(cls, (int)j);
+      const u64 m = __ballot(((am >> lane) & 1ull) && lane > j && cls == cj);
+      if (m == 0ull) continue;
+      float4 pj;
+      pj.x = __shfl(box.x, (int)j);
+      pj.y = __shfl(box.y, (int)j);
+      pj.z = __shfl(box.z, (int)j);
+      pj.w = __shfl(box.w, (int)j);
+      const float aj = __shfl(area, (int)j);
+      const bool sup = ((m >> lane) & 1ull) && suppressed_by(box, area, pj, aj, thr, diou);
+      am &= ~__ballot(sup);
+    }
+    // 3. append the block's survivors
+    const bool keep = (am >> lane) & 1ull;
+    const u32 slot = nk + mbcnt(am);
+    if (keep && slot < ndet) {
+      kbox[slot] = box;
+      karea[slot] = area;
+      kcls[slot] = cls;
+      os[slot] = score;
+      ob[slot] = box;
+      oc[slot] = cls;
+    }
+    nk += (u32)__popcll(am);
+    if (nk > ndet) nk = ndet;
+  }
+  // zero padding (box.py:489-491)
+  for (u32 i = nk + lane; i < ndet; i += 64) {
+    os[i] = 0.f;
+    ob[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    oc[i] = 0.f;
+  }
+}
+
+static size_t nms_lds_bytes(int N, int ndet) {
+  size_t M = 64;
+  while (M < (size_t)N) M <<= 1;
+  return M * 8 + (size_t)ndet * (16 + 4 + 4) + 16;
+}
+
+static int launch_nms(const float* scores, const float* boxes, const float* classes, int B, int N,
+                      float thr, int ndet, int diou, float* os, float* ob, float* oc, hipStream_t stream) {
+  if (!scores || !boxes || !classes || !os || !ob || !oc) {
+    set_error("nms: null pointer");
+    return SSDK_E_BADARG;
+  }
+  if (B < 1 || N < 1 || N > SSDK_MAX_NMS_N || ndet < 1 || ndet > SSDK_MAX_NDET) {
+    set_error("nms: B=%d N=%d ndetections=%d out of range (N<=%d, ndet<=%d)", B, N, ndet,
+              SSDK_MAX_NMS_N, SSDK_MAX_NDET);
+    return SSDK_E_BADARG;
+  }
+  if (((uintptr_t)boxes & 15) || ((uintptr_t)ob & 15)) {
+    set_error("nms: box pointers must be 16-byte aligned");
+    return SSDK_E_BADARG;
+  }
+  NmsParams p;
+  p.scores = scores;
+  p.boxes = boxes;
+  p.classes = classes;
+  p.N = N;
+  p.ndet = ndet;
+  p.diou = diou;
+  p.thr = thr;
+  p.out_scores = os;
+  p.out_boxes = ob;
+  p.out_classes = oc;
+  hipLaunchKernelGGL(nms_kernel, dim3((unsigned)B), dim3(kNmsThreads), nms_lds_bytes(N, ndet), stream, p);
+  return check_launch("nms_kernel");
+}
+
+}  // namespace ssdk
+
+extern "C" size_t ssdk_nms_workspace_bytes(int B, int N, int ndetections) {
+  (void)B;
+  (void)N;
+  (void)ndetections;
+  return 0;  // everything lives in LDS
+}
+
+extern "C" int ssdk_nms(const float* scores, const float* boxes, const float* classes, int B, int N,
+                        float nms_threshold, int ndetections, int using_diou, float* out_scores,
+                        float* out_boxes, float* out_classes, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  (void)workspace;
+  (void)workspace_bytes;
+  return ssdk::launch_nms(scores, boxes, classes, B, N, nms_threshold, ndetections, using_diou,
+                          out_scores, out_boxes, out_classes, (hipStream_t)stream);
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t ssdk_decode_nms_workspace_bytes(const ssdk_level* levels, int L, int B, int dtype,
+                                                  int top_n_per_level, int ndetections) {
+  (void)ndetections;
+  const size_t dec = ssdk::decode_ws_bytes(levels, L, B, dtype, top_n_per_level);
+  if (!dec) return 0;
+  const size_t n = (size_t)B * L * top_n_per_level;
+  return align256(dec) + align256(n * 4) + align256(n * 16) + align256(n * 4);
+}
+
+extern "C" int ssdk_decode_nms(const ssdk_level* levels, int L, int B, int dtype, float threshold,
+                               int top_n_per_level, int rescore, float nms_threshold, int ndetections,
+                               int using_diou, float* out_scores, float* out_boxes, float* out_classes,
+                               float* mid_scores, float* mid_boxes, float* mid_classes, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  const size_t dec = ssdk::decode_ws_bytes(levels, L, B, dtype, top_n_per_level);
+  if (!dec) return SSDK_E_BADARG;
+  const size_t need = ssdk_decode_nms_workspace_bytes(levels, L, B, dtype, top_n_per_level, ndetections);
+  if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255)) {
+    ssdk::set_error("decode_nms: workspace too small or not 256-byte aligned (%zu < %zu)", workspace_bytes, need);
+    return SSDK_E_WORKSPACE;
+  }
+  const size_t n = (size_t)B * L * top_n_per_level;
+  char* w = (char*)workspace + align256(dec);
+  float* ms = mid_scores ? mid_scores : (float*)w;
+  w += align256(n * 4);
+  float* mb = mid_boxes ? mid_boxes : (float*)w;
+  w += align256(n * 16);
+  float* mc = mid_classes ? mid_classes : (float*)w;
+  int rc = ssdk::decode_levels(levels, L, B, dtype, threshold, top_n_per_level, rescore, ms, mb, mc,
+                               workspace, dec, stream);
+  if (rc) return rc;
+  return ssdk::launch_nms(ms, mb, mc, B, L * top_n_per_level, nms_threshold, ndetections, using_diou,
+                          out_scores, out_boxes, out_classes, (hipStream_t)stream);
+}

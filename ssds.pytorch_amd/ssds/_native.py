@@ -1,0 +1,157 @@
+"""ctypes binding of libssdk.so (C-ABI: include/ssdk.h) -- the only door to the HIP kernels.
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+Tensors are passed as raw ``data_ptr()`` values plus the caller's current HIP stream, so every call is
+asynchronous and hipGraph-capturable.  This module is the `ssds._C` the reference names but never
+ships (reference ssds/modeling/layers/box.py:3-4, 419-421, 483-485).
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libssdk.so")
+
+MAX_LEVELS = 8
+MAX_ANCHORS = 16
+MAX_TOPN = 1024
+MAX_NDET = 1024
+MAX_NMS_N = 8192
+MAX_GT = 256
+
+F32, BF16, F16 = 0, 1, 2
+ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3, "sigmoid": 4}
+_DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+
+
+class Level(ctypes.Structure):
+    _fields_ = [
+        ("cls", ctypes.c_void_p),
+        ("box", ctypes.c_void_p),
+        ("A", ctypes.c_int32),
+        ("C", ctypes.c_int32),
+        ("H", ctypes.c_int32),
+        ("W", ctypes.c_int32),
+        ("stride", ctypes.c_int32),
+        ("anchors", ctypes.c_float * (MAX_ANCHORS * 4)),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libssdk.so not found at {} -- build it first: `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C ssds.pytorch_amd/csrc` (there is no CPU fallback)".format(LIB_PATH)
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, i32, f32, sz = c.c_void_p, c.c_int, c.c_float, c.c_size_t
+    lib.ssdk_version.restype = i32
+    lib.ssdk_last_error.restype = c.c_char_p
+    lib.ssdk_device_info.argtypes = [c.POINTER(i32), c.POINTER(i32), c.POINTER(sz), c.c_char_p, i32]
+    lib.ssdk_generate_anchors.argtypes = [i32, c.POINTER(f32), i32, c.POINTER(f32), i32, c.POINTER(f32)]
+    lib.ssdk_decode_workspace_bytes.restype = sz
+    lib.ssdk_decode_workspace_bytes.argtypes = [c.POINTER(Level), i32, i32, i32, i32]
+    lib.ssdk_decode.argtypes = [c.POINTER(Level), i32, i32, f32, i32, i32, vp, vp, vp, vp, sz, vp]
+    lib.ssdk_nms_workspace_bytes.restype = sz
+    lib.ssdk_nms_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.ssdk_nms.argtypes = [vp, vp, vp, i32, i32, f32, i32, i32, vp, vp, vp, vp, sz, vp]
+    lib.ssdk_decode_nms_workspace_bytes.restype = sz
+    lib.ssdk_decode_nms_workspace_bytes.argtypes = [c.POINTER(Level), i32, i32, i32, i32, i32]
+    lib.ssdk_decode_nms.argtypes = [c.POINTER(Level), i32, i32, i32, f32, i32, i32, f32, i32, i32,
+                                    vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.ssdk_match_targets.argtypes = [vp, i32, i32, c.POINTER(f32), i32, i32, i32, i32, i32, f32, f32,
+                                       f32, vp, vp, vp, vp]
+    lib.ssdk_conv_workspace_bytes.restype = sz
+    lib.ssdk_conv_workspace_bytes.argtypes = [i32] * 8
+    lib.ssdk_conv_bn_act.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32,
+                                     vp, vp, sz, vp]
+    for name in ("ssdk_device_info", "ssdk_generate_anchors", "ssdk_decode", "ssdk_nms",
+                 "ssdk_decode_nms", "ssdk_match_targets", "ssdk_conv_bn_act"):
+        getattr(lib, name).restype = i32
+    return lib
+
+
+lib = _load()
+EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_device_info", "ssdk_generate_anchors",
+           "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
+           "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
+           "ssdk_conv_workspace_bytes", "ssdk_conv_bn_act")
+
+
+class SsdkError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SsdkError("{} failed ({}): {}".format(what, rc, lib.ssdk_last_error().decode()))
+
+
+def dtype_code(t):
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise TypeError("unsupported dtype {} (float32, bfloat16, float16)".format(t.dtype))
+
+
+def require_device(t, what):
+    if not t.is_cuda:
+        raise SsdkError(
+            "{}: tensor is on '{}' -- the MI355X path has no CPU fallback; move it to a HIP device".format(
+                what, t.device))
+    return t
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_ws_lock = threading.Lock()
+_ws = {}
+
+
+def workspace(device, nbytes):
+    """Grow-only per-(device, stream) scratch buffer.  Kernels are stream-ordered, so consecutive
+    calls on the same stream may share it."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    nbytes = max(int(nbytes), 256)
+    with _ws_lock:
+        buf = _ws.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, device=device)
+            _ws[key] = buf
+    return buf
+
+
+def make_level(cls, box, stride, anchors):
+    """anchors: CPU float tensor / ndarray [A,4].  cls [B, A*C, H, W], box [B, A*4, H, W]."""
+    import numpy as np
+
+    anc = np.ascontiguousarray(
+        anchors.detach().cpu().numpy() if torch.is_tensor(anchors) else anchors, dtype=np.float32)
+    A = int(anc.shape[0])
+    if A > MAX_ANCHORS:
+        raise SsdkError("at most {} anchors per location (got {})".format(MAX_ANCHORS, A))
+    if cls.shape[1] % A or box.shape[1] != 4 * A:
+        raise SsdkError("head channels {} / {} do not match {} anchors".format(cls.shape[1], box.shape[1], A))
+    lv = Level()
+    lv.cls = cls.data_ptr()
+    lv.box = box.data_ptr()
+    lv.A = A
+    lv.C = int(cls.shape[1] // A)
+    lv.H, lv.W = int(cls.shape[-2]), int(cls.shape[-1])
+    lv.stride = int(stride)
+    flat = anc.reshape(-1)
+    for i in range(flat.shape[0]):
+        lv.anchors[i] = float(flat[i])
+    return lv
+
+
+def device_info():
+    cu, khz, mem = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+    arch = ctypes.create_string_buffer(64)
+    check(lib.ssdk_device_info(ctypes.byref(cu), ctypes.byref(khz), ctypes.byref(mem), arch, 64), "device_info")
+    return {"cu_count": cu.value, "clock_khz": khz.value, "hbm_bytes": mem.value, "arch": arch.value.decode()}

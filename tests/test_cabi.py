@@ -1,0 +1,79 @@
+"""CPU-side checks of the C-ABI library (no GPU compute): it loads, exports every symbol that
+include/ssdk.h declares, the host-only entry points are bit-exact with the reference fixtures, and
+bad arguments come back as error codes with a message (never a crash)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    from ssds import _native as N
+
+    hdr = open(os.path.join(ROOT, "include", "ssdk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ssdk_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(N.EXPORTS), declared ^ set(N.EXPORTS)
+    for name in declared:
+        assert hasattr(N.lib, name), name
+    assert N.lib.ssdk_version() == 100
+
+
+def test_library_is_in_tree_and_has_gfx950_code():
+    from ssds import _native as N
+
+    assert N.LIB_PATH.startswith(ROOT)
+    blob = open(N.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+
+
+def test_generate_anchors_bit_exact_with_reference_fixture(golden_dir):
+    from ssds.modeling.layers import box
+
+    g = np.load(os.path.join(golden_dir, "anchors.npz"))
+    for k in g.files:
+        if k.endswith("_spec"):
+            continue
+        spec = g[k + "_spec"]
+        s, nr, ns = int(spec[0]), int(spec[1]), int(spec[2])
+        r = [float(v) for v in spec[3:3 + nr]]
+        sc = [float(v) for v in spec[3 + nr:3 + nr + ns]]
+        got = box.generate_anchors(s, r, sc)
+        assert got.dtype.is_floating_point and tuple(got.shape) == (nr * ns, 4)
+        np.testing.assert_array_equal(got.numpy(), g[k], err_msg=k)
+
+
+def test_bad_arguments_return_codes():
+    from ssds import _native as N
+
+    out = (ctypes.c_float * 4)()
+    assert N.lib.ssdk_generate_anchors(0, out, 1, out, 1, out) == -1
+    assert b"generate_anchors" in N.lib.ssdk_last_error()
+    lv = N.Level()
+    lv.A, lv.C, lv.H, lv.W, lv.stride = 3, 5, 7, 9, 8
+    # top_n beyond the documented limit -> workspace query refuses (0) and decode returns BADARG
+    assert N.lib.ssdk_decode_workspace_bytes(ctypes.byref(lv), 1, 2, 0, 5000) == 0
+    assert N.lib.ssdk_decode(ctypes.byref(lv), 2, 0, 0.05, 5000, 1, None, None, None, None, 0, None) == -1
+    assert N.lib.ssdk_decode_workspace_bytes(ctypes.byref(lv), 1, 2, 0, 50) > 0
+    # null pointers
+    assert N.lib.ssdk_nms(None, None, None, 1, 10, 0.5, 5, 1, None, None, None, None, 0, None) == -1
+    assert N.lib.ssdk_match_targets(None, 1, 1, out, 1, 1, 1, 1, 8, 0.5, 0.4, 0.0, None, None, None, None) == -1
+
+
+def test_no_cpu_fallback():
+    import torch
+    from ssds import _native as N
+    from ssds.modeling.layers import box
+
+    cls = torch.zeros(1, 2, 2, 2)
+    loc = torch.zeros(1, 4, 2, 2)
+    anc = torch.tensor([[-4.0, -4, 11, 11]])
+    with pytest.raises(N.SsdkError, match="no CPU fallback"):
+        box.decode(cls, loc, 8, 0.05, 10, anc)
+    with pytest.raises(N.SsdkError, match="no CPU fallback"):
+        box.nms(torch.zeros(1, 4), torch.zeros(1, 4, 4), torch.zeros(1, 4))

@@ -1,0 +1,244 @@
+"""Parity of the HIP kernels (through the C-ABI) with the reference fixtures and the pinned oracle.
+
+Bars (north_star): anchor indices / classes / NMS keep sets bit-exact, decoded box coordinates within
+1e-3, scores within 1e-5 relative."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import box_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+F32 = np.float32
+BOX_ATOL = 1e-3
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def dev_heads(d):
+    import torch
+
+    if d["dtype"] == "f32":
+        return torch.from_numpy(d["cls"]).cuda(), torch.from_numpy(d["box"]).cuda()
+    tdt = torch.bfloat16 if d["dtype"] == "bf16" else torch.float16
+    c = torch.from_numpy(d["raw_cls"].view(np.int16)).cuda().view(tdt)
+    b = torch.from_numpy(d["raw_box"].view(np.int16)).cuda().view(tdt)
+    return c, b
+
+
+def cmp_decode(got, want, what):
+    s, b, c = (t.cpu().numpy() for t in got)
+    ws, wb, wc = want
+    np.testing.assert_array_equal(c, wc, err_msg=what + " classes")
+    np.testing.assert_allclose(b, wb, atol=BOX_ATOL, rtol=0, err_msg=what + " boxes")
+    np.testing.assert_allclose(s, ws, atol=1e-6, rtol=1e-5, equal_nan=True, err_msg=what + " scores")
+
+
+@pytest.mark.parametrize("name", list(cases.DECODE_CASES))
+def test_decode_vs_reference_and_oracle(name):
+    import torch
+    from ssds.modeling.layers import box
+
+    g = load("decode")
+    d = cases.decode_inputs(name)
+    anchors = cases.anchors_for(d["A"], d["stride"], O.generate_anchors)
+    cls, loc = dev_heads(d)
+    got = box.decode(cls, loc, d["stride"], d["thr"], d["top_n"], torch.from_numpy(anchors), d["rescore"])
+    assert all(t.dtype == torch.float32 for t in got)
+    cmp_decode(got, (g[name + "_scores"], g[name + "_boxes"], g[name + "_classes"]), name + " vs reference")
+    want = O.decode(d["cls"], d["box"], d["stride"], d["thr"], d["top_n"], anchors, d["rescore"])
+    cmp_decode(got, want, name + " vs oracle")
+
+
+def test_decode_kat():
+    import torch
+    from ssds.modeling.layers import box
+
+    conf = torch.zeros(1, 2, 2, 2)
+    conf[0, 1, 0, 1] = 0.9
+    conf[0, 0, 1, 0] = 0.6
+    loc = torch.zeros(1, 4, 2, 2)
+    anc = torch.tensor([[-4.0, -4, 11, 11]])
+    s, b, c = box.decode(conf.cuda(), loc.cuda(), 8, 0.05, 10, anc, False)
+    np.testing.assert_array_equal(s.cpu().numpy()[0, :3], F32([0.9, 0.6, 0]))
+    np.testing.assert_array_equal(b.cpu().numpy()[0, :2], [[4, 0, 15, 11], [0, 4, 11, 15]])
+    np.testing.assert_array_equal(c.cpu().numpy()[0, :2], [1, 0])
+    s, _, _ = box.decode(conf.cuda(), loc.cuda(), 8, 0.05, 10, anc, True)
+    np.testing.assert_allclose(s.cpu().numpy()[0, :2], [0.42, 0.28], atol=1e-6)
+
+
+def _tie_case(kind, n_img, A, C, H, W, seed):
+    rs = np.random.RandomState(seed)
+    n = A * C * H * W
+    if kind == "constant":
+        cls = np.full((n_img, n), 0.5, F32)
+    elif kind == "ramp_up":  # every new element beats everything seen so far: worst case for pruning
+        cls = np.tile(np.linspace(0.02, 0.98, n, dtype=F32), (n_img, 1))
+    elif kind == "ramp_down":
+        cls = np.tile(np.linspace(0.98, 0.02, n, dtype=F32), (n_img, 1))
+    elif kind == "quantized":  # few distinct values -> massive ties at the cut
+        cls = (rs.randint(0, 16, size=(n_img, n)) / 16.0).astype(F32)
+    elif kind == "sparse":  # almost nothing passes
+        cls = np.zeros((n_img, n), F32)
+        for b in range(n_img):
+            hot = rs.choice(n, size=37, replace=False)
+            cls[b, hot] = (0.1 + 0.8 * rs.random_sample(37)).astype(F32)
+    else:
+        raise ValueError(kind)
+    box = (rs.standard_normal((n_img, A * 4 * H * W)) * 0.5).astype(F32)
+    return cls.reshape(n_img, A * C, H, W), box.reshape(n_img, A * 4, H, W)
+
+
+@pytest.mark.parametrize("kind", ["constant", "ramp_up", "ramp_down", "quantized", "sparse"])
+@pytest.mark.parametrize("tpu", ["1", "4", "0"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_decode_tie_contract_and_multi_unit(kind, tpu, dtype, monkeypatch):
+    """Ties, monotone ramps and multi-unit merges against the oracle's (score desc, index asc) contract.
+    SSDK_TILES_PER_UNIT=1/4 forces many units per (image, level) so that the merge path is exercised."""
+    import torch
+    from ssds.modeling.layers import box
+
+    monkeypatch.setenv("SSDK_TILES_PER_UNIT", tpu)
+    A, C, H, W, stride = 3, 20, 24, 28, 8
+    cls, loc = _tie_case(kind, 2, A, C, H, W, 7)
+    if dtype == "bf16":
+        tc = torch.from_numpy(cls).to(torch.bfloat16)
+        tl = torch.from_numpy(loc).to(torch.bfloat16)
+        cls, loc = tc.float().numpy(), tl.float().numpy()
+    else:
+        tc, tl = torch.from_numpy(cls), torch.from_numpy(loc)
+    anchors = O.generate_anchors(stride, [1, 2, 0.5], [2.0])
+    for top_n, thr in ((300, 0.05), (64, 0.3), (1000, 0.01)):
+        got = box.decode(tc.cuda(), tl.cuda(), stride, thr, top_n, torch.from_numpy(anchors), True)
+        want = O.decode(cls, loc, stride, thr, top_n, anchors, True)
+        cmp_decode(got, want, "%s tpu=%s %s top_n=%d" % (kind, tpu, dtype, top_n))
+
+
+def test_decode_unaligned_images():
+    """n = A*C*H*W not a multiple of the 16-byte vector: images start misaligned, tail is partial."""
+    import torch
+    from ssds.modeling.layers import box
+
+    rs = np.random.RandomState(3)
+    for (A, C, H, W) in ((3, 5, 7, 9), (1, 3, 5, 7), (2, 7, 3, 3), (1, 1, 1, 1), (3, 1, 1, 3)):
+        for dtype in (torch.float32, torch.bfloat16, torch.float16):
+            n = A * C * H * W
+            cls = torch.from_numpy(rs.random_sample((5, A * C, H, W)).astype(F32)).to(dtype)
+            loc = torch.from_numpy((rs.standard_normal((5, A * 4, H, W)) * 0.3).astype(F32)).to(dtype)
+            anchors = cases.anchors_for(A, 16, O.generate_anchors)
+            cf = cases.make_unique_above(cls.float().numpy(), 0.0) if dtype == torch.float32 else cls.float().numpy()
+            if dtype == torch.float32:
+                cls = torch.from_numpy(cf)
+            got = box.decode(cls.cuda(), loc.cuda(), 16, 0.2, 40, torch.from_numpy(anchors), True)
+            want = O.decode(cf, loc.float().numpy(), 16, 0.2, 40, anchors, True)
+            cmp_decode(got, want, "unaligned n=%d %s" % (n, dtype))
+
+
+@pytest.mark.parametrize("name", list(cases.NMS_CASES))
+def test_nms_vs_reference(name):
+    import torch
+    from ssds.modeling.layers import box
+
+    g = load("nms")
+    d = cases.nms_inputs(name)
+    s, b, c = box.nms(torch.from_numpy(d["scores"]).cuda(), torch.from_numpy(d["boxes"]).cuda(),
+                      torch.from_numpy(d["classes"]).cuda(), d["thr"], d["ndet"], d["diou"])
+    np.testing.assert_array_equal(s.cpu().numpy(), g[name + "_scores"])  # keep set + order bit exact
+    np.testing.assert_array_equal(b.cpu().numpy(), g[name + "_boxes"])
+    np.testing.assert_array_equal(c.cpu().numpy(), g[name + "_classes"])
+
+
+def test_nms_kat_and_ties():
+    import torch
+    from ssds.modeling.layers import box
+
+    s, b, c = box.nms(torch.tensor([[0.9, 0.8, 0.5]]).cuda(),
+                      torch.tensor([[[0.0, 0, 10, 10], [0, 0, 10, 10], [20, 20, 30, 30]]]).cuda(),
+                      torch.zeros(1, 3).cuda(), 0.5, 3, True)
+    np.testing.assert_array_equal(s.cpu().numpy(), F32([[0.9, 0.5, 0]]))
+    # equal scores: stable order (position ascending), oracle contract
+    rs = np.random.RandomState(9)
+    d = cases.nms_inputs("clustered_diou")
+    sc = (np.round(d["scores"] * 8) / 8).astype(F32)
+    got = box.nms(torch.from_numpy(sc).cuda(), torch.from_numpy(d["boxes"]).cuda(),
+                  torch.from_numpy(d["classes"]).cuda(), 0.5, 100, True)
+    want = O.nms(sc, d["boxes"], d["classes"], 0.5, 100, True)
+    for g_, w_ in zip(got, want):
+        np.testing.assert_array_equal(g_.cpu().numpy(), w_)
+
+
+@pytest.mark.parametrize("name", list(cases.DECODER_CASES))
+def test_decoder_vs_reference(name):
+    import torch
+    from ssds.modeling.layers.box import decode_nms
+    from ssds.modeling.layers.decoder import Decoder
+
+    g = load("decoder")
+    d = cases.decoder_inputs(name, O.generate_anchors)
+    loc = [torch.from_numpy(x).cuda() for x in d["loc"]]
+    conf = [torch.from_numpy(x).cuda() for x in d["conf"]]
+    anchors = OrderedDict((k, torch.from_numpy(v)) for k, v in d["anchors"].items())
+    dec = Decoder(d["thr"], d["nms"], d["top_n"], d["per_level"], d["rescore"], d["diou"])
+    s, b, c = dec(loc, conf, anchors)
+    np.testing.assert_array_equal(c.cpu().numpy(), g[name + "_classes"])
+    np.testing.assert_allclose(b.cpu().numpy(), g[name + "_boxes"], atol=BOX_ATOL, rtol=0)
+    np.testing.assert_allclose(s.cpu().numpy(), g[name + "_scores"], atol=1e-6, rtol=1e-5)
+    # the concatenated per-level decode the reference materialises (decoder.py:48)
+    (_, _, _), mid = decode_nms(loc, conf, anchors, d["thr"], d["per_level"], d["rescore"], d["nms"],
+                                d["top_n"], d["diou"], return_mid=True)
+    np.testing.assert_array_equal(mid[2].cpu().numpy(), g[name + "_mid_classes"])
+    np.testing.assert_allclose(mid[1].cpu().numpy(), g[name + "_mid_boxes"], atol=BOX_ATOL, rtol=0)
+    np.testing.assert_allclose(mid[0].cpu().numpy(), g[name + "_mid_scores"], atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", list(cases.MATCH_CASES))
+def test_extract_targets_vs_reference(name):
+    import torch
+    from ssds.modeling.layers import box
+
+    g = load("match")
+    d = cases.match_inputs(name, O.generate_anchors)
+    anchors = OrderedDict([(d["stride"], torch.from_numpy(d["anchors"]))])
+    ct, bt, dp = box.extract_targets(torch.from_numpy(d["targets"]).cuda(), anchors, d["C"], d["stride"],
+                                     d["size"], list(map(float, d["match"])), d["radius"])
+    np.testing.assert_array_equal(dp.cpu().numpy(), g[name + "_depth"])  # matching decisions bit exact
+    np.testing.assert_array_equal(ct.cpu().numpy().astype(np.uint8), g[name + "_cls"])
+    np.testing.assert_allclose(bt.cpu().numpy(), g[name + "_box"], rtol=1e-5, atol=1e-5)
+
+
+def test_full_size_ssd512_bf16_properties_and_sampled_oracle():
+    """BASELINE config 2 shape (SSD-MobileNetV2@512, B=64, bf16 heads): size-independent properties over
+    the whole batch + the oracle on a sample of images."""
+    import torch
+    from ssds.modeling.layers.decoder import Decoder
+
+    torch.manual_seed(1234)
+    B, A, C = 64, 6, 80
+    maps, strides = [32, 16, 8, 4, 2, 1], [16, 32, 64, 128, 256, 512]
+    conf = [torch.sigmoid(torch.randn(B, A * C, m, m, device="cuda") * 1.5 - 4.6).to(torch.bfloat16) for m in maps]
+    loc = [(torch.randn(B, A * 4, m, m, device="cuda") * 0.5).to(torch.bfloat16) for m in maps]
+    anchors = OrderedDict((s, torch.from_numpy(O.generate_anchors(s, [1, 2, 0.5], [2.0, 2.828]))) for s in strides)
+    dec = Decoder(0.01, 0.6, 100, 300, True, True)
+    s, b, c = dec(loc, conf, anchors)
+    s2, b2, c2 = dec(loc, conf, anchors)  # deterministic (no atomics-order dependence in the result)
+    assert torch.equal(s, s2) and torch.equal(b, b2) and torch.equal(c, c2)
+    sn, bn, cn = s.cpu().numpy(), b.cpu().numpy(), c.cpu().numpy()
+    assert sn.shape == (B, 100) and bn.shape == (B, 100, 4)
+    assert np.all(np.diff(sn, axis=1) <= 0), "scores must be sorted descending"
+    assert np.all((bn >= 0) & (bn <= 511)) and np.all(bn[..., 2:] >= bn[..., :2] - 1)
+    assert np.all((cn >= 0) & (cn < C) & (cn == np.round(cn)))
+    oanch = OrderedDict((k, v.numpy()) for k, v in anchors.items())
+    odec = O.Decoder(0.01, 0.6, 100, 300, True, True)
+    for img in (0, 17, 63):
+        w = odec([l[img:img + 1].float().cpu().numpy() for l in loc],
+                 [x[img:img + 1].float().cpu().numpy() for x in conf], oanch)
+        # bf16 heads tie heavily: the contract (score desc, index asc) makes this exact
+        np.testing.assert_array_equal(cn[img:img + 1], w[2])
+        np.testing.assert_allclose(bn[img:img + 1], w[1], atol=BOX_ATOL, rtol=0)
+        np.testing.assert_allclose(sn[img:img + 1], w[0], atol=1e-6, rtol=1e-5)
