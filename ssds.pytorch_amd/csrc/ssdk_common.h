@@ -54,7 +54,8 @@ __device__ __forceinline__ float f16_bits_to_f32(u32 h) {
 template <int DT, int E>
 __device__ __forceinline__ float vec_elem(const u32x4& v) {
   if constexpr (DT == SSDK_F32) {
-    return __builtin_bit_cast(float, v[E]);
+    const u32 w = v[E];  // (bit_cast straight from the vector-element lvalue reads element 0)
+    return __builtin_bit_cast(float, w);
   } else {
     u32 w = v[E >> 1];
     u32 h = (E & 1) ? (w >> 16) : (w & 0xffffu);
