@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the detection hot path (fwd + decode + NMS) of SSD-MobileNetV2@512 on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic images already resident in HBM:
+backbone + extras + multibox heads forward (bf16), decode of every level and NMS.  BASELINE.json's metric
+is quoted on `configs[1]` (SSD + MobileNetV2 @512x512 bf16, batch 64, one MI355X); with N > 1 every rank
+runs the same per-GPU batch (weak scaling, replicas only: inference has no collective -- SURVEY.md 8e).
+
+Prints ONE JSON line (rank 0).  Besides the driver's contract fields it carries
+  roofline      HBM roofline of the dominant hand-written kernel (scan_kernel: the one pass over the conf
+                tensors), from hipEvents recorded live inside the timed region (ssdk_set_profiling ring)
+  stages        per-stage milliseconds (forward / decode+NMS kernels) for orientation
+  cpu_baseline  the CPU path (torch fp32 forward of the same module + the numpy oracle's Decoder) timed on
+                this host on a bounded sample of the same workload (N=1 runs only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from collections import OrderedDict
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "ssds.pytorch_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--cfg", default=os.path.join(ROOT, "experiments", "cfgs", "ssd_mobilenetv2_512.yml"))
+    ap.add_argument("--cpu-sample", type=int, default=4, help="images for the CPU baseline (0 = skip)")
+    ap.add_argument("--channels-last", type=int, default=int(os.environ.get("SSDK_CHANNELS_LAST", "0")))
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from ssds import _native as N
+    from ssds.core import config
+    from ssds.modeling import model_builder
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+    n_gpus = world
+
+    cfg = config.cfg_from_file(args.cfg)
+    torch.manual_seed(1234)  # same random-init weights on every rank (reference init, conf bias -log 99)
+    model = model_builder.create_model(cfg.MODEL).eval()
+    cpu_state = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and args.cpu_sample) else None
+    model = model.to(dev, torch.bfloat16)
+    if args.channels_last:
+        model = model.to(memory_format=torch.channels_last)
+    anchors = model_builder.create_anchors(cfg.MODEL, model, cfg.MODEL.IMAGE_SIZE)
+    decoder = model_builder.create_decoder(cfg.POST_PROCESS)
+    H, W = cfg.MODEL.IMAGE_SIZE
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.rand((B, 3, H, W), device=dev, generator=g).to(torch.bfloat16)  # synthetic, resident in HBM
+    if args.channels_last:
+        x = x.contiguous(memory_format=torch.channels_last)
+
+    @torch.no_grad()
+    def step():
+        loc, conf = model(x)
+        return decoder(loc, conf, anchors)
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    N.set_profiling(True)  # event ring: recorded inside the timed region, read back after it
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel times recorded live in the timed region -------------------------------------------
+    nprof = min(args.steps, 256)
+    tim = np.array([N.timings_ms(i) for i in range(nprof)], dtype=np.float64)  # [steps, (scan, level, nms)]
+    scan_ms, level_ms, nms_ms = tim.mean(0)
+    N.set_profiling(False)
+
+    @torch.no_grad()
+    def time_fn(fn, n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / n
+
+    with torch.no_grad():
+        loc, conf = model(x)
+    fwd_ms = time_fn(lambda: model(x), max(3, min(10, args.steps)))
+    dec_ms = time_fn(lambda: decoder(loc, conf, anchors), max(3, min(20, args.steps)))
+
+    conf_bytes = sum(c.numel() * c.element_size() for c in conf)  # the scan kernel reads conf exactly once
+    loc_bytes = sum(l.numel() * l.element_size() for l in loc)
+    K, D, L = decoder.top_n_per_level, decoder.top_n, len(conf)
+    stage_bytes = conf_bytes + loc_bytes + B * (2 * 24 * L * K + 24 * D)  # SURVEY.md 8d (1.465 MB/img)
+    scan_gbs = conf_bytes / (scan_ms * 1e-3) / 1e9
+    roofline = {
+        "kernel": "ssdk::scan_kernel<bf16> (threshold + exact top-k over the conf tensors, one pass)",
+        "bound": "hbm",
+        "achieved": round(scan_gbs, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(scan_gbs / HBM_PEAK_GBS, 4),
+        "traffic": None,  # PMC pass (FETCH_SIZE) is collected separately: profiles/
+        "algorithmic_bytes_per_launch": int(conf_bytes),
+        "avg_launch_ms": round(float(scan_ms), 5),
+        "decode_nms_stage": {
+            "algorithmic_bytes": int(stage_bytes),
+            "kernels_ms": {"scan": round(float(scan_ms), 5), "level": round(float(level_ms), 5),
+                           "nms": round(float(nms_ms), 5)},
+            "achieved_GBps": round(stage_bytes / ((scan_ms + level_ms + nms_ms) * 1e-3) / 1e9, 1),
+            "frac": round(stage_bytes / ((scan_ms + level_ms + nms_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        },
+    }
+
+    result = OrderedDict()
+    result["metric"] = "images/sec (fwd+decode+NMS) SSD-MobileNetV2@512"
+    result["value"] = round(n_gpus * B * args.steps / elapsed, 2)
+    result["unit"] = "images/sec"
+    result["n_gpus"] = n_gpus
+    result["steps"] = args.steps
+    result["warmup"] = args.warmup
+    result["ms_per_step"] = round(elapsed / args.steps * 1e3, 4)
+    result["higher_is_better"] = True
+    result["scaling"] = "weak"
+    result["vs_baseline"] = None  # the reference publishes no numbers
+    result["dtype"] = "bf16"
+    result["data"] = "synthetic"
+    result["config"] = {
+        "workload": "SSD+MobileNetV2 @512x512 bf16, batch 64 per GPU: backbone+extras+heads forward, "
+                    "decode (thr .01, 300/level, rescore) + DIoU-NMS (.6, 100 dets); random-init weights "
+                    "(reference init), torch.rand images resident in HBM",
+        "cfg": os.path.relpath(args.cfg, ROOT),
+        "batch_per_gpu": B,
+        "global_batch": B * n_gpus,
+        "image_size": [H, W],
+        "parallelism": "replicas x%d (no collective)" % n_gpus,
+        "fused_head_conv": os.environ.get("SSDK_FUSED_CONV", "1") != "0",
+        "channels_last": bool(args.channels_last),
+    }
+    result["roofline"] = roofline
+    result["stages"] = {"forward_ms": round(fwd_ms, 4), "decode_nms_ms": round(dec_ms, 4)}
+
+    # ---- CPU baseline (rank 0, N = 1): torch fp32 forward + numpy oracle decoder, bounded sample ----------
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        from oracle import box_oracle as O  # checker / baseline only
+
+        S = args.cpu_sample
+        config.reset_cfg()
+        cfg2 = config.cfg_from_file(args.cfg)
+        cpu_model = model_builder.create_model(cfg2.MODEL).eval()
+        cpu_model.load_state_dict(cpu_state)
+        xs = x[:S].float().cpu()
+        oanch = OrderedDict((k, v.numpy()) for k, v in anchors.items())
+        odec = O.Decoder(decoder.conf_threshold, decoder.nms_threshold, decoder.top_n, decoder.top_n_per_level,
+                         decoder.rescore, decoder.use_diou)
+        with torch.no_grad():
+            cpu_model(xs[:1])  # warm
+            t0 = time.perf_counter()
+            cl, cc = cpu_model(xs)
+            odec([t.numpy() for t in cl], [t.numpy() for t in cc], oanch)
+            cpu_s = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": round(S / cpu_s, 3),
+            "unit": "images/sec",
+            "cores": int(torch.get_num_threads()),
+            "kind": "port",
+            "sample": "%d of the %d images of one batch: torch fp32 CPU forward of the same module (%d threads) "
+                      "+ numpy oracle decode+NMS (1 thread), %.1f s" % (S, B, torch.get_num_threads(), cpu_s),
+        }
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,6 +107,14 @@ int ssdk_decode_nms(const ssdk_level* levels, int L, int B, int dtype, float thr
                     float* mid_scores, float* mid_boxes, float* mid_classes, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* Optional per-kernel timing for roofline accounting (bench.py): when enabled, ssdk_decode_nms records
+ * hipEvents on the caller's stream around its three launches into a ring of 256 slots (no
+ * synchronisation inside the timed region).  ssdk_get_timings(back, ms, 3) returns ms[0..2] = scan_kernel,
+ * level_kernel, nms_kernel of the call `back` calls before the most recent one; it synchronises on that
+ * call's last event. */
+int ssdk_set_profiling(int enable);
+int ssdk_get_timings(int back, float* ms, int n);
+
 /* box.py:362-405 extract_targets + box.py:116-226 snap_to_anchors_by_iou for ONE level and the whole
  * batch in one launch.  targets[B*G*5] device fp32 (x, y, w, h, label), rows with label <= -1 are
  * padding (box.py:375).  anchors[A*4] HOST fp32.  Outputs device fp32, fully written:

@@ -319,6 +319,8 @@ __global__ __launch_bounds__(kLevelThreads) void level_kernel(const LevelParams 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+hipEvent_t* g_prof_events = nullptr;  // [0] before scan, [1] after scan, [2] after level
+
 struct DecodePlan {
   u32 tiles_per_unit, units_per_image;
   u32 units[SSDK_MAX_LEVELS], unit_base[SSDK_MAX_LEVELS], n[SSDK_MAX_LEVELS];
@@ -440,13 +442,17 @@ static int launch_decode(const ssdk_level* lv, int L, int B, int dtype, float th
 
   const size_t lds = lds_bytes_for((u32)K);
   const dim3 grid((unsigned)(B * pl.units_per_image));
+  if (g_prof_events) (void)hipEventRecord(g_prof_events[0], stream);
   if (dtype == SSDK_F32) hipLaunchKernelGGL(scan_kernel<SSDK_F32>, grid, dim3(kScanThreads), lds, stream, sp);
   else if (dtype == SSDK_BF16) hipLaunchKernelGGL(scan_kernel<SSDK_BF16>, grid, dim3(kScanThreads), lds, stream, sp);
   else hipLaunchKernelGGL(scan_kernel<SSDK_F16>, grid, dim3(kScanThreads), lds, stream, sp);
   rc = check_launch("scan_kernel");
   if (rc) return rc;
+  if (g_prof_events) (void)hipEventRecord(g_prof_events[1], stream);
   hipLaunchKernelGGL(level_kernel, dim3((unsigned)L, (unsigned)B), dim3(kLevelThreads), lds, stream, lp);
-  return check_launch("level_kernel");
+  rc = check_launch("level_kernel");
+  if (g_prof_events) (void)hipEventRecord(g_prof_events[2], stream);
+  return rc;
 }
 
 // shared with ssdk_nms.hip (fused decode_nms entry point lives there)

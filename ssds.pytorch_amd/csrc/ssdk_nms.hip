@@ -24,6 +24,8 @@ size_t decode_ws_bytes(const ssdk_level* lv, int L, int B, int dtype, int K);
 int decode_levels(const ssdk_level* lv, int L, int B, int dtype, float thr, int K, int rescore,
                   float* scores, float* boxes, float* classes, void* ws, size_t ws_bytes, void* stream);
 
+extern hipEvent_t* g_prof_events;  // set by ssdk_decode_nms while profiling (ssdk_decode.hip)
+
 constexpr int kNmsThreads = 256;
 
 struct NmsParams {
@@ -231,6 +233,45 @@ extern "C" int ssdk_nms(const float* scores, const float* boxes, const float* cl
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// ---- optional per-kernel timing (bench.py roofline): events on the caller's stream ---------------
+// A ring of event quadruples so that a whole timed region can be profiled without any synchronisation
+// inside it; the host reads the slots back after its own final sync.
+constexpr int kProfSlots = 256;
+static int g_prof_on = 0;
+static hipEvent_t g_ev[kProfSlots][4];
+static int g_ev_ready = 0;
+static long long g_prof_calls = 0;
+
+extern "C" int ssdk_set_profiling(int enable) {
+  if (enable && !g_ev_ready) {
+    for (int s = 0; s < kProfSlots; ++s)
+      for (int i = 0; i < 4; ++i)
+        if (hipEventCreate(&g_ev[s][i]) != hipSuccess) {
+          ssdk::set_error("set_profiling: hipEventCreate failed");
+          return SSDK_E_LAUNCH;
+        }
+    g_ev_ready = 1;
+  }
+  g_prof_on = enable ? 1 : 0;
+  g_prof_calls = 0;
+  return SSDK_OK;
+}
+
+// ms[0] = scan_kernel, ms[1] = level_kernel, ms[2] = nms_kernel of the profiled ssdk_decode_nms call
+// `back` calls before the most recent one (0 = last).  Synchronises on that call's last event.
+extern "C" int ssdk_get_timings(int back, float* ms, int n) {
+  if (!ms || n < 3 || back < 0 || back >= kProfSlots || (long long)back >= g_prof_calls) {
+    ssdk::set_error("get_timings: slot %d not recorded (%lld profiled calls, ring of %d)", back, g_prof_calls,
+                    kProfSlots);
+    return SSDK_E_BADARG;
+  }
+  hipEvent_t* ev = g_ev[(g_prof_calls - 1 - back) % kProfSlots];
+  if (hipEventSynchronize(ev[3]) != hipSuccess) return SSDK_E_LAUNCH;
+  for (int i = 0; i < 3; ++i)
+    if (hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) != hipSuccess) return SSDK_E_LAUNCH;
+  return SSDK_OK;
+}
+
 extern "C" size_t ssdk_decode_nms_workspace_bytes(const ssdk_level* levels, int L, int B, int dtype,
                                                   int top_n_per_level, int ndetections) {
   (void)ndetections;
@@ -259,9 +300,18 @@ extern "C" int ssdk_decode_nms(const ssdk_level* levels, int L, int B, int dtype
   float* mb = mid_boxes ? mid_boxes : (float*)w;
   w += align256(n * 16);
   float* mc = mid_classes ? mid_classes : (float*)w;
+  const bool prof = g_prof_on && g_ev_ready;
+  hipEvent_t* ev = prof ? g_ev[g_prof_calls % kProfSlots] : nullptr;
+  ssdk::g_prof_events = ev;
   int rc = ssdk::decode_levels(levels, L, B, dtype, threshold, top_n_per_level, rescore, ms, mb, mc,
                                workspace, dec, stream);
+  ssdk::g_prof_events = nullptr;
   if (rc) return rc;
-  return ssdk::launch_nms(ms, mb, mc, B, L * top_n_per_level, nms_threshold, ndetections, using_diou,
-                          out_scores, out_boxes, out_classes, (hipStream_t)stream);
+  rc = ssdk::launch_nms(ms, mb, mc, B, L * top_n_per_level, nms_threshold, ndetections, using_diou,
+                        out_scores, out_boxes, out_classes, (hipStream_t)stream);
+  if (prof) {
+    (void)hipEventRecord(ev[3], (hipStream_t)stream);
+    ++g_prof_calls;
+  }
+  return rc;
 }

@@ -68,7 +68,9 @@ def _load():
     lib.ssdk_conv_workspace_bytes.argtypes = [i32] * 8
     lib.ssdk_conv_bn_act.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                      vp, vp, sz, vp]
-    for name in ("ssdk_device_info", "ssdk_generate_anchors", "ssdk_decode", "ssdk_nms",
+    lib.ssdk_set_profiling.argtypes = [i32]
+    lib.ssdk_get_timings.argtypes = [i32, c.POINTER(f32), i32]
+    for name in ("ssdk_set_profiling", "ssdk_get_timings", "ssdk_device_info", "ssdk_generate_anchors", "ssdk_decode", "ssdk_nms",
                  "ssdk_decode_nms", "ssdk_match_targets", "ssdk_conv_bn_act"):
         getattr(lib, name).restype = i32
     return lib
@@ -78,7 +80,7 @@ lib = _load()
 EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_device_info", "ssdk_generate_anchors",
            "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
-           "ssdk_conv_workspace_bytes", "ssdk_conv_bn_act")
+           "ssdk_conv_workspace_bytes", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 
 
 class SsdkError(RuntimeError):
@@ -148,6 +150,18 @@ def make_level(cls, box, stride, anchors):
     for i in range(flat.shape[0]):
         lv.anchors[i] = float(flat[i])
     return lv
+
+
+def set_profiling(on):
+    check(lib.ssdk_set_profiling(1 if on else 0), "set_profiling")
+
+
+def timings_ms(back=0):
+    """(scan_kernel, level_kernel, nms_kernel) milliseconds of the profiled decode_nms call `back` calls
+    before the most recent one."""
+    ms = (ctypes.c_float * 3)()
+    check(lib.ssdk_get_timings(int(back), ms, 3), "get_timings")
+    return float(ms[0]), float(ms[1]), float(ms[2])
 
 
 def device_info():

@@ -1,0 +1,104 @@
+"""SSDFPN (RetinaNet-style FPN + shared towers) -- constructor, ``add_extras`` factory, module names
+(``transforms``, ``extras``, ``loc``, ``conf``) and forward contract of the reference's
+``ssds/modeling/ssds/fpn.py`` (SharedHead :10-18, forward :58-101, add_extras :103-147).
+
+MI355X execution (eval, HIP device): the two shared towers -- 4 x (3x3 conv 256->256 + BN + ReLU) and a
+final 3x3 conv to A*4 / A*C channels, weights shared by every level -- are the dominant dense
+contraction of BASELINE config 3 (110 GFLOP/img); each conv of a tower is one fused MFMA launch per
+level (BN folded, ReLU / sigmoid in the epilogue)."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ssds.modeling.layers.basic_layers import ConvBNReLU
+from ssds.modeling.layers.fused_conv import FusedSequentialMixin
+
+from .ssdsbase import SSDSBase
+
+
+class SharedHead(FusedSequentialMixin, nn.Sequential):
+    """4 x ConvBNReLU(256, 256, 3) + Conv2d(256, out_planes, 3) (reference fpn.py:10-18)."""
+
+    def __init__(self, out_planes):
+        layers = [ConvBNReLU(256, 256, 3) for _ in range(4)]
+        layers += [nn.Conv2d(256, out_planes, 3, padding=1)]
+        super(SharedHead, self).__init__(*layers)
+
+    def forward(self, x, final_act="none"):
+        for m in list(self.children())[:-1]:
+            x = m(x)
+        last = list(self.children())[-1]
+        return _final_conv(self, last, x, final_act)
+
+
+def _final_conv(owner, conv, x, act):
+    from ssds.modeling.layers.fused_conv import conv_bn_act_native, conv_supported, fold_bn, fused_enabled
+
+    if not owner.training and fused_enabled() and conv_supported(conv, x):
+        _, bias = fold_bn(conv, None)
+        return conv_bn_act_native(x, conv.weight.detach(), None, bias, conv.kernel_size[0], conv.stride[0], act)
+    y = conv(x)
+    return y.sigmoid() if act == "sigmoid" else y
+
+
+class SSDFPN(SSDSBase):
+    """RetinaNet (https://arxiv.org/abs/1708.02002) with ConvBNReLU extras/towers like the reference."""
+
+    def __init__(self, backbone, extras, head, num_classes):
+        super(SSDFPN, self).__init__(backbone, num_classes)
+        self.transforms = nn.ModuleList(extras[0])
+        self.extras = nn.ModuleList(extras[1])
+        self.loc = head[0]
+        self.conf = head[1]
+        self.initialize()
+
+    def initialize(self):
+        self.backbone.initialize()
+        self.transforms.apply(self.initialize_extra)
+        self.extras.apply(self.initialize_extra)
+        self.loc.apply(self.initialize_head)
+        self.conf.apply(self.initialize_head)
+        self.conf[-1].apply(self.initialize_prior)
+
+    def _towers(self, xx, loc, conf):
+        loc.append(self.loc(xx, "none"))
+        conf.append(self.conf(xx, "none" if self.training else "sigmoid"))
+
+    def forward(self, x):
+        loc, conf = [], []
+        features = self.backbone(x)
+        x = features[-1]
+        n = len(features)
+        xx = None
+        for i in range(n - 1, -1, -1):  # top-down pathway (reference fpn.py:80-87)
+            lateral = self.transforms[i](features[i])
+            xx = lateral if i == n - 1 else F.interpolate(xx, scale_factor=2, mode="nearest") + lateral
+            features[i] = xx
+        for i, v in enumerate(self.extras):  # reference fpn.py:89-97
+            if i < n:
+                xx = v(features[i])
+            elif i == n:
+                xx = v(x)
+            else:
+                xx = v(xx)
+            self._towers(xx, loc, conf)
+        return tuple(loc), tuple(conf)
+
+    @staticmethod
+    def add_extras(feature_layer, mbox, num_classes):
+        """ints -> backbone output + 1x1 lateral (bias, no BN) + 3x3 ConvBNReLU; "Conv:S" -> stride-2
+        ConvBNReLU on the previous map; one pair of shared towers (reference fpn.py:103-147)."""
+        nets_outputs, transform_layers, extra_layers = [], [], []
+        if not all(mbox[i] == mbox[i + 1] for i in range(len(mbox) - 1)):
+            raise ValueError("For SSDFPN module, the number of box have to be same in every layer")
+        loc_layers = SharedHead(mbox[0] * 4)
+        conf_layers = SharedHead(mbox[0] * num_classes)
+        for layer, depth in zip(feature_layer[0], feature_layer[1]):
+            if isinstance(layer, int):
+                nets_outputs.append(layer)
+                transform_layers += [nn.Conv2d(depth, 256, 1)]
+                extra_layers += [ConvBNReLU(256, 256, 3)]
+            elif layer == "Conv:S":
+                extra_layers += [ConvBNReLU(depth, 256, 3, stride=2)]
+            else:
+                raise ValueError(layer + " does not support by SSDFPN")
+        return nets_outputs, (transform_layers, extra_layers), (loc_layers, conf_layers)

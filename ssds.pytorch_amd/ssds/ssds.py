@@ -1,0 +1,57 @@
+"""``SSDDetector`` -- the inference entry point (reference ``ssds/ssds.py:7-68``): cfg file ->
+model + anchors + decoder; numpy image(s) in, numpy detections out."""
+import numpy as np
+import torch
+
+from .core import checkpoint, config
+from .modeling import model_builder
+
+
+class SSDDetector(object):
+    r"""Args:
+        cfg_file (str):  path to the yaml config
+        is_print (bool): print the model and the anchor shapes
+        dtype: compute dtype of the network on the HIP device (bf16 by default; the reference is fp32)
+    """
+
+    def __init__(self, cfg_file, is_print=False, dtype=torch.bfloat16):
+        cfg = config.cfg_from_file(cfg_file)
+        print("===> Building model")
+        self.model = model_builder.create_model(cfg.MODEL)
+        if is_print:
+            print("Model architectures:\n{}\n".format(self.model))
+        if not torch.cuda.is_available():
+            raise RuntimeError("SSDDetector needs a HIP device (MI355X); there is no CPU path")
+        self.device = torch.device("cuda:0")
+        if cfg.RESUME_CHECKPOINT:
+            print("Loading initial model weights from {:s}".format(cfg.RESUME_CHECKPOINT))
+            checkpoint.resume_checkpoint(self.model, cfg.RESUME_CHECKPOINT, "")
+        self.dtype = dtype
+        self.model.eval().to(self.device, dtype)
+        self.anchors = model_builder.create_anchors(cfg.MODEL, self.model, cfg.MODEL.IMAGE_SIZE, is_print)
+        self.decoder = model_builder.create_decoder(cfg.POST_PROCESS)
+        self.image_size = tuple(cfg.MODEL.IMAGE_SIZE)
+        self.num_classes = cfg.MODEL.NUM_CLASSES
+        self.mean = cfg.DATASET.PREPROC.MEAN
+        self.std = cfg.DATASET.PREPROC.STD
+
+    @torch.no_grad()
+    def __call__(self, imgs):
+        r"""imgs: np.ndarray [H,W,3], [3,H,W], [N,H,W,3] or [N,3,H,W] (reference ssds.py:41-68).
+        Returns (scores [N,100] f32, boxes [N,100,4] int, classes [N,100] int); 3-d input drops N."""
+        pick1st = False
+        if len(imgs.shape) == 3:
+            imgs = imgs[None, ...]
+            pick1st = True
+        if len(imgs.shape) != 4:
+            raise AssertionError("image dims has to be 3 or 4")
+        if imgs.shape[3] == 3:
+            imgs = imgs.transpose(0, 3, 1, 2)
+        x = torch.from_numpy(np.ascontiguousarray(imgs)).to(self.device, torch.float32)
+        x = ((x - self.mean) / self.std).to(self.dtype)
+        loc, conf = self.model(x)
+        detections = self.decoder(loc, conf, self.anchors)
+        out_scores, out_boxes, out_classes = (d.cpu().numpy() for d in detections)  # the one D2H copy
+        if pick1st:
+            return out_scores[0], out_boxes[0].astype(int), out_classes[0].astype(int)
+        return out_scores, out_boxes.astype(int), out_classes.astype(int)

@@ -1,0 +1,125 @@
+"""Host-side plugin surface (no GPU): config schema behaviour, the model_builder factories for the four
+BASELINE geometries (shapes, strides, anchor counts of SURVEY.md section 8), checkpoint round trip."""
+import os
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "experiments", "cfgs")
+
+
+@pytest.fixture(autouse=True)
+def fresh_cfg():
+    from ssds.core import config
+
+    config.reset_cfg()
+    yield
+    config.reset_cfg()
+
+
+def test_config_defaults_and_errors(tmp_path):
+    from ssds.core import config
+
+    c = config.cfg
+    assert c.POST_PROCESS.SCORE_THRESHOLD == 0.01 and c.POST_PROCESS.MAX_DETECTIONS_PER_LEVEL == 300
+    assert c.MATCHER.MATCH_THRESHOLD == [0.5, 0.4] and c.POST_PROCESS.USE_DIOU is True
+    bad = tmp_path / "bad.yml"
+    bad.write_text("MODEL:\n  NOT_A_KEY: 1\n")
+    with pytest.raises(KeyError, match="Non-existent config key: MODEL.NOT_A_KEY"):
+        config.cfg_from_file(str(bad))
+    bad.write_text("MODEL:\n  NUM_CLASSES: 'eighty'\n")
+    with pytest.raises(ValueError, match="Type mismatch"):
+        config.cfg_from_file(str(bad))
+    ok = tmp_path / "ok.yml"
+    ok.write_text("MODEL:\n  NUM_CLASSES: 7\n  IMAGE_SIZE: (320, 320)\nTRAIN:\n  MAX_EPOCHS: 9\n"
+                  "  LR_SCHEDULER:\n    WARM_UP_EPOCHS: 2\n")
+    c = config.cfg_from_file(str(ok))
+    assert c.POST_PROCESS.NUM_CLASSES == 7 and c.MATCHER.NUM_CLASSES == 7  # derived fields
+    assert c.MODEL.IMAGE_SIZE == [320, 320] and c.DATASET.IMAGE_SIZE == [320, 320]
+    assert c.TRAIN.LR_SCHEDULER.MAX_EPOCHS == 7
+
+
+GEOM = [
+    ("ssd_mobilenetv2_300", [15, 30, 60, 100, 150, 300], [19, 10, 5, 3, 2, 1], 6, 3000),
+    ("ssd_mobilenetv2_512", [16, 32, 64, 128, 256, 512], [32, 16, 8, 4, 2, 1], 6, 8190),
+]
+
+
+@pytest.mark.parametrize("name,strides,maps,A,total", GEOM)
+def test_ssd_builder_geometry(name, strides, maps, A, total):
+    from ssds.core import config
+    from ssds.modeling import model_builder
+
+    cfg = config.cfg_from_file(os.path.join(CFG, name + ".yml"))
+    model = model_builder.create_model(cfg.MODEL)
+    assert model.training
+    anchors = model_builder.create_anchors(cfg.MODEL, model, cfg.MODEL.IMAGE_SIZE)
+    assert model.training, "create_anchors must restore the mode"
+    assert list(anchors.keys()) == strides
+    assert all(tuple(a.shape) == (A, 4) and a.dtype == torch.float32 and not a.is_cuda for a in anchors.values())
+    x = torch.rand(2, 3, *cfg.MODEL.IMAGE_SIZE)
+    loc, conf = model(x)  # training mode: logits
+    assert [c.shape[-1] for c in conf] == maps
+    assert all(l.shape[1] == A * 4 and c.shape[1] == A * 80 for l, c in zip(loc, conf))
+    assert sum(A * m * m for m in maps) == total
+    model.eval()
+    with torch.no_grad():
+        _, conf_e = model(x)
+    assert all(float(c.min()) >= 0 and float(c.max()) <= 1 for c in conf_e)  # sigmoid in eval (ssd.py:72)
+    # conf prior: bias = -log(99) -> an untrained head scores ~0.01 (ssdsbase.py:15-19)
+    assert abs(float(conf_e[0].mean()) - 0.01) < 5e-3
+    dec = model_builder.create_decoder(cfg.POST_PROCESS)
+    assert (dec.conf_threshold, dec.nms_threshold, dec.top_n, dec.top_n_per_level, dec.rescore, dec.use_diou) == (
+        0.01, 0.6, 100, 300, True, True)
+    names = list(model.state_dict().keys())
+    assert "backbone.conv1.0.weight" in names and "extras.0.3.weight" in names
+    assert "loc.5.bias" in names and "conf.0.weight" in names
+
+
+def test_fpn_and_bifpn_build_small():
+    from ssds.modeling import nets, ssds
+
+    for cls, net, outs, depth in ((ssds.SSDFPN, "ResNet18", [3, 4, 5], [128, 256, 512]),
+                                  (ssds.SSDBiFPN, "RegNetX002", [2, 3, 4], [56, 152, 368])):
+        fl = [outs + ["Conv:S", "Conv:S"], depth + [depth[-1], 256]]
+        nets_outputs, extras, head = cls.add_extras(fl, [9] * 5, 4)
+        model = cls(getattr(nets, net)(outputs=nets_outputs), extras, head, 4).eval()
+        with torch.no_grad():
+            loc, conf = model(torch.rand(1, 3, 128, 128))
+        assert [c.shape[-1] for c in conf] == [16, 8, 4, 2, 1]
+        assert all(l.shape[1] == 36 and c.shape[1] == 36 for l, c in zip(loc, conf))
+    with pytest.raises(ValueError, match="number of box"):
+        ssds.SSDFPN.add_extras([[3, 4], [128, 256]], [9, 6], 4)
+
+
+def test_backbone_registry_and_parser():
+    from ssds.modeling import nets
+    from ssds.modeling.layers.layers_parser import parse_feature_layer
+
+    for n in ("MobileNetV1", "MobileNetV2", "ResNet50", "RegNetX008"):
+        assert hasattr(nets, n)
+    assert nets.RegNetX008(outputs=[2, 3, 4]).stage_widths == [64, 128, 288, 672]
+    with pytest.raises(AssertionError, match="Undefined layer"):
+        parse_feature_layer("Bogus", 8, 8)
+
+
+def test_checkpoint_round_trip(tmp_path):
+    from ssds.core import checkpoint
+    from ssds.modeling import nets, ssds
+
+    def make():
+        o, e, h = ssds.SSD.add_extras([[5, 7, "Conv:S"], [96, 320, 64]], [2, 2, 2], 3)
+        return ssds.SSD(nets.MobileNetV2(outputs=o), e, h, 3)
+
+    a, b = make(), make()
+    path = checkpoint.save_checkpoints(a, str(tmp_path), "ssd_test", 3)
+    assert checkpoint.find_previous_checkpoint(str(tmp_path)) == ([3], [path])
+    # a reference checkpoint also carries the unused classifier tail and a DataParallel prefix
+    sd = {"module." + k: v for k, v in torch.load(path).items()}
+    sd["module.backbone.classifier.1.weight"] = torch.zeros(10, 10)
+    torch.save(sd, path)
+    assert checkpoint.resume_checkpoint(b, path, "") is b
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(va, vb), k
+    assert checkpoint.resume_checkpoint(b, str(tmp_path / "missing.pth"), "") is False
