@@ -124,11 +124,38 @@ int ssdk_match_targets(const float* targets, int B, int G, const float* anchors,
                        float center_sampling_radius, float* cls_target, float* box_target,
                        float* depth, void* stream);
 
-/* basic_layers.py:28-57 (Conv+BN+ReLU blocks) and ssd.py:100-103 / fpn.py:10-18 (head convs) as one
- * fused implicit-GEMM on MFMA: y = act(conv(x, w) * scale[c] + bias[c]).
- * x [N,Cin,H,W] NCHW (dtype), w [Cout,Cin,kh,kw] (dtype), scale/bias [Cout] fp32 (folded BN; scale may
- * be NULL = 1), y [N,Cout,Ho,Wo] NCHW (out_dtype).  kh=kw in {1,3}, stride in {1,2}, pad = k/2. */
+/* Fused convolution + folded BatchNorm + activation (+ residual) for the detector network:
+ * basic_layers.py:5-57 (SepConvBNReLU / ConvBNReLU / ConvBNReLUx2), the MobileNetV2 blocks behind
+ * nets/mobilenet.py:56-99, and the bare multibox head convs ssd.py:100-103 / fpn.py:10-18.
+ *   y = act(conv(x, w) * scale[c] + bias[c]) (+ residual)
+ * Dispatch:  groups == 1, Cin % 8 == 0  -> MFMA implicit GEMM (1x1 / 3x3, stride 1|2, pad k/2)
+ *            groups == Cin == Cout      -> depthwise 3x3 (HBM-bound, NHWC)
+ *            Cin <= 4 (image stem)      -> direct 3x3; w is fp32 with the BN scale folded in, scale = NULL
+ * Layouts:   x NHWC (= torch channels_last) except the stem which also takes NCHW;
+ *            w KRSC [Cout][kh][kw][Cin/groups] in the activation dtype;  scale (may be NULL = 1), bias fp32;
+ *            y NHWC, or NCHW for the multibox heads (the [B, A*C, H, W] layout decode consumes); with NCHW
+ *            output channels >= split go to y2 with activation act2 (loc | conf of one SSD level as ONE GEMM).
+ */
+enum { SSDK_LAYOUT_NCHW = 0, SSDK_LAYOUT_NHWC = 1 };
+typedef struct ssdk_conv_desc {
+  const void* x;
+  const void* w;
+  const float* scale;
+  const float* bias;
+  const void* residual; /* optional, NHWC, added after the activation-free linear bottleneck conv */
+  void* y;
+  void* y2;             /* optional second output (NCHW split) */
+  int32_t N, Cin, H, W, Cout, k, stride, groups;
+  int32_t act, act2, split;
+  int32_t dtype;        /* SSDK_BF16 | SSDK_F16 (input, weights and output) */
+  int32_t in_layout, out_layout;
+} ssdk_conv_desc;
 size_t ssdk_conv_workspace_bytes(int N, int Cin, int H, int W, int Cout, int k, int stride, int dtype);
+int ssdk_conv(const ssdk_conv_desc* desc, void* workspace, size_t workspace_bytes, void* stream);
+/* a whole pre-planned network: descs[0..n) launched in order on `stream` (one host call per forward) */
+int ssdk_conv_sequence(const ssdk_conv_desc* descs, int n, void* workspace, size_t workspace_bytes,
+                       void* stream);
+/* convenience wrapper: dense conv, NHWC in/out, single output */
 int ssdk_conv_bn_act(const void* x, const void* w, const float* scale, const float* bias, int N,
                      int Cin, int H, int W, int Cout, int k, int stride, int act, int dtype,
                      int out_dtype, void* y, void* workspace, size_t workspace_bytes, void* stream);

@@ -39,6 +39,20 @@ class Level(ctypes.Structure):
     ]
 
 
+class ConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("residual", ctypes.c_void_p), ("y", ctypes.c_void_p), ("y2", ctypes.c_void_p),
+        ("N", ctypes.c_int32), ("Cin", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+        ("Cout", ctypes.c_int32), ("k", ctypes.c_int32), ("stride", ctypes.c_int32), ("groups", ctypes.c_int32),
+        ("act", ctypes.c_int32), ("act2", ctypes.c_int32), ("split", ctypes.c_int32),
+        ("dtype", ctypes.c_int32), ("in_layout", ctypes.c_int32), ("out_layout", ctypes.c_int32),
+    ]
+
+
+NCHW, NHWC = 0, 1
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -68,6 +82,10 @@ def _load():
     lib.ssdk_conv_workspace_bytes.argtypes = [i32] * 8
     lib.ssdk_conv_bn_act.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                      vp, vp, sz, vp]
+    lib.ssdk_conv.argtypes = [c.POINTER(ConvDesc), vp, sz, vp]
+    lib.ssdk_conv.restype = i32
+    lib.ssdk_conv_sequence.argtypes = [c.POINTER(ConvDesc), i32, vp, sz, vp]
+    lib.ssdk_conv_sequence.restype = i32
     lib.ssdk_set_profiling.argtypes = [i32]
     lib.ssdk_get_timings.argtypes = [i32, c.POINTER(f32), i32]
     for name in ("ssdk_set_profiling", "ssdk_get_timings", "ssdk_device_info", "ssdk_generate_anchors", "ssdk_decode", "ssdk_nms",
@@ -80,7 +98,7 @@ lib = _load()
 EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_device_info", "ssdk_generate_anchors",
            "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
-           "ssdk_conv_workspace_bytes", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
+           "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 
 
 class SsdkError(RuntimeError):

@@ -1,12 +1,19 @@
-"""Host side of the fused conv + folded-BN + activation kernel (C-ABI ``ssdk_conv_bn_act``).
+"""Host side of the fused conv + folded-BN + activation kernels (C-ABI ``ssdk_conv`` /
+``ssdk_conv_sequence``, csrc/ssdk_conv.hip).
 
-``fused_conv_bn_act(x, conv, bn, act)`` folds the BatchNorm running statistics into a per-channel
-(scale, bias) pair and launches the MFMA implicit-GEMM kernel.  ``FusedSequentialMixin`` lets the
-reference-shaped nn.Sequential blocks use it in eval mode without changing their state_dict layout.
+* ``pack_conv(conv, bn, dtype)`` folds the BatchNorm running statistics into a per-channel fp32
+  (scale, bias) pair and re-packs the weight once into the KRSC layout the kernels read.
+* ``conv_native(x, pack, ...)`` launches one layer (activations are NHWC = torch ``channels_last``).
+* ``ConvPlan`` records a whole network as an array of descriptors with pre-assigned activation buffers and
+  replays it with ONE host call per forward (``ssdk_conv_sequence``): ~2 us of host time per layer instead
+  of a Python round trip per layer, and trivially hipGraph-capturable.
+* ``FusedSequentialMixin`` lets the reference-shaped nn.Sequential blocks (basic_layers.py) use the fused
+  kernels in eval mode without changing their state_dict layout.
 
-Switch: ``SSDK_FUSED_CONV`` = "1" (default: use the HIP kernel for dense 1x1/3x3 convs in eval mode on a
-HIP device) or "0" (always torch/MIOpen; used by A/B measurements, never silently).
+Switch: ``SSDK_FUSED_CONV`` = "1" (default: HIP kernels in eval mode on a HIP device) or "0" (torch/MIOpen
+everywhere; for A/B measurements only, never chosen silently).
 """
+import ctypes
 import os
 
 import torch
@@ -16,6 +23,8 @@ import torch.nn.functional as F
 from ssds import _native as N
 
 _ACT_OF = {nn.ReLU: "relu", nn.ReLU6: "relu6", nn.SiLU: "silu", nn.Sigmoid: "sigmoid"}
+
+STATS = {"native_layers": 0, "plan_runs": 0, "torch_fallback_layers": 0}
 
 
 def fused_enabled():
@@ -29,7 +38,7 @@ def fold_bn(conv, bn):
     if bn is None:
         scale = torch.ones(cout, device=dev, dtype=torch.float32)
         bias = conv.bias.detach().float() if conv.bias is not None else torch.zeros(cout, device=dev)
-        return scale, bias
+        return scale, bias.contiguous()
     var = bn.running_var.detach().float()
     mean = bn.running_mean.detach().float()
     gamma = bn.weight.detach().float() if bn.affine else torch.ones_like(var)
@@ -37,90 +46,273 @@ def fold_bn(conv, bn):
     scale = gamma / torch.sqrt(var + bn.eps)
     b0 = conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(mean)
     bias = (b0 - mean) * scale + beta
-    return scale, bias
+    return scale.contiguous(), bias.contiguous()
 
 
-def conv_supported(conv, x):
+def conv_kind(conv):
+    """'dense' | 'dw' | 'stem' | None (None: not covered by the HIP kernels -> torch, reported)."""
     k = conv.kernel_size
-    return (
-        x.is_cuda
-        and x.dtype in (torch.bfloat16, torch.float16)
-        and conv.groups == 1
-        and k[0] == k[1]
-        and k[0] in (1, 3)
-        and conv.stride[0] == conv.stride[1]
-        and conv.stride[0] in (1, 2)
-        and conv.padding[0] == k[0] // 2
-        and conv.padding[1] == k[0] // 2
-        and conv.dilation == (1, 1)
-        and conv.padding_mode == "zeros"
-    )
+    if not (k[0] == k[1] and k[0] in (1, 3) and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2)
+            and conv.padding == (k[0] // 2, k[0] // 2) and conv.dilation == (1, 1)
+            and conv.padding_mode == "zeros"):
+        return None
+    if conv.groups == 1:
+        if conv.in_channels <= 4:
+            return "stem" if (k[0] == 3 and conv.out_channels in (16, 32, 64)) else None
+        return "dense" if conv.in_channels % 8 == 0 else None
+    if conv.groups == conv.in_channels == conv.out_channels and k[0] == 3 and conv.in_channels % 8 == 0:
+        return "dw"
+    return None
 
 
-def conv_bn_act_native(x, weight, scale, bias, k, stride, act="none", out_dtype=None):
-    """y = act(conv(x, weight) * scale + bias) on the MFMA kernel.  x [N,Cin,H,W] NCHW bf16/f16."""
-    N.require_device(x, "conv_bn_act")
-    x = x.contiguous()
-    weight = weight.contiguous().to(x.dtype)
-    n, cin, h, w = (int(v) for v in x.shape)
-    cout = int(weight.shape[0])
-    ho = (h + 2 * (k // 2) - k) // stride + 1
-    wo = (w + 2 * (k // 2) - k) // stride + 1
-    out_dtype = out_dtype or x.dtype
-    y = torch.empty((n, cout, ho, wo), device=x.device, dtype=out_dtype)
-    dt = N.dtype_code(x)
+class ConvPack(object):
+    """Weights of one fused layer in kernel layout (built once per model/dtype)."""
+
+    __slots__ = ("kind", "w", "scale", "bias", "cin", "cout", "k", "stride", "groups", "act")
+
+    def __init__(self, conv, bn, act, dtype, extra_cout=None):
+        self.kind = conv_kind(conv)
+        if self.kind is None:
+            raise N.SsdkError("conv {} is not covered by the HIP kernels".format(conv))
+        scale, bias = fold_bn(conv, bn)
+        w = conv.weight.detach().float()
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.k, self.stride, self.groups, self.act = conv.kernel_size[0], conv.stride[0], conv.groups, act
+        if self.kind == "stem":  # fp32 weights with the BN scale folded in, KRSC
+            self.w = (w * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).contiguous()
+            self.scale = None
+        elif self.kind == "dw":  # [C,1,3,3] -> [3][3][C]
+            self.w = w[:, 0].permute(1, 2, 0).contiguous().to(dtype)
+            self.scale = scale
+        else:  # [Cout,Cin,kh,kw] -> [Cout][kh][kw][Cin]
+            self.w = w.permute(0, 2, 3, 1).contiguous().to(dtype)
+            self.scale = scale if bn is not None else None
+        self.bias = bias
+
+
+def pack_heads(loc_conv, conf_conv, dtype):
+    """loc | conf of one SSD level as ONE GEMM with N = A*(4+C): concatenated KRSC weights + biases."""
+    p = ConvPack(loc_conv, None, "none", dtype)
+    q = ConvPack(conf_conv, None, "none", dtype)
+    p.w = torch.cat([p.w, q.w], 0).contiguous()
+    p.bias = torch.cat([p.bias, q.bias], 0).contiguous()
+    p.cout = loc_conv.out_channels + conf_conv.out_channels
+    return p
+
+
+def _out_hw(h, w, k, stride):
+    pad = k // 2
+    return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+
+
+def fill_desc(d, x_ptr, n, h, w, pack, dtype_code, act, y_ptr, in_layout=N.NHWC, out_layout=N.NHWC,
+              residual_ptr=None, y2_ptr=None, split=None, act2=None):
+    d.x, d.w = x_ptr, pack.w.data_ptr()
+    d.scale = pack.scale.data_ptr() if pack.scale is not None else None
+    d.bias = pack.bias.data_ptr()
+    d.residual, d.y, d.y2 = residual_ptr, y_ptr, y2_ptr
+    d.N, d.Cin, d.H, d.W, d.Cout = n, pack.cin, h, w, pack.cout
+    d.k, d.stride, d.groups = pack.k, pack.stride, pack.groups
+    d.act = N.ACT[act]
+    d.act2 = N.ACT[act2 if act2 is not None else act]
+    d.split = split if split is not None else pack.cout
+    d.dtype, d.in_layout, d.out_layout = dtype_code, in_layout, out_layout
+    return d
+
+
+def conv_native(x, pack, act=None, residual=None, nchw_out=False, split=None, act2=None):
+    """One fused layer.  x: [N,C,H,W] tensor in channels_last memory (converted if not; the stem also takes
+    plain NCHW).  Returns a channels_last tensor, or NCHW tensor(s) when ``nchw_out`` (heads)."""
+    N.require_device(x, "conv")
+    act = pack.act if act is None else act
+    n, c, h, w = (int(v) for v in x.shape)
+    in_layout = N.NHWC
+    if pack.kind == "stem" and x.is_contiguous():
+        in_layout = N.NCHW
+    elif not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    ho, wo = _out_hw(h, w, pack.k, pack.stride)
+    y2 = None
+    if nchw_out:
+        if split is not None:
+            y = torch.empty((n, split, ho, wo), device=x.device, dtype=x.dtype)
+            y2 = torch.empty((n, pack.cout - split, ho, wo), device=x.device, dtype=x.dtype)
+        else:
+            y = torch.empty((n, pack.cout, ho, wo), device=x.device, dtype=x.dtype)
+    else:
+        y = torch.empty((n, pack.cout, ho, wo), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+    if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+        residual = residual.contiguous(memory_format=torch.channels_last)
+    d = fill_desc(N.ConvDesc(), x.data_ptr(), n, h, w, pack, N.dtype_code(x), act, y.data_ptr(), in_layout,
+                  N.NCHW if nchw_out else N.NHWC, residual.data_ptr() if residual is not None else None,
+                  y2.data_ptr() if y2 is not None else None, split, act2)
     with torch.cuda.device(x.device):
-        need = N.lib.ssdk_conv_workspace_bytes(n, cin, h, w, cout, k, stride, dt)
-        ws = N.workspace(x.device, need)
-        rc = N.lib.ssdk_conv_bn_act(
-            x.data_ptr(), weight.data_ptr(), scale.data_ptr() if scale is not None else None,
-            bias.data_ptr(), n, cin, h, w, cout, k, stride, N.ACT[act], dt, N.dtype_code(y),
-            y.data_ptr(), ws.data_ptr(), ws.numel(), N.stream_ptr(x.device))
-    N.check(rc, "conv_bn_act")
-    return y
+        rc = N.lib.ssdk_conv(ctypes.byref(d), None, 0, N.stream_ptr(x.device))
+    N.check(rc, "conv")
+    STATS["native_layers"] += 1
+    return (y, y2) if y2 is not None else y
+
+
+class _Arena(object):
+    """Greedy re-use of activation buffers inside one plan (the network is a chain: a buffer is free again
+    once its last reader has been recorded)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = []  # [tensor(uint8), free]
+
+    def get(self, nbytes):
+        best = None
+        for i, (t, free) in enumerate(self.bufs):
+            if free and t.numel() >= nbytes and (best is None or t.numel() < self.bufs[best][0].numel()):
+                best = i
+        if best is None:
+            self.bufs.append([torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device), False])
+            return len(self.bufs) - 1
+        self.bufs[best][1] = False
+        return best
+
+    def release(self, i):
+        if i is not None:
+            self.bufs[i][1] = True
+
+    def ptr(self, i):
+        return self.bufs[i][0].data_ptr()
+
+    def total_bytes(self):
+        return sum(t.numel() for t, _ in self.bufs)
+
+
+class ConvPlan(object):
+    """A recorded forward: descriptors + buffers.  ``record_*`` while walking the model once for a given
+    input shape; ``run(x)`` replays it with one C call.  Head outputs are allocated per call (they are
+    returned to the caller); all other activations live in the plan's arena."""
+
+    def __init__(self, device, dtype, in_shape):
+        self.device, self.dtype, self.in_shape = device, dtype, tuple(in_shape)
+        self.dtype_code = N._DTYPES[dtype]
+        self.es = 2
+        self.arena = _Arena(device)
+        self.layers = []   # dicts with everything fill_desc needs
+        self.heads = []    # (layer index, n, split, cout, ho, wo)
+        self.keep = []     # packs kept alive
+        self.descs = None
+        self.report = []
+
+    # a "value" is (buffer index or None for the external input, n, c, h, w)
+    def input_value(self):
+        n, c, h, w = self.in_shape
+        return (None, n, c, h, w)
+
+    def conv(self, val, pack, act=None, residual=None):
+        buf, n, c, h, w = val
+        assert c == pack.cin, (c, pack.cin)
+        ho, wo = _out_hw(h, w, pack.k, pack.stride)
+        out = self.arena.get(n * pack.cout * ho * wo * self.es)
+        self.layers.append(dict(x=buf, n=n, h=h, w=w, pack=pack, act=pack.act if act is None else act, y=out,
+                                res=residual[0] if residual is not None else None, nchw=False))
+        self.keep.append(pack)
+        return (out, n, pack.cout, ho, wo)
+
+    def head(self, val, pack, split, act2):
+        buf, n, c, h, w = val
+        ho, wo = _out_hw(h, w, pack.k, pack.stride)
+        self.layers.append(dict(x=buf, n=n, h=h, w=w, pack=pack, act="none", y=None, res=None, nchw=True,
+                                split=split, act2=act2))
+        self.heads.append((len(self.layers) - 1, n, split, pack.cout, ho, wo))
+        self.keep.append(pack)
+
+    def release(self, val):
+        self.arena.release(val[0])
+
+    def finalize(self):
+        self.descs = (N.ConvDesc * len(self.layers))()
+        for i, L in enumerate(self.layers):
+            x_ptr = self.arena.ptr(L["x"]) if L["x"] is not None else 0
+            y_ptr = self.arena.ptr(L["y"]) if L["y"] is not None else 0
+            res_ptr = self.arena.ptr(L["res"]) if L["res"] is not None else None
+            in_layout = N.NHWC
+            fill_desc(self.descs[i], x_ptr, L["n"], L["h"], L["w"], L["pack"], self.dtype_code, L["act"], y_ptr,
+                      in_layout, N.NCHW if L["nchw"] else N.NHWC, res_ptr, None, L.get("split"), L.get("act2"))
+        return self
+
+    def run(self, x):
+        """x: [N,3,H,W] (NCHW contiguous or channels_last).  Returns (loc tuple, conf tuple) NCHW."""
+        if tuple(x.shape) != self.in_shape or x.dtype != self.dtype:
+            raise N.SsdkError("plan was recorded for {} {}, got {} {}".format(self.in_shape, self.dtype,
+                                                                          tuple(x.shape), x.dtype))
+        first = self.descs[0]
+        if x.is_contiguous():
+            first.in_layout = N.NCHW if self.layers[0]["pack"].kind == "stem" else N.NHWC
+            if first.in_layout == N.NHWC:
+                x = x.contiguous(memory_format=torch.channels_last)
+        else:
+            x = x.contiguous(memory_format=torch.channels_last)
+            first.in_layout = N.NHWC
+        first.x = x.data_ptr()
+        loc, conf = [], []
+        for (li, n, split, cout, ho, wo) in self.heads:
+            l = torch.empty((n, split, ho, wo), device=self.device, dtype=self.dtype)
+            c = torch.empty((n, cout - split, ho, wo), device=self.device, dtype=self.dtype)
+            self.descs[li].y, self.descs[li].y2 = l.data_ptr(), c.data_ptr()
+            loc.append(l)
+            conf.append(c)
+        with torch.cuda.device(self.device):
+            rc = N.lib.ssdk_conv_sequence(self.descs, len(self.layers), None, 0, N.stream_ptr(self.device))
+        N.check(rc, "conv_sequence")
+        STATS["plan_runs"] += 1
+        STATS["native_layers"] += len(self.layers)
+        return tuple(loc), tuple(conf)
+
+
+def sequential_groups(seq):
+    """[Conv2d, (BatchNorm2d), (activation)]* -> [(conv, bn, act)], or None if the pattern does not match."""
+    mods = list(seq.children())
+    i, out = 0, []
+    while i < len(mods):
+        conv = mods[i]
+        if not isinstance(conv, nn.Conv2d):
+            return None
+        bn, act, j = None, "none", i + 1
+        if j < len(mods) and isinstance(mods[j], nn.BatchNorm2d):
+            bn, j = mods[j], j + 1
+        if j < len(mods) and type(mods[j]) in _ACT_OF:
+            act, j = _ACT_OF[type(mods[j])], j + 1
+        out.append((conv, bn, act))
+        i = j
+    return out
 
 
 class FusedSequentialMixin(object):
-    """nn.Sequential of [Conv2d, (BatchNorm2d), (activation)]* groups: in eval mode on a HIP device run
-    each group as one fused launch; otherwise (training / CPU / unsupported conv) the plain torch ops."""
+    """nn.Sequential of [Conv2d, (BatchNorm2d), (activation)]* groups: in eval mode on a HIP device each
+    group is one fused launch; in training mode (or with SSDK_FUSED_CONV=0) the plain torch modules run."""
 
-    def _groups(self):
-        mods = list(self.children())
-        i, out = 0, []
-        while i < len(mods):
-            conv = mods[i]
-            if not isinstance(conv, nn.Conv2d):
-                return None
-            bn, act, j = None, "none", i + 1
-            if j < len(mods) and isinstance(mods[j], nn.BatchNorm2d):
-                bn, j = mods[j], j + 1
-            if j < len(mods) and type(mods[j]) in _ACT_OF:
-                act, j = _ACT_OF[type(mods[j])], j + 1
-            out.append((conv, bn, act))
-            i = j
-        return out
+    def _packs(self, dtype):
+        cache = getattr(self, "_ssdk_packs", None)
+        if cache is None or cache[0] != dtype:
+            groups = sequential_groups(self)
+            packs = None
+            if groups is not None and all(conv_kind(c) is not None for c, _, _ in groups):
+                packs = [ConvPack(c, b, a, dtype) for c, b, a in groups]
+            cache = (dtype, packs)
+            object.__setattr__(self, "_ssdk_packs", cache)
+        return cache[1]
+
+    def train(self, mode=True):
+        object.__setattr__(self, "_ssdk_packs", None)  # weights may change: re-fold on the next eval forward
+        return nn.Sequential.train(self, mode)
+
+    def _apply(self, fn, *a, **kw):
+        object.__setattr__(self, "_ssdk_packs", None)
+        return nn.Sequential._apply(self, fn, *a, **kw)
 
     def forward(self, x):
-        if self.training or not fused_enabled() or not x.is_cuda:
+        if self.training or not fused_enabled() or not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16):
             return nn.Sequential.forward(self, x)
-        groups = self._groups()
-        if groups is None:
+        packs = self._packs(x.dtype)
+        if packs is None:
+            STATS["torch_fallback_layers"] += 1
             return nn.Sequential.forward(self, x)
-        for conv, bn, act in groups:
-            if conv_supported(conv, x):
-                scale, bias = fold_bn(conv, bn)
-                x = conv_bn_act_native(x, conv.weight.detach(), scale, bias, conv.kernel_size[0],
-                                       conv.stride[0], act)
-            else:
-                x = conv(x)
-                if bn is not None:
-                    x = bn(x)
-                if act == "relu":
-                    x = F.relu(x)
-                elif act == "relu6":
-                    x = F.relu6(x)
-                elif act == "silu":
-                    x = F.silu(x)
-                elif act == "sigmoid":
-                    x = torch.sigmoid(x)
+        for p in packs:
+            x = conv_native(x, p)
         return x

@@ -1,0 +1,90 @@
+"""Records the eval forward of a detector as a ``ConvPlan`` (fused_conv.py): every Conv-BN-activation
+group becomes one descriptor of the fused HIP kernels, block-level residual adds ride in the epilogue of
+the projecting 1x1 conv, and the loc | conf convs of each level become one split-output GEMM.
+
+Covered: MobileNet v1/v2 backbones (nets/mobilenet.py), the SSD extras and heads (ssds/ssd.py) -- i.e. the
+network of BASELINE configs 1, 2 and 4.  Anything else raises ``PlanUnsupported`` and the caller runs the
+module-by-module path instead (and says so in ``fused_conv.STATS``)."""
+import torch.nn as nn
+
+from .fused_conv import ConvPack, ConvPlan, conv_kind, pack_heads, sequential_groups
+
+
+class PlanUnsupported(Exception):
+    pass
+
+
+def flatten(module):
+    """nn.Sequential tree -> flat list of leaf modules in execution order."""
+    out = []
+    for m in module.children():
+        if isinstance(m, nn.Sequential):
+            out.extend(flatten(m))
+        else:
+            out.append(m)
+    return out
+
+
+def groups_of(module):
+    seq = nn.Sequential(*flatten(module))
+    groups = sequential_groups(seq)
+    if groups is None:
+        raise PlanUnsupported("not a Conv-BN-act chain: {}".format(type(module).__name__))
+    for conv, _, _ in groups:
+        if conv_kind(conv) is None:
+            raise PlanUnsupported("conv not covered by the HIP kernels: {}".format(conv))
+    return groups
+
+
+def record_chain(plan, val, module, residual=None, keep_input=False):
+    """Record the Conv-BN-act chain of ``module`` starting from value ``val``; the residual (if any, always
+    the chain input) is added in the epilogue of the LAST conv.  Intermediate buffers are released as soon
+    as they have been read; the chain input is released at the end unless ``keep_input``."""
+    groups = groups_of(module)
+    cur = val
+    for i, (conv, bn, act) in enumerate(groups):
+        pack = ConvPack(conv, bn, act, plan.dtype)
+        last = i == len(groups) - 1
+        nxt = plan.conv(cur, pack, residual=residual if last else None)
+        if cur is not val:
+            plan.release(cur)
+        cur = nxt
+    if not keep_input:
+        plan.release(val)
+    return cur
+
+
+def record_mobilenet(plan, val, net):
+    from ssds.modeling.nets.mobilenet import InvertedResidual, MobileNetEx
+
+    if not isinstance(net, MobileNetEx):
+        raise PlanUnsupported("backbone {} has no planner".format(type(net).__name__))
+    cur = record_chain(plan, val, net.conv1, keep_input=True)  # the image is not an arena buffer
+    outputs = []
+    for j in range(len(net.settings)):
+        level = j + 1
+        if level > max(net.outputs):
+            break
+        for blk in getattr(net, "layer{}".format(level)):
+            is_out_input = any(cur is o for o in outputs)
+            if isinstance(blk, InvertedResidual):
+                res = cur if blk.use_res_connect else None
+                cur = record_chain(plan, cur, blk.conv, residual=res, keep_input=is_out_input)
+            else:
+                cur = record_chain(plan, cur, blk, keep_input=is_out_input)
+        if level in net.outputs:
+            outputs.append(cur)
+    return outputs
+
+
+def build_ssd_plan(model, x):
+    """SSD (ssds/ssd.py) on a MobileNet backbone -> finalized ConvPlan for inputs shaped like ``x``."""
+    plan = ConvPlan(x.device, x.dtype, x.shape)
+    feats = record_mobilenet(plan, plan.input_value(), model.backbone)
+    for extra in model.extras:
+        feats.append(record_chain(plan, feats[-1], extra, keep_input=True))
+    for f, l, c in zip(feats, model.loc, model.conf):
+        if conv_kind(l) != "dense" or conv_kind(c) != "dense":
+            raise PlanUnsupported("head conv not covered")
+        plan.head(f, pack_heads(l, c, plan.dtype), split=l.out_channels, act2="sigmoid")
+    return plan.finalize()

@@ -23,6 +23,14 @@ class SharedHead(FusedSequentialMixin, nn.Sequential):
         layers += [nn.Conv2d(256, out_planes, 3, padding=1)]
         super(SharedHead, self).__init__(*layers)
 
+    def train(self, mode=True):
+        self.__dict__["_final_pack"] = None
+        return super(SharedHead, self).train(mode)
+
+    def _apply(self, fn, *a, **kw):
+        self.__dict__["_final_pack"] = None
+        return super(SharedHead, self)._apply(fn, *a, **kw)
+
     def forward(self, x, final_act="none"):
         for m in list(self.children())[:-1]:
             x = m(x)
@@ -31,11 +39,18 @@ class SharedHead(FusedSequentialMixin, nn.Sequential):
 
 
 def _final_conv(owner, conv, x, act):
-    from ssds.modeling.layers.fused_conv import conv_bn_act_native, conv_supported, fold_bn, fused_enabled
+    """Last conv of a tower: NCHW output (the layout decode consumes), bias + optional sigmoid fused."""
+    import torch
 
-    if not owner.training and fused_enabled() and conv_supported(conv, x):
-        _, bias = fold_bn(conv, None)
-        return conv_bn_act_native(x, conv.weight.detach(), None, bias, conv.kernel_size[0], conv.stride[0], act)
+    from ssds.modeling.layers import fused_conv as FC
+
+    if (not owner.training and FC.fused_enabled() and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)
+            and FC.conv_kind(conv) == "dense"):
+        cache = owner.__dict__.get("_final_pack")
+        if cache is None or cache[0] != x.dtype:
+            cache = (x.dtype, FC.ConvPack(conv, None, "none", x.dtype))
+            owner.__dict__["_final_pack"] = cache
+        return FC.conv_native(x, cache[1], act=act, nchw_out=True)
     y = conv(x)
     return y.sigmoid() if act == "sigmoid" else y
 

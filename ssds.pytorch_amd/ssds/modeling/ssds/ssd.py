@@ -11,8 +11,11 @@ the epilogue (``ssdk_conv_bn_act``); the extras (1x1 + 3x3/s2 Conv-BN-ReLU pairs
 with folded BatchNorm.  Training mode is ordinary autograd (MIOpen)."""
 import torch.nn as nn
 
-from ssds.modeling.layers.fused_conv import conv_bn_act_native, conv_supported, fold_bn, fused_enabled
+import torch
+
+from ssds.modeling.layers import fused_conv as FC
 from ssds.modeling.layers.layers_parser import parse_feature_layer
+from ssds.modeling.layers.planner import PlanUnsupported, build_ssd_plan
 
 from .ssdsbase import SSDSBase
 
@@ -42,23 +45,68 @@ class SSD(SSDSBase):
         for c in self.conf:
             c.apply(self.initialize_prior)
 
-    def _head(self, x, conv, act):
-        if not self.training and fused_enabled() and conv_supported(conv, x):
-            scale, bias = fold_bn(conv, None)
-            return conv_bn_act_native(x, conv.weight.detach(), None, bias, conv.kernel_size[0],
-                                      conv.stride[0], act)
-        y = conv(x)
-        return y.sigmoid() if act == "sigmoid" else y
+    # ---- MI355X inference engine: the whole eval forward as one recorded plan ---------------------------
+    def invalidate_plans(self):
+        """Drop recorded plans / folded weights (called automatically by train(), load_state_dict(), .to());
+        call it yourself after editing parameters in place."""
+        self._plans = {}
+        self._head_packs = None
+
+    def train(self, mode=True):
+        self.invalidate_plans()
+        return super(SSD, self).train(mode)
+
+    def _apply(self, fn, *a, **kw):
+        self.invalidate_plans()
+        return super(SSD, self)._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self.invalidate_plans()
+        return super(SSD, self).load_state_dict(*a, **kw)
+
+    def _native_ok(self, x):
+        return (not self.training and FC.fused_enabled() and x.is_cuda
+                and x.dtype in (torch.bfloat16, torch.float16))
+
+    def _plan(self, x):
+        plans = self.__dict__.setdefault("_plans", {})
+        key = (tuple(x.shape), x.dtype, x.device.index)
+        if key not in plans:
+            try:
+                with torch.no_grad():
+                    plans[key] = build_ssd_plan(self, x)
+            except PlanUnsupported as e:
+                plans[key] = str(e)
+        return plans[key]
+
+    def _heads_native(self, features):
+        packs = self.__dict__.get("_head_packs")
+        if packs is None or packs[0] != features[0].dtype:
+            packs = (features[0].dtype, [FC.pack_heads(l, c, features[0].dtype) for l, c in zip(self.loc, self.conf)])
+            self.__dict__["_head_packs"] = packs
+        loc, conf = [], []
+        for f, l, pk in zip(features, self.loc, packs[1]):
+            y, y2 = FC.conv_native(f, pk, act="none", nchw_out=True, split=l.out_channels, act2="sigmoid")
+            loc.append(y)
+            conf.append(y2)
+        return tuple(loc), tuple(conf)
 
     def forward(self, x):
+        if self._native_ok(x):
+            plan = self._plan(x)
+            if not isinstance(plan, str):
+                return plan.run(x)  # backbone + extras + heads: one C call, one launch per fused layer
         loc, conf = [], []
         features = self.backbone(x)
         for v in self.extras:  # each extra consumes the previous last feature (reference ssd.py:63-65)
             features.append(v(features[-1]))
-        conf_act = "none" if self.training else "sigmoid"
+        if self._native_ok(x) and all(FC.conv_kind(m) == "dense" for m in list(self.loc) + list(self.conf)):
+            return self._heads_native(features)  # backbone without a planner: fused heads only
         for f, l, c in zip(features, self.loc, self.conf):
-            loc.append(self._head(f, l, "none"))
-            conf.append(self._head(f, c, conf_act))
+            loc.append(l(f))
+            conf.append(c(f))
+        if not self.training:
+            conf = [c.sigmoid() for c in conf]
         return tuple(loc), tuple(conf)
 
     @staticmethod

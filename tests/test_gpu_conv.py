@@ -1,0 +1,200 @@
+"""Numerics of the fused conv kernels (MFMA implicit GEMM, depthwise, stem) against a plain PyTorch fp32
+reference of the same op on the same (bf16/f16-rounded) operands.  Tolerance: the kernels accumulate in
+fp32 and round once to the 16-bit output type, so |err| <= ~2^-8 relative to the output magnitude (bf16)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, conv, bn, act, residual=None):
+    import torch
+    import torch.nn.functional as F
+
+    w = conv.weight.detach().float().cpu()
+    y = F.conv2d(x.float().cpu(), w, None, conv.stride, conv.padding, 1, conv.groups)
+    from ssds.modeling.layers.fused_conv import fold_bn
+
+    scale, bias = fold_bn(conv, bn)
+    y = y * scale.cpu().view(1, -1, 1, 1) + bias.cpu().view(1, -1, 1, 1)
+    if act == "relu":
+        y = y.clamp(min=0)
+    elif act == "relu6":
+        y = y.clamp(0, 6)
+    elif act == "silu":
+        y = y * torch.sigmoid(y)
+    elif act == "sigmoid":
+        y = torch.sigmoid(y)
+    if residual is not None:
+        y = y.to(x.dtype).float() + residual.float().cpu()
+    return y
+
+
+def _check(got, want, dtype, what):
+    import torch
+
+    tol = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -9
+    g = got.float().cpu().contiguous()
+    scale = max(float(want.abs().max()), 1e-3)
+    err = float((g - want).abs().max())
+    assert g.shape == want.shape, (what, g.shape, want.shape)
+    assert err <= tol * scale + 1e-3, "%s: max err %.4g (scale %.3g)" % (what, err, scale)
+
+
+DENSE = [
+    # cin, cout, k, stride, h, w, n, act
+    (16, 96, 1, 1, 20, 24, 2, "relu6"),
+    (24, 144, 1, 1, 9, 7, 3, "relu6"),      # Cin not a multiple of the 32-wide k chunk
+    (96, 24, 1, 1, 17, 17, 2, "none"),      # small N tile
+    (144, 32, 1, 1, 8, 8, 1, "none"),
+    (32, 16, 1, 1, 33, 31, 2, "none"),      # N = 16 tile
+    (96, 504, 3, 1, 19, 19, 2, "none"),     # SSD head geometry (level 0 @300)
+    (320, 256, 1, 1, 10, 10, 2, "relu"),    # extras 1x1
+    (256, 512, 3, 2, 10, 10, 2, "relu"),    # extras 3x3 stride 2
+    (64, 64, 3, 1, 5, 5, 1, "silu"),
+    (128, 40, 3, 2, 7, 9, 2, "sigmoid"),    # odd sizes, Cout not a multiple of 16
+    (256, 256, 3, 1, 40, 40, 1, "relu"),    # FPN tower geometry
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,h,w,n,act", DENSE)
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+def test_dense_conv(cin, cout, k, stride, h, w, n, act, dtype_name):
+    import torch
+    import torch.nn as nn
+    from ssds.modeling.layers import fused_conv as FC
+
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    torch.manual_seed(cin * 131 + cout + k)
+    conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False)
+    bn = nn.BatchNorm2d(cout)
+    bn.running_mean.normal_(0, 0.2)
+    bn.running_var.uniform_(0.5, 1.5)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_(0, 0.2)
+    conv.weight.data = conv.weight.data.to(dtype).float()
+    x = torch.randn(n, cin, h, w).to(dtype)
+    conv, bn = conv.cuda(), bn.cuda()
+    pack = FC.ConvPack(conv, bn, act, dtype)
+    assert pack.kind == "dense"
+    y = FC.conv_native(x.cuda(), pack)
+    assert y.is_contiguous(memory_format=torch.channels_last) and y.dtype == dtype
+    _check(y, _ref(x, conv, bn, act), dtype, "dense nhwc")
+    y2 = FC.conv_native(x.cuda(), pack, nchw_out=True)  # NCHW epilogue (head layout)
+    assert y2.is_contiguous()
+    _check(y2, _ref(x, conv, bn, act), dtype, "dense nchw")
+
+
+def test_dense_conv_residual_and_split():
+    import torch
+    import torch.nn as nn
+    from ssds.modeling.layers import fused_conv as FC
+
+    dtype = torch.bfloat16
+    torch.manual_seed(5)
+    conv = nn.Conv2d(192, 32, 1, bias=False).cuda()
+    bn = nn.BatchNorm2d(32).cuda()
+    conv.weight.data = conv.weight.data.to(dtype).float()
+    x = torch.randn(2, 192, 13, 11).to(dtype)
+    res = torch.randn(2, 32, 13, 11).to(dtype)
+    y = FC.conv_native(x.cuda(), FC.ConvPack(conv, bn, "none", dtype), residual=res.cuda())
+    _check(y, _ref(x, conv, bn, "none", res), dtype, "residual")
+    # loc | conf of one level as ONE GEMM, two NCHW outputs, sigmoid only on the conf part
+    loc = nn.Conv2d(96, 24, 3, padding=1).cuda()
+    conf = nn.Conv2d(96, 480, 3, padding=1).cuda()
+    for m in (loc, conf):
+        m.weight.data = (m.weight.data * 3).to(dtype).float()
+        m.bias.data.normal_(0, 0.5)
+    f = torch.randn(3, 96, 19, 19).to(dtype)
+    pk = FC.pack_heads(loc, conf, dtype)
+    l, c = FC.conv_native(f.cuda(), pk, act="none", nchw_out=True, split=24, act2="sigmoid")
+    assert tuple(l.shape) == (3, 24, 19, 19) and tuple(c.shape) == (3, 480, 19, 19) and l.is_contiguous()
+    _check(l, _ref(f, loc, None, "none"), dtype, "split loc")
+    _check(c, _ref(f, conf, None, "sigmoid"), dtype, "split conf")
+
+
+@pytest.mark.parametrize("c,stride,h,w", [(32, 1, 16, 16), (96, 2, 17, 15), (144, 1, 9, 9), (576, 2, 8, 8),
+                                           (960, 1, 5, 3), (8, 2, 6, 6)])
+def test_depthwise(c, stride, h, w):
+    import torch
+    import torch.nn as nn
+    from ssds.modeling.layers import fused_conv as FC
+
+    dtype = torch.bfloat16
+    torch.manual_seed(c)
+    conv = nn.Conv2d(c, c, 3, stride, 1, groups=c, bias=False).cuda()
+    bn = nn.BatchNorm2d(c).cuda()
+    bn.running_mean.normal_(0, 0.2)
+    bn.running_var.uniform_(0.5, 1.5)
+    conv.weight.data = conv.weight.data.to(dtype).float()
+    x = torch.randn(2, c, h, w).to(dtype)
+    pack = FC.ConvPack(conv, bn, "relu6", dtype)
+    assert pack.kind == "dw"
+    _check(FC.conv_native(x.cuda(), pack), _ref(x, conv, bn, "relu6"), dtype, "depthwise")
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_stem(layout):
+    import torch
+    import torch.nn as nn
+    from ssds.modeling.layers import fused_conv as FC
+
+    dtype = torch.bfloat16
+    torch.manual_seed(1)
+    conv = nn.Conv2d(3, 32, 3, 2, 1, bias=False).cuda()
+    bn = nn.BatchNorm2d(32).cuda()
+    bn.running_mean.normal_(0, 0.2)
+    bn.running_var.uniform_(0.5, 1.5)
+    x = torch.rand(2, 3, 33, 30).to(dtype)
+    xin = x.cuda() if layout == "nchw" else x.cuda().contiguous(memory_format=torch.channels_last)
+    pack = FC.ConvPack(conv, bn, "relu6", dtype)
+    assert pack.kind == "stem"
+    # the stem keeps fp32 weights: reference with fp32 weights
+    _check(FC.conv_native(xin, pack), _ref(x, conv, bn, "relu6"), dtype, "stem " + layout)
+
+
+def test_ssd_mobilenetv2_plan_matches_torch():
+    """Whole network (BASELINE config 1 geometry): recorded plan on the HIP kernels vs the same module in
+    fp32 on torch.  bf16 activations through ~55 layers: compare with a loose relative tolerance, and the
+    confidence maps (what decode thresholds) tightly in absolute terms."""
+    import os
+    import torch
+    from ssds.core import config
+    from ssds.modeling import model_builder
+    from ssds.modeling.layers import fused_conv as FC
+
+    config.reset_cfg()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = config.cfg_from_file(os.path.join(root, "experiments", "cfgs", "ssd_mobilenetv2_300.yml"))
+    torch.manual_seed(3)
+    model = model_builder.create_model(cfg.MODEL).eval()
+    for m in model.modules():  # non-trivial BN statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.8, 1.2)
+    x = torch.rand(2, 3, 300, 300)
+    with torch.no_grad():
+        ref_loc, ref_conf = model.float()(x)  # CPU fp32 (torch path)
+    model = model.cuda().to(torch.bfloat16)
+    before = dict(FC.STATS)
+    with torch.no_grad():
+        loc, conf = model(x.cuda().to(torch.bfloat16))
+        loc2, conf2 = model(x.cuda().to(torch.bfloat16))
+    assert FC.STATS["plan_runs"] == before["plan_runs"] + 2, "the recorded plan did not run"
+    assert FC.STATS["torch_fallback_layers"] == before["torch_fallback_layers"]
+    for a, b in zip(conf, conf2):
+        assert torch.equal(a, b)
+    for l, rl, c, rc in zip(loc, ref_loc, conf, ref_conf):
+        assert l.shape == rl.shape and c.shape == rc.shape and l.is_contiguous() and c.is_contiguous()
+        assert float((c.float().cpu() - rc).abs().max()) < 2e-3   # sigmoid around 0.01
+        scale = max(float(rl.abs().max()), 1e-2)
+        assert float((l.float().cpu() - rl).abs().max()) < 0.05 * scale + 5e-3
+    # A/B switch: the torch path on the same device agrees too
+    os.environ["SSDK_FUSED_CONV"] = "0"
+    try:
+        with torch.no_grad():
+            tl, tc = model(x.cuda().to(torch.bfloat16))
+    finally:
+        os.environ["SSDK_FUSED_CONV"] = "1"
+    for c, t in zip(conf, tc):
+        assert float((c.float() - t.float()).abs().max()) < 4e-3
