@@ -1,0 +1,98 @@
+"""Training step of the anchor-based detectors under data parallelism -- the step body of the reference's
+``ssds/pipeline/pipeline_anchor_apex.py`` (ModelWithLossBasic :16-72, train loop :75-171) without Apex:
+
+    loc, conf = model(images)                      (bf16 autocast on the HIP device)
+    per level: extract_targets (ONE HIP launch for the whole batch), focal + smooth-L1, masks, sums
+    loss / sum_levels clamp(#foreground, 1)        (LOCAL normaliser, like the reference :69-71)
+    backward  -> bucketed RCCL all-reduce (mean) overlapped with backward (torch DDP)
+    optimizer.step()
+
+The reference skips a step on NaN/Inf with a per-rank ``continue`` before backward (:110-111, 126-127),
+which under DDP would leave the other ranks waiting in the all-reduce; here the decision is collective
+(one all-reduced flag) and taken after backward so every rank always joins the gradient all-reduce."""
+import time
+
+import torch
+import torch.distributed as dist
+
+from ssds.modeling.layers import box
+
+
+class ModelWithLossBasic(torch.nn.Module):
+    r"""model + target assignment + losses in one module so that DDP wraps the whole step
+    (reference pipeline_anchor_apex.py:16-72).  forward(images, targets, anchors) ->
+    (cls_loss, loc_loss, [cls_loss per level], [loc_loss per level])."""
+
+    def __init__(self, model, cls_criterion, loc_criterion, num_classes, match, center_sampling_radius):
+        super(ModelWithLossBasic, self).__init__()
+        self.model = model
+        self.cls_criterion = cls_criterion
+        self.loc_criterion = loc_criterion
+        self.num_classes = num_classes
+        self.match = match
+        self.center_radius = center_sampling_radius
+
+    def forward(self, images, targets, anchors):
+        loc, conf = self.model(images)
+        cls_losses, loc_losses, fg_targets = [], [], []
+        for j, (stride, anchor) in enumerate(anchors.items()):
+            size = conf[j].shape[-2:]
+            with torch.no_grad():
+                conf_target, loc_target, depth = box.extract_targets(
+                    targets, anchors, self.num_classes, stride, size, self.match, self.center_radius)
+            fg_targets.append((depth > 0).sum().float().clamp(min=1))
+
+            c = conf[j].view_as(conf_target).float()
+            cls_mask = (depth >= 0).expand_as(conf_target).float()
+            cls_loss = self.cls_criterion(c, conf_target, depth)
+            cls_losses.append((cls_mask * cls_loss).sum())
+
+            l = loc[j].view_as(loc_target).float()
+            loc_loss = self.loc_criterion(l, loc_target)
+            loc_mask = (depth > 0).expand_as(loc_loss).float()
+            loc_losses.append((loc_mask * loc_loss).sum())
+
+        fg_targets = torch.stack(fg_targets).sum()
+        cls_loss = torch.stack(cls_losses).sum() / fg_targets
+        loc_loss = torch.stack(loc_losses).sum() / fg_targets
+        return cls_loss, loc_loss, cls_losses, loc_losses
+
+
+def train_step(model_with_loss, images, targets, anchors, optimizer, autocast_dtype=torch.bfloat16):
+    """One optimisation step.  Returns (cls_loss, loc_loss, skipped): the losses stay on the device, the only
+    host synchronisation is the collective skip flag (the reference syncs 4-6 times per step,
+    pipeline_anchor_apex.py:114-126)."""
+    dev = images.device
+    optimizer.zero_grad(set_to_none=True)
+    use_autocast = dev.type == "cuda" and autocast_dtype is not None
+    with torch.autocast(device_type=dev.type, dtype=autocast_dtype, enabled=use_autocast):
+        cls_loss, loc_loss, _, _ = model_with_loss(images, targets, anchors)
+        total = cls_loss + loc_loss
+    bad = (~torch.isfinite(total.detach())).float()
+    # every rank runs backward so that the bucketed gradient all-reduce is always matched; a non-finite
+    # loss is replaced by zero gradients on that rank only if NOBODY may step
+    torch.nan_to_num(total, nan=0.0, posinf=0.0, neginf=0.0).backward()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)  # collective decision
+    skipped = bool(bad.item() > 0)  # the one host sync of the step (the reference has 4-6)
+    if not skipped:
+        optimizer.step()
+    return cls_loss.detach(), loc_loss.detach(), skipped
+
+
+def train_anchor_based_epoch(model, data_loader, optimizer, anchors, epoch, device, local_rank, log_every=20):
+    """Epoch loop (reference pipeline_anchor_apex.py:75-171 without tqdm/TensorBoard): stdout lines on
+    rank 0, losses fetched from the device only every ``log_every`` steps."""
+    model.train()
+    start = time.time()
+    n = len(data_loader)
+    for batch_idx, (images, targets) in enumerate(data_loader):
+        if images.device != device:
+            images, targets = images.to(device), targets.to(device)
+        if targets.dtype != torch.float:
+            targets = targets.float()
+        cls_loss, loc_loss, skipped = train_step(model, images, targets, anchors, optimizer)
+        if local_rank == 0 and ((batch_idx + 1) % log_every == 0 or batch_idx + 1 == n):
+            print("Train: epoch {} | {}/{} | cls_loss {:.4f} | loc_loss {:.4f} | lr {:.5f} | skipped {} | "
+                  "{:.1f}s".format(epoch, batch_idx + 1, n, float(cls_loss), float(loc_loss),
+                                   optimizer.param_groups[0]["lr"], int(skipped), time.time() - start))

@@ -1,0 +1,78 @@
+"""Training-step throughput (BASELINE config 4: SSD+MobileNetV2@512 DDP step, synthetic COCO-shaped targets).
+    python tools/bench_train.py --steps 10            (1 GPU)
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py
+Prints one JSON line on rank 0 (images/sec of the full step: fwd, target assignment, loss, bwd, all-reduce,
+optimizer)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "ssds.pytorch_amd")]
+import torch
+import torch.distributed as dist
+
+from ssds.core import config
+from ssds.dataset.synthetic import SyntheticDetectionLoader
+from ssds.modeling import model_builder
+from ssds.pipeline.pipeline_anchor_ddp import train_step
+from ssds.utils.train_ddp import Solver
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--channels-last", type=int, default=0)
+args = ap.parse_args()
+world = int(os.environ.get("WORLD_SIZE", "1"))
+rank = int(os.environ.get("RANK", "0"))
+lr = int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(lr)
+dev = torch.device("cuda", lr)
+if world > 1:
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", device_id=dev)
+cfg = config.cfg_from_file(os.path.join(ROOT, "experiments", "cfgs", "ssd_mobilenetv2_512.yml"))
+cfg.TRAIN.BATCH_SIZE = args.batch
+cfg.EXP_DIR = "/tmp/ssdk_bench_train"
+torch.manual_seed(1234)
+solver = Solver(cfg, lr, dev)
+if args.channels_last:
+    solver.model.to(memory_format=torch.channels_last)
+mwl = solver.wrap()
+mwl.train()
+inner = mwl.module.model if hasattr(mwl, "module") else mwl.model
+anchors = model_builder.create_anchors(cfg.MODEL, inner, cfg.MODEL.IMAGE_SIZE)
+mwl.train()
+loader = SyntheticDetectionLoader(args.batch, cfg.MODEL.IMAGE_SIZE, cfg.MODEL.NUM_CLASSES, 1, dev, seed=1234 + rank)
+images, targets = loader.batch()
+if args.channels_last:
+    images = images.contiguous(memory_format=torch.channels_last)
+
+
+def sync():
+    if world > 1:
+        dist.barrier(device_ids=[lr])
+    torch.cuda.synchronize()
+
+
+for _ in range(args.warmup):
+    train_step(mwl, images, targets, anchors, solver.optimizer)
+sync()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    c, l, sk = train_step(mwl, images, targets, anchors, solver.optimizer)
+sync()
+el = time.perf_counter() - t0
+if world > 1:
+    t = torch.tensor([el], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t)
+if rank == 0:
+    print(json.dumps({"metric": "images/sec (DDP training step) SSD-MobileNetV2@512", "value": round(world * args.batch * args.steps / el, 1),
+                      "n_gpus": world, "ms_per_step": round(el / args.steps * 1e3, 2), "batch_per_gpu": args.batch,
+                      "cls_loss": float(c), "loc_loss": float(l), "dtype": "bf16 autocast", "data": "synthetic"}))
+if world > 1:
+    dist.destroy_process_group()
