@@ -155,6 +155,36 @@ int ssdk_conv(const ssdk_conv_desc* desc, void* workspace, size_t workspace_byte
 /* a whole pre-planned network: descs[0..n) launched in order on `stream` (one host call per forward) */
 int ssdk_conv_sequence(const ssdk_conv_desc* descs, int n, void* workspace, size_t workspace_bytes,
                        void* stream);
+
+/* One MobileNetV2 inverted-residual block (the torchvision InvertedResidual behind nets/mobilenet.py:56,
+ * 84-89) as ONE kernel: 1x1 expand + BN + ReLU6 -> 3x3 depthwise (stride 1|2) + BN + ReLU6 -> 1x1 linear
+ * projection + BN (+ x), the expanded tensor never leaves the chip.  NHWC in/out, bf16 | f16.
+ * w_expand [Chid][Cin], w_dw [3][3][Chid], w_project [Cout][Chid] in the activation dtype; scale/bias fp32
+ * (folded BN).  Limits: Cin <= 160, Cout <= 320, channels % 8 == 0; residual needs stride 1, Cin == Cout. */
+typedef struct ssdk_mbconv_desc {
+  const void* x;
+  void* y;
+  const void* w_expand;
+  const float* scale_expand;
+  const float* bias_expand;
+  const void* w_dw;
+  const float* scale_dw;
+  const float* bias_dw;
+  const void* w_project;
+  const float* scale_project;
+  const float* bias_project;
+  int32_t N, H, W, Cin, Chid, Cout, stride, residual, dtype, reserved;
+} ssdk_mbconv_desc;
+int ssdk_mbconv(const ssdk_mbconv_desc* desc, void* stream);
+
+/* Plan executor: a recorded forward as a list of tagged ops, replayed with one host call. */
+enum { SSDK_OP_CONV = 0, SSDK_OP_MBCONV = 1 };
+typedef struct ssdk_op {
+  int32_t kind, reserved;
+  ssdk_conv_desc conv;
+  ssdk_mbconv_desc mb;
+} ssdk_op;
+int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t workspace_bytes, void* stream);
 /* convenience wrapper: dense conv, NHWC in/out, single output */
 int ssdk_conv_bn_act(const void* x, const void* w, const float* scale, const float* bias, int N,
                      int Cin, int H, int W, int Cout, int k, int stride, int act, int dtype,

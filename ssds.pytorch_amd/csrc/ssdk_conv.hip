@@ -652,6 +652,29 @@ extern "C" int ssdk_conv_sequence(const ssdk_conv_desc* descs, int n, void* work
   return SSDK_OK;
 }
 
+extern "C" int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!ops || n < 0) {
+    set_error("run_ops: bad arguments");
+    return SSDK_E_BADARG;
+  }
+  for (int i = 0; i < n; ++i) {
+    int rc;
+    if (ops[i].kind == SSDK_OP_CONV) rc = ssdk_conv(&ops[i].conv, workspace, workspace_bytes, stream);
+    else if (ops[i].kind == SSDK_OP_MBCONV) rc = ssdk_mbconv(&ops[i].mb, stream);
+    else {
+      set_error("unknown op kind %d", ops[i].kind);
+      rc = SSDK_E_BADARG;
+    }
+    if (rc) {
+      char msg[400];
+      snprintf(msg, sizeof(msg), "%s", ssdk_last_error());
+      set_error("run_ops: op %d of %d: %s", i, n, msg);
+      return rc;
+    }
+  }
+  return SSDK_OK;
+}
+
 extern "C" int ssdk_conv_bn_act(const void* x, const void* w, const float* scale, const float* bias, int N,
                                 int Cin, int H, int W, int Cout, int k, int stride, int act, int dtype,
                                 int out_dtype, void* y, void* workspace, size_t workspace_bytes, void* stream) {

@@ -50,6 +50,18 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class MbConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "x", "y", "w_expand", "scale_expand", "bias_expand", "w_dw", "scale_dw", "bias_dw", "w_project",
+        "scale_project", "bias_project")] + [(n, ctypes.c_int32) for n in (
+            "N", "H", "W", "Cin", "Chid", "Cout", "stride", "residual", "dtype", "reserved")]
+
+
+class Op(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("conv", ConvDesc), ("mb", MbConvDesc)]
+
+
+OP_CONV, OP_MBCONV = 0, 1
 NCHW, NHWC = 0, 1
 
 
@@ -86,6 +98,10 @@ def _load():
     lib.ssdk_conv.restype = i32
     lib.ssdk_conv_sequence.argtypes = [c.POINTER(ConvDesc), i32, vp, sz, vp]
     lib.ssdk_conv_sequence.restype = i32
+    lib.ssdk_mbconv.argtypes = [c.POINTER(MbConvDesc), vp]
+    lib.ssdk_mbconv.restype = i32
+    lib.ssdk_run_ops.argtypes = [c.POINTER(Op), i32, vp, sz, vp]
+    lib.ssdk_run_ops.restype = i32
     lib.ssdk_set_profiling.argtypes = [i32]
     lib.ssdk_get_timings.argtypes = [i32, c.POINTER(f32), i32]
     for name in ("ssdk_set_profiling", "ssdk_get_timings", "ssdk_device_info", "ssdk_generate_anchors", "ssdk_decode", "ssdk_nms",
@@ -98,7 +114,7 @@ lib = _load()
 EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_device_info", "ssdk_generate_anchors",
            "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
-           "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
+           "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 
 
 class SsdkError(RuntimeError):

@@ -100,6 +100,61 @@ def pack_heads(loc_conv, conf_conv, dtype):
     return p
 
 
+class MbPack(object):
+    """One MobileNetV2 inverted-residual block (expand 1x1 -> depthwise 3x3 -> project 1x1) packed for the
+    fused block kernel (csrc/ssdk_mbconv.hip).  ``groups`` = [(conv, bn, act)] x 3 as produced by
+    ``sequential_groups`` on the flattened block."""
+
+    __slots__ = ("e", "d", "p", "cin", "chid", "cout", "stride", "residual")
+
+    @staticmethod
+    def supported(groups, residual):
+        if len(groups) != 3:
+            return False
+        (ce, _, ae), (cd, _, ad), (cp, _, ap) = groups
+        return (conv_kind(ce) == "dense" and ce.kernel_size == (1, 1) and ce.stride == (1, 1) and ae == "relu6"
+                and conv_kind(cd) == "dw" and ad == "relu6"
+                and conv_kind(cp) == "dense" and cp.kernel_size == (1, 1) and cp.stride == (1, 1) and ap == "none"
+                and ce.in_channels <= 160 and cp.out_channels <= 320 and cp.out_channels % 8 == 0
+                and ce.out_channels == cd.in_channels == cp.in_channels
+                and all(bn is not None for _, bn, _ in groups)
+                and (not residual or (cd.stride[0] == 1 and ce.in_channels == cp.out_channels)))
+
+    def __init__(self, groups, residual, dtype):
+        (ce, be, _), (cd, bd, _), (cp, bp, _) = groups
+        self.e = ConvPack(ce, be, "relu6", dtype)
+        self.d = ConvPack(cd, bd, "relu6", dtype)
+        self.p = ConvPack(cp, bp, "none", dtype)
+        self.cin, self.chid, self.cout = ce.in_channels, ce.out_channels, cp.out_channels
+        self.stride, self.residual = cd.stride[0], bool(residual)
+
+
+def fill_mb_desc(d, x_ptr, y_ptr, n, h, w, pk, dtype_code):
+    d.x, d.y = x_ptr, y_ptr
+    d.w_expand, d.scale_expand, d.bias_expand = pk.e.w.data_ptr(), pk.e.scale.data_ptr(), pk.e.bias.data_ptr()
+    d.w_dw, d.scale_dw, d.bias_dw = pk.d.w.data_ptr(), pk.d.scale.data_ptr(), pk.d.bias.data_ptr()
+    d.w_project, d.scale_project, d.bias_project = pk.p.w.data_ptr(), pk.p.scale.data_ptr(), pk.p.bias.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Chid, d.Cout = n, h, w, pk.cin, pk.chid, pk.cout
+    d.stride, d.residual, d.dtype = pk.stride, int(pk.residual), dtype_code
+    return d
+
+
+def mbconv_native(x, pk):
+    """One fused inverted-residual block; x channels_last [N,Cin,H,W] -> channels_last [N,Cout,Ho,Wo]."""
+    N.require_device(x, "mbconv")
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    n, c, h, w = (int(v) for v in x.shape)
+    ho, wo = _out_hw(h, w, 3, pk.stride)
+    y = torch.empty((n, pk.cout, ho, wo), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+    d = fill_mb_desc(N.MbConvDesc(), x.data_ptr(), y.data_ptr(), n, h, w, pk, N.dtype_code(x))
+    with torch.cuda.device(x.device):
+        rc = N.lib.ssdk_mbconv(ctypes.byref(d), N.stream_ptr(x.device))
+    N.check(rc, "mbconv")
+    STATS["native_layers"] += 1
+    return y
+
+
 def _out_hw(h, w, k, stride):
     pad = k // 2
     return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
@@ -196,7 +251,7 @@ class ConvPlan(object):
         self.layers = []   # dicts with everything fill_desc needs
         self.heads = []    # (layer index, n, split, cout, ho, wo)
         self.keep = []     # packs kept alive
-        self.descs = None
+        self.ops = None
         self.report = []
 
     # a "value" is (buffer index or None for the external input, n, c, h, w)
@@ -214,6 +269,15 @@ class ConvPlan(object):
         self.keep.append(pack)
         return (out, n, pack.cout, ho, wo)
 
+    def mbconv(self, val, pk):
+        buf, n, c, h, w = val
+        assert c == pk.cin, (c, pk.cin)
+        ho, wo = _out_hw(h, w, 3, pk.stride)
+        out = self.arena.get(n * pk.cout * ho * wo * self.es)
+        self.layers.append(dict(kind="mb", x=buf, n=n, h=h, w=w, pack=pk, y=out))
+        self.keep.append(pk)
+        return (out, n, pk.cout, ho, wo)
+
     def head(self, val, pack, split, act2):
         buf, n, c, h, w = val
         ho, wo = _out_hw(h, w, pack.k, pack.stride)
@@ -226,14 +290,18 @@ class ConvPlan(object):
         self.arena.release(val[0])
 
     def finalize(self):
-        self.descs = (N.ConvDesc * len(self.layers))()
+        self.ops = (N.Op * len(self.layers))()
         for i, L in enumerate(self.layers):
             x_ptr = self.arena.ptr(L["x"]) if L["x"] is not None else 0
             y_ptr = self.arena.ptr(L["y"]) if L["y"] is not None else 0
+            if L.get("kind") == "mb":
+                self.ops[i].kind = N.OP_MBCONV
+                fill_mb_desc(self.ops[i].mb, x_ptr, y_ptr, L["n"], L["h"], L["w"], L["pack"], self.dtype_code)
+                continue
+            self.ops[i].kind = N.OP_CONV
             res_ptr = self.arena.ptr(L["res"]) if L["res"] is not None else None
-            in_layout = N.NHWC
-            fill_desc(self.descs[i], x_ptr, L["n"], L["h"], L["w"], L["pack"], self.dtype_code, L["act"], y_ptr,
-                      in_layout, N.NCHW if L["nchw"] else N.NHWC, res_ptr, None, L.get("split"), L.get("act2"))
+            fill_desc(self.ops[i].conv, x_ptr, L["n"], L["h"], L["w"], L["pack"], self.dtype_code, L["act"], y_ptr,
+                      N.NHWC, N.NCHW if L["nchw"] else N.NHWC, res_ptr, None, L.get("split"), L.get("act2"))
         return self
 
     def run(self, x):
@@ -241,7 +309,7 @@ class ConvPlan(object):
         if tuple(x.shape) != self.in_shape or x.dtype != self.dtype:
             raise N.SsdkError("plan was recorded for {} {}, got {} {}".format(self.in_shape, self.dtype,
                                                                           tuple(x.shape), x.dtype))
-        first = self.descs[0]
+        first = self.ops[0].conv
         if x.is_contiguous():
             first.in_layout = N.NCHW if self.layers[0]["pack"].kind == "stem" else N.NHWC
             if first.in_layout == N.NHWC:
@@ -254,12 +322,12 @@ class ConvPlan(object):
         for (li, n, split, cout, ho, wo) in self.heads:
             l = torch.empty((n, split, ho, wo), device=self.device, dtype=self.dtype)
             c = torch.empty((n, cout - split, ho, wo), device=self.device, dtype=self.dtype)
-            self.descs[li].y, self.descs[li].y2 = l.data_ptr(), c.data_ptr()
+            self.ops[li].conv.y, self.ops[li].conv.y2 = l.data_ptr(), c.data_ptr()
             loc.append(l)
             conf.append(c)
         with torch.cuda.device(self.device):
-            rc = N.lib.ssdk_conv_sequence(self.descs, len(self.layers), None, 0, N.stream_ptr(self.device))
-        N.check(rc, "conv_sequence")
+            rc = N.lib.ssdk_run_ops(self.ops, len(self.layers), None, 0, N.stream_ptr(self.device))
+        N.check(rc, "run_ops")
         STATS["plan_runs"] += 1
         STATS["native_layers"] += len(self.layers)
         return tuple(loc), tuple(conf)

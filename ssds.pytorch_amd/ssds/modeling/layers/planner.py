@@ -7,7 +7,9 @@ network of BASELINE configs 1, 2 and 4.  Anything else raises ``PlanUnsupported`
 module-by-module path instead (and says so in ``fused_conv.STATS``)."""
 import torch.nn as nn
 
-from .fused_conv import ConvPack, ConvPlan, conv_kind, pack_heads, sequential_groups
+import os
+
+from .fused_conv import ConvPack, ConvPlan, MbPack, conv_kind, pack_heads, sequential_groups
 
 
 class PlanUnsupported(Exception):
@@ -69,7 +71,14 @@ def record_mobilenet(plan, val, net):
             is_out_input = any(cur is o for o in outputs)
             if isinstance(blk, InvertedResidual):
                 res = cur if blk.use_res_connect else None
-                cur = record_chain(plan, cur, blk.conv, residual=res, keep_input=is_out_input)
+                groups = groups_of(blk.conv)
+                if os.environ.get("SSDK_FUSED_BLOCK", "1") != "0" and MbPack.supported(groups, blk.use_res_connect):
+                    nxt = plan.mbconv(cur, MbPack(groups, blk.use_res_connect, plan.dtype))  # whole block, 1 launch
+                    if not is_out_input:
+                        plan.release(cur)
+                    cur = nxt
+                else:
+                    cur = record_chain(plan, cur, blk.conv, residual=res, keep_input=is_out_input)
             else:
                 cur = record_chain(plan, cur, blk, keep_input=is_out_input)
         if level in net.outputs:

@@ -198,3 +198,48 @@ def test_ssd_mobilenetv2_plan_matches_torch():
         os.environ["SSDK_FUSED_CONV"] = "1"
     for c, t in zip(conf, tc):
         assert float((c.float() - t.float()).abs().max()) < 4e-3
+
+
+MB = [  # cin, cout, stride, h, w  (hidden = 6*cin)
+    (16, 24, 2, 32, 32), (24, 24, 1, 16, 16), (24, 32, 2, 19, 17), (32, 32, 1, 9, 11), (32, 64, 2, 16, 16),
+    (64, 64, 1, 8, 8), (64, 96, 1, 10, 6), (96, 96, 1, 8, 8), (96, 160, 2, 13, 13), (160, 160, 1, 5, 7),
+    (160, 320, 1, 8, 8),
+]
+
+
+@pytest.mark.parametrize("cin,cout,stride,h,w", MB)
+def test_fused_inverted_residual_block(cin, cout, stride, h, w):
+    """The one-kernel MobileNetV2 block against the torch fp32 block on bf16-rounded weights."""
+    import torch
+    from ssds.modeling.layers import fused_conv as FC
+    from ssds.modeling.layers.planner import groups_of
+    from ssds.modeling.nets.mobilenet import InvertedResidual
+
+    dtype = torch.bfloat16
+    torch.manual_seed(cin * 7 + cout + stride)
+    blk = InvertedResidual(cin, cout, stride, 6).eval()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data = (m.weight.data * 2).to(dtype).float()
+    x = torch.randn(3, cin, h, w).to(dtype)
+    with torch.no_grad():
+        # reference with the same intermediate roundings the kernel applies (bf16 E and D tensors)
+        y = x.float()
+        mods = list(blk.conv.children())
+        y = mods[0](y).to(dtype).float()
+        y = mods[1](y).to(dtype).float()
+        y = mods[3](mods[2](y))
+        if blk.use_res_connect:
+            y = y.to(dtype).float() + x.float()
+    blk = blk.cuda()
+    groups = groups_of(blk.conv)
+    assert FC.MbPack.supported(groups, blk.use_res_connect)
+    pk = FC.MbPack(groups, blk.use_res_connect, dtype)
+    got = FC.mbconv_native(x.cuda(), pk)
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    _check(got, y, dtype, "mbconv %d->%d s%d" % (cin, cout, stride))
