@@ -159,8 +159,11 @@ int ssdk_conv_sequence(const ssdk_conv_desc* descs, int n, void* workspace, size
 /* One MobileNetV2 inverted-residual block (the torchvision InvertedResidual behind nets/mobilenet.py:56,
  * 84-89) as ONE kernel: 1x1 expand + BN + ReLU6 -> 3x3 depthwise (stride 1|2) + BN + ReLU6 -> 1x1 linear
  * projection + BN (+ x), the expanded tensor never leaves the chip.  NHWC in/out, bf16 | f16.
- * w_expand [Chid][Cin], w_dw [3][3][Chid], w_project [Cout][Chid] in the activation dtype; scale/bias fp32
- * (folded BN).  Limits: Cin <= 160, Cout <= 320, channels % 8 == 0; residual needs stride 1, Cin == Cout. */
+ * The expanded and depthwise tensors are internal (LDS only) and held in fp16 whatever the model dtype:
+ *   w_expand [Chid][Cin] activation dtype, scale_expand / bias_expand fp32 [Chid] (folded BN);
+ *   w_dw fp16 [3][3][Chid] with the BN scale folded in, bias_dw fp16 [Chid];
+ *   w_project fp16 [Cout][Chid], scale_project / bias_project fp32 [Cout].
+ * Limits: Cin <= 160, Cout <= 320, channels % 8 == 0; residual needs stride 1, Cin == Cout. */
 typedef struct ssdk_mbconv_desc {
   const void* x;
   void* y;
@@ -168,8 +171,7 @@ typedef struct ssdk_mbconv_desc {
   const float* scale_expand;
   const float* bias_expand;
   const void* w_dw;
-  const float* scale_dw;
-  const float* bias_dw;
+  const void* bias_dw;
   const void* w_project;
   const float* scale_project;
   const float* bias_project;

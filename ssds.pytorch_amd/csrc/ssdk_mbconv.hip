@@ -27,18 +27,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct MbParams {
   const u16* x;
   u16* y;
-  const u16* we;  // [Chid][Cin]
-  const float* se;
+  const u16* we;    // [Chid][Cin], activation dtype
+  const float* se;  // [Chid] folded BN of the expand conv
   const float* be;
-  const u16* wd;  // [3][3][Chid]
-  const float* sd;
-  const float* bd;
-  const u16* wp;  // [Cout][Chid]
-  const float* sp;
+  const u16* wd;    // fp16 [3][3][Chid], BN scale folded in
+  const u16* bd;    // fp16 [Chid]
+  const u16* wp;    // fp16 [Cout][Chid]
+  const float* sp;  // [Cout]
   const float* bp;
   int N, H, W, Cin, Chid, Cout, Ho, Wo, residual;
   int tiles_x, tiles_y;
-  int xs;  // LDS row stride of sX in bytes
+  int xs;      // LDS row stride of sX (bytes)
+  int wes;     // LDS row stride of the staged We chunk (bytes)
+  int off_wp, off_wd, off_sb, wbuf;  // byte offsets inside / size of one staged weight buffer
 };
 
 template <int DT> __device__ __forceinline__ u32 mb_to16(float v) {
@@ -62,13 +63,23 @@ __device__ __forceinline__ f32x4 mb_mfma(const u32x4& a, const u32x4& b, f32x4 c
   else
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-__device__ __forceinline__ float relu6f(float v) { return v < 0.f ? 0.f : (v > 6.f ? 6.f : v); }
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+// NOTE: never __builtin_bit_cast straight from a vector-element lvalue (v[e]): clang reads element 0.
+__device__ __forceinline__ h2 as_h2(u32 w) { return __builtin_bit_cast(h2, w); }
+__device__ __forceinline__ u32 pk_relu6_f16(float a, float b) {  // clamp to [0,6], pack two halves
+  return __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(a, 0.f, 6.f),
+                                                            __builtin_amdgcn_fmed3f(b, 0.f, 6.f)));
+}
 
 constexpr int kMbThreads = 256;
 constexpr int HC = 32;       // hidden channels per chunk
-constexpr int ES = 80;       // LDS row stride (bytes) of sE / sD: 32 ch * 2 B + 16 B pad
+constexpr int ES = 80;       // LDS row stride (bytes) of sE / sD / staged Wp: 32 halves + 16 B pad
 constexpr int MAX_KS = 5;    // Cin <= 160
+constexpr int SB_BYTES = 128 + 128 + 64;  // se, be (fp32 x32), bd (fp16 x32)
 
+// E (expanded) and D (depthwise output) are INTERNAL tensors: they are kept in fp16 whatever the model
+// dtype (values are ReLU6-bounded, fp16 carries 3 more mantissa bits than bf16), so P2 runs on packed
+// fp16 math (v_pk_fma_f16: 2 channels per instruction) and P3 on the f16 MFMA with fp16 projection weights.
 template <int DT, int S, int NFO, int KSMAX>
 __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   constexpr int RW = 8 * S + (3 - S);          // 10 (s=1) or 17 (s=2) input columns / rows per tile
@@ -76,11 +87,14 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   constexpr int MF = (P + 15) / 16;            // m-frags of the expand GEMM
   constexpr int P16 = MF * 16;
   constexpr int MFW = (MF + 3) / 4;            // m-frags per wave (max)
+  constexpr int NPA = (32 * KSMAX * 4 + kMbThreads - 1) / kMbThreads;   // We pieces per thread
+  constexpr int NPB = (NFO * 16 * 4 + kMbThreads - 1) / kMbThreads;     // Wp pieces per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int XS = p.xs;
+  const int XS = p.xs, WES = p.wes;
   unsigned char* sX = smem;                                  // [P16][XS]
   unsigned char* sE = sX + (size_t)P16 * XS;                 // [P16][ES]
   unsigned char* sD = sE + (size_t)P16 * ES;                 // [64][ES]
+  unsigned char* sW = sD + 64 * ES;                          // 2 staged weight buffers
 
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u32 fr = lane & 15u, fg = lane >> 4;
@@ -93,10 +107,67 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
   const int Cin = p.Cin, Chid = p.Chid, Cout = p.Cout, H = p.H, W = p.W;
   const int KS = (Cin + 31) / 32;
+  const int cpr = Cin / 8;  // 16-byte pieces per pixel / per We row
 
+  // ---- weight staging: global (L2) -> registers one chunk ahead -> LDS -------------------------------
+  u32x4 ra[NPA], rb[NPB], rc;
+  auto load_w = [&](int hc0) {
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {  // We rows [hc0, hc0+32) x Cin
+      const int q = (int)tid + i * kMbThreads;
+      const int row = q / cpr, c = q % cpr;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < 32 && hc0 + row < Chid) v = *reinterpret_cast<const u32x4*>(p.we + (size_t)(hc0 + row) * Cin + c * 8);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {  // Wp rows [0, Cout) x hidden [hc0, hc0+32)
+      const int q = (int)tid + i * kMbThreads;
+      const int row = q >> 2, c = q & 3;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < Cout && hc0 + c * 8 < Chid) v = *reinterpret_cast<const u32x4*>(p.wp + (size_t)row * Chid + hc0 + c * 8);
+      rb[i] = v;
+    }
+    {  // 36 pieces of Wd, 8 + 8 of se / be, 4 of bd
+      const int q = (int)tid;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (q < 36) {
+        const int tap = q >> 2, c = q & 3;
+        if (hc0 + c * 8 < Chid) v = *reinterpret_cast<const u32x4*>(p.wd + (size_t)tap * Chid + hc0 + c * 8);
+      } else if (q < 52) {
+        const int c = (q - 36) & 7;
+        const float* src = (q < 44) ? p.se : p.be;
+        if (hc0 + c * 4 < Chid) v = *reinterpret_cast<const u32x4*>(src + hc0 + c * 4);
+      } else if (q < 56) {
+        const int c = q - 52;
+        if (hc0 + c * 8 < Chid) v = *reinterpret_cast<const u32x4*>(p.bd + hc0 + c * 8);
+      }
+      rc = v;
+    }
+  };
+  auto store_w = [&](int buf) {
+    unsigned char* w = sW + (size_t)buf * p.wbuf;
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+      const int q = (int)tid + i * kMbThreads;
+      const int row = q / cpr, c = q % cpr;
+      if (row < 32) *reinterpret_cast<u32x4*>(w + (size_t)row * WES + c * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+      const int q = (int)tid + i * kMbThreads;
+      if (q < NFO * 64) *reinterpret_cast<u32x4*>(w + p.off_wp + (size_t)(q >> 2) * ES + (q & 3) * 16) = rb[i];
+    }
+    {
+      const int q = (int)tid;
+      if (q < 36) *reinterpret_cast<u32x4*>(w + p.off_wd + q * 16) = rc;
+      else if (q < 56) *reinterpret_cast<u32x4*>(w + p.off_sb + (q - 36) * 16) = rc;
+    }
+  };
+
+  load_w(0);
   // ---- phase 0: input tile + halo -> sX (zeros outside the image and in the padding rows) -------------
   {
-    const int cpr = Cin / 8;  // 16-byte chunks per pixel
     const int total = P16 * cpr;
     const u16* xin = p.x + (size_t)n * H * W * Cin;
     for (int q = (int)tid; q < total; q += kMbThreads) {
@@ -110,6 +181,7 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
       *reinterpret_cast<u32x4*>(sX + (size_t)pix * XS + c * 16) = v;
     }
   }
+  store_w(0);
   // validity of the region pixels this lane produces in P1 (bit i: m-frag wave + 4*i)
   u32 pvalid = 0;
 #pragma unroll
@@ -130,113 +202,89 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   const u32 d_oy = d_px >> 3, d_ox = d_px & 7u;
 
   for (int c = 0; c < nchunks; ++c) {
-    const int hc0 = c * HC;
-    // weights of this chunk straight from global/L2 into fragment registers (issued first: their latency
-    // hides under the LDS reads / MFMAs of P1)
-    u32x4 wef[2][KSMAX];
+    const unsigned char* wcur = sW + (size_t)(c & 1) * p.wbuf;
+    if (c + 1 < nchunks) load_w((c + 1) * HC);  // next chunk's weights in flight under this chunk's work
+    // ---- P1: expand the region for channels [hc0, hc0+32) -> sE (fp16) -----------------------------
+    {
+      const f32x4 se0 = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + (fg * 4) * 4);
+      const f32x4 se1 = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + (16 + fg * 4) * 4);
+      const f32x4 be0 = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + 128 + (fg * 4) * 4);
+      const f32x4 be1 = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + 128 + (16 + fg * 4) * 4);
 #pragma unroll
-    for (int jf = 0; jf < 2; ++jf)
+      for (int i = 0; i < MFW; ++i) {
+        const int mf = (int)wave + 4 * i;
+        if (mf < MF) {  // wave-uniform
+          f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+          const unsigned char* xrow = sX + (size_t)(mf * 16 + (int)fr) * XS;
 #pragma unroll
-      for (int ks = 0; ks < KSMAX; ++ks) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        const int hc = hc0 + jf * 16 + (int)fr, k = ks * 32 + (int)fg * 8;
-        if (ks < KS && hc < Chid && k < Cin) v = *reinterpret_cast<const u32x4*>(p.we + (size_t)hc * Cin + k);
-        wef[jf][ks] = v;
-      }
-    u32x4 wpf[NFO];
-#pragma unroll
-    for (int j = 0; j < NFO; ++j) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      const int co = j * 16 + (int)fr, k = hc0 + (int)fg * 8;
-      if (co < Cout && k < Chid) v = *reinterpret_cast<const u32x4*>(p.wp + (size_t)co * Chid + k);
-      wpf[j] = v;
-    }
-    // ---- P1: expand the region for channels [hc0, hc0+32) -> sE -----------------------------------
-    float se4[2][4], be4[2][4];
-#pragma unroll
-    for (int jf = 0; jf < 2; ++jf)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int hc = hc0 + jf * 16 + (int)fg * 4 + r;
-        se4[jf][r] = hc < Chid ? p.se[hc] : 0.f;
-        be4[jf][r] = hc < Chid ? p.be[hc] : 0.f;
-      }
-#pragma unroll
-    for (int i = 0; i < MFW; ++i) {
-      const int mf = (int)wave + 4 * i;
-      if (mf < MF) {  // wave-uniform
-        f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
-        const unsigned char* xrow = sX + (size_t)(mf * 16 + (int)fr) * XS;
-#pragma unroll
-        for (int ks = 0; ks < KSMAX; ++ks) {
-          if (ks < KS) {
-            u32x4 xf = {0u, 0u, 0u, 0u};
-            const int k = ks * 32 + (int)fg * 8;
-            if (k < Cin) xf = *reinterpret_cast<const u32x4*>(xrow + k * 2);
-            e0 = mb_mfma<DT>(wef[0][ks], xf, e0);  // D[hc = fg*4+r][pixel = fr]
-            e1 = mb_mfma<DT>(wef[1][ks], xf, e1);
+          for (int ks = 0; ks < KSMAX; ++ks) {
+            if (ks < KS) {
+              u32x4 xf = {0u, 0u, 0u, 0u}, w0 = {0u, 0u, 0u, 0u}, w1 = {0u, 0u, 0u, 0u};
+              const int k = ks * 32 + (int)fg * 8;
+              if (k < Cin) {
+                xf = *reinterpret_cast<const u32x4*>(xrow + k * 2);
+                w0 = *reinterpret_cast<const u32x4*>(wcur + (size_t)fr * WES + k * 2);
+                w1 = *reinterpret_cast<const u32x4*>(wcur + (size_t)(16 + fr) * WES + k * 2);
+              }
+              e0 = mb_mfma<DT>(w0, xf, e0);  // D[hc = fg*4+r][pixel = fr]
+              e1 = mb_mfma<DT>(w1, xf, e1);
+            }
           }
+          uint2 o0 = make_uint2(0u, 0u), o1 = make_uint2(0u, 0u);
+          if ((pvalid >> i) & 1u) {
+            o0.x = pk_relu6_f16(fmaf(e0[0], se0[0], be0[0]), fmaf(e0[1], se0[1], be0[1]));
+            o0.y = pk_relu6_f16(fmaf(e0[2], se0[2], be0[2]), fmaf(e0[3], se0[3], be0[3]));
+            o1.x = pk_relu6_f16(fmaf(e1[0], se1[0], be1[0]), fmaf(e1[1], se1[1], be1[1]));
+            o1.y = pk_relu6_f16(fmaf(e1[2], se1[2], be1[2]), fmaf(e1[3], se1[3], be1[3]));
+          }
+          unsigned char* erow = sE + (size_t)(mf * 16 + (int)fr) * ES;
+          *reinterpret_cast<uint2*>(erow + (fg * 4) * 2) = o0;
+          *reinterpret_cast<uint2*>(erow + (16 + fg * 4) * 2) = o1;
         }
-        const bool ok = (pvalid >> i) & 1u;
-        u32 h0[4], h1[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          h0[r] = ok ? mb_to16<DT>(relu6f(e0[r] * se4[0][r] + be4[0][r])) : 0u;
-          h1[r] = ok ? mb_to16<DT>(relu6f(e1[r] * se4[1][r] + be4[1][r])) : 0u;
-        }
-        unsigned char* erow = sE + (size_t)(mf * 16 + (int)fr) * ES;
-        *reinterpret_cast<uint2*>(erow + (fg * 4) * 2) = make_uint2(h0[0] | (h0[1] << 16), h0[2] | (h0[3] << 16));
-        *reinterpret_cast<uint2*>(erow + (16 + fg * 4) * 2) = make_uint2(h1[0] | (h1[1] << 16), h1[2] | (h1[3] << 16));
       }
     }
     __syncthreads();
-    // ---- P2: depthwise 3x3 stride S on the chunk -> sD ------------------------------------------------
+    // ---- P2: depthwise 3x3 stride S on the chunk, packed fp16 -> sD ------------------------------------
     {
-      float acc[8];
+      h2 acc[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-      const int ch = hc0 + (int)d_cg * 8;
-      const bool chok = ch < Chid;
+      for (int e = 0; e < 4; ++e) acc[e] = h2{(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const int rp = ((int)d_oy * S + ky) * RW + (int)d_ox * S + kx;
           const u32x4 ev = *reinterpret_cast<const u32x4*>(sE + (size_t)rp * ES + d_cg * 16);
-          u32x4 wv = {0u, 0u, 0u, 0u};
-          if (chok) wv = *reinterpret_cast<const u32x4*>(p.wd + (size_t)(ky * 3 + kx) * Chid + ch);
+          const u32x4 wv = *reinterpret_cast<const u32x4*>(wcur + p.off_wd + (ky * 3 + kx) * 64 + d_cg * 16);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc[2 * e] = fmaf(mb_from16<DT>(ev[e] & 0xffffu), mb_from16<DT>(wv[e] & 0xffffu), acc[2 * e]);
-            acc[2 * e + 1] = fmaf(mb_from16<DT>(ev[e] >> 16), mb_from16<DT>(wv[e] >> 16), acc[2 * e + 1]);
-          }
+          for (int e = 0; e < 4; ++e)
+            acc[e] = __builtin_elementwise_fma(as_h2(ev[e]), as_h2(wv[e]), acc[e]);
         }
+      const u32x4 bv = *reinterpret_cast<const u32x4*>(wcur + p.off_sb + 256 + d_cg * 16);
+      const h2 zero = {(_Float16)0.f, (_Float16)0.f}, six = {(_Float16)6.f, (_Float16)6.f};
       u32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float s0 = 0.f, b0 = 0.f, s1 = 0.f, b1 = 0.f;
-        if (chok) {
-          s0 = p.sd[ch + 2 * e];
-          b0 = p.bd[ch + 2 * e];
-          s1 = p.sd[ch + 2 * e + 1];
-          b1 = p.bd[ch + 2 * e + 1];
-        }
-        const u32 lo = chok ? mb_to16<DT>(relu6f(acc[2 * e] * s0 + b0)) : 0u;
-        const u32 hi = chok ? mb_to16<DT>(relu6f(acc[2 * e + 1] * s1 + b1)) : 0u;
-        o[e] = lo | (hi << 16);
+        h2 v = acc[e] + as_h2(bv[e]);
+        v = __builtin_elementwise_min(__builtin_elementwise_max(v, zero), six);
+        o[e] = __builtin_bit_cast(u32, v);
       }
       *reinterpret_cast<u32x4*>(sD + (size_t)d_px * ES + d_cg * 16) = o;
     }
+    if (c + 1 < nchunks) store_w((c + 1) & 1);  // visible to the next chunk's P1 after the barrier below
     __syncthreads();
-    // ---- P3: project: wave w owns output pixels [16w, 16w+16) x all Cout ----------------------------
+    // ---- P3: project: wave w owns output pixels [16w, 16w+16) x all Cout (f16 MFMA) -----------------
     {
       const u32x4 df = *reinterpret_cast<const u32x4*>(sD + (size_t)(wave * 16 + fr) * ES + fg * 16);
 #pragma unroll
-      for (int j = 0; j < NFO; ++j) yacc[j] = mb_mfma<DT>(wpf[j], df, yacc[j]);  // D[co = fg*4+r][px = fr]
+      for (int j = 0; j < NFO; ++j) {
+        const u32x4 wf = *reinterpret_cast<const u32x4*>(wcur + p.off_wp + (size_t)(j * 16 + fr) * ES + fg * 16);
+        yacc[j] = mb_mfma<SSDK_F16>(wf, df, yacc[j]);  // D[co = fg*4+r][px = fr]
+      }
     }
-    // (no barrier here: the next chunk's P1 writes sE, which P2 of this chunk finished reading before the
-    //  barrier above; its P2 writes sD only after the barrier that follows its P1, i.e. after every wave
-    //  has passed this P3)
+    // No barrier here.  The next chunk's P1 writes sE (P2 of this chunk finished reading it before the
+    // barrier above) and reads the OTHER weight buffer; its P2 writes sD and its store_w overwrites THIS
+    // weight buffer only after the barrier that follows its P1, i.e. after every wave has passed this P3.
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------
@@ -249,12 +297,11 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
     for (int j = 0; j < NFO; ++j) {
       const int co = j * 16 + (int)fg * 4;
       if (co < Cout) {  // Cout is a multiple of 8, so 4-channel groups are all-or-nothing
+        const f32x4 sp4 = *reinterpret_cast<const f32x4*>(p.sp + co);
+        const f32x4 bp4 = *reinterpret_cast<const f32x4*>(p.bp + co);
         u32 h[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = yacc[j][r] * p.sp[co + r] + p.bp[co + r];
-          h[r] = mb_to16<DT>(v);
-        }
+        for (int r = 0; r < 4; ++r) h[r] = mb_to16<DT>(fmaf(yacc[j][r], sp4[r], bp4[r]));
         if (p.residual) {
           const uint2 xv = *reinterpret_cast<const uint2*>(xres + co * 2);
           const u32 xr[4] = {xv.x & 0xffffu, xv.x >> 16, xv.y & 0xffffu, xv.y >> 16};
@@ -296,7 +343,7 @@ using namespace ssdk;
 extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!d || !d->x || !d->y || !d->w_expand || !d->w_dw || !d->w_project || !d->scale_expand || !d->bias_expand ||
-      !d->scale_dw || !d->bias_dw || !d->scale_project || !d->bias_project) {
+      !d->bias_dw || !d->scale_project || !d->bias_project) {
     set_error("mbconv: null pointer");
     return SSDK_E_BADARG;
   }
@@ -318,8 +365,7 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   p.se = d->scale_expand;
   p.be = d->bias_expand;
   p.wd = (const u16*)d->w_dw;
-  p.sd = d->scale_dw;
-  p.bd = d->bias_dw;
+  p.bd = (const u16*)d->bias_dw;
   p.wp = (const u16*)d->w_project;
   p.sp = d->scale_project;
   p.bp = d->bias_project;
@@ -338,7 +384,14 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   p.xs = d->Cin * 2 + ((cpr % 2 == 0) ? 16 : 0);  // odd number of 16-byte slots per row
   const int rw = d->stride == 1 ? 10 : 17;
   const int p16 = ((rw * rw + 15) / 16) * 16;
-  const size_t lds = (size_t)p16 * p.xs + (size_t)p16 * ES + 64 * ES;
+  const int nfo_t = (d->Cout + 15) / 16;
+  const int nfo_inst = nfo_t <= 2 ? 2 : nfo_t <= 4 ? 4 : nfo_t <= 6 ? 6 : nfo_t <= 10 ? 10 : 20;
+  p.wes = p.xs;
+  p.off_wp = 32 * p.wes;
+  p.off_wd = p.off_wp + nfo_inst * 16 * ES;
+  p.off_sb = p.off_wd + 9 * 64;
+  p.wbuf = p.off_sb + SB_BYTES;
+  const size_t lds = (size_t)p16 * p.xs + (size_t)p16 * ES + 64 * ES + 2 * (size_t)p.wbuf;
   if (lds > 160 * 1024) {
     set_error("mbconv: tile needs %zu bytes of LDS", lds);
     return SSDK_E_BADARG;

@@ -52,7 +52,7 @@ class ConvDesc(ctypes.Structure):
 
 class MbConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
-        "x", "y", "w_expand", "scale_expand", "bias_expand", "w_dw", "scale_dw", "bias_dw", "w_project",
+        "x", "y", "w_expand", "scale_expand", "bias_expand", "w_dw", "bias_dw", "w_project",
         "scale_project", "bias_project")] + [(n, ctypes.c_int32) for n in (
             "N", "H", "W", "Cin", "Chid", "Cout", "stride", "residual", "dtype", "reserved")]
 

@@ -105,7 +105,7 @@ class MbPack(object):
     fused block kernel (csrc/ssdk_mbconv.hip).  ``groups`` = [(conv, bn, act)] x 3 as produced by
     ``sequential_groups`` on the flattened block."""
 
-    __slots__ = ("e", "d", "p", "cin", "chid", "cout", "stride", "residual")
+    __slots__ = ("e", "d", "p", "wd", "bd", "wp", "cin", "chid", "cout", "stride", "residual")
 
     @staticmethod
     def supported(groups, residual):
@@ -127,13 +127,19 @@ class MbPack(object):
         self.p = ConvPack(cp, bp, "none", dtype)
         self.cin, self.chid, self.cout = ce.in_channels, ce.out_channels, cp.out_channels
         self.stride, self.residual = cd.stride[0], bool(residual)
+        # internal tensors are fp16: depthwise weights with the BN scale folded in, fp16 bias, fp16 projection
+        sd, bdv = fold_bn(cd, bd)
+        wdw = cd.weight.detach().float()[:, 0] * sd.view(-1, 1, 1)  # [C,3,3]
+        self.wd = wdw.permute(1, 2, 0).contiguous().to(torch.float16)
+        self.bd = bdv.to(torch.float16).contiguous()
+        self.wp = cp.weight.detach().float().permute(0, 2, 3, 1).contiguous().to(torch.float16)
 
 
 def fill_mb_desc(d, x_ptr, y_ptr, n, h, w, pk, dtype_code):
     d.x, d.y = x_ptr, y_ptr
     d.w_expand, d.scale_expand, d.bias_expand = pk.e.w.data_ptr(), pk.e.scale.data_ptr(), pk.e.bias.data_ptr()
-    d.w_dw, d.scale_dw, d.bias_dw = pk.d.w.data_ptr(), pk.d.scale.data_ptr(), pk.d.bias.data_ptr()
-    d.w_project, d.scale_project, d.bias_project = pk.p.w.data_ptr(), pk.p.scale.data_ptr(), pk.p.bias.data_ptr()
+    d.w_dw, d.bias_dw = pk.wd.data_ptr(), pk.bd.data_ptr()
+    d.w_project, d.scale_project, d.bias_project = pk.wp.data_ptr(), pk.p.scale.data_ptr(), pk.p.bias.data_ptr()
     d.N, d.H, d.W, d.Cin, d.Chid, d.Cout = n, h, w, pk.cin, pk.chid, pk.cout
     d.stride, d.residual, d.dtype = pk.stride, int(pk.residual), dtype_code
     return d
