@@ -135,31 +135,43 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
   }
   constexpr int B_PER = (BN * 4 + kConvThreads - 1) / kConvThreads;  // chunks of B per thread
   const int KK = p.k * p.k;
+  long w_base[B_PER];
+  bool w_ok[B_PER];
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const u32 row = lr + i * 64;
+    w_ok[i] = row < (u32)BN && n0 + row < (u32)p.Cout;
+    w_base[i] = (long)(n0 + row) * KK * Cin;
+  }
 
+  // k-tiles are visited tap-major, channel-chunk-minor; the running state below replaces the per-tile
+  // divisions (kt / cin_chunks, kpos / k ...) that used to cost ~90 VALU + ~90 SALU per k-step.
+  int t_kpos = 0, t_ky = 0, t_kx = 0, t_cc = 0;
   u32x4 ra[2], rb[B_PER];
-  auto load_tile = [&](int kt) {
-    const int kpos = kt / p.cin_chunks;
-    const int ci = (kt % p.cin_chunks) * BK + (int)lc * 8;
-    const int ky = kpos / p.k, kx = kpos % p.k;
+  auto load_tile = [&]() {  // loads the tile of the current state, then advances the state
+    const int ci = t_cc * BK + (int)lc * 8;
     const bool cok = ci < Cin;
+    const int tap_ci = (t_ky * W + t_kx) * Cin + ci;
+    const int w_ci = t_kpos * Cin + ci;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (cok && ((a_mask[i] >> kpos) & 1u)) {
-        const long off = a_base[i] + ((long)ky * W + kx) * Cin + ci;
-        v = *reinterpret_cast<const u32x4*>((const u16*)p.x + off);
-      }
+      if (cok && ((a_mask[i] >> t_kpos) & 1u)) v = *reinterpret_cast<const u32x4*>((const u16*)p.x + (a_base[i] + tap_ci));
       ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
-      const u32 row = lr + i * 64;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < (u32)BN && n0 + row < (u32)p.Cout && cok) {
-        const long off = ((long)(n0 + row) * KK + kpos) * Cin + ci;
-        v = *reinterpret_cast<const u32x4*>((const u16*)p.w + off);
-      }
+      if (w_ok[i] && cok) v = *reinterpret_cast<const u32x4*>((const u16*)p.w + (w_base[i] + w_ci));
       rb[i] = v;
+    }
+    if (++t_cc == p.cin_chunks) {
+      t_cc = 0;
+      ++t_kpos;
+      if (++t_kx == p.k) {
+        t_kx = 0;
+        ++t_ky;
+      }
     }
   };
   auto store_tile = [&](int buf) {
@@ -184,13 +196,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const u32 fr = lane & 15u, fg = lane >> 4;
-  load_tile(0);
+  load_tile();
   store_tile(0);
   __syncthreads();
   const int KT = p.KT;
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < KT) load_tile(kt + 1);  // global loads in flight while the MFMAs run
+    if (kt + 1 < KT) load_tile();  // global loads in flight while the MFMAs run
     const unsigned char* sA = smem + cur * STAGE;
     const unsigned char* sB = sA + A_BYTES;
     u32x4 fa[FM], fb[FN];

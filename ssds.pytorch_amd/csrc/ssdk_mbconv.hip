@@ -40,6 +40,9 @@ struct MbParams {
   int xs;      // LDS row stride of sX (bytes)
   int wes;     // LDS row stride of the staged We chunk (bytes)
   int off_wp, off_wd, off_sb, wbuf;  // byte offsets inside / size of one staged weight buffer
+  // stem mode: x is the [N,Cimg,Himg,Wimg] image (1 = NCHW, 2 = NHWC); the "expand" GEMM is the 3x3/s2 stem
+  // conv on an im2col image of the tile built in LDS (K = 9*Cimg <= 32); H, W are the stem-output grid.
+  int stem, Himg, Wimg, Cimg;
 };
 
 template <int DT> __device__ __forceinline__ u32 mb_to16(float v) {
@@ -71,7 +74,8 @@ __device__ __forceinline__ u32 pk_relu6_f16(float a, float b) {  // clamp to [0,
                                                             __builtin_amdgcn_fmed3f(b, 0.f, 6.f)));
 }
 
-constexpr int kMbThreads = 256;
+constexpr int kMbThreads = 512;  // 8 waves: two per SIMD, so LDS / MFMA latencies of one wave hide under the other
+constexpr int kMbWaves = kMbThreads / 64;
 constexpr int HC = 32;       // hidden channels per chunk
 constexpr int ES = 80;       // LDS row stride (bytes) of sE / sD / staged Wp: 32 halves + 16 B pad
 constexpr int MAX_KS = 5;    // Cin <= 160
@@ -80,15 +84,17 @@ constexpr int SB_BYTES = 128 + 128 + 64;  // se, be (fp32 x32), bd (fp16 x32)
 // E (expanded) and D (depthwise output) are INTERNAL tensors: they are kept in fp16 whatever the model
 // dtype (values are ReLU6-bounded, fp16 carries 3 more mantissa bits than bf16), so P2 runs on packed
 // fp16 math (v_pk_fma_f16: 2 channels per instruction) and P3 on the f16 MFMA with fp16 projection weights.
-template <int DT, int S, int NFO, int KSMAX>
+template <int DT, int S, int NFO, int KSMAX, bool STEM = false>
 __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   constexpr int RW = 8 * S + (3 - S);          // 10 (s=1) or 17 (s=2) input columns / rows per tile
   constexpr int P = RW * RW;                   // region pixels
   constexpr int MF = (P + 15) / 16;            // m-frags of the expand GEMM
   constexpr int P16 = MF * 16;
-  constexpr int MFW = (MF + 3) / 4;            // m-frags per wave (max)
+  constexpr int MFW = (MF + kMbWaves - 1) / kMbWaves;                   // m-frags per wave (max)
   constexpr int NPA = (32 * KSMAX * 4 + kMbThreads - 1) / kMbThreads;   // We pieces per thread
   constexpr int NPB = (NFO * 16 * 4 + kMbThreads - 1) / kMbThreads;     // Wp pieces per thread
+  constexpr int NFH = NFO / 2;                                          // projection n-frags per wave
+  static_assert(NFO % 2 == 0, "NFO must be even");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int XS = p.xs, WES = p.wes;
   unsigned char* sX = smem;                                  // [P16][XS]
@@ -109,65 +115,104 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   const int KS = (Cin + 31) / 32;
   const int cpr = Cin / 8;  // 16-byte pieces per pixel / per We row
 
-  // ---- weight staging: global (L2) -> registers one chunk ahead -> LDS -------------------------------
+  // ---- weight staging: global (L2) -> registers one chunk ahead -> LDS.  The piece -> (row, column)
+  //      decode is chunk-invariant and done once here. ---------------------------------------------------
+  int a_src[NPA], a_dst[NPA], a_row[NPA];
+#pragma unroll
+  for (int i = 0; i < NPA; ++i) {
+    const int q = (int)tid + i * kMbThreads;
+    const int row = q / cpr, c = q % cpr;
+    a_row[i] = row < 32 ? row : (1 << 30);   // invalid pieces never pass "hc0 + row < Chid"
+    a_src[i] = row * Cin + c * 8;
+    a_dst[i] = row * WES + c * 16;
+  }
+  int b_src[NPB], b_dst[NPB], b_c8[NPB];
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int q = (int)tid + i * kMbThreads;
+    const int row = q >> 2, c = q & 3;
+    b_c8[i] = (row < Cout && q < NFO * 64) ? c * 8 : (1 << 30);
+    b_src[i] = row * Chid + c * 8;
+    b_dst[i] = (q < NFO * 64) ? p.off_wp + row * ES + c * 16 : -1;
+  }
+  // tid < 56: one piece of {Wd (36), se (8), be (8), bd (4)}
+  const u16* c_src = nullptr;
+  int c_mul = 0, c_off = 1 << 30, c_dst = -1;
+  if (tid < 36) {
+    c_src = p.wd + (size_t)(tid >> 2) * Chid + (tid & 3) * 8;
+    c_mul = 1;
+    c_off = (int)(tid & 3) * 8;
+    c_dst = p.off_wd + (int)tid * 16;
+  } else if (tid < 52) {
+    const int c = ((int)tid - 36) & 7;
+    c_src = reinterpret_cast<const u16*>((tid < 44 ? p.se : p.be) + c * 4);
+    c_mul = 2;  // fp32: two u16 per element
+    c_off = c * 4;
+    c_dst = p.off_sb + ((int)tid - 36) * 16;
+  } else if (tid < 56) {
+    const int c = (int)tid - 52;
+    c_src = p.bd + c * 8;
+    c_mul = 1;
+    c_off = c * 8;
+    c_dst = p.off_sb + 256 + c * 16;
+  }
   u32x4 ra[NPA], rb[NPB], rc;
   auto load_w = [&](int hc0) {
 #pragma unroll
-    for (int i = 0; i < NPA; ++i) {  // We rows [hc0, hc0+32) x Cin
-      const int q = (int)tid + i * kMbThreads;
-      const int row = q / cpr, c = q % cpr;
+    for (int i = 0; i < NPA; ++i) {
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < 32 && hc0 + row < Chid) v = *reinterpret_cast<const u32x4*>(p.we + (size_t)(hc0 + row) * Cin + c * 8);
+      if (hc0 + a_row[i] < Chid) v = *reinterpret_cast<const u32x4*>(p.we + (size_t)hc0 * Cin + a_src[i]);
       ra[i] = v;
     }
 #pragma unroll
-    for (int i = 0; i < NPB; ++i) {  // Wp rows [0, Cout) x hidden [hc0, hc0+32)
-      const int q = (int)tid + i * kMbThreads;
-      const int row = q >> 2, c = q & 3;
+    for (int i = 0; i < NPB; ++i) {
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < Cout && hc0 + c * 8 < Chid) v = *reinterpret_cast<const u32x4*>(p.wp + (size_t)row * Chid + hc0 + c * 8);
+      if (hc0 + b_c8[i] < Chid) v = *reinterpret_cast<const u32x4*>(p.wp + hc0 + b_src[i]);
       rb[i] = v;
     }
-    {  // 36 pieces of Wd, 8 + 8 of se / be, 4 of bd
-      const int q = (int)tid;
+    {
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (q < 36) {
-        const int tap = q >> 2, c = q & 3;
-        if (hc0 + c * 8 < Chid) v = *reinterpret_cast<const u32x4*>(p.wd + (size_t)tap * Chid + hc0 + c * 8);
-      } else if (q < 52) {
-        const int c = (q - 36) & 7;
-        const float* src = (q < 44) ? p.se : p.be;
-        if (hc0 + c * 4 < Chid) v = *reinterpret_cast<const u32x4*>(src + hc0 + c * 4);
-      } else if (q < 56) {
-        const int c = q - 52;
-        if (hc0 + c * 8 < Chid) v = *reinterpret_cast<const u32x4*>(p.bd + hc0 + c * 8);
-      }
+      if (hc0 + c_off < Chid) v = *reinterpret_cast<const u32x4*>(c_src + (size_t)hc0 * c_mul);
       rc = v;
     }
   };
   auto store_w = [&](int buf) {
     unsigned char* w = sW + (size_t)buf * p.wbuf;
 #pragma unroll
-    for (int i = 0; i < NPA; ++i) {
-      const int q = (int)tid + i * kMbThreads;
-      const int row = q / cpr, c = q % cpr;
-      if (row < 32) *reinterpret_cast<u32x4*>(w + (size_t)row * WES + c * 16) = ra[i];
-    }
+    for (int i = 0; i < NPA; ++i)
+      if (a_row[i] < 32) *reinterpret_cast<u32x4*>(w + a_dst[i]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < NPB; ++i) {
-      const int q = (int)tid + i * kMbThreads;
-      if (q < NFO * 64) *reinterpret_cast<u32x4*>(w + p.off_wp + (size_t)(q >> 2) * ES + (q & 3) * 16) = rb[i];
-    }
-    {
-      const int q = (int)tid;
-      if (q < 36) *reinterpret_cast<u32x4*>(w + p.off_wd + q * 16) = rc;
-      else if (q < 56) *reinterpret_cast<u32x4*>(w + p.off_sb + (q - 36) * 16) = rc;
-    }
+    for (int i = 0; i < NPB; ++i)
+      if (b_dst[i] >= 0) *reinterpret_cast<u32x4*>(w + b_dst[i]) = rb[i];
+    if (c_dst >= 0) *reinterpret_cast<u32x4*>(w + c_dst) = rc;
   };
 
   load_w(0);
   // ---- phase 0: input tile + halo -> sX (zeros outside the image and in the padding rows) -------------
-  {
+  if constexpr (STEM) {
+    // im2col of the image patch: row = region pixel (stem-output coordinates), k = (ky*3+kx)*Cimg + ci.
+    // One item = (pixel, tap): Cimg 2-byte loads + Cimg 2-byte LDS writes; the tap-8 item also zeroes the
+    // K padding of its row.  Every byte of every row is written (zeros for padding / outside the image).
+    const int Ci = p.Cimg, Hi = p.Himg, Wi = p.Wimg;
+    const u16* img = p.x + (size_t)n * Ci * Hi * Wi;
+    const size_t cstride = p.stem == 1 ? (size_t)Hi * Wi : 1, pstride = p.stem == 1 ? 1 : (size_t)Ci;
+    for (int q = (int)tid; q < P16 * 9; q += kMbThreads) {
+      const int pix = q / 9, tap = q % 9;
+      bool ok = false;
+      size_t off = 0;
+      if (pix < P) {
+        const int soy = iy0 + pix / RW, sox = ix0 + pix % RW;
+        const int iy = 2 * soy + tap / 3 - 1, ix = 2 * sox + tap % 3 - 1;
+        ok = (unsigned)soy < (unsigned)H && (unsigned)sox < (unsigned)W && (unsigned)iy < (unsigned)Hi &&
+             (unsigned)ix < (unsigned)Wi;
+        off = ((size_t)iy * Wi + ix) * pstride;
+      }
+      u16* row = reinterpret_cast<u16*>(sX + (size_t)pix * XS);
+      for (int ci = 0; ci < Ci; ++ci) row[tap * Ci + ci] = ok ? img[off + ci * cstride] : (u16)0;
+      if (tap == 8)
+        for (int k = 9 * Ci; k < 32; ++k) row[k] = 0;
+    }
+  } else {
     const int total = P16 * cpr;
     const u16* xin = p.x + (size_t)n * H * W * Cin;
     for (int q = (int)tid; q < total; q += kMbThreads) {
@@ -182,24 +227,25 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
     }
   }
   store_w(0);
-  // validity of the region pixels this lane produces in P1 (bit i: m-frag wave + 4*i)
+  // validity of the region pixels this lane produces in P1 (bit i: m-frag wave + 8*i)
   u32 pvalid = 0;
 #pragma unroll
   for (int i = 0; i < MFW; ++i) {
-    const int pix = ((int)wave + 4 * i) * 16 + (int)fr;
+    const int pix = ((int)wave + kMbWaves * i) * 16 + (int)fr;
     if (pix < P) {
       const int iy = iy0 + pix / RW, ix = ix0 + pix % RW;
       if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) pvalid |= 1u << i;
     }
   }
-  f32x4 yacc[NFO];
+  f32x4 yacc[NFH];
 #pragma unroll
-  for (int j = 0; j < NFO; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < NFH; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
   const int nchunks = (Chid + HC - 1) / HC;
-  const u32 d_px = tid >> 2, d_cg = tid & 3u;      // P2 role: output pixel, 8-channel group
+  const u32 d_px = tid >> 3, d_cg = tid & 7u;      // P2 role: output pixel, 4-channel group
   const u32 d_oy = d_px >> 3, d_ox = d_px & 7u;
+  const u32 m_fr = wave & 3u, n_half = wave >> 2;  // P3 role: pixel frag, interleaved half of the n-frags
 
   for (int c = 0; c < nchunks; ++c) {
     const unsigned char* wcur = sW + (size_t)(c & 1) * p.wbuf;
@@ -212,7 +258,7 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
       const f32x4 be1 = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + 128 + (16 + fg * 4) * 4);
 #pragma unroll
       for (int i = 0; i < MFW; ++i) {
-        const int mf = (int)wave + 4 * i;
+        const int mf = (int)wave + kMbWaves * i;
         if (mf < MF) {  // wave-uniform
           f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
           const unsigned char* xrow = sX + (size_t)(mf * 16 + (int)fr) * XS;
@@ -244,42 +290,36 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
       }
     }
     __syncthreads();
-    // ---- P2: depthwise 3x3 stride S on the chunk, packed fp16 -> sD ------------------------------------
+    // ---- P2: depthwise 3x3 stride S on the chunk, packed fp16 (4 channels per lane) -> sD ----------------
     {
-      h2 acc[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = h2{(_Float16)0.f, (_Float16)0.f};
+      h2 acc0 = {(_Float16)0.f, (_Float16)0.f}, acc1 = acc0;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const int rp = ((int)d_oy * S + ky) * RW + (int)d_ox * S + kx;
-          const u32x4 ev = *reinterpret_cast<const u32x4*>(sE + (size_t)rp * ES + d_cg * 16);
-          const u32x4 wv = *reinterpret_cast<const u32x4*>(wcur + p.off_wd + (ky * 3 + kx) * 64 + d_cg * 16);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acc[e] = __builtin_elementwise_fma(as_h2(ev[e]), as_h2(wv[e]), acc[e]);
+          const uint2 ev = *reinterpret_cast<const uint2*>(sE + (size_t)rp * ES + d_cg * 8);
+          const uint2 wv = *reinterpret_cast<const uint2*>(wcur + p.off_wd + (ky * 3 + kx) * 64 + d_cg * 8);
+          acc0 = __builtin_elementwise_fma(as_h2(ev.x), as_h2(wv.x), acc0);
+          acc1 = __builtin_elementwise_fma(as_h2(ev.y), as_h2(wv.y), acc1);
         }
-      const u32x4 bv = *reinterpret_cast<const u32x4*>(wcur + p.off_sb + 256 + d_cg * 16);
+      const uint2 bv = *reinterpret_cast<const uint2*>(wcur + p.off_sb + 256 + d_cg * 8);
       const h2 zero = {(_Float16)0.f, (_Float16)0.f}, six = {(_Float16)6.f, (_Float16)6.f};
-      u32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        h2 v = acc[e] + as_h2(bv[e]);
-        v = __builtin_elementwise_min(__builtin_elementwise_max(v, zero), six);
-        o[e] = __builtin_bit_cast(u32, v);
-      }
-      *reinterpret_cast<u32x4*>(sD + (size_t)d_px * ES + d_cg * 16) = o;
+      const h2 v0 = __builtin_elementwise_min(__builtin_elementwise_max(acc0 + as_h2(bv.x), zero), six);
+      const h2 v1 = __builtin_elementwise_min(__builtin_elementwise_max(acc1 + as_h2(bv.y), zero), six);
+      *reinterpret_cast<uint2*>(sD + (size_t)d_px * ES + d_cg * 8) =
+          make_uint2(__builtin_bit_cast(u32, v0), __builtin_bit_cast(u32, v1));
     }
     if (c + 1 < nchunks) store_w((c + 1) & 1);  // visible to the next chunk's P1 after the barrier below
     __syncthreads();
-    // ---- P3: project: wave w owns output pixels [16w, 16w+16) x all Cout (f16 MFMA) -----------------
+    // ---- P3: project: wave (m_fr, n_half) owns pixels [16 m_fr, +16) x n-frags n_half, n_half+2, ... ----
     {
-      const u32x4 df = *reinterpret_cast<const u32x4*>(sD + (size_t)(wave * 16 + fr) * ES + fg * 16);
+      const u32x4 df = *reinterpret_cast<const u32x4*>(sD + (size_t)(m_fr * 16 + fr) * ES + fg * 16);
 #pragma unroll
-      for (int j = 0; j < NFO; ++j) {
+      for (int jj = 0; jj < NFH; ++jj) {
+        const int j = (int)n_half + 2 * jj;
         const u32x4 wf = *reinterpret_cast<const u32x4*>(wcur + p.off_wp + (size_t)(j * 16 + fr) * ES + fg * 16);
-        yacc[j] = mb_mfma<SSDK_F16>(wf, df, yacc[j]);  // D[co = fg*4+r][px = fr]
+        yacc[jj] = mb_mfma<SSDK_F16>(wf, df, yacc[jj]);  // D[co = fg*4+r][px = fr]
       }
     }
     // No barrier here.  The next chunk's P1 writes sE (P2 of this chunk finished reading it before the
@@ -288,20 +328,20 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------
-  const int q = (int)wave * 16 + (int)fr;  // output pixel inside the tile
+  const int q = (int)m_fr * 16 + (int)fr;  // output pixel inside the tile
   const int oy = oy0 + (q >> 3), ox = ox0 + (q & 7);
   if (oy < p.Ho && ox < p.Wo) {
     u16* yrow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * Cout;
     const unsigned char* xres = sX + (size_t)(((q >> 3) * S + 1) * RW + (q & 7) * S + 1) * XS;
 #pragma unroll
-    for (int j = 0; j < NFO; ++j) {
-      const int co = j * 16 + (int)fg * 4;
+    for (int jj = 0; jj < NFH; ++jj) {
+      const int co = ((int)n_half + 2 * jj) * 16 + (int)fg * 4;
       if (co < Cout) {  // Cout is a multiple of 8, so 4-channel groups are all-or-nothing
         const f32x4 sp4 = *reinterpret_cast<const f32x4*>(p.sp + co);
         const f32x4 bp4 = *reinterpret_cast<const f32x4*>(p.bp + co);
         u32 h[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = mb_to16<DT>(fmaf(yacc[j][r], sp4[r], bp4[r]));
+        for (int r = 0; r < 4; ++r) h[r] = mb_to16<DT>(fmaf(yacc[jj][r], sp4[r], bp4[r]));
         if (p.residual) {
           const uint2 xv = *reinterpret_cast<const uint2*>(xres + co * 2);
           const u32 xr[4] = {xv.x & 0xffffu, xv.x >> 16, xv.y & 0xffffu, xv.y >> 16};
@@ -314,17 +354,22 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   }
 }
 
-template <int DT, int S, int NFO, int KSMAX>
+template <int DT, int S, int NFO, int KSMAX, bool STEM = false>
 static void launch_one(const MbParams& p, size_t lds, unsigned grid, hipStream_t stream) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<DT, S, NFO, KSMAX>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<DT, S, NFO, KSMAX, STEM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((mbconv_kernel<DT, S, NFO, KSMAX>), dim3(grid), dim3(kMbThreads), lds, stream, p);
+  hipLaunchKernelGGL((mbconv_kernel<DT, S, NFO, KSMAX, STEM>), dim3(grid), dim3(kMbThreads), lds, stream, p);
 }
 
 // (k-steps of the expand GEMM, n-frags of the projection) pairs of the MobileNetV2 family get their own
 // instantiation (register budget = occupancy); everything else runs on the most general one.
 template <int DT, int S>
 static int launch_mb(const MbParams& p, int ks, int nfo, size_t lds, unsigned grid, hipStream_t stream) {
+  if (p.stem) {
+    if (nfo <= 2) launch_one<DT, S, 2, 1, true>(p, lds, grid, stream);
+    else launch_one<DT, S, 4, 1, true>(p, lds, grid, stream);
+    return check_launch("mbconv_kernel(stem)");
+  }
   if (ks <= 1 && nfo <= 2) launch_one<DT, S, 2, 1>(p, lds, grid, stream);
   else if (ks <= 1 && nfo <= 4) launch_one<DT, S, 4, 1>(p, lds, grid, stream);
   else if (ks <= 2 && nfo <= 4) launch_one<DT, S, 4, 2>(p, lds, grid, stream);
@@ -351,9 +396,14 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
     set_error("mbconv: dtype must be bf16 or f16");
     return SSDK_E_BADARG;
   }
-  if (d->N < 1 || d->H < 1 || d->W < 1 || (d->stride != 1 && d->stride != 2) || d->Cin < 8 || (d->Cin % 8) ||
-      d->Cin > 32 * MAX_KS || (d->Chid % 8) || d->Chid < 8 || (d->Cout % 8) || d->Cout < 8 || d->Cout > 320 ||
-      (d->residual && (d->stride != 1 || d->Cin != d->Cout))) {
+  const int stem = d->stem;
+  if (stem && (stem < 1 || stem > 2 || d->Cin < 1 || 9 * d->Cin > 32 || d->residual || d->Cout > 64)) {
+    set_error("mbconv(stem): needs 9*Cin <= 32, no residual, Cout <= 64 (Cin=%d Cout=%d)", d->Cin, d->Cout);
+    return SSDK_E_BADARG;
+  }
+  if (d->N < 1 || d->H < 1 || d->W < 1 || (d->stride != 1 && d->stride != 2) ||
+      (!stem && (d->Cin < 8 || (d->Cin % 8) || d->Cin > 32 * MAX_KS)) || (d->Chid % 8) || d->Chid < 8 ||
+      (d->Cout % 8) || d->Cout < 8 || d->Cout > 320 || (d->residual && (d->stride != 1 || d->Cin != d->Cout))) {
     set_error("mbconv: unsupported geometry Cin=%d Chid=%d Cout=%d stride=%d residual=%d (Cin<=160, Cout<=320, "
               "channels %% 8 == 0)", d->Cin, d->Chid, d->Cout, d->stride, d->residual);
     return SSDK_E_BADARG;
@@ -373,15 +423,24 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   p.H = d->H;
   p.W = d->W;
   p.Cin = d->Cin;
+  p.stem = stem;
+  p.Himg = d->H;
+  p.Wimg = d->W;
+  p.Cimg = d->Cin;
+  if (stem) {  // the block's grid is the stem conv's output (3x3, stride 2, pad 1); K padded to 32
+    p.H = (d->H + 2 - 3) / 2 + 1;
+    p.W = (d->W + 2 - 3) / 2 + 1;
+    p.Cin = 32;
+  }
   p.Chid = d->Chid;
   p.Cout = d->Cout;
-  p.Ho = (d->H + 2 - 3) / d->stride + 1;
-  p.Wo = (d->W + 2 - 3) / d->stride + 1;
+  p.Ho = (p.H + 2 - 3) / d->stride + 1;
+  p.Wo = (p.W + 2 - 3) / d->stride + 1;
   p.residual = d->residual;
   p.tiles_x = (p.Wo + 7) / 8;
   p.tiles_y = (p.Ho + 7) / 8;
-  const int cpr = d->Cin / 8;
-  p.xs = d->Cin * 2 + ((cpr % 2 == 0) ? 16 : 0);  // odd number of 16-byte slots per row
+  const int cpr = p.Cin / 8;
+  p.xs = p.Cin * 2 + ((cpr % 2 == 0) ? 16 : 0);  // odd number of 16-byte slots per row
   const int rw = d->stride == 1 ? 10 : 17;
   const int p16 = ((rw * rw + 15) / 16) * 16;
   const int nfo_t = (d->Cout + 15) / 16;
@@ -397,7 +456,7 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
     return SSDK_E_BADARG;
   }
   const unsigned grid = (unsigned)((long)d->N * p.tiles_x * p.tiles_y);
-  const int nfo = (d->Cout + 15) / 16, ks = (d->Cin + 31) / 32;
+  const int nfo = (d->Cout + 15) / 16, ks = (p.Cin + 31) / 32;
   if (d->dtype == SSDK_BF16)
     return d->stride == 1 ? launch_mb<SSDK_BF16, 1>(p, ks, nfo, lds, grid, stream)
                           : launch_mb<SSDK_BF16, 2>(p, ks, nfo, lds, grid, stream);

@@ -54,7 +54,7 @@ class MbConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "x", "y", "w_expand", "scale_expand", "bias_expand", "w_dw", "bias_dw", "w_project",
         "scale_project", "bias_project")] + [(n, ctypes.c_int32) for n in (
-            "N", "H", "W", "Cin", "Chid", "Cout", "stride", "residual", "dtype", "reserved")]
+            "N", "H", "W", "Cin", "Chid", "Cout", "stride", "residual", "dtype", "stem")]
 
 
 class Op(ctypes.Structure):

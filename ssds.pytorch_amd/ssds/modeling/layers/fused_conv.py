@@ -105,7 +105,7 @@ class MbPack(object):
     fused block kernel (csrc/ssdk_mbconv.hip).  ``groups`` = [(conv, bn, act)] x 3 as produced by
     ``sequential_groups`` on the flattened block."""
 
-    __slots__ = ("e", "d", "p", "wd", "bd", "wp", "cin", "chid", "cout", "stride", "residual")
+    __slots__ = ("e", "d", "p", "we", "wd", "bd", "wp", "cin", "chid", "cout", "stride", "residual", "stem")
 
     @staticmethod
     def supported(groups, residual):
@@ -120,13 +120,44 @@ class MbPack(object):
                 and all(bn is not None for _, bn, _ in groups)
                 and (not residual or (cd.stride[0] == 1 and ce.in_channels == cp.out_channels)))
 
-    def __init__(self, groups, residual, dtype):
+    @staticmethod
+    def stem_supported(stem_groups, block_groups):
+        """network stem (3x3/s2 conv on <=3 channels, BN, ReLU6) + an expand-free block (dw, pw-linear)."""
+        if len(stem_groups) != 1 or len(block_groups) != 2:
+            return False
+        (cs, bs, a_s), (cd, bdn, ad), (cp, bpn, ap) = stem_groups[0], block_groups[0], block_groups[1]
+        return (cs.kernel_size == (3, 3) and cs.stride == (2, 2) and cs.padding == (1, 1) and cs.groups == 1
+                and 9 * cs.in_channels <= 32 and cs.out_channels % 8 == 0 and a_s == "relu6" and bs is not None
+                and conv_kind(cd) == "dw" and ad == "relu6" and cd.in_channels == cs.out_channels
+                and conv_kind(cp) == "dense" and cp.kernel_size == (1, 1) and cp.stride == (1, 1) and ap == "none"
+                and cp.out_channels <= 64 and cp.out_channels % 8 == 0 and bdn is not None and bpn is not None)
+
+    def __init__(self, groups, residual, dtype, stem_group=None):
+        self.stem = 0
+        if stem_group is not None:  # the stem conv plays the role of the expand conv
+            cs, bs, _ = stem_group
+            (cd, bd, _), (cp, bp, _) = groups
+            scale, bias = fold_bn(cs, bs)
+            w = cs.weight.detach().float().permute(0, 2, 3, 1).reshape(cs.out_channels, -1)  # [Cout][(ky,kx,ci)]
+            wpad = torch.zeros((cs.out_channels, 32), device=w.device, dtype=torch.float32)
+            wpad[:, : w.shape[1]] = w
+            self.e = ConvPack.__new__(ConvPack)
+            self.e.w, self.e.scale, self.e.bias = wpad.to(dtype).contiguous(), scale, bias
+            self.d = ConvPack(cd, bd, "relu6", dtype)
+            self.p = ConvPack(cp, bp, "none", dtype)
+            self.cin, self.chid, self.cout = cs.in_channels, cs.out_channels, cp.out_channels
+            self.stride, self.residual, self.stem = cd.stride[0], False, 1
+            self._fold_tail(cd, bd, cp)
+            return
         (ce, be, _), (cd, bd, _), (cp, bp, _) = groups
         self.e = ConvPack(ce, be, "relu6", dtype)
         self.d = ConvPack(cd, bd, "relu6", dtype)
         self.p = ConvPack(cp, bp, "none", dtype)
         self.cin, self.chid, self.cout = ce.in_channels, ce.out_channels, cp.out_channels
         self.stride, self.residual = cd.stride[0], bool(residual)
+        self._fold_tail(cd, bd, cp)
+
+    def _fold_tail(self, cd, bd, cp):
         # internal tensors are fp16: depthwise weights with the BN scale folded in, fp16 bias, fp16 projection
         sd, bdv = fold_bn(cd, bd)
         wdw = cd.weight.detach().float()[:, 0] * sd.view(-1, 1, 1)  # [C,3,3]
@@ -141,19 +172,26 @@ def fill_mb_desc(d, x_ptr, y_ptr, n, h, w, pk, dtype_code):
     d.w_dw, d.bias_dw = pk.wd.data_ptr(), pk.bd.data_ptr()
     d.w_project, d.scale_project, d.bias_project = pk.wp.data_ptr(), pk.p.scale.data_ptr(), pk.p.bias.data_ptr()
     d.N, d.H, d.W, d.Cin, d.Chid, d.Cout = n, h, w, pk.cin, pk.chid, pk.cout
-    d.stride, d.residual, d.dtype = pk.stride, int(pk.residual), dtype_code
+    d.stride, d.residual, d.dtype, d.stem = pk.stride, int(pk.residual), dtype_code, pk.stem
     return d
 
 
 def mbconv_native(x, pk):
     """One fused inverted-residual block; x channels_last [N,Cin,H,W] -> channels_last [N,Cout,Ho,Wo]."""
     N.require_device(x, "mbconv")
-    if not x.is_contiguous(memory_format=torch.channels_last):
-        x = x.contiguous(memory_format=torch.channels_last)
+    stem = pk.stem
+    if stem and x.is_contiguous():
+        stem = 1  # NCHW image
+    else:
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        stem = 2 if stem else 0
     n, c, h, w = (int(v) for v in x.shape)
-    ho, wo = _out_hw(h, w, 3, pk.stride)
+    hs, ws = _out_hw(h, w, 3, 2) if pk.stem else (h, w)
+    ho, wo = _out_hw(hs, ws, 3, pk.stride)
     y = torch.empty((n, pk.cout, ho, wo), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
     d = fill_mb_desc(N.MbConvDesc(), x.data_ptr(), y.data_ptr(), n, h, w, pk, N.dtype_code(x))
+    d.stem = stem
     with torch.cuda.device(x.device):
         rc = N.lib.ssdk_mbconv(ctypes.byref(d), N.stream_ptr(x.device))
     N.check(rc, "mbconv")
@@ -278,7 +316,8 @@ class ConvPlan(object):
     def mbconv(self, val, pk):
         buf, n, c, h, w = val
         assert c == pk.cin, (c, pk.cin)
-        ho, wo = _out_hw(h, w, 3, pk.stride)
+        hs, ws = _out_hw(h, w, 3, 2) if pk.stem else (h, w)
+        ho, wo = _out_hw(hs, ws, 3, pk.stride)
         out = self.arena.get(n * pk.cout * ho * wo * self.es)
         self.layers.append(dict(kind="mb", x=buf, n=n, h=h, w=w, pack=pk, y=out))
         self.keep.append(pk)
@@ -315,14 +354,22 @@ class ConvPlan(object):
         if tuple(x.shape) != self.in_shape or x.dtype != self.dtype:
             raise N.SsdkError("plan was recorded for {} {}, got {} {}".format(self.in_shape, self.dtype,
                                                                           tuple(x.shape), x.dtype))
-        first = self.ops[0].conv
-        if x.is_contiguous():
-            first.in_layout = N.NCHW if self.layers[0]["pack"].kind == "stem" else N.NHWC
-            if first.in_layout == N.NHWC:
+        if self.ops[0].kind == N.OP_MBCONV:  # stem + first block fused: the image is read by the block kernel
+            first = self.ops[0].mb
+            if x.is_contiguous():
+                first.stem = 1
+            else:
                 x = x.contiguous(memory_format=torch.channels_last)
+                first.stem = 2
         else:
-            x = x.contiguous(memory_format=torch.channels_last)
-            first.in_layout = N.NHWC
+            first = self.ops[0].conv
+            if x.is_contiguous():
+                first.in_layout = N.NCHW if self.layers[0]["pack"].kind == "stem" else N.NHWC
+                if first.in_layout == N.NHWC:
+                    x = x.contiguous(memory_format=torch.channels_last)
+            else:
+                x = x.contiguous(memory_format=torch.channels_last)
+                first.in_layout = N.NHWC
         first.x = x.data_ptr()
         loc, conf = [], []
         for (li, n, split, cout, ho, wo) in self.heads:

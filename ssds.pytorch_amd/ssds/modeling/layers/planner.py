@@ -61,18 +61,29 @@ def record_mobilenet(plan, val, net):
 
     if not isinstance(net, MobileNetEx):
         raise PlanUnsupported("backbone {} has no planner".format(type(net).__name__))
-    cur = record_chain(plan, val, net.conv1, keep_input=True)  # the image is not an arena buffer
+    fused_block = os.environ.get("SSDK_FUSED_BLOCK", "1") != "0"
+    first_blk = net.layer1[0]
+    stem_fused = False
+    if fused_block and isinstance(first_blk, InvertedResidual) and not first_blk.use_res_connect:
+        sg, bg = groups_of(net.conv1), groups_of(first_blk.conv)
+        if MbPack.stem_supported(sg, bg):  # stem conv + expand-free first block: ONE launch from the image
+            cur = plan.mbconv(val, MbPack(bg, False, plan.dtype, stem_group=sg[0]))
+            stem_fused = True
+    if not stem_fused:
+        cur = record_chain(plan, val, net.conv1, keep_input=True)  # the image is not an arena buffer
     outputs = []
     for j in range(len(net.settings)):
         level = j + 1
         if level > max(net.outputs):
             break
-        for blk in getattr(net, "layer{}".format(level)):
+        for bi, blk in enumerate(getattr(net, "layer{}".format(level))):
+            if stem_fused and level == 1 and bi == 0:
+                continue
             is_out_input = any(cur is o for o in outputs)
             if isinstance(blk, InvertedResidual):
                 res = cur if blk.use_res_connect else None
                 groups = groups_of(blk.conv)
-                if os.environ.get("SSDK_FUSED_BLOCK", "1") != "0" and MbPack.supported(groups, blk.use_res_connect):
+                if fused_block and MbPack.supported(groups, blk.use_res_connect):
                     nxt = plan.mbconv(cur, MbPack(groups, blk.use_res_connect, plan.dtype))  # whole block, 1 launch
                     if not is_out_input:
                         plan.release(cur)

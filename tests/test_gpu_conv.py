@@ -243,3 +243,71 @@ def test_fused_inverted_residual_block(cin, cout, stride, h, w):
     got = FC.mbconv_native(x.cuda(), pk)
     assert got.is_contiguous(memory_format=torch.channels_last)
     _check(got, y, dtype, "mbconv %d->%d s%d" % (cin, cout, stride))
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("h,w", [(64, 64), (37, 45)])
+def test_fused_stem_block(layout, h, w):
+    """Stem (3x3/s2, BN, ReLU6) + expand-free first block (dw 3x3, pw 32->16) as ONE launch from the image."""
+    import torch
+    from ssds.modeling.layers import fused_conv as FC
+    from ssds.modeling.layers.planner import groups_of
+    from ssds.modeling.nets.mobilenet import ConvBNReLU6, InvertedResidual
+
+    dtype = torch.bfloat16
+    torch.manual_seed(11)
+    stem = ConvBNReLU6(3, 32, stride=2).eval()
+    blk = InvertedResidual(32, 16, 1, 1).eval()
+    for m in list(stem.modules()) + list(blk.modules()):
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data = (m.weight.data * 2).to(dtype).float()
+    x = torch.rand(2, 3, h, w).to(dtype)
+    with torch.no_grad():
+        y = stem(x.float()).to(dtype).float()
+        mods = list(blk.conv.children())
+        y = mods[0](y).to(dtype).float()
+        y = mods[2](mods[1](y))
+    stem, blk = stem.cuda(), blk.cuda()
+    sg, bg = groups_of(stem), groups_of(blk.conv)
+    assert FC.MbPack.stem_supported(sg, bg)
+    pk = FC.MbPack(bg, False, dtype, stem_group=sg[0])
+    xin = x.cuda() if layout == "nchw" else x.cuda().contiguous(memory_format=torch.channels_last)
+    got = FC.mbconv_native(xin, pk)
+    _check(got, y, dtype, "stem block " + layout)
+
+
+@pytest.mark.parametrize("head,net,outs,depth", [("SSDFPN", "ResNet18", [3, 4, 5], [128, 256, 512]),
+                                                 ("SSDBiFPN", "RegNetX002", [2, 3, 4], [56, 152, 368])])
+def test_fpn_bifpn_eval_on_device(head, net, outs, depth):
+    """BASELINE configs 3 / 5 families: backbone on PyTorch-ROCm, ConvBNReLU blocks and the shared towers on
+    the fused MFMA kernel (per-layer calls), NCHW head outputs with the sigmoid fused; vs the fp32 module."""
+    import torch
+    from ssds.modeling import nets, ssds
+    from ssds.modeling.layers import fused_conv as FC
+
+    cls = getattr(ssds, head)
+    torch.manual_seed(2)
+    fl = [outs + ["Conv:S", "Conv:S"], depth + [depth[-1], 256]]
+    nets_outputs, extras, hd = cls.add_extras(fl, [9] * 5, 6)
+    model = cls(getattr(nets, net)(outputs=nets_outputs), extras, hd, 6).eval()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.05)
+            m.running_var.uniform_(0.9, 1.1)
+    x = torch.rand(2, 3, 128, 160)
+    with torch.no_grad():
+        rl, rc = model(x)
+    model = model.cuda().to(torch.bfloat16)
+    before = FC.STATS["native_layers"]
+    with torch.no_grad():
+        loc, conf = model(x.cuda().to(torch.bfloat16))
+    assert FC.STATS["native_layers"] - before >= 5 * 10, "towers did not run on the fused kernels"
+    for l, a, c, b in zip(loc, rl, conf, rc):
+        assert l.shape == a.shape and c.shape == b.shape and l.is_contiguous() and c.is_contiguous()
+        assert float((c.float().cpu() - b).abs().max()) < 3e-3
+        assert float((l.float().cpu() - a).abs().max()) < 0.05 * max(float(a.abs().max()), 1e-2) + 5e-3
