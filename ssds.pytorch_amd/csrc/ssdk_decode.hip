@@ -71,16 +71,48 @@ __host__ __device__ inline size_t lds_bytes_for(u32 K) {
          sizeof(LevelLds);
 }
 
+// One 16-byte vector per lane: every element that beats the running cut (score, index) becomes a 64-bit key.
+// The wave appends all of them with ONE LDS atomic: per-lane counts -> wave exclusive scan (shuffles) ->
+// the last lane reserves the wave's range -> every lane writes its keys at base + prefix + local rank.
+// (The first version did ballot + atomic per element slot: 8 dependent LDS-atomic round trips per tile.)
 template <int DT, int E>
-__device__ __forceinline__ void scan_elems(const u32x4& v, u32 idx0, u32 n, float cut, u32 cut_idx,
-                                           u64* buf, StreamCtl* ctl, u32 limit, u32 tile) {
+__device__ __forceinline__ void scan_flags(const u32x4& v, u32 idx0, u32 n, float cut, u32 cut_idx, u32& pmask,
+                                           float (&sv)[DType<DT>::vec]) {
   if constexpr (E < DType<DT>::vec) {
     const float s = vec_elem<DT, E>(v);
     const u32 idx = idx0 + E;  // wraps to a huge value for the (masked) head elements
     const bool pass = (idx < n) & ((s > cut) | ((s == cut) & (idx < cut_idx)));
-    stream_append(buf, ctl, limit, tile, pass, make_key(s, idx));
-    scan_elems<DT, E + 1>(v, idx0, n, cut, cut_idx, buf, ctl, limit, tile);
+    pmask |= pass ? (1u << E) : 0u;
+    sv[E] = s;
+    scan_flags<DT, E + 1>(v, idx0, n, cut, cut_idx, pmask, sv);
   }
+}
+
+template <int DT>
+__device__ __forceinline__ void scan_vec(const u32x4& v, u32 idx0, u32 n, float cut, u32 cut_idx, u64* buf,
+                                         StreamCtl* ctl, u32 limit, u32 tile) {
+  constexpr int VEC = DType<DT>::vec;
+  u32 pmask = 0;
+  float sv[VEC];
+  scan_flags<DT, 0>(v, idx0, n, cut, cut_idx, pmask, sv);
+  if (__ballot(pmask != 0u) == 0ull) return;  // nothing in this wave beats the cut (the common case later on)
+  const u32 cnt = (u32)__popc(pmask);
+  u32 incl = cnt;
+  const u32 lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u32 y = __shfl_up(incl, d);
+    if ((int)lane >= d) incl += y;
+  }
+  u32 base = 0;
+  if (lane == 63) {  // incl == wave total
+    base = atomicAdd(&ctl->cnt, incl);
+    if (base <= limit && base + incl > limit) ctl->flag[tile & 1u] = tile + 1u;  // the unique crosser
+  }
+  base = __shfl(base, 63) + (incl - cnt);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e)
+    if ((pmask >> e) & 1u) buf[base + (u32)__popc(pmask & ((1u << e) - 1u))] = make_key(sv[e], idx0 + (u32)e);
 }
 
 template <int DT>
@@ -166,7 +198,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) 
         const u32x4 v = pf[i];
         pf[i] = load_vec(t + kPrefetch);
         const u32 idx0 = (vec0 + t * NT + tid) * VEC - head;
-        scan_elems<DT, 0>(v, idx0, n, cut, cut_idx, buf, ctl, limit, t);
+        scan_vec<DT>(v, idx0, n, cut, cut_idx, buf, ctl, limit, t);
         u64 T;
         if (stream_finish_tile<NT>(buf, sel, ss, ctl, t, K, &T)) {
           cut = key_score(T);

@@ -64,45 +64,29 @@ __device__ __forceinline__ bool suppressed_by(const float4 b, float ab, const fl
   return !(iou <= thr);
 }
 
+constexpr u32 kNmsRound = 256;  // candidates sorted + walked per round
+
+// Lazy sort: the greedy walk almost always stops (ndetections survivors) inside the first few hundred
+// candidates, so instead of sorting all L*K keys the workgroup repeatedly extracts the exact top-256 of the
+// remaining keys (radix select), sorts those 256 and lets one wave walk them; further rounds only run
+// while fewer than ndetections boxes survived and candidates remain.  Result identical to a full sort.
 __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
   constexpr int NT = kNmsThreads;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const u32 tid = threadIdx.x, lane = tid & 63u;
   const u32 b = blockIdx.x;
   const u32 N = (u32)p.N;
-  u32 M = 64;
-  while (M < N) M <<= 1;
-  u64* keys = reinterpret_cast<u64*>(smem);                       // M
-  float4* kbox = reinterpret_cast<float4*>(keys + M);              // ndet
+  u64* keys = reinterpret_cast<u64*>(smem);                        // N (unsorted; taken keys are zeroed)
+  u64* top = keys + ((N + 1) & ~1u);                               // kNmsRound
+  float4* kbox = reinterpret_cast<float4*>(top + kNmsRound);       // ndet
   float* karea = reinterpret_cast<float*>(kbox + p.ndet);          // ndet
   float* kcls = karea + p.ndet;                                    // ndet
-  u32* ctl = reinterpret_cast<u32*>(kcls + p.ndet);                // [0] = nvalid
+  u32* ctl = reinterpret_cast<u32*>(kcls + p.ndet);                // [0] nvalid, [1] nk, [2] top count
+  SelScratch* ss = reinterpret_cast<SelScratch*>(ctl + 4);
 
   const float* sc = p.scores + (size_t)b * N;
   const float4* bx = reinterpret_cast<const float4*>(p.boxes) + (size_t)b * N;
   const float* cl = p.classes + (size_t)b * N;
-
-  if (tid == 0) ctl[0] = 0;
-  __syncthreads();
-  u32 local = 0;
-  for (u32 i = tid; i < M; i += NT) {
-    u64 k = 0;
-    if (i < N) {
-      const float s = sc[i];
-      if (s > 0.0f) {  // box.py:496
-        k = make_key(s, i);
-        ++local;
-      }
-    }
-    keys[i] = k;
-  }
-  atomicAdd(&ctl[0], local);
-  __syncthreads();
-  const u32 nvalid = ctl[0];
-  wg_bitonic_sort_desc<NT>(keys, M);  // box.py:505
-
-  if (tid >= 64) return;  // the greedy walk is one wave; everything below is wave-synchronous
-
   const u32 ndet = (u32)p.ndet;
   float* os = p.out_scores + (size_t)b * ndet;
   float4* ob = reinterpret_cast<float4*>(p.out_boxes) + (size_t)b * ndet;
@@ -110,66 +94,110 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
   const float thr = p.thr;
   const int diou = p.diou;
 
+  if (tid == 0) {
+    ctl[0] = 0;
+    ctl[1] = 0;
+  }
+  __syncthreads();
+  u32 local = 0;
+  for (u32 i = tid; i < N; i += NT) {
+    u64 k = 0;
+    const float s = sc[i];
+    if (s > 0.0f) {  // box.py:496 (NaN drops out too)
+      k = make_key(s, i);
+      ++local;
+    }
+    keys[i] = k;
+  }
+  if (local) atomicAdd(&ctl[0], local);
+  __syncthreads();
+  u32 left = ctl[0];
   u32 nk = 0;
-  for (u32 base = 0; base < nvalid && nk < ndet; base += 64) {
-    const u32 i = base + lane;
-    const bool valid = i < nvalid;
-    float score = 0.f, cls = -1.f, area = 0.f;
-    float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) {
+
+  while (left > 0 && nk < ndet) {  // workgroup-uniform
+    const u32 r = left < kNmsRound ? left : kNmsRound;
+    u64 T = 1;  // every remaining (non-zero) key
+    if (left > r) T = wg_select_kth<NT>(keys, N, r, ss);  // r-th largest of the remaining keys (box.py:505)
+    if (tid == 0) ctl[2] = 0;
+    __syncthreads();
+    for (u32 i = tid; i < N; i += NT) {
       const u64 k = keys[i];
-      const u32 pos = key_index(k);
-      score = key_score(k);
-      box = bx[pos];
-      cls = cl[pos];
-      area = (box.z - box.x + 1.0f) * (box.w - box.y + 1.0f);  // box.py:507
-    }
-    bool alive = valid;
-    // 1. against the survivors kept so far
-    for (u32 k = 0; k < nk; ++k) {
-      const float ck = kcls[k];
-      if (__ballot(alive && cls == ck) == 0ull) continue;
-      const bool sup = (cls == ck) && suppressed_by(box, area, kbox[k], karea[k], thr, diou);
-      alive = alive && !sup;
-    }
-    // 2. inside the block, in order
-    u64 am = __ballot(alive);
-    u32 kept_here = 0;
-    for (u32 j = 0; j < 64; ++j) {
-      if (!((am >> j) & 1ull)) continue;
-      if (nk + kept_here >= ndet) {  // truncated to ndetections survivors (box.py:512)
-        am &= (1ull << j) - 1ull;
-        break;
+      if (k >= T) {
+        top[atomicAdd(&ctl[2], 1u)] = k;
+        keys[i] = 0;
       }
-      ++kept_here;
-      const float cj = __shfl(cls, (int)j);
-      const u64 m = __ballot(((am >> lane) & 1ull) && lane > j && cls == cj);
-      if (m == 0ull) continue;
-      float4 pj;
-      pj.x = __shfl(box.x, (int)j);
-      pj.y = __shfl(box.y, (int)j);
-      pj.z = __shfl(box.z, (int)j);
-      pj.w = __shfl(box.w, (int)j);
-      const float aj = __shfl(area, (int)j);
-      const bool sup = ((m >> lane) & 1ull) && suppressed_by(box, area, pj, aj, thr, diou);
-      am &= ~__ballot(sup);
     }
-    // 3. append the block's survivors
-    const bool keep = (am >> lane) & 1ull;
-    const u32 slot = nk + mbcnt(am);
-    if (keep && slot < ndet) {
-      kbox[slot] = box;
-      karea[slot] = area;
-      kcls[slot] = cls;
-      os[slot] = score;
-      ob[slot] = box;
-      oc[slot] = cls;
+    __syncthreads();
+    for (u32 i = r + tid; i < kNmsRound; i += NT) top[i] = 0;
+    __syncthreads();
+    wg_bitonic_sort_desc<NT>(top, kNmsRound);  // descending key == (score desc, position asc)
+
+    if (tid < 64) {  // the greedy walk is one wave; wave-synchronous below
+      for (u32 base = 0; base < r && nk < ndet; base += 64) {
+        const u32 i = base + lane;
+        const bool valid = i < r;
+        float score = 0.f, cls = -1.f, area = 0.f;
+        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+          const u64 k = top[i];
+          const u32 pos = key_index(k);
+          score = key_score(k);
+          box = bx[pos];
+          cls = cl[pos];
+          area = (box.z - box.x + 1.0f) * (box.w - box.y + 1.0f);  // box.py:507
+        }
+        bool alive = valid;
+        // 1. against the survivors kept so far
+        for (u32 k = 0; k < nk; ++k) {
+          const float ck = kcls[k];
+          if (__ballot(alive && cls == ck) == 0ull) continue;
+          const bool sup = (cls == ck) && suppressed_by(box, area, kbox[k], karea[k], thr, diou);
+          alive = alive && !sup;
+        }
+        // 2. inside the block, in order
+        u64 am = __ballot(alive);
+        u32 kept_here = 0;
+        for (u32 j = 0; j < 64; ++j) {
+          if (!((am >> j) & 1ull)) continue;
+          if (nk + kept_here >= ndet) {  // truncated to ndetections survivors (box.py:512)
+            am &= (1ull << j) - 1ull;
+            break;
+          }
+          ++kept_here;
+          const float cj = __shfl(cls, (int)j);
+          const u64 m = __ballot(((am >> lane) & 1ull) && lane > j && cls == cj);
+          if (m == 0ull) continue;
+          float4 pj;
+          pj.x = __shfl(box.x, (int)j);
+          pj.y = __shfl(box.y, (int)j);
+          pj.z = __shfl(box.z, (int)j);
+          pj.w = __shfl(box.w, (int)j);
+          const float aj = __shfl(area, (int)j);
+          const bool sup = ((m >> lane) & 1ull) && suppressed_by(box, area, pj, aj, thr, diou);
+          am &= ~__ballot(sup);
+        }
+        // 3. append the block's survivors
+        const bool keep = (am >> lane) & 1ull;
+        const u32 slot = nk + mbcnt(am);
+        if (keep && slot < ndet) {
+          kbox[slot] = box;
+          karea[slot] = area;
+          kcls[slot] = cls;
+          os[slot] = score;
+          ob[slot] = box;
+          oc[slot] = cls;
+        }
+        nk += (u32)__popcll(am);
+        if (nk > ndet) nk = ndet;
+      }
+      if (lane == 0) ctl[1] = nk;
     }
-    nk += (u32)__popcll(am);
-    if (nk > ndet) nk = ndet;
+    __syncthreads();
+    nk = ctl[1];
+    left -= r;
   }
   // zero padding (box.py:489-491)
-  for (u32 i = nk + lane; i < ndet; i += 64) {
+  for (u32 i = nk + tid; i < ndet; i += NT) {
     os[i] = 0.f;
     ob[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     oc[i] = 0.f;
@@ -177,9 +205,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
 }
 
 static size_t nms_lds_bytes(int N, int ndet) {
-  size_t M = 64;
-  while (M < (size_t)N) M <<= 1;
-  return M * 8 + (size_t)ndet * (16 + 4 + 4) + 16;
+  return (size_t)((N + 1) & ~1) * 8 + kNmsRound * 8 + (size_t)ndet * (16 + 4 + 4) + 16 + sizeof(SelScratch) + 16;
 }
 
 static int launch_nms(const float* scores, const float* boxes, const float* classes, int B, int N,

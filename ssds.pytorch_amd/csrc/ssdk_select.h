@@ -16,6 +16,11 @@
 
 namespace ssdk {
 
+#ifndef SSDK_RANK_MAX
+#define SSDK_RANK_MAX 96
+#endif
+constexpr u32 kRankMax = SSDK_RANK_MAX;  // candidates resolved by O(cb^2/NT) rank counting (<= 512)
+
 struct SelScratch {  // LDS, 8-byte aligned
   u64 acc_or, acc_and, T;
   u32 hist[1024];  // reused as u64 small[512]
@@ -87,9 +92,20 @@ __device__ u64 wg_select_kth(const u64* buf, u32 n, u32 K, SelScratch* s) {
       s->acc_or = 0;
       s->acc_and = ~0ull;
     }
-    for (u32 i = tid; i < n; i += NT) {
-      u64 k = buf[i];
-      if ((k & pfx_mask) == pfx_val) atomicAdd(&s->hist[(u32)(k >> shift) & nbmask], 1u);
+    for (u32 i0 = 0; i0 < n; i0 += NT) {  // uniform trip count: the wave-level aggregation below needs all lanes
+      const u32 i = i0 + tid;
+      const u64 k = i < n ? buf[i] : 0ull;
+      const bool c = i < n && (k & pfx_mask) == pfx_val;
+      const u32 bin = (u32)(k >> shift) & nbmask;
+      const u64 m = __ballot(c);
+      if (m) {
+        // heavy ties put most candidates of a wave into one bin: let one lane add the whole group
+        const u32 lead = (u32)__ffsll((long long)m) - 1u;
+        const u32 b0 = __shfl(bin, (int)lead);
+        const u64 same = __ballot(c && bin == b0);
+        if (lane == lead) atomicAdd(&s->hist[b0], (u32)__popcll(same));
+        if (c && bin != b0) atomicAdd(&s->hist[bin], 1u);
+      }
     }
     __syncthreads();
     u32 local = 0;
@@ -120,7 +136,7 @@ __device__ u64 wg_select_kth(const u64* buf, u32 n, u32 K, SelScratch* s) {
       T = pfx_val;
       break;
     }
-    if (cb <= 512) {  // resolve the remaining candidates by rank counting
+    if (cb <= kRankMax) {  // resolve the remaining candidates by rank counting
       u64* small = reinterpret_cast<u64*>(s->hist);
       if (tid == 0) s->small_cnt = 0;
       __syncthreads();
