@@ -84,7 +84,7 @@ constexpr int SB_BYTES = 128 + 128 + 64;  // se, be (fp32 x32), bd (fp16 x32)
 // E (expanded) and D (depthwise output) are INTERNAL tensors: they are kept in fp16 whatever the model
 // dtype (values are ReLU6-bounded, fp16 carries 3 more mantissa bits than bf16), so P2 runs on packed
 // fp16 math (v_pk_fma_f16: 2 channels per instruction) and P3 on the f16 MFMA with fp16 projection weights.
-template <int DT, int S, int NFO, int KSMAX, bool STEM = false>
+template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = false>
 __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   constexpr int RW = 8 * S + (3 - S);          // 10 (s=1) or 17 (s=2) input columns / rows per tile
   constexpr int P = RW * RW;                   // region pixels
@@ -94,6 +94,8 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   constexpr int NPA = (32 * KSMAX * 4 + kMbThreads - 1) / kMbThreads;   // We pieces per thread
   constexpr int NPB = (NFO * 16 * 4 + kMbThreads - 1) / kMbThreads;     // Wp pieces per thread
   constexpr int NFH = NFO / 2;                                          // projection n-frags per wave
+  constexpr int NPX = STEM ? (P16 * 9 + kMbThreads - 1) / kMbThreads                      // (pixel, tap) items
+                           : (P16 * KSMAX * 4 + kMbThreads - 1) / kMbThreads;             // 16-byte pieces of sX
   static_assert(NFO % 2 == 0, "NFO must be even");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int XS = p.xs, WES = p.wes;
@@ -104,14 +106,16 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
 
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u32 fr = lane & 15u, fg = lane >> 4;
-  u32 bid = blockIdx.x;
-  const int tx = (int)(bid % (u32)p.tiles_x);
-  bid /= (u32)p.tiles_x;
-  const int ty = (int)(bid % (u32)p.tiles_y);
-  const int n = (int)(bid / (u32)p.tiles_y);
-  const int oy0 = ty * 8, ox0 = tx * 8;
-  const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
   const int Cin = p.Cin, Chid = p.Chid, Cout = p.Cout, H = p.H, W = p.W;
+  const u32 ntiles = (u32)p.N * (u32)p.tiles_y * (u32)p.tiles_x;
+  int n = 0, oy0 = 0, ox0 = 0, iy0 = 0, ix0 = 0;
+  auto tile_coords = [&](u32 t, int& tn, int& toy0, int& tox0) {
+    const int ttx = (int)(t % (u32)p.tiles_x);
+    t /= (u32)p.tiles_x;
+    toy0 = (int)(t % (u32)p.tiles_y) * 8;
+    tox0 = ttx * 8;
+    tn = (int)(t / (u32)p.tiles_y);
+  };
   const int KS = (Cin + 31) / 32;
   const int cpr = Cin / 8;  // 16-byte pieces per pixel / per We row
 
@@ -187,46 +191,103 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
     if (c_dst >= 0) *reinterpret_cast<u32x4*>(w + c_dst) = rc;
   };
 
-  load_w(0);
-  // ---- phase 0: input tile + halo -> sX (zeros outside the image and in the padding rows) -------------
-  if constexpr (STEM) {
-    // im2col of the image patch: row = region pixel (stem-output coordinates), k = (ky*3+kx)*Cimg + ci.
-    // One item = (pixel, tap): Cimg 2-byte loads + Cimg 2-byte LDS writes; the tap-8 item also zeroes the
-    // K padding of its row.  Every byte of every row is written (zeros for padding / outside the image).
-    const int Ci = p.Cimg, Hi = p.Himg, Wi = p.Wimg;
-    const u16* img = p.x + (size_t)n * Ci * Hi * Wi;
-    const size_t cstride = p.stem == 1 ? (size_t)Hi * Wi : 1, pstride = p.stem == 1 ? 1 : (size_t)Ci;
-    for (int q = (int)tid; q < P16 * 9; q += kMbThreads) {
-      const int pix = q / 9, tap = q % 9;
-      bool ok = false;
-      size_t off = 0;
-      if (pix < P) {
-        const int soy = iy0 + pix / RW, sox = ix0 + pix % RW;
-        const int iy = 2 * soy + tap / 3 - 1, ix = 2 * sox + tap % 3 - 1;
-        ok = (unsigned)soy < (unsigned)H && (unsigned)sox < (unsigned)W && (unsigned)iy < (unsigned)Hi &&
-             (unsigned)ix < (unsigned)Wi;
-        off = ((size_t)iy * Wi + ix) * pstride;
+  // ---- input tile (+ halo) staging: global -> registers (fetch_x, may run one tile ahead) -> sX (put_x) --
+  u32x4 xr[STEM ? 1 : NPX];
+  u16 xs16[STEM ? NPX : 1][3];
+  auto fetch_x = [&](u32 t) {
+    int tn, toy0, tox0;
+    tile_coords(t, tn, toy0, tox0);
+    const int tiy0 = toy0 * S - 1, tix0 = tox0 * S - 1;
+    if constexpr (STEM) {
+      // im2col source: item = (region pixel in stem-output coordinates, tap); Cimg 2-byte loads each
+      const int Ci = p.Cimg, Hi = p.Himg, Wi = p.Wimg;
+      const u16* img = p.x + (size_t)tn * Ci * Hi * Wi;
+      const size_t cstride = p.stem == 1 ? (size_t)Hi * Wi : 1, pstride = p.stem == 1 ? 1 : (size_t)Ci;
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        const int q = (int)tid + i * kMbThreads;
+        const int pix = q / 9, tap = q % 9;
+        bool ok = false;
+        size_t off = 0;
+        if (pix < P) {
+          const int soy = tiy0 + pix / RW, sox = tix0 + pix % RW;
+          const int iy = 2 * soy + tap / 3 - 1, ix = 2 * sox + tap % 3 - 1;
+          ok = (unsigned)soy < (unsigned)H && (unsigned)sox < (unsigned)W && (unsigned)iy < (unsigned)Hi &&
+               (unsigned)ix < (unsigned)Wi;
+          off = ((size_t)iy * Wi + ix) * pstride;
+        }
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) xs16[i][ci] = (ok && ci < Ci) ? img[off + ci * cstride] : (u16)0;
       }
-      u16* row = reinterpret_cast<u16*>(sX + (size_t)pix * XS);
-      for (int ci = 0; ci < Ci; ++ci) row[tap * Ci + ci] = ok ? img[off + ci * cstride] : (u16)0;
-      if (tap == 8)
-        for (int k = 9 * Ci; k < 32; ++k) row[k] = 0;
+    } else {
+      const u16* xin = p.x + (size_t)tn * H * W * Cin;
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        const int q = (int)tid + i * kMbThreads;
+        const int pix = q / cpr, c = q % cpr;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (pix < P) {
+          const int iy = tiy0 + pix / RW, ix = tix0 + pix % RW;
+          if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            v = *reinterpret_cast<const u32x4*>(xin + ((size_t)iy * W + ix) * Cin + c * 8);
+        }
+        xr[i] = v;
+      }
     }
+  };
+  auto put_x = [&]() {
+    if constexpr (STEM) {
+      const int Ci = p.Cimg;
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        const int q = (int)tid + i * kMbThreads;
+        const int pix = q / 9, tap = q % 9;
+        if (pix < P16) {  // every byte of every row is written (zeros for padding / outside the image)
+          u16* row = reinterpret_cast<u16*>(sX + (size_t)pix * XS);
+#pragma unroll
+          for (int ci = 0; ci < 3; ++ci)
+            if (ci < Ci) row[tap * Ci + ci] = xs16[i][ci];
+          if (tap == 8)
+            for (int k = 9 * Ci; k < 32; ++k) row[k] = 0;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        const int q = (int)tid + i * kMbThreads;
+        const int pix = q / cpr, c = q % cpr;
+        if (pix < P16) *reinterpret_cast<u32x4*>(sX + (size_t)pix * XS + c * 16) = xr[i];
+      }
+    }
+  };
+
+  const int nchunks = (Chid + HC - 1) / HC;
+  u32 tile = blockIdx.x;
+  if constexpr (RESIDENT) {  // every chunk's weights live in LDS for the whole (persistent) workgroup
+    for (int c = 0; c < nchunks; ++c) {
+      load_w(c * HC);
+      store_w(c);
+    }
+    fetch_x(tile);
   } else {
-    const int total = P16 * cpr;
-    const u16* xin = p.x + (size_t)n * H * W * Cin;
-    for (int q = (int)tid; q < total; q += kMbThreads) {
-      const int pix = q / cpr, c = q % cpr;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (pix < P) {
-        const int iy = iy0 + pix / RW, ix = ix0 + pix % RW;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-          v = *reinterpret_cast<const u32x4*>(xin + ((size_t)iy * W + ix) * Cin + c * 8);
-      }
-      *reinterpret_cast<u32x4*>(sX + (size_t)pix * XS + c * 16) = v;
-    }
+    load_w(0);
+    fetch_x(tile);
+    put_x();
+    store_w(0);
   }
-  store_w(0);
+  const u32 d_px = tid >> 3, d_cg = tid & 7u;      // P2 role: output pixel, 4-channel group
+  const u32 d_oy = d_px >> 3, d_ox = d_px & 7u;
+  const u32 m_fr = wave & 3u, n_half = wave >> 2;  // P3 role: pixel frag, interleaved half of the n-frags
+
+  for (; tile < ntiles; tile += gridDim.x) {  // one iteration unless RESIDENT (persistent grid)
+  tile_coords(tile, n, oy0, ox0);
+  iy0 = oy0 * S - 1;
+  ix0 = ox0 * S - 1;
+  if constexpr (RESIDENT) {
+    __syncthreads();  // previous tile: every wave is done with sX (residual reads) and sE/sD
+    put_x();
+    if (tile + gridDim.x < ntiles) fetch_x(tile + gridDim.x);  // next tile's input in flight under this tile
+  }
   // validity of the region pixels this lane produces in P1 (bit i: m-frag wave + 8*i)
   u32 pvalid = 0;
 #pragma unroll
@@ -242,14 +303,10 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   for (int j = 0; j < NFH; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
-  const int nchunks = (Chid + HC - 1) / HC;
-  const u32 d_px = tid >> 3, d_cg = tid & 7u;      // P2 role: output pixel, 4-channel group
-  const u32 d_oy = d_px >> 3, d_ox = d_px & 7u;
-  const u32 m_fr = wave & 3u, n_half = wave >> 2;  // P3 role: pixel frag, interleaved half of the n-frags
-
   for (int c = 0; c < nchunks; ++c) {
-    const unsigned char* wcur = sW + (size_t)(c & 1) * p.wbuf;
-    if (c + 1 < nchunks) load_w((c + 1) * HC);  // next chunk's weights in flight under this chunk's work
+    const unsigned char* wcur = sW + (size_t)(RESIDENT ? c : (c & 1)) * p.wbuf;
+    if constexpr (!RESIDENT)
+      if (c + 1 < nchunks) load_w((c + 1) * HC);  // next chunk's weights in flight under this chunk's work
     // ---- P1: expand the region for channels [hc0, hc0+32) -> sE (fp16) -----------------------------
     {
       const f32x4 se0 = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + (fg * 4) * 4);
@@ -310,7 +367,8 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
       *reinterpret_cast<uint2*>(sD + (size_t)d_px * ES + d_cg * 8) =
           make_uint2(__builtin_bit_cast(u32, v0), __builtin_bit_cast(u32, v1));
     }
-    if (c + 1 < nchunks) store_w((c + 1) & 1);  // visible to the next chunk's P1 after the barrier below
+    if constexpr (!RESIDENT)
+      if (c + 1 < nchunks) store_w((c + 1) & 1);  // visible to the next chunk's P1 after the barrier below
     __syncthreads();
     // ---- P3: project: wave (m_fr, n_half) owns pixels [16 m_fr, +16) x n-frags n_half, n_half+2, ... ----
     {
@@ -352,23 +410,34 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
       }
     }
   }
+  }  // tile loop
 }
 
-template <int DT, int S, int NFO, int KSMAX, bool STEM = false>
+template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = false>
 static void launch_one(const MbParams& p, size_t lds, unsigned grid, hipStream_t stream) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<DT, S, NFO, KSMAX, STEM>),
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((mbconv_kernel<DT, S, NFO, KSMAX, STEM>), dim3(grid), dim3(kMbThreads), lds, stream, p);
+  hipLaunchKernelGGL((mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT>), dim3(grid), dim3(kMbThreads), lds, stream, p);
 }
 
 // (k-steps of the expand GEMM, n-frags of the projection) pairs of the MobileNetV2 family get their own
 // instantiation (register budget = occupancy); everything else runs on the most general one.
 template <int DT, int S>
-static int launch_mb(const MbParams& p, int ks, int nfo, size_t lds, unsigned grid, hipStream_t stream) {
+static int launch_mb(const MbParams& p, int ks, int nfo, size_t lds, unsigned grid, hipStream_t stream, bool resident) {
   if (p.stem) {
-    if (nfo <= 2) launch_one<DT, S, 2, 1, true>(p, lds, grid, stream);
-    else launch_one<DT, S, 4, 1, true>(p, lds, grid, stream);
+    if (resident) {
+      if (nfo <= 2) launch_one<DT, S, 2, 1, true, true>(p, lds, grid, stream);
+      else launch_one<DT, S, 4, 1, true, true>(p, lds, grid, stream);
+    } else {
+      if (nfo <= 2) launch_one<DT, S, 2, 1, true>(p, lds, grid, stream);
+      else launch_one<DT, S, 4, 1, true>(p, lds, grid, stream);
+    }
     return check_launch("mbconv_kernel(stem)");
+  }
+  if (resident && ks <= 1 && nfo <= 4) {  // small-channel, high-resolution blocks: persistent grid, resident weights
+    if (nfo <= 2) launch_one<DT, S, 2, 1, false, true>(p, lds, grid, stream);
+    else launch_one<DT, S, 4, 1, false, true>(p, lds, grid, stream);
+    return check_launch("mbconv_kernel(resident)");
   }
   if (ks <= 1 && nfo <= 2) launch_one<DT, S, 2, 1>(p, lds, grid, stream);
   else if (ks <= 1 && nfo <= 4) launch_one<DT, S, 4, 1>(p, lds, grid, stream);
@@ -450,16 +519,35 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   p.off_wd = p.off_wp + nfo_inst * 16 * ES;
   p.off_sb = p.off_wd + 9 * 64;
   p.wbuf = p.off_sb + SB_BYTES;
-  const size_t lds = (size_t)p16 * p.xs + (size_t)p16 * ES + 64 * ES + 2 * (size_t)p.wbuf;
+  const int nchunks = (d->Chid + HC - 1) / HC;
+  static const int env_res = getenv("SSDK_MB_RESIDENT") ? atoi(getenv("SSDK_MB_RESIDENT")) : 1;
+  const size_t fixed = (size_t)p16 * p.xs + (size_t)p16 * ES + 64 * ES;
+  const int ks_t = (p.Cin + 31) / 32;
+  bool resident = env_res && ks_t <= 1 && nfo_inst <= 4 && (size_t)nchunks * p.wbuf <= 56 * 1024;
+  const size_t lds = fixed + (resident ? (size_t)nchunks : 2) * (size_t)p.wbuf;
   if (lds > 160 * 1024) {
     set_error("mbconv: tile needs %zu bytes of LDS", lds);
     return SSDK_E_BADARG;
   }
-  const unsigned grid = (unsigned)((long)d->N * p.tiles_x * p.tiles_y);
+  unsigned grid = (unsigned)((long)d->N * p.tiles_x * p.tiles_y);
+  if (resident) {  // persistent: as many workgroups as stay resident (LDS- and wave-limited: <= 4 x 8 waves per CU)
+    static int cus = 0;
+    if (!cus) {
+      hipDeviceProp_t prop;
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    unsigned per_cu = (unsigned)((160 * 1024) / lds);
+    if (per_cu > 3) per_cu = 3;
+    if (per_cu < 1) per_cu = 1;
+    const unsigned cap = (unsigned)cus * per_cu;
+    if (grid > cap) grid = cap;
+  }
   const int nfo = (d->Cout + 15) / 16, ks = (p.Cin + 31) / 32;
   if (d->dtype == SSDK_BF16)
-    return d->stride == 1 ? launch_mb<SSDK_BF16, 1>(p, ks, nfo, lds, grid, stream)
-                          : launch_mb<SSDK_BF16, 2>(p, ks, nfo, lds, grid, stream);
-  return d->stride == 1 ? launch_mb<SSDK_F16, 1>(p, ks, nfo, lds, grid, stream)
-                        : launch_mb<SSDK_F16, 2>(p, ks, nfo, lds, grid, stream);
+    return d->stride == 1 ? launch_mb<SSDK_BF16, 1>(p, ks, nfo, lds, grid, stream, resident)
+                          : launch_mb<SSDK_BF16, 2>(p, ks, nfo, lds, grid, stream, resident);
+  return d->stride == 1 ? launch_mb<SSDK_F16, 1>(p, ks, nfo, lds, grid, stream, resident)
+                        : launch_mb<SSDK_F16, 2>(p, ks, nfo, lds, grid, stream, resident);
 }
