@@ -50,6 +50,13 @@ struct ConvParams {
   int KT;          // k*k*cin_chunks
   int act, act2, split;  // channels >= split use act2 and go to y2 (split == Cout: single output)
   int in_layout, out_layout;
+  // split-K (small-M layers: too few output tiles to fill 256 CUs and a long, latency-bound k-loop):
+  // blockIdx.z owns k-tiles [z*kt_per, (z+1)*kt_per); partial accumulators go to fp32 slabs in fragment order,
+  // the last workgroup to arrive on a tile (agent-scope release/acquire on a counter) sums them and runs
+  // the epilogue.  Counters are zero on entry and reset by the last arriver.
+  int ksplits, kt_per;
+  float* slabs;
+  unsigned* counters;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -146,7 +153,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
 
   // k-tiles are visited tap-major, channel-chunk-minor; the running state below replaces the per-tile
   // divisions (kt / cin_chunks, kpos / k ...) that used to cost ~90 VALU + ~90 SALU per k-step.
-  int t_kpos = 0, t_ky = 0, t_kx = 0, t_cc = 0;
+  const int kt_begin = (int)blockIdx.z * p.kt_per;
+  const int kt_end = (kt_begin + p.kt_per < p.KT) ? kt_begin + p.kt_per : p.KT;
+  int t_kpos = kt_begin / p.cin_chunks, t_cc = kt_begin % p.cin_chunks;
+  int t_ky = t_kpos / p.k, t_kx = t_kpos % p.k;
   u32x4 ra[2], rb[B_PER];
   auto load_tile = [&]() {  // loads the tile of the current state, then advances the state
     const int ci = t_cc * BK + (int)lc * 8;
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
   load_tile();
   store_tile(0);
   __syncthreads();
-  const int KT = p.KT;
+  const int KT = kt_end - kt_begin;
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < KT) load_tile();  // global loads in flight while the MFMAs run
@@ -222,6 +232,50 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
       for (int j = 0; j < FN; ++j) acc[i][j] = mfma16<DT>(fa[i], fb[j], acc[i][j]);
     if (kt + 1 < KT) store_tile(cur ^ 1);
     __syncthreads();
+  }
+
+  if (p.ksplits > 1) {
+    // ---- split-K hand-off (cdna_hip_programming.md G16, counter form): slab stores -> every wave drains
+    //      vmcnt -> barrier -> one lane: agent release + drained wait -> relaxed ticket; the last arriver
+    //      acquires once, then every wave reads the other slabs with plain loads. ------------------------
+    const u32 tile_id = blockIdx.y * gridDim.x + blockIdx.x;
+    constexpr int FRAGS = FM * FN;
+    float* my = p.slabs + ((size_t)tile_id * p.ksplits + blockIdx.z) * (size_t)(4 * FRAGS * 256);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        *reinterpret_cast<f32x4*>(my + ((size_t)(i * FN + j) * 256 + tid) * 4) = acc[i][j];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    u32* flag = reinterpret_cast<u32*>(smem);  // staging buffers are free now
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned old = __hip_atomic_fetch_add(p.counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned last = (old == (unsigned)p.ksplits - 1u) ? 1u : 0u;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(p.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    const bool last = *flag != 0u;
+    __syncthreads();  // everyone has read the flag before the epilogue reuses the LDS
+    if (!last) return;
+    const float* base = p.slabs + (size_t)tile_id * p.ksplits * (size_t)(4 * FRAGS * 256);
+    for (int z = 0; z < p.ksplits; ++z) {
+      if (z == (int)blockIdx.z) continue;
+      const float* other = base + (size_t)z * (size_t)(4 * FRAGS * 256);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(other + ((size_t)(i * FN + j) * 256 + tid) * 4);
+          acc[i][j] += v;
+        }
+    }
   }
 
   // ---- epilogue: scale/bias/activation in fp32, tile through LDS, 16-byte coalesced stores ------------
@@ -473,20 +527,37 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstParams p) {
 // ------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------
+static int gemm_bn(int cout) { return cout > 64 ? 128 : cout > 32 ? 64 : cout > 16 ? 32 : 16; }
+
+// split-K plan: only when the tile grid cannot fill the chip and the k-loop is long enough to amortise
+// the slab round trip; aims at ~2 workgroups per CU.
+static int plan_splits(int M, int Cout, int KT) {
+  static const int env = getenv("SSDK_SPLITK") ? atoi(getenv("SSDK_SPLITK")) : 1;
+  if (!env) return 1;
+  const int bn = gemm_bn(Cout);
+  const long tiles = (long)((M + BM - 1) / BM) * ((Cout + bn - 1) / bn);
+  if (tiles >= 192 || KT < 16) return 1;
+  long s = (512 + tiles - 1) / tiles;
+  if (s > KT / 8) s = KT / 8;
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : (int)s;
+}
+
 template <int DT>
 static int launch_gemm(const ConvParams& p, hipStream_t stream) {
   const unsigned gm = (unsigned)((p.M + BM - 1) / BM);
+  const unsigned gz = (unsigned)p.ksplits;
   if (p.Cout > 64) {
-    dim3 grid(gm, (unsigned)((p.Cout + 127) / 128));
+    dim3 grid(gm, (unsigned)((p.Cout + 127) / 128), gz);
     hipLaunchKernelGGL((conv_gemm_kernel<DT, 2, 2, 4, 4>), grid, dim3(kConvThreads), 0, stream, p);
   } else if (p.Cout > 32) {
-    dim3 grid(gm, (unsigned)((p.Cout + 63) / 64));
+    dim3 grid(gm, (unsigned)((p.Cout + 63) / 64), gz);
     hipLaunchKernelGGL((conv_gemm_kernel<DT, 4, 1, 2, 4>), grid, dim3(kConvThreads), 0, stream, p);
   } else if (p.Cout > 16) {
-    dim3 grid(gm, 1);
+    dim3 grid(gm, 1, gz);
     hipLaunchKernelGGL((conv_gemm_kernel<DT, 4, 1, 2, 2>), grid, dim3(kConvThreads), 0, stream, p);
   } else {
-    dim3 grid(gm, 1);
+    dim3 grid(gm, 1, gz);
     hipLaunchKernelGGL((conv_gemm_kernel<DT, 4, 1, 2, 1>), grid, dim3(kConvThreads), 0, stream, p);
   }
   return check_launch("conv_gemm_kernel");
@@ -496,11 +567,29 @@ static int launch_gemm(const ConvParams& p, hipStream_t stream) {
 
 using namespace ssdk;
 
-extern "C" size_t ssdk_conv_workspace_bytes(int, int, int, int, int, int, int, int) { return 0; }
+static size_t splitk_ws_bytes(long M, int Cin, int Cout, int k, int* splits_out, int* kt_per_out) {
+  const int cin_chunks = (Cin + BK - 1) / BK;
+  const int KT = k * k * cin_chunks;
+  int splits = plan_splits((int)M, Cout, KT);
+  const int kt_per = (KT + splits - 1) / splits;
+  splits = (KT + kt_per - 1) / kt_per;  // every split owns at least one k-tile
+  if (splits_out) *splits_out = splits;
+  if (kt_per_out) *kt_per_out = kt_per;
+  if (splits <= 1) return 0;
+  const int bn = gemm_bn(Cout);
+  const size_t tiles = (size_t)((M + BM - 1) / BM) * ((Cout + bn - 1) / bn);
+  return 4096 /* counters */ + tiles * splits * (size_t)BM * bn * 4;
+}
+
+extern "C" size_t ssdk_conv_workspace_bytes(int N, int Cin, int H, int W, int Cout, int k, int stride, int dtype) {
+  (void)dtype;
+  if (Cin <= 4 || (k != 1 && k != 3) || (stride != 1 && stride != 2)) return 0;
+  const int pad = k / 2;
+  const long M = (long)N * ((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
+  return splitk_ws_bytes(M, Cin, Cout, k, nullptr, nullptr);
+}
 
 extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream_) {
-  (void)workspace;
-  (void)workspace_bytes;
   hipStream_t stream = (hipStream_t)stream_;
   if (!d || !d->x || !d->w || !d->bias || !d->y) {
     set_error("conv: null pointer (x, w, bias and y are mandatory)");
@@ -641,6 +730,22 @@ extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t worksp
   p.split = split;
   p.in_layout = d->in_layout;
   p.out_layout = d->out_layout;
+  p.ksplits = 1;
+  p.kt_per = p.KT;
+  p.slabs = nullptr;
+  p.counters = nullptr;
+  {
+    int splits = 1, kt_per = p.KT;
+    const size_t need = splitk_ws_bytes(M, d->Cin, d->Cout, d->k, &splits, &kt_per);
+    const int tiles = ((int)((M + BM - 1) / BM)) * ((d->Cout + gemm_bn(d->Cout) - 1) / gemm_bn(d->Cout));
+    // the workspace is optional: without one (or a too small one) the layer simply runs unsplit
+    if (splits > 1 && workspace && workspace_bytes >= need && !((uintptr_t)workspace & 255) && tiles * 4 <= 4096) {
+      p.ksplits = splits;
+      p.kt_per = kt_per;
+      p.counters = (unsigned*)workspace;  // zero on entry (allocated zeroed; re-armed by every last arriver)
+      p.slabs = (float*)((char*)workspace + 4096);
+    }
+  }
   return d->dtype == SSDK_BF16 ? launch_gemm<SSDK_BF16>(p, stream) : launch_gemm<SSDK_F16>(p, stream);
 }
 

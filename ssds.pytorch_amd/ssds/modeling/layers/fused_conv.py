@@ -219,6 +219,20 @@ def fill_desc(d, x_ptr, n, h, w, pack, dtype_code, act, y_ptr, in_layout=N.NHWC,
     return d
 
 
+_SPLITK_WS = {}
+
+
+def _splitk_ws(device, nbytes):
+    """Zero-initialised split-K scratch per (device, stream); the kernels re-arm their counters, so it stays
+    valid across calls as long as calls on it are stream-ordered."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SPLITK_WS.get(key)
+    if buf is None or buf.numel() < nbytes + 256:
+        buf = torch.zeros(nbytes + 256, dtype=torch.uint8, device=device)
+        _SPLITK_WS[key] = buf
+    return buf
+
+
 def conv_native(x, pack, act=None, residual=None, nchw_out=False, split=None, act2=None):
     """One fused layer.  x: [N,C,H,W] tensor in channels_last memory (converted if not; the stem also takes
     plain NCHW).  Returns a channels_last tensor, or NCHW tensor(s) when ``nchw_out`` (heads)."""
@@ -246,7 +260,13 @@ def conv_native(x, pack, act=None, residual=None, nchw_out=False, split=None, ac
                   N.NCHW if nchw_out else N.NHWC, residual.data_ptr() if residual is not None else None,
                   y2.data_ptr() if y2 is not None else None, split, act2)
     with torch.cuda.device(x.device):
-        rc = N.lib.ssdk_conv(ctypes.byref(d), None, 0, N.stream_ptr(x.device))
+        need = int(N.lib.ssdk_conv_workspace_bytes(n, pack.cin, h, w, pack.cout, pack.k, pack.stride, N.dtype_code(x)))
+        if need:
+            ws = _splitk_ws(x.device, need)
+            wptr = (ws.data_ptr() + 255) & ~255
+            rc = N.lib.ssdk_conv(ctypes.byref(d), wptr, ws.numel() - (wptr - ws.data_ptr()), N.stream_ptr(x.device))
+        else:
+            rc = N.lib.ssdk_conv(ctypes.byref(d), None, 0, N.stream_ptr(x.device))
     N.check(rc, "conv")
     STATS["native_layers"] += 1
     return (y, y2) if y2 is not None else y
@@ -335,6 +355,14 @@ class ConvPlan(object):
         self.arena.release(val[0])
 
     def finalize(self):
+        need = 0
+        for L in self.layers:
+            if L.get("kind") != "mb":
+                pk = L["pack"]
+                need = max(need, int(N.lib.ssdk_conv_workspace_bytes(L["n"], pk.cin, L["h"], L["w"], pk.cout, pk.k,
+                                                                      pk.stride, self.dtype_code)))
+        # split-K scratch (fp32 slabs + arrival counters): zero-initialised once, re-armed by the kernels
+        self.ws = torch.zeros(need + 256, dtype=torch.uint8, device=self.device) if need else None
         self.ops = (N.Op * len(self.layers))()
         for i, L in enumerate(self.layers):
             x_ptr = self.arena.ptr(L["x"]) if L["x"] is not None else 0
@@ -379,7 +407,12 @@ class ConvPlan(object):
             loc.append(l)
             conf.append(c)
         with torch.cuda.device(self.device):
-            rc = N.lib.ssdk_run_ops(self.ops, len(self.layers), None, 0, N.stream_ptr(self.device))
+            if self.ws is not None:
+                wptr = (self.ws.data_ptr() + 255) & ~255
+                rc = N.lib.ssdk_run_ops(self.ops, len(self.layers), wptr, self.ws.numel() - (wptr - self.ws.data_ptr()),
+                                        N.stream_ptr(self.device))
+            else:
+                rc = N.lib.ssdk_run_ops(self.ops, len(self.layers), None, 0, N.stream_ptr(self.device))
         N.check(rc, "run_ops")
         STATS["plan_runs"] += 1
         STATS["native_layers"] += len(self.layers)
