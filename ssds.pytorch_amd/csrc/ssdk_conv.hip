@@ -102,7 +102,7 @@ __device__ __forceinline__ u32 swz(u32 row, u32 chunk) {
 constexpr int kConvThreads = 256;
 constexpr int BM = 128, BK = 32;
 
-template <int DT, int WAVES_M, int WAVES_N, int FM, int FN>
+template <int DT, int WAVES_M, int WAVES_N, int FM, int FN, bool SPLITK = false>
 __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParams p) {
   constexpr int BN = WAVES_N * FN * 16;
   static_assert(WAVES_M * FM * 16 == BM, "tile");
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
 
   // k-tiles are visited tap-major, channel-chunk-minor; the running state below replaces the per-tile
   // divisions (kt / cin_chunks, kpos / k ...) that used to cost ~90 VALU + ~90 SALU per k-step.
-  const int kt_begin = (int)blockIdx.z * p.kt_per;
-  const int kt_end = (kt_begin + p.kt_per < p.KT) ? kt_begin + p.kt_per : p.KT;
+  const int kt_begin = SPLITK ? (int)blockIdx.z * p.kt_per : 0;
+  const int kt_end = (SPLITK && kt_begin + p.kt_per < p.KT) ? kt_begin + p.kt_per : p.KT;
   int t_kpos = kt_begin / p.cin_chunks, t_cc = kt_begin % p.cin_chunks;
   int t_ky = t_kpos / p.k, t_kx = t_kpos % p.k;
   u32x4 ra[2], rb[B_PER];
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
     __syncthreads();
   }
 
-  if (p.ksplits > 1) {
+  if constexpr (SPLITK) {
     // ---- split-K hand-off (cdna_hip_programming.md G16, counter form): slab stores -> every wave drains
     //      vmcnt -> barrier -> one lane: agent release + drained wait -> relaxed ticket; the last arriver
     //      acquires once, then every wave reads the other slabs with plain loads. ------------------------
@@ -547,19 +547,17 @@ template <int DT>
 static int launch_gemm(const ConvParams& p, hipStream_t stream) {
   const unsigned gm = (unsigned)((p.M + BM - 1) / BM);
   const unsigned gz = (unsigned)p.ksplits;
-  if (p.Cout > 64) {
-    dim3 grid(gm, (unsigned)((p.Cout + 127) / 128), gz);
-    hipLaunchKernelGGL((conv_gemm_kernel<DT, 2, 2, 4, 4>), grid, dim3(kConvThreads), 0, stream, p);
-  } else if (p.Cout > 32) {
-    dim3 grid(gm, (unsigned)((p.Cout + 63) / 64), gz);
-    hipLaunchKernelGGL((conv_gemm_kernel<DT, 4, 1, 2, 4>), grid, dim3(kConvThreads), 0, stream, p);
-  } else if (p.Cout > 16) {
-    dim3 grid(gm, 1, gz);
-    hipLaunchKernelGGL((conv_gemm_kernel<DT, 4, 1, 2, 2>), grid, dim3(kConvThreads), 0, stream, p);
-  } else {
-    dim3 grid(gm, 1, gz);
-    hipLaunchKernelGGL((conv_gemm_kernel<DT, 4, 1, 2, 1>), grid, dim3(kConvThreads), 0, stream, p);
-  }
+#define SSDK_GEMM(WM, WN, FM_, FN_, GY)                                                                          \
+  do {                                                                                                          \
+    dim3 grid(gm, (unsigned)(GY), gz);                                                                          \
+    if (gz > 1) hipLaunchKernelGGL((conv_gemm_kernel<DT, WM, WN, FM_, FN_, true>), grid, dim3(kConvThreads), 0, stream, p); \
+    else hipLaunchKernelGGL((conv_gemm_kernel<DT, WM, WN, FM_, FN_, false>), grid, dim3(kConvThreads), 0, stream, p);      \
+  } while (0)
+  if (p.Cout > 64) SSDK_GEMM(2, 2, 4, 4, (p.Cout + 127) / 128);
+  else if (p.Cout > 32) SSDK_GEMM(4, 1, 2, 4, (p.Cout + 63) / 64);
+  else if (p.Cout > 16) SSDK_GEMM(4, 1, 2, 2, 1);
+  else SSDK_GEMM(4, 1, 2, 1, 1);
+#undef SSDK_GEMM
   return check_launch("conv_gemm_kernel");
 }
 
