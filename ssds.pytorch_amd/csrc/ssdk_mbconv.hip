@@ -16,6 +16,8 @@
 //
 // Two barriers per chunk.  HBM traffic = block input (with a 1.13-1.56x halo) + block output + weights
 // from L2: the roofline of the fused block is its input+output bytes.
+#include <stdio.h>
+
 #include "ssdk_common.h"
 
 namespace ssdk {
@@ -43,6 +45,7 @@ struct MbParams {
   // stem mode: x is the [N,Cimg,Himg,Wimg] image (1 = NCHW, 2 = NHWC); the "expand" GEMM is the 3x3/s2 stem
   // conv on an im2col image of the tile built in LDS (K = 9*Cimg <= 32); H, W are the stem-output grid.
   int stem, Himg, Wimg, Cimg;
+  unsigned long long* dbg;  // SSDK_MB_DBG=1: cycle stamps of workgroup 0 (debug builds of the schedule only)
 };
 
 template <int DT> __device__ __forceinline__ u32 mb_to16(float v) {
@@ -279,7 +282,24 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   const u32 d_oy = d_px >> 3, d_ox = d_px & 7u;
   const u32 m_fr = wave & 3u, n_half = wave >> 2;  // P3 role: pixel frag, interleaved half of the n-frags
 
+  f32x4 sp4[NFH], bp4[NFH];  // projection BN (loop invariant: loaded once per workgroup)
+#pragma unroll
+  for (int jj = 0; jj < NFH; ++jj) {
+    const int co = ((int)n_half + 2 * jj) * 16 + (int)fg * 4;
+    sp4[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bp4[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (co < Cout) {
+      sp4[jj] = *reinterpret_cast<const f32x4*>(p.sp + co);
+      bp4[jj] = *reinterpret_cast<const f32x4*>(p.bp + co);
+    }
+  }
+  int dbg_k = 0;
+#define MB_STAMP()                                                                         \
+  do {                                                                                     \
+    if (p.dbg && blockIdx.x == 0 && tid == 0 && dbg_k < 60) p.dbg[dbg_k++] = __builtin_readcyclecounter(); \
+  } while (0)
   for (; tile < ntiles; tile += gridDim.x) {  // one iteration unless RESIDENT (persistent grid)
+  MB_STAMP();
   tile_coords(tile, n, oy0, ox0);
   iy0 = oy0 * S - 1;
   ix0 = ox0 * S - 1;
@@ -303,6 +323,7 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   for (int j = 0; j < NFH; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
+  MB_STAMP();
   for (int c = 0; c < nchunks; ++c) {
     const unsigned char* wcur = sW + (size_t)(RESIDENT ? c : (c & 1)) * p.wbuf;
     if constexpr (!RESIDENT)
@@ -346,7 +367,9 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
         }
       }
     }
+    MB_STAMP();
     __syncthreads();
+    MB_STAMP();
     // ---- P2: depthwise 3x3 stride S on the chunk, packed fp16 (4 channels per lane) -> sD ----------------
     {
       h2 acc0 = {(_Float16)0.f, (_Float16)0.f}, acc1 = acc0;
@@ -369,7 +392,9 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
     }
     if constexpr (!RESIDENT)
       if (c + 1 < nchunks) store_w((c + 1) & 1);  // visible to the next chunk's P1 after the barrier below
+    MB_STAMP();
     __syncthreads();
+    MB_STAMP();
     // ---- P3: project: wave (m_fr, n_half) owns pixels [16 m_fr, +16) x n-frags n_half, n_half+2, ... ----
     {
       const u32x4 df = *reinterpret_cast<const u32x4*>(sD + (size_t)(m_fr * 16 + fr) * ES + fg * 16);
@@ -385,6 +410,7 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
     // weight buffer only after the barrier that follows its P1, i.e. after every wave has passed this P3.
   }
 
+  MB_STAMP();
   // ---- epilogue -------------------------------------------------------------------------------------
   const int q = (int)m_fr * 16 + (int)fr;  // output pixel inside the tile
   const int oy = oy0 + (q >> 3), ox = ox0 + (q & 7);
@@ -395,11 +421,9 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
     for (int jj = 0; jj < NFH; ++jj) {
       const int co = ((int)n_half + 2 * jj) * 16 + (int)fg * 4;
       if (co < Cout) {  // Cout is a multiple of 8, so 4-channel groups are all-or-nothing
-        const f32x4 sp4 = *reinterpret_cast<const f32x4*>(p.sp + co);
-        const f32x4 bp4 = *reinterpret_cast<const f32x4*>(p.bp + co);
         u32 h[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = mb_to16<DT>(fmaf(yacc[jj][r], sp4[r], bp4[r]));
+        for (int r = 0; r < 4; ++r) h[r] = mb_to16<DT>(fmaf(yacc[jj][r], sp4[jj][r], bp4[jj][r]));
         if (p.residual) {
           const uint2 xv = *reinterpret_cast<const uint2*>(xres + co * 2);
           const u32 xr[4] = {xv.x & 0xffffu, xv.x >> 16, xv.y & 0xffffu, xv.y >> 16};
@@ -410,7 +434,9 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
       }
     }
   }
+  MB_STAMP();
   }  // tile loop
+#undef MB_STAMP
 }
 
 template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = false>
@@ -529,6 +555,14 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
     set_error("mbconv: tile needs %zu bytes of LDS", lds);
     return SSDK_E_BADARG;
   }
+  p.dbg = nullptr;
+  static const int env_dbg = getenv("SSDK_MB_DBG") ? atoi(getenv("SSDK_MB_DBG")) : 0;
+  static unsigned long long* dbg_dev = nullptr;
+  if (env_dbg) {
+    if (!dbg_dev) (void)hipMalloc(&dbg_dev, 64 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dbg_dev, 0, 64 * sizeof(unsigned long long), stream);
+    p.dbg = dbg_dev;
+  }
   unsigned grid = (unsigned)((long)d->N * p.tiles_x * p.tiles_y);
   if (resident) {  // persistent: as many workgroups as stay resident (LDS- and wave-limited: <= 4 x 8 waves per CU)
     static int cus = 0;
@@ -545,9 +579,21 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
     if (grid > cap) grid = cap;
   }
   const int nfo = (d->Cout + 15) / 16, ks = (p.Cin + 31) / 32;
+  int rc;
   if (d->dtype == SSDK_BF16)
-    return d->stride == 1 ? launch_mb<SSDK_BF16, 1>(p, ks, nfo, lds, grid, stream, resident)
-                          : launch_mb<SSDK_BF16, 2>(p, ks, nfo, lds, grid, stream, resident);
-  return d->stride == 1 ? launch_mb<SSDK_F16, 1>(p, ks, nfo, lds, grid, stream, resident)
+    rc = d->stride == 1 ? launch_mb<SSDK_BF16, 1>(p, ks, nfo, lds, grid, stream, resident)
+                        : launch_mb<SSDK_BF16, 2>(p, ks, nfo, lds, grid, stream, resident);
+  else
+    rc = d->stride == 1 ? launch_mb<SSDK_F16, 1>(p, ks, nfo, lds, grid, stream, resident)
                         : launch_mb<SSDK_F16, 2>(p, ks, nfo, lds, grid, stream, resident);
+  if (env_dbg && rc == 0) {  // debug only: synchronises
+    unsigned long long h[64];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[mbconv dbg] Cin=%d Chid=%d Cout=%d s=%d stem=%d res=%d grid=%u lds=%zu :", d->Cin, d->Chid,
+            d->Cout, d->stride, p.stem, (int)resident, grid, lds);
+    for (int i = 1; i < 60 && h[i]; ++i) fprintf(stderr, " %llu", h[i] - h[i - 1]);
+    fprintf(stderr, "\n");
+  }
+  return rc;
 }
