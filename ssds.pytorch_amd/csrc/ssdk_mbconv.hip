@@ -45,6 +45,7 @@ struct MbParams {
   // stem mode: x is the [N,Cimg,Himg,Wimg] image (1 = NCHW, 2 = NHWC); the "expand" GEMM is the 3x3/s2 stem
   // conv on an im2col image of the tile built in LDS (K = 9*Cimg <= 32); H, W are the stem-output grid.
   int stem, Himg, Wimg, Cimg;
+  int hc;                    // hidden channels per chunk (32 | 64)
   unsigned long long* dbg;  // SSDK_MB_DBG=1: cycle stamps of workgroup 0 (debug builds of the schedule only)
 };
 
@@ -79,23 +80,30 @@ __device__ __forceinline__ u32 pk_relu6_f16(float a, float b) {  // clamp to [0,
 
 constexpr int kMbThreads = 512;  // 8 waves: two per SIMD, so LDS / MFMA latencies of one wave hide under the other
 constexpr int kMbWaves = kMbThreads / 64;
-constexpr int HC = 32;       // hidden channels per chunk
-constexpr int ES = 80;       // LDS row stride (bytes) of sE / sD / staged Wp: 32 halves + 16 B pad
 constexpr int MAX_KS = 5;    // Cin <= 160
-constexpr int SB_BYTES = 128 + 128 + 64;  // se, be (fp32 x32), bd (fp16 x32)
+// HC = hidden channels per chunk (32 or 64): ES = HC halves + 16 B pad is the LDS row stride of sE / sD / the
+// staged Wp (an odd number of 16-byte slots); the staged per-chunk scalars are se, be (fp32 x HC), bd (fp16 x HC).
+constexpr int es_of(int hc) { return hc * 2 + 16; }
+constexpr int sb_of(int hc) { return hc * 10; }
 
 // E (expanded) and D (depthwise output) are INTERNAL tensors: they are kept in fp16 whatever the model
 // dtype (values are ReLU6-bounded, fp16 carries 3 more mantissa bits than bf16), so P2 runs on packed
 // fp16 math (v_pk_fma_f16: 2 channels per instruction) and P3 on the f16 MFMA with fp16 projection weights.
-template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = false>
+template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = false, int HC = 32>
 __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
+  constexpr int ES = es_of(HC);
+  constexpr int NJ = HC / 16;   // n-frags of the expand GEMM per chunk
+  constexpr int KP = HC / 32;   // k-steps of the projection per chunk
+  constexpr int NI = HC / 32;   // depthwise items (4 channels of one pixel) per thread
+  constexpr int HP = HC / 8;    // 16-byte pieces per HC halves
   constexpr int RW = 8 * S + (3 - S);          // 10 (s=1) or 17 (s=2) input columns / rows per tile
   constexpr int P = RW * RW;                   // region pixels
   constexpr int MF = (P + 15) / 16;            // m-frags of the expand GEMM
   constexpr int P16 = MF * 16;
   constexpr int MFW = (MF + kMbWaves - 1) / kMbWaves;                   // m-frags per wave (max)
-  constexpr int NPA = (32 * KSMAX * 4 + kMbThreads - 1) / kMbThreads;   // We pieces per thread
-  constexpr int NPB = (NFO * 16 * 4 + kMbThreads - 1) / kMbThreads;     // Wp pieces per thread
+  constexpr int NPA = (HC * KSMAX * 4 + kMbThreads - 1) / kMbThreads;   // We pieces per thread
+  constexpr int NPB = (NFO * 16 * HP + kMbThreads - 1) / kMbThreads;    // Wp pieces per thread
+  constexpr int NM_WD = 9 * HP, NM_S = HC / 4, NM_B = HP;               // misc pieces: Wd, se|be, bd
   constexpr int NFH = NFO / 2;                                          // projection n-frags per wave
   constexpr int NPX = STEM ? (P16 * 9 + kMbThreads - 1) / kMbThreads                      // (pixel, tap) items
                            : (P16 * KSMAX * 4 + kMbThreads - 1) / kMbThreads;             // 16-byte pieces of sX
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   for (int i = 0; i < NPA; ++i) {
     const int q = (int)tid + i * kMbThreads;
     const int row = q / cpr, c = q % cpr;
-    a_row[i] = row < 32 ? row : (1 << 30);   // invalid pieces never pass "hc0 + row < Chid"
+    a_row[i] = row < HC ? row : (1 << 30);   // invalid pieces never pass "hc0 + row < Chid"
     a_src[i] = row * Cin + c * 8;
     a_dst[i] = row * WES + c * 16;
   }
@@ -137,31 +145,33 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
 #pragma unroll
   for (int i = 0; i < NPB; ++i) {
     const int q = (int)tid + i * kMbThreads;
-    const int row = q >> 2, c = q & 3;
-    b_c8[i] = (row < Cout && q < NFO * 64) ? c * 8 : (1 << 30);
+    const int row = q / HP, c = q % HP;
+    b_c8[i] = (row < Cout && q < NFO * 16 * HP) ? c * 8 : (1 << 30);
     b_src[i] = row * Chid + c * 8;
-    b_dst[i] = (q < NFO * 64) ? p.off_wp + row * ES + c * 16 : -1;
+    b_dst[i] = (q < NFO * 16 * HP) ? p.off_wp + row * ES + c * 16 : -1;
   }
-  // tid < 56: one piece of {Wd (36), se (8), be (8), bd (4)}
+  // tid < NM_WD + 2*NM_S + NM_B: one piece of {Wd (9 taps x HC), se, be (fp32 x HC), bd (fp16 x HC)}
   const u16* c_src = nullptr;
   int c_mul = 0, c_off = 1 << 30, c_dst = -1;
-  if (tid < 36) {
-    c_src = p.wd + (size_t)(tid >> 2) * Chid + (tid & 3) * 8;
+  if (tid < NM_WD) {
+    const int tap = (int)tid / HP, c = (int)tid % HP;
+    c_src = p.wd + (size_t)tap * Chid + c * 8;
     c_mul = 1;
-    c_off = (int)(tid & 3) * 8;
-    c_dst = p.off_wd + (int)tid * 16;
-  } else if (tid < 52) {
-    const int c = ((int)tid - 36) & 7;
-    c_src = reinterpret_cast<const u16*>((tid < 44 ? p.se : p.be) + c * 4);
+    c_off = c * 8;
+    c_dst = p.off_wd + tap * (HC * 2) + c * 16;
+  } else if (tid < NM_WD + 2 * NM_S) {
+    const int r = (int)tid - NM_WD;
+    const int c = r % NM_S;
+    c_src = reinterpret_cast<const u16*>((r < NM_S ? p.se : p.be) + c * 4);
     c_mul = 2;  // fp32: two u16 per element
     c_off = c * 4;
-    c_dst = p.off_sb + ((int)tid - 36) * 16;
-  } else if (tid < 56) {
-    const int c = (int)tid - 52;
+    c_dst = p.off_sb + r * 16;
+  } else if (tid < NM_WD + 2 * NM_S + NM_B) {
+    const int c = (int)tid - NM_WD - 2 * NM_S;
     c_src = p.bd + c * 8;
     c_mul = 1;
     c_off = c * 8;
-    c_dst = p.off_sb + 256 + c * 16;
+    c_dst = p.off_sb + HC * 8 + c * 16;
   }
   u32x4 ra[NPA], rb[NPB], rc;
   auto load_w = [&](int hc0) {
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
     unsigned char* w = sW + (size_t)buf * p.wbuf;
 #pragma unroll
     for (int i = 0; i < NPA; ++i)
-      if (a_row[i] < 32) *reinterpret_cast<u32x4*>(w + a_dst[i]) = ra[i];
+      if (a_row[i] < HC) *reinterpret_cast<u32x4*>(w + a_dst[i]) = ra[i];
 #pragma unroll
     for (int i = 0; i < NPB; ++i)
       if (b_dst[i] >= 0) *reinterpret_cast<u32x4*>(w + b_dst[i]) = rb[i];
@@ -330,40 +340,45 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
       if (c + 1 < nchunks) load_w((c + 1) * HC);  // next chunk's weights in flight under this chunk's work
     // ---- P1: expand the region for channels [hc0, hc0+32) -> sE (fp16) -----------------------------
     {
-      const f32x4 se0 = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + (fg * 4) * 4);
-      const f32x4 se1 = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + (16 + fg * 4) * 4);
-      const f32x4 be0 = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + 128 + (fg * 4) * 4);
-      const f32x4 be1 = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + 128 + (16 + fg * 4) * 4);
+      f32x4 sev[NJ], bev[NJ];
+#pragma unroll
+      for (int jf = 0; jf < NJ; ++jf) {
+        sev[jf] = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + (jf * 16 + fg * 4) * 4);
+        bev[jf] = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + HC * 4 + (jf * 16 + fg * 4) * 4);
+      }
 #pragma unroll
       for (int i = 0; i < MFW; ++i) {
         const int mf = (int)wave + kMbWaves * i;
         if (mf < MF) {  // wave-uniform
-          f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+          f32x4 e[NJ];
+#pragma unroll
+          for (int jf = 0; jf < NJ; ++jf) e[jf] = f32x4{0.f, 0.f, 0.f, 0.f};
           const unsigned char* xrow = sX + (size_t)(mf * 16 + (int)fr) * XS;
 #pragma unroll
           for (int ks = 0; ks < KSMAX; ++ks) {
             if (ks < KS) {
-              u32x4 xf = {0u, 0u, 0u, 0u}, w0 = {0u, 0u, 0u, 0u}, w1 = {0u, 0u, 0u, 0u};
               const int k = ks * 32 + (int)fg * 8;
-              if (k < Cin) {
-                xf = *reinterpret_cast<const u32x4*>(xrow + k * 2);
-                w0 = *reinterpret_cast<const u32x4*>(wcur + (size_t)fr * WES + k * 2);
-                w1 = *reinterpret_cast<const u32x4*>(wcur + (size_t)(16 + fr) * WES + k * 2);
+              u32x4 xf = {0u, 0u, 0u, 0u};
+              if (k < Cin) xf = *reinterpret_cast<const u32x4*>(xrow + k * 2);
+#pragma unroll
+              for (int jf = 0; jf < NJ; ++jf) {
+                u32x4 wv = {0u, 0u, 0u, 0u};
+                if (k < Cin) wv = *reinterpret_cast<const u32x4*>(wcur + (size_t)(jf * 16 + fr) * WES + k * 2);
+                e[jf] = mb_mfma<DT>(wv, xf, e[jf]);  // D[hc = fg*4+r][pixel = fr]
               }
-              e0 = mb_mfma<DT>(w0, xf, e0);  // D[hc = fg*4+r][pixel = fr]
-              e1 = mb_mfma<DT>(w1, xf, e1);
             }
           }
-          uint2 o0 = make_uint2(0u, 0u), o1 = make_uint2(0u, 0u);
-          if ((pvalid >> i) & 1u) {
-            o0.x = pk_relu6_f16(fmaf(e0[0], se0[0], be0[0]), fmaf(e0[1], se0[1], be0[1]));
-            o0.y = pk_relu6_f16(fmaf(e0[2], se0[2], be0[2]), fmaf(e0[3], se0[3], be0[3]));
-            o1.x = pk_relu6_f16(fmaf(e1[0], se1[0], be1[0]), fmaf(e1[1], se1[1], be1[1]));
-            o1.y = pk_relu6_f16(fmaf(e1[2], se1[2], be1[2]), fmaf(e1[3], se1[3], be1[3]));
-          }
+          const bool ok = (pvalid >> i) & 1u;
           unsigned char* erow = sE + (size_t)(mf * 16 + (int)fr) * ES;
-          *reinterpret_cast<uint2*>(erow + (fg * 4) * 2) = o0;
-          *reinterpret_cast<uint2*>(erow + (16 + fg * 4) * 2) = o1;
+#pragma unroll
+          for (int jf = 0; jf < NJ; ++jf) {
+            uint2 o = make_uint2(0u, 0u);
+            if (ok) {
+              o.x = pk_relu6_f16(fmaf(e[jf][0], sev[jf][0], bev[jf][0]), fmaf(e[jf][1], sev[jf][1], bev[jf][1]));
+              o.y = pk_relu6_f16(fmaf(e[jf][2], sev[jf][2], bev[jf][2]), fmaf(e[jf][3], sev[jf][3], bev[jf][3]));
+            }
+            *reinterpret_cast<uint2*>(erow + (jf * 16 + fg * 4) * 2) = o;
+          }
         }
       }
     }
@@ -372,23 +387,33 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
     MB_STAMP();
     // ---- P2: depthwise 3x3 stride S on the chunk, packed fp16 (4 channels per lane) -> sD ----------------
     {
-      h2 acc0 = {(_Float16)0.f, (_Float16)0.f}, acc1 = acc0;
+      const h2 zero = {(_Float16)0.f, (_Float16)0.f}, six = {(_Float16)6.f, (_Float16)6.f};
+      h2 acc0[NI], acc1[NI];
+#pragma unroll
+      for (int it = 0; it < NI; ++it) acc0[it] = acc1[it] = zero;
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const int rp = ((int)d_oy * S + ky) * RW + (int)d_ox * S + kx;
-          const uint2 ev = *reinterpret_cast<const uint2*>(sE + (size_t)rp * ES + d_cg * 8);
-          const uint2 wv = *reinterpret_cast<const uint2*>(wcur + p.off_wd + (ky * 3 + kx) * 64 + d_cg * 8);
-          acc0 = __builtin_elementwise_fma(as_h2(ev.x), as_h2(wv.x), acc0);
-          acc1 = __builtin_elementwise_fma(as_h2(ev.y), as_h2(wv.y), acc1);
+#pragma unroll
+          for (int it = 0; it < NI; ++it) {  // independent chains: channel groups d_cg and d_cg + 8
+            const u32 cg = d_cg + 8u * it;
+            const uint2 ev = *reinterpret_cast<const uint2*>(sE + (size_t)rp * ES + cg * 8);
+            const uint2 wv = *reinterpret_cast<const uint2*>(wcur + p.off_wd + (ky * 3 + kx) * (HC * 2) + cg * 8);
+            acc0[it] = __builtin_elementwise_fma(as_h2(ev.x), as_h2(wv.x), acc0[it]);
+            acc1[it] = __builtin_elementwise_fma(as_h2(ev.y), as_h2(wv.y), acc1[it]);
+          }
         }
-      const uint2 bv = *reinterpret_cast<const uint2*>(wcur + p.off_sb + 256 + d_cg * 8);
-      const h2 zero = {(_Float16)0.f, (_Float16)0.f}, six = {(_Float16)6.f, (_Float16)6.f};
-      const h2 v0 = __builtin_elementwise_min(__builtin_elementwise_max(acc0 + as_h2(bv.x), zero), six);
-      const h2 v1 = __builtin_elementwise_min(__builtin_elementwise_max(acc1 + as_h2(bv.y), zero), six);
-      *reinterpret_cast<uint2*>(sD + (size_t)d_px * ES + d_cg * 8) =
-          make_uint2(__builtin_bit_cast(u32, v0), __builtin_bit_cast(u32, v1));
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        const u32 cg = d_cg + 8u * it;
+        const uint2 bv = *reinterpret_cast<const uint2*>(wcur + p.off_sb + HC * 8 + cg * 8);
+        const h2 v0 = __builtin_elementwise_min(__builtin_elementwise_max(acc0[it] + as_h2(bv.x), zero), six);
+        const h2 v1 = __builtin_elementwise_min(__builtin_elementwise_max(acc1[it] + as_h2(bv.y), zero), six);
+        *reinterpret_cast<uint2*>(sD + (size_t)d_px * ES + cg * 8) =
+            make_uint2(__builtin_bit_cast(u32, v0), __builtin_bit_cast(u32, v1));
+      }
     }
     if constexpr (!RESIDENT)
       if (c + 1 < nchunks) store_w((c + 1) & 1);  // visible to the next chunk's P1 after the barrier below
@@ -397,12 +422,18 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
     MB_STAMP();
     // ---- P3: project: wave (m_fr, n_half) owns pixels [16 m_fr, +16) x n-frags n_half, n_half+2, ... ----
     {
-      const u32x4 df = *reinterpret_cast<const u32x4*>(sD + (size_t)(m_fr * 16 + fr) * ES + fg * 16);
+      u32x4 df[KP];
+#pragma unroll
+      for (int kp = 0; kp < KP; ++kp)
+        df[kp] = *reinterpret_cast<const u32x4*>(sD + (size_t)(m_fr * 16 + fr) * ES + kp * 64 + fg * 16);
 #pragma unroll
       for (int jj = 0; jj < NFH; ++jj) {
         const int j = (int)n_half + 2 * jj;
-        const u32x4 wf = *reinterpret_cast<const u32x4*>(wcur + p.off_wp + (size_t)(j * 16 + fr) * ES + fg * 16);
-        yacc[jj] = mb_mfma<SSDK_F16>(wf, df, yacc[jj]);  // D[co = fg*4+r][px = fr]
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+          const u32x4 wf = *reinterpret_cast<const u32x4*>(wcur + p.off_wp + (size_t)(j * 16 + fr) * ES + kp * 64 + fg * 16);
+          yacc[jj] = mb_mfma<SSDK_F16>(wf, df[kp], yacc[jj]);  // D[co = fg*4+r][px = fr]
+        }
       }
     }
     // No barrier here.  The next chunk's P1 writes sE (P2 of this chunk finished reading it before the
@@ -441,9 +472,15 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
 
 template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = false>
 static void launch_one(const MbParams& p, size_t lds, unsigned grid, hipStream_t stream) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT>), dim3(grid), dim3(kMbThreads), lds, stream, p);
+  if (p.hc == 64) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 64>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 64>), dim3(grid), dim3(kMbThreads), lds, stream, p);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 32>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 32>), dim3(grid), dim3(kMbThreads), lds, stream, p);
+  }
 }
 
 // (k-steps of the expand GEMM, n-frags of the projection) pairs of the MobileNetV2 family get their own
@@ -541,16 +578,32 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   const int nfo_t = (d->Cout + 15) / 16;
   const int nfo_inst = nfo_t <= 2 ? 2 : nfo_t <= 4 ? 4 : nfo_t <= 6 ? 6 : nfo_t <= 10 ? 10 : 20;
   p.wes = p.xs;
-  p.off_wp = 32 * p.wes;
-  p.off_wd = p.off_wp + nfo_inst * 16 * ES;
-  p.off_sb = p.off_wd + 9 * 64;
-  p.wbuf = p.off_sb + SB_BYTES;
-  const int nchunks = (d->Chid + HC - 1) / HC;
-  static const int env_res = getenv("SSDK_MB_RESIDENT") ? atoi(getenv("SSDK_MB_RESIDENT")) : 1;
-  const size_t fixed = (size_t)p16 * p.xs + (size_t)p16 * ES + 64 * ES;
   const int ks_t = (p.Cin + 31) / 32;
-  bool resident = env_res && ks_t <= 1 && nfo_inst <= 4 && (size_t)nchunks * p.wbuf <= 56 * 1024;
-  const size_t lds = fixed + (resident ? (size_t)nchunks : 2) * (size_t)p.wbuf;
+  static const int env_res = getenv("SSDK_MB_RESIDENT") ? atoi(getenv("SSDK_MB_RESIDENT")) : 1;
+  static const int env_hc = getenv("SSDK_MB_HC") ? atoi(getenv("SSDK_MB_HC")) : 0;
+  const long tiles_total = (long)d->N * p.tiles_x * p.tiles_y;
+  bool resident = false;
+  auto layout = [&](int hc) -> size_t {  // fills the staged-buffer offsets for `hc`, returns the LDS bytes
+    const int es = es_of(hc);
+    p.hc = hc;
+    p.off_wp = hc * p.wes;
+    p.off_wd = p.off_wp + nfo_inst * 16 * es;
+    p.off_sb = p.off_wd + 9 * hc * 2;
+    p.wbuf = (p.off_sb + sb_of(hc) + 15) & ~15;
+    const int nch = (d->Chid + hc - 1) / hc;
+    resident = env_res && ks_t <= 1 && nfo_inst <= 4 && (size_t)nch * p.wbuf <= 56 * 1024;
+    return (size_t)p16 * p.xs + (size_t)p16 * es + 64 * (size_t)es + (resident ? (size_t)nch : 2) * (size_t)p.wbuf;
+  };
+  // 64-channel chunks halve the barriers per hidden channel but cost LDS (fewer workgroups per CU); measured on
+  // SSD-MobileNetV2@512 batch 64 they LOSE 13 % end to end (forward 2.93 vs 2.55 ms), so 32 is the default and
+  // SSDK_MB_HC=64 remains as an A/B switch.
+  size_t lds;
+  {
+    (void)tiles_total;
+    const size_t l64 = layout(64);
+    const int hc = (env_hc == 64 && l64 <= 160 * 1024) ? 64 : 32;
+    lds = layout(hc);
+  }
   if (lds > 160 * 1024) {
     set_error("mbconv: tile needs %zu bytes of LDS", lds);
     return SSDK_E_BADARG;
