@@ -49,8 +49,11 @@ __device__ __forceinline__ bool suppressed_by(const float4 b, float ab, const fl
   w = (w < 0.0f) ? 0.0f : w;  // clamp(0) keeps NaN like torch
   h = (h < 0.0f) ? 0.0f : h;
   const float inter = w * h;
-  float iou = inter / (ab + ap - inter + 1e-7f);
-  if (diou) {
+  const float iou = inter / (ab + ap - inter + 1e-7f);
+  bool over = !(iou <= thr);
+  // DIoU = clamp(IoU - penalty, -1, 1) with penalty >= 0: a pair with IoU <= thr can never exceed thr, so the
+  // penalty (a second division) is only evaluated for the few pairs that overlap enough (finite boxes).
+  if (over && diou) {
     const float ox1 = tmin(b.x, p.x), oy1 = tmin(b.y, p.y);
     const float ox2 = tmax(b.z, p.z), oy2 = tmax(b.w, p.w);
     const float dx = b.x - p.x, dy = b.y - p.y;
@@ -59,9 +62,14 @@ __device__ __forceinline__ bool suppressed_by(const float4 b, float ab, const fl
     const float outer_diag = (ow * ow + oh * oh) + 1e-7f;
     float v = iou - inter_diag / outer_diag;
     v = (v < -1.0f) ? -1.0f : ((v > 1.0f) ? 1.0f : v);
-    iou = v;
+    over = !(v <= thr);
   }
-  return !(iou <= thr);
+  return over;
+}
+
+// broadcast of lane j's value when j is wave-uniform: v_readlane (scalar path) instead of ds_bpermute
+__device__ __forceinline__ float bcast(float v, u32 j) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)j));
 }
 
 constexpr u32 kNmsRound = 256;  // candidates sorted + walked per round
@@ -73,12 +81,15 @@ constexpr u32 kNmsRound = 256;  // candidates sorted + walked per round
 __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
   constexpr int NT = kNmsThreads;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const u32 tid = threadIdx.x, lane = tid & 63u;
+  constexpr u32 NW = NT / 64;
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u32 b = blockIdx.x;
   const u32 N = (u32)p.N;
   u64* keys = reinterpret_cast<u64*>(smem);                        // N (unsorted; taken keys are zeroed)
   u64* top = keys + ((N + 1) & ~1u);                               // kNmsRound
-  float4* kbox = reinterpret_cast<float4*>(top + kNmsRound);       // ndet
+  u64* rows = top + kNmsRound;                                     // 64 suppression rows of the current block
+  u64* blk_dead = rows + 64;                                       // (+1 pad) dead bits from the kept-list test
+  float4* kbox = reinterpret_cast<float4*>(rows + 66);             // ndet
   float* karea = reinterpret_cast<float*>(kbox + p.ndet);          // ndet
   float* kcls = karea + p.ndet;                                    // ndet
   u32* ctl = reinterpret_cast<u32*>(kcls + p.ndet);                // [0] nvalid, [1] nk, [2] top count
@@ -97,6 +108,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
   if (tid == 0) {
     ctl[0] = 0;
     ctl[1] = 0;
+    *blk_dead = 0ull;
   }
   __syncthreads();
   u32 local = 0;
@@ -132,51 +144,71 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
     __syncthreads();
     wg_bitonic_sort_desc<NT>(top, kNmsRound);  // descending key == (score desc, position asc)
 
-    if (tid < 64) {  // the greedy walk is one wave; wave-synchronous below
-      for (u32 base = 0; base < r && nk < ndet; base += 64) {
-        const u32 i = base + lane;
-        const bool valid = i < r;
-        float score = 0.f, cls = -1.f, area = 0.f;
-        float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) {
-          const u64 k = top[i];
-          const u32 pos = key_index(k);
-          score = key_score(k);
-          box = bx[pos];
-          cls = cl[pos];
-          area = (box.z - box.x + 1.0f) * (box.w - box.y + 1.0f);  // box.py:507
+    // Greedy walk over the sorted round, 64 candidates (one per lane) at a time.  Every wave holds the same
+    // block; the pair tests are split across the waves and only the final in-order resolve is serial:
+    //   1. wave w tests the block against kept survivors k = w, w+NW, ...        -> dead bits (LDS OR)
+    //   2. wave w builds the suppression rows of pivots j in [w*64/NW, (w+1)*64/NW): row[j] = lanes i > j of
+    //      the same class that j would suppress                                   -> rows[] (LDS)
+    //   3. wave 0 walks the alive bits in order applying rows of pivots that are still alive -- exactly the
+    //      reference's sequential loop (box.py:505-530), minus the arithmetic.
+    for (u32 base = 0; base < r && nk < ndet; base += 64) {  // workgroup-uniform
+      const u32 i = base + lane;
+      const bool valid = i < r;
+      float score = 0.f, cls = -1.f, area = 0.f;
+      float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) {
+        const u64 k = top[i];
+        const u32 pos = key_index(k);
+        score = key_score(k);
+        box = bx[pos];
+        cls = cl[pos];
+        area = (box.z - box.x + 1.0f) * (box.w - box.y + 1.0f);  // box.py:507
+      }
+      bool alive = valid;
+      for (u32 k = wave; k < nk; k += NW) {
+        const float ck = kcls[k];
+        if (__ballot(alive && cls == ck) == 0ull) continue;
+        const bool sup = (cls == ck) && suppressed_by(box, area, kbox[k], karea[k], thr, diou);
+        alive = alive && !sup;
+      }
+      const u64 dead = __ballot(valid && !alive);
+      if (lane == 0 && dead) atomicOr(blk_dead, dead);
+      constexpr u32 PPW = 64 / NW;
+      for (u32 jj = 0; jj < PPW; ++jj) {
+        const u32 j = wave * PPW + jj;
+        const float cj = bcast(cls, j);
+        const u64 m = __ballot(valid && lane > j && cls == cj);
+        u64 row = 0;
+        if (m != 0ull) {
+          float4 pj;
+          pj.x = bcast(box.x, j);
+          pj.y = bcast(box.y, j);
+          pj.z = bcast(box.z, j);
+          pj.w = bcast(box.w, j);
+          const float aj = bcast(area, j);
+          row = __ballot(((m >> lane) & 1ull) && suppressed_by(box, area, pj, aj, thr, diou));
         }
-        bool alive = valid;
-        // 1. against the survivors kept so far
-        for (u32 k = 0; k < nk; ++k) {
-          const float ck = kcls[k];
-          if (__ballot(alive && cls == ck) == 0ull) continue;
-          const bool sup = (cls == ck) && suppressed_by(box, area, kbox[k], karea[k], thr, diou);
-          alive = alive && !sup;
-        }
-        // 2. inside the block, in order
-        u64 am = __ballot(alive);
+        if (lane == 0) rows[j] = row;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        u64 am = __ballot(valid) & ~*blk_dead;
+        const u64 myrow = rows[lane];
+        const u32 row_lo = (u32)myrow, row_hi = (u32)(myrow >> 32);
         u32 kept_here = 0;
-        for (u32 j = 0; j < 64; ++j) {
-          if (!((am >> j) & 1ull)) continue;
+        u64 todo = am;
+        while (todo) {
+          const u32 j = (u32)__ffsll((long long)todo) - 1u;
           if (nk + kept_here >= ndet) {  // truncated to ndetections survivors (box.py:512)
             am &= (1ull << j) - 1ull;
             break;
           }
           ++kept_here;
-          const float cj = __shfl(cls, (int)j);
-          const u64 m = __ballot(((am >> lane) & 1ull) && lane > j && cls == cj);
-          if (m == 0ull) continue;
-          float4 pj;
-          pj.x = __shfl(box.x, (int)j);
-          pj.y = __shfl(box.y, (int)j);
-          pj.z = __shfl(box.z, (int)j);
-          pj.w = __shfl(box.w, (int)j);
-          const float aj = __shfl(area, (int)j);
-          const bool sup = ((m >> lane) & 1ull) && suppressed_by(box, area, pj, aj, thr, diou);
-          am &= ~__ballot(sup);
+          const u64 rj = (u64)(u32)__builtin_amdgcn_readlane((int)row_lo, (int)j) |
+                         ((u64)(u32)__builtin_amdgcn_readlane((int)row_hi, (int)j) << 32);
+          am &= ~rj;
+          todo = am & ~((2ull << j) - 1ull);  // alive candidates after j
         }
-        // 3. append the block's survivors
         const bool keep = (am >> lane) & 1ull;
         const u32 slot = nk + mbcnt(am);
         if (keep && slot < ndet) {
@@ -187,13 +219,16 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
           ob[slot] = box;
           oc[slot] = cls;
         }
-        nk += (u32)__popcll(am);
-        if (nk > ndet) nk = ndet;
+        u32 nk2 = nk + (u32)__popcll(am);
+        if (nk2 > ndet) nk2 = ndet;
+        if (lane == 0) {
+          ctl[1] = nk2;
+          *blk_dead = 0ull;
+        }
       }
-      if (lane == 0) ctl[1] = nk;
+      __syncthreads();
+      nk = ctl[1];
     }
-    __syncthreads();
-    nk = ctl[1];
     left -= r;
   }
   // zero padding (box.py:489-491)
@@ -205,7 +240,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsParams p) {
 }
 
 static size_t nms_lds_bytes(int N, int ndet) {
-  return (size_t)((N + 1) & ~1) * 8 + kNmsRound * 8 + (size_t)ndet * (16 + 4 + 4) + 16 + sizeof(SelScratch) + 16;
+  return (size_t)((N + 1) & ~1) * 8 + kNmsRound * 8 + 66 * 8 + (size_t)ndet * (16 + 4 + 4) + 16 + sizeof(SelScratch) + 16;
 }
 
 static int launch_nms(const float* scores, const float* boxes, const float* classes, int B, int N,
