@@ -124,6 +124,18 @@ int ssdk_match_targets(const float* targets, int B, int G, const float* anchors,
                        float center_sampling_radius, float* cls_target, float* box_target,
                        float* depth, void* stream);
 
+/* box.py:229-359 snap_to_anchors_by_scale (FCOS-style scale-range assignment, reached from
+ * extract_targets box.py:388-400 when `match[0]` is a list) for ONE level and the whole batch.  A box is a
+ * candidate for grid point (x, y) of anchor a when the point lies strictly inside it and
+ * lower_scale*sqrt(area_a) (clamped at -1) <= max(l,t,r,b) <= upper_scale*sqrt(area_a); with
+ * center_sampling != 0 the point must lie in the box's centre region (radius 1.5 strides, the reference's
+ * fixed default) and the box's sqrt-area is compared instead.  The smallest candidate wins; depth is
+ * label+1 or 0 (no ignore band).  Same buffers and layout as ssdk_match_targets. */
+int ssdk_match_targets_by_scale(const float* targets, int B, int G, const float* anchors, int A, int C,
+                                int H, int W, int stride, float lower_scale, float upper_scale,
+                                int center_sampling, float* cls_target, float* box_target, float* depth,
+                                void* stream);
+
 /* Fused convolution + folded BatchNorm + activation (+ residual) for the detector network:
  * basic_layers.py:5-57 (SepConvBNReLU / ConvBNReLU / ConvBNReLUx2), the MobileNetV2 blocks behind
  * nets/mobilenet.py:56-99, and the bare multibox head convs ssd.py:100-103 / fpn.py:10-18.

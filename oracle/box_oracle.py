@@ -202,29 +202,119 @@ def snap_to_anchors_by_iou(
     )
 
 
+INF = 100000  # box.py:5
+
+
+def snap_to_anchors_by_scale(
+    boxes, size, stride, anchors, num_classes, match, center_sampling_radius=0
+):
+    """box.py:229-359 (``is_centerness=False`` branch; the other branch reads an undefined name and
+    cannot run).  match = [lower, upper] multipliers of sqrt(anchor area) for this level.
+    Returns cls_target [A,C,H,W], box_target [A,4,H,W], depth [A,1,H,W] (fp32)."""
+    anchors = np.asarray(anchors, F32)
+    A = anchors.shape[0]
+    width, height = int(size[0] / stride), int(size[1] / stride)  # :244
+    boxes = np.asarray(boxes, F32).reshape(-1, 5)
+    if boxes.size == 0:  # :246-260
+        return (
+            np.zeros([A, num_classes, height, width], F32),
+            np.zeros([A, 4, height, width], F32),
+            np.zeros([A, 1, height, width], F32),
+        )
+    boxes, classes = boxes[:, :4], boxes[:, 4:]  # :262
+
+    # per-anchor size range   :265-268
+    anchors_wh = anchors[:, 2:] - anchors[:, :2] + F32(1)
+    anchors_size = np.sqrt(anchors_wh[:, 0] * anchors_wh[:, 1]).astype(F32)[:, None, None]
+    lower = np.maximum(F32(match[0]) * anchors_size, F32(-1))
+    upper = F32(match[1]) * anchors_size
+
+    # grid anchors (x major) and anchor points   :271-281
+    xs = np.arange(0, size[0], stride, dtype=F32)
+    ys = np.arange(0, size[1], stride, dtype=F32)
+    x, y = np.meshgrid(xs, ys, indexing="ij")  # [W, H]
+    xyxy = np.stack((x, y, x, y), 2)[None]
+    ganchors = (xyxy + anchors.reshape(-1, 1, 1, 4)).reshape(-1, 4)
+    anchor_points = np.stack((x, y), 2) + F32(stride // 2)  # [W, H, 2]
+
+    boxes = np.concatenate([boxes[:, :2], boxes[:, :2] + boxes[:, 2:] - F32(1)], 1)  # :284
+    bwh = boxes[:, 2:] - boxes[:, :2] + F32(1)
+    boxes_area = np.sqrt(bwh[:, 0] * bwh[:, 1]).astype(F32)  # :285 (a sqrt-area)
+
+    G = boxes.shape[0]
+    if center_sampling_radius > 0:  # :288-299; get_sample_region runs with its default radius 1.5
+        cared = (boxes_area >= lower) & (boxes_area <= upper)  # [A,1,G]
+        inside = get_sample_region(boxes, stride, anchor_points).reshape(-1, G)  # [W*H, G]
+    else:  # :300-311
+        ap = anchor_points.reshape(-1, 2)
+        lt = ap[:, None, :] - boxes[:, :2]
+        rb = boxes[:, 2:] - ap[:, None, :]
+        reg = np.concatenate([lt, rb], -1)  # [W*H, G, 4]
+        mx = reg.max(-1)
+        cared = (mx >= lower) & (mx <= upper)  # [A, W*H, G]
+        inside = reg.min(-1) > 0
+    mask = (cared & inside).reshape(-1, G)  # :315  [A*W*H, G]
+    area = np.tile(boxes_area, (mask.shape[0], 1))
+    area[~mask] = INF
+    anymask = mask.any(1)
+    indices = area.argmin(1)  # first minimum wins
+
+    box_target = box2delta(boxes[indices], ganchors)  # :323
+    box_target = box_target.reshape(A, width, height, 4).transpose(0, 3, 2, 1)
+
+    depth = np.zeros(mask.shape[0], F32)  # :328-331
+    depth[anymask] = classes[indices][anymask].reshape(-1) + F32(1)
+    depth = depth.reshape(A, width, height).transpose(0, 2, 1)
+
+    cls = classes[indices].astype(np.int64).reshape(-1)  # :334-346
+    cls[~anymask] = num_classes
+    cls_target = np.zeros((ganchors.shape[0], num_classes + 1), F32)
+    cls_target[np.arange(cls.shape[0]), cls] = 1
+    cls_target = cls_target[:, :num_classes].reshape(A, width, height, num_classes).transpose(0, 3, 2, 1)
+
+    return (
+        np.ascontiguousarray(cls_target, F32).reshape(A, num_classes, height, width),
+        np.ascontiguousarray(box_target, F32).reshape(A, 4, height, width),
+        np.ascontiguousarray(depth, F32).reshape(A, 1, height, width),
+    )
+
+
 def extract_targets(
     targets, anchors, classes, stride, size, match=(0.5, 0.4), center_sampling_radius=0
 ):
-    """box.py:362-405 (IoU matching; ``match[0]`` is a float).
+    """box.py:362-405.  ``match[0]`` float -> IoU matching; list -> one [lower, upper] scale range per
+    level, selected by the position of ``stride`` among the anchor keys (:389).
 
     targets [B,G,5] padded with label -1; anchors = OrderedDict{stride: [A,4]};
     size = (h, w) of the level's feature map.
     """
-    if not isinstance(match[0], float):
+    by_scale = isinstance(match[0], (list, tuple))
+    if not by_scale and not isinstance(match[0], float):
         raise ValueError("unvalidate match param")
     targets = np.asarray(targets, F32)
     outs = ([], [], [])
     for target in targets:
         target = target[target[:, -1] > -1]  # :375
-        snapped = snap_to_anchors_by_iou(
-            target,
-            [s * stride for s in size[::-1]],  # :379
-            stride,
-            anchors[stride],
-            classes,
-            match,
-            center_sampling_radius,
-        )
+        if by_scale:
+            snapped = snap_to_anchors_by_scale(
+                target,
+                [s * stride for s in size[::-1]],
+                stride,
+                anchors[stride],
+                classes,
+                match[list(anchors).index(stride)],
+                center_sampling_radius,
+            )
+        else:
+            snapped = snap_to_anchors_by_iou(
+                target,
+                [s * stride for s in size[::-1]],  # :379
+                stride,
+                anchors[stride],
+                classes,
+                match,
+                center_sampling_radius,
+            )
         for lst, s in zip(outs, snapped):
             lst.append(s)
     return tuple(np.stack(o) for o in outs)

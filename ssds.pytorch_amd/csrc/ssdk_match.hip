@@ -6,6 +6,10 @@
 // anchor (a, y, x), walks the image's valid ground-truth rows (staged in LDS, order preserved so that
 // the first maximum wins like torch.max on CPU), and writes its column of the three target tensors.
 // Write-bound: (A*C + A*4 + A)*H*W*4 bytes per image.
+//
+// by_scale = 1 selects box.snap_to_anchors_by_scale (reference box.py:229-359, FCOS-style): a ground-truth box
+// is a candidate for a grid point when the point lies inside it (or inside its centre region) and the box's
+// regression range (or sqrt-area) falls in [lo, hi] * sqrt(anchor area); the smallest candidate wins.
 #include "ssdk_common.h"
 
 namespace ssdk {
@@ -17,6 +21,7 @@ struct MatchParams {
   int G, A, C, H, W, stride;
   float hi, lo, radius_px;  // radius_px = float(stride * radius); 0 = off
   int use_radius;
+  int by_scale;  // 0: IoU matching (hi/lo = match/unmatch thresholds); 1: scale-range matching (lo/hi multipliers)
   float anchors[SSDK_MAX_ANCHORS * 4];
   float* cls_target;  // [B, A, C, H, W]
   float* box_target;  // [B, A, 4, H, W]
@@ -62,7 +67,8 @@ __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams 
     g.y2 = r[1] + r[3] - 1.0f;
     g.area = (g.x2 - g.x1 + 1.0f) * (g.y2 - g.y1 + 1.0f);  // box.py:166
     g.label = r[4];
-    g.pad0 = g.pad1 = 0.f;
+    g.pad0 = sqrtf(g.area);  // box.py:287 (scale matching compares sqrt-areas)
+    g.pad1 = 0.f;
     gt[off + mbcnt(m)] = g;
   }
   __syncthreads();
@@ -95,26 +101,55 @@ __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams 
   float best = 0.f;
   u32 bi = 0;
   bool inside = false;
-  const float apx = fx + (float)(p.stride / 2), apy = fy + (float)(p.stride / 2);  // box.py:185
-  for (u32 g = 0; g < ng; ++g) {
-    const GtRow q = gt[g];
-    const float x1 = tmax(ax1, q.x1), y1 = tmax(ay1, q.y1);  // box.py:163-165
-    const float x2 = tmin(ax2, q.x2), y2 = tmin(ay2, q.y2);
-    float w = x2 - x1 + 1.0f, h = y2 - y1 + 1.0f;
-    w = (w < 0.f) ? 0.f : w;
-    h = (h < 0.f) ? 0.f : h;
-    const float inter = w * h;
-    const float ov = inter / (aarea + q.area - inter);  // box.py:168 (no epsilon)
-    if (g == 0 || ov > best) {  // box.py:171: first maximum wins
-      best = ov;
-      bi = g;
+  const float apx = fx + (float)(p.stride / 2), apy = fy + (float)(p.stride / 2);  // box.py:185, 281
+  if (p.by_scale) {
+    const float asz = sqrtf((s_anchor[a * 4 + 2] - s_anchor[a * 4 + 0] + 1.0f) *
+                            (s_anchor[a * 4 + 3] - s_anchor[a * 4 + 1] + 1.0f));  // box.py:265-266
+    const float lo = tmax(p.lo * asz, -1.0f), hi = p.hi * asz;                     // box.py:267-268
+    for (u32 g = 0; g < ng; ++g) {
+      const GtRow q = gt[g];
+      bool cared, in;
+      if (p.use_radius) {  // box.py:290-299 (get_sample_region is called with its default radius 1.5)
+        cared = (q.pad0 >= lo) && (q.pad0 <= hi);
+        const float cx = (q.x1 + q.x2) / 2.0f, cy = (q.y1 + q.y2) / 2.0f;
+        const float lx = apx - tmax(cx - p.radius_px, q.x1), ly = apy - tmax(cy - p.radius_px, q.y1);
+        const float rx = tmin(cx + p.radius_px, q.x2) - apx, ry = tmin(cy + p.radius_px, q.y2) - apy;
+        in = tmin(tmin(lx, ly), tmin(rx, ry)) > 0.f;
+      } else {  // box.py:300-311
+        const float l = apx - q.x1, t2 = apy - q.y1, r2 = q.x2 - apx, b2 = q.y2 - apy;
+        const float mx = tmax(tmax(l, t2), tmax(r2, b2));
+        cared = (mx >= lo) && (mx <= hi);
+        in = tmin(tmin(l, t2), tmin(r2, b2)) > 0.f;
+      }
+      const bool cand = cared && in;
+      const float v = cand ? q.pad0 : 100000.0f;  // box.py:5,316-318: INF for non-candidates
+      inside = inside || cand;
+      if (g == 0 || v < best) {  // box.py:320: first minimum wins
+        best = v;
+        bi = g;
+      }
     }
-    if (p.use_radius) {  // box.py:90-113 get_sample_region
-      const float cx = (q.x1 + q.x2) / 2.0f, cy = (q.y1 + q.y2) / 2.0f;
-      const float lx = apx - tmax(cx - p.radius_px, q.x1), ly = apy - tmax(cy - p.radius_px, q.y1);
-      const float rx = tmin(cx + p.radius_px, q.x2) - apx, ry = tmin(cy + p.radius_px, q.y2) - apy;
-      const float mn = tmin(tmin(lx, ly), tmin(rx, ry));
-      inside = inside || (mn > 0.f);
+  } else {
+    for (u32 g = 0; g < ng; ++g) {
+      const GtRow q = gt[g];
+      const float x1 = tmax(ax1, q.x1), y1 = tmax(ay1, q.y1);  // box.py:163-165
+      const float x2 = tmin(ax2, q.x2), y2 = tmin(ay2, q.y2);
+      float w = x2 - x1 + 1.0f, h = y2 - y1 + 1.0f;
+      w = (w < 0.f) ? 0.f : w;
+      h = (h < 0.f) ? 0.f : h;
+      const float inter = w * h;
+      const float ov = inter / (aarea + q.area - inter);  // box.py:168 (no epsilon)
+      if (g == 0 || ov > best) {  // box.py:171: first maximum wins
+        best = ov;
+        bi = g;
+      }
+      if (p.use_radius) {  // box.py:90-113 get_sample_region
+        const float cx = (q.x1 + q.x2) / 2.0f, cy = (q.y1 + q.y2) / 2.0f;
+        const float lx = apx - tmax(cx - p.radius_px, q.x1), ly = apy - tmax(cy - p.radius_px, q.y1);
+        const float rx = tmin(cx + p.radius_px, q.x2) - apx, ry = tmin(cy + p.radius_px, q.y2) - apy;
+        const float mn = tmin(tmin(lx, ly), tmin(rx, ry));
+        inside = inside || (mn > 0.f);
+      }
     }
   }
   const GtRow q = gt[bi];
@@ -129,30 +164,35 @@ __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams 
   box_o[(size_t)3 * HW] = logf(bh / ah);
 
   float dep = -1.0f;  // box.py:177-182
-  if (best < p.lo) dep = 0.f;
-  if (best >= p.hi) dep = q.label + 1.0f;
-  if (p.use_radius) dep = tmin(dep, inside ? 1.0f : 0.f);  // box.py:191
+  int lab;
+  if (p.by_scale) {  // box.py:328-330, 340: no ignore band
+    dep = inside ? q.label + 1.0f : 0.f;
+    lab = inside ? (int)(long long)q.label : p.C;
+  } else {
+    if (best < p.lo) dep = 0.f;
+    if (best >= p.hi) dep = q.label + 1.0f;
+    if (p.use_radius) dep = tmin(dep, inside ? 1.0f : 0.f);  // box.py:191
+    // box.py:195-207: one-hot at the matched label unless background (overlap < unmatch threshold)
+    lab = (best < p.lo) ? p.C : (int)(long long)q.label;
+  }
   dep_o[0] = dep;
 
-  // box.py:195-207: one-hot at the matched label unless background (overlap < unmatch threshold)
-  const int lab = (best < p.lo) ? p.C : (int)(long long)q.label;
   for (int c = 0; c < p.C; ++c) cls_o[(size_t)c * HW] = (c == lab) ? 1.0f : 0.f;
 }
 
 }  // namespace ssdk
 
-extern "C" int ssdk_match_targets(const float* targets, int B, int G, const float* anchors, int A, int C,
-                                  int H, int W, int stride, float match_threshold, float unmatch_threshold,
-                                  float center_sampling_radius, float* cls_target, float* box_target,
-                                  float* depth, void* stream) {
-  using namespace ssdk;
+namespace ssdk {
+static int launch_match(const char* what, int by_scale, const float* targets, int B, int G, const float* anchors,
+                        int A, int C, int H, int W, int stride, float hi, float lo, float radius,
+                        float* cls_target, float* box_target, float* depth, void* stream) {
   if (!targets || !anchors || !cls_target || !box_target || !depth) {
-    set_error("match_targets: null pointer");
+    set_error("%s: null pointer", what);
     return SSDK_E_BADARG;
   }
   if (B < 1 || G < 0 || G > SSDK_MAX_GT || A < 1 || A > SSDK_MAX_ANCHORS || C < 1 || H < 1 || W < 1 ||
       stride < 1) {
-    set_error("match_targets: bad dims B=%d G=%d (<=%d) A=%d (<=%d) C=%d H=%d W=%d stride=%d", B, G,
+    set_error("%s: bad dims B=%d G=%d (<=%d) A=%d (<=%d) C=%d H=%d W=%d stride=%d", what, B, G,
               SSDK_MAX_GT, A, SSDK_MAX_ANCHORS, C, H, W, stride);
     return SSDK_E_BADARG;
   }
@@ -165,10 +205,11 @@ extern "C" int ssdk_match_targets(const float* targets, int B, int G, const floa
   p.H = H;
   p.W = W;
   p.stride = stride;
-  p.hi = match_threshold;
-  p.lo = unmatch_threshold;
-  p.use_radius = center_sampling_radius > 0.f;
-  p.radius_px = (float)((double)stride * (double)center_sampling_radius);
+  p.hi = hi;
+  p.lo = lo;
+  p.by_scale = by_scale;
+  p.use_radius = radius > 0.f;
+  p.radius_px = (float)((double)stride * (double)radius);
   memcpy(p.anchors, anchors, sizeof(float) * 4 * A);
   p.cls_target = cls_target;
   p.box_target = box_target;
@@ -177,4 +218,23 @@ extern "C" int ssdk_match_targets(const float* targets, int B, int G, const floa
   dim3 grid((total + kMatchThreads - 1) / kMatchThreads, (unsigned)B);
   hipLaunchKernelGGL(match_kernel, grid, dim3(kMatchThreads), 0, (hipStream_t)stream, p);
   return check_launch("match_kernel");
+}
+}  // namespace ssdk
+
+extern "C" int ssdk_match_targets(const float* targets, int B, int G, const float* anchors, int A, int C,
+                                  int H, int W, int stride, float match_threshold, float unmatch_threshold,
+                                  float center_sampling_radius, float* cls_target, float* box_target,
+                                  float* depth, void* stream) {
+  return ssdk::launch_match("match_targets", 0, targets, B, G, anchors, A, C, H, W, stride, match_threshold,
+                            unmatch_threshold, center_sampling_radius, cls_target, box_target, depth, stream);
+}
+
+extern "C" int ssdk_match_targets_by_scale(const float* targets, int B, int G, const float* anchors, int A,
+                                           int C, int H, int W, int stride, float lower_scale,
+                                           float upper_scale, int center_sampling, float* cls_target,
+                                           float* box_target, float* depth, void* stream) {
+  // the reference calls get_sample_region with its default radius (1.5) whatever the configured value is
+  return ssdk::launch_match("match_targets_by_scale", 1, targets, B, G, anchors, A, C, H, W, stride,
+                            upper_scale, lower_scale, center_sampling ? 1.5f : 0.f, cls_target, box_target,
+                            depth, stream);
 }

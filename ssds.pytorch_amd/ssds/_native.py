@@ -90,6 +90,8 @@ def _load():
                                     vp, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.ssdk_match_targets.argtypes = [vp, i32, i32, c.POINTER(f32), i32, i32, i32, i32, i32, f32, f32,
                                        f32, vp, vp, vp, vp]
+    lib.ssdk_match_targets_by_scale.argtypes = [vp, i32, i32, c.POINTER(f32), i32, i32, i32, i32, i32, f32,
+                                                f32, i32, vp, vp, vp, vp]
     lib.ssdk_conv_workspace_bytes.restype = sz
     lib.ssdk_conv_workspace_bytes.argtypes = [i32] * 8
     lib.ssdk_conv_bn_act.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32,
@@ -105,7 +107,7 @@ def _load():
     lib.ssdk_set_profiling.argtypes = [i32]
     lib.ssdk_get_timings.argtypes = [i32, c.POINTER(f32), i32]
     for name in ("ssdk_set_profiling", "ssdk_get_timings", "ssdk_device_info", "ssdk_generate_anchors", "ssdk_decode", "ssdk_nms",
-                 "ssdk_decode_nms", "ssdk_match_targets", "ssdk_conv_bn_act"):
+                 "ssdk_decode_nms", "ssdk_match_targets", "ssdk_match_targets_by_scale", "ssdk_conv_bn_act"):
         getattr(lib, name).restype = i32
     return lib
 
@@ -114,7 +116,7 @@ lib = _load()
 EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_device_info", "ssdk_generate_anchors",
            "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
-           "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
+           "ssdk_match_targets_by_scale", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 
 
 class SsdkError(RuntimeError):

@@ -90,18 +90,20 @@ def extract_targets(
     is_centerness=False,
 ):
     """Snap ground-truth boxes to the anchors of one level for the whole batch in ONE launch
-    (reference box.py:362-405 + snap_to_anchors_by_iou box.py:116-226).
+    (reference box.py:362-405 + snap_to_anchors_by_iou box.py:116-226 / snap_to_anchors_by_scale
+    box.py:229-359).
 
     targets [B,G,5] (x, y, w, h, label; label -1 = padding) on a HIP device, anchors =
-    OrderedDict{stride: [A,4]}, size = (h, w) of the level.  Returns fp32
+    OrderedDict{stride: [A,4]}, size = (h, w) of the level.  ``match`` is either the IoU pair
+    [match, unmatch] or, for scale-range assignment, one [lower, upper] pair per level (the pair of this
+    level is found by the position of ``stride`` among the anchor keys, box.py:389).  Returns fp32
     (cls_target [B,A,C,H,W], box_target [B,A,4,H,W], depth [B,A,1,H,W])."""
-    if isinstance(match[0], list):
-        raise NotImplementedError(
-            "scale-range matching (snap_to_anchors_by_scale, box.py:229-359) is outside the MI355X hot path")
-    if not isinstance(match[0], float):
+    by_scale = isinstance(match[0], list)
+    if not by_scale and not isinstance(match[0], float):
         raise ValueError("unvalidate match param")
     if is_centerness:
-        raise NotImplementedError("is_centerness targets are outside the MI355X hot path")
+        # the reference's centerness branch reads an undefined name (box.py:343-344) and cannot run
+        raise NotImplementedError("is_centerness targets are not produced by the reference either")
     N.require_device(targets, "extract_targets")
     anc = _anchor_array(anchors, stride)
     A = anc.shape[0]
@@ -112,11 +114,19 @@ def extract_targets(
     cls_t = torch.empty((B, A, classes, H, W), device=dev, dtype=torch.float32)
     box_t = torch.empty((B, A, 4, H, W), device=dev, dtype=torch.float32)
     depth = torch.empty((B, A, 1, H, W), device=dev, dtype=torch.float32)
+    anc_p = anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
     with torch.cuda.device(dev):
-        rc = N.lib.ssdk_match_targets(
-            t.data_ptr(), B, G, anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), A, int(classes), H, W,
-            int(stride), float(match[0]), float(match[1]), float(center_sampling_radius),
-            cls_t.data_ptr(), box_t.data_ptr(), depth.data_ptr(), N.stream_ptr(dev))
+        if by_scale:
+            lo, hi = match[list(anchors).index(stride)]  # box.py:389-397
+            rc = N.lib.ssdk_match_targets_by_scale(
+                t.data_ptr(), B, G, anc_p, A, int(classes), H, W, int(stride), float(lo), float(hi),
+                int(center_sampling_radius > 0), cls_t.data_ptr(), box_t.data_ptr(), depth.data_ptr(),
+                N.stream_ptr(dev))
+        else:
+            rc = N.lib.ssdk_match_targets(
+                t.data_ptr(), B, G, anc_p, A, int(classes), H, W, int(stride), float(match[0]),
+                float(match[1]), float(center_sampling_radius), cls_t.data_ptr(), box_t.data_ptr(),
+                depth.data_ptr(), N.stream_ptr(dev))
     N.check(rc, "match_targets")
     return cls_t, box_t, depth
 

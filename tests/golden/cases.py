@@ -238,8 +238,24 @@ MATCH_CASES = OrderedDict(
 )
 
 
-def match_inputs(name, gen):
-    seed, B, maxG, C, H, W, stride, A, match, radius = MATCH_CASES[name]
+# scale-range assignment (snap_to_anchors_by_scale): match = (lower, upper) multipliers of sqrt(anchor area)
+SCALE_MATCH_CASES = OrderedDict(
+    [
+        ("s_ssd300_l0", (61, 3, 8, 80, 19, 19, 15, 6, (0.5, 4.0), 0)),
+        ("s_ssd300_l2", (62, 3, 8, 80, 5, 5, 60, 6, (0.0, 2.0), 0)),
+        ("s_nonsquare", (63, 2, 5, 11, 6, 10, 16, 3, (-1.0, 1000.0), 0)),
+        ("s_center", (64, 3, 6, 5, 8, 8, 16, 3, (0.5, 4.0), 1.5)),
+        ("s_center_r3", (65, 2, 6, 5, 8, 8, 16, 3, (0.2, 8.0), 3.0)),  # radius value is ignored (always 1.5)
+        ("s_ties", (66, 2, 6, 9, 8, 8, 16, 2, (0.0, 100.0), 0)),
+        ("s_one_by_one", (67, 2, 3, 6, 1, 1, 300, 6, (0.0, 4.0), 0)),
+        ("s_single_anchor", (68, 2, 4, 3, 7, 5, 8, 1, (0.0, 6.0), 0)),
+    ]
+)
+
+
+def match_inputs(name, gen, table=None):
+    table = table or (SCALE_MATCH_CASES if name in SCALE_MATCH_CASES else MATCH_CASES)
+    seed, B, maxG, C, H, W, stride, A, match, radius = table[name]
     anchors = anchors_for(A, stride, gen)
     if name == "kat_layout":
         targets = np.array([[[12, 4, 16, 16, 5], [-1, -1, -1, -1, -1]]], F32)
@@ -259,5 +275,9 @@ def match_inputs(name, gen):
                 x = rs.random_sample() * max(iw - w, 1)
                 y = rs.random_sample() * max(ih - h, 1)
                 targets[b, j] = [np.floor(x), np.floor(y), np.ceil(w), np.ceil(h), rs.randint(0, C)]
+        if name == "s_ties":  # equal-area boxes at the same place with different labels: the first one wins
+            targets[0, 1, :4] = targets[0, 0, :4]
+            targets[0, 1, 4] = (targets[0, 0, 4] + 1) % C
+            targets[0, 3, 2:4] = targets[0, 2, 3:1:-1]  # transposed box: same area, different shape
     return dict(targets=targets, anchors=anchors, C=C, stride=stride, size=(H, W),
                 match=match, radius=radius)

@@ -160,6 +160,21 @@ def gen_match():
     save("match", **out)
 
 
+def gen_match_scale():
+    out = {}
+    for name in cases.SCALE_MATCH_CASES:
+        d = cases.match_inputs(name, ref_gen)
+        anchors = OrderedDict([(d["stride"], t(d["anchors"]))])
+        ct, bt, dp = rbox.extract_targets(
+            t(d["targets"]), anchors, d["C"], d["stride"], d["size"], [list(map(float, d["match"]))], d["radius"]
+        )
+        out[name + "_cls"], out[name + "_box"], out[name + "_depth"] = (
+            ct.numpy().astype(np.uint8), bt.numpy(), dp.numpy())
+        out[name + "_crc"] = cases.checksum(d["targets"], d["anchors"])
+        print("match_scale", name, "fg", int((dp > 0).sum()), "shape", tuple(ct.shape))
+    save("match_scale", **out)
+
+
 if __name__ == "__main__":
     gen_anchors()
     gen_codec()
@@ -167,3 +182,4 @@ if __name__ == "__main__":
     gen_nms()
     gen_decoder()
     gen_match()
+    gen_match_scale()

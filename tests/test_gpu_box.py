@@ -220,6 +220,53 @@ def test_extract_targets_vs_reference(name):
     np.testing.assert_allclose(bt.cpu().numpy(), g[name + "_box"], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("name", list(cases.SCALE_MATCH_CASES))
+def test_extract_targets_by_scale_vs_reference(name):
+    import torch
+    from ssds.modeling.layers import box
+
+    g = load("match_scale")
+    d = cases.match_inputs(name, O.generate_anchors)
+    anchors = OrderedDict([(d["stride"], torch.from_numpy(d["anchors"]))])
+    ct, bt, dp = box.extract_targets(torch.from_numpy(d["targets"]).cuda(), anchors, d["C"], d["stride"],
+                                     d["size"], [list(map(float, d["match"]))], d["radius"])
+    np.testing.assert_array_equal(dp.cpu().numpy(), g[name + "_depth"])  # assignment decisions bit exact
+    np.testing.assert_array_equal(ct.cpu().numpy().astype(np.uint8), g[name + "_cls"])
+    np.testing.assert_allclose(bt.cpu().numpy(), g[name + "_box"], rtol=1e-5, atol=1e-5)
+
+
+def test_extract_targets_by_scale_full_size_vs_oracle():
+    """SSD-MobileNetV2@512 level 0 (32x32, A=6, C=80), B=64, G=32: whole batch in one launch vs the oracle
+    on a sample of images; every image obeys the structural properties (one-hot rows, depth <-> class)."""
+    import torch
+    from ssds.modeling.layers import box
+
+    rs = np.random.RandomState(77)
+    B, G, C, H, W, stride = 64, 32, 80, 32, 32, 16
+    anc = O.generate_anchors(stride, [1, 2, 0.5], [2.0, 2.828])
+    targets = np.full((B, G, 5), -1, np.float32)
+    for b in range(B):
+        n = rs.randint(0, G + 1)
+        wh = np.ceil(rs.uniform(0.02 * 512, 0.4 * 512, (n, 2)))
+        xy = np.floor(rs.uniform(0, 0.8 * 512, (n, 2)))
+        wh = np.minimum(wh, 512 - xy)
+        targets[b, :n] = np.concatenate([xy, wh, rs.randint(0, C, (n, 1))], 1)
+    anchors = OrderedDict([(stride, torch.from_numpy(anc))])
+    for rng, radius in (([0.5, 4.0], 0), ([0.25, 3.0], 1.5)):
+        ct, bt, dp = box.extract_targets(torch.from_numpy(targets).cuda(), anchors, C, stride, (H, W), [rng], radius)
+        ctn, btn, dpn = ct.cpu().numpy(), bt.cpu().numpy(), dp.cpu().numpy()
+        assert ((ctn == 0) | (ctn == 1)).all()
+        onehot = ctn.sum(2, keepdims=True)
+        np.testing.assert_array_equal(onehot, (dpn > 0).astype(np.float32))  # fg <=> exactly one class bit
+        lab = ctn.argmax(2)[:, :, None]
+        np.testing.assert_array_equal(np.where(dpn > 0, lab + 1, 0), dpn)
+        for b in (0, 7, 63):
+            oc, ob, od = O.extract_targets(targets[b:b + 1], OrderedDict([(stride, anc)]), C, stride, (H, W), [rng], radius)
+            np.testing.assert_array_equal(dpn[b:b + 1], od)
+            np.testing.assert_array_equal(ctn[b:b + 1], oc)
+            np.testing.assert_allclose(btn[b:b + 1], ob, rtol=1e-5, atol=1e-5)
+
+
 def test_full_size_ssd512_bf16_properties_and_sampled_oracle():
     """BASELINE config 2 shape (SSD-MobileNetV2@512, B=64, bf16 heads): size-independent properties over
     the whole batch + the oracle on a sample of images."""

@@ -141,6 +141,32 @@ def test_extract_targets_vs_reference(name):
     np.testing.assert_allclose(bt, g[name + "_box"], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("name", list(cases.SCALE_MATCH_CASES))
+def test_extract_targets_by_scale_vs_reference(name):
+    g = load("match_scale")
+    d = cases.match_inputs(name, O.generate_anchors)
+    assert cases.checksum(d["targets"], d["anchors"]) == g[name + "_crc"]
+    anchors = OrderedDict([(d["stride"], d["anchors"])])
+    ct, bt, dp = O.extract_targets(d["targets"], anchors, d["C"], d["stride"], d["size"],
+                                   [list(map(float, d["match"]))], d["radius"])
+    np.testing.assert_array_equal(dp, g[name + "_depth"])  # assignment decisions bit exact
+    np.testing.assert_array_equal(ct.astype(np.uint8), g[name + "_cls"])
+    np.testing.assert_allclose(bt, g[name + "_box"], rtol=1e-5, atol=1e-5)
+
+
+def test_match_by_scale_picks_level_range_by_stride_position():
+    # box.py:389: the [lower, upper] pair of a level is match[list(anchors).index(stride)]
+    d = cases.match_inputs("s_ssd300_l2", O.generate_anchors)
+    other = O.generate_anchors(30, [1, 2, 0.5], [2.0, 2.828])
+    anchors = OrderedDict([(30, other), (d["stride"], d["anchors"])])
+    rng = list(map(float, d["match"]))
+    a = O.extract_targets(d["targets"], anchors, d["C"], d["stride"], d["size"], [[9.0, 9.5], rng], 0)
+    b = O.extract_targets(d["targets"], OrderedDict([(d["stride"], d["anchors"])]), d["C"], d["stride"],
+                          d["size"], [rng], 0)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_match_kat_layout():
     # output index order [B, A, ., y(H), x(W)]
     d = cases.match_inputs("kat_layout", O.generate_anchors)
