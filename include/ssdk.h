@@ -70,6 +70,8 @@ typedef struct ssdk_level {
 
 int ssdk_version(void);
 const char* ssdk_last_error(void);
+/* name of the kernel the calling thread launched last (which variant a layer was dispatched to; tests, tools) */
+const char* ssdk_last_kernel(void);
 
 /* Device facts the host side needs for roofline accounting (bench.py). Returns 0 / SSDK_E_NODEVICE. */
 int ssdk_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes, char* arch, int arch_len);

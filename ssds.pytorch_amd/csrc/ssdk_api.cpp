@@ -18,7 +18,10 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local const char* g_last_kernel = "";
+
 int check_launch(const char* what) {
+  g_last_kernel = what;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error("%s: %s", what, hipGetErrorString(e));
@@ -31,6 +34,7 @@ int check_launch(const char* what) {
 
 extern "C" int ssdk_version(void) { return SSDK_VERSION; }
 extern "C" const char* ssdk_last_error(void) { return ssdk::g_err; }
+extern "C" const char* ssdk_last_kernel(void) { return ssdk::g_last_kernel; }
 
 extern "C" int ssdk_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes, char* arch, int arch_len) {
   int dev = 0;

@@ -24,73 +24,9 @@
 //   w      KRSC [Cout][kh][kw][Cin/groups]                         same dtype (fp32 for conv_first)
 //   scale, bias  fp32 [Cout]  (scale may be NULL = 1)
 //   y      NHWC [N][Ho][Wo][Cout] or NCHW [N][Cout][Ho][Wo]        same dtype
-#include <stdio.h>
-
-#include "ssdk_common.h"
+#include "ssdk_conv_common.h"
 
 namespace ssdk {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-enum { LAYOUT_NCHW = 0, LAYOUT_NHWC = 1 };
-
-struct ConvParams {
-  const void* x;
-  const void* w;
-  const float* scale;
-  const float* bias;
-  const void* res;  // residual, same layout/dtype as y (NHWC only)
-  void* y;
-  void* y2;
-  int N, Cin, H, W, Cout, k, stride, pad, Ho, Wo;
-  int M;           // N*Ho*Wo
-  int cin_chunks;  // ceil(Cin/32)
-  int KT;          // k*k*cin_chunks
-  int act, act2, split;  // channels >= split use act2 and go to y2 (split == Cout: single output)
-  int in_layout, out_layout;
-  // split-K (small-M layers: too few output tiles to fill 256 CUs and a long, latency-bound k-loop):
-  // blockIdx.z owns k-tiles [z*kt_per, (z+1)*kt_per); partial accumulators go to fp32 slabs in fragment order,
-  // the last workgroup to arrive on a tile (agent-scope release/acquire on a counter) sums them and runs
-  // the epilogue.  Counters are zero on entry and reset by the last arriver.
-  int ksplits, kt_per;
-  float* slabs;
-  unsigned* counters;
-};
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-  switch (act) {
-    case SSDK_ACT_RELU: return v > 0.f ? v : 0.f;
-    case SSDK_ACT_RELU6: return v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
-    case SSDK_ACT_SILU: return v / (1.0f + __expf(-v));
-    case SSDK_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
-    default: return v;
-  }
-}
-
-template <int DT> __device__ __forceinline__ u32 f32_to_bits16(float v);
-template <> __device__ __forceinline__ u32 f32_to_bits16<SSDK_BF16>(float v) {
-  u32 b = __builtin_bit_cast(u32, v);
-  if ((b & 0x7fffffffu) > 0x7f800000u) return (b >> 16) | 0x40u;  // quiet NaN
-  return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;                  // round to nearest even
-}
-template <> __device__ __forceinline__ u32 f32_to_bits16<SSDK_F16>(float v) {
-  _Float16 h = (_Float16)v;
-  return (u32)__builtin_bit_cast(u16, h);
-}
-template <int DT> __device__ __forceinline__ float bits16_to_f32(u32 h) {
-  if constexpr (DT == SSDK_BF16) return bf16_bits_to_f32(h);
-  else return f16_bits_to_f32(h);
-}
-
-template <int DT>
-__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, f32x4 c) {
-  if constexpr (DT == SSDK_BF16)
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
 
 // 16-byte chunk swizzle inside a 64-byte LDS row: makes the 16-lane groups of ds_read_b128 conflict free
 // (rows r, r+4, r+8, r+12 share the same bank phase; S permutes their chunk index).
@@ -373,6 +309,238 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_gemm256_kernel: the large-layer variant (SSD heads L0-L2, FPN/BiFPN towers, wide 1x1 convs).
+//
+// 256 x 256 x 64 tiles, 8 waves as 2(M) x 4(N), each wave a 128 x 64 sub-tile = 8 x 4 accumulator fragments of
+// v_mfma_f32_16x16x32.  Both operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave
+// instruction, no staging VGPRs, no ds_write pass) into two 64 KiB stages; the LDS image is lane-linear per
+// instruction, so the bank swizzle (16-byte chunk index ^ (row >> 1) & 7 inside each 128-byte row) is applied to
+// the SOURCE address: lane -> (row, logical chunk) is chosen such that the physical chunk is the lane's slot.
+// The reduction index is the flat k = (ky*kw + kx)*Cin + ci (tap-major, channel-minor = KRSC weight order), so a
+// 64-wide k-tile may straddle taps: every lane tracks (tap, ci) of its own 8-channel chunk.  Out-of-image taps,
+// rows >= M / >= Cout and k >= K read a 16-byte zero page instead (a masked lane would leave stale LDS).
+// One workgroup per CU (128 KiB LDS); tile ids are remapped so that the tiles sharing an M-panel run on one XCD.
+// ------------------------------------------------------------------------------------------------
+
+constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64, G2_THREADS = 512;
+constexpr int G2_STAGE = (G2_BM + G2_BN) * G2_BK * 2;  // 64 KiB
+constexpr int G2_LDS = 2 * G2_STAGE;
+
+template <int DT>
+__global__ __launch_bounds__(G2_THREADS) void conv_gemm256_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const u32 tid = threadIdx.x, lane = tid & 63u;
+  const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const u32 wm = wave >> 2, wn = wave & 3u;
+
+  // XCD-aware (bijective) tile order: ids i, i+8, i+16 ... share an XCD; give each XCD a contiguous tile range
+  const u32 nwg = gridDim.x, id = blockIdx.x;
+  const u32 q = nwg >> 3, r8 = nwg & 7u, xcd = id & 7u;
+  const u32 lin = (xcd < r8 ? xcd * (q + 1u) : r8 * (q + 1u) + (xcd - r8) * q) + (id >> 3);
+  const u32 NT = (u32)((p.Cout + G2_BN - 1) / G2_BN);
+  const u32 m0 = (lin / NT) * G2_BM, n0 = (lin % NT) * G2_BN;
+
+  const int Cin = p.Cin, H = p.H, W = p.W;
+  const int Ktot = p.k * p.k * Cin;
+
+  // ---- loader roles: wave instruction g = j*8 + wave covers tile rows g*8 .. g*8+7 (1 KiB of LDS) -------------
+  const u32 lrow = lane >> 3;                                        // row inside the 8-row group
+  const u32 lchunk = (lane & 7u) ^ (((lane >> 4) + 4u * (wave & 1u)) & 7u);  // logical 16-byte chunk of this lane
+  long a_off[4];
+  u32 a_mask[4];
+  long b_off[4];
+  bool b_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32 row = ((u32)j * 8u + wave) * 8u + lrow;
+    const u32 m = m0 + row;
+    u32 mask = 0;
+    long base = 0;
+    if (m < (u32)p.M) {
+      const u32 hw = (u32)(p.Ho * p.Wo);
+      const u32 b = m / hw, r = m % hw;
+      const int oy = (int)(r / (u32)p.Wo), ox = (int)(r % (u32)p.Wo);
+      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      base = (((long)b * H + iy0) * W + ix0) * Cin;
+      for (int ky = 0; ky < p.k; ++ky)
+        for (int kx = 0; kx < p.k; ++kx)
+          if ((unsigned)(iy0 + ky) < (unsigned)H && (unsigned)(ix0 + kx) < (unsigned)W) mask |= 1u << (ky * p.k + kx);
+    }
+    a_off[j] = base;
+    a_mask[j] = mask;
+    const u32 n = n0 + row;
+    b_ok[j] = n < (u32)p.Cout;
+    b_off[j] = (long)n * Ktot;
+  }
+  // k-tiles are visited channel-chunk-major, tap-minor: the nine taps of one 64-channel slab re-read the same
+  // 256-pixel (+halo) footprint of 128 B per pixel back to back, which stays in L2 (tap-major order re-reads the
+  // whole Cin-deep footprint only every Cin/64 steps and thrashes the 4 MiB L2 of an XCD at Cin >= 256).
+  const int KK = p.k * p.k;
+  const int cchunks = (Cin + G2_BK - 1) / G2_BK;
+  int t_tap = 0, t_cc = 0;
+  // masked chunks read the zero page: select the byte OFFSET (one v_cndmask pair), not the pointer (branches)
+  const unsigned char* xg = (const unsigned char*)p.x;
+  const unsigned char* wg = (const unsigned char*)p.w;
+  const long zx = reinterpret_cast<const unsigned char*>(g_zero16) - xg;
+  const long zw = reinterpret_cast<const unsigned char*>(g_zero16) - wg;
+
+  auto issue = [&](int buf) {
+    unsigned char* sA = smem + buf * G2_STAGE + wave * 1024u;
+    unsigned char* sB = sA + G2_BM * G2_BK * 2;
+    const int ci = t_cc * G2_BK + (int)lchunk * 8;
+    const bool cok = ci < Cin;
+    const int ky = (p.k == 3) ? ((t_tap * 11) >> 5) : 0;
+    const int kx = t_tap - ky * p.k;
+    const int tap = (ky * W + kx) * Cin + ci;
+    const int wk = t_tap * Cin + ci;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = cok && ((a_mask[j] >> t_tap) & 1u);
+      const long off = ok ? (a_off[j] + tap) * 2 : zx;
+      glds16(xg + off, sA + j * 8192);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = cok && b_ok[j];
+      const long off = ok ? (b_off[j] + wk) * 2 : zw;
+      glds16(wg + off, sB + j * 8192);
+    }
+    if (++t_tap == KK) {
+      t_tap = 0;
+      ++t_cc;
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const u32 fr = lane & 15u, fg = lane >> 4;
+  const u32 a_rd = (wm * 128u + fr) * 128u;  // byte offset of fragment row 0 of this wave (i adds 16 rows = 2 KiB)
+  const u32 b_rd = (u32)(G2_BM * G2_BK * 2) + (wn * 64u + fr) * 128u;
+  const u32 sw = fr >> 1;  // (row >> 1) & 7 for every fragment row of this lane
+
+  const int KT = KK * cchunks;
+  issue(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) issue(cur ^ 1);
+    const unsigned char* st = smem + cur * G2_STAGE;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const u32 ch = (((u32)s2 * 4u + fg) ^ sw) * 16u;
+      u32x4 fa[8], fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const u32x4*>(st + b_rd + j * 2048 + ch);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const u32x4*>(st + a_rd + i * 2048 + ch);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<DT>(fa[i], fb[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue in two passes of 128 output channels (the staging image must fit the 128 KiB) ------------------
+  u16* sC = reinterpret_cast<u16*>(smem);
+  const bool nchw = p.out_layout == LAYOUT_NCHW;
+  constexpr int LDC_M = 128 + 8;      // NHWC image sC[m][n-local]
+  constexpr int LDC_N = G2_BM + 8;    // NCHW image sC[n-local][m]
+  const u32 hw = (u32)(p.Ho * p.Wo);
+  for (u32 half = 0; half < 2; ++half) {
+    if (n0 + half * 128u >= (u32)p.Cout) break;  // workgroup-uniform
+    if ((wn >> 1) == half) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 nl = (wn & 1u) * 64u + j * 16 + fr;
+        const u32 n = n0 + half * 128u + nl;
+        float sc = 1.f, bi = 0.f;
+        int act = p.act;
+        if (n < (u32)p.Cout) {
+          if (p.scale) sc = p.scale[n];
+          bi = p.bias[n];
+          if ((int)n >= p.split) act = p.act2;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const u32 ml = wm * 128u + i * 16 + fg * 4;
+          u32 h[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = f32_to_bits16<DT>(apply_act(acc[i][j][r] * sc + bi, act));
+          if (nchw) {
+            *reinterpret_cast<uint2*>(&sC[nl * LDC_N + ml]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sC[(ml + r) * LDC_M + nl] = (u16)h[r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (!nchw) {
+      for (u32 qd = tid; qd < (u32)(G2_BM * 16); qd += G2_THREADS) {
+        const u32 row = qd >> 4, cc = qd & 15u;
+        const u32 m = m0 + row, n = n0 + half * 128u + cc * 8;
+        if (m >= (u32)p.M || n >= (u32)p.Cout) continue;
+        u32x4 v = *reinterpret_cast<const u32x4*>(&sC[row * LDC_M + cc * 8]);
+        u16* dst = (u16*)p.y + (size_t)m * p.Cout + n;
+        if (n + 8 <= (u32)p.Cout) {
+          if (p.res) {
+            const u32x4 rv = *reinterpret_cast<const u32x4*>((const u16*)p.res + (size_t)m * p.Cout + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float lo = bits16_to_f32<DT>(v[e] & 0xffffu) + bits16_to_f32<DT>(rv[e] & 0xffffu);
+              const float hi = bits16_to_f32<DT>(v[e] >> 16) + bits16_to_f32<DT>(rv[e] >> 16);
+              v[e] = f32_to_bits16<DT>(lo) | (f32_to_bits16<DT>(hi) << 16);
+            }
+          }
+          *reinterpret_cast<u32x4*>(dst) = v;
+        } else {
+          for (u32 e = 0; e < 8 && n + e < (u32)p.Cout; ++e) {
+            float f = bits16_to_f32<DT>((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+            if (p.res) f += bits16_to_f32<DT>(((const u16*)p.res)[(size_t)m * p.Cout + n + e]);
+            dst[e] = (u16)f32_to_bits16<DT>(f);
+          }
+        }
+      }
+    } else {
+      for (u32 qd = tid; qd < (u32)(128 * 32); qd += G2_THREADS) {
+        const u32 nl = qd >> 5, cc = qd & 31u;
+        const u32 n = n0 + half * 128u + nl, m = m0 + cc * 8;
+        if (n >= (u32)p.Cout || m >= (u32)p.M) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&sC[nl * LDC_N + cc * 8]);
+        u16* ybase;
+        u32 ch, cy;
+        if ((int)n < p.split) {
+          ybase = (u16*)p.y;
+          ch = n;
+          cy = (u32)p.split;
+        } else {
+          ybase = (u16*)p.y2;
+          ch = n - (u32)p.split;
+          cy = (u32)(p.Cout - p.split);
+        }
+        const u32 b = m / hw, pix = m % hw;
+        u16* dst = ybase + ((size_t)b * cy + ch) * hw + pix;
+        if (pix + 8 <= hw && m + 8 <= (u32)p.M && (((uintptr_t)dst) & 15u) == 0) {
+          *reinterpret_cast<u32x4*>(dst) = v;
+        } else {
+          for (u32 e = 0; e < 8 && m + e < (u32)p.M; ++e) {
+            const u32 mm = m + e, bb = mm / hw, pp = mm % hw;
+            ybase[((size_t)bb * cy + ch) * hw + pp] = (u16)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // depthwise 3x3
 // ------------------------------------------------------------------------------------------------
 struct DwParams {
@@ -543,8 +711,31 @@ static int plan_splits(int M, int Cout, int KT) {
   return s < 2 ? 1 : (int)s;
 }
 
+// the 256x256 glds kernel pays when there are enough output tiles to fill the chip and N is wide
+static bool use_gemm256(const ConvParams& p) {
+  static const int env = getenv("SSDK_GEMM256") ? atoi(getenv("SSDK_GEMM256")) : 1;
+  if (!env || p.ksplits > 1 || (p.Cin % 8)) return false;
+  const long tiles = (long)((p.M + G2_BM - 1) / G2_BM) * ((p.Cout + G2_BN - 1) / G2_BN);
+  if (env == 2) return true;
+  return p.Cout >= 192 && tiles >= 128;
+}
+
+template <int DT>
+static int launch_gemm256(const ConvParams& p, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm256_kernel<DT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS);
+    attr_done = true;
+  }
+  const unsigned tiles = (unsigned)((p.M + G2_BM - 1) / G2_BM) * (unsigned)((p.Cout + G2_BN - 1) / G2_BN);
+  hipLaunchKernelGGL((conv_gemm256_kernel<DT>), dim3(tiles), dim3(G2_THREADS), G2_LDS, stream, p);
+  return check_launch("conv_gemm256_kernel");
+}
+
 template <int DT>
 static int launch_gemm(const ConvParams& p, hipStream_t stream) {
+  if (use_gemm256(p)) return launch_gemm256<DT>(p, stream);
   const unsigned gm = (unsigned)((p.M + BM - 1) / BM);
   const unsigned gz = (unsigned)p.ksplits;
 #define SSDK_GEMM(WM, WN, FM_, FN_, GY)                                                                          \
@@ -743,6 +934,10 @@ extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t worksp
       p.counters = (unsigned*)workspace;  // zero on entry (allocated zeroed; re-armed by every last arriver)
       p.slabs = (float*)((char*)workspace + 4096);
     }
+  }
+  {
+    const int rc = launch_conv3x3_halo(p, d->dtype, stream);  // 3x3 stride-1 layers with enough tiles
+    if (rc != 1) return rc;
   }
   return d->dtype == SSDK_BF16 ? launch_gemm<SSDK_BF16>(p, stream) : launch_gemm<SSDK_F16>(p, stream);
 }

@@ -1,0 +1,87 @@
+// ssdk_conv_common.h -- parameter block and device helpers shared by the convolution kernels
+// (ssdk_conv.hip: 128-tile / 256-tile implicit GEMM, depthwise, stem; ssdk_conv3x3.hip: halo-tile 3x3).
+#pragma once
+#include <stdio.h>
+
+#include "ssdk_common.h"
+
+namespace ssdk {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { LAYOUT_NCHW = 0, LAYOUT_NHWC = 1 };
+
+struct ConvParams {
+  const void* x;
+  const void* w;
+  const float* scale;
+  const float* bias;
+  const void* res;  // residual, same layout/dtype as y (NHWC only)
+  void* y;
+  void* y2;
+  int N, Cin, H, W, Cout, k, stride, pad, Ho, Wo;
+  int M;           // N*Ho*Wo
+  int cin_chunks;  // ceil(Cin/32)
+  int KT;          // k*k*cin_chunks
+  int act, act2, split;  // channels >= split use act2 and go to y2 (split == Cout: single output)
+  int in_layout, out_layout;
+  // split-K (small-M layers: too few output tiles to fill 256 CUs and a long, latency-bound k-loop):
+  // blockIdx.z owns k-tiles [z*kt_per, (z+1)*kt_per); partial accumulators go to fp32 slabs in fragment order,
+  // the last workgroup to arrive on a tile (agent-scope release/acquire on a counter) sums them and runs
+  // the epilogue.  Counters are zero on entry and reset by the last arriver.
+  int ksplits, kt_per;
+  float* slabs;
+  unsigned* counters;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case SSDK_ACT_RELU: return v > 0.f ? v : 0.f;
+    case SSDK_ACT_RELU6: return v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
+    case SSDK_ACT_SILU: return v / (1.0f + __expf(-v));
+    case SSDK_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+    default: return v;
+  }
+}
+
+template <int DT> __device__ __forceinline__ u32 f32_to_bits16(float v);
+template <> __device__ __forceinline__ u32 f32_to_bits16<SSDK_BF16>(float v) {
+  u32 b = __builtin_bit_cast(u32, v);
+  if ((b & 0x7fffffffu) > 0x7f800000u) return (b >> 16) | 0x40u;  // quiet NaN
+  return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;                  // round to nearest even
+}
+template <> __device__ __forceinline__ u32 f32_to_bits16<SSDK_F16>(float v) {
+  _Float16 h = (_Float16)v;
+  return (u32)__builtin_bit_cast(u16, h);
+}
+template <int DT> __device__ __forceinline__ float bits16_to_f32(u32 h) {
+  if constexpr (DT == SSDK_BF16) return bf16_bits_to_f32(h);
+  else return f16_bits_to_f32(h);
+}
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, f32x4 c) {
+  if constexpr (DT == SSDK_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(1))) const unsigned char glb_u8;
+
+// 16-byte zero page: masked chunks of a direct-to-LDS load read it (a masked-off lane would leave stale LDS)
+static __device__ __attribute__((aligned(16))) unsigned g_zero16[4];  // one copy per translation unit
+
+// async global -> LDS copy of 16 bytes per lane; the LDS destination is wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((glb_u8*)g, (lds_u8*)l, 16, 0, 0);
+}
+
+// halo-tile 3x3 kernel (ssdk_conv3x3.hip); returns SSDK_OK, or 1 when the layer does not fit it
+int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream);
+
+}  // namespace ssdk

@@ -76,6 +76,7 @@ def _load():
     vp, i32, f32, sz = c.c_void_p, c.c_int, c.c_float, c.c_size_t
     lib.ssdk_version.restype = i32
     lib.ssdk_last_error.restype = c.c_char_p
+    lib.ssdk_last_kernel.restype = c.c_char_p
     lib.ssdk_device_info.argtypes = [c.POINTER(i32), c.POINTER(i32), c.POINTER(sz), c.c_char_p, i32]
     lib.ssdk_generate_anchors.argtypes = [i32, c.POINTER(f32), i32, c.POINTER(f32), i32, c.POINTER(f32)]
     lib.ssdk_decode_workspace_bytes.restype = sz
@@ -113,10 +114,15 @@ def _load():
 
 
 lib = _load()
-EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_device_info", "ssdk_generate_anchors",
+EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_device_info", "ssdk_generate_anchors",
            "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
            "ssdk_match_targets_by_scale", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
+
+
+def last_kernel():
+    """Name of the kernel this thread launched last (which variant a layer was dispatched to)."""
+    return lib.ssdk_last_kernel().decode()
 
 
 class SsdkError(RuntimeError):

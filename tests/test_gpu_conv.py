@@ -85,6 +85,82 @@ def test_dense_conv(cin, cout, k, stride, h, w, n, act, dtype_name):
     _check(y2, _ref(x, conv, bn, act), dtype, "dense nchw")
 
 
+HALO, G256 = "conv3x3_halo_kernel", "conv_gemm256_kernel"
+LARGE = [
+    # cin, cout, k, stride, h, w, n, act, kernel the layer must be dispatched to
+    (96, 504, 3, 1, 32, 32, 8, "none", HALO),      # SSD head L0: 16x16 patches, last slab holds 32 channels
+    (40, 128, 3, 1, 32, 32, 24, "relu", HALO),     # Cin < 64: one partial slab, masked lanes
+    (320, 504, 3, 1, 16, 16, 32, "sigmoid", HALO), # SSD head L1: one whole map per tile
+    (64, 720, 3, 1, 19, 19, 16, "relu", HALO),     # odd map: ragged patches, scalar NCHW stores
+    (256, 256, 3, 1, 40, 40, 8, "relu", HALO),     # FPN tower P4: 6x40 patches
+    (128, 256, 3, 1, 10, 10, 128, "relu", HALO),   # two whole maps per tile
+    (512, 504, 3, 1, 8, 8, 96, "none", HALO),      # SSD head L2: four whole maps per tile
+    (64, 256, 1, 1, 64, 64, 8, "relu", G256),      # wide 1x1
+    (96, 320, 3, 2, 64, 64, 32, "relu6", G256),    # 3x3 stride 2, partial 64-channel slab
+    (72, 200, 1, 1, 90, 50, 8, "silu", G256),      # ragged everything
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,h,w,n,act,kernel", LARGE)
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+def test_large_tile_kernels(cin, cout, k, stride, h, w, n, act, kernel, dtype_name):
+    """The 256-row tile kernels (halo-tile 3x3, 256x256 flat-K) only take layers with enough tiles to fill the
+    chip; these shapes are sized to reach them, and the dispatch is asserted."""
+    import torch
+    import torch.nn as nn
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    torch.manual_seed(cin * 7 + cout + h)
+    conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False)
+    bn = nn.BatchNorm2d(cout)
+    bn.running_mean.normal_(0, 0.2)
+    bn.running_var.uniform_(0.5, 1.5)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_(0, 0.2)
+    conv.weight.data = conv.weight.data.to(dtype).float()
+    x = torch.randn(n, cin, h, w).to(dtype)
+    conv, bn = conv.cuda(), bn.cuda()
+    pack = FC.ConvPack(conv, bn, act, dtype)
+    want = _ref(x, conv, bn, act)
+    y = FC.conv_native(x.cuda(), pack)
+    assert N.last_kernel() == kernel, N.last_kernel()
+    _check(y, want, dtype, "large nhwc")
+    y2 = FC.conv_native(x.cuda(), pack, nchw_out=True)
+    assert N.last_kernel() == kernel
+    _check(y2, want, dtype, "large nchw")
+
+
+def test_halo_kernel_residual_and_split_heads():
+    import torch
+    import torch.nn as nn
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+
+    dtype = torch.bfloat16
+    torch.manual_seed(11)
+    conv = nn.Conv2d(256, 256, 3, padding=1, bias=False).cuda()
+    bn = nn.BatchNorm2d(256).cuda()
+    conv.weight.data = conv.weight.data.to(dtype).float()
+    x = torch.randn(48, 256, 16, 16).to(dtype)
+    res = torch.randn(48, 256, 16, 16).to(dtype)
+    y = FC.conv_native(x.cuda(), FC.ConvPack(conv, bn, "none", dtype), residual=res.cuda())
+    assert N.last_kernel() == HALO
+    _check(y, _ref(x, conv, bn, "none", res), dtype, "halo residual")
+    loc = nn.Conv2d(96, 24, 3, padding=1).cuda()
+    conf = nn.Conv2d(96, 480, 3, padding=1).cuda()
+    for m in (loc, conf):
+        m.weight.data = (m.weight.data * 3).to(dtype).float()
+        m.bias.data.normal_(0, 0.5)
+    f = torch.randn(8, 96, 32, 32).to(dtype)
+    l, c = FC.conv_native(f.cuda(), FC.pack_heads(loc, conf, dtype), act="none", nchw_out=True, split=24,
+                          act2="sigmoid")
+    assert N.last_kernel() == HALO
+    _check(l, _ref(f, loc, None, "none"), dtype, "halo split loc")
+    _check(c, _ref(f, conf, None, "sigmoid"), dtype, "halo split conf")
+
+
 def test_dense_conv_residual_and_split():
     import torch
     import torch.nn as nn
