@@ -220,6 +220,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
   const bool nchw = p.out_layout == LAYOUT_NCHW;
   constexpr int LDC_M = BN + 8;   // NHWC image: sC[m][n], row stride in elements
   constexpr int LDC_N = BM + 8;   // NCHW image: sC[n][m]
+  const bool any_sig = act_is_sig(p.act) || act_is_sig(p.act2);
+  const bool any_clamp = act_is_clamp(p.act) || act_is_clamp(p.act2);
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const u32 nl = wn * (FN * 16) + j * 16 + fr;
@@ -231,18 +233,18 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
       bi = p.bias[n];
       if ((int)n >= p.split) act = p.act2;
     }
+    const ActSel as = act_sel(act);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const u32 ml = wm * (FM * 16) + i * 16 + fg * 4;
-      u32 h[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) h[r] = f32_to_bits16<DT>(apply_act(acc[i][j][r] * sc + bi, act));
+      const uint2 h = epilogue4<DT>(acc[i][j], sc, bi, as, any_sig, any_clamp);
       if (nchw) {
-        uint2 pk = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-        *reinterpret_cast<uint2*>(&sC[nl * LDC_N + ml]) = pk;
+        *reinterpret_cast<uint2*>(&sC[nl * LDC_N + ml]) = h;
       } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sC[(ml + r) * LDC_M + nl] = (u16)h[r];
+        sC[(ml + 0) * LDC_M + nl] = (u16)(h.x & 0xffffu);
+        sC[(ml + 1) * LDC_M + nl] = (u16)(h.x >> 16);
+        sC[(ml + 2) * LDC_M + nl] = (u16)(h.y & 0xffffu);
+        sC[(ml + 3) * LDC_M + nl] = (u16)(h.y >> 16);
       }
     }
   }
@@ -454,6 +456,8 @@ __global__ __launch_bounds__(G2_THREADS) void conv_gemm256_kernel(const ConvPara
   for (u32 half = 0; half < 2; ++half) {
     if (n0 + half * 128u >= (u32)p.Cout) break;  // workgroup-uniform
     if ((wn >> 1) == half) {
+      const bool any_sig = act_is_sig(p.act) || act_is_sig(p.act2);
+      const bool any_clamp = act_is_clamp(p.act) || act_is_clamp(p.act2);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const u32 nl = (wn & 1u) * 64u + j * 16 + fr;
@@ -465,17 +469,18 @@ __global__ __launch_bounds__(G2_THREADS) void conv_gemm256_kernel(const ConvPara
           bi = p.bias[n];
           if ((int)n >= p.split) act = p.act2;
         }
+        const ActSel as = act_sel(act);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const u32 ml = wm * 128u + i * 16 + fg * 4;
-          u32 h[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = f32_to_bits16<DT>(apply_act(acc[i][j][r] * sc + bi, act));
+          const uint2 h = epilogue4<DT>(acc[i][j], sc, bi, as, any_sig, any_clamp);
           if (nchw) {
-            *reinterpret_cast<uint2*>(&sC[nl * LDC_N + ml]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            *reinterpret_cast<uint2*>(&sC[nl * LDC_N + ml]) = h;
           } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sC[(ml + r) * LDC_M + nl] = (u16)h[r];
+            sC[(ml + 0) * LDC_M + nl] = (u16)(h.x & 0xffffu);
+            sC[(ml + 1) * LDC_M + nl] = (u16)(h.x >> 16);
+            sC[(ml + 2) * LDC_M + nl] = (u16)(h.y & 0xffffu);
+            sC[(ml + 3) * LDC_M + nl] = (u16)(h.y >> 16);
           }
         }
       }

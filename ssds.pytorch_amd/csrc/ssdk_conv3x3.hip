@@ -43,15 +43,30 @@ struct HaloParams {
   int n_tiles;               // ceil(Cout / 128)
   int vec_nchw;              // tw % 8 == 0 && Wo % 8 == 0: 16-byte NCHW stores
   unsigned x_bytes, w_bytes;  // buffer-descriptor ranges (tensors < 4 GiB)
+  unsigned mg_ntiles, mg_tx, mg_ty, mg_ppi, mg_tw, mg_hw2, mg_halo;  // ceil(2^32 / d) of the divisors below
+  long long* dbg;             // SSDK_H3_DBG=1: cycle stamps of workgroup 0 / wave 0 (4 per k-step)
 };
 
+// n / d for n*d < 2^32 with M = ceil(2^32 / d) (host side: magic()); d == 1 has no 32-bit magic
+__device__ __forceinline__ u32 fdiv(u32 n, u32 d, u32 M) { return d == 1u ? n : __umulhi(n, M); }
+
 #define H3_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define H3_STAMP(slot)                                                                      \
+  do {                                                                                      \
+    if (hp.dbg && blockIdx.x == 0 && tid == 0 && stamp_i < 60)                              \
+      hp.dbg[stamp_i * 4 + (slot)] = (long long)__builtin_readcyclecounter();               \
+  } while (0)
 
 template <int DT>
 __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloParams hp) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const ConvParams& p = hp.c;
   const u32 tid = threadIdx.x, lane = tid & 63u;
+#define H3_MARK(slot)                                                                                   \
+  do {                                                                                                  \
+    if (hp.dbg && blockIdx.x == 0 && tid == 0) hp.dbg[240 + (slot)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+  H3_MARK(0);
   const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const u32 wm = wave >> 1, wn = wave & 1u;
 
@@ -59,14 +74,27 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
   const u32 nwg = gridDim.x, id = blockIdx.x;
   const u32 q8 = nwg >> 3, r8 = nwg & 7u, xcd = id & 7u;
   const u32 lin = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (id >> 3);
-  const u32 nt = lin % (u32)hp.n_tiles;
-  u32 pt = lin / (u32)hp.n_tiles;
-  const u32 tx = pt % (u32)hp.tiles_x;
-  pt /= (u32)hp.tiles_x;
-  const u32 ty = pt % (u32)hp.tiles_y;
-  const u32 grp = pt / (u32)hp.tiles_y;
+  u32 pt = fdiv(lin, (u32)hp.n_tiles, hp.mg_ntiles);
+  const u32 nt = lin - pt * (u32)hp.n_tiles;
+  u32 pq = fdiv(pt, (u32)hp.tiles_x, hp.mg_tx);
+  const u32 tx = pt - pq * (u32)hp.tiles_x;
+  const u32 grp = fdiv(pq, (u32)hp.tiles_y, hp.mg_ty);
+  const u32 ty = pq - grp * (u32)hp.tiles_y;
   const int b0 = (int)grp * hp.imgs, y0 = (int)ty * hp.th, x0 = (int)tx * hp.tw;
   const u32 n0 = nt * H3_BN;
+
+  // per-column scale / bias of this lane's four accumulator columns: fetched first, used last
+  float e_sc[4], e_bi[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32 n = n0 + wn * 64u + j * 16 + (lane & 15u);
+    e_sc[j] = 1.f;
+    e_bi[j] = 0.f;
+    if (n < (u32)p.Cout) {
+      if (p.scale) e_sc[j] = p.scale[n];
+      e_bi[j] = p.bias[n];
+    }
+  }
 
   const int Cin = p.Cin, H = p.H, W = p.W;
   const int HW2 = hp.tw + 2, HH2 = hp.th + 2;
@@ -92,8 +120,8 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
     const int hr = (t * 8 + (int)wave) * 8 + (int)lrow;
     u32 off = OOB;
     if (hr < hp.hrows) {
-      const int img = hr / (HH2 * HW2), rr = hr % (HH2 * HW2);
-      const int hy = rr / HW2, hx = rr % HW2;
+      const int img = (int)fdiv((u32)hr, (u32)(HH2 * HW2), hp.mg_halo), rr = hr - img * (HH2 * HW2);
+      const int hy = (int)fdiv((u32)rr, (u32)HW2, hp.mg_hw2), hx = rr - hy * HW2;
       const int b = b0 + img, iy = y0 + hy - 1, ix = x0 + hx - 1;
       if (b < p.N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
         off = (u32)(((((long)b * H + iy) * W + ix) * Cin + lci) * 2);
@@ -118,8 +146,8 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
     for (int i = 0; i < 4; ++i) {
       int ml = (int)(wm * 64u + i * 16 + fr);
       if (ml >= npix) ml = 0;  // rows past the patch compute garbage that is never stored
-      const int img = ml / (hp.th * hp.tw), rr = ml % (hp.th * hp.tw);
-      const int y = rr / hp.tw, x = rr % hp.tw;
+      const int img = (int)fdiv((u32)ml, (u32)(hp.th * hp.tw), hp.mg_ppi), rr = ml - img * (hp.th * hp.tw);
+      const int y = (int)fdiv((u32)rr, (u32)hp.tw, hp.mg_tw), x = rr - y * hp.tw;
       a_hr[i] = (img * HH2 + y) * HW2 + x;
     }
 #pragma unroll
@@ -161,122 +189,166 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
   for (int t = 0; t < H3_NPIECE; ++t) load_a(t, 0);
   load_b(0, 0, 0);
   load_b(1, 0, 1);
+  H3_MARK(1);
   H3_WAIT(2);  // everything but the weights of step 1
   __builtin_amdgcn_s_barrier();
+  H3_MARK(2);
 
+  // ---- main loop: two phases per k-step, the two wave groups staggered by one phase ---------------------------
+  //   R(k): issue the loads of step k+2, read ALL fragments of step k into registers, counted vmcnt wait
+  //   M(k): 32 MFMAs
+  // separated by workgroup barriers.  Waves w and w+4 share a SIMD; group 1 (waves 4..7) runs one extra barrier
+  // first and therefore stays one phase behind: while a SIMD's group-0 wave is in M(k) its group-1 wave is in
+  // R(k), then group 1 runs M(k) while group 0 reads R(k+1) -- the matrix pipe of every SIMD always has a wave
+  // with operands ready, and no wave waits for LDS latency while holding the pipe.
+  // Hazards (slot 2k = group 0 in R(k) / group 1 in M(k-1); slot 2k+1 = group 0 in M(k) / group 1 in R(k)):
+  //   weights of step k+1 are waited for at the end of R(k) by both groups (slots 2k, 2k+1) and first read in slot
+  //   2k+2; their stage was last read in slot 2k-3 and is refilled from slot 2k-2 on; halo pieces likewise.
   const bool tail_half = tail <= 32;  // the last slab holds <= 32 channels: one k-substep is enough
+  const bool g1 = wave >= 4u;
   u32 abuf = 0;                       // byte offset of the current halo buffer
+  if (g1) __builtin_amdgcn_s_barrier();
   for (int cc = 0; cc < cchunks; ++cc) {
     const bool half = tail_half && cc == cchunks - 1;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      // loads: weights two steps ahead + (taps 0..6) one halo piece of the next slab
+      const int stamp_i = cc * 9 + tap;
+      H3_STAMP(0);
+      // R: loads two steps ahead (+ taps 0..5: one halo piece of the next slab), then this step's fragments
       if (tap + 2 < 9) load_b((tap + 2) % 3, cc, tap + 2);
       else load_b((tap + 2) % 3, cc + 1, tap + 2 - 9);
       if (tap < H3_NPIECE) load_a(tap, cc + 1);
       const u32 sboff = (u32)((tap % 3) * H3_B_BYTES);
-      {
-        u32x4 fa[4], fb[4];
+      u32x4 fa0[4], fb0[4], fa1[4], fb1[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const u32x4*>(smem + b_ad0 + sboff + j * 2048);
+      for (int j = 0; j < 4; ++j) fb0[j] = *reinterpret_cast<const u32x4*>(smem + b_ad0 + sboff + j * 2048);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(smem + (a_ad[tap][i] + abuf));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<DT>(fa[i], fb[j], acc[i][j]);
-      }
+      for (int i = 0; i < 4; ++i) fa0[i] = *reinterpret_cast<const u32x4*>(smem + (a_ad[tap][i] + abuf));
       if (!half) {
-        u32x4 fa[4], fb[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const u32x4*>(smem + b_ad1 + sboff + j * 2048);
+        for (int j = 0; j < 4; ++j) fb1[j] = *reinterpret_cast<const u32x4*>(smem + b_ad1 + sboff + j * 2048);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(smem + ((a_ad[tap][i] + abuf) ^ 64u));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<DT>(fa[i], fb[j], acc[i][j]);
+        for (int i = 0; i < 4; ++i) fa1[i] = *reinterpret_cast<const u32x4*>(smem + ((a_ad[tap][i] + abuf) ^ 64u));
       }
+      H3_STAMP(1);
       if (tap < H3_NPIECE) H3_WAIT(3);
       else H3_WAIT(2);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      H3_STAMP(2);
+      // M
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<DT>(fa0[i], fb0[j], acc[i][j]);
+      if (!half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<DT>(fa1[i], fb1[j], acc[i][j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      H3_STAMP(3);
     }
-    abuf ^= (u32)H3_A_BYTES;  // (buffer 0 starts at 0, so toggling the offset is an XOR with its size: 57344 = 0xE000)
+    abuf ^= (u32)H3_A_BYTES;
   }
+  if (!g1) __builtin_amdgcn_s_barrier();  // re-align the groups
   H3_WAIT(0);
   __builtin_amdgcn_s_barrier();
+  H3_MARK(3);
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
   u16* sC = reinterpret_cast<u16*>(smem);
   const bool nchw = p.out_layout == LAYOUT_NCHW;
   constexpr int LDC_M = H3_BN + 8;  // NHWC image sC[m][n]
   constexpr int LDC_N = 256 + 8;    // NCHW image sC[n][m]
+  const bool any_sig = act_is_sig(p.act) || act_is_sig(p.act2);
+  const bool any_clamp = act_is_clamp(p.act) || act_is_clamp(p.act2);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const u32 nl = wn * 64u + j * 16 + fr;
     const u32 n = n0 + nl;
-    float sc = 1.f, bi = 0.f;
-    int act = p.act;
-    if (n < (u32)p.Cout) {
-      if (p.scale) sc = p.scale[n];
-      bi = p.bias[n];
-      if ((int)n >= p.split) act = p.act2;
-    }
+    const float sc = e_sc[j], bi = e_bi[j];
+    const ActSel as = act_sel((int)n >= p.split ? p.act2 : p.act);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const u32 ml = wm * 64u + i * 16 + fg * 4;
-      u32 h[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) h[r] = f32_to_bits16<DT>(apply_act(acc[i][j][r] * sc + bi, act));
+      const uint2 h = epilogue4<DT>(acc[i][j], sc, bi, as, any_sig, any_clamp);
       if (nchw) {
-        *reinterpret_cast<uint2*>(&sC[nl * LDC_N + ml]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        *reinterpret_cast<uint2*>(&sC[nl * LDC_N + ml]) = h;
       } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sC[(ml + r) * LDC_M + nl] = (u16)h[r];
+        sC[(ml + 0) * LDC_M + nl] = (u16)(h.x & 0xffffu);
+        sC[(ml + 1) * LDC_M + nl] = (u16)(h.x >> 16);
+        sC[(ml + 2) * LDC_M + nl] = (u16)(h.y & 0xffffu);
+        sC[(ml + 3) * LDC_M + nl] = (u16)(h.y >> 16);
       }
     }
   }
   __syncthreads();
+  H3_MARK(4);
 
   const int ppi = hp.th * hp.tw;  // pixels per image of the patch
   const u32 hw = (u32)(p.Ho * p.Wo);
+  auto pixel_of = [&](int ml, u32* b_out, u32* pix_out) -> bool {  // tile row -> (image, oy*Wo + ox)
+    if (ml >= npix) return false;
+    const int img = (int)fdiv((u32)ml, (u32)ppi, hp.mg_ppi), rr = ml - img * ppi;
+    const int yy = (int)fdiv((u32)rr, (u32)hp.tw, hp.mg_tw);
+    const int oy = y0 + yy, ox = x0 + (rr - yy * hp.tw), b = b0 + img;
+    if (b >= p.N || oy >= p.Ho || ox >= p.Wo) return false;
+    *b_out = (u32)b;
+    *pix_out = (u32)(oy * p.Wo + ox);
+    return true;
+  };
   if (!nchw) {
-    for (u32 qd = tid; qd < 256u * 16u; qd += H3_THREADS) {
-      const u32 row = qd >> 4, cch = qd & 15u;
-      const u32 n = n0 + cch * 8;
-      if ((int)row >= npix || n >= (u32)p.Cout) continue;
-      const int img = (int)row / ppi, rr = (int)row % ppi;
-      const int oy = y0 + rr / hp.tw, ox = x0 + rr % hp.tw, b = b0 + img;
-      if (b >= p.N || oy >= p.Ho || ox >= p.Wo) continue;
-      const size_t m = ((size_t)b * p.Ho + oy) * p.Wo + ox;
-      u32x4 v = *reinterpret_cast<const u32x4*>(&sC[row * LDC_M + cch * 8]);
-      u16* dst = (u16*)p.y + m * p.Cout + n;
-      if (n + 8 <= (u32)p.Cout) {
-        if (p.res) {
-          const u32x4 rv = *reinterpret_cast<const u32x4*>((const u16*)p.res + m * p.Cout + n);
+    const u32 cch = tid & 15u, n = n0 + cch * 8;  // this thread's 8-channel column group in every iteration
+    if (n < (u32)p.Cout) {
+#pragma unroll 2
+      for (u32 it = 0; it < 8; ++it) {
+        const u32 row = (tid >> 4) + it * 32u;
+        u32 pb, pp;
+        if (!pixel_of((int)row, &pb, &pp)) continue;
+        const size_t m = (size_t)pb * hw + pp;
+        u32x4 v = *reinterpret_cast<const u32x4*>(&sC[row * LDC_M + cch * 8]);
+        u16* dst = (u16*)p.y + m * p.Cout + n;
+        if (n + 8 <= (u32)p.Cout) {
+          if (p.res) {
+            const u32x4 rv = *reinterpret_cast<const u32x4*>((const u16*)p.res + m * p.Cout + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float lo = bits16_to_f32<DT>(v[e] & 0xffffu) + bits16_to_f32<DT>(rv[e] & 0xffffu);
-            const float hi = bits16_to_f32<DT>(v[e] >> 16) + bits16_to_f32<DT>(rv[e] >> 16);
-            v[e] = f32_to_bits16<DT>(lo) | (f32_to_bits16<DT>(hi) << 16);
+            for (int e = 0; e < 4; ++e) {
+              const float lo = bits16_to_f32<DT>(v[e] & 0xffffu) + bits16_to_f32<DT>(rv[e] & 0xffffu);
+              const float hi = bits16_to_f32<DT>(v[e] >> 16) + bits16_to_f32<DT>(rv[e] >> 16);
+              v[e] = pack2_16<DT>(lo, hi);
+            }
           }
-        }
-        *reinterpret_cast<u32x4*>(dst) = v;
-      } else {
-        for (u32 e = 0; e < 8 && n + e < (u32)p.Cout; ++e) {
-          float f = bits16_to_f32<DT>((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-          if (p.res) f += bits16_to_f32<DT>(((const u16*)p.res)[m * p.Cout + n + e]);
-          dst[e] = (u16)f32_to_bits16<DT>(f);
+          *reinterpret_cast<u32x4*>(dst) = v;
+        } else {
+          for (u32 e = 0; e < 8 && n + e < (u32)p.Cout; ++e) {
+            float f = bits16_to_f32<DT>((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+            if (p.res) f += bits16_to_f32<DT>(((const u16*)p.res)[m * p.Cout + n + e]);
+            dst[e] = (u16)f32_to_bits16<DT>(f);
+          }
         }
       }
     }
   } else {
-    for (u32 qd = tid; qd < (u32)H3_BN * 32u; qd += H3_THREADS) {
-      const u32 nl = qd >> 5, cch = qd & 31u;
+    // this thread owns the same 8 pixels (tile rows ml .. ml+7) in every iteration; only the channel changes
+    const int ml = (int)(tid & 31u) * 8;
+    u32 b8[8], p8[8];
+    bool ok8[8];
+    if (hp.vec_nchw) {
+      ok8[0] = pixel_of(ml, &b8[0], &p8[0]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ok8[e] = pixel_of(ml + e, &b8[e], &p8[e]);
+    }
+    for (u32 it = 0; it < (u32)H3_BN / 16u; ++it) {
+      const u32 nl = (tid >> 5) + it * 16u;
       const u32 n = n0 + nl;
-      const int ml = (int)cch * 8;
-      if (n >= (u32)p.Cout || ml >= npix) continue;
+      if (n >= (u32)p.Cout) break;
       const u32x4 v = *reinterpret_cast<const u32x4*>(&sC[nl * LDC_N + ml]);
       u16* ybase;
       u32 ch, cy;
@@ -290,21 +362,18 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
         cy = (u32)(p.Cout - p.split);
       }
       if (hp.vec_nchw) {  // the 8 pixels are consecutive in x and 16-byte aligned in global memory
-        const int img = ml / ppi, rr = ml % ppi;
-        const int oy = y0 + rr / hp.tw, ox = x0 + rr % hp.tw, b = b0 + img;
-        if (b >= p.N || oy >= p.Ho || ox >= p.Wo) continue;
-        u16* dst = ybase + ((size_t)b * cy + ch) * hw + (size_t)oy * p.Wo + ox;
-        *reinterpret_cast<u32x4*>(dst) = v;
+        if (!ok8[0]) break;
+        *reinterpret_cast<u32x4*>(ybase + ((size_t)b8[0] * cy + ch) * hw + p8[0]) = v;
       } else {
-        for (int e = 0; e < 8 && ml + e < npix; ++e) {
-          const int mm = ml + e, img = mm / ppi, rr = mm % ppi;
-          const int oy = y0 + rr / hp.tw, ox = x0 + rr % hp.tw, b = b0 + img;
-          if (b >= p.N || oy >= p.Ho || ox >= p.Wo) continue;
-          ybase[((size_t)b * cy + ch) * hw + (size_t)oy * p.Wo + ox] = (u16)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (!ok8[e]) continue;
+          ybase[((size_t)b8[e] * cy + ch) * hw + p8[e]] = (u16)((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
         }
       }
     }
   }
+  H3_MARK(5);
 }
 
 // Patch shape for an (N, Ho, Wo) output: maximise the fraction of the 256 tile rows that are real pixels.
@@ -357,13 +426,21 @@ int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream) {
   hp.c = p;
   if (!plan_patch(p.N, p.Ho, p.Wo, &hp)) return 1;
   hp.n_tiles = (p.Cout + H3_BN - 1) / H3_BN;
+  auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+  hp.mg_ntiles = magic(hp.n_tiles);
+  hp.mg_tx = magic(hp.tiles_x);
+  hp.mg_ty = magic(hp.tiles_y);
+  hp.mg_ppi = magic(hp.th * hp.tw);
+  hp.mg_tw = magic(hp.tw);
+  hp.mg_hw2 = magic(hp.tw + 2);
+  hp.mg_halo = magic((hp.th + 2) * (hp.tw + 2));
   const long xb = (long)p.N * p.H * p.W * p.Cin * 2, wb = (long)p.Cout * 9 * p.Cin * 2;
   if (xb >= 0xfffffff0l || wb >= 0xfffffff0l) return 1;  // 32-bit buffer offsets
   hp.x_bytes = (unsigned)xb;
   hp.w_bytes = (unsigned)wb;
   const long tiles = (long)hp.groups * hp.tiles_y * hp.tiles_x * hp.n_tiles;
   if (env != 2 && tiles < 96) return 1;  // too few tiles to fill the chip: the split-K path is faster
-  if (tiles >= (1l << 31)) return 1;
+  if (tiles >= (1l << 26)) return 1;  // keeps tile-id * divisor < 2^32 for the magic divisions
   static bool attr_done[2] = {false, false};
   const int di = dtype == SSDK_BF16 ? 0 : 1;
   if (!attr_done[di]) {
@@ -375,10 +452,31 @@ int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS);
     attr_done[di] = true;
   }
+  static const int dbg = getenv("SSDK_H3_DBG") ? atoi(getenv("SSDK_H3_DBG")) : 0;
+  hp.dbg = nullptr;
+  if (dbg) {
+    (void)hipMalloc((void**)&hp.dbg, 64 * 4 * sizeof(long long));
+    (void)hipMemsetAsync(hp.dbg, 0, 64 * 4 * sizeof(long long), stream);
+  }
   if (di == 0)
     hipLaunchKernelGGL((conv3x3_halo_kernel<SSDK_BF16>), dim3((unsigned)tiles), dim3(H3_THREADS), H3_LDS, stream, hp);
   else
     hipLaunchKernelGGL((conv3x3_halo_kernel<SSDK_F16>), dim3((unsigned)tiles), dim3(H3_THREADS), H3_LDS, stream, hp);
+  if (dbg) {  // debug only: synchronises and prints the per-step phase times of workgroup 0 / wave 0
+    long long h[64 * 4];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(h, hp.dbg, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(hp.dbg);
+    static int printed = 0;
+    if (printed++ < dbg) {
+      fprintf(stderr, "[h3 dbg] step: issue+reads | waits+barrier | mfma+barrier | (next step start - this)\n");
+      fprintf(stderr, "[h3 dbg] setup %lld | first loads %lld | loop %lld | epilogue math+stage %lld | stores %lld\n",
+              h[241] - h[240], h[242] - h[241], h[243] - h[242], h[244] - h[243], h[245] - h[244]);
+      for (int i = 0; i < 60 && h[i * 4] && dbg > 1; ++i)
+        fprintf(stderr, "[h3 dbg] %2d: %6lld %6lld %6lld  total %6lld\n", i, h[i * 4 + 1] - h[i * 4], h[i * 4 + 2] - h[i * 4 + 1],
+                h[i * 4 + 3] - h[i * 4 + 2], (i < 63 && h[(i + 1) * 4]) ? h[(i + 1) * 4] - h[i * 4] : 0ll);
+    }
+  }
   return check_launch("conv3x3_halo_kernel");
 }
 

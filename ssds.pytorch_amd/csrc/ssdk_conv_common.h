@@ -70,6 +70,61 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, f32x4 c)
 }
 
 
+// ---- epilogue arithmetic: y = act(acc * scale + bias) -> 16-bit, four accumulator rows at a time -------------
+// The activation id can differ per lane (split heads: loc columns are linear, conf columns sigmoid), so it is
+// turned into per-lane clamp bounds + a sigmoid/silu selector once per column; the transcendental uses the
+// hardware exp2/rcp (1 ulp each, far below the 16-bit output rounding) and the conversion the packed
+// v_cvt_pk_bf16_f32 / v_cvt_f16_f32 (round to nearest even, NaN preserved).
+struct ActSel {
+  float lo, hi;
+  int mode;  // 0 linear/clamp, 1 sigmoid, 2 silu
+};
+__device__ __forceinline__ ActSel act_sel(int act) {
+  ActSel a;
+  a.lo = -__builtin_inff();
+  a.hi = __builtin_inff();
+  a.mode = 0;
+  if (act == SSDK_ACT_RELU) a.lo = 0.f;
+  else if (act == SSDK_ACT_RELU6) {
+    a.lo = 0.f;
+    a.hi = 6.f;
+  } else if (act == SSDK_ACT_SIGMOID) a.mode = 1;
+  else if (act == SSDK_ACT_SILU) a.mode = 2;
+  return a;
+}
+__device__ __forceinline__ bool act_is_sig(int act) { return act == SSDK_ACT_SIGMOID || act == SSDK_ACT_SILU; }
+__device__ __forceinline__ bool act_is_clamp(int act) { return act == SSDK_ACT_RELU || act == SSDK_ACT_RELU6; }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int DT>
+__device__ __forceinline__ u32 pack2_16(float a, float b) {
+  const f32x2 v = {a, b};
+  if constexpr (DT == SSDK_BF16) return __builtin_bit_cast(u32, __builtin_convertvector(v, bf16x2));
+  else return __builtin_bit_cast(u32, __builtin_convertvector(v, f16x2));
+}
+// any_sig / any_clamp are workgroup-uniform (does ANY column of this launch use a sigmoid-type / clamp-type act)
+template <int DT>
+__device__ __forceinline__ uint2 epilogue4(const f32x4 acc, float sc, float bi, const ActSel a, bool any_sig,
+                                           bool any_clamp) {
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = acc[r] * sc + bi;
+  if (any_sig) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * v[r]));
+      v[r] = a.mode == 1 ? sg : (a.mode == 2 ? v[r] * sg : v[r]);
+    }
+  }
+  if (any_clamp) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = __builtin_fminf(__builtin_fmaxf(v[r], a.lo), a.hi);
+  }
+  return make_uint2(pack2_16<DT>(v[0], v[1]), pack2_16<DT>(v[2], v[3]));
+}
+
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef __attribute__((address_space(1))) const unsigned char glb_u8;
 
