@@ -29,6 +29,7 @@ for _p in (ROOT, os.path.join(ROOT, "ssds.pytorch_amd")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md), no sparsity
 
 
 def parse():
@@ -39,6 +40,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--cfg", default=os.path.join(ROOT, "experiments", "cfgs", "ssd_mobilenetv2_512.yml"))
     ap.add_argument("--cpu-sample", type=int, default=4, help="images for the CPU baseline (0 = skip)")
+    ap.add_argument("--layers", type=int, default=0, help="1: add the per-layer table (us, TFLOP/s, GB/s) to the JSON")
     ap.add_argument("--channels-last", type=int, default=int(os.environ.get("SSDK_CHANNELS_LAST", "0")))
     return ap.parse_args()
 
@@ -127,6 +129,33 @@ def main():
     fwd_ms = time_fn(lambda: model(x), max(3, min(10, args.steps)))
     dec_ms = time_fn(lambda: decoder(loc, conf, anchors), max(3, min(20, args.steps)))
 
+    # ---- per-layer table (separate, untimed pass: one hipEvent per op of the recorded plan) ------------------
+    layers, heads = None, None
+    plan = model._plan(x) if hasattr(model, "_plan") else None
+    if plan is not None and not isinstance(plan, str):
+        N.lib.ssdk_set_op_profiling(1)
+        acc = None
+        with torch.no_grad():
+            for _ in range(5):
+                model(x)
+                torch.cuda.synchronize(dev)
+                t = N.op_timings()
+                acc = [a + b[1] for a, b in zip(acc, t)] if acc else [b[1] for b in t]
+        N.lib.ssdk_set_op_profiling(0)
+        names = [k for k, _ in t]
+        layers = []
+        for row, kern, ms5 in zip(plan.layer_table(), names, acc):
+            ms = ms5 / 5.0
+            layers.append({"layer": row["name"], "kernel": kern.replace("_kernel", ""), "us": round(ms * 1e3, 1),
+                           "TFLOPs": round(row["flops"] / (ms * 1e-3) / 1e12, 1),
+                           "GBps": round(row["bytes"] / (ms * 1e-3) / 1e9, 0), "kind": row["kind"]})
+        hl = [(r, l) for r, l in zip(plan.layer_table(), layers) if r["kind"] == "head"]
+        h_flops = sum(r["flops"] for r, _ in hl)
+        h_ms = sum(l["us"] for _, l in hl) * 1e-3
+        heads = {"flops": h_flops, "ms": round(h_ms, 4), "achieved_TFLOPs": round(h_flops / (h_ms * 1e-3) / 1e12, 1),
+                 "peak_TFLOPs": MFMA_PEAK_TFLOPS, "frac": round(h_flops / (h_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                 "note": "loc|conf 3x3 head convs of all levels (one fused GEMM per level), bf16 MFMA dense peak"}
+
     conf_bytes = sum(c.numel() * c.element_size() for c in conf)  # the scan kernel reads conf exactly once
     loc_bytes = sum(l.numel() * l.element_size() for l in loc)
     K, D, L = decoder.top_n_per_level, decoder.top_n, len(conf)
@@ -178,6 +207,10 @@ def main():
     }
     result["roofline"] = roofline
     result["stages"] = {"forward_ms": round(fwd_ms, 4), "decode_nms_ms": round(dec_ms, 4)}
+    if heads is not None:
+        result["roofline"]["head_convs_mfma"] = heads
+    if layers is not None and args.layers:
+        result["layers"] = layers
 
     # ---- CPU baseline (rank 0, N = 1): torch fp32 forward + numpy oracle decoder, bounded sample ----------
     if rank == 0 and world == 1 and args.cpu_sample > 0:

@@ -115,6 +115,11 @@ int ssdk_decode_nms(const ssdk_level* levels, int L, int B, int dtype, float thr
  * level_kernel, nms_kernel of the call `back` calls before the most recent one; it synchronises on that
  * call's last event. */
 int ssdk_set_profiling(int enable);
+/* Per-op timing of ssdk_run_ops: when enabled, an event is recorded before every op (and after the last) on the
+ * caller's stream.  After synchronising, ssdk_get_op_timings fills ms[i] / kernels[i] (kernel name, may be NULL)
+ * for the ops of the most recent profiled ssdk_run_ops call and returns their count. */
+int ssdk_set_op_profiling(int enable);
+int ssdk_get_op_timings(float* ms, const char** kernels, int n_max);
 int ssdk_get_timings(int back, float* ms, int n);
 
 /* box.py:362-405 extract_targets + box.py:116-226 snap_to_anchors_by_iou for ONE level and the whole
@@ -197,10 +202,14 @@ typedef struct ssdk_mbconv_desc {
 } ssdk_mbconv_desc;
 int ssdk_mbconv(const ssdk_mbconv_desc* desc, void* stream);
 
-/* Plan executor: a recorded forward as a list of tagged ops, replayed with one host call. */
+/* Plan executor: a recorded forward as a list of tagged ops (topological order), replayed with one host call.
+ * lane 0 ops run in order on the caller's stream.  lane 1 ops (the multibox heads: leaves that depend only on
+ * ops listed before them) are forked onto a library-owned side stream and run concurrently with the following
+ * lane 0 ops; they use the upper half of the workspace, and everything is joined back onto the caller's stream
+ * before the call returns.  Buffers read or written by lane 1 ops must not be reused by later ops of the list. */
 enum { SSDK_OP_CONV = 0, SSDK_OP_MBCONV = 1 };
 typedef struct ssdk_op {
-  int32_t kind, reserved;
+  int32_t kind, lane;
   ssdk_conv_desc conv;
   ssdk_mbconv_desc mb;
 } ssdk_op;

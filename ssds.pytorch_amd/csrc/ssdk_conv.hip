@@ -311,6 +311,179 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_wave_kernel: the tiny-layer variant (SSD extras at 8x8 .. 1x1, heads of the last levels).
+//
+// These layers hold a few MFLOP each and are pure latency: with the tiled kernel every k-step is a
+// global-load -> LDS -> barrier round trip (~1 us) and a layer costs 15-40 us whatever its size.  Here ONE WAVE
+// owns a 16-pixel x 64-channel output tile and needs no LDS and no barrier: each lane loads its own MFMA
+// fragments (16 bytes of one pixel row / one weight row) straight from L2, four k-steps of loads are in flight
+// ahead of the matrix pipe, and the k range is split over blockIdx-derived slices when the tile grid is small.
+// Split-K partials go to fp32 slabs in fragment order; the last slice to arrive on a tile (agent-scope
+// release / acquire around one relaxed ticket, all inside the wave) sums them and runs the epilogue.
+// Operand re-reads (x by every n-tile, w by every m-tile) come from L2 and bound the kernel's use to small M*N*K.
+// ------------------------------------------------------------------------------------------------
+constexpr int WV_DEPTH = 4;
+
+template <int DT>
+__global__ __launch_bounds__(256) void conv_wave_kernel(const ConvParams p, int mt, int ntl) {
+  const u32 lane = threadIdx.x & 63u;
+  const u32 gid = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const u32 tiles = (u32)mt * (u32)ntl;
+  if (gid >= tiles * (u32)p.ksplits) return;  // wave-uniform
+  const u32 z = gid / tiles, tile = gid % tiles;
+  const u32 m0 = (tile % (u32)mt) * 16u, n0 = (tile / (u32)mt) * 64u;
+  const u32 fr = lane & 15u, fg = lane >> 4;
+  const int Cin = p.Cin, H = p.H, W = p.W;
+  const int KK = p.k * p.k;
+
+  // A fragment row of this lane = output pixel m0 + fr
+  long a_base = 0;
+  u32 a_mask = 0;
+  {
+    const u32 m = m0 + fr;
+    if (m < (u32)p.M) {
+      const u32 hw = (u32)(p.Ho * p.Wo);
+      const u32 b = m / hw, r = m % hw;
+      const int oy = (int)(r / (u32)p.Wo), ox = (int)(r % (u32)p.Wo);
+      const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+      a_base = (((long)b * H + iy0) * W + ix0) * Cin;
+      for (int ky = 0; ky < p.k; ++ky)
+        for (int kx = 0; kx < p.k; ++kx)
+          if ((unsigned)(iy0 + ky) < (unsigned)H && (unsigned)(ix0 + kx) < (unsigned)W) a_mask |= 1u << (ky * p.k + kx);
+    }
+  }
+  long w_base[4];
+  bool w_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32 n = n0 + j * 16 + fr;
+    w_ok[j] = n < (u32)p.Cout;
+    w_base[j] = (long)n * KK * Cin;
+  }
+  const int kt_begin = (int)z * p.kt_per;
+  const int kt_end = (kt_begin + p.kt_per < p.KT) ? kt_begin + p.kt_per : p.KT;
+  int t_kpos = kt_begin / p.cin_chunks, t_cc = kt_begin % p.cin_chunks;
+  int t_ky = t_kpos / p.k, t_kx = t_kpos % p.k;
+  int t_left = kt_end - kt_begin;  // k-steps not yet loaded
+  auto load = [&](u32x4& ra, u32x4 (&rb)[4]) {  // fragments of the next k-step (zeros past the end), then advance
+    const int ci = t_cc * 32 + (int)fg * 8;
+    const bool live = t_left > 0 && ci < Cin;
+    ra = u32x4{0u, 0u, 0u, 0u};
+    if (live && ((a_mask >> t_kpos) & 1u))
+      ra = *reinterpret_cast<const u32x4*>((const u16*)p.x + (a_base + (long)(t_ky * W + t_kx) * Cin + ci));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rb[j] = u32x4{0u, 0u, 0u, 0u};
+      if (live && w_ok[j]) rb[j] = *reinterpret_cast<const u32x4*>((const u16*)p.w + (w_base[j] + (long)t_kpos * Cin + ci));
+    }
+    --t_left;
+    if (++t_cc == p.cin_chunks) {
+      t_cc = 0;
+      ++t_kpos;
+      if (++t_kx == p.k) {
+        t_kx = 0;
+        ++t_ky;
+      }
+    }
+  };
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 ra[WV_DEPTH], rb[WV_DEPTH][4];
+#pragma unroll
+  for (int d = 0; d < WV_DEPTH; ++d) load(ra[d], rb[d]);
+  const int nsteps = kt_end - kt_begin;
+  for (int s0 = 0; s0 < nsteps; s0 += WV_DEPTH) {
+#pragma unroll
+    for (int d = 0; d < WV_DEPTH; ++d) {
+      // steps past the end hold zero fragments: the MFMAs are harmless and keep the loop branch-free
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = mfma16<DT>(ra[d], rb[d][j], acc[j]);
+      load(ra[d], rb[d]);
+    }
+  }
+
+  if (p.ksplits > 1) {
+    float* my = p.slabs + ((size_t)tile * p.ksplits + z) * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(my + (j * 64 + (int)lane) * 4) = acc[j];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    u32 last = 0;
+    if (lane == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned old = __hip_atomic_fetch_add(p.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (old == (unsigned)p.ksplits - 1u) ? 1u : 0u;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(p.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+      }
+    }
+    last = (u32)__builtin_amdgcn_readfirstlane((int)last);
+    if (!last) return;
+    const float* base = p.slabs + (size_t)tile * p.ksplits * 1024;
+    for (int zz = 0; zz < p.ksplits; ++zz) {
+      if (zz == (int)z) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += *reinterpret_cast<const f32x4*>(base + (size_t)zz * 1024 + (j * 64 + (int)lane) * 4);
+    }
+  }
+
+  // epilogue: D[row = fg*4 + r][col = fr] of fragment j  ->  pixel m0 + fg*4 + r, channel n0 + j*16 + fr
+  const bool any_sig = act_is_sig(p.act) || act_is_sig(p.act2);
+  const bool any_clamp = act_is_clamp(p.act) || act_is_clamp(p.act2);
+  const u32 hw = (u32)(p.Ho * p.Wo);
+  const bool nchw = p.out_layout == LAYOUT_NCHW;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32 n = n0 + j * 16 + fr;
+    if (n >= (u32)p.Cout) continue;
+    const float sc = p.scale ? p.scale[n] : 1.f, bi = p.bias[n];
+    const ActSel as = act_sel((int)n >= p.split ? p.act2 : p.act);
+    const uint2 h = epilogue4<DT>(acc[j], sc, bi, as, any_sig, any_clamp);
+    const u32 hv[4] = {h.x & 0xffffu, h.x >> 16, h.y & 0xffffu, h.y >> 16};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const u32 m = m0 + fg * 4 + r;
+      if (m >= (u32)p.M) continue;
+      if (!nchw) {
+        u32 v = hv[r];
+        if (p.res) v = f32_to_bits16<DT>(bits16_to_f32<DT>(v) + bits16_to_f32<DT>(((const u16*)p.res)[(size_t)m * p.Cout + n]));
+        ((u16*)p.y)[(size_t)m * p.Cout + n] = (u16)v;
+      } else {
+        const u32 b = m / hw, pix = m % hw;
+        if ((int)n < p.split) ((u16*)p.y)[((size_t)b * p.split + n) * hw + pix] = (u16)hv[r];
+        else ((u16*)p.y2)[((size_t)b * (p.Cout - p.split) + (n - p.split)) * hw + pix] = (u16)hv[r];
+      }
+    }
+  }
+}
+
+// tiny layers: operand re-reads from L2 stay below ~100 MB and the tile grid is far from filling the chip
+static bool wave_plan(long M, int Cin, int Cout, int k, int* splits_out, int* kt_per_out, int* mt_out, int* ntl_out) {
+  static const int env = getenv("SSDK_CONV_WAVE") ? atoi(getenv("SSDK_CONV_WAVE")) : 1;
+  if (!env || (Cin % 8)) return false;
+  const double work = (double)M * Cout * Cin * k * k;
+  if (env != 2 && (work > 3e8 || M > 256)) return false;  // measured: the tiled kernel wins again from M = 1024 on
+  const int mt = (int)((M + 15) / 16), ntl = (Cout + 63) / 64;
+  const long tiles = (long)mt * ntl;
+  const int KT = k * k * ((Cin + 31) / 32);
+  long s = (768 + tiles - 1) / tiles;
+  if (s > KT / 4) s = KT / 4;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  if (tiles > 1024) s = 1;  // counters live in the first 4 KiB of the workspace
+  int kt_per = (int)((KT + s - 1) / s);
+  s = (KT + kt_per - 1) / kt_per;
+  if (splits_out) *splits_out = (int)s;
+  if (kt_per_out) *kt_per_out = kt_per;
+  if (mt_out) *mt_out = mt;
+  if (ntl_out) *ntl_out = ntl;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv_gemm256_kernel: the large-layer variant (SSD heads L0-L2, FPN/BiFPN towers, wide 1x1 convs).
 //
 // 256 x 256 x 64 tiles, 8 waves as 2(M) x 4(N), each wave a 128 x 64 sub-tile = 8 x 4 accumulator fragments of
@@ -706,13 +879,15 @@ static int gemm_bn(int cout) { return cout > 64 ? 128 : cout > 32 ? 64 : cout > 
 // the slab round trip; aims at ~2 workgroups per CU.
 static int plan_splits(int M, int Cout, int KT) {
   static const int env = getenv("SSDK_SPLITK") ? atoi(getenv("SSDK_SPLITK")) : 1;
+  static const int target = getenv("SSDK_SPLITK_WGS") ? atoi(getenv("SSDK_SPLITK_WGS")) : 512;
+  static const int min_kt = getenv("SSDK_SPLITK_MINKT") ? atoi(getenv("SSDK_SPLITK_MINKT")) : 8;
   if (!env) return 1;
   const int bn = gemm_bn(Cout);
   const long tiles = (long)((M + BM - 1) / BM) * ((Cout + bn - 1) / bn);
-  if (tiles >= 192 || KT < 16) return 1;
-  long s = (512 + tiles - 1) / tiles;
-  if (s > KT / 8) s = KT / 8;
-  if (s > 16) s = 16;
+  if (tiles >= 192 || KT < 2 * min_kt) return 1;
+  long s = (target + tiles - 1) / tiles;
+  if (s > KT / min_kt) s = KT / min_kt;
+  if (s > 32) s = 32;
   return s < 2 ? 1 : (int)s;
 }
 
@@ -780,7 +955,13 @@ extern "C" size_t ssdk_conv_workspace_bytes(int N, int Cin, int H, int W, int Co
   if (Cin <= 4 || (k != 1 && k != 3) || (stride != 1 && stride != 2)) return 0;
   const int pad = k / 2;
   const long M = (long)N * ((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
-  return splitk_ws_bytes(M, Cin, Cout, k, nullptr, nullptr);
+  size_t need = splitk_ws_bytes(M, Cin, Cout, k, nullptr, nullptr);
+  int ws = 1, wk = 0, mt = 0, ntl = 0;
+  if (wave_plan(M, Cin, Cout, k, &ws, &wk, &mt, &ntl) && ws > 1) {
+    const size_t w = 4096 + (size_t)mt * ntl * ws * 4096;
+    if (w > need) need = w;
+  }
+  return need;
 }
 
 extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream_) {
@@ -929,6 +1110,28 @@ extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t worksp
   p.slabs = nullptr;
   p.counters = nullptr;
   {
+    int ws = 1, wk = p.KT, mt = 0, ntl = 0;
+    if (wave_plan(M, d->Cin, d->Cout, d->k, &ws, &wk, &mt, &ntl)) {
+      const size_t need = ws > 1 ? 4096 + (size_t)mt * ntl * ws * 4096 : 0;
+      if (ws > 1 && !(workspace && workspace_bytes >= need && !((uintptr_t)workspace & 255))) {
+        ws = 1;  // no scratch: unsplit
+        wk = p.KT;
+      }
+      p.ksplits = ws;
+      p.kt_per = wk;
+      if (ws > 1) {
+        p.counters = (unsigned*)workspace;
+        p.slabs = (float*)((char*)workspace + 4096);
+      }
+      const unsigned waves = (unsigned)mt * ntl * ws;
+      if (d->dtype == SSDK_BF16)
+        hipLaunchKernelGGL((conv_wave_kernel<SSDK_BF16>), dim3((waves + 3) / 4), dim3(256), 0, stream, p, mt, ntl);
+      else
+        hipLaunchKernelGGL((conv_wave_kernel<SSDK_F16>), dim3((waves + 3) / 4), dim3(256), 0, stream, p, mt, ntl);
+      return check_launch("conv_wave_kernel");
+    }
+  }
+  {
     int splits = 1, kt_per = p.KT;
     const size_t need = splitk_ws_bytes(M, d->Cin, d->Cout, d->k, &splits, &kt_per);
     const int tiles = ((int)((M + BM - 1) / BM)) * ((d->Cout + gemm_bn(d->Cout) - 1) / gemm_bn(d->Cout));
@@ -967,15 +1170,107 @@ extern "C" int ssdk_conv_sequence(const ssdk_conv_desc* descs, int n, void* work
   return SSDK_OK;
 }
 
+// Per-op timing of ssdk_run_ops (tools / bench.py layer table): one hipEvent before every op and one after the
+// last, on the caller's stream; read back with ssdk_get_op_timings after the stream has been synchronised.
+constexpr int kMaxProfOps = 128;
+static int g_op_prof = 0, g_op_n = 0;
+static hipEvent_t g_op_ev[kMaxProfOps + 1];
+static bool g_op_ev_ready = false;
+static const char* g_op_kernel[kMaxProfOps];
+
+extern "C" int ssdk_set_op_profiling(int enable) {
+  if (enable && !g_op_ev_ready) {
+    for (int i = 0; i <= kMaxProfOps; ++i)
+      if (hipEventCreate(&g_op_ev[i]) != hipSuccess) {
+        set_error("set_op_profiling: hipEventCreate failed");
+        return SSDK_E_LAUNCH;
+      }
+    g_op_ev_ready = true;
+  }
+  g_op_prof = enable ? 1 : 0;
+  g_op_n = 0;
+  return SSDK_OK;
+}
+
+extern "C" int ssdk_get_op_timings(float* ms, const char** kernels, int n_max) {
+  if (!ms || n_max < g_op_n) {
+    set_error("get_op_timings: need room for %d ops", g_op_n);
+    return SSDK_E_BADARG;
+  }
+  for (int i = 0; i < g_op_n; ++i) {
+    if (hipEventElapsedTime(&ms[i], g_op_ev[i], g_op_ev[i + 1]) != hipSuccess) {
+      set_error("get_op_timings: events of op %d not complete (synchronise the stream first)", i);
+      return SSDK_E_LAUNCH;
+    }
+    if (kernels) kernels[i] = g_op_kernel[i];
+  }
+  return g_op_n;
+}
+
+// Fork/join onto a library-owned side stream: ops whose `lane` is 1 (the multibox heads: they only depend on
+// their feature map, not on each other or on the layers that follow) run concurrently with the main chain.
+// The tiny tail layers (extras at 8x8..1x1, heads of the last levels) are launch/latency bound; overlapped with
+// the big head GEMMs they disappear from the critical path.  Everything is joined back onto the caller's stream
+// before returning, so the caller sees ordinary stream semantics (and the whole call is graph-capturable).
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_fork[32], g_join;
+static bool g_side_ready = false;
+
+static bool side_init() {
+  // default off: measured neutral on SSD-MobileNetV2@512 (the concurrent kernels share the same CUs and the split-K
+  // hand-offs of the small heads slow down under concurrency); kept for wider / deeper heads (SSDK_SIDE_STREAM=1)
+  static const int env = getenv("SSDK_SIDE_STREAM") ? atoi(getenv("SSDK_SIDE_STREAM")) : 0;
+  if (!env) return false;
+  if (!g_side_ready) {
+    if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) return false;
+    for (int i = 0; i < 32; ++i)
+      if (hipEventCreateWithFlags(&g_fork[i], hipEventDisableTiming) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&g_join, hipEventDisableTiming) != hipSuccess) return false;
+    g_side_ready = true;
+  }
+  return true;
+}
+
 extern "C" int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t workspace_bytes, void* stream) {
   if (!ops || n < 0) {
     set_error("run_ops: bad arguments");
     return SSDK_E_BADARG;
   }
+  hipStream_t main_s = (hipStream_t)stream;
+  const bool prof = g_op_prof && g_op_ev_ready && n <= kMaxProfOps;
+  if (prof) g_op_n = 0;
+  int n_side = 0;
+  for (int i = 0; i < n; ++i) n_side += ops[i].lane == 1 ? 1 : 0;
+  // concurrent lanes need disjoint split-K scratch: the side lane gets the upper half of the workspace
+  const bool use_side = n_side > 0 && n_side <= 32 && !prof && side_init();
+  char* ws_main = (char*)workspace;
+  size_t ws_main_bytes = workspace_bytes;
+  char* ws_side = nullptr;
+  size_t ws_side_bytes = 0;
+  if (use_side && workspace) {
+    const size_t half = (workspace_bytes / 2) & ~(size_t)255;
+    ws_main_bytes = half;
+    ws_side = ws_main + half;
+    ws_side_bytes = workspace_bytes - half;
+  }
+  int forks = 0;
   for (int i = 0; i < n; ++i) {
+    if (prof) (void)hipEventRecord(g_op_ev[i], main_s);
+    const bool side = use_side && ops[i].lane == 1;
+    hipStream_t st = main_s;
+    void* w = ws_main;
+    size_t wb = ws_main_bytes;
+    if (side) {
+      (void)hipEventRecord(g_fork[forks], main_s);  // everything recorded so far (the op's producers) ...
+      (void)hipStreamWaitEvent(g_side, g_fork[forks], 0);  // ... happens before the side op
+      ++forks;
+      st = g_side;
+      w = ws_side;
+      wb = ws_side_bytes;
+    }
     int rc;
-    if (ops[i].kind == SSDK_OP_CONV) rc = ssdk_conv(&ops[i].conv, workspace, workspace_bytes, stream);
-    else if (ops[i].kind == SSDK_OP_MBCONV) rc = ssdk_mbconv(&ops[i].mb, stream);
+    if (ops[i].kind == SSDK_OP_CONV) rc = ssdk_conv(&ops[i].conv, w, wb, st);
+    else if (ops[i].kind == SSDK_OP_MBCONV) rc = ssdk_mbconv(&ops[i].mb, st);
     else {
       set_error("unknown op kind %d", ops[i].kind);
       rc = SSDK_E_BADARG;
@@ -984,8 +1279,21 @@ extern "C" int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t w
       char msg[400];
       snprintf(msg, sizeof(msg), "%s", ssdk_last_error());
       set_error("run_ops: op %d of %d: %s", i, n, msg);
+      if (forks) {  // never leave the side stream dangling
+        (void)hipEventRecord(g_join, g_side);
+        (void)hipStreamWaitEvent(main_s, g_join, 0);
+      }
       return rc;
     }
+    if (prof) g_op_kernel[i] = ssdk_last_kernel();
+  }
+  if (forks) {
+    (void)hipEventRecord(g_join, g_side);
+    (void)hipStreamWaitEvent(main_s, g_join, 0);
+  }
+  if (prof) {
+    (void)hipEventRecord(g_op_ev[n], main_s);
+    g_op_n = n;
   }
   return SSDK_OK;
 }

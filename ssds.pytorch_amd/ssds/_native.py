@@ -58,7 +58,7 @@ class MbConvDesc(ctypes.Structure):
 
 
 class Op(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("conv", ConvDesc), ("mb", MbConvDesc)]
+    _fields_ = [("kind", ctypes.c_int32), ("lane", ctypes.c_int32), ("conv", ConvDesc), ("mb", MbConvDesc)]
 
 
 OP_CONV, OP_MBCONV = 0, 1
@@ -77,6 +77,8 @@ def _load():
     lib.ssdk_version.restype = i32
     lib.ssdk_last_error.restype = c.c_char_p
     lib.ssdk_last_kernel.restype = c.c_char_p
+    lib.ssdk_set_op_profiling.argtypes = [i32]
+    lib.ssdk_get_op_timings.argtypes = [c.POINTER(f32), c.POINTER(c.c_char_p), i32]
     lib.ssdk_device_info.argtypes = [c.POINTER(i32), c.POINTER(i32), c.POINTER(sz), c.c_char_p, i32]
     lib.ssdk_generate_anchors.argtypes = [i32, c.POINTER(f32), i32, c.POINTER(f32), i32, c.POINTER(f32)]
     lib.ssdk_decode_workspace_bytes.restype = sz
@@ -114,10 +116,20 @@ def _load():
 
 
 lib = _load()
-EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_device_info", "ssdk_generate_anchors",
+EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_profiling", "ssdk_get_op_timings", "ssdk_device_info", "ssdk_generate_anchors",
            "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
            "ssdk_match_targets_by_scale", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
+
+
+def op_timings():
+    """[(kernel name, ms)] of the most recent ssdk_run_ops call made while op profiling was on (stream synchronised)."""
+    ms = (ctypes.c_float * 128)()
+    names = (ctypes.c_char_p * 128)()
+    n = lib.ssdk_get_op_timings(ms, names, 128)
+    if n < 0:
+        raise SsdkError(lib.ssdk_last_error().decode())
+    return [(names[i].decode() if names[i] else "", float(ms[i])) for i in range(n)]
 
 
 def last_kernel():

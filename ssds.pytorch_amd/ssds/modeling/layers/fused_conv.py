@@ -361,8 +361,10 @@ class ConvPlan(object):
                 pk = L["pack"]
                 need = max(need, int(N.lib.ssdk_conv_workspace_bytes(L["n"], pk.cin, L["h"], L["w"], pk.cout, pk.k,
                                                                       pk.stride, self.dtype_code)))
-        # split-K scratch (fp32 slabs + arrival counters): zero-initialised once, re-armed by the kernels
-        self.ws = torch.zeros(need + 256, dtype=torch.uint8, device=self.device) if need else None
+        # split-K scratch (fp32 slabs + arrival counters): zero-initialised once, re-armed by the kernels.  The heads
+        # run on the executor's side stream concurrently with the main chain and get their own half.
+        need = (need + 255) & ~255
+        self.ws = torch.zeros(2 * need + 512, dtype=torch.uint8, device=self.device) if need else None
         self.ops = (N.Op * len(self.layers))()
         for i, L in enumerate(self.layers):
             x_ptr = self.arena.ptr(L["x"]) if L["x"] is not None else 0
@@ -372,10 +374,37 @@ class ConvPlan(object):
                 fill_mb_desc(self.ops[i].mb, x_ptr, y_ptr, L["n"], L["h"], L["w"], L["pack"], self.dtype_code)
                 continue
             self.ops[i].kind = N.OP_CONV
+            self.ops[i].lane = 1 if L["nchw"] else 0  # heads are leaves: side stream
             res_ptr = self.arena.ptr(L["res"]) if L["res"] is not None else None
             fill_desc(self.ops[i].conv, x_ptr, L["n"], L["h"], L["w"], L["pack"], self.dtype_code, L["act"], y_ptr,
                       N.NHWC, N.NCHW if L["nchw"] else N.NHWC, res_ptr, None, L.get("split"), L.get("act2"))
         return self
+
+    def layer_table(self):
+        """Geometry of every op of the plan: dicts with name, flops (2*MAC) and algorithmic HBM bytes
+        (input + output + weights, each once) -- what the per-layer roofline numbers are computed from."""
+        rows = []
+        for L in self.layers:
+            pk, n, h, w, es = L["pack"], L["n"], L["h"], L["w"], self.es
+            if L.get("kind") == "mb":
+                hs, ws = _out_hw(h, w, 3, 2) if pk.stem else (h, w)
+                ho, wo = _out_hw(hs, ws, 3, pk.stride)
+                if pk.stem:  # stem 3x3/s2 (cin -> chid) + depthwise + projection
+                    macs = n * (hs * ws * 9 * pk.cin * pk.chid + ho * wo * 9 * pk.chid + ho * wo * pk.chid * pk.cout)
+                else:
+                    macs = n * (h * w * pk.cin * pk.chid + ho * wo * 9 * pk.chid + ho * wo * pk.chid * pk.cout)
+                byt = es * n * (h * w * pk.cin + ho * wo * pk.cout)
+                name = "mbconv%s %d>%d>%d s%d @%dx%d" % ("+stem" if pk.stem else "", pk.cin, pk.chid, pk.cout,
+                                                         pk.stride, h, w)
+                rows.append(dict(name=name, flops=2.0 * macs, bytes=float(byt), kind="mbconv"))
+                continue
+            ho, wo = _out_hw(h, w, pk.k, pk.stride)
+            macs = n * ho * wo * pk.cout * (pk.cin // pk.groups) * pk.k * pk.k
+            byt = es * (n * (h * w * pk.cin + ho * wo * pk.cout) + pk.cout * (pk.cin // pk.groups) * pk.k * pk.k)
+            kind = "head" if L["nchw"] else ("dw" if pk.groups > 1 else "conv")
+            rows.append(dict(name="%s %d>%d k%d s%d @%dx%d" % (kind, pk.cin, pk.cout, pk.k, pk.stride, h, w),
+                             flops=2.0 * macs, bytes=float(byt), kind=kind))
+        return rows
 
     def run(self, x):
         """x: [N,3,H,W] (NCHW contiguous or channels_last).  Returns (loc tuple, conf tuple) NCHW."""

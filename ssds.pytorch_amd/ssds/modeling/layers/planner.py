@@ -56,7 +56,7 @@ def record_chain(plan, val, module, residual=None, keep_input=False):
     return cur
 
 
-def record_mobilenet(plan, val, net):
+def record_mobilenet(plan, val, net, on_output=None):
     from ssds.modeling.nets.mobilenet import InvertedResidual, MobileNetEx
 
     if not isinstance(net, MobileNetEx):
@@ -94,17 +94,25 @@ def record_mobilenet(plan, val, net):
                 cur = record_chain(plan, cur, blk, keep_input=is_out_input)
         if level in net.outputs:
             outputs.append(cur)
+            if on_output is not None:
+                on_output(len(outputs) - 1, cur)
     return outputs
 
 
 def build_ssd_plan(model, x):
     """SSD (ssds/ssd.py) on a MobileNet backbone -> finalized ConvPlan for inputs shaped like ``x``."""
     plan = ConvPlan(x.device, x.dtype, x.shape)
-    feats = record_mobilenet(plan, plan.input_value(), model.backbone)
-    for extra in model.extras:
-        feats.append(record_chain(plan, feats[-1], extra, keep_input=True))
-    for f, l, c in zip(feats, model.loc, model.conf):
+
+    def head(i, f):
+        # recorded right behind its feature map: the executor forks it onto the side stream, where it overlaps
+        # the rest of the backbone / the extras chain (feature maps are never released, so that is safe)
+        l, c = model.loc[i], model.conf[i]
         if conv_kind(l) != "dense" or conv_kind(c) != "dense":
             raise PlanUnsupported("head conv not covered")
         plan.head(f, pack_heads(l, c, plan.dtype), split=l.out_channels, act2="sigmoid")
+
+    feats = record_mobilenet(plan, plan.input_value(), model.backbone, on_output=head)
+    for extra in model.extras:
+        feats.append(record_chain(plan, feats[-1], extra, keep_input=True))
+        head(len(feats) - 1, feats[-1])
     return plan.finalize()
