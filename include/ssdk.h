@@ -161,13 +161,15 @@ typedef struct ssdk_conv_desc {
   const void* w;
   const float* scale;
   const float* bias;
-  const void* residual; /* optional, NHWC, added after the activation-free linear bottleneck conv */
+  const void* residual; /* optional, NHWC: y = act(conv) + residual, or act(conv + residual) with res_mode bit 1 */
   void* y;
   void* y2;             /* optional second output (NCHW split) */
   int32_t N, Cin, H, W, Cout, k, stride, groups;
   int32_t act, act2, split;
   int32_t dtype;        /* SSDK_BF16 | SSDK_F16 (input, weights and output) */
   int32_t in_layout, out_layout;
+  int32_t res_mode;     /* bit 0: `residual` is half resolution [N][H/2][W/2][Cout], added nearest-x2-upsampled (FPN
+                           top-down path, fpn.py:80-87); bit 1: activation applied AFTER the add (ResNet blocks) */
 } ssdk_conv_desc;
 size_t ssdk_conv_workspace_bytes(int N, int Cin, int H, int W, int Cout, int k, int stride, int dtype);
 int ssdk_conv(const ssdk_conv_desc* desc, void* workspace, size_t workspace_bytes, void* stream);
@@ -202,16 +204,35 @@ typedef struct ssdk_mbconv_desc {
 } ssdk_mbconv_desc;
 int ssdk_mbconv(const ssdk_mbconv_desc* desc, void* stream);
 
+/* Weighted feature fusion of the BiFPN (bifpn.py:41-62), NHWC, one launch:
+ *   y = w0 * a + w1 * R_b(b) [+ w2 * R_c(c)]      a, y: [N][H][W][C]
+ * R = SAME (source [N][H][W][C]), UP2 (nearest x2 upsample of [N][H/2][W/2][C], F.interpolate scale_factor=2) or
+ * POOL2 (F.max_pool2d(kernel_size=2) of [N][hb][wb][C], floor(hb/2) == H).  fp32 accumulate, one rounding.  c may be NULL. */
+enum { SSDK_FUSE_SAME = 0, SSDK_FUSE_UP2 = 1, SSDK_FUSE_POOL2 = 2 };
+typedef struct ssdk_fuse_desc {
+  const void* a;
+  const void* b;
+  const void* c;
+  void* y;
+  float w0, w1, w2;
+  int32_t mode_b, mode_c;
+  int32_t N, H, W, C;
+  int32_t hb, wb, hc, wc; /* source dims of b / c; only read for POOL2 (floor mode: 2H or 2H+1) */
+  int32_t dtype;
+} ssdk_fuse_desc;
+int ssdk_fuse(const ssdk_fuse_desc* desc, void* stream);
+
 /* Plan executor: a recorded forward as a list of tagged ops (topological order), replayed with one host call.
  * lane 0 ops run in order on the caller's stream.  lane 1 ops (the multibox heads: leaves that depend only on
  * ops listed before them) are forked onto a library-owned side stream and run concurrently with the following
  * lane 0 ops; they use the upper half of the workspace, and everything is joined back onto the caller's stream
  * before the call returns.  Buffers read or written by lane 1 ops must not be reused by later ops of the list. */
-enum { SSDK_OP_CONV = 0, SSDK_OP_MBCONV = 1 };
+enum { SSDK_OP_CONV = 0, SSDK_OP_MBCONV = 1, SSDK_OP_FUSE = 2 };
 typedef struct ssdk_op {
   int32_t kind, lane;
   ssdk_conv_desc conv;
   ssdk_mbconv_desc mb;
+  ssdk_fuse_desc fuse;
 } ssdk_op;
 int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t workspace_bytes, void* stream);
 /* convenience wrapper: dense conv, NHWC in/out, single output */

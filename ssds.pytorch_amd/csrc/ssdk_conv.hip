@@ -218,6 +218,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
   // (the last __syncthreads() above guarantees nobody still reads the staging buffers)
   u16* sC = reinterpret_cast<u16*>(smem);
   const bool nchw = p.out_layout == LAYOUT_NCHW;
+  const int post = p.post;
   constexpr int LDC_M = BN + 8;   // NHWC image: sC[m][n], row stride in elements
   constexpr int LDC_N = BM + 8;   // NCHW image: sC[n][m]
   const bool any_sig = act_is_sig(p.act) || act_is_sig(p.act2);
@@ -259,20 +260,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
       u32x4 v = *reinterpret_cast<const u32x4*>(&sC[row * LDC_M + cc * 8]);
       u16* dst = (u16*)p.y + (size_t)m * p.Cout + n;
       if (n + 8 <= (u32)p.Cout) {
-        if (p.res) {
-          const u32x4 rv = *reinterpret_cast<const u32x4*>((const u16*)p.res + (size_t)m * p.Cout + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float lo = bits16_to_f32<DT>(v[e] & 0xffffu) + bits16_to_f32<DT>(rv[e] & 0xffffu);
-            const float hi = bits16_to_f32<DT>(v[e] >> 16) + bits16_to_f32<DT>(rv[e] >> 16);
-            v[e] = f32_to_bits16<DT>(lo) | (f32_to_bits16<DT>(hi) << 16);
-          }
-        }
+        if (p.res) v = add_residual8<DT>(v, (const u16*)p.res + res_pixel_offset(p, m) + n, post);
         *reinterpret_cast<u32x4*>(dst) = v;
       } else {
         for (u32 e = 0; e < 8 && n + e < (u32)p.Cout; ++e) {
           float f = bits16_to_f32<DT>((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-          if (p.res) f += bits16_to_f32<DT>(((const u16*)p.res)[(size_t)m * p.Cout + n + e]);
+          if (p.res) f = post_act(f + bits16_to_f32<DT>(((const u16*)p.res)[res_pixel_offset(p, m) + n + e]), post);
           dst[e] = (u16)f32_to_bits16<DT>(f);
         }
       }
@@ -435,6 +428,7 @@ __global__ __launch_bounds__(256) void conv_wave_kernel(const ConvParams p, int 
   const bool any_clamp = act_is_clamp(p.act) || act_is_clamp(p.act2);
   const u32 hw = (u32)(p.Ho * p.Wo);
   const bool nchw = p.out_layout == LAYOUT_NCHW;
+  const int post = p.post;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const u32 n = n0 + j * 16 + fr;
@@ -449,7 +443,7 @@ __global__ __launch_bounds__(256) void conv_wave_kernel(const ConvParams p, int 
       if (m >= (u32)p.M) continue;
       if (!nchw) {
         u32 v = hv[r];
-        if (p.res) v = f32_to_bits16<DT>(bits16_to_f32<DT>(v) + bits16_to_f32<DT>(((const u16*)p.res)[(size_t)m * p.Cout + n]));
+        if (p.res) v = add_residual1<DT>(v, (const u16*)p.res + res_pixel_offset(p, m) + n, post);
         ((u16*)p.y)[(size_t)m * p.Cout + n] = (u16)v;
       } else {
         const u32 b = m / hw, pix = m % hw;
@@ -623,6 +617,7 @@ __global__ __launch_bounds__(G2_THREADS) void conv_gemm256_kernel(const ConvPara
   // ---- epilogue in two passes of 128 output channels (the staging image must fit the 128 KiB) ------------------
   u16* sC = reinterpret_cast<u16*>(smem);
   const bool nchw = p.out_layout == LAYOUT_NCHW;
+  const int post = p.post;
   constexpr int LDC_M = 128 + 8;      // NHWC image sC[m][n-local]
   constexpr int LDC_N = G2_BM + 8;    // NCHW image sC[n-local][m]
   const u32 hw = (u32)(p.Ho * p.Wo);
@@ -667,20 +662,12 @@ __global__ __launch_bounds__(G2_THREADS) void conv_gemm256_kernel(const ConvPara
         u32x4 v = *reinterpret_cast<const u32x4*>(&sC[row * LDC_M + cc * 8]);
         u16* dst = (u16*)p.y + (size_t)m * p.Cout + n;
         if (n + 8 <= (u32)p.Cout) {
-          if (p.res) {
-            const u32x4 rv = *reinterpret_cast<const u32x4*>((const u16*)p.res + (size_t)m * p.Cout + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float lo = bits16_to_f32<DT>(v[e] & 0xffffu) + bits16_to_f32<DT>(rv[e] & 0xffffu);
-              const float hi = bits16_to_f32<DT>(v[e] >> 16) + bits16_to_f32<DT>(rv[e] >> 16);
-              v[e] = f32_to_bits16<DT>(lo) | (f32_to_bits16<DT>(hi) << 16);
-            }
-          }
+          if (p.res) v = add_residual8<DT>(v, (const u16*)p.res + res_pixel_offset(p, m) + n, post);
           *reinterpret_cast<u32x4*>(dst) = v;
         } else {
           for (u32 e = 0; e < 8 && n + e < (u32)p.Cout; ++e) {
             float f = bits16_to_f32<DT>((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-            if (p.res) f += bits16_to_f32<DT>(((const u16*)p.res)[(size_t)m * p.Cout + n + e]);
+            if (p.res) f = post_act(f + bits16_to_f32<DT>(((const u16*)p.res)[res_pixel_offset(p, m) + n + e]), post);
             dst[e] = (u16)f32_to_bits16<DT>(f);
           }
         }
@@ -1102,6 +1089,21 @@ extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t worksp
   p.KT = d->k * d->k * p.cin_chunks;
   p.act = d->act;
   p.act2 = d->act2;
+  p.res_mode = d->residual ? d->res_mode : 0;
+  p.post = SSDK_ACT_NONE;
+  if (d->residual && (d->res_mode & 2)) {  // y = act(conv + residual): the staged value is linear
+    if (d->act != SSDK_ACT_NONE && d->act != SSDK_ACT_RELU && d->act != SSDK_ACT_RELU6) {
+      set_error("conv: only relu / relu6 can follow the residual add");
+      return SSDK_E_BADARG;
+    }
+    p.post = d->act;
+    p.act = SSDK_ACT_NONE;
+    p.act2 = SSDK_ACT_NONE;
+  }
+  if (d->residual && (d->res_mode & 1) && ((Ho | Wo) & 1)) {
+    set_error("conv: a half-resolution residual needs even output dims (%dx%d)", Ho, Wo);
+    return SSDK_E_BADARG;
+  }
   p.split = split;
   p.in_layout = d->in_layout;
   p.out_layout = d->out_layout;
@@ -1271,6 +1273,7 @@ extern "C" int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t w
     int rc;
     if (ops[i].kind == SSDK_OP_CONV) rc = ssdk_conv(&ops[i].conv, w, wb, st);
     else if (ops[i].kind == SSDK_OP_MBCONV) rc = ssdk_mbconv(&ops[i].mb, st);
+    else if (ops[i].kind == SSDK_OP_FUSE) rc = ssdk_fuse(&ops[i].fuse, st);
     else {
       set_error("unknown op kind %d", ops[i].kind);
       rc = SSDK_E_BADARG;

@@ -315,20 +315,12 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
         u32x4 v = *reinterpret_cast<const u32x4*>(&sC[row * LDC_M + cch * 8]);
         u16* dst = (u16*)p.y + m * p.Cout + n;
         if (n + 8 <= (u32)p.Cout) {
-          if (p.res) {
-            const u32x4 rv = *reinterpret_cast<const u32x4*>((const u16*)p.res + m * p.Cout + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float lo = bits16_to_f32<DT>(v[e] & 0xffffu) + bits16_to_f32<DT>(rv[e] & 0xffffu);
-              const float hi = bits16_to_f32<DT>(v[e] >> 16) + bits16_to_f32<DT>(rv[e] >> 16);
-              v[e] = pack2_16<DT>(lo, hi);
-            }
-          }
+          if (p.res) v = add_residual8<DT>(v, (const u16*)p.res + res_pixel_offset(p, (u32)m) + n, p.post);
           *reinterpret_cast<u32x4*>(dst) = v;
         } else {
           for (u32 e = 0; e < 8 && n + e < (u32)p.Cout; ++e) {
             float f = bits16_to_f32<DT>((v[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-            if (p.res) f += bits16_to_f32<DT>(((const u16*)p.res)[m * p.Cout + n + e]);
+            if (p.res) f = post_act(f + bits16_to_f32<DT>(((const u16*)p.res)[res_pixel_offset(p, (u32)m) + n + e]), p.post);
             dst[e] = (u16)f32_to_bits16<DT>(f);
           }
         }

@@ -27,6 +27,8 @@ struct ConvParams {
   int KT;          // k*k*cin_chunks
   int act, act2, split;  // channels >= split use act2 and go to y2 (split == Cout: single output)
   int in_layout, out_layout;
+  int post;      // activation applied after the residual add (res_mode bit 1), else SSDK_ACT_NONE
+  int res_mode;  // bit 0: the residual tensor is half resolution (nearest x2 upsample); bit 1: activation AFTER the add
   // split-K (small-M layers: too few output tiles to fill 256 CUs and a long, latency-bound k-loop):
   // blockIdx.z owns k-tiles [z*kt_per, (z+1)*kt_per); partial accumulators go to fp32 slabs in fragment order,
   // the last workgroup to arrive on a tile (agent-scope release/acquire on a counter) sums them and runs
@@ -123,6 +125,40 @@ __device__ __forceinline__ uint2 epilogue4(const f32x4 acc, float sc, float bi, 
     for (int r = 0; r < 4; ++r) v[r] = __builtin_fminf(__builtin_fmaxf(v[r], a.lo), a.hi);
   }
   return make_uint2(pack2_16<DT>(v[0], v[1]), pack2_16<DT>(v[2], v[3]));
+}
+
+// ---- residual add at the NHWC store stage (values already rounded to 16 bit, like the framework's tensor add) ----
+// element offset of channel 0 of the residual pixel that belongs to output pixel m = (b, oy, ox)
+__device__ __forceinline__ size_t res_pixel_offset(const ConvParams& p, u32 b, u32 oy, u32 ox) {
+  if (p.res_mode & 1) return (((size_t)b * (u32)(p.Ho >> 1) + (oy >> 1)) * (u32)(p.Wo >> 1) + (ox >> 1)) * (u32)p.Cout;
+  return (((size_t)b * (u32)p.Ho + oy) * (u32)p.Wo + ox) * (u32)p.Cout;
+}
+__device__ __forceinline__ size_t res_pixel_offset(const ConvParams& p, u32 m) {
+  if (!(p.res_mode & 1)) return (size_t)m * (u32)p.Cout;
+  const u32 hw = (u32)(p.Ho * p.Wo);
+  const u32 b = m / hw, r = m % hw;
+  return res_pixel_offset(p, b, r / (u32)p.Wo, r % (u32)p.Wo);
+}
+__device__ __forceinline__ float post_act(float v, int act) {  // res_mode bit 1: relu / relu6 after the add
+  if (act == SSDK_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == SSDK_ACT_RELU6) return v < 0.f ? 0.f : (v > 6.f ? 6.f : v);
+  return v;
+}
+template <int DT>
+__device__ __forceinline__ u32x4 add_residual8(u32x4 v, const u16* res, int post) {  // 8 channels, 16-byte aligned
+  const u32x4 rv = *reinterpret_cast<const u32x4*>(res);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const u32 a = v[e], r = rv[e];
+    const float lo = post_act(bits16_to_f32<DT>(a & 0xffffu) + bits16_to_f32<DT>(r & 0xffffu), post);
+    const float hi = post_act(bits16_to_f32<DT>(a >> 16) + bits16_to_f32<DT>(r >> 16), post);
+    v[e] = pack2_16<DT>(lo, hi);
+  }
+  return v;
+}
+template <int DT>
+__device__ __forceinline__ u32 add_residual1(u32 v, const u16* res, int post) {
+  return f32_to_bits16<DT>(post_act(bits16_to_f32<DT>(v) + bits16_to_f32<DT>((u32)*res), post));
 }
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;

@@ -47,6 +47,7 @@ class ConvDesc(ctypes.Structure):
         ("Cout", ctypes.c_int32), ("k", ctypes.c_int32), ("stride", ctypes.c_int32), ("groups", ctypes.c_int32),
         ("act", ctypes.c_int32), ("act2", ctypes.c_int32), ("split", ctypes.c_int32),
         ("dtype", ctypes.c_int32), ("in_layout", ctypes.c_int32), ("out_layout", ctypes.c_int32),
+        ("res_mode", ctypes.c_int32),
     ]
 
 
@@ -57,11 +58,22 @@ class MbConvDesc(ctypes.Structure):
             "N", "H", "W", "Cin", "Chid", "Cout", "stride", "residual", "dtype", "stem")]
 
 
+class FuseDesc(ctypes.Structure):
+    _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("c", ctypes.c_void_p), ("y", ctypes.c_void_p),
+                ("w0", ctypes.c_float), ("w1", ctypes.c_float), ("w2", ctypes.c_float),
+                ("mode_b", ctypes.c_int32), ("mode_c", ctypes.c_int32),
+                ("N", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("hb", ctypes.c_int32), ("wb", ctypes.c_int32), ("hc", ctypes.c_int32), ("wc", ctypes.c_int32),
+                ("dtype", ctypes.c_int32)]
+
+
 class Op(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_int32), ("lane", ctypes.c_int32), ("conv", ConvDesc), ("mb", MbConvDesc)]
+    _fields_ = [("kind", ctypes.c_int32), ("lane", ctypes.c_int32), ("conv", ConvDesc), ("mb", MbConvDesc),
+                ("fuse", FuseDesc)]
 
 
-OP_CONV, OP_MBCONV = 0, 1
+OP_CONV, OP_MBCONV, OP_FUSE = 0, 1, 2
+FUSE_SAME, FUSE_UP2, FUSE_POOL2 = 0, 1, 2
 NCHW, NHWC = 0, 1
 
 
@@ -77,6 +89,8 @@ def _load():
     lib.ssdk_version.restype = i32
     lib.ssdk_last_error.restype = c.c_char_p
     lib.ssdk_last_kernel.restype = c.c_char_p
+    lib.ssdk_fuse.argtypes = [c.POINTER(FuseDesc), vp]
+    lib.ssdk_fuse.restype = i32
     lib.ssdk_set_op_profiling.argtypes = [i32]
     lib.ssdk_get_op_timings.argtypes = [c.POINTER(f32), c.POINTER(c.c_char_p), i32]
     lib.ssdk_device_info.argtypes = [c.POINTER(i32), c.POINTER(i32), c.POINTER(sz), c.c_char_p, i32]
@@ -119,7 +133,7 @@ lib = _load()
 EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_profiling", "ssdk_get_op_timings", "ssdk_device_info", "ssdk_generate_anchors",
            "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
-           "ssdk_match_targets_by_scale", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
+           "ssdk_match_targets_by_scale", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_fuse", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 
 
 def op_timings():

@@ -176,6 +176,29 @@ def fill_mb_desc(d, x_ptr, y_ptr, n, h, w, pk, dtype_code):
     return d
 
 
+def fuse_native(a, b, c=None, weights=(1.0, 1.0, 0.0), mode_b=N.FUSE_SAME, mode_c=N.FUSE_SAME):
+    """y = w0*a + w1*R_b(b) [+ w2*R_c(c)] (BiFPN weighted fusion, csrc/ssdk_fuse.hip); channels_last tensors."""
+    N.require_device(a, "fuse")
+    ts = [t if t is None or t.is_contiguous(memory_format=torch.channels_last) else
+          t.contiguous(memory_format=torch.channels_last) for t in (a, b, c)]
+    a, b, c = ts
+    n, ch, h, w = (int(v) for v in a.shape)
+    y = torch.empty_like(a, memory_format=torch.channels_last)
+    d = N.FuseDesc()
+    d.a, d.b, d.c, d.y = a.data_ptr(), b.data_ptr(), (c.data_ptr() if c is not None else None), y.data_ptr()
+    d.w0, d.w1, d.w2 = (float(v) for v in weights)
+    d.mode_b, d.mode_c = mode_b, mode_c
+    d.N, d.H, d.W, d.C = n, h, w, ch
+    d.hb, d.wb = int(b.shape[2]), int(b.shape[3])
+    if c is not None:
+        d.hc, d.wc = int(c.shape[2]), int(c.shape[3])
+    d.dtype = N.dtype_code(a)
+    with torch.cuda.device(a.device):
+        rc = N.lib.ssdk_fuse(ctypes.byref(d), N.stream_ptr(a.device))
+    N.check(rc, "fuse")
+    return y
+
+
 def mbconv_native(x, pk):
     """One fused inverted-residual block; x channels_last [N,Cin,H,W] -> channels_last [N,Cout,Ho,Wo]."""
     N.require_device(x, "mbconv")
@@ -233,7 +256,7 @@ def _splitk_ws(device, nbytes):
     return buf
 
 
-def conv_native(x, pack, act=None, residual=None, nchw_out=False, split=None, act2=None):
+def conv_native(x, pack, act=None, residual=None, nchw_out=False, split=None, act2=None, res_mode=0):
     """One fused layer.  x: [N,C,H,W] tensor in channels_last memory (converted if not; the stem also takes
     plain NCHW).  Returns a channels_last tensor, or NCHW tensor(s) when ``nchw_out`` (heads)."""
     N.require_device(x, "conv")
@@ -259,6 +282,7 @@ def conv_native(x, pack, act=None, residual=None, nchw_out=False, split=None, ac
     d = fill_desc(N.ConvDesc(), x.data_ptr(), n, h, w, pack, N.dtype_code(x), act, y.data_ptr(), in_layout,
                   N.NCHW if nchw_out else N.NHWC, residual.data_ptr() if residual is not None else None,
                   y2.data_ptr() if y2 is not None else None, split, act2)
+    d.res_mode = res_mode
     with torch.cuda.device(x.device):
         need = int(N.lib.ssdk_conv_workspace_bytes(n, pack.cin, h, w, pack.cout, pack.k, pack.stride, N.dtype_code(x)))
         if need:
@@ -302,34 +326,56 @@ class _Arena(object):
         return sum(t.numel() for t, _ in self.bufs)
 
 
-class ConvPlan(object):
-    """A recorded forward: descriptors + buffers.  ``record_*`` while walking the model once for a given
-    input shape; ``run(x)`` replays it with one C call.  Head outputs are allocated per call (they are
-    returned to the caller); all other activations live in the plan's arena."""
+class ExtBuf(object):
+    """An external input of a plan (the image, or a backbone feature map computed outside the plan): the
+    descriptors that read it are patched with the tensor's address on every run."""
 
-    def __init__(self, device, dtype, in_shape):
-        self.device, self.dtype, self.in_shape = device, dtype, tuple(in_shape)
+    def __init__(self, index, shape):
+        self.index, self.shape = index, tuple(shape)
+
+
+class ConvPlan(object):
+    """A recorded forward: ops (fused convs, fused MobileNet blocks, BiFPN fusions) on arena buffers.
+    ``record`` by walking the model once for given input shapes; ``run(*inputs)`` replays it with ONE C call.
+    Head outputs are allocated per call (they are returned to the caller); all other activations live in the
+    plan's arena.  A "value" is ``(buffer index | ExtBuf, n, c, h, w)``."""
+
+    def __init__(self, device, dtype, in_shape=None):
+        self.device, self.dtype = device, dtype
         self.dtype_code = N._DTYPES[dtype]
         self.es = 2
         self.arena = _Arena(device)
-        self.layers = []   # dicts with everything fill_desc needs
-        self.heads = []    # (layer index, n, split, cout, ho, wo)
+        self.layers = []   # dicts with everything the descriptor fillers need
+        self.heads = []    # (layer index, n, split | None, cout, ho, wo, tag)
         self.keep = []     # packs kept alive
+        self.inputs = []   # ExtBuf
         self.ops = None
         self.report = []
+        self.in_shape = tuple(in_shape) if in_shape is not None else None
+        if in_shape is not None:
+            self.add_input(in_shape)
 
-    # a "value" is (buffer index or None for the external input, n, c, h, w)
+    def add_input(self, shape):
+        """Declare an external [N,C,H,W] input (channels_last memory at run time); returns its value."""
+        e = ExtBuf(len(self.inputs), shape)
+        self.inputs.append(e)
+        n, c, h, w = e.shape
+        return (e, n, c, h, w)
+
     def input_value(self):
-        n, c, h, w = self.in_shape
-        return (None, n, c, h, w)
+        e = self.inputs[0]
+        n, c, h, w = e.shape
+        return (e, n, c, h, w)
 
-    def conv(self, val, pack, act=None, residual=None):
+    def conv(self, val, pack, act=None, residual=None, res_mode=0):
+        """res_mode bit 0: the residual value is half resolution (nearest x2 upsample, FPN top-down);
+        bit 1: the activation follows the add (ResNet blocks)."""
         buf, n, c, h, w = val
         assert c == pack.cin, (c, pack.cin)
         ho, wo = _out_hw(h, w, pack.k, pack.stride)
         out = self.arena.get(n * pack.cout * ho * wo * self.es)
         self.layers.append(dict(x=buf, n=n, h=h, w=w, pack=pack, act=pack.act if act is None else act, y=out,
-                                res=residual[0] if residual is not None else None, nchw=False))
+                                res=residual[0] if residual is not None else None, res_mode=res_mode, nchw=False))
         self.keep.append(pack)
         return (out, n, pack.cout, ho, wo)
 
@@ -343,41 +389,80 @@ class ConvPlan(object):
         self.keep.append(pk)
         return (out, n, pk.cout, ho, wo)
 
-    def head(self, val, pack, split, act2):
+    def fuse(self, a, b, c=None, weights=(1.0, 1.0, 0.0), mode_b=N.FUSE_SAME, mode_c=N.FUSE_SAME):
+        """y = w0*a + w1*R_b(b) [+ w2*R_c(c)] at the resolution of ``a`` (BiFPN weighted fusion)."""
+        _, n, ch, h, w = a
+        out = self.arena.get(n * ch * h * w * self.es)
+        self.layers.append(dict(kind="fuse", a=a, b=b, c=c, w=tuple(float(v) for v in weights), mode_b=mode_b,
+                                mode_c=mode_c, n=n, h=h, w_=w, ch=ch, y=out))
+        return (out, n, ch, h, w)
+
+    def head(self, val, pack, split=None, act="none", act2=None, tag="both"):
+        """An NCHW output of the plan: loc|conf of one SSD level as one split GEMM (``tag='both'``) or the last
+        conv of one shared tower (``tag='loc' | 'conf'``)."""
         buf, n, c, h, w = val
         ho, wo = _out_hw(h, w, pack.k, pack.stride)
-        self.layers.append(dict(x=buf, n=n, h=h, w=w, pack=pack, act="none", y=None, res=None, nchw=True,
+        self.layers.append(dict(x=buf, n=n, h=h, w=w, pack=pack, act=act, y=None, res=None, res_mode=0, nchw=True,
                                 split=split, act2=act2))
-        self.heads.append((len(self.layers) - 1, n, split, pack.cout, ho, wo))
+        self.heads.append((len(self.layers) - 1, n, split, pack.cout, ho, wo, tag))
         self.keep.append(pack)
 
     def release(self, val):
-        self.arena.release(val[0])
+        if not isinstance(val[0], ExtBuf):
+            self.arena.release(val[0])
+
+    def _ptr(self, buf, patches, op_index, field):
+        if buf is None:
+            return 0
+        if isinstance(buf, ExtBuf):
+            patches.append((op_index, field, buf.index))
+            return 0
+        return self.arena.ptr(buf)
 
     def finalize(self):
         need = 0
         for L in self.layers:
-            if L.get("kind") != "mb":
+            if L.get("kind") is None:
                 pk = L["pack"]
                 need = max(need, int(N.lib.ssdk_conv_workspace_bytes(L["n"], pk.cin, L["h"], L["w"], pk.cout, pk.k,
                                                                       pk.stride, self.dtype_code)))
         # split-K scratch (fp32 slabs + arrival counters): zero-initialised once, re-armed by the kernels.  The heads
-        # run on the executor's side stream concurrently with the main chain and get their own half.
+        # may run on the executor's side stream concurrently with the main chain and get their own half.
         need = (need + 255) & ~255
         self.ws = torch.zeros(2 * need + 512, dtype=torch.uint8, device=self.device) if need else None
         self.ops = (N.Op * len(self.layers))()
+        self.patches = []  # (op index, field name, external input index)
         for i, L in enumerate(self.layers):
-            x_ptr = self.arena.ptr(L["x"]) if L["x"] is not None else 0
-            y_ptr = self.arena.ptr(L["y"]) if L["y"] is not None else 0
-            if L.get("kind") == "mb":
-                self.ops[i].kind = N.OP_MBCONV
-                fill_mb_desc(self.ops[i].mb, x_ptr, y_ptr, L["n"], L["h"], L["w"], L["pack"], self.dtype_code)
+            op = self.ops[i]
+            kind = L.get("kind")
+            if kind == "mb":
+                op.kind = N.OP_MBCONV
+                fill_mb_desc(op.mb, self._ptr(L["x"], self.patches, i, "mb.x"), self.arena.ptr(L["y"]), L["n"], L["h"],
+                             L["w"], L["pack"], self.dtype_code)
                 continue
-            self.ops[i].kind = N.OP_CONV
-            self.ops[i].lane = 1 if L["nchw"] else 0  # heads are leaves: side stream
-            res_ptr = self.arena.ptr(L["res"]) if L["res"] is not None else None
-            fill_desc(self.ops[i].conv, x_ptr, L["n"], L["h"], L["w"], L["pack"], self.dtype_code, L["act"], y_ptr,
-                      N.NHWC, N.NCHW if L["nchw"] else N.NHWC, res_ptr, None, L.get("split"), L.get("act2"))
+            if kind == "fuse":
+                op.kind = N.OP_FUSE
+                f = op.fuse
+                f.a = self._ptr(L["a"][0], self.patches, i, "fuse.a")
+                f.b = self._ptr(L["b"][0], self.patches, i, "fuse.b")
+                f.c = self._ptr(L["c"][0], self.patches, i, "fuse.c") if L["c"] is not None else None
+                f.y = self.arena.ptr(L["y"])
+                f.w0, f.w1, f.w2 = L["w"]
+                f.mode_b, f.mode_c = L["mode_b"], L["mode_c"]
+                f.N, f.H, f.W, f.C = L["n"], L["h"], L["w_"], L["ch"]
+                f.hb, f.wb = L["b"][3], L["b"][4]
+                if L["c"] is not None:
+                    f.hc, f.wc = L["c"][3], L["c"][4]
+                f.dtype = self.dtype_code
+                continue
+            op.kind = N.OP_CONV
+            op.lane = 1 if L["nchw"] else 0  # heads are leaves: side stream when enabled
+            y_ptr = self.arena.ptr(L["y"]) if L["y"] is not None else 0
+            res_ptr = self._ptr(L["res"], self.patches, i, "conv.residual") if L["res"] is not None else None
+            fill_desc(op.conv, self._ptr(L["x"], self.patches, i, "conv.x"), L["n"], L["h"], L["w"], L["pack"],
+                      self.dtype_code, L["act"], y_ptr, N.NHWC, N.NCHW if L["nchw"] else N.NHWC, res_ptr, None,
+                      L.get("split"), L.get("act2"))
+            op.conv.res_mode = L.get("res_mode", 0)
         return self
 
     def layer_table(self):
@@ -385,7 +470,15 @@ class ConvPlan(object):
         (input + output + weights, each once) -- what the per-layer roofline numbers are computed from."""
         rows = []
         for L in self.layers:
-            pk, n, h, w, es = L["pack"], L["n"], L["h"], L["w"], self.es
+            es = self.es
+            if L.get("kind") == "fuse":
+                n, h, w, ch = L["n"], L["h"], L["w_"], L["ch"]
+                srcs = [L["a"], L["b"]] + ([L["c"]] if L["c"] is not None else [])
+                byt = es * (sum(v[1] * v[2] * v[3] * v[4] for v in srcs) + n * ch * h * w)
+                rows.append(dict(name="fuse x%d %d @%dx%d" % (len(srcs), ch, h, w), flops=2.0 * len(srcs) * n * ch * h * w,
+                                 bytes=float(byt), kind="fuse"))
+                continue
+            pk, n, h, w = L["pack"], L["n"], L["h"], L["w"]
             if L.get("kind") == "mb":
                 hs, ws = _out_hw(h, w, 3, 2) if pk.stem else (h, w)
                 ho, wo = _out_hw(hs, ws, 3, pk.stride)
@@ -406,35 +499,60 @@ class ConvPlan(object):
                              flops=2.0 * macs, bytes=float(byt), kind=kind))
         return rows
 
-    def run(self, x):
-        """x: [N,3,H,W] (NCHW contiguous or channels_last).  Returns (loc tuple, conf tuple) NCHW."""
-        if tuple(x.shape) != self.in_shape or x.dtype != self.dtype:
-            raise N.SsdkError("plan was recorded for {} {}, got {} {}".format(self.in_shape, self.dtype,
-                                                                          tuple(x.shape), x.dtype))
-        if self.ops[0].kind == N.OP_MBCONV:  # stem + first block fused: the image is read by the block kernel
-            first = self.ops[0].mb
-            if x.is_contiguous():
-                first.stem = 1
-            else:
-                x = x.contiguous(memory_format=torch.channels_last)
-                first.stem = 2
-        else:
-            first = self.ops[0].conv
-            if x.is_contiguous():
-                first.in_layout = N.NCHW if self.layers[0]["pack"].kind == "stem" else N.NHWC
-                if first.in_layout == N.NHWC:
+    def _set_field(self, op_index, field, ptr):
+        sub, name = field.split(".")
+        setattr(getattr(self.ops[op_index], sub), name, ptr)
+
+    def run(self, *inputs):
+        """inputs: the tensors declared with ``add_input`` (the image: NCHW contiguous or channels_last; feature
+        maps: converted to channels_last if needed).  Returns (loc tuple, conf tuple), NCHW."""
+        if len(inputs) != len(self.inputs):
+            raise N.SsdkError("plan expects {} inputs, got {}".format(len(self.inputs), len(inputs)))
+        held = []
+        for e, x in zip(self.inputs, inputs):
+            if tuple(x.shape) != e.shape or x.dtype != self.dtype:
+                raise N.SsdkError("plan input {} was recorded as {} {}, got {} {}".format(
+                    e.index, e.shape, self.dtype, tuple(x.shape), x.dtype))
+        first_kind = self.ops[0].kind
+        image_first = len(self.inputs) == 1 and self.inputs[0].shape[1] <= 4
+        xs = list(inputs)
+        if image_first:
+            x = xs[0]
+            if first_kind == N.OP_MBCONV:  # stem + first block fused: the image is read by the block kernel
+                first = self.ops[0].mb
+                if x.is_contiguous():
+                    first.stem = 1
+                else:
                     x = x.contiguous(memory_format=torch.channels_last)
+                    first.stem = 2
             else:
-                x = x.contiguous(memory_format=torch.channels_last)
-                first.in_layout = N.NHWC
-        first.x = x.data_ptr()
+                first = self.ops[0].conv
+                if x.is_contiguous():
+                    first.in_layout = N.NCHW if self.layers[0]["pack"].kind == "stem" else N.NHWC
+                    if first.in_layout == N.NHWC:
+                        x = x.contiguous(memory_format=torch.channels_last)
+                else:
+                    x = x.contiguous(memory_format=torch.channels_last)
+                    first.in_layout = N.NHWC
+            xs[0] = x
+        else:
+            xs = [x if x.is_contiguous(memory_format=torch.channels_last) else
+                  x.contiguous(memory_format=torch.channels_last) for x in xs]
+        held.extend(xs)
+        for (oi, field, ei) in self.patches:
+            self._set_field(oi, field, xs[ei].data_ptr())
         loc, conf = [], []
-        for (li, n, split, cout, ho, wo) in self.heads:
-            l = torch.empty((n, split, ho, wo), device=self.device, dtype=self.dtype)
-            c = torch.empty((n, cout - split, ho, wo), device=self.device, dtype=self.dtype)
-            self.ops[li].conv.y, self.ops[li].conv.y2 = l.data_ptr(), c.data_ptr()
-            loc.append(l)
-            conf.append(c)
+        for (li, n, split, cout, ho, wo, tag) in self.heads:
+            if tag == "both":
+                l = torch.empty((n, split, ho, wo), device=self.device, dtype=self.dtype)
+                c = torch.empty((n, cout - split, ho, wo), device=self.device, dtype=self.dtype)
+                self.ops[li].conv.y, self.ops[li].conv.y2 = l.data_ptr(), c.data_ptr()
+                loc.append(l)
+                conf.append(c)
+            else:
+                t = torch.empty((n, cout, ho, wo), device=self.device, dtype=self.dtype)
+                self.ops[li].conv.y = t.data_ptr()
+                (loc if tag == "loc" else conf).append(t)
         with torch.cuda.device(self.device):
             if self.ws is not None:
                 wptr = (self.ws.data_ptr() + 255) & ~255

@@ -3,8 +3,10 @@ group becomes one descriptor of the fused HIP kernels, block-level residual adds
 the projecting 1x1 conv, and the loc | conf convs of each level become one split-output GEMM.
 
 Covered: MobileNet v1/v2 backbones (nets/mobilenet.py), the SSD extras and heads (ssds/ssd.py) -- i.e. the
-network of BASELINE configs 1, 2 and 4.  Anything else raises ``PlanUnsupported`` and the caller runs the
-module-by-module path instead (and says so in ``fused_conv.STATS``)."""
+network of BASELINE configs 1, 2 and 4 -- and the FPN / BiFPN necks with their shared towers (ssds/fpn.py,
+ssds/bifpn.py; configs 3 and 5) on top of backbone feature maps handed in as external inputs.  Anything else
+raises ``PlanUnsupported`` and the caller runs the module-by-module path instead (and says so in
+``fused_conv.STATS``)."""
 import torch.nn as nn
 
 import os
@@ -109,10 +111,126 @@ def build_ssd_plan(model, x):
         l, c = model.loc[i], model.conf[i]
         if conv_kind(l) != "dense" or conv_kind(c) != "dense":
             raise PlanUnsupported("head conv not covered")
-        plan.head(f, pack_heads(l, c, plan.dtype), split=l.out_channels, act2="sigmoid")
+        plan.head(f, pack_heads(l, c, plan.dtype), split=l.out_channels, act="none", act2="sigmoid", tag="both")
 
     feats = record_mobilenet(plan, plan.input_value(), model.backbone, on_output=head)
     for extra in model.extras:
         feats.append(record_chain(plan, feats[-1], extra, keep_input=True))
         head(len(feats) - 1, feats[-1])
+    return plan.finalize()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# FPN / BiFPN necks + shared towers on external backbone features
+# --------------------------------------------------------------------------------------------------------------
+def _tower_packs(tower, dtype):
+    """SharedHead (4 x ConvBNReLU + final conv) -> ([ConvPack] of the ConvBNReLU layers, final ConvPack).  The
+    towers are shared by every pyramid level, so they are packed once."""
+    mods = list(tower.children())
+    body = []
+    for m in mods[:-1]:
+        (conv, bn, act), = groups_of(m)
+        body.append(ConvPack(conv, bn, act, dtype))
+    last = mods[-1]
+    if conv_kind(last) != "dense":
+        raise PlanUnsupported("tower output conv not covered")
+    return body, ConvPack(last, None, "none", dtype)
+
+
+def _record_towers(plan, xx, loc_packs, conf_packs):
+    for (body, final), act, tag in ((loc_packs, "none", "loc"), (conf_packs, "sigmoid", "conf")):
+        cur = xx
+        for pk in body:
+            nxt = plan.conv(cur, pk)
+            if cur is not xx:
+                plan.release(cur)
+            cur = nxt
+        plan.head(cur, final, act=act, tag=tag)
+        if cur is not xx:
+            plan.release(cur)
+
+
+def _record_extras_and_towers(plan, model, pyramid, raw_last):
+    """reference fpn.py:89-97 / bifpn.py:131-138: extras[i] on pyramid level i, extras[n] on the RAW last
+    backbone map, later extras on the previous extra; both towers on every result."""
+    n = len(pyramid)
+    loc_packs, conf_packs = _tower_packs(model.loc, plan.dtype), _tower_packs(model.conf, plan.dtype)
+    xx = None
+    for i, v in enumerate(model.extras):
+        src = pyramid[i] if i < n else (raw_last if i == n else xx)
+        xx = record_chain(plan, src, v, keep_input=True)
+        _record_towers(plan, xx, loc_packs, conf_packs)
+
+
+def build_fpn_plan(model, features):
+    """SSDFPN (ssds/fpn.py) neck + towers on the backbone maps ``features`` -> finalized ConvPlan.  The 1x1
+    lateral of level i and the nearest-x2 upsample-add of level i+1 (reference fpn.py:80-87) are ONE launch:
+    the coarser map rides in as a half-resolution residual of the lateral GEMM's epilogue."""
+    f0 = features[0]
+    plan = ConvPlan(f0.device, f0.dtype)
+    vals = [plan.add_input(f.shape) for f in features]
+    n = len(vals)
+    pyramid = [None] * n
+    for i in range(n - 1, -1, -1):
+        conv = model.transforms[i]
+        if conv_kind(conv) != "dense":
+            raise PlanUnsupported("lateral conv not covered: {}".format(conv))
+        pack = ConvPack(conv, None, "none", plan.dtype)
+        if i == n - 1:
+            pyramid[i] = plan.conv(vals[i], pack)
+        else:
+            if pyramid[i + 1][3] * 2 != vals[i][3] or pyramid[i + 1][4] * 2 != vals[i][4]:
+                raise PlanUnsupported("pyramid levels are not exact halves")
+            pyramid[i] = plan.conv(vals[i], pack, residual=pyramid[i + 1], res_mode=1)
+    _record_extras_and_towers(plan, model, pyramid, vals[n - 1])
+    return plan.finalize()
+
+
+def _fusion_weights(w, dtype):
+    """relu(w) / (sum relu(w) + 1e-6), rounded to the model dtype like the module path does (bifpn.py:35-38)."""
+    import torch
+
+    w = torch.relu(w.detach().float())
+    w = w / (w.sum(0) + 1e-6)
+    return w.to(dtype).float().cpu()
+
+
+def _record_bifpn_layer(plan, m, xx):
+    from ssds import _native as N
+
+    n = m.levels
+    assert len(xx) == n
+    w1, w2 = _fusion_weights(m.w1, plan.dtype), _fusion_weights(m.w2, plan.dtype)
+    xx = list(xx)
+    skips = [None] + xx[1:-1] + [None]
+    for i in range(n - 1, 0, -1):  # top-down (reference bifpn.py:41-46)
+        if xx[i][3] * 2 != xx[i - 1][3] or xx[i][4] * 2 != xx[i - 1][4]:
+            raise PlanUnsupported("BiFPN levels are not exact halves")
+        fused = plan.fuse(xx[i - 1], xx[i], weights=(w1[0, i - 1], w1[1, i - 1], 0.0), mode_b=N.FUSE_UP2)
+        xx[i - 1] = record_chain(plan, fused, getattr(m, "top-down-{}".format(i - 1)))
+    for i in range(0, n - 2):  # bottom-up with skip (reference bifpn.py:49-55)
+        fused = plan.fuse(xx[i + 1], xx[i], skips[i + 1], weights=(w2[0, i], w2[1, i], w2[2, i]),
+                          mode_b=N.FUSE_POOL2, mode_c=N.FUSE_SAME)
+        xx[i + 1] = record_chain(plan, fused, getattr(m, "bottom-up-{}".format(i + 1)))
+    fused = plan.fuse(xx[n - 1], xx[n - 2], weights=(w1[0, n - 1], w1[1, n - 1], 0.0), mode_b=N.FUSE_POOL2)
+    xx[n - 1] = record_chain(plan, fused, getattr(m, "bottom-up-{}".format(n - 1)))  # reference bifpn.py:57-62
+    return xx
+
+
+def build_bifpn_plan(model, features):
+    """SSDBiFPN (ssds/bifpn.py): 1x1 transforms, stacked BiFPN layers (weighted fusions as one launch each),
+    extras and shared towers on the backbone maps ``features`` -> finalized ConvPlan."""
+    f0 = features[0]
+    plan = ConvPlan(f0.device, f0.dtype)
+    vals = [plan.add_input(f.shape) for f in features]
+    n = len(vals)
+    xx = []
+    for i in range(n):
+        conv = model.transforms[i]
+        if conv_kind(conv) != "dense":
+            raise PlanUnsupported("transform conv not covered: {}".format(conv))
+        xx.append(plan.conv(vals[i], ConvPack(conv, None, "none", plan.dtype)))
+    for m in model.stack_bifpn:
+        xx = _record_bifpn_layer(plan, m, xx)
+    _record_extras_and_towers(plan, model, xx, vals[n - 1])
     return plan.finalize()

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 from ssds.modeling.layers.basic_layers import ConvBNReLU
 
 from .fpn import SharedHead
-from .ssdsbase import SSDSBase
+from .ssdsbase import NeckPlanMixin, SSDSBase
 
 
 class BiFPNModule(nn.Module):
@@ -52,7 +52,7 @@ class BiFPNModule(nn.Module):
         return xx
 
 
-class SSDBiFPN(SSDSBase):
+class SSDBiFPN(NeckPlanMixin, SSDSBase):
     """EfficientDet (https://arxiv.org/abs/1911.09070) head with the reference's ConvBNReLU blocks."""
 
     def __init__(self, backbone, extras, head, num_classes):
@@ -72,9 +72,17 @@ class SSDBiFPN(SSDSBase):
         self.conf.apply(self.initialize_head)
         self.conf[-1].apply(self.initialize_prior)
 
+    def _build_neck_plan(self, features):
+        from ssds.modeling.layers.planner import build_bifpn_plan
+
+        return build_bifpn_plan(self, features)
+
     def forward(self, x):
         loc, conf = [], []
         features = self.backbone(x)
+        out = self._neck_native(features)  # eval on a HIP device: transforms, BiFPN layers, extras, towers = one plan
+        if out is not None:
+            return out
         x = features[-1]
         n = len(features)
         features = [self.transforms[i](features[i]) for i in range(n)]

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from ssds.modeling.layers.basic_layers import ConvBNReLU
 from ssds.modeling.layers.fused_conv import FusedSequentialMixin
 
-from .ssdsbase import SSDSBase
+from .ssdsbase import NeckPlanMixin, SSDSBase
 
 
 class SharedHead(FusedSequentialMixin, nn.Sequential):
@@ -55,7 +55,7 @@ def _final_conv(owner, conv, x, act):
     return y.sigmoid() if act == "sigmoid" else y
 
 
-class SSDFPN(SSDSBase):
+class SSDFPN(NeckPlanMixin, SSDSBase):
     """RetinaNet (https://arxiv.org/abs/1708.02002) with ConvBNReLU extras/towers like the reference."""
 
     def __init__(self, backbone, extras, head, num_classes):
@@ -78,9 +78,17 @@ class SSDFPN(SSDSBase):
         loc.append(self.loc(xx, "none"))
         conf.append(self.conf(xx, "none" if self.training else "sigmoid"))
 
+    def _build_neck_plan(self, features):
+        from ssds.modeling.layers.planner import build_fpn_plan
+
+        return build_fpn_plan(self, features)
+
     def forward(self, x):
         loc, conf = [], []
         features = self.backbone(x)
+        out = self._neck_native(features)  # eval on a HIP device: laterals, top-down adds, extras, towers = one plan
+        if out is not None:
+            return out
         x = features[-1]
         n = len(features)
         xx = None

@@ -3,6 +3,7 @@ initialisers for extras (Xavier), heads (N(0, 0.01)) and the class-prior bias (p
 untrained conf head outputs sigmoid = 0.01, exactly at the default SCORE_THRESHOLD)."""
 import math
 
+import torch
 import torch.nn as nn
 
 
@@ -29,3 +30,46 @@ class SSDSBase(nn.Module):
             nn.init.xavier_uniform_(layer.weight)
             if layer.bias is not None:
                 nn.init.constant_(layer.bias, val=0)
+
+
+class NeckPlanMixin(object):
+    """Eval forward of a detector whose backbone runs on PyTorch-ROCm and whose neck + towers run as one
+    recorded plan (``ssds/modeling/layers/planner.py``) on the backbone's feature maps.  ``_build_neck_plan`` is
+    provided by the subclass; plans are cached per feature shapes and dropped by train() / .to() /
+    load_state_dict()."""
+
+    def invalidate_plans(self):
+        self.__dict__["_neck_plans"] = {}
+
+    def train(self, mode=True):
+        self.invalidate_plans()
+        return super(NeckPlanMixin, self).train(mode)
+
+    def _apply(self, fn, *a, **kw):
+        self.invalidate_plans()
+        return super(NeckPlanMixin, self)._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self.invalidate_plans()
+        return super(NeckPlanMixin, self).load_state_dict(*a, **kw)
+
+    def _neck_native(self, features):
+        """(loc, conf) through the plan, or None when the plan path does not apply."""
+        from ssds.modeling.layers import fused_conv as FC
+        from ssds.modeling.layers.planner import PlanUnsupported
+
+        f0 = features[0]
+        if self.training or not FC.fused_enabled() or not f0.is_cuda or f0.dtype not in (torch.bfloat16, torch.float16):
+            return None
+        plans = self.__dict__.setdefault("_neck_plans", {})
+        key = (tuple(tuple(f.shape) for f in features), f0.dtype, f0.device.index)
+        if key not in plans:
+            try:
+                with torch.no_grad():
+                    plans[key] = self._build_neck_plan(features)
+            except PlanUnsupported as e:
+                plans[key] = str(e)
+        plan = plans[key]
+        if isinstance(plan, str):
+            return None
+        return plan.run(*features)

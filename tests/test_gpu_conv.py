@@ -161,6 +161,85 @@ def test_halo_kernel_residual_and_split_heads():
     _check(c, _ref(f, conf, None, "sigmoid"), dtype, "halo split conf")
 
 
+@pytest.mark.parametrize("cin,cout,k,h,w,n,kernel", [
+    (64, 256, 1, 16, 20, 2, "conv_gemm_kernel"),       # FPN lateral + top-down add, tiled kernel
+    (128, 256, 1, 64, 64, 16, G256),                   # same on the 256x256 kernel
+    (64, 64, 1, 2, 2, 8, "conv_wave_kernel"),          # same on the wave kernel
+])
+def test_conv_half_resolution_residual(cin, cout, k, h, w, n, kernel):
+    """lateral(x) + upsample2x_nearest(coarse) as ONE launch (reference fpn.py:80-87)."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+
+    dtype = torch.bfloat16
+    torch.manual_seed(h * 3 + cout)
+    conv = nn.Conv2d(cin, cout, k, 1, k // 2, bias=True).cuda()
+    conv.weight.data = conv.weight.data.to(dtype).float()
+    x = torch.randn(n, cin, h, w).to(dtype)
+    coarse = torch.randn(n, cout, h // 2, w // 2).to(dtype)
+    want = _ref(x, conv, None, "none").to(dtype).float() + F.interpolate(coarse.float(), scale_factor=2, mode="nearest")
+    y = FC.conv_native(x.cuda(), FC.ConvPack(conv, None, "none", dtype), residual=coarse.cuda(), res_mode=1)
+    assert N.last_kernel() == kernel, N.last_kernel()
+    _check(y, want, dtype, "half-resolution residual")
+
+
+@pytest.mark.parametrize("cin,cout,k,h,w,n,act,kernel", [
+    (64, 64, 3, 14, 14, 2, "relu", "conv_gemm_kernel"),
+    (128, 256, 3, 16, 16, 48, "relu", HALO),
+    (256, 512, 1, 64, 32, 16, "relu", G256),
+    (64, 64, 3, 2, 2, 8, "relu6", "conv_wave_kernel"),
+])
+def test_conv_activation_after_residual(cin, cout, k, h, w, n, act, kernel):
+    """ResNet block tail: relu(bn(conv(x)) + identity) as one launch (res_mode bit 1)."""
+    import torch
+    import torch.nn as nn
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+
+    dtype = torch.bfloat16
+    torch.manual_seed(cin + h)
+    conv = nn.Conv2d(cin, cout, k, 1, k // 2, bias=False).cuda()
+    bn = nn.BatchNorm2d(cout).cuda()
+    bn.running_mean.normal_(0, 0.2)
+    bn.running_var.uniform_(0.5, 1.5)
+    conv.weight.data = conv.weight.data.to(dtype).float()
+    x = torch.randn(n, cin, h, w).to(dtype)
+    res = torch.randn(n, cout, h, w).to(dtype)
+    lin = _ref(x, conv, bn, "none").to(dtype).float() + res.float()
+    want = lin.clamp(min=0) if act == "relu" else lin.clamp(0, 6)
+    y = FC.conv_native(x.cuda(), FC.ConvPack(conv, bn, act, dtype), residual=res.cuda(), res_mode=2)
+    assert N.last_kernel() == kernel, N.last_kernel()
+    _check(y, want, dtype, "activation after residual")
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+def test_fuse_kernel(dtype_name):
+    """BiFPN weighted fusions (reference bifpn.py:41-62) against torch fp32."""
+    import torch
+    import torch.nn.functional as F
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    torch.manual_seed(3)
+    a = torch.randn(3, 64, 14, 10).to(dtype)
+    up = torch.randn(3, 64, 7, 5).to(dtype)
+    big = torch.randn(3, 64, 29, 21).to(dtype)  # odd: max_pool2d floors to 14 x 10
+    skip = torch.randn(3, 64, 14, 10).to(dtype)
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last)
+    y = FC.fuse_native(cl(a), cl(up), None, (0.25, 0.75, 0.0), N.FUSE_UP2)
+    want = 0.25 * a.float() + 0.75 * F.interpolate(up.float(), scale_factor=2, mode="nearest")
+    _check(y, want, dtype, "top-down fusion")
+    y = FC.fuse_native(cl(a), cl(big), cl(skip), (0.5, 0.3, 0.2), N.FUSE_POOL2, N.FUSE_SAME)
+    want = 0.5 * a.float() + 0.3 * F.max_pool2d(big.float(), 2) + 0.2 * skip.float()
+    _check(y, want, dtype, "bottom-up fusion")
+    with pytest.raises(N.SsdkError):
+        FC.fuse_native(cl(a), cl(torch.randn(3, 64, 9, 5).to(dtype)), None, (1, 1, 0), N.FUSE_POOL2)
+
+
 def test_dense_conv_residual_and_split():
     import torch
     import torch.nn as nn
@@ -379,10 +458,11 @@ def test_fpn_bifpn_eval_on_device(head, net, outs, depth):
     with torch.no_grad():
         rl, rc = model(x)
     model = model.cuda().to(torch.bfloat16)
-    before = FC.STATS["native_layers"]
+    before, plans = FC.STATS["native_layers"], FC.STATS["plan_runs"]
     with torch.no_grad():
         loc, conf = model(x.cuda().to(torch.bfloat16))
     assert FC.STATS["native_layers"] - before >= 5 * 10, "towers did not run on the fused kernels"
+    assert FC.STATS["plan_runs"] == plans + 1, "neck + towers did not run as one recorded plan"
     for l, a, c, b in zip(loc, rl, conf, rc):
         assert l.shape == a.shape and c.shape == b.shape and l.is_contiguous() and c.is_contiguous()
         assert float((c.float().cpu() - b).abs().max()) < 3e-3
