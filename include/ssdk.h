@@ -222,17 +222,40 @@ typedef struct ssdk_fuse_desc {
 } ssdk_fuse_desc;
 int ssdk_fuse(const ssdk_fuse_desc* desc, void* stream);
 
+/* ResNet stem (nets/resnet.py:41-46): 7x7 / stride 2 / pad 3 convolution on the 3-channel image + folded BN +
+ * activation -> NHWC, and the 3x3 / stride 2 / pad 1 max pooling (NHWC -> NHWC, -inf padding like torch).
+ *   x  image [N,3,H,W] (in_layout NCHW) or [N,H,W,3] (NHWC), activation dtype
+ *   w  [Cout][7][8][4] activation dtype: (ky, kx padded to 8, ci padded to 4), zeros in the padding slots
+ *   scale / bias  fp32 [Cout] folded BN;  Cout in {32, 64} */
+typedef struct ssdk_stem_desc {
+  const void* x;
+  const void* w;
+  const float* scale;
+  const float* bias;
+  void* y;
+  int32_t N, H, W, Cin, Cout, act, dtype, in_layout;
+} ssdk_stem_desc;
+int ssdk_conv_stem7(const ssdk_stem_desc* desc, void* stream);
+typedef struct ssdk_pool_desc {
+  const void* x;
+  void* y;
+  int32_t N, H, W, C, dtype, pad;
+} ssdk_pool_desc;
+int ssdk_maxpool3x3s2(const ssdk_pool_desc* desc, void* stream);
+
 /* Plan executor: a recorded forward as a list of tagged ops (topological order), replayed with one host call.
  * lane 0 ops run in order on the caller's stream.  lane 1 ops (the multibox heads: leaves that depend only on
  * ops listed before them) are forked onto a library-owned side stream and run concurrently with the following
  * lane 0 ops; they use the upper half of the workspace, and everything is joined back onto the caller's stream
  * before the call returns.  Buffers read or written by lane 1 ops must not be reused by later ops of the list. */
-enum { SSDK_OP_CONV = 0, SSDK_OP_MBCONV = 1, SSDK_OP_FUSE = 2 };
+enum { SSDK_OP_CONV = 0, SSDK_OP_MBCONV = 1, SSDK_OP_FUSE = 2, SSDK_OP_STEM7 = 3, SSDK_OP_POOL = 4 };
 typedef struct ssdk_op {
   int32_t kind, lane;
   ssdk_conv_desc conv;
   ssdk_mbconv_desc mb;
   ssdk_fuse_desc fuse;
+  ssdk_stem_desc stem;
+  ssdk_pool_desc pool;
 } ssdk_op;
 int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t workspace_bytes, void* stream);
 /* convenience wrapper: dense conv, NHWC in/out, single output */

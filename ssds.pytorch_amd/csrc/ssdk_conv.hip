@@ -1274,6 +1274,8 @@ extern "C" int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t w
     if (ops[i].kind == SSDK_OP_CONV) rc = ssdk_conv(&ops[i].conv, w, wb, st);
     else if (ops[i].kind == SSDK_OP_MBCONV) rc = ssdk_mbconv(&ops[i].mb, st);
     else if (ops[i].kind == SSDK_OP_FUSE) rc = ssdk_fuse(&ops[i].fuse, st);
+    else if (ops[i].kind == SSDK_OP_STEM7) rc = ssdk_conv_stem7(&ops[i].stem, st);
+    else if (ops[i].kind == SSDK_OP_POOL) rc = ssdk_maxpool3x3s2(&ops[i].pool, st);
     else {
       set_error("unknown op kind %d", ops[i].kind);
       rc = SSDK_E_BADARG;

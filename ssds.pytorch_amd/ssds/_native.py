@@ -67,12 +67,23 @@ class FuseDesc(ctypes.Structure):
                 ("dtype", ctypes.c_int32)]
 
 
+class StemDesc(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("y", ctypes.c_void_p)] + [(n, ctypes.c_int32) for n in (
+                    "N", "H", "W", "Cin", "Cout", "act", "dtype", "in_layout")]
+
+
+class PoolDesc(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p)] + [(n, ctypes.c_int32) for n in (
+        "N", "H", "W", "C", "dtype", "pad")]
+
+
 class Op(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("lane", ctypes.c_int32), ("conv", ConvDesc), ("mb", MbConvDesc),
-                ("fuse", FuseDesc)]
+                ("fuse", FuseDesc), ("stem", StemDesc), ("pool", PoolDesc)]
 
 
-OP_CONV, OP_MBCONV, OP_FUSE = 0, 1, 2
+OP_CONV, OP_MBCONV, OP_FUSE, OP_STEM7, OP_POOL = 0, 1, 2, 3, 4
 FUSE_SAME, FUSE_UP2, FUSE_POOL2 = 0, 1, 2
 NCHW, NHWC = 0, 1
 
@@ -91,6 +102,10 @@ def _load():
     lib.ssdk_last_kernel.restype = c.c_char_p
     lib.ssdk_fuse.argtypes = [c.POINTER(FuseDesc), vp]
     lib.ssdk_fuse.restype = i32
+    lib.ssdk_conv_stem7.argtypes = [c.POINTER(StemDesc), vp]
+    lib.ssdk_conv_stem7.restype = i32
+    lib.ssdk_maxpool3x3s2.argtypes = [c.POINTER(PoolDesc), vp]
+    lib.ssdk_maxpool3x3s2.restype = i32
     lib.ssdk_set_op_profiling.argtypes = [i32]
     lib.ssdk_get_op_timings.argtypes = [c.POINTER(f32), c.POINTER(c.c_char_p), i32]
     lib.ssdk_device_info.argtypes = [c.POINTER(i32), c.POINTER(i32), c.POINTER(sz), c.c_char_p, i32]
@@ -133,7 +148,7 @@ lib = _load()
 EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_profiling", "ssdk_get_op_timings", "ssdk_device_info", "ssdk_generate_anchors",
            "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
-           "ssdk_match_targets_by_scale", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_fuse", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
+           "ssdk_match_targets_by_scale", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_fuse", "ssdk_conv_stem7", "ssdk_maxpool3x3s2", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 
 
 def op_timings():

@@ -90,6 +90,62 @@ class ConvPack(object):
         self.bias = bias
 
 
+class StemPack(object):
+    """7x7 / stride 2 / pad 3 stem conv on a 3-channel image + BN + activation (ResNet conv1/bn1/relu) packed for
+    csrc/ssdk_stem.hip: weights [Cout][ky 7][kx padded to 8][ci padded to 4], zeros in the padding slots."""
+
+    __slots__ = ("w", "scale", "bias", "cin", "cout", "act")
+
+    @staticmethod
+    def supported(conv, bn):
+        return (bn is not None and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
+                and conv.groups == 1 and conv.in_channels == 3 and conv.out_channels in (32, 64))
+
+    def __init__(self, conv, bn, act, dtype):
+        self.scale, self.bias = fold_bn(conv, bn)
+        w = conv.weight.detach().float().permute(0, 2, 3, 1)  # [Cout][ky][kx][ci]
+        wp = torch.zeros((conv.out_channels, 7, 8, 4), device=w.device, dtype=torch.float32)
+        wp[:, :, :7, :3] = w
+        self.w = wp.to(dtype).contiguous()
+        self.cin, self.cout, self.act = 3, conv.out_channels, act
+
+
+def stem7_native(x, pack):
+    """[N,3,H,W] image (NCHW contiguous or channels_last) -> channels_last [N,Cout,H/2,W/2]."""
+    N.require_device(x, "conv_stem7")
+    n, c, h, w = (int(v) for v in x.shape)
+    layout = N.NCHW
+    if not x.is_contiguous():
+        x = x.contiguous(memory_format=torch.channels_last)
+        layout = N.NHWC
+    ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    y = torch.empty((n, pack.cout, ho, wo), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+    d = N.StemDesc()
+    d.x, d.w, d.scale, d.bias, d.y = x.data_ptr(), pack.w.data_ptr(), pack.scale.data_ptr(), pack.bias.data_ptr(), y.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.act, d.dtype, d.in_layout = n, h, w, c, pack.cout, N.ACT[pack.act], N.dtype_code(x), layout
+    with torch.cuda.device(x.device):
+        rc = N.lib.ssdk_conv_stem7(ctypes.byref(d), N.stream_ptr(x.device))
+    N.check(rc, "conv_stem7")
+    return y
+
+
+def maxpool_native(x):
+    """F.max_pool2d(x, 3, 2, 1) on a channels_last tensor."""
+    N.require_device(x, "maxpool3x3s2")
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    n, c, h, w = (int(v) for v in x.shape)
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    y = torch.empty((n, c, ho, wo), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+    d = N.PoolDesc()
+    d.x, d.y = x.data_ptr(), y.data_ptr()
+    d.N, d.H, d.W, d.C, d.dtype = n, h, w, c, N.dtype_code(x)
+    with torch.cuda.device(x.device):
+        rc = N.lib.ssdk_maxpool3x3s2(ctypes.byref(d), N.stream_ptr(x.device))
+    N.check(rc, "maxpool3x3s2")
+    return y
+
+
 def pack_heads(loc_conv, conf_conv, dtype):
     """loc | conf of one SSD level as ONE GEMM with N = A*(4+C): concatenated KRSC weights + biases."""
     p = ConvPack(loc_conv, None, "none", dtype)
@@ -389,6 +445,21 @@ class ConvPlan(object):
         self.keep.append(pk)
         return (out, n, pk.cout, ho, wo)
 
+    def stem7(self, val, pack):
+        buf, n, c, h, w = val
+        ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+        out = self.arena.get(n * pack.cout * ho * wo * self.es)
+        self.layers.append(dict(kind="stem7", x=buf, n=n, h=h, w=w, pack=pack, y=out))
+        self.keep.append(pack)
+        return (out, n, pack.cout, ho, wo)
+
+    def pool(self, val):
+        buf, n, c, h, w = val
+        ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        out = self.arena.get(n * c * ho * wo * self.es)
+        self.layers.append(dict(kind="pool", x=buf, n=n, h=h, w=w, ch=c, y=out))
+        return (out, n, c, ho, wo)
+
     def fuse(self, a, b, c=None, weights=(1.0, 1.0, 0.0), mode_b=N.FUSE_SAME, mode_c=N.FUSE_SAME):
         """y = w0*a + w1*R_b(b) [+ w2*R_c(c)] at the resolution of ``a`` (BiFPN weighted fusion)."""
         _, n, ch, h, w = a
@@ -440,6 +511,20 @@ class ConvPlan(object):
                 fill_mb_desc(op.mb, self._ptr(L["x"], self.patches, i, "mb.x"), self.arena.ptr(L["y"]), L["n"], L["h"],
                              L["w"], L["pack"], self.dtype_code)
                 continue
+            if kind == "stem7":
+                op.kind = N.OP_STEM7
+                st, pk = op.stem, L["pack"]
+                st.x = self._ptr(L["x"], self.patches, i, "stem.x")
+                st.w, st.scale, st.bias, st.y = pk.w.data_ptr(), pk.scale.data_ptr(), pk.bias.data_ptr(), self.arena.ptr(L["y"])
+                st.N, st.H, st.W, st.Cin, st.Cout = L["n"], L["h"], L["w"], 3, pk.cout
+                st.act, st.dtype, st.in_layout = N.ACT[pk.act], self.dtype_code, N.NCHW
+                continue
+            if kind == "pool":
+                op.kind = N.OP_POOL
+                pl = op.pool
+                pl.x, pl.y = self._ptr(L["x"], self.patches, i, "pool.x"), self.arena.ptr(L["y"])
+                pl.N, pl.H, pl.W, pl.C, pl.dtype = L["n"], L["h"], L["w"], L["ch"], self.dtype_code
+                continue
             if kind == "fuse":
                 op.kind = N.OP_FUSE
                 f = op.fuse
@@ -471,6 +556,18 @@ class ConvPlan(object):
         rows = []
         for L in self.layers:
             es = self.es
+            if L.get("kind") == "stem7":
+                pk, n, h, w = L["pack"], L["n"], L["h"], L["w"]
+                ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+                rows.append(dict(name="stem7 3>%d @%dx%d" % (pk.cout, h, w), flops=2.0 * n * ho * wo * 147 * pk.cout,
+                                 bytes=float(es * n * (3 * h * w + pk.cout * ho * wo)), kind="stem"))
+                continue
+            if L.get("kind") == "pool":
+                n, h, w, ch = L["n"], L["h"], L["w"], L["ch"]
+                ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+                rows.append(dict(name="maxpool %d @%dx%d" % (ch, h, w), flops=9.0 * n * ch * ho * wo,
+                                 bytes=float(es * n * ch * (h * w + ho * wo)), kind="pool"))
+                continue
             if L.get("kind") == "fuse":
                 n, h, w, ch = L["n"], L["h"], L["w_"], L["ch"]
                 srcs = [L["a"], L["b"]] + ([L["c"]] if L["c"] is not None else [])
@@ -518,7 +615,14 @@ class ConvPlan(object):
         xs = list(inputs)
         if image_first:
             x = xs[0]
-            if first_kind == N.OP_MBCONV:  # stem + first block fused: the image is read by the block kernel
+            if first_kind == N.OP_STEM7:  # ResNet stem reads the image in either layout
+                first = self.ops[0].stem
+                if x.is_contiguous():
+                    first.in_layout = N.NCHW
+                else:
+                    x = x.contiguous(memory_format=torch.channels_last)
+                    first.in_layout = N.NHWC
+            elif first_kind == N.OP_MBCONV:  # stem + first block fused: the image is read by the block kernel
                 first = self.ops[0].mb
                 if x.is_contiguous():
                     first.stem = 1

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 import os
 
-from .fused_conv import ConvPack, ConvPlan, MbPack, conv_kind, pack_heads, sequential_groups
+from .fused_conv import ConvPack, ConvPlan, MbPack, StemPack, conv_kind, pack_heads, sequential_groups
 
 
 class PlanUnsupported(Exception):
@@ -102,7 +102,7 @@ def record_mobilenet(plan, val, net, on_output=None):
 
 
 def build_ssd_plan(model, x):
-    """SSD (ssds/ssd.py) on a MobileNet backbone -> finalized ConvPlan for inputs shaped like ``x``."""
+    """SSD (ssds/ssd.py) on a planned backbone (MobileNet, ResNet) -> finalized ConvPlan for inputs shaped like ``x``."""
     plan = ConvPlan(x.device, x.dtype, x.shape)
 
     def head(i, f):
@@ -113,11 +113,86 @@ def build_ssd_plan(model, x):
             raise PlanUnsupported("head conv not covered")
         plan.head(f, pack_heads(l, c, plan.dtype), split=l.out_channels, act="none", act2="sigmoid", tag="both")
 
-    feats = record_mobilenet(plan, plan.input_value(), model.backbone, on_output=head)
+    from ssds.modeling.nets.mobilenet import MobileNetEx
+
+    if isinstance(model.backbone, MobileNetEx):
+        feats = record_mobilenet(plan, plan.input_value(), model.backbone, on_output=head)
+    else:
+        feats = record_backbone(plan, plan.input_value(), model.backbone)
+        for i, f in enumerate(feats):
+            head(i, f)
     for extra in model.extras:
         feats.append(record_chain(plan, feats[-1], extra, keep_input=True))
         head(len(feats) - 1, feats[-1])
     return plan.finalize()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# ResNet backbones (nets/resnet.py)
+# --------------------------------------------------------------------------------------------------------------
+def _pack(conv, bn, act, dtype):
+    if conv_kind(conv) != "dense":
+        raise PlanUnsupported("conv not covered by the HIP kernels: {}".format(conv))
+    return ConvPack(conv, bn, act, dtype)
+
+
+def record_resnet(plan, val, net):
+    """conv1/bn1/relu (7x7 stem kernel) -> maxpool -> layer1..4; every block ends in ONE launch that adds the
+    identity and applies the ReLU in the epilogue of its last conv (res_mode bit 1)."""
+    from ssds.modeling.nets.resnet import BasicBlock, Bottleneck, ResNet
+
+    if not isinstance(net, ResNet):
+        raise PlanUnsupported("backbone {} has no planner".format(type(net).__name__))
+    if not StemPack.supported(net.conv1, net.bn1):
+        raise PlanUnsupported("stem not covered")
+    dt = plan.dtype
+    cur = plan.stem7(val, StemPack(net.conv1, net.bn1, "relu", dt))
+    pooled = plan.pool(cur)
+    plan.release(cur)
+    cur = pooled
+    outputs = []
+    for li, layer in enumerate([net.layer1, net.layer2, net.layer3, net.layer4]):
+        level = li + 2
+        if level > max(net.outputs):
+            break
+        for blk in layer:
+            keep_cur = any(cur is o for o in outputs)
+            idt = cur
+            if blk.downsample is not None:
+                dconv, dbn = blk.downsample[0], blk.downsample[1]
+                idt = plan.conv(cur, _pack(dconv, dbn, "none", dt))
+            if isinstance(blk, Bottleneck):
+                o1 = plan.conv(cur, _pack(blk.conv1, blk.bn1, "relu", dt))
+                o2 = plan.conv(o1, _pack(blk.conv2, blk.bn2, "relu", dt))
+                plan.release(o1)
+                out = plan.conv(o2, _pack(blk.conv3, blk.bn3, "relu", dt), residual=idt, res_mode=2)
+                plan.release(o2)
+            elif isinstance(blk, BasicBlock):
+                o1 = plan.conv(cur, _pack(blk.conv1, blk.bn1, "relu", dt))
+                out = plan.conv(o1, _pack(blk.conv2, blk.bn2, "relu", dt), residual=idt, res_mode=2)
+                plan.release(o1)
+            else:
+                raise PlanUnsupported("block {} has no planner".format(type(blk).__name__))
+            if idt is not cur:
+                plan.release(idt)
+            if not keep_cur:
+                plan.release(cur)
+            cur = out
+        if level in net.outputs:
+            outputs.append(cur)
+    return outputs
+
+
+def record_backbone(plan, val, net):
+    """Backbone maps of a planned backbone (MobileNet, ResNet) from the image value; PlanUnsupported otherwise."""
+    from ssds.modeling.nets.mobilenet import MobileNetEx
+    from ssds.modeling.nets.resnet import ResNet
+
+    if isinstance(net, MobileNetEx):
+        return record_mobilenet(plan, val, net)
+    if isinstance(net, ResNet):
+        return record_resnet(plan, val, net)
+    raise PlanUnsupported("backbone {} has no planner".format(type(net).__name__))
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -162,13 +237,22 @@ def _record_extras_and_towers(plan, model, pyramid, raw_last):
         _record_towers(plan, xx, loc_packs, conf_packs)
 
 
-def build_fpn_plan(model, features):
-    """SSDFPN (ssds/fpn.py) neck + towers on the backbone maps ``features`` -> finalized ConvPlan.  The 1x1
-    lateral of level i and the nearest-x2 upsample-add of level i+1 (reference fpn.py:80-87) are ONE launch:
-    the coarser map rides in as a half-resolution residual of the lateral GEMM's epilogue."""
+def _neck_inputs(model, features, image):
+    """(plan, backbone map values): from the image through a planned backbone, or the maps as external inputs."""
+    if image is not None:
+        plan = ConvPlan(image.device, image.dtype, image.shape)
+        return plan, record_backbone(plan, plan.input_value(), model.backbone)
     f0 = features[0]
     plan = ConvPlan(f0.device, f0.dtype)
-    vals = [plan.add_input(f.shape) for f in features]
+    return plan, [plan.add_input(f.shape) for f in features]
+
+
+def build_fpn_plan(model, features=None, image=None):
+    """SSDFPN (ssds/fpn.py) neck + towers -> finalized ConvPlan, on the backbone maps ``features`` (external
+    inputs) or, with ``image``, including a planned backbone.  The 1x1 lateral of level i and the nearest-x2
+    upsample-add of level i+1 (reference fpn.py:80-87) are ONE launch: the coarser map rides in as a
+    half-resolution residual of the lateral GEMM's epilogue."""
+    plan, vals = _neck_inputs(model, features, image)
     n = len(vals)
     pyramid = [None] * n
     for i in range(n - 1, -1, -1):
@@ -217,12 +301,10 @@ def _record_bifpn_layer(plan, m, xx):
     return xx
 
 
-def build_bifpn_plan(model, features):
+def build_bifpn_plan(model, features=None, image=None):
     """SSDBiFPN (ssds/bifpn.py): 1x1 transforms, stacked BiFPN layers (weighted fusions as one launch each),
-    extras and shared towers on the backbone maps ``features`` -> finalized ConvPlan."""
-    f0 = features[0]
-    plan = ConvPlan(f0.device, f0.dtype)
-    vals = [plan.add_input(f.shape) for f in features]
+    extras and shared towers -> finalized ConvPlan (inputs as in ``build_fpn_plan``)."""
+    plan, vals = _neck_inputs(model, features, image)
     n = len(vals)
     xx = []
     for i in range(n):

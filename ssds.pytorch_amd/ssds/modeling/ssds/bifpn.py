@@ -72,12 +72,15 @@ class SSDBiFPN(NeckPlanMixin, SSDSBase):
         self.conf.apply(self.initialize_head)
         self.conf[-1].apply(self.initialize_prior)
 
-    def _build_neck_plan(self, features):
+    def _build_neck_plan(self, features, image=None):
         from ssds.modeling.layers.planner import build_bifpn_plan
 
-        return build_bifpn_plan(self, features)
+        return build_bifpn_plan(self, features, image=image)
 
     def forward(self, x):
+        out = self._full_native(x)  # planned backbone (MobileNet / ResNet): image -> heads is one plan
+        if out is not None:
+            return out
         loc, conf = [], []
         features = self.backbone(x)
         out = self._neck_native(features)  # eval on a HIP device: transforms, BiFPN layers, extras, towers = one plan

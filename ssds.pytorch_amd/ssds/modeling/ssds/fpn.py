@@ -78,12 +78,15 @@ class SSDFPN(NeckPlanMixin, SSDSBase):
         loc.append(self.loc(xx, "none"))
         conf.append(self.conf(xx, "none" if self.training else "sigmoid"))
 
-    def _build_neck_plan(self, features):
+    def _build_neck_plan(self, features, image=None):
         from ssds.modeling.layers.planner import build_fpn_plan
 
-        return build_fpn_plan(self, features)
+        return build_fpn_plan(self, features, image=image)
 
     def forward(self, x):
+        out = self._full_native(x)  # planned backbone (MobileNet / ResNet): image -> heads is one plan
+        if out is not None:
+            return out
         loc, conf = [], []
         features = self.backbone(x)
         out = self._neck_native(features)  # eval on a HIP device: laterals, top-down adds, extras, towers = one plan

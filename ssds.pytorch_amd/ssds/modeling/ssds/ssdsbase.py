@@ -53,6 +53,27 @@ class NeckPlanMixin(object):
         self.invalidate_plans()
         return super(NeckPlanMixin, self).load_state_dict(*a, **kw)
 
+    def _full_native(self, x):
+        """Image -> (loc, conf) with backbone, neck and towers as ONE plan, or None (backbone without a planner,
+        training mode, CPU tensors ...)."""
+        from ssds.modeling.layers import fused_conv as FC
+        from ssds.modeling.layers.planner import PlanUnsupported
+
+        if self.training or not FC.fused_enabled() or not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16):
+            return None
+        plans = self.__dict__.setdefault("_neck_plans", {})
+        key = ("image", tuple(x.shape), x.dtype, x.device.index)
+        if key not in plans:
+            try:
+                with torch.no_grad():
+                    plans[key] = self._build_neck_plan(None, image=x)
+            except PlanUnsupported as e:
+                plans[key] = str(e)
+        plan = plans[key]
+        if isinstance(plan, str):
+            return None
+        return plan.run(x)
+
     def _neck_native(self, features):
         """(loc, conf) through the plan, or None when the plan path does not apply."""
         from ssds.modeling.layers import fused_conv as FC

@@ -215,6 +215,69 @@ def test_conv_activation_after_residual(cin, cout, k, h, w, n, act, kernel):
     _check(y, want, dtype, "activation after residual")
 
 
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("h,w,dtype_name", [(64, 96, "bf16"), (75, 53, "bf16"), (40, 40, "f16")])
+def test_resnet_stem_and_maxpool(layout, h, w, dtype_name):
+    """conv1 7x7/2 + bn1 + relu on the MFMA im2col kernel and maxpool 3x3/2 (nets/resnet.py:41-46) vs torch fp32."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from ssds.modeling.layers import fused_conv as FC
+
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    torch.manual_seed(h + w)
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+    bn = nn.BatchNorm2d(64)
+    bn.running_mean.normal_(0, 0.2)
+    bn.running_var.uniform_(0.5, 1.5)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_(0, 0.2)
+    conv.weight.data = conv.weight.data.to(dtype).float()
+    x = torch.randn(3, 3, h, w).to(dtype)
+    want = _ref(x, conv, bn, "relu")
+    conv, bn = conv.cuda(), bn.cuda()
+    assert FC.StemPack.supported(conv, bn)
+    xin = x.cuda() if layout == "nchw" else x.cuda().contiguous(memory_format=torch.channels_last)
+    y = FC.stem7_native(xin, FC.StemPack(conv, bn, "relu", dtype))
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    _check(y, want, dtype, "stem 7x7")
+    pooled = FC.maxpool_native(y)
+    assert torch.equal(pooled.float().cpu(), F.max_pool2d(y.float().cpu(), 3, 2, 1)), "maxpool must be exact"
+
+
+@pytest.mark.parametrize("net,outs,depth", [("ResNet18", [3, 4, 5], [128, 256, 512]), ("ResNet50", [4, 5], [1024, 2048])])
+def test_ssd_on_resnet_plan_matches_torch(net, outs, depth):
+    """SSD heads on a ResNet backbone: image -> heads as one recorded plan (stem kernel, maxpool, residual blocks
+    with the ReLU after the add) vs the fp32 module."""
+    import torch
+    from ssds.modeling import nets, ssds
+    from ssds.modeling.layers import fused_conv as FC
+
+    torch.manual_seed(4)
+    fl = [outs + ["Conv:S"], depth + [256]]
+    nets_outputs, extras, hd = ssds.SSD.add_extras(fl, [6] * (len(outs) + 1), 5)
+    model = ssds.SSD(getattr(nets, net)(outputs=nets_outputs), extras, hd, 5).eval()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.05)
+            m.running_var.uniform_(0.9, 1.1)
+    x = torch.rand(2, 3, 96, 128)
+    with torch.no_grad():
+        rl, rc = model(x)
+    model = model.cuda().to(torch.bfloat16)
+    plans = FC.STATS["plan_runs"]
+    with torch.no_grad():
+        loc, conf = model(x.cuda().to(torch.bfloat16))
+    assert FC.STATS["plan_runs"] == plans + 1, "the ResNet forward did not run as one plan"
+    # a random-init 18/50-layer network amplifies the per-layer bf16 rounding (2^-8 relative) to a few percent; a
+    # structural error (wrong residual, stride, layout) shows up as O(100 %): bound the relative L2 error
+    for l, a, c, b in zip(loc, rl, conf, rc):
+        assert l.shape == a.shape and c.shape == b.shape
+        for got, want in ((l, a), (c, b)):
+            err = float((got.float().cpu() - want).norm() / want.norm().clamp(min=1e-6))
+            assert err < 0.06, err
+
+
 @pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
 def test_fuse_kernel(dtype_name):
     """BiFPN weighted fusions (reference bifpn.py:41-62) against torch fp32."""
