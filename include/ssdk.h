@@ -164,7 +164,7 @@ typedef struct ssdk_conv_desc {
   const void* residual; /* optional, NHWC: y = act(conv) + residual, or act(conv + residual) with res_mode bit 1 */
   void* y;
   void* y2;             /* optional second output (NCHW split) */
-  int32_t N, Cin, H, W, Cout, k, stride, groups;
+  int32_t N, Cin, H, W, Cout, k, stride, groups; /* groups: 1 dense | Cin depthwise (k=3) | Cin/16 grouped (k=3) */
   int32_t act, act2, split;
   int32_t dtype;        /* SSDK_BF16 | SSDK_F16 (input, weights and output) */
   int32_t in_layout, out_layout;

@@ -200,9 +200,14 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
     const bool last = *flag != 0u;
     __syncthreads();  // everyone has read the flag before the epilogue reuses the LDS
     if (!last) return;
+    // sum the slabs in slice order, the reducer's own included: the result must not depend on which slice
+    // happens to arrive last (bit-reproducible outputs run to run)
     const float* base = p.slabs + (size_t)tile_id * p.ksplits * (size_t)(4 * FRAGS * 256);
-    for (int z = 0; z < p.ksplits; ++z) {
-      if (z == (int)blockIdx.z) continue;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = *reinterpret_cast<const f32x4*>(base + ((size_t)(i * FN + j) * 256 + tid) * 4);
+    for (int z = 1; z < p.ksplits; ++z) {
       const float* other = base + (size_t)z * (size_t)(4 * FRAGS * 256);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
@@ -415,9 +420,11 @@ __global__ __launch_bounds__(256) void conv_wave_kernel(const ConvParams p, int 
     }
     last = (u32)__builtin_amdgcn_readfirstlane((int)last);
     if (!last) return;
+    // slabs summed in slice order (own slice included): independent of the arrival order, bit-reproducible
     const float* base = p.slabs + (size_t)tile * p.ksplits * 1024;
-    for (int zz = 0; zz < p.ksplits; ++zz) {
-      if (zz == (int)z) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = *reinterpret_cast<const f32x4*>(base + (j * 64 + (int)lane) * 4);
+    for (int zz = 1; zz < p.ksplits; ++zz) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] += *reinterpret_cast<const f32x4*>(base + (size_t)zz * 1024 + (j * 64 + (int)lane) * 4);
     }
@@ -1014,8 +1021,10 @@ extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t worksp
     }
     return check_launch("dwconv3x3_kernel");
   }
-  if (d->groups != 1) {
-    set_error("conv: only groups == 1 (dense) and groups == Cin == Cout (depthwise) are built");
+  if (d->groups != 1) {  // grouped: 16 channels per group (RegNetX bottlenecks)
+    if (d->groups * 16 == d->Cin && d->Cin == d->Cout) return launch_gconv3x3_g16(d, Ho, Wo, stream);
+    set_error("conv: groups must be 1 (dense), Cin (depthwise) or Cin/16 (16-channel groups); got %d for Cin=%d",
+              d->groups, d->Cin);
     return SSDK_E_BADARG;
   }
   if (d->Cin <= 4) {  // stem: w is fp32 [Cout][3][3][Cin] with the BN scale folded in

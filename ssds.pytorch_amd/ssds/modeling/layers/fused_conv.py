@@ -50,7 +50,7 @@ def fold_bn(conv, bn):
 
 
 def conv_kind(conv):
-    """'dense' | 'dw' | 'stem' | None (None: not covered by the HIP kernels -> torch, reported)."""
+    """'dense' | 'dw' | 'g16' | 'stem' | None (None: not covered by the HIP kernels -> torch, reported)."""
     k = conv.kernel_size
     if not (k[0] == k[1] and k[0] in (1, 3) and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2)
             and conv.padding == (k[0] // 2, k[0] // 2) and conv.dilation == (1, 1)
@@ -62,6 +62,8 @@ def conv_kind(conv):
         return "dense" if conv.in_channels % 8 == 0 else None
     if conv.groups == conv.in_channels == conv.out_channels and k[0] == 3 and conv.in_channels % 8 == 0:
         return "dw"
+    if conv.in_channels == conv.out_channels == conv.groups * 16 and k[0] == 3:
+        return "g16"  # 16 channels per group (RegNetX bottlenecks): csrc/ssdk_gconv.hip
     return None
 
 
@@ -591,7 +593,7 @@ class ConvPlan(object):
             ho, wo = _out_hw(h, w, pk.k, pk.stride)
             macs = n * ho * wo * pk.cout * (pk.cin // pk.groups) * pk.k * pk.k
             byt = es * (n * (h * w * pk.cin + ho * wo * pk.cout) + pk.cout * (pk.cin // pk.groups) * pk.k * pk.k)
-            kind = "head" if L["nchw"] else ("dw" if pk.groups > 1 else "conv")
+            kind = "head" if L["nchw"] else ("dw" if pk.kind == "dw" else ("gconv" if pk.groups > 1 else "conv"))
             rows.append(dict(name="%s %d>%d k%d s%d @%dx%d" % (kind, pk.cin, pk.cout, pk.k, pk.stride, h, w),
                              flops=2.0 * macs, bytes=float(byt), kind=kind))
         return rows

@@ -130,8 +130,8 @@ def build_ssd_plan(model, x):
 # --------------------------------------------------------------------------------------------------------------
 # ResNet backbones (nets/resnet.py)
 # --------------------------------------------------------------------------------------------------------------
-def _pack(conv, bn, act, dtype):
-    if conv_kind(conv) != "dense":
+def _pack(conv, bn, act, dtype, kinds=("dense",)):
+    if conv_kind(conv) not in kinds:
         raise PlanUnsupported("conv not covered by the HIP kernels: {}".format(conv))
     return ConvPack(conv, bn, act, dtype)
 
@@ -183,15 +183,54 @@ def record_resnet(plan, val, net):
     return outputs
 
 
+def record_regnet(plan, val, net):
+    """RegNetX (nets/regnet.py): 3x3/s2 stem, then bottleneck blocks 1x1 -> grouped 3x3 (16 channels per group,
+    stride s) -> 1x1 whose last conv adds the (projected) skip and applies the ReLU in its epilogue."""
+    from ssds.modeling.nets.regnet import RegNet
+
+    if not isinstance(net, RegNet):
+        raise PlanUnsupported("backbone {} has no planner".format(type(net).__name__))
+    dt = plan.dtype
+    cur = plan.conv(val, _pack(net.stem.conv, net.stem.bn, "relu", dt, kinds=("stem",)))
+    outputs = []
+    for i, stage in enumerate([net.s1, net.s2, net.s3, net.s4]):
+        level = i + 1
+        if level > max(net.outputs):
+            break
+        for blk in stage.children():
+            keep_cur = any(cur is o for o in outputs)
+            skip = cur
+            if blk.proj_block:
+                skip = plan.conv(cur, _pack(blk.proj, blk.bn, "none", dt))
+            f = blk.f
+            a = plan.conv(cur, _pack(f.a, f.a_bn, "relu", dt))
+            b = plan.conv(a, _pack(f.b, f.b_bn, "relu", dt, kinds=("g16", "dense")))
+            plan.release(a)
+            out = plan.conv(b, _pack(f.c, f.c_bn, "relu", dt), residual=skip, res_mode=2)
+            plan.release(b)
+            if skip is not cur:
+                plan.release(skip)
+            if not keep_cur:
+                plan.release(cur)
+            cur = out
+        if level in net.outputs:
+            outputs.append(cur)
+    return outputs
+
+
 def record_backbone(plan, val, net):
-    """Backbone maps of a planned backbone (MobileNet, ResNet) from the image value; PlanUnsupported otherwise."""
+    """Backbone maps of a planned backbone (MobileNet, ResNet, RegNetX) from the image value; PlanUnsupported
+    otherwise."""
     from ssds.modeling.nets.mobilenet import MobileNetEx
+    from ssds.modeling.nets.regnet import RegNet
     from ssds.modeling.nets.resnet import ResNet
 
     if isinstance(net, MobileNetEx):
         return record_mobilenet(plan, val, net)
     if isinstance(net, ResNet):
         return record_resnet(plan, val, net)
+    if isinstance(net, RegNet):
+        return record_regnet(plan, val, net)
     raise PlanUnsupported("backbone {} has no planner".format(type(net).__name__))
 
 

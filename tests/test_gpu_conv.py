@@ -245,7 +245,36 @@ def test_resnet_stem_and_maxpool(layout, h, w, dtype_name):
     assert torch.equal(pooled.float().cpu(), F.max_pool2d(y.float().cpu(), 3, 2, 1)), "maxpool must be exact"
 
 
-@pytest.mark.parametrize("net,outs,depth", [("ResNet18", [3, 4, 5], [128, 256, 512]), ("ResNet50", [4, 5], [1024, 2048])])
+@pytest.mark.parametrize("c,stride,h,w,n", [(64, 1, 20, 24, 2), (128, 2, 33, 31, 3), (288, 1, 7, 9, 2), (672, 2, 14, 14, 1)])
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+def test_grouped_conv_16_per_group(c, stride, h, w, n, dtype_name):
+    """RegNetX bottleneck conv: 3x3, groups = C/16 (+ BN + ReLU) vs torch fp32."""
+    import torch
+    import torch.nn as nn
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    torch.manual_seed(c + stride)
+    conv = nn.Conv2d(c, c, 3, stride, 1, groups=c // 16, bias=False)
+    bn = nn.BatchNorm2d(c)
+    bn.running_mean.normal_(0, 0.2)
+    bn.running_var.uniform_(0.5, 1.5)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_(0, 0.2)
+    conv.weight.data = conv.weight.data.to(dtype).float()
+    x = torch.randn(n, c, h, w).to(dtype)
+    want = _ref(x, conv, bn, "relu")
+    conv, bn = conv.cuda(), bn.cuda()
+    pack = FC.ConvPack(conv, bn, "relu", dtype)
+    assert pack.kind == "g16"
+    y = FC.conv_native(x.cuda(), pack)
+    assert N.last_kernel() == "gconv3x3_g16_kernel"
+    _check(y, want, dtype, "grouped conv")
+
+
+@pytest.mark.parametrize("net,outs,depth", [("ResNet18", [3, 4, 5], [128, 256, 512]), ("ResNet50", [4, 5], [1024, 2048]),
+                                            ("RegNetX008", [2, 3, 4], [128, 288, 672])])
 def test_ssd_on_resnet_plan_matches_torch(net, outs, depth):
     """SSD heads on a ResNet backbone: image -> heads as one recorded plan (stem kernel, maxpool, residual blocks
     with the ReLU after the add) vs the fp32 module."""
