@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--cfg", default=os.path.join(ROOT, "experiments", "cfgs", "ssd_mobilenetv2_512.yml"))
     ap.add_argument("--cpu-sample", type=int, default=4, help="images for the CPU baseline (0 = skip)")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the step as one captured hipGraph")
     ap.add_argument("--layers", type=int, default=0, help="1: add the per-layer table (us, TFLOP/s, GB/s) to the JSON")
     ap.add_argument("--channels-last", type=int, default=int(os.environ.get("SSDK_CHANNELS_LAST", "0")))
     return ap.parse_args()
@@ -88,6 +89,15 @@ def main():
         loc, conf = model(x)
         return decoder(loc, conf, anchors)
 
+    if args.graph:
+        from ssds.utils.graph import GraphedInference
+
+        graphed = GraphedInference(model, decoder, anchors, x)
+        eager_step = step
+
+        def step():  # noqa: F811 -- the timed step is one hipGraphLaunch (the input is the static, resident batch)
+            return graphed(graphed.static_x)
+
     def barrier():
         if world > 1:
             dist.barrier(device_ids=[local_rank])
@@ -95,7 +105,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    N.set_profiling(True)  # event ring: recorded inside the timed region, read back after it
+    N.set_profiling(not args.graph)  # event ring: recorded inside the timed region (not capturable: eager only)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -109,6 +119,12 @@ def main():
 
     # ---- per-kernel times recorded live in the timed region -------------------------------------------
     nprof = min(args.steps, 256)
+    if args.graph:  # per-kernel events cannot be recorded inside a captured graph: a few eager steps afterwards
+        N.set_profiling(True)
+        nprof = 5
+        for _ in range(nprof):
+            eager_step()
+        torch.cuda.synchronize(dev)
     tim = np.array([N.timings_ms(i) for i in range(nprof)], dtype=np.float64)  # [steps, (scan, level, nms)]
     scan_ms, level_ms, nms_ms = tim.mean(0)
     N.set_profiling(False)
@@ -181,7 +197,9 @@ def main():
     }
 
     result = OrderedDict()
-    result["metric"] = "images/sec (fwd+decode+NMS) SSD-MobileNetV2@512"
+    name = "%s-%s@%d" % (cfg.MODEL.SSDS.upper().replace("SSD", "SSD", 1), cfg.MODEL.NETS, H)
+    is_headline = os.path.basename(args.cfg) == "ssd_mobilenetv2_512.yml"
+    result["metric"] = "images/sec (fwd+decode+NMS) " + ("SSD-MobileNetV2@512" if is_headline else name)
     result["value"] = round(n_gpus * B * args.steps / elapsed, 2)
     result["unit"] = "images/sec"
     result["n_gpus"] = n_gpus
@@ -194,15 +212,16 @@ def main():
     result["dtype"] = "bf16"
     result["data"] = "synthetic"
     result["config"] = {
-        "workload": "SSD+MobileNetV2 @512x512 bf16, batch 64 per GPU: backbone+extras+heads forward, "
-                    "decode (thr .01, 300/level, rescore) + DIoU-NMS (.6, 100 dets); random-init weights "
-                    "(reference init), torch.rand images resident in HBM",
+        "workload": ("SSD+MobileNetV2" if is_headline else name) + " @%dx%d bf16, batch %d per GPU: backbone+neck+heads "
+                    "forward, decode (thr .01, 300/level, rescore) + DIoU-NMS (.6, 100 dets); random-init weights "
+                    "(reference init), torch.rand images resident in HBM" % (H, W, B),
         "cfg": os.path.relpath(args.cfg, ROOT),
         "batch_per_gpu": B,
         "global_batch": B * n_gpus,
         "image_size": [H, W],
         "parallelism": "replicas x%d (no collective)" % n_gpus,
         "fused_head_conv": os.environ.get("SSDK_FUSED_CONV", "1") != "0",
+        "hipgraph": bool(args.graph),
         "channels_last": bool(args.channels_last),
     }
     result["roofline"] = roofline

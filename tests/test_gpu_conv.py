@@ -559,3 +559,31 @@ def test_fpn_bifpn_eval_on_device(head, net, outs, depth):
         assert l.shape == a.shape and c.shape == b.shape and l.is_contiguous() and c.is_contiguous()
         assert float((c.float().cpu() - b).abs().max()) < 3e-3
         assert float((l.float().cpu() - a).abs().max()) < 0.05 * max(float(a.abs().max()), 1e-2) + 5e-3
+
+
+def test_hipgraph_captured_inference_matches_eager():
+    """forward + decode + NMS captured once as a hipGraph (BASELINE config 5 mode); replays on new inputs equal
+    the eager pipeline bit for bit."""
+    import torch
+    from collections import OrderedDict
+    from ssds.modeling import nets, ssds
+    from ssds.modeling.layers import box
+    from ssds.modeling.layers.decoder import Decoder
+    from ssds.utils.graph import GraphedInference
+
+    torch.manual_seed(6)
+    fl = [[5, 7, "Conv:S"], [96, 320, 256]]
+    nets_outputs, extras, hd = ssds.SSD.add_extras(fl, [6, 6, 6], 7)
+    model = ssds.SSD(nets.MobileNetV2(outputs=nets_outputs), extras, hd, 7).eval().cuda().to(torch.bfloat16)
+    anchors = OrderedDict((s, box.generate_anchors(s, [1, 2, 0.5], [2.0, 2.828])) for s in (16, 32, 64))
+    dec = Decoder(0.005, 0.6, 50, 100, True, True)
+    x0 = torch.rand(4, 3, 128, 128, device="cuda").to(torch.bfloat16)
+    g = GraphedInference(model, dec, anchors, x0)
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        x = torch.rand(4, 3, 128, 128, device="cuda").to(torch.bfloat16)
+        got = [t.clone() for t in g(x)]
+        with torch.no_grad():
+            want = dec(*model(x), anchors)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
