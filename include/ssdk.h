@@ -199,7 +199,7 @@ typedef struct ssdk_mbconv_desc {
   int32_t N, H, W, Cin, Chid, Cout, stride, residual, dtype;
   int32_t stem; /* 0: x is the NHWC block input.  1 | 2: x is the NCHW | NHWC IMAGE [N,Cin<=3,H,W] and the
                    "expand" conv is the network stem (3x3, stride 2, pad 1, BN, ReLU6; w_expand
-                   [Chid][32] = KRSC taps zero-padded to 32): stem + first depthwise-separable block
+                   [Chid][3][8][4] = (ky, kx zero-padded to 8, ci zero-padded to 4)): stem + first depthwise-separable block
                    (mobilenet.py:78-89, expand_ratio 1) in one launch */
 } ssdk_mbconv_desc;
 int ssdk_mbconv(const ssdk_mbconv_desc* desc, void* stream);

@@ -105,7 +105,9 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   constexpr int NPB = (NFO * 16 * HP + kMbThreads - 1) / kMbThreads;    // Wp pieces per thread
   constexpr int NM_WD = 9 * HP, NM_S = HC / 4, NM_B = HP;               // misc pieces: Wd, se|be, bd
   constexpr int NFH = NFO / 2;                                          // projection n-frags per wave
-  constexpr int NPX = STEM ? (P16 * 9 + kMbThreads - 1) / kMbThreads                      // (pixel, tap) items
+  constexpr int PR = 2 * RW + 1;   // stem mode: rows / columns of the image patch behind the RW x RW stem outputs
+  constexpr int PC = PR + 1;       // LDS row stride of the patch in pixels (even: 16-byte aligned pixel pairs)
+  constexpr int NPX = STEM ? (PR * PR * 3 + kMbThreads - 1) / kMbThreads                  // image elements
                            : (P16 * KSMAX * 4 + kMbThreads - 1) / kMbThreads;             // 16-byte pieces of sX
   static_assert(NFO % 2 == 0, "NFO must be even");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -206,31 +208,28 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
 
   // ---- input tile (+ halo) staging: global -> registers (fetch_x, may run one tile ahead) -> sX (put_x) --
   u32x4 xr[STEM ? 1 : NPX];
-  u16 xs16[STEM ? NPX : 1][3];
+  u16 xs16[STEM ? NPX : 1];
   auto fetch_x = [&](u32 t) {
     int tn, toy0, tox0;
     tile_coords(t, tn, toy0, tox0);
     const int tiy0 = toy0 * S - 1, tix0 = tox0 * S - 1;
     if constexpr (STEM) {
-      // im2col source: item = (region pixel in stem-output coordinates, tap); Cimg 2-byte loads each
+      // the image patch behind the tile's RW x RW stem outputs: (channel, row, column) with columns fastest, so a
+      // wave reads runs of consecutive pixels of one image row (the first version gathered 2 bytes per (pixel, tap)
+      // and fetched 5.7x the image from HBM, profiles/r01_pmc_fetch_size_v4.csv)
       const int Ci = p.Cimg, Hi = p.Himg, Wi = p.Wimg;
       const u16* img = p.x + (size_t)tn * Ci * Hi * Wi;
       const size_t cstride = p.stem == 1 ? (size_t)Hi * Wi : 1, pstride = p.stem == 1 ? 1 : (size_t)Ci;
+      const int py0 = 2 * tiy0 - 1, px0 = 2 * tix0 - 1;
 #pragma unroll
       for (int i = 0; i < NPX; ++i) {
-        const int q = (int)tid + i * kMbThreads;
-        const int pix = q / 9, tap = q % 9;
-        bool ok = false;
-        size_t off = 0;
-        if (pix < P) {
-          const int soy = tiy0 + pix / RW, sox = tix0 + pix % RW;
-          const int iy = 2 * soy + tap / 3 - 1, ix = 2 * sox + tap % 3 - 1;
-          ok = (unsigned)soy < (unsigned)H && (unsigned)sox < (unsigned)W && (unsigned)iy < (unsigned)Hi &&
-               (unsigned)ix < (unsigned)Wi;
-          off = ((size_t)iy * Wi + ix) * pstride;
-        }
-#pragma unroll
-        for (int ci = 0; ci < 3; ++ci) xs16[i][ci] = (ok && ci < Ci) ? img[off + ci * cstride] : (u16)0;
+        const int e = (int)tid + i * kMbThreads;
+        const int ch = e / (PR * PR), rc = e % (PR * PR);
+        const int iy = py0 + rc / PR, ix = px0 + rc % PR;
+        u16 v = 0;
+        if (ch < Ci && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi)
+          v = img[((size_t)iy * Wi + ix) * pstride + ch * cstride];
+        xs16[i] = v;
       }
     } else {
       const u16* xin = p.x + (size_t)tn * H * W * Cin;
@@ -249,20 +248,13 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
     }
   };
   auto put_x = [&]() {
-    if constexpr (STEM) {
-      const int Ci = p.Cimg;
+    if constexpr (STEM) {  // sX = the patch as [row][column (stride PC)][4 channels]; channel 3 / the pad column stay zero
+      u16* patch = reinterpret_cast<u16*>(sX);
 #pragma unroll
       for (int i = 0; i < NPX; ++i) {
-        const int q = (int)tid + i * kMbThreads;
-        const int pix = q / 9, tap = q % 9;
-        if (pix < P16) {  // every byte of every row is written (zeros for padding / outside the image)
-          u16* row = reinterpret_cast<u16*>(sX + (size_t)pix * XS);
-#pragma unroll
-          for (int ci = 0; ci < 3; ++ci)
-            if (ci < Ci) row[tap * Ci + ci] = xs16[i][ci];
-          if (tap == 8)
-            for (int k = 9 * Ci; k < 32; ++k) row[k] = 0;
-        }
+        const int e = (int)tid + i * kMbThreads;
+        const int ch = e / (PR * PR), rc = e % (PR * PR);
+        if (ch < 3) patch[((rc / PR) * PC + rc % PR) * 4 + ch] = xs16[i];
       }
     } else {
 #pragma unroll
@@ -276,6 +268,11 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
 
   const int nchunks = (Chid + HC - 1) / HC;
   u32 tile = blockIdx.x;
+  if constexpr (STEM) {
+    // (+8 pixels: the kx = 3..7 slots of the last row read past the patch; their weights are zero, the data must be finite)
+    for (u32 i = tid; i < (u32)((PR * PC + 8) * 2); i += kMbThreads) reinterpret_cast<u32*>(sX)[i] = 0u;
+    __syncthreads();
+  }
   if constexpr (RESIDENT) {  // every chunk's weights live in LDS for the whole (persistent) workgroup
     for (int c = 0; c < nchunks; ++c) {
       load_w(c * HC);
@@ -354,12 +351,16 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
 #pragma unroll
           for (int jf = 0; jf < NJ; ++jf) e[jf] = f32x4{0.f, 0.f, 0.f, 0.f};
           const unsigned char* xrow = sX + (size_t)(mf * 16 + (int)fr) * XS;
+          int spix = mf * 16 + (int)fr;  // stem mode: k-step = kernel row, a lane's 8 k-values = 2 patch pixels x 4 ch
+          if (spix >= P) spix = 0;
+          const unsigned char* prow = sX + (size_t)(((spix / RW) * 2) * PC + (spix % RW) * 2 + 2 * (int)fg) * 8;
 #pragma unroll
           for (int ks = 0; ks < KSMAX; ++ks) {
             if (ks < KS) {
               const int k = ks * 32 + (int)fg * 8;
               u32x4 xf = {0u, 0u, 0u, 0u};
-              if (k < Cin) xf = *reinterpret_cast<const u32x4*>(xrow + k * 2);
+              if constexpr (STEM) xf = *reinterpret_cast<const u32x4*>(prow + (size_t)ks * PC * 8);
+              else if (k < Cin) xf = *reinterpret_cast<const u32x4*>(xrow + k * 2);
 #pragma unroll
               for (int jf = 0; jf < NJ; ++jf) {
                 u32x4 wv = {0u, 0u, 0u, 0u};
@@ -489,11 +490,11 @@ template <int DT, int S>
 static int launch_mb(const MbParams& p, int ks, int nfo, size_t lds, unsigned grid, hipStream_t stream, bool resident) {
   if (p.stem) {
     if (resident) {
-      if (nfo <= 2) launch_one<DT, S, 2, 1, true, true>(p, lds, grid, stream);
-      else launch_one<DT, S, 4, 1, true, true>(p, lds, grid, stream);
+      if (nfo <= 2) launch_one<DT, S, 2, 3, true, true>(p, lds, grid, stream);
+      else launch_one<DT, S, 4, 3, true, true>(p, lds, grid, stream);
     } else {
-      if (nfo <= 2) launch_one<DT, S, 2, 1, true>(p, lds, grid, stream);
-      else launch_one<DT, S, 4, 1, true>(p, lds, grid, stream);
+      if (nfo <= 2) launch_one<DT, S, 2, 3, true>(p, lds, grid, stream);
+      else launch_one<DT, S, 4, 3, true>(p, lds, grid, stream);
     }
     return check_launch("mbconv_kernel(stem)");
   }
@@ -559,10 +560,10 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   p.Himg = d->H;
   p.Wimg = d->W;
   p.Cimg = d->Cin;
-  if (stem) {  // the block's grid is the stem conv's output (3x3, stride 2, pad 1); K padded to 32
+  if (stem) {  // the block's grid is the stem conv's output (3x3, stride 2, pad 1); K = (ky, kx padded to 8, ci padded to 4)
     p.H = (d->H + 2 - 3) / 2 + 1;
     p.W = (d->W + 2 - 3) / 2 + 1;
-    p.Cin = 32;
+    p.Cin = 96;
   }
   p.Chid = d->Chid;
   p.Cout = d->Cout;
@@ -591,7 +592,7 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
     p.off_sb = p.off_wd + 9 * hc * 2;
     p.wbuf = (p.off_sb + sb_of(hc) + 15) & ~15;
     const int nch = (d->Chid + hc - 1) / hc;
-    resident = env_res && ks_t <= 1 && nfo_inst <= 4 && (size_t)nch * p.wbuf <= 56 * 1024;
+    resident = env_res && (ks_t <= 1 || stem) && nfo_inst <= 4 && (size_t)nch * p.wbuf <= 56 * 1024;
     return (size_t)p16 * p.xs + (size_t)p16 * es + 64 * (size_t)es + (resident ? (size_t)nch : 2) * (size_t)p.wbuf;
   };
   // 64-channel chunks halve the barriers per hidden channel but cost LDS (fewer workgroups per CU); measured on

@@ -196,11 +196,13 @@ class MbPack(object):
             cs, bs, _ = stem_group
             (cd, bd, _), (cp, bp, _) = groups
             scale, bias = fold_bn(cs, bs)
-            w = cs.weight.detach().float().permute(0, 2, 3, 1).reshape(cs.out_channels, -1)  # [Cout][(ky,kx,ci)]
-            wpad = torch.zeros((cs.out_channels, 32), device=w.device, dtype=torch.float32)
-            wpad[:, : w.shape[1]] = w
+            # K layout of the stem GEMM = (ky, kx padded 3 -> 8, ci padded -> 4): a k-step is one kernel row and a
+            # lane's 8 k-values are 2 neighbouring patch pixels x 4 channels (csrc/ssdk_mbconv.hip stem mode)
+            w = cs.weight.detach().float().permute(0, 2, 3, 1)  # [Cout][ky][kx][ci]
+            wpad = torch.zeros((cs.out_channels, 3, 8, 4), device=w.device, dtype=torch.float32)
+            wpad[:, :, :3, : w.shape[3]] = w
             self.e = ConvPack.__new__(ConvPack)
-            self.e.w, self.e.scale, self.e.bias = wpad.to(dtype).contiguous(), scale, bias
+            self.e.w, self.e.scale, self.e.bias = wpad.reshape(cs.out_channels, 96).to(dtype).contiguous(), scale, bias
             self.d = ConvPack(cd, bd, "relu6", dtype)
             self.p = ConvPack(cp, bp, "none", dtype)
             self.cin, self.chid, self.cout = cs.in_channels, cs.out_channels, cp.out_channels
