@@ -46,6 +46,7 @@ struct MbParams {
   // conv on an im2col image of the tile built in LDS (K = 9*Cimg <= 32); H, W are the stem-output grid.
   int stem, Himg, Wimg, Cimg;
   int hc;                    // hidden channels per chunk (32 | 64)
+  int ts;                    // output tile side (8 | 16)
   unsigned long long* dbg;  // SSDK_MB_DBG=1: cycle stamps of workgroup 0 (debug builds of the schedule only)
 };
 
@@ -89,14 +90,19 @@ constexpr int sb_of(int hc) { return hc * 10; }
 // E (expanded) and D (depthwise output) are INTERNAL tensors: they are kept in fp16 whatever the model
 // dtype (values are ReLU6-bounded, fp16 carries 3 more mantissa bits than bf16), so P2 runs on packed
 // fp16 math (v_pk_fma_f16: 2 channels per instruction) and P3 on the f16 MFMA with fp16 projection weights.
-template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = false, int HC = 32>
+template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = false, int HC = 32, int TS = 8>
 __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   constexpr int ES = es_of(HC);
   constexpr int NJ = HC / 16;   // n-frags of the expand GEMM per chunk
   constexpr int KP = HC / 32;   // k-steps of the projection per chunk
   constexpr int NI = HC / 32;   // depthwise items (4 channels of one pixel) per thread
   constexpr int HP = HC / 8;    // 16-byte pieces per HC halves
-  constexpr int RW = 8 * S + (3 - S);          // 10 (s=1) or 17 (s=2) input columns / rows per tile
+  // TS x TS output pixels per workgroup.  16 x 16 (stride-1 blocks on large maps) quarters the phases (barriers,
+  // LDS round trips) per pixel, shrinks the halo overhead of the expand GEMM from 1.56x to 1.27x and lets the
+  // depthwise phase reuse its LDS reads over 1 x 4 pixel strips.
+  static_assert(TS == 8 || (TS == 16 && S == 1 && HC == 32), "16x16 tiles: stride 1, 32-channel chunks");
+  constexpr int OP = TS * TS;                   // output pixels per tile
+  constexpr int RW = TS * S + (3 - S);          // 10 | 18 (s=1) or 17 (s=2) input columns / rows per tile
   constexpr int P = RW * RW;                   // region pixels
   constexpr int MF = (P + 15) / 16;            // m-frags of the expand GEMM
   constexpr int P16 = MF * 16;
@@ -104,7 +110,10 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   constexpr int NPA = (HC * KSMAX * 4 + kMbThreads - 1) / kMbThreads;   // We pieces per thread
   constexpr int NPB = (NFO * 16 * HP + kMbThreads - 1) / kMbThreads;    // Wp pieces per thread
   constexpr int NM_WD = 9 * HP, NM_S = HC / 4, NM_B = HP;               // misc pieces: Wd, se|be, bd
-  constexpr int NFH = NFO / 2;                                          // projection n-frags per wave
+  constexpr int MF3 = OP / 16;                   // pixel fragments of the projection GEMM: 4 | 16
+  constexpr int NSPLIT = MF3 >= kMbWaves ? 1 : kMbWaves / MF3;          // waves sharing one pixel fragment
+  constexpr int MPW = MF3 >= kMbWaves ? MF3 / kMbWaves : 1;             // pixel fragments per wave
+  constexpr int NFH = NFO / NSPLIT;                                     // projection n-frags per wave
   constexpr int PR = 2 * RW + 1;   // stem mode: rows / columns of the image patch behind the RW x RW stem outputs
   constexpr int PC = PR + 1;       // LDS row stride of the patch in pixels (even: 16-byte aligned pixel pairs)
   constexpr int NPX = STEM ? (PR * PR * 3 + kMbThreads - 1) / kMbThreads                  // image elements
@@ -113,9 +122,10 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int XS = p.xs, WES = p.wes;
   unsigned char* sX = smem;                                  // [P16][XS]
-  unsigned char* sE = sX + (size_t)P16 * XS;                 // [P16][ES]
-  unsigned char* sD = sE + (size_t)P16 * ES;                 // [64][ES]
-  unsigned char* sW = sD + 64 * ES;                          // 2 staged weight buffers
+  const size_t sx_bytes = STEM ? (size_t)(((PR * PC + 8) * 8 + 15) & ~15) : (size_t)P16 * XS;  // stem: the image patch
+  unsigned char* sE = sX + sx_bytes;                         // [P16][ES]
+  unsigned char* sD = sE + (size_t)P16 * ES;                 // [OP][ES]
+  unsigned char* sW = sD + OP * ES;                          // 2 staged weight buffers
 
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u32 fr = lane & 15u, fg = lane >> 4;
@@ -125,8 +135,8 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   auto tile_coords = [&](u32 t, int& tn, int& toy0, int& tox0) {
     const int ttx = (int)(t % (u32)p.tiles_x);
     t /= (u32)p.tiles_x;
-    toy0 = (int)(t % (u32)p.tiles_y) * 8;
-    tox0 = ttx * 8;
+    toy0 = (int)(t % (u32)p.tiles_y) * TS;
+    tox0 = ttx * TS;
     tn = (int)(t / (u32)p.tiles_y);
   };
   const int KS = (Cin + 31) / 32;
@@ -287,12 +297,13 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   }
   const u32 d_px = tid >> 3, d_cg = tid & 7u;      // P2 role: output pixel, 4-channel group
   const u32 d_oy = d_px >> 3, d_ox = d_px & 7u;
-  const u32 m_fr = wave & 3u, n_half = wave >> 2;  // P3 role: pixel frag, interleaved half of the n-frags
+  // P3 role: 8x8 tiles: pixel frag wave & 3, interleaved half (wave >> 2) of the n-frags; 16x16: frags 2*wave, 2*wave+1, all n
+  const u32 m_base = NSPLIT == 2 ? (wave & 3u) : wave * (u32)MPW, n_half = NSPLIT == 2 ? (wave >> 2) : 0u;
 
   f32x4 sp4[NFH], bp4[NFH];  // projection BN (loop invariant: loaded once per workgroup)
 #pragma unroll
   for (int jj = 0; jj < NFH; ++jj) {
-    const int co = ((int)n_half + 2 * jj) * 16 + (int)fg * 4;
+    const int co = ((int)n_half + NSPLIT * jj) * 16 + (int)fg * 4;
     sp4[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
     bp4[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (co < Cout) {
@@ -325,9 +336,11 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
       if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) pvalid |= 1u << i;
     }
   }
-  f32x4 yacc[NFH];
+  f32x4 yacc[MPW][NFH];
 #pragma unroll
-  for (int j = 0; j < NFH; ++j) yacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MPW; ++i)
+#pragma unroll
+    for (int j = 0; j < NFH; ++j) yacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
   MB_STAMP();
@@ -343,6 +356,65 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
         sev[jf] = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + (jf * 16 + fg * 4) * 4);
         bev[jf] = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + HC * 4 + (jf * 16 + fg * 4) * 4);
       }
+      if constexpr (TS == 16) {  // (measured: the same restructuring LOSES on the 8x8 stride-2 instances -- VGPRs / occupancy)
+        // 16x16 tiles: 3 m-frags per wave.  Weight fragments are shared by them and loaded once; all operand reads
+        // are issued before the first MFMA and all results are written after the last one, so the three dependent
+        // LDS -> MFMA -> LDS chains overlap instead of running back to back.
+        u32x4 wv[KSMAX][NJ], xf[MFW][KSMAX];
+#pragma unroll
+        for (int ks = 0; ks < KSMAX; ++ks) {
+          const int k = ks * 32 + (int)fg * 8;
+#pragma unroll
+          for (int jf = 0; jf < NJ; ++jf) {
+            wv[ks][jf] = u32x4{0u, 0u, 0u, 0u};
+            if (ks < KS && k < Cin) wv[ks][jf] = *reinterpret_cast<const u32x4*>(wcur + (size_t)(jf * 16 + fr) * WES + k * 2);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < MFW; ++i) {
+          const int mf = (int)wave + kMbWaves * i;
+          int spix = mf * 16 + (int)fr;
+          if (spix >= P) spix = 0;  // also covers mf >= MF: the result is not stored
+          const unsigned char* xrow = sX + (size_t)spix * XS;
+          const unsigned char* prow = sX + (size_t)(((spix / RW) * 2) * PC + (spix % RW) * 2 + 2 * (int)fg) * 8;
+#pragma unroll
+          for (int ks = 0; ks < KSMAX; ++ks) {
+            const int k = ks * 32 + (int)fg * 8;
+            xf[i][ks] = u32x4{0u, 0u, 0u, 0u};
+            if (ks < KS) {
+              if constexpr (STEM) xf[i][ks] = *reinterpret_cast<const u32x4*>(prow + (size_t)ks * PC * 8);
+              else if (k < Cin) xf[i][ks] = *reinterpret_cast<const u32x4*>(xrow + k * 2);
+            }
+          }
+        }
+        f32x4 e[MFW][NJ];
+#pragma unroll
+        for (int i = 0; i < MFW; ++i)
+#pragma unroll
+          for (int jf = 0; jf < NJ; ++jf) {
+            e[i][jf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KSMAX; ++ks)
+              if (ks < KS) e[i][jf] = mb_mfma<DT>(wv[ks][jf], xf[i][ks], e[i][jf]);  // D[hc = fg*4+r][pixel = fr]
+          }
+#pragma unroll
+        for (int i = 0; i < MFW; ++i) {
+          const int mf = (int)wave + kMbWaves * i;
+          if (mf < MF) {
+            const bool ok = (pvalid >> i) & 1u;
+            unsigned char* erow = sE + (size_t)(mf * 16 + (int)fr) * ES;
+#pragma unroll
+            for (int jf = 0; jf < NJ; ++jf) {
+              uint2 o = make_uint2(0u, 0u);
+              if (ok) {
+                o.x = pk_relu6_f16(fmaf(e[i][jf][0], sev[jf][0], bev[jf][0]), fmaf(e[i][jf][1], sev[jf][1], bev[jf][1]));
+                o.y = pk_relu6_f16(fmaf(e[i][jf][2], sev[jf][2], bev[jf][2]), fmaf(e[i][jf][3], sev[jf][3], bev[jf][3]));
+              }
+              *reinterpret_cast<uint2*>(erow + (jf * 16 + fg * 4) * 2) = o;
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < MFW; ++i) {
         const int mf = (int)wave + kMbWaves * i;
@@ -382,12 +454,13 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
           }
         }
       }
+      }
     }
     MB_STAMP();
     __syncthreads();
     MB_STAMP();
     // ---- P2: depthwise 3x3 stride S on the chunk, packed fp16 (4 channels per lane) -> sD ----------------
-    {
+    if constexpr (TS == 8) {
       const h2 zero = {(_Float16)0.f, (_Float16)0.f}, six = {(_Float16)6.f, (_Float16)6.f};
       h2 acc0[NI], acc1[NI];
 #pragma unroll
@@ -415,6 +488,40 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
         *reinterpret_cast<uint2*>(sD + (size_t)d_px * ES + cg * 8) =
             make_uint2(__builtin_bit_cast(u32, v0), __builtin_bit_cast(u32, v1));
       }
+    } else {
+      // 16x16 tile: a lane owns a 1 x 4 strip of pixels x 4 channels; each of the 3 input rows is 6 LDS reads that
+      // feed 12 taps (the 8x8 mapping reads 9 vectors per pixel): 2.7x less LDS traffic in the phase that is
+      // closest to its LDS-bandwidth bound
+      const h2 zero = {(_Float16)0.f, (_Float16)0.f}, six = {(_Float16)6.f, (_Float16)6.f};
+      const u32 strip = tid >> 3, cg = tid & 7u;
+      const u32 srow = strip >> 2, scol = (strip & 3u) * 4u;
+      h2 a0[4], a1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a0[j] = a1[j] = zero;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const unsigned char* erow = sE + (size_t)((srow + ky) * RW + scol) * ES + cg * 8;
+        uint2 ev[6];
+#pragma unroll
+        for (int cc = 0; cc < 6; ++cc) ev[cc] = *reinterpret_cast<const uint2*>(erow + (size_t)cc * ES);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const uint2 wv = *reinterpret_cast<const uint2*>(wcur + p.off_wd + (ky * 3 + kx) * (HC * 2) + cg * 8);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            a0[j] = __builtin_elementwise_fma(as_h2(ev[j + kx].x), as_h2(wv.x), a0[j]);
+            a1[j] = __builtin_elementwise_fma(as_h2(ev[j + kx].y), as_h2(wv.y), a1[j]);
+          }
+        }
+      }
+      const uint2 bv = *reinterpret_cast<const uint2*>(wcur + p.off_sb + HC * 8 + cg * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const h2 v0 = __builtin_elementwise_min(__builtin_elementwise_max(a0[j] + as_h2(bv.x), zero), six);
+        const h2 v1 = __builtin_elementwise_min(__builtin_elementwise_max(a1[j] + as_h2(bv.y), zero), six);
+        *reinterpret_cast<uint2*>(sD + (size_t)(srow * TS + scol + j) * ES + cg * 8) =
+            make_uint2(__builtin_bit_cast(u32, v0), __builtin_bit_cast(u32, v1));
+      }
     }
     if constexpr (!RESIDENT)
       if (c + 1 < nchunks) store_w((c + 1) & 1);  // visible to the next chunk's P1 after the barrier below
@@ -422,18 +529,19 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
     __syncthreads();
     MB_STAMP();
     // ---- P3: project: wave (m_fr, n_half) owns pixels [16 m_fr, +16) x n-frags n_half, n_half+2, ... ----
-    {
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi) {
       u32x4 df[KP];
 #pragma unroll
       for (int kp = 0; kp < KP; ++kp)
-        df[kp] = *reinterpret_cast<const u32x4*>(sD + (size_t)(m_fr * 16 + fr) * ES + kp * 64 + fg * 16);
+        df[kp] = *reinterpret_cast<const u32x4*>(sD + (size_t)((m_base + mi) * 16 + fr) * ES + kp * 64 + fg * 16);
 #pragma unroll
       for (int jj = 0; jj < NFH; ++jj) {
-        const int j = (int)n_half + 2 * jj;
+        const int j = (int)n_half + NSPLIT * jj;
 #pragma unroll
         for (int kp = 0; kp < KP; ++kp) {
           const u32x4 wf = *reinterpret_cast<const u32x4*>(wcur + p.off_wp + (size_t)(j * 16 + fr) * ES + kp * 64 + fg * 16);
-          yacc[jj] = mb_mfma<SSDK_F16>(wf, df[kp], yacc[jj]);  // D[co = fg*4+r][px = fr]
+          yacc[mi][jj] = mb_mfma<SSDK_F16>(wf, df[kp], yacc[mi][jj]);  // D[co = fg*4+r][px = fr]
         }
       }
     }
@@ -444,25 +552,28 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
 
   MB_STAMP();
   // ---- epilogue -------------------------------------------------------------------------------------
-  const int q = (int)m_fr * 16 + (int)fr;  // output pixel inside the tile
-  const int oy = oy0 + (q >> 3), ox = ox0 + (q & 7);
-  if (oy < p.Ho && ox < p.Wo) {
-    u16* yrow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * Cout;
-    const unsigned char* xres = sX + (size_t)(((q >> 3) * S + 1) * RW + (q & 7) * S + 1) * XS;
 #pragma unroll
-    for (int jj = 0; jj < NFH; ++jj) {
-      const int co = ((int)n_half + 2 * jj) * 16 + (int)fg * 4;
-      if (co < Cout) {  // Cout is a multiple of 8, so 4-channel groups are all-or-nothing
-        u32 h[4];
+  for (int mi = 0; mi < MPW; ++mi) {
+    const int q = (int)(m_base + mi) * 16 + (int)fr;  // output pixel inside the tile
+    const int oy = oy0 + q / TS, ox = ox0 + q % TS;
+    if (oy < p.Ho && ox < p.Wo) {
+      u16* yrow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * Cout;
+      const unsigned char* xres = sX + (size_t)(((q / TS) * S + 1) * RW + (q % TS) * S + 1) * XS;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = mb_to16<DT>(fmaf(yacc[jj][r], sp4[jj][r], bp4[jj][r]));
-        if (p.residual) {
-          const uint2 xv = *reinterpret_cast<const uint2*>(xres + co * 2);
-          const u32 xr[4] = {xv.x & 0xffffu, xv.x >> 16, xv.y & 0xffffu, xv.y >> 16};
+      for (int jj = 0; jj < NFH; ++jj) {
+        const int co = ((int)n_half + NSPLIT * jj) * 16 + (int)fg * 4;
+        if (co < Cout) {  // Cout is a multiple of 8, so 4-channel groups are all-or-nothing
+          u32 h[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = mb_to16<DT>(mb_from16<DT>(h[r]) + mb_from16<DT>(xr[r]));
+          for (int r = 0; r < 4; ++r) h[r] = mb_to16<DT>(fmaf(yacc[mi][jj][r], sp4[jj][r], bp4[jj][r]));
+          if (p.residual) {
+            const uint2 xv = *reinterpret_cast<const uint2*>(xres + co * 2);
+            const u32 xr[4] = {xv.x & 0xffffu, xv.x >> 16, xv.y & 0xffffu, xv.y >> 16};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = mb_to16<DT>(mb_from16<DT>(h[r]) + mb_from16<DT>(xr[r]));
+          }
+          *reinterpret_cast<uint2*>(yrow + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
         }
-        *reinterpret_cast<uint2*>(yrow + co) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
       }
     }
   }
@@ -473,6 +584,14 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
 
 template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = false>
 static void launch_one(const MbParams& p, size_t lds, unsigned grid, hipStream_t stream) {
+  if constexpr (S == 1 && KSMAX <= 3 && NFO <= 4) {  // the instantiations that exist with 16x16 tiles
+    if (p.ts == 16) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 32, 16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 32, 16>), dim3(grid), dim3(kMbThreads), lds, stream, p);
+      return;
+    }
+  }
   if (p.hc == 64) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 64>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -570,11 +689,19 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   p.Ho = (p.H + 2 - 3) / d->stride + 1;
   p.Wo = (p.W + 2 - 3) / d->stride + 1;
   p.residual = d->residual;
-  p.tiles_x = (p.Wo + 7) / 8;
-  p.tiles_y = (p.Ho + 7) / 8;
+  // 16x16 output tiles for stride-1 blocks with few channels on maps large enough to still fill the chip
+  static const int env_ts = getenv("SSDK_MB_TS") ? atoi(getenv("SSDK_MB_TS")) : 0;
+  {
+    const int nfo16 = (d->Cout + 15) / 16, ks16 = ((stem ? 96 : d->Cin) + 31) / 32;
+    const long tiles16 = (long)d->N * ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
+    const bool can16 = d->stride == 1 && nfo16 <= 4 && (stem || ks16 <= 1);
+    p.ts = (can16 && env_ts != 8 && (tiles16 >= 512 || env_ts == 16)) ? 16 : 8;
+  }
+  p.tiles_x = (p.Wo + p.ts - 1) / p.ts;
+  p.tiles_y = (p.Ho + p.ts - 1) / p.ts;
   const int cpr = p.Cin / 8;
   p.xs = p.Cin * 2 + ((cpr % 2 == 0) ? 16 : 0);  // odd number of 16-byte slots per row
-  const int rw = d->stride == 1 ? 10 : 17;
+  const int rw = p.ts * d->stride + (3 - d->stride);
   const int p16 = ((rw * rw + 15) / 16) * 16;
   const int nfo_t = (d->Cout + 15) / 16;
   const int nfo_inst = nfo_t <= 2 ? 2 : nfo_t <= 4 ? 4 : nfo_t <= 6 ? 6 : nfo_t <= 10 ? 10 : 20;
@@ -593,7 +720,9 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
     p.wbuf = (p.off_sb + sb_of(hc) + 15) & ~15;
     const int nch = (d->Chid + hc - 1) / hc;
     resident = env_res && (ks_t <= 1 || stem) && nfo_inst <= 4 && (size_t)nch * p.wbuf <= 56 * 1024;
-    return (size_t)p16 * p.xs + (size_t)p16 * es + 64 * (size_t)es + (resident ? (size_t)nch : 2) * (size_t)p.wbuf;
+    const int pr = 2 * rw + 1;
+    const size_t sx = stem ? (size_t)(((pr * (pr + 1) + 8) * 8 + 15) & ~15) : (size_t)p16 * p.xs;
+    return sx + (size_t)p16 * es + (size_t)(p.ts * p.ts) * es + (resident ? (size_t)nch : 2) * (size_t)p.wbuf;
   };
   // 64-channel chunks halve the barriers per hidden channel but cost LDS (fewer workgroups per CU); measured on
   // SSD-MobileNetV2@512 batch 64 they LOSE 13 % end to end (forward 2.93 vs 2.55 ms), so 32 is the default and
@@ -602,8 +731,16 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   {
     (void)tiles_total;
     const size_t l64 = layout(64);
-    const int hc = (env_hc == 64 && l64 <= 160 * 1024) ? 64 : 32;
+    const int hc = (env_hc == 64 && p.ts == 8 && l64 <= 160 * 1024) ? 64 : 32;
     lds = layout(hc);
+    if (p.ts == 16 && resident && lds > 80 * 1024) {  // two workgroups per CU beat resident weights
+      const int nch = (d->Chid + hc - 1) / hc;
+      const size_t l2 = lds - (size_t)nch * p.wbuf + 2 * (size_t)p.wbuf;
+      if (l2 <= 80 * 1024) {
+        resident = false;
+        lds = l2;
+      }
+    }
   }
   if (lds > 160 * 1024) {
     set_error("mbconv: tile needs %zu bytes of LDS", lds);
@@ -644,8 +781,8 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
     unsigned long long h[64];
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpy(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[mbconv dbg] Cin=%d Chid=%d Cout=%d s=%d stem=%d res=%d grid=%u lds=%zu :", d->Cin, d->Chid,
-            d->Cout, d->stride, p.stem, (int)resident, grid, lds);
+    fprintf(stderr, "[mbconv dbg] Cin=%d Chid=%d Cout=%d s=%d stem=%d res=%d ts=%d tiles=%dx%d grid=%u lds=%zu :", d->Cin,
+            d->Chid, d->Cout, d->stride, p.stem, (int)resident, p.ts, p.tiles_x, p.tiles_y, grid, lds);
     for (int i = 1; i < 60 && h[i]; ++i) fprintf(stderr, " %llu", h[i] - h[i - 1]);
     fprintf(stderr, "\n");
   }
