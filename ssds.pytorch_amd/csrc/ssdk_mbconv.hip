@@ -724,14 +724,15 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
     const size_t sx = stem ? (size_t)(((pr * (pr + 1) + 8) * 8 + 15) & ~15) : (size_t)p16 * p.xs;
     return sx + (size_t)p16 * es + (size_t)(p.ts * p.ts) * es + (resident ? (size_t)nch : 2) * (size_t)p.wbuf;
   };
-  // 64-channel chunks halve the barriers per hidden channel but cost LDS (fewer workgroups per CU); measured on
-  // SSD-MobileNetV2@512 batch 64 they LOSE 13 % end to end (forward 2.93 vs 2.55 ms), so 32 is the default and
-  // SSDK_MB_HC=64 remains as an A/B switch.
+  // SSDK_MB_HC = 32 | 64 forces the chunk width (A/B switch); 0 = the per-block rule below.
   size_t lds;
   {
     (void)tiles_total;
     const size_t l64 = layout(64);
-    const int hc = (env_hc == 64 && p.ts == 8 && l64 <= 160 * 1024) ? 64 : 32;
+    // 64-channel chunks halve the phases per hidden channel but cost LDS (occupancy): measured per block on
+    // SSD-MobileNetV2@512 they win from Cin = 96 on (long chunk loops, one workgroup per CU anyway) and lose below
+    const bool want64 = env_hc == 64 || (env_hc == 0 && !stem && p.Cin >= 96);
+    const int hc = (want64 && p.ts == 8 && l64 <= 160 * 1024) ? 64 : 32;
     lds = layout(hc);
     if (p.ts == 16 && resident && lds > 80 * 1024) {  // two workgroups per CU beat resident weights
       const int nch = (d->Chid + hc - 1) / hc;
