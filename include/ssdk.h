@@ -50,7 +50,7 @@ enum {
   SSDK_E_NODEVICE = -4   /* no HIP device / wrong architecture                    */
 };
 
-typedef enum { SSDK_F32 = 0, SSDK_BF16 = 1, SSDK_F16 = 2 } ssdk_dtype;
+typedef enum { SSDK_F32 = 0, SSDK_BF16 = 1, SSDK_F16 = 2, SSDK_U8 = 3 /* ssdk_preprocess source only */ } ssdk_dtype;
 typedef enum {
   SSDK_ACT_NONE = 0,
   SSDK_ACT_RELU = 1,
@@ -221,6 +221,14 @@ typedef struct ssdk_fuse_desc {
   int32_t dtype;
 } ssdk_fuse_desc;
 int ssdk_fuse(const ssdk_fuse_desc* desc, void* stream);
+
+/* Detector front door (SSDDetector.__call__, ssds.py:47-57): transpose + `(x - mean) / std` + cast in one pass.
+ *   x  raw image batch on the device: [N,H,W,C] (src_layout NHWC = 1) or [N,C,H,W] (NCHW = 0), C <= 4,
+ *      src_dtype SSDK_U8 | SSDK_F32 | SSDK_BF16 | SSDK_F16
+ *   mean, std  HOST fp32 [C];   y  [N,C,H,W] of dst_dtype (SSDK_F32 | SSDK_BF16 | SSDK_F16)
+ * fp32 arithmetic in the reference's order (subtract, divide), one rounding to dst_dtype. */
+int ssdk_preprocess(const void* x, int src_dtype, int src_layout, int N, int H, int W, int C, const float* mean,
+                    const float* std, void* y, int dst_dtype, void* stream);
 
 /* ResNet stem (nets/resnet.py:41-46): 7x7 / stride 2 / pad 3 convolution on the 3-channel image + folded BN +
  * activation -> NHWC, and the 3x3 / stride 2 / pad 1 max pooling (NHWC -> NHWC, -inf padding like torch).

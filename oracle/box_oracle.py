@@ -460,3 +460,18 @@ def make_anchors(strides, ratios, scales):
     return OrderedDict(
         (strides[i], generate_anchors(strides[i], ratios[i], scales[i])) for i in range(len(strides))
     )
+
+
+# --------------------------------------------------------------------------- #
+# detector front door (ssds/ssds.py:47-57)
+# --------------------------------------------------------------------------- #
+def preprocess(imgs, mean, std):
+    """HWC -> CHW (when ``shape[3] == 3``), float32, ``(x - mean) / std`` in that order -> fp32 [N,C,H,W]."""
+    imgs = np.asarray(imgs)
+    if imgs.shape[3] == 3:  # ssds.py:53-54
+        imgs = imgs.transpose(0, 3, 1, 2)
+    x = imgs.astype(F32)
+    c = x.shape[1]
+    m = np.broadcast_to(np.asarray(mean, F32).reshape(-1), (c,)).reshape(1, c, 1, 1)
+    s = np.broadcast_to(np.asarray(std, F32).reshape(-1), (c,)).reshape(1, c, 1, 1)
+    return ((x - m) / s).astype(F32)

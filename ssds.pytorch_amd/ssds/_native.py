@@ -24,6 +24,7 @@ MAX_GT = 256
 F32, BF16, F16 = 0, 1, 2
 ACT = {"none": 0, "relu": 1, "relu6": 2, "silu": 3, "sigmoid": 4}
 _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+U8 = 3  # ssdk_preprocess source only
 
 
 class Level(ctypes.Structure):
@@ -102,6 +103,8 @@ def _load():
     lib.ssdk_last_kernel.restype = c.c_char_p
     lib.ssdk_fuse.argtypes = [c.POINTER(FuseDesc), vp]
     lib.ssdk_fuse.restype = i32
+    lib.ssdk_preprocess.argtypes = [vp, i32, i32, i32, i32, i32, i32, c.POINTER(f32), c.POINTER(f32), vp, i32, vp]
+    lib.ssdk_preprocess.restype = i32
     lib.ssdk_conv_stem7.argtypes = [c.POINTER(StemDesc), vp]
     lib.ssdk_conv_stem7.restype = i32
     lib.ssdk_maxpool3x3s2.argtypes = [c.POINTER(PoolDesc), vp]
@@ -148,7 +151,7 @@ lib = _load()
 EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_profiling", "ssdk_get_op_timings", "ssdk_device_info", "ssdk_generate_anchors",
            "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
-           "ssdk_match_targets_by_scale", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_fuse", "ssdk_conv_stem7", "ssdk_maxpool3x3s2", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
+           "ssdk_match_targets_by_scale", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_fuse", "ssdk_preprocess", "ssdk_conv_stem7", "ssdk_maxpool3x3s2", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 
 
 def op_timings():

@@ -1,10 +1,37 @@
 """``SSDDetector`` -- the inference entry point (reference ``ssds/ssds.py:7-68``): cfg file ->
 model + anchors + decoder; numpy image(s) in, numpy detections out."""
+import ctypes
+
 import numpy as np
 import torch
 
+from . import _native as N
 from .core import checkpoint, config
 from .modeling import model_builder
+
+
+def preprocess(imgs, mean, std, dtype=torch.bfloat16):
+    """Raw image batch on a HIP device -> normalised [N,C,H,W] ``dtype`` tensor in ONE launch
+    (``ssdk_preprocess``): transpose (if NHWC), ``(x - mean) / std`` in fp32 in the reference's order
+    (ssds.py:55), one rounding.  imgs: uint8 / float32 / bf16 / f16, [N,H,W,C] or [N,C,H,W] with C <= 4 (NHWC is
+    recognised like the reference does, ``shape[3] == 3``, ssds.py:53); mean / std: scalars or per-channel lists."""
+    N.require_device(imgs, "preprocess")
+    nhwc = imgs.shape[3] == 3
+    imgs = imgs.contiguous()
+    n = int(imgs.shape[0])
+    h, w, c = (int(v) for v in (imgs.shape[1:] if nhwc else (imgs.shape[2], imgs.shape[3], imgs.shape[1])))
+    src = N.U8 if imgs.dtype == torch.uint8 else N.dtype_code(imgs)
+
+    def vec(v):
+        v = [float(v)] * c if not isinstance(v, (list, tuple)) else [float(t) for t in v]
+        return (ctypes.c_float * c)(*v)
+
+    y = torch.empty((n, c, h, w), device=imgs.device, dtype=dtype)
+    with torch.cuda.device(imgs.device):
+        rc = N.lib.ssdk_preprocess(imgs.data_ptr(), src, N.NHWC if nhwc else N.NCHW, n, h, w, c, vec(mean), vec(std),
+                                   y.data_ptr(), N._DTYPES[dtype], N.stream_ptr(imgs.device))
+    N.check(rc, "preprocess")
+    return y
 
 
 class SSDDetector(object):
@@ -45,10 +72,10 @@ class SSDDetector(object):
             pick1st = True
         if len(imgs.shape) != 4:
             raise AssertionError("image dims has to be 3 or 4")
-        if imgs.shape[3] == 3:
-            imgs = imgs.transpose(0, 3, 1, 2)
-        x = torch.from_numpy(np.ascontiguousarray(imgs)).to(self.device, torch.float32)
-        x = ((x - self.mean) / self.std).to(self.dtype)
+        if imgs.dtype not in (np.uint8, np.float32, np.float16):
+            imgs = imgs.astype(np.float32)  # what the reference's torch.Tensor(imgs) does (ssds.py:54)
+        raw = torch.from_numpy(np.ascontiguousarray(imgs)).to(self.device)  # raw upload (uint8: 1/4 of the fp32 bytes)
+        x = preprocess(raw, self.mean, self.std, self.dtype)  # transpose + normalise + cast: one launch
         loc, conf = self.model(x)
         detections = self.decoder(loc, conf, self.anchors)
         out_scores, out_boxes, out_classes = (d.cpu().numpy() for d in detections)  # the one D2H copy

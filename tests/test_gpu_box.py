@@ -297,3 +297,21 @@ def test_full_size_ssd512_bf16_properties_and_sampled_oracle():
         np.testing.assert_array_equal(cn[img:img + 1], w[2])
         np.testing.assert_allclose(bn[img:img + 1], w[1], atol=BOX_ATOL, rtol=0)
         np.testing.assert_allclose(sn[img:img + 1], w[0], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("src", ["u8_nhwc", "u8_nchw", "f32_nhwc", "f32_nchw"])
+@pytest.mark.parametrize("dst", ["float32", "bfloat16", "float16"])
+def test_preprocess_matches_reference_expression(src, dst):
+    """ssdk_preprocess == torch.Tensor(imgs) -> (x - mean) / std -> .to(dtype) (ssds.py:53-55), bit for bit."""
+    import torch
+    from ssds.ssds import preprocess
+
+    rs = np.random.RandomState(5)
+    n, h, w = 3, 37, 53  # odd width: partial 8-pixel groups
+    shape = (n, h, w, 3) if src.endswith("nhwc") else (n, 3, h, w)
+    raw = rs.randint(0, 256, shape).astype(np.uint8) if src.startswith("u8") else (rs.rand(*shape) * 255).astype(np.float32)
+    for mean, std in ((0, 255), ([123.675, 116.28, 103.53], [58.395, 57.12, 57.375])):
+        want = torch.from_numpy(O.preprocess(raw, mean, std)).to(getattr(torch, dst))
+        got = preprocess(torch.from_numpy(raw).cuda(), mean, std, getattr(torch, dst))
+        assert got.shape == want.shape and got.is_contiguous()
+        assert torch.equal(got.cpu(), want)

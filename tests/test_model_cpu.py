@@ -123,3 +123,31 @@ def test_checkpoint_round_trip(tmp_path):
     for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert torch.equal(va, vb), k
     assert checkpoint.resume_checkpoint(b, str(tmp_path / "missing.pth"), "") is False
+
+
+def test_export_sidecar_has_the_reference_layout(tmp_path):
+    """reference export.py:94-106: keys, value layout (flattened [A*4] anchors per level, level order)."""
+    import json
+    from collections import OrderedDict
+
+    import torch
+    from ssds.core import config
+    from ssds.utils import export as E
+    from oracle import box_oracle as O
+
+    config.reset_cfg()
+    cfg = config.cfg_from_file(os.path.join(ROOT, "experiments", "cfgs", "ssd_mobilenetv2_300.yml"))
+    strides = [15, 30, 60, 100, 150, 300]
+    anchors = OrderedDict((s, torch.from_numpy(O.generate_anchors(s, [1, 2, 0.5], [2.0, 2.828]))) for s in strides)
+    model = torch.nn.Linear(2, 2)
+    jpath, ppath = E.save_export(model, cfg, anchors, str(tmp_path / "net"))
+    p = json.load(open(jpath))
+    assert list(p) == ["image_size", "score", "iou", "max_detects", "max_detects_per_level", "rescore", "use_diou",
+                       "NHWC", "anchors"]
+    assert p["image_size"] == [300, 300] and p["score"] == 0.01 and p["iou"] == 0.6 and p["max_detects"] == 100
+    assert len(p["anchors"]) == 6 and all(len(a) == 24 for a in p["anchors"])
+    assert p["anchors"][0] == anchors[15].reshape(-1).tolist()
+    assert set(torch.load(ppath)) == {"weight", "bias"}
+    dec, back = E.decoder_from_params(p)
+    assert list(back) == strides and all(torch.equal(back[s], anchors[s]) for s in strides)
+    assert dec.top_n == 100 and dec.top_n_per_level == 300 and dec.use_diou and dec.rescore

@@ -177,3 +177,14 @@ def test_match_kat_layout():
     np.testing.assert_array_equal(dp[0, 1, 0], 0)
     assert ct[0, 0, :, 1, 2].argmax() == 5 and ct[0, 0, :, 1, 2].sum() == 1
     np.testing.assert_array_equal(bt[0, 0, :, 1, 2], 0)
+
+
+def test_preprocess_oracle_matches_reference_expression():
+    """The oracle's front-door restatement against the literal reference expression in torch (ssds.py:53-55)."""
+    import torch
+
+    rs = np.random.RandomState(2)
+    imgs = rs.randint(0, 256, (2, 9, 7, 3)).astype(np.uint8)
+    t = torch.Tensor(imgs.transpose(0, 3, 1, 2))
+    np.testing.assert_array_equal(O.preprocess(imgs, 0, 255), ((t - 0) / 255).numpy())
+    np.testing.assert_array_equal(O.preprocess(imgs.transpose(0, 3, 1, 2), 3.0, 2.0), ((t - 3.0) / 2.0).numpy())
