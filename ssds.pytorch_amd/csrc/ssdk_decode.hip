@@ -21,7 +21,8 @@ namespace ssdk {
 
 constexpr int kScanThreads = 256;
 constexpr u32 kCap = 4096;         // LDS candidate slots per workgroup
-constexpr int kPrefetch = 4;       // 16-byte loads in flight per lane
+static_assert(kCap == kStreamCap, "stream buffers are kStreamCap keys");
+constexpr int kPrefetch = 4;       // 16-byte loads in flight per lane (8 measured the same)
 
 struct ScanLevel {
   const void* cls;
@@ -96,20 +97,23 @@ __device__ __forceinline__ void scan_vec(const u32x4& v, u32 idx0, u32 n, float 
   float sv[VEC];
   scan_flags<DT, 0>(v, idx0, n, cut, cut_idx, pmask, sv);
   if (__ballot(pmask != 0u) == 0ull) return;  // nothing in this wave beats the cut (the common case later on)
+  // exclusive prefix of the per-lane counts (0..8) without a shuffle chain: one ballot per count bit, the lanes
+  // below me that have the bit set (mbcnt) weigh 2^bit.  (The first version ran a 6-step __shfl_up scan = six
+  // dependent ds_bpermute round trips per 16-byte vector.)
   const u32 cnt = (u32)__popc(pmask);
-  u32 incl = cnt;
-  const u32 lane = lane_id();
+  u32 excl = 0, total = 0;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const u32 y = __shfl_up(incl, d);
-    if ((int)lane >= d) incl += y;
+  for (int b = 0; b < 4; ++b) {
+    const u64 mb = __ballot((cnt >> b) & 1u);
+    excl += mbcnt(mb) << b;
+    total += (u32)__popcll(mb) << b;
   }
   u32 base = 0;
-  if (lane == 63) {  // incl == wave total
-    base = atomicAdd(&ctl->cnt, incl);
-    if (base <= limit && base + incl > limit) ctl->flag[tile & 1u] = tile + 1u;  // the unique crosser
+  if (lane_id() == 0) {
+    base = atomicAdd(&ctl->cnt, total);
+    if (base <= limit && base + total > limit) ctl->flag[tile & 1u] = tile + 1u;  // the unique crosser
   }
-  base = __shfl(base, 63) + (incl - cnt);
+  base = (u32)__builtin_amdgcn_readfirstlane((int)base) + excl;
 #pragma unroll
   for (int e = 0; e < VEC; ++e)
     if ((pmask >> e) & 1u) buf[base + (u32)__popc(pmask & ((1u << e) - 1u))] = make_key(sv[e], idx0 + (u32)e);

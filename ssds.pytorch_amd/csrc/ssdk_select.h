@@ -47,8 +47,12 @@ __device__ __forceinline__ u32 wg_incl_suffix_sum(u32 v, u32* wsum) {
   return x + add;
 }
 
+// approx_max > 0 (intermediate prunes of a stream): stop after the FIRST radix pass when the bin holding the K-th
+// key plus everything above it is at most approx_max keys, and return the bin's lowest possible key: pruning with
+// `key >= T` then keeps a superset of the top K (K .. approx_max keys) at a third of the cost -- the ties inside the
+// bin (bf16 scores: hundreds per value) are only resolved by the exact select at the end of the stream.
 template <int NT>
-__device__ u64 wg_select_kth(const u64* buf, u32 n, u32 K, SelScratch* s) {
+__device__ u64 wg_select_kth(const u64* buf, u32 n, u32 K, SelScratch* s, u32 approx_max = 0) {
   const u32 tid = threadIdx.x, lane = tid & 63u;
   constexpr int BPT = 1024 / NT;
   if (tid == 0) {
@@ -132,8 +136,8 @@ __device__ u64 wg_select_kth(const u64* buf, u32 n, u32 K, SelScratch* s) {
     const u64 above_top = (top == 63) ? 0ull : (~0ull << (top + 1));
     pfx_val = (common & above_top) | ((u64)bin << shift);
     pfx_mask = (shift == 0) ? ~0ull : (~0ull << shift);
-    if (cb == want) {  // the whole bin is selected; T = smallest possible key of the bin
-      T = pfx_val;
+    if (cb == want || (approx_max && pass == 0 && (K - want) + cb <= approx_max)) {
+      T = pfx_val;  // the whole bin is selected (or kept: approximate prune); T = smallest possible key of the bin
       break;
     }
     if (cb <= kRankMax) {  // resolve the remaining candidates by rank counting
@@ -178,6 +182,26 @@ __device__ void wg_compact_ge(u64* buf, u32 n, u64 T, u32 K, u64* sel, SelScratc
   __syncthreads();
 }
 
+// keep every key >= T at the front of buf, in place: each thread first pulls its (<= PER) keys into registers, so
+// nobody overwrites a key that has not been read yet.  Returns the number kept (n <= PER * NT).
+template <int NT, int PER>
+__device__ u32 wg_compact_ge_inplace(u64* buf, u32 n, u64 T, SelScratch* s) {
+  const u32 tid = threadIdx.x;
+  u64 r[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const u32 i = tid + (u32)j * NT;
+    r[j] = i < n ? buf[i] : 0ull;
+  }
+  if (tid == 0) s->sel_cnt = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < PER; ++j)
+    if (r[j] >= T && r[j] != 0ull) buf[atomicAdd(&s->sel_cnt, 1u)] = r[j];
+  __syncthreads();
+  return s->sel_cnt;
+}
+
 template <int NT>
 __device__ void wg_bitonic_sort_desc(u64* a, u32 M) {  // M power of two
   const u32 tid = threadIdx.x;
@@ -199,6 +223,8 @@ __device__ void wg_bitonic_sort_desc(u64* a, u32 M) {  // M power of two
 }
 
 // ---- streaming accumulator --------------------------------------------------------------------
+constexpr u32 kStreamCap = 4096;    // LDS key slots of a stream (== kCap of the kernels that use it)
+constexpr u32 kApproxKeep = 1024;   // an intermediate prune may keep up to this many keys
 struct StreamCtl {  // LDS
   u32 cnt;
   u32 flag[2];
@@ -230,9 +256,10 @@ __device__ __forceinline__ bool stream_finish_tile(u64* buf, u64* sel, SelScratc
   __syncthreads();
   if (c->flag[tile & 1u] != tile + 1u) return false;
   const u32 n = c->cnt;
-  const u64 T = wg_select_kth<NT>(buf, n, K, s);
-  wg_compact_ge<NT>(buf, n, T, K, sel, s);
-  if (threadIdx.x == 0) c->cnt = K;
+  (void)sel;
+  const u64 T = wg_select_kth<NT>(buf, n, K, s, kApproxKeep);  // superset prune: K .. kApproxKeep keys survive
+  const u32 kept = wg_compact_ge_inplace<NT, kStreamCap / NT>(buf, n, T, s);
+  if (threadIdx.x == 0) c->cnt = kept;
   __syncthreads();
   *T_out = T;
   return true;
