@@ -146,7 +146,7 @@ def main():
     dec_ms = time_fn(lambda: decoder(loc, conf, anchors), max(3, min(20, args.steps)))
 
     # ---- per-layer table (separate, untimed pass: one hipEvent per op of the recorded plan) ------------------
-    layers, heads = None, None
+    layers, heads, body = None, None, None
     plan = model._plan(x) if hasattr(model, "_plan") else None
     if plan is not None and not isinstance(plan, str):
         N.lib.ssdk_set_op_profiling(1)
@@ -168,6 +168,14 @@ def main():
         hl = [(r, l) for r, l in zip(plan.layer_table(), layers) if r["kind"] == "head"]
         h_flops = sum(r["flops"] for r, _ in hl)
         h_ms = sum(l["us"] for _, l in hl) * 1e-3
+        bl = [(r, l) for r, l in zip(plan.layer_table(), layers) if r["kind"] in ("mbconv", "conv", "dw", "gconv", "stem", "pool", "fuse")]
+        b_ms = sum(l["us"] for _, l in bl) * 1e-3
+        b_bytes, b_flops = sum(r["bytes"] for r, _ in bl), sum(r["flops"] for r, _ in bl)
+        body = {"ms": round(b_ms, 4), "algorithmic_bytes": b_bytes, "flops": b_flops,
+                "achieved_GBps": round(b_bytes / (b_ms * 1e-3) / 1e9, 1), "hbm_frac": round(b_bytes / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "achieved_TFLOPs": round(b_flops / (b_ms * 1e-3) / 1e12, 1),
+                "note": "backbone + extras (every op of the plan that is not a head): the part of the step that dominates "
+                        "by time; bytes = each op's input + output + weights once"}
         heads = {"flops": h_flops, "ms": round(h_ms, 4), "achieved_TFLOPs": round(h_flops / (h_ms * 1e-3) / 1e12, 1),
                  "peak_TFLOPs": MFMA_PEAK_TFLOPS, "frac": round(h_flops / (h_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                  "note": "loc|conf 3x3 head convs of all levels (one fused GEMM per level), bf16 MFMA dense peak"}
@@ -228,6 +236,7 @@ def main():
     result["stages"] = {"forward_ms": round(fwd_ms, 4), "decode_nms_ms": round(dec_ms, 4)}
     if heads is not None:
         result["roofline"]["head_convs_mfma"] = heads
+        result["roofline"]["backbone_by_time"] = body
     if layers is not None and args.layers:
         result["layers"] = layers
 
