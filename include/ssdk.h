@@ -230,6 +230,19 @@ int ssdk_fuse(const ssdk_fuse_desc* desc, void* stream);
 int ssdk_preprocess(const void* x, int src_dtype, int src_layout, int N, int H, int W, int C, const float* mean,
                     const float* std, void* y, int dst_dtype, void* stream);
 
+/* Depthwise 3x3 convolution (pad 1, stride 1|2) for the TRAINING step: forward, input gradient and weight gradient,
+ * NCHW contiguous, dtype SSDK_F32 | SSDK_BF16 | SSDK_F16, fp32 accumulation (replaces MIOpen's naive_conv_* kernels
+ * behind torch.nn.functional.conv2d(groups = C) in the DDP step, pipeline_anchor_apex.py:75-171).
+ *   fwd:        x [N,C,H,W], w [C,1,3,3] -> y [N,C,Ho,Wo]
+ *   bwd_data:   dy [N,C,Ho,Wo], w -> dx [N,C,H,W]           (H, W are the INPUT dims in all three calls)
+ *   bwd_weight: x, dy -> dw fp32 [C,1,3,3]; two-stage fixed-order reduction (bit-reproducible) through `workspace` */
+int ssdk_dwconv_fwd(const void* x, const void* w, void* y, int N, int C, int H, int W, int stride, int dtype, void* stream);
+int ssdk_dwconv_bwd_data(const void* dy, const void* w, void* dx, int N, int C, int H, int W, int stride, int dtype,
+                         void* stream);
+size_t ssdk_dwconv_bwd_weight_workspace_bytes(int N, int C, int H, int W, int stride);
+int ssdk_dwconv_bwd_weight(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int C,
+                           int H, int W, int stride, int dtype, void* stream);
+
 /* ResNet stem (nets/resnet.py:41-46): 7x7 / stride 2 / pad 3 convolution on the 3-channel image + folded BN +
  * activation -> NHWC, and the 3x3 / stride 2 / pad 1 max pooling (NHWC -> NHWC, -inf padding like torch).
  *   x  image [N,3,H,W] (in_layout NCHW) or [N,H,W,3] (NHWC), activation dtype

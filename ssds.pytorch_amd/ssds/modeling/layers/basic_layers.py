@@ -5,6 +5,7 @@ implicit-GEMM launch (``ssdk_conv_bn_act``: BN folded into scale/bias, ReLU in t
 mode the triple is ordinary torch autograd (MIOpen)."""
 import torch.nn as nn
 
+from .dwconv import make_conv2d
 from .fused_conv import FusedSequentialMixin
 
 
@@ -14,7 +15,7 @@ class SepConvBNReLU(FusedSequentialMixin, nn.Sequential):
     def __init__(self, in_planes, out_planes, kernel_size=3, stride=1, expand_ratio=1):
         padding = (kernel_size - 1) // 2
         super(SepConvBNReLU, self).__init__(
-            nn.Conv2d(in_planes, in_planes, kernel_size, stride, padding, groups=in_planes, bias=False),
+            make_conv2d(in_planes, in_planes, kernel_size, stride, padding, groups=in_planes, bias=False),
             nn.BatchNorm2d(in_planes),
             nn.ReLU(inplace=True),
             nn.Conv2d(in_planes, out_planes, 1, 1, 0, bias=False),

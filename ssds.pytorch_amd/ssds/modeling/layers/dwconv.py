@@ -1,0 +1,94 @@
+"""Depthwise 3x3 convolution with hand-written HIP forward / input-gradient / weight-gradient kernels
+(``csrc/ssdk_dwtrain.hip``) behind ``torch.autograd`` -- the training-step replacement for what PyTorch-ROCm
+dispatches to MIOpen's ``naive_conv_*`` kernels (more than half of the GPU time of the reference's DDP step on
+SSD-MobileNetV2: pipeline_anchor_apex.py:75-171 over torchvision ``InvertedResidual`` blocks, mobilenet.py:56).
+
+``DepthwiseConv2d`` is an ``nn.Conv2d`` (same parameters, same ``state_dict`` keys, same initialisation); on CPU
+tensors or for geometries the kernels do not cover it IS ``nn.Conv2d``."""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from ssds import _native as N
+
+
+def _launch(fn, *args):
+    N.check(fn(*args), fn.__name__)
+
+
+class _DwConv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        x = x.contiguous()
+        w = w.contiguous()
+        n, c, h, wd = (int(v) for v in x.shape)
+        ho, wo = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
+        y = torch.empty((n, c, ho, wo), device=x.device, dtype=x.dtype)
+        with torch.cuda.device(x.device):
+            _launch(N.lib.ssdk_dwconv_fwd, x.data_ptr(), w.data_ptr(), y.data_ptr(), n, c, h, wd, stride, N.dtype_code(x),
+                    N.stream_ptr(x.device))
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride = ctx.stride
+        gy = gy.contiguous()
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        n, c, h, wd = (int(v) for v in x.shape)
+        gx = gw = None
+        dev = x.device
+        with torch.cuda.device(dev):
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty_like(x)
+                _launch(N.lib.ssdk_dwconv_bwd_data, gy.data_ptr(), w.data_ptr(), gx.data_ptr(), n, c, h, wd, stride,
+                        N.dtype_code(x), N.stream_ptr(dev))
+            if ctx.needs_input_grad[1]:
+                need = int(N.lib.ssdk_dwconv_bwd_weight_workspace_bytes(n, c, h, wd, stride))
+                ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                gw32 = torch.empty((c, 1, 3, 3), device=dev, dtype=torch.float32)
+                _launch(N.lib.ssdk_dwconv_bwd_weight, x.data_ptr(), gy.data_ptr(), gw32.data_ptr(), ws.data_ptr(), need,
+                        n, c, h, wd, stride, N.dtype_code(x), N.stream_ptr(dev))
+                gw = gw32.to(w.dtype)
+        return gx, gw, None
+
+
+def dwconv3x3(x, weight, stride):
+    """Depthwise 3x3, pad 1, no bias: x [N,C,H,W], weight [C,1,3,3] (same floating dtype), differentiable."""
+    return _DwConv3x3.apply(x, weight, stride)
+
+
+class DepthwiseConv2d(nn.Conv2d):
+    """``nn.Conv2d(C, C, 3, stride, 1, groups=C, bias=False)`` whose HIP-device forward/backward run on the
+    ssdk kernels; anything else falls through to ``nn.Conv2d.forward``."""
+
+    def _native(self, x):
+        return (x.is_cuda and x.dim() == 4 and self.kernel_size == (3, 3) and self.padding == (1, 1)
+                and self.dilation == (1, 1) and self.stride[0] == self.stride[1] and self.stride[0] in (1, 2)
+                and self.groups == self.in_channels == self.out_channels and self.bias is None
+                and self.padding_mode == "zeros")
+
+    def forward(self, x):
+        if not self._native(x):
+            return super(DepthwiseConv2d, self).forward(x)
+        w = self.weight
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_gpu_dtype()
+            x, w = x.to(dt), w.to(dt)
+        elif w.dtype != x.dtype:
+            w = w.to(x.dtype)
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            return super(DepthwiseConv2d, self).forward(x)
+        with torch.autocast("cuda", enabled=False):
+            return dwconv3x3(x, w, self.stride[0])
+
+
+def make_conv2d(in_planes, out_planes, kernel_size, stride=1, padding=0, groups=1, bias=True):
+    """``nn.Conv2d`` factory used by the backbones: depthwise 3x3 convolutions get the kernel-backed subclass."""
+    if groups == in_planes == out_planes and groups > 1 and kernel_size == 3 and padding == 1 and not bias:
+        return DepthwiseConv2d(in_planes, out_planes, 3, stride, 1, groups=groups, bias=False)
+    return nn.Conv2d(in_planes, out_planes, kernel_size, stride, padding, groups=groups, bias=bias)

@@ -8,6 +8,8 @@ torchvision is not a dependency: the (standard) inverted-residual block is defin
 and pointwise convolutions are HBM-bound and run on PyTorch-ROCm/MIOpen."""
 import torch.nn as nn
 
+from ssds.modeling.layers.dwconv import make_conv2d
+
 from .rutils import register
 
 
@@ -24,7 +26,7 @@ class ConvBNReLU6(nn.Sequential):
     def __init__(self, in_planes, out_planes, kernel_size=3, stride=1, groups=1):
         padding = (kernel_size - 1) // 2
         super(ConvBNReLU6, self).__init__(
-            nn.Conv2d(in_planes, out_planes, kernel_size, stride, padding, groups=groups, bias=False),
+            make_conv2d(in_planes, out_planes, kernel_size, stride, padding, groups=groups, bias=False),
             nn.BatchNorm2d(out_planes),
             nn.ReLU6(inplace=True),
         )
@@ -57,7 +59,7 @@ class SepConvBNReLU6(nn.Sequential):
     def __init__(self, in_planes, out_planes, kernel_size=3, stride=1, expand_ratio=1):
         padding = (kernel_size - 1) // 2
         super(SepConvBNReLU6, self).__init__(
-            nn.Conv2d(in_planes, in_planes, kernel_size, stride, padding, groups=in_planes, bias=False),
+            make_conv2d(in_planes, in_planes, kernel_size, stride, padding, groups=in_planes, bias=False),
             nn.BatchNorm2d(in_planes),
             nn.ReLU6(inplace=True),
             nn.Conv2d(in_planes, out_planes, 1, 1, 0, bias=False),

@@ -54,3 +54,43 @@ def test_model_with_loss_matches_cpu_oracle_step():
     c, l, skipped = train_step(mwl, images, targets, anchors, opt)
     after = torch.cat([p.detach().flatten() for p in mwl.parameters()])
     assert not skipped and torch.isfinite(after).all() and not torch.equal(before, after)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype_name,tol", [("float32", 1e-4), ("bfloat16", 2e-2), ("float16", 4e-3)])
+@pytest.mark.parametrize("c,stride,h,w,n", [(32, 1, 20, 24, 3), (96, 2, 33, 31, 2), (144, 2, 64, 70, 2), (8, 1, 5, 130, 1)])
+def test_depthwise_autograd_kernels_match_torch(c, stride, h, w, n, dtype_name, tol):
+    """forward / input gradient / weight gradient of the training depthwise kernels vs torch fp32 autograd."""
+    import torch
+    import torch.nn.functional as F
+    from ssds.modeling.layers.dwconv import DepthwiseConv2d
+
+    dtype = getattr(torch, dtype_name)
+    torch.manual_seed(c + stride)
+    m = DepthwiseConv2d(c, c, 3, stride, 1, groups=c, bias=False).cuda()
+    x = torch.randn(n, c, h, w, device="cuda").to(dtype).requires_grad_(True)
+    w32 = m.weight.detach().to(dtype).float().requires_grad_(True)
+    x32 = x.detach().float().requires_grad_(True)
+    ref = F.conv2d(x32, w32, None, stride, 1, 1, c)
+    g = torch.randn_like(ref)
+    ref.backward(g)
+    m.weight.data = m.weight.data.to(dtype)
+    y = m(x)
+    assert y.dtype == dtype and y.shape == ref.shape
+    y.backward(g.to(dtype))
+
+    def close(a, b, what):
+        err = float((a.float() - b).abs().max()) / max(float(b.abs().max()), 1e-6)
+        assert err < tol, "%s: rel err %.3g" % (what, err)
+
+    close(y, ref, "forward")
+    close(x.grad, x32.grad, "input gradient")
+    close(m.weight.grad, w32.grad, "weight gradient")
+    # bit-reproducible (no float atomics in the weight gradient)
+    m.weight.grad = None
+    x.grad = None
+    m(x).backward(g.to(dtype))
+    y2g = m.weight.grad.clone()
+    m.weight.grad = None
+    m(x).backward(g.to(dtype))
+    assert torch.equal(y2g, m.weight.grad)
