@@ -8,8 +8,8 @@
 //   forward        y[n,c,oy,ox] = sum_t w[c,t] * x[n,c, oy*s + ky - 1, ox*s + kx - 1]
 //   input grad     dx[n,c,iy,ix] = sum_t w[c,t] * dy[n,c,(iy + 1 - ky)/s, (ix + 1 - kx)/s]   (exact divisions only)
 //   weight grad    dw[c,t]      = sum_{n,oy,ox} x[n,c, oy*s + ky - 1, ox*s + kx - 1] * dy[n,c,oy,ox]
-// A workgroup is a 4-row x 64-column tile of one plane (lanes consecutive in x: coalesced, the 3x3 window re-reads
-// hit L1/L2).  The weight gradient is a two-stage reduction in a FIXED order (per-plane-tile partial sums, then one
+// A workgroup owns an 8-row x 64-column output tile of one plane: the input tile (+halo) is staged once in LDS by
+// coalesced reads (lanes consecutive in x) and the 3x3 windows are served from there.  The weight gradient is a two-stage reduction in a FIXED order (per-plane-tile partial sums, then one
 // thread per (c, tap) adds them up) -- no float atomics, bit-reproducible run to run.
 #include "ssdk_conv_common.h"
 
@@ -33,80 +33,115 @@ template <int DT> __device__ __forceinline__ void stf(void* p, size_t i, float v
   else ((u16*)p)[i] = (u16)f32_to_bits16<DT>(v);
 }
 
-template <int DT, int S>
-__global__ __launch_bounds__(256) void dw_fwd_kernel(const DwtParams p) {
-  const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
-  const int plane = blockIdx.y;  // n*C + c
-  const int c = plane % p.C;
-  const int ox = tx * 64 + (threadIdx.x & 63), oy = ty * 4 + (threadIdx.x >> 6);
-  if (ox >= p.Wo || oy >= p.Ho) return;
-  const size_t xb = (size_t)plane * p.H * p.W;
-  float acc = 0.f;
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int iy = oy * S + ky - 1;
-    if ((unsigned)iy >= (unsigned)p.H) continue;
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int ix = ox * S + kx - 1;
-      if ((unsigned)ix >= (unsigned)p.W) continue;
-      acc += ldf<DT>(p.b, (size_t)c * 9 + ky * 3 + kx) * ldf<DT>(p.a, xb + (size_t)iy * p.W + ix);
-    }
+constexpr int DT_TH = 8, DT_TW = 64;  // output tile of a workgroup (256 threads x 2 rows)
+
+// stage rows [r0, r0+NR) x cols [c0, c0+NC) of one plane into LDS as fp32, zeros outside the plane; lanes run along
+// the columns, so the global reads are coalesced and every element is fetched once per tile
+template <int DT>
+__device__ __forceinline__ void stage_tile(float* lds, int ld, const void* src, size_t plane_base, int Hs, int Ws, int r0,
+                                           int c0, int NR, int NC) {
+  for (int i = threadIdx.x; i < NR * NC; i += 256) {
+    const int r = i / NC, c = i - r * NC;
+    const int y = r0 + r, x = c0 + c;
+    float v = 0.f;
+    if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) v = ldf<DT>(src, plane_base + (size_t)y * Ws + x);
+    lds[r * ld + c] = v;
   }
-  stf<DT>(p.out, (size_t)plane * p.Ho * p.Wo + (size_t)oy * p.Wo + ox, acc);
 }
 
 template <int DT, int S>
-__global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwtParams p) {  // output = dx [N,C,H,W]
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const DwtParams p) {
+  constexpr int NR = (DT_TH - 1) * S + 3, NC = (DT_TW - 1) * S + 3, LD = NC + 1;
+  __shared__ float xt[NR * LD];
+  const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
+  const int plane = blockIdx.y;  // n*C + c
+  const int c = plane % p.C;
+  const int oy0 = ty * DT_TH, ox0 = tx * DT_TW;
+  stage_tile<DT>(xt, LD, p.a, (size_t)plane * p.H * p.W, p.H, p.W, oy0 * S - 1, ox0 * S - 1, NR, NC);
+  float w[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w[t] = ldf<DT>(p.b, (size_t)c * 9 + t);
+  __syncthreads();
+  const int col = threadIdx.x & 63;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int row = (threadIdx.x >> 6) + rr * 4;
+    const int oy = oy0 + row, ox = ox0 + col;
+    if (oy >= p.Ho || ox >= p.Wo) continue;
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) acc += w[ky * 3 + kx] * xt[(row * S + ky) * LD + col * S + kx];
+    stf<DT>(p.out, (size_t)plane * p.Ho * p.Wo + (size_t)oy * p.Wo + ox, acc);
+  }
+}
+
+template <int DT, int S>
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwtParams p) {  // output tile = 8 x 64 of dx [N,C,H,W]
+  // dy rows / cols that can reach the tile: (iy + 1 - ky) / S for iy in [iy0, iy0 + 8), ky in 0..2
+  constexpr int NR = (DT_TH + 1) / S + 2, NC = (DT_TW + 1) / S + 2, LD = NC + 1;
+  __shared__ float gt[NR * LD];
   const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
   const int plane = blockIdx.y;
   const int c = plane % p.C;
-  const int ix = tx * 64 + (threadIdx.x & 63), iy = ty * 4 + (threadIdx.x >> 6);
-  if (ix >= p.W || iy >= p.H) return;
-  const size_t yb = (size_t)plane * p.Ho * p.Wo;
-  float acc = 0.f;
+  const int iy0 = ty * DT_TH, ix0 = tx * DT_TW;
+  // first dy row / col staged: floor((iy0 - 1) / S) (iy0 is a multiple of 8, so (iy0 - 1 - (S - 1)) / S for S = 2)
+  const int gy0 = S == 1 ? iy0 - 1 : iy0 / 2 - 1, gx0 = S == 1 ? ix0 - 1 : ix0 / 2 - 1;
+  stage_tile<DT>(gt, LD, p.a, (size_t)plane * p.Ho * p.Wo, p.Ho, p.Wo, gy0, gx0, NR, NC);
+  float w[9];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int ny = iy + 1 - ky;
-    if (ny < 0 || (S == 2 && (ny & 1))) continue;
-    const int oy = ny / S;
-    if (oy >= p.Ho) continue;
+  for (int t = 0; t < 9; ++t) w[t] = ldf<DT>(p.b, (size_t)c * 9 + t);
+  __syncthreads();
+  const int col = threadIdx.x & 63;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int nx = ix + 1 - kx;
-      if (nx < 0 || (S == 2 && (nx & 1))) continue;
-      const int ox = nx / S;
-      if (ox >= p.Wo) continue;
-      acc += ldf<DT>(p.b, (size_t)c * 9 + ky * 3 + kx) * ldf<DT>(p.a, yb + (size_t)oy * p.Wo + ox);
+  for (int rr = 0; rr < 2; ++rr) {
+    const int row = (threadIdx.x >> 6) + rr * 4;
+    const int iy = iy0 + row, ix = ix0 + col;
+    if (iy >= p.H || ix >= p.W) continue;
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ny = iy + 1 - ky;
+      if (S == 2 && (ny & 1)) continue;
+      const int oy = (S == 1 ? ny : ny >> 1) - gy0;  // staged rows outside the plane hold zeros
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int nx = ix + 1 - kx;
+        if (S == 2 && (nx & 1)) continue;
+        const int ox = (S == 1 ? nx : nx >> 1) - gx0;
+        acc += w[ky * 3 + kx] * gt[oy * LD + ox];
+      }
     }
+    stf<DT>(p.out, (size_t)plane * p.H * p.W + (size_t)iy * p.W + ix, acc);
   }
-  stf<DT>(p.out, (size_t)plane * p.H * p.W + (size_t)iy * p.W + ix, acc);
 }
 
 // stage 1: partial[(plane * tiles + tile) * 9 + t] = sum over the tile's output pixels
 template <int DT, int S>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwtParams p) {
+  constexpr int NR = (DT_TH - 1) * S + 3, NC = (DT_TW - 1) * S + 3, LD = NC + 1;
+  __shared__ float xt[NR * LD];
   __shared__ float red[4][9];
   const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
   const int plane = blockIdx.y;
-  const int ox = tx * 64 + (threadIdx.x & 63), oy = ty * 4 + (threadIdx.x >> 6);
+  const int oy0 = ty * DT_TH, ox0 = tx * DT_TW;
+  stage_tile<DT>(xt, LD, p.a, (size_t)plane * p.H * p.W, p.H, p.W, oy0 * S - 1, ox0 * S - 1, NR, NC);
+  __syncthreads();
   float acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-  if (ox < p.Wo && oy < p.Ho) {
+  const int col = threadIdx.x & 63;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int row = (threadIdx.x >> 6) + rr * 4;
+    const int oy = oy0 + row, ox = ox0 + col;
+    if (oy >= p.Ho || ox >= p.Wo) continue;
     const float g = ldf<DT>(p.b, (size_t)plane * p.Ho * p.Wo + (size_t)oy * p.Wo + ox);
-    const size_t xb = (size_t)plane * p.H * p.W;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = oy * S + ky - 1;
-      if ((unsigned)iy >= (unsigned)p.H) continue;
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = ox * S + kx - 1;
-        if ((unsigned)ix >= (unsigned)p.W) continue;
-        acc[ky * 3 + kx] = g * ldf<DT>(p.a, xb + (size_t)iy * p.W + ix);
-      }
-    }
+      for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] += g * xt[(row * S + ky) * LD + col * S + kx];
   }
   const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -123,17 +158,28 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwtParams p) {
   }
 }
 
-// stage 2: dw[c][t] = sum over images and tiles, in index order
+// stage 2: dw[c][t] = sum over images and tiles: one wave per channel, lane l adds the (image, tile) partials
+// l, l + 64, ... in index order, then a fixed butterfly -- deterministic
 __global__ __launch_bounds__(64) void dw_wgrad_reduce_kernel(const float* partial, float* dw, int N, int C, int tiles) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= C * 9) return;
-  const int c = i / 9, t = i % 9;
-  float s = 0.f;
-  for (int n = 0; n < N; ++n) {
-    const float* q = partial + ((size_t)(n * C + c) * tiles) * 9 + t;
-    for (int k = 0; k < tiles; ++k) s += q[(size_t)k * 9];
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x;
+  float acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+  const int total = N * tiles;
+  for (int j = lane; j < total; j += 64) {
+    const int n = j / tiles, k = j - n * tiles;
+    const float* q = partial + ((size_t)(n * C + c) * tiles + k) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] += q[t];
   }
-  dw[i] = s;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float v = acc[t];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0) dw[c * 9 + t] = v;
+  }
 }
 
 static int dwt_check(const char* what, const void* a, const void* b, const void* o, int N, int C, int H, int W, int stride,
@@ -165,8 +211,8 @@ static DwtParams dwt_params(const void* a, const void* b, void* o, int N, int C,
   p.Ho = (H + 2 - 3) / stride + 1;
   p.Wo = (W + 2 - 3) / stride + 1;
   const int oh = out_is_input_space ? H : p.Ho, ow = out_is_input_space ? W : p.Wo;
-  p.tiles_x = (ow + 63) / 64;
-  p.tiles_y = (oh + 3) / 4;
+  p.tiles_x = (ow + DT_TW - 1) / DT_TW;
+  p.tiles_y = (oh + DT_TH - 1) / DT_TH;
   return p;
 }
 
@@ -210,7 +256,7 @@ extern "C" int ssdk_dwconv_bwd_data(const void* dy, const void* w, void* dx, int
 
 extern "C" size_t ssdk_dwconv_bwd_weight_workspace_bytes(int N, int C, int H, int W, int stride) {
   const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-  return (size_t)N * C * ((Wo + 63) / 64) * ((Ho + 3) / 4) * 9 * sizeof(float);
+  return (size_t)N * C * ((Wo + DT_TW - 1) / DT_TW) * ((Ho + DT_TH - 1) / DT_TH) * 9 * sizeof(float);
 }
 
 extern "C" int ssdk_dwconv_bwd_weight(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
@@ -227,7 +273,7 @@ extern "C" int ssdk_dwconv_bwd_weight(const void* x, const void* dy, float* dw, 
   SSDK_DWT_LAUNCH(dw_wgrad_kernel, grid);
   int rc2 = check_launch("dw_wgrad_kernel");
   if (rc2) return rc2;
-  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)((C * 9 + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)C), dim3(64), 0, (hipStream_t)stream,
                      (const float*)workspace, dw, N, C, tiles);
   return check_launch("dw_wgrad_reduce_kernel");
 }
