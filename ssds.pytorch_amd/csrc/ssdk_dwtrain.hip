@@ -8,8 +8,8 @@
 //   forward        y[n,c,oy,ox] = sum_t w[c,t] * x[n,c, oy*s + ky - 1, ox*s + kx - 1]
 //   input grad     dx[n,c,iy,ix] = sum_t w[c,t] * dy[n,c,(iy + 1 - ky)/s, (ix + 1 - kx)/s]   (exact divisions only)
 //   weight grad    dw[c,t]      = sum_{n,oy,ox} x[n,c, oy*s + ky - 1, ox*s + kx - 1] * dy[n,c,oy,ox]
-// A workgroup owns an 8-row x 64-column output tile of one plane: the input tile (+halo) is staged once in LDS by
-// coalesced reads (lanes consecutive in x) and the 3x3 windows are served from there.  The weight gradient is a two-stage reduction in a FIXED order (per-plane-tile partial sums, then one
+// A workgroup owns a 32-row x 64-column output tile of one plane: the input tile (+halo) is staged once in LDS as
+// fp32 by aligned 16-byte reads, a lane computes 8 consecutive pixels of one row and stores them as 16 bytes.  The weight gradient is a two-stage reduction in a FIXED order (per-plane-tile partial sums, then one
 // thread per (c, tap) adds them up) -- no float atomics, bit-reproducible run to run.
 #include "ssdk_conv_common.h"
 
@@ -33,26 +33,87 @@ template <int DT> __device__ __forceinline__ void stf(void* p, size_t i, float v
   else ((u16*)p)[i] = (u16)f32_to_bits16<DT>(v);
 }
 
-constexpr int DT_TH = 8, DT_TW = 64;  // output tile of a workgroup (256 threads x 2 rows)
+constexpr int DT_TH = 32, DT_TW = 64;  // output tile of a workgroup: 256 threads = 32 rows x 8 groups of 8 pixels
 
-// stage rows [r0, r0+NR) x cols [c0, c0+NC) of one plane into LDS as fp32, zeros outside the plane; lanes run along
-// the columns, so the global reads are coalesced and every element is fetched once per tile
+// 8 (2-byte types) or 4 (fp32) consecutive elements <-> fp32
+template <int DT> struct Vec16 { static constexpr int n = DT == SSDK_F32 ? 4 : 8; };
+template <int DT>
+__device__ __forceinline__ void load16(const void* src, size_t i, float (&v)[8]) {  // i: element index, 16-byte aligned
+  if constexpr (DT == SSDK_F32) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>((const float*)src + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = q[e];
+  } else {
+    const u32x4 q = *reinterpret_cast<const u32x4*>((const u16*)src + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] = bits16_to_f32<DT>(q[e] & 0xffffu);
+      v[2 * e + 1] = bits16_to_f32<DT>(q[e] >> 16);
+    }
+  }
+}
+
+// stage rows [r0, r0+NR) x cols [c0, c0+NC) of one plane into LDS as fp32, zeros outside the plane.  When the rows
+// of the plane are 16-byte aligned (Ws a multiple of the vector width) a lane fetches one aligned 16-byte chunk and
+// scatters its in-range elements; otherwise element by element.  Either way lanes run along the columns.
 template <int DT>
 __device__ __forceinline__ void stage_tile(float* lds, int ld, const void* src, size_t plane_base, int Hs, int Ws, int r0,
                                            int c0, int NR, int NC) {
-  for (int i = threadIdx.x; i < NR * NC; i += 256) {
-    const int r = i / NC, c = i - r * NC;
-    const int y = r0 + r, x = c0 + c;
-    float v = 0.f;
-    if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) v = ldf<DT>(src, plane_base + (size_t)y * Ws + x);
-    lds[r * ld + c] = v;
+  constexpr int VN = Vec16<DT>::n;
+  const bool vec = (Ws % VN) == 0 && (plane_base % VN) == 0 && (((uintptr_t)src) & 15u) == 0;
+  if (vec) {
+    const int cbeg = c0 >= 0 ? (c0 / VN) * VN : -(((-c0) + VN - 1) / VN) * VN;  // floor to a chunk boundary
+    const int nch = (c0 + NC - cbeg + VN - 1) / VN;
+    for (int i = threadIdx.x; i < NR * nch; i += 256) {
+      const int r = i / nch, ch = i - r * nch;
+      const int y = r0 + r, x = cbeg + ch * VN;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      if ((unsigned)y < (unsigned)Hs && x >= 0 && x + VN <= Ws) load16<DT>(src, plane_base + (size_t)y * Ws + x, v);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        const int c = x + e - c0;
+        if (c >= 0 && c < NC) lds[r * ld + c] = v[e];
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < NR * NC; i += 256) {
+      const int r = i / NC, c = i - r * NC;
+      const int y = r0 + r, x = c0 + c;
+      float v = 0.f;
+      if ((unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws) v = ldf<DT>(src, plane_base + (size_t)y * Ws + x);
+      lds[r * ld + c] = v;
+    }
+  }
+}
+
+// 8 consecutive outputs of one row: 16-byte store(s) when aligned and complete, element stores otherwise
+template <int DT>
+__device__ __forceinline__ void store8(void* dst, size_t i, const float (&v)[8], int valid) {
+  if constexpr (DT == SSDK_F32) {
+    float* d = (float*)dst + i;
+    if (valid == 8 && (((uintptr_t)d) & 15u) == 0) {
+      *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+      for (int e = 0; e < valid; ++e) d[e] = v[e];
+    }
+  } else {
+    u16* d = (u16*)dst + i;
+    if (valid == 8 && (((uintptr_t)d) & 15u) == 0) {
+      *reinterpret_cast<u32x4*>(d) = u32x4{pack2_16<DT>(v[0], v[1]), pack2_16<DT>(v[2], v[3]), pack2_16<DT>(v[4], v[5]),
+                                           pack2_16<DT>(v[6], v[7])};
+    } else {
+      for (int e = 0; e < valid; ++e) d[e] = (u16)f32_to_bits16<DT>(v[e]);
+    }
   }
 }
 
 template <int DT, int S>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwtParams p) {
-  constexpr int NR = (DT_TH - 1) * S + 3, NC = (DT_TW - 1) * S + 3, LD = NC + 1;
-  __shared__ float xt[NR * LD];
+  constexpr int NR = (DT_TH - 1) * S + 3, NC = (DT_TW - 1) * S + 3, LD = NC | 1;
+  extern __shared__ float xt[];
   const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
   const int plane = blockIdx.y;  // n*C + c
   const int c = plane % p.C;
@@ -62,66 +123,68 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwtParams p) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) w[t] = ldf<DT>(p.b, (size_t)c * 9 + t);
   __syncthreads();
-  const int col = threadIdx.x & 63;
+  const int row = threadIdx.x >> 3, g = threadIdx.x & 7;
+  const int oy = oy0 + row, ox = ox0 + g * 8;
+  if (oy >= p.Ho || ox >= p.Wo) return;
+  float acc[8];
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int row = (threadIdx.x >> 6) + rr * 4;
-    const int oy = oy0 + row, ox = ox0 + col;
-    if (oy >= p.Ho || ox >= p.Wo) continue;
-    float acc = 0.f;
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+  for (int ky = 0; ky < 3; ++ky) {
+    const float* xr = xt + (row * S + ky) * LD + g * 8 * S;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) acc += w[ky * 3 + kx] * xt[(row * S + ky) * LD + col * S + kx];
-    stf<DT>(p.out, (size_t)plane * p.Ho * p.Wo + (size_t)oy * p.Wo + ox, acc);
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) acc[e] += w[ky * 3 + kx] * xr[e * S + kx];
   }
+  store8<DT>(p.out, (size_t)plane * p.Ho * p.Wo + (size_t)oy * p.Wo + ox, acc, p.Wo - ox >= 8 ? 8 : p.Wo - ox);
 }
 
 template <int DT, int S>
-__global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwtParams p) {  // output tile = 8 x 64 of dx [N,C,H,W]
-  // dy rows / cols that can reach the tile: (iy + 1 - ky) / S for iy in [iy0, iy0 + 8), ky in 0..2
-  constexpr int NR = (DT_TH + 1) / S + 2, NC = (DT_TW + 1) / S + 2, LD = NC + 1;
-  __shared__ float gt[NR * LD];
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwtParams p) {  // output tile = 32 x 64 of dx [N,C,H,W]
+  // dy rows / cols that can reach the tile: (iy + 1 - ky) / S for iy in [iy0, iy0 + 32), ky in 0..2
+  constexpr int NR = (DT_TH + 1) / S + 2, NC = (DT_TW + 1) / S + 2, LD = NC | 1;
+  extern __shared__ float gt[];
   const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
   const int plane = blockIdx.y;
   const int c = plane % p.C;
   const int iy0 = ty * DT_TH, ix0 = tx * DT_TW;
-  // first dy row / col staged: floor((iy0 - 1) / S) (iy0 is a multiple of 8, so (iy0 - 1 - (S - 1)) / S for S = 2)
+  // first dy row / col staged: floor((iy0 - 1) / S); iy0, ix0 are even
   const int gy0 = S == 1 ? iy0 - 1 : iy0 / 2 - 1, gx0 = S == 1 ? ix0 - 1 : ix0 / 2 - 1;
   stage_tile<DT>(gt, LD, p.a, (size_t)plane * p.Ho * p.Wo, p.Ho, p.Wo, gy0, gx0, NR, NC);
   float w[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) w[t] = ldf<DT>(p.b, (size_t)c * 9 + t);
   __syncthreads();
-  const int col = threadIdx.x & 63;
+  const int row = threadIdx.x >> 3, g = threadIdx.x & 7;
+  const int iy = iy0 + row, ixb = ix0 + g * 8;
+  if (iy >= p.H || ixb >= p.W) return;
+  float acc[8];
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int row = (threadIdx.x >> 6) + rr * 4;
-    const int iy = iy0 + row, ix = ix0 + col;
-    if (iy >= p.H || ix >= p.W) continue;
-    float acc = 0.f;
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int ny = iy + 1 - ky;
-      if (S == 2 && (ny & 1)) continue;
-      const int oy = (S == 1 ? ny : ny >> 1) - gy0;  // staged rows outside the plane hold zeros
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ny = iy + 1 - ky;
+    if (S == 2 && (ny & 1)) continue;
+    const float* gr = gt + ((S == 1 ? ny : ny >> 1) - gy0) * LD;  // staged rows outside the plane hold zeros
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const int nx = ix + 1 - kx;
+        const int nx = ixb + e + 1 - kx;
         if (S == 2 && (nx & 1)) continue;
-        const int ox = (S == 1 ? nx : nx >> 1) - gx0;
-        acc += w[ky * 3 + kx] * gt[oy * LD + ox];
+        acc[e] += w[ky * 3 + kx] * gr[(S == 1 ? nx : nx >> 1) - gx0];
       }
-    }
-    stf<DT>(p.out, (size_t)plane * p.H * p.W + (size_t)iy * p.W + ix, acc);
   }
+  store8<DT>(p.out, (size_t)plane * p.H * p.W + (size_t)iy * p.W + ixb, acc, p.W - ixb >= 8 ? 8 : p.W - ixb);
 }
 
 // stage 1: partial[(plane * tiles + tile) * 9 + t] = sum over the tile's output pixels
 template <int DT, int S>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwtParams p) {
-  constexpr int NR = (DT_TH - 1) * S + 3, NC = (DT_TW - 1) * S + 3, LD = NC + 1;
-  __shared__ float xt[NR * LD];
+  constexpr int NR = (DT_TH - 1) * S + 3, NC = (DT_TW - 1) * S + 3, LD = NC | 1;
+  constexpr int VN = Vec16<DT>::n;
+  extern __shared__ float xt[];
   __shared__ float red[4][9];
   const int tx = blockIdx.x % p.tiles_x, ty = blockIdx.x / p.tiles_x;
   const int plane = blockIdx.y;
@@ -131,17 +194,32 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwtParams p) {
   float acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-  const int col = threadIdx.x & 63;
+  const int row = threadIdx.x >> 3, g = threadIdx.x & 7;
+  const int oy = oy0 + row, ox = ox0 + g * 8;
+  if (oy < p.Ho && ox < p.Wo) {
+    const size_t gi = (size_t)plane * p.Ho * p.Wo + (size_t)oy * p.Wo + ox;
+    float gv[8];
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int row = (threadIdx.x >> 6) + rr * 4;
-    const int oy = oy0 + row, ox = ox0 + col;
-    if (oy >= p.Ho || ox >= p.Wo) continue;
-    const float g = ldf<DT>(p.b, (size_t)plane * p.Ho * p.Wo + (size_t)oy * p.Wo + ox);
+    for (int e = 0; e < 8; ++e) gv[e] = 0.f;
+    if (p.Wo - ox >= 8 && (p.Wo % VN) == 0 && (((size_t)plane * p.Ho * p.Wo) % VN) == 0 && (((uintptr_t)p.b) & 15u) == 0) {
+      load16<DT>(p.b, gi, gv);
+      if (VN == 4) {
+        float hi[8];
+        load16<DT>(p.b, gi + 4, hi);
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+        for (int e = 0; e < 4; ++e) gv[4 + e] = hi[e];
+      }
+    } else {
+      for (int e = 0; e < 8 && ox + e < p.Wo; ++e) gv[e] = ldf<DT>(p.b, gi + e);
+    }
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] += g * xt[(row * S + ky) * LD + col * S + kx];
+    for (int ky = 0; ky < 3; ++ky) {
+      const float* xr = xt + (row * S + ky) * LD + g * 8 * S;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] += gv[e] * xr[e * S + kx];
+    }
   }
   const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -216,19 +294,27 @@ static DwtParams dwt_params(const void* a, const void* b, void* o, int N, int C,
   return p;
 }
 
-#define SSDK_DWT_LAUNCH(KERNEL, grid)                                                                     \
-  do {                                                                                                    \
-    if (dtype == SSDK_F32) {                                                                              \
-      if (stride == 1) hipLaunchKernelGGL((KERNEL<SSDK_F32, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);   \
-      else hipLaunchKernelGGL((KERNEL<SSDK_F32, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);               \
-    } else if (dtype == SSDK_BF16) {                                                                      \
-      if (stride == 1) hipLaunchKernelGGL((KERNEL<SSDK_BF16, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);  \
-      else hipLaunchKernelGGL((KERNEL<SSDK_BF16, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);              \
-    } else {                                                                                              \
-      if (stride == 1) hipLaunchKernelGGL((KERNEL<SSDK_F16, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);   \
-      else hipLaunchKernelGGL((KERNEL<SSDK_F16, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);               \
-    }                                                                                                     \
+// lds1 / lds2: dynamic LDS bytes of the stride-1 / stride-2 instantiation (the staged tile)
+#define SSDK_DWT_LAUNCH(KERNEL, grid, lds1, lds2)                                                                \
+  do {                                                                                                           \
+    if (dtype == SSDK_F32) {                                                                                     \
+      if (stride == 1) hipLaunchKernelGGL((KERNEL<SSDK_F32, 1>), grid, dim3(256), lds1, (hipStream_t)stream, p);  \
+      else hipLaunchKernelGGL((KERNEL<SSDK_F32, 2>), grid, dim3(256), lds2, (hipStream_t)stream, p);              \
+    } else if (dtype == SSDK_BF16) {                                                                             \
+      if (stride == 1) hipLaunchKernelGGL((KERNEL<SSDK_BF16, 1>), grid, dim3(256), lds1, (hipStream_t)stream, p); \
+      else hipLaunchKernelGGL((KERNEL<SSDK_BF16, 2>), grid, dim3(256), lds2, (hipStream_t)stream, p);             \
+    } else {                                                                                                     \
+      if (stride == 1) hipLaunchKernelGGL((KERNEL<SSDK_F16, 1>), grid, dim3(256), lds1, (hipStream_t)stream, p);  \
+      else hipLaunchKernelGGL((KERNEL<SSDK_F16, 2>), grid, dim3(256), lds2, (hipStream_t)stream, p);              \
+    }                                                                                                            \
   } while (0)
+
+static constexpr size_t dwt_lds_in(int s) {  // tile of the input behind a DT_TH x DT_TW output tile
+  return (size_t)((DT_TH - 1) * s + 3) * ((((DT_TW - 1) * s + 3)) | 1) * sizeof(float);
+}
+static constexpr size_t dwt_lds_dy(int s) {  // tile of dy behind a DT_TH x DT_TW tile of dx
+  return (size_t)((DT_TH + 1) / s + 2) * (((DT_TW + 1) / s + 2) | 1) * sizeof(float);
+}
 
 }  // namespace ssdk
 
@@ -240,7 +326,7 @@ extern "C" int ssdk_dwconv_fwd(const void* x, const void* w, void* y, int N, int
   if (rc) return rc;
   DwtParams p = dwt_params(x, w, y, N, C, H, W, stride, dtype, false);
   const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)(N * C));
-  SSDK_DWT_LAUNCH(dw_fwd_kernel, grid);
+  SSDK_DWT_LAUNCH(dw_fwd_kernel, grid, dwt_lds_in(1), dwt_lds_in(2));
   return check_launch("dw_fwd_kernel");
 }
 
@@ -250,7 +336,7 @@ extern "C" int ssdk_dwconv_bwd_data(const void* dy, const void* w, void* dx, int
   if (rc) return rc;
   DwtParams p = dwt_params(dy, w, dx, N, C, H, W, stride, dtype, true);
   const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)(N * C));
-  SSDK_DWT_LAUNCH(dw_dgrad_kernel, grid);
+  SSDK_DWT_LAUNCH(dw_dgrad_kernel, grid, dwt_lds_dy(1), dwt_lds_dy(2));
   return check_launch("dw_dgrad_kernel");
 }
 
@@ -270,7 +356,7 @@ extern "C" int ssdk_dwconv_bwd_weight(const void* x, const void* dy, float* dw, 
   DwtParams p = dwt_params(x, dy, workspace, N, C, H, W, stride, dtype, false);
   const int tiles = p.tiles_x * p.tiles_y;
   const dim3 grid((unsigned)tiles, (unsigned)(N * C));
-  SSDK_DWT_LAUNCH(dw_wgrad_kernel, grid);
+  SSDK_DWT_LAUNCH(dw_wgrad_kernel, grid, dwt_lds_in(1), dwt_lds_in(2));
   int rc2 = check_launch("dw_wgrad_kernel");
   if (rc2) return rc2;
   hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((unsigned)C), dim3(64), 0, (hipStream_t)stream,
