@@ -243,6 +243,20 @@ size_t ssdk_dwconv_bwd_weight_workspace_bytes(int N, int C, int H, int W, int st
 int ssdk_dwconv_bwd_weight(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int C,
                            int H, int W, int stride, int dtype, void* stream);
 
+/* BatchNorm2d with batch statistics for the TRAINING step (replaces MIOpenBatchNorm{Fwd,Bwd}Spatial), NCHW
+ * contiguous data of dtype SSDK_F32 | SSDK_BF16 | SSDK_F16, fp32 parameters / statistics, HW = H*W.
+ *   fwd: y = (x - mean_c) * invstd_c * weight_c + bias_c;  save_mean / save_invstd fp32 [C] (for backward);
+ *        running_mean / running_var (may both be NULL) updated like torch: momentum, unbiased variance
+ *   bwd: dx, dweight = sum(dy * xhat), dbias = sum(dy)   (dweight / dbias may be NULL)
+ * Reductions run in a fixed order (bit-reproducible).  workspace: ssdk_bn_workspace_bytes(N, C), 16-byte aligned. */
+size_t ssdk_bn_workspace_bytes(int N, int C);
+int ssdk_bn_train_fwd(const void* x, const float* weight, const float* bias, float* running_mean, float* running_var,
+                      void* y, float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, int N, int C,
+                      int HW, float momentum, float eps, int dtype, void* stream);
+int ssdk_bn_train_bwd(const void* x, const void* dy, const float* weight, const float* save_mean, const float* save_invstd,
+                      void* dx, float* dweight, float* dbias, void* workspace, size_t workspace_bytes, int N, int C,
+                      int HW, int dtype, void* stream);
+
 /* ResNet stem (nets/resnet.py:41-46): 7x7 / stride 2 / pad 3 convolution on the 3-channel image + folded BN +
  * activation -> NHWC, and the 3x3 / stride 2 / pad 1 max pooling (NHWC -> NHWC, -inf padding like torch).
  *   x  image [N,3,H,W] (in_layout NCHW) or [N,H,W,3] (NHWC), activation dtype

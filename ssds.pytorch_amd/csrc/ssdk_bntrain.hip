@@ -1,0 +1,311 @@
+// ssdk_bntrain.hip -- BatchNorm2d training forward / backward (batch statistics), NCHW, fp32 | bf16 | f16 data with
+// fp32 parameters and statistics, on gfx950.
+//
+// Why: after the depthwise convolutions, MIOpenBatchNorm{Fwd,Bwd}Spatial are the largest item of the reference's DDP
+// training step on SSD-MobileNetV2 (22 of 57 ms at batch 64; they move ~28 GB where ~7 ms of HBM time would do).
+// Both directions are two HBM-bound passes:
+//   forward   (1) per-channel sum / sum of squares about a pivot (the channel's first element: avoids the
+//                 cancellation of E[x^2] - E[x]^2), partials per (channel, image-slice) in a fixed order
+//             (2) y = x * a[c] + b[c],  a = gamma * invstd, b = beta - mean * a;  running statistics updated like
+//                 torch (momentum, unbiased variance)
+//   backward  (1) per-channel sum(dy), sum(dy * xhat)            -> dbeta, dgamma
+//             (2) dx = a * dy + x * k1[c] + k0[c]   (the usual formula with the per-channel scalars folded)
+// A workgroup of a reduction pass owns (channel c, slice s): the planes n = s, s + SPLIT, ... of that channel, read
+// with 16-byte vectors; partials are combined by one thread per channel in index order (bit-reproducible).
+#include "ssdk_conv_common.h"
+
+namespace ssdk {
+
+struct BnParams {
+  const void* x;
+  const void* dy;
+  void* out;               // y | dx
+  const float* weight;
+  const float* bias;
+  float* running_mean;
+  float* running_var;
+  float* save_mean;
+  float* save_invstd;
+  float* dweight;
+  float* dbias;
+  float* partial;          // [C][SPLIT][2]
+  float* coef;             // [C][4] per-channel scalars of the apply pass
+  int N, C, HW, split, dtype;
+  float momentum, eps;
+};
+
+template <int DT> struct BnVec { static constexpr int n = DT == SSDK_F32 ? 4 : 8; };
+
+template <int DT>
+__device__ __forceinline__ void bn_load(const void* src, size_t i, float (&v)[8]) {
+  if constexpr (DT == SSDK_F32) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>((const float*)src + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = q[e];
+  } else {
+    const u32x4 q = *reinterpret_cast<const u32x4*>((const u16*)src + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] = bits16_to_f32<DT>(q[e] & 0xffffu);
+      v[2 * e + 1] = bits16_to_f32<DT>(q[e] >> 16);
+    }
+  }
+}
+template <int DT> __device__ __forceinline__ float bn_ld1(const void* p, size_t i) {
+  if constexpr (DT == SSDK_F32) return ((const float*)p)[i];
+  else return bits16_to_f32<DT>(((const u16*)p)[i]);
+}
+
+__device__ __forceinline__ void block_sum2(float& a, float& b, float (*red)[2]) {  // fixed butterfly + wave order
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    a += __shfl_xor(a, d);
+    b += __shfl_xor(b, d);
+  }
+  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[wave][0] = a;
+    red[wave][1] = b;
+  }
+  __syncthreads();
+  a = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+  b = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
+}
+
+// MODE 0: sums of (x - pivot), (x - pivot)^2.  MODE 1: sums of dy, dy * (x - mean) * invstd.
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const BnParams p) {
+  __shared__ float red[4][2];
+  constexpr int VN = BnVec<DT>::n;
+  const int c = blockIdx.x, s = blockIdx.y;
+  const bool vec = (p.HW % VN) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)p.dy)) & 15u) == 0;
+  const float k = MODE == 0 ? bn_ld1<DT>(p.x, (size_t)c * p.HW) : p.save_mean[c];
+  const float istd = MODE == 0 ? 1.f : p.save_invstd[c];
+  float a = 0.f, b = 0.f;
+  for (int n = s; n < p.N; n += p.split) {
+    const size_t base = ((size_t)n * p.C + c) * p.HW;
+    if (vec) {
+      for (int i = threadIdx.x * VN; i < p.HW; i += 256 * VN) {
+        float xv[8], gv[8];
+        bn_load<DT>(p.x, base + i, xv);
+        if (MODE == 1) bn_load<DT>(p.dy, base + i, gv);
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+          const float d = xv[e] - k;
+          if (MODE == 0) {
+            a += d;
+            b += d * d;
+          } else {
+            a += gv[e];
+            b += gv[e] * d * istd;
+          }
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < p.HW; i += 256) {
+        const float d = bn_ld1<DT>(p.x, base + i) - k;
+        if (MODE == 0) {
+          a += d;
+          b += d * d;
+        } else {
+          const float g = bn_ld1<DT>(p.dy, base + i);
+          a += g;
+          b += g * d * istd;
+        }
+      }
+    }
+  }
+  block_sum2(a, b, red);
+  if (threadIdx.x == 0) {
+    p.partial[((size_t)c * p.split + s) * 2 + 0] = a;
+    p.partial[((size_t)c * p.split + s) * 2 + 1] = b;
+  }
+}
+
+// forward statistics -> mean, invstd, running stats, apply coefficients (a, b)
+template <int DT>
+__global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const BnParams p) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= p.C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int s = 0; s < p.split; ++s) {
+    s1 += p.partial[((size_t)c * p.split + s) * 2 + 0];
+    s2 += p.partial[((size_t)c * p.split + s) * 2 + 1];
+  }
+  const float M = (float)p.N * (float)p.HW;
+  const float pivot = bn_ld1<DT>(p.x, (size_t)c * p.HW);
+  const float m1 = s1 / M;
+  const float mean = pivot + m1;
+  float var = s2 / M - m1 * m1;  // biased
+  var = var < 0.f ? 0.f : var;
+  const float invstd = 1.0f / sqrtf(var + p.eps);
+  p.save_mean[c] = mean;
+  p.save_invstd[c] = invstd;
+  if (p.running_mean) {
+    const float unbiased = M > 1.f ? var * (M / (M - 1.f)) : var;
+    p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * mean;
+    p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * unbiased;
+  }
+  const float g = p.weight ? p.weight[c] : 1.f, bt = p.bias ? p.bias[c] : 0.f;
+  p.coef[c * 4 + 0] = g * invstd;
+  p.coef[c * 4 + 1] = bt - mean * g * invstd;
+  p.coef[c * 4 + 2] = 0.f;
+}
+
+// backward sums -> dgamma, dbeta, coefficients of dx = a*dy + k1*x + k0
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const BnParams p) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= p.C) return;
+  float sg = 0.f, sgx = 0.f;
+  for (int s = 0; s < p.split; ++s) {
+    sg += p.partial[((size_t)c * p.split + s) * 2 + 0];
+    sgx += p.partial[((size_t)c * p.split + s) * 2 + 1];
+  }
+  if (p.dweight) p.dweight[c] = sgx;
+  if (p.dbias) p.dbias[c] = sg;
+  const float M = (float)p.N * (float)p.HW;
+  const float g = p.weight ? p.weight[c] : 1.f;
+  const float invstd = p.save_invstd[c], mean = p.save_mean[c];
+  const float a = g * invstd;
+  const float k1 = -a * invstd * sgx / M;
+  p.coef[c * 4 + 0] = a;
+  p.coef[c * 4 + 1] = -a * sg / M - k1 * mean;  // k0
+  p.coef[c * 4 + 2] = k1;
+}
+
+// MODE 0: out = x*a + b.  MODE 1: out = dy*a + x*k1 + k0.   grid (chunks of a plane, N*C planes)
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const BnParams p) {
+  constexpr int VN = BnVec<DT>::n;
+  const int plane = blockIdx.y;
+  const int c = plane % p.C;
+  const float a = p.coef[c * 4 + 0], k0 = p.coef[c * 4 + 1], k1 = p.coef[c * 4 + 2];
+  const size_t base = (size_t)plane * p.HW;
+  const bool vec = (p.HW % VN) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)p.dy) | ((uintptr_t)p.out)) & 15u) == 0;
+  if (vec) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) * VN;
+    if (i >= p.HW) return;
+    float xv[8], gv[8], o[8];
+    bn_load<DT>(p.x, base + i, xv);
+    if (MODE == 1) bn_load<DT>(p.dy, base + i, gv);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) o[e] = MODE == 0 ? xv[e] * a + k0 : gv[e] * a + xv[e] * k1 + k0;
+    if constexpr (DT == SSDK_F32) {
+      *reinterpret_cast<f32x4*>((float*)p.out + base + i) = f32x4{o[0], o[1], o[2], o[3]};
+    } else {
+      *reinterpret_cast<u32x4*>((u16*)p.out + base + i) =
+          u32x4{pack2_16<DT>(o[0], o[1]), pack2_16<DT>(o[2], o[3]), pack2_16<DT>(o[4], o[5]), pack2_16<DT>(o[6], o[7])};
+    }
+  } else {
+    for (int e = 0; e < VN; ++e) {
+      const int i = (blockIdx.x * 256 + threadIdx.x) * VN + e;
+      if (i >= p.HW) return;
+      const float xv = bn_ld1<DT>(p.x, base + i);
+      const float o = MODE == 0 ? xv * a + k0 : bn_ld1<DT>(p.dy, base + i) * a + xv * k1 + k0;
+      if constexpr (DT == SSDK_F32) ((float*)p.out)[base + i] = o;
+      else ((u16*)p.out)[base + i] = (u16)f32_to_bits16<DT>(o);
+    }
+  }
+}
+
+static int bn_split(int N, int C) {
+  int s = (1024 + C - 1) / C;
+  if (s > N) s = N;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : s;
+}
+
+template <int MODE>
+static void bn_launch(const BnParams& p, hipStream_t st) {
+  const dim3 rgrid((unsigned)p.C, (unsigned)p.split);
+  const int vn = p.dtype == SSDK_F32 ? 4 : 8;
+  const dim3 agrid((unsigned)((p.HW + 256 * vn - 1) / (256 * vn)), (unsigned)((long)p.N * p.C));
+#define SSDK_BN(DT)                                                                                         \
+  do {                                                                                                      \
+    hipLaunchKernelGGL((bn_reduce_kernel<DT, MODE>), rgrid, dim3(256), 0, st, p);                           \
+    if (MODE == 0) hipLaunchKernelGGL((bn_fwd_finalize_kernel<DT>), dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p); \
+    else hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p);  \
+    hipLaunchKernelGGL((bn_apply_kernel<DT, MODE>), agrid, dim3(256), 0, st, p);                             \
+  } while (0)
+  if (p.dtype == SSDK_F32) SSDK_BN(SSDK_F32);
+  else if (p.dtype == SSDK_BF16) SSDK_BN(SSDK_BF16);
+  else SSDK_BN(SSDK_F16);
+#undef SSDK_BN
+}
+
+}  // namespace ssdk
+
+using namespace ssdk;
+
+extern "C" size_t ssdk_bn_workspace_bytes(int N, int C) {
+  return ((size_t)C * bn_split(N, C) * 2 + (size_t)C * 4) * sizeof(float);
+}
+
+static int bn_common(BnParams& p, const char* what, int N, int C, int HW, int dtype, void* workspace, size_t workspace_bytes) {
+  if (N < 1 || C < 1 || HW < 1 || (dtype != SSDK_F32 && dtype != SSDK_BF16 && dtype != SSDK_F16) || (long)N * C > 2147483647l) {
+    set_error("%s: bad arguments N=%d C=%d HW=%d dtype=%d", what, N, C, HW, dtype);
+    return SSDK_E_BADARG;
+  }
+  if (!workspace || workspace_bytes < ssdk_bn_workspace_bytes(N, C) || ((uintptr_t)workspace & 15)) {
+    set_error("%s: workspace too small or misaligned", what);
+    return SSDK_E_BADARG;
+  }
+  p.N = N;
+  p.C = C;
+  p.HW = HW;
+  p.dtype = dtype;
+  p.split = bn_split(N, C);
+  p.partial = (float*)workspace;
+  p.coef = p.partial + (size_t)C * p.split * 2;
+  return SSDK_OK;
+}
+
+extern "C" int ssdk_bn_train_fwd(const void* x, const float* weight, const float* bias, float* running_mean,
+                                 float* running_var, void* y, float* save_mean, float* save_invstd, void* workspace,
+                                 size_t workspace_bytes, int N, int C, int HW, float momentum, float eps, int dtype,
+                                 void* stream) {
+  if (!x || !y || !save_mean || !save_invstd || (!running_mean) != (!running_var)) {
+    set_error("bn_train_fwd: null pointer");
+    return SSDK_E_BADARG;
+  }
+  BnParams p;
+  memset(&p, 0, sizeof(p));
+  const int rc = bn_common(p, "bn_train_fwd", N, C, HW, dtype, workspace, workspace_bytes);
+  if (rc) return rc;
+  p.x = x;
+  p.dy = x;
+  p.out = y;
+  p.weight = weight;
+  p.bias = bias;
+  p.running_mean = running_mean;
+  p.running_var = running_var;
+  p.save_mean = save_mean;
+  p.save_invstd = save_invstd;
+  p.momentum = momentum;
+  p.eps = eps;
+  bn_launch<0>(p, (hipStream_t)stream);
+  return check_launch("bn_train_fwd");
+}
+
+extern "C" int ssdk_bn_train_bwd(const void* x, const void* dy, const float* weight, const float* save_mean,
+                                 const float* save_invstd, void* dx, float* dweight, float* dbias, void* workspace,
+                                 size_t workspace_bytes, int N, int C, int HW, int dtype, void* stream) {
+  if (!x || !dy || !dx || !save_mean || !save_invstd) {
+    set_error("bn_train_bwd: null pointer");
+    return SSDK_E_BADARG;
+  }
+  BnParams p;
+  memset(&p, 0, sizeof(p));
+  const int rc = bn_common(p, "bn_train_bwd", N, C, HW, dtype, workspace, workspace_bytes);
+  if (rc) return rc;
+  p.x = x;
+  p.dy = dy;
+  p.out = dx;
+  p.weight = weight;
+  p.save_mean = const_cast<float*>(save_mean);
+  p.save_invstd = const_cast<float*>(save_invstd);
+  p.dweight = dweight;
+  p.dbias = dbias;
+  bn_launch<1>(p, (hipStream_t)stream);
+  return check_launch("bn_train_bwd");
+}

@@ -110,6 +110,12 @@ def _load():
     lib.ssdk_dwconv_bwd_weight.argtypes = [vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]
     for _n in ("ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data", "ssdk_dwconv_bwd_weight"):
         getattr(lib, _n).restype = i32
+    lib.ssdk_bn_workspace_bytes.argtypes = [i32, i32]
+    lib.ssdk_bn_workspace_bytes.restype = sz
+    lib.ssdk_bn_train_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, f32, f32, i32, vp]
+    lib.ssdk_bn_train_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]
+    lib.ssdk_bn_train_fwd.restype = i32
+    lib.ssdk_bn_train_bwd.restype = i32
     lib.ssdk_preprocess.argtypes = [vp, i32, i32, i32, i32, i32, i32, c.POINTER(f32), c.POINTER(f32), vp, i32, vp]
     lib.ssdk_preprocess.restype = i32
     lib.ssdk_conv_stem7.argtypes = [c.POINTER(StemDesc), vp]
@@ -159,7 +165,8 @@ EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_p
            "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
            "ssdk_match_targets_by_scale", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_fuse", "ssdk_preprocess", "ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data",
-           "ssdk_dwconv_bwd_weight_workspace_bytes", "ssdk_dwconv_bwd_weight", "ssdk_conv_stem7", "ssdk_maxpool3x3s2", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
+           "ssdk_dwconv_bwd_weight_workspace_bytes", "ssdk_dwconv_bwd_weight", "ssdk_bn_workspace_bytes",
+           "ssdk_bn_train_fwd", "ssdk_bn_train_bwd", "ssdk_conv_stem7", "ssdk_maxpool3x3s2", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 
 
 def op_timings():

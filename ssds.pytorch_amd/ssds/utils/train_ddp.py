@@ -36,6 +36,10 @@ class Solver(object):
         self.load_model()
         if sync_bn:
             self.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(self.model)
+        elif os.environ.get("SSDK_FAST_BN", "1") != "0":
+            from ssds.modeling.layers.batchnorm import use_fast_batchnorm
+
+            use_fast_batchnorm(self.model)  # training BN on the ssdk kernels (local statistics, like the default)
         self.model.to(self.device)
         if render and local_rank == 0:
             print("Model architectures:\n{}\n".format(self.model))

@@ -94,3 +94,47 @@ def test_depthwise_autograd_kernels_match_torch(c, stride, h, w, n, dtype_name, 
     m.weight.grad = None
     m(x).backward(g.to(dtype))
     assert torch.equal(y2g, m.weight.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype_name,tol", [("float32", 2e-4), ("bfloat16", 2e-2), ("float16", 4e-3)])
+@pytest.mark.parametrize("n,c,h,w", [(4, 32, 16, 24), (3, 17, 9, 7), (64, 8, 32, 32), (2, 144, 13, 13)])
+def test_batchnorm_training_kernels_match_torch(n, c, h, w, dtype_name, tol):
+    """forward (output, running statistics) and backward (dx, dweight, dbias) vs nn.BatchNorm2d in fp32."""
+    import torch
+    import torch.nn as nn
+    from ssds.modeling.layers.batchnorm import FastBatchNorm2d
+
+    dtype = getattr(torch, dtype_name)
+    torch.manual_seed(n * c + h)
+    ref = nn.BatchNorm2d(c).cuda().train()
+    ref.weight.data.uniform_(0.5, 1.5)
+    ref.bias.data.normal_(0, 0.3)
+    ref.running_mean.normal_(0, 0.2)
+    ref.running_var.uniform_(0.5, 1.5)
+    fast = FastBatchNorm2d(c).cuda().train()
+    fast.load_state_dict(ref.state_dict())
+    x = (torch.randn(n, c, h, w, device="cuda") * 2 + 3).to(dtype)  # mean >> 0: the case E[x^2]-E[x]^2 gets wrong
+    x32 = x.detach().float().clone().requires_grad_(True)
+    xf = x.detach().clone().requires_grad_(True)
+    yr = ref(x32)
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    yf = fast(xf)
+    assert yf.dtype == dtype
+    yf.backward(g.to(dtype))
+
+    def close(a, b, what):
+        err = float((a.float() - b.float()).abs().max()) / max(float(b.abs().max()), 1e-6)
+        assert err < tol, "%s: rel err %.3g" % (what, err)
+
+    close(yf, yr, "output")
+    close(xf.grad, x32.grad, "dx")
+    close(fast.weight.grad, ref.weight.grad, "dweight")
+    close(fast.bias.grad, ref.bias.grad, "dbias")
+    close(fast.running_mean, ref.running_mean, "running_mean")
+    close(fast.running_var, ref.running_var, "running_var")
+    assert int(fast.num_batches_tracked) == 1
+    fast.eval()
+    ref.eval()
+    close(fast(x), ref(x.float()), "eval path is nn.BatchNorm2d")
