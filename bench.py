@@ -46,6 +46,22 @@ def parse():
     return ap.parse_args()
 
 
+def scan_traffic_bytes():
+    """HBM read bytes per scan_kernel launch measured by the separate `rocprofv3 --pmc FETCH_SIZE` pass of the same
+    command (profiles/r01_pmc_fetch_size_*.csv: raw KB x 1024 x 2, the gfx950 correction of MI355X_MICROARCH.md), or
+    None when no such profile is committed.  PMC collection cannot run inside the timed region."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size_*.csv")))
+    if not files:
+        return None
+    for row in csv.DictReader(open(files[-1])):
+        if "scan_kernel" in row["kernel"]:
+            return int(float(row["bytes_per_dispatch_x2_gfx950_correction"]))
+    return None
+
+
 def main():
     args = parse()
     import numpy as np
@@ -192,7 +208,7 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": round(scan_gbs / HBM_PEAK_GBS, 4),
-        "traffic": None,  # PMC pass (FETCH_SIZE) is collected separately: profiles/
+        "traffic": scan_traffic_bytes(),  # HBM bytes per launch from the separate PMC pass (FETCH_SIZE x2), profiles/
         "algorithmic_bytes_per_launch": int(conf_bytes),
         "avg_launch_ms": round(float(scan_ms), 5),
         "decode_nms_stage": {
