@@ -615,12 +615,12 @@ static int launch_mb(const MbParams& p, int ks, int nfo, size_t lds, unsigned gr
       if (nfo <= 2) launch_one<DT, S, 2, 3, true>(p, lds, grid, stream);
       else launch_one<DT, S, 4, 3, true>(p, lds, grid, stream);
     }
-    return check_launch("mbconv_kernel(stem)");
+    return check_launch(p.ts == 16 ? "mbconv_kernel(stem, 16x16)" : "mbconv_kernel(stem)");
   }
   if (resident && ks <= 1 && nfo <= 4) {  // small-channel, high-resolution blocks: persistent grid, resident weights
     if (nfo <= 2) launch_one<DT, S, 2, 1, false, true>(p, lds, grid, stream);
     else launch_one<DT, S, 4, 1, false, true>(p, lds, grid, stream);
-    return check_launch("mbconv_kernel(resident)");
+    return check_launch(p.ts == 16 ? "mbconv_kernel(resident, 16x16)" : "mbconv_kernel(resident)");
   }
   if (ks <= 1 && nfo <= 2) launch_one<DT, S, 2, 1>(p, lds, grid, stream);
   else if (ks <= 1 && nfo <= 4) launch_one<DT, S, 4, 1>(p, lds, grid, stream);
@@ -630,7 +630,7 @@ static int launch_mb(const MbParams& p, int ks, int nfo, size_t lds, unsigned gr
   else if (ks <= 3 && nfo <= 10) launch_one<DT, S, 10, 3>(p, lds, grid, stream);
   else if (nfo <= 10) launch_one<DT, S, 10, 5>(p, lds, grid, stream);
   else launch_one<DT, S, 20, 5>(p, lds, grid, stream);
-  return check_launch("mbconv_kernel");
+  return check_launch(p.ts == 16 ? "mbconv_kernel(16x16)" : "mbconv_kernel");
 }
 
 }  // namespace ssdk

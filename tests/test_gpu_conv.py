@@ -528,6 +528,59 @@ def test_fused_stem_block(layout, h, w):
     _check(got, y, dtype, "stem block " + layout)
 
 
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+def test_fused_blocks_16x16_tiles(dtype_name):
+    """Stride-1 blocks on maps large enough for >= 512 tiles run on the 16x16-tile instantiations (strip-tiled
+    depthwise, batched expand fragments): a residual block and the stem block, ragged sizes included."""
+    import torch
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+    from ssds.modeling.layers.planner import groups_of
+    from ssds.modeling.nets.mobilenet import ConvBNReLU6, InvertedResidual
+
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    torch.manual_seed(21)
+
+    def randomize(mods):
+        for m in mods:
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.normal_(0, 0.2)
+            if isinstance(m, torch.nn.Conv2d):
+                m.weight.data = (m.weight.data * 2).to(dtype).float()
+
+    # residual block 24 -> 144 -> 24 on 10 images of 120 x 104 (8 x 7 tiles of 16 x 16, ragged right/bottom edges)
+    blk = InvertedResidual(24, 24, 1, 6).eval()
+    randomize(blk.modules())
+    x = torch.randn(10, 24, 120, 104).to(dtype)
+    with torch.no_grad():
+        mods = list(blk.conv.children())
+        y = mods[0](x.float()).to(torch.float16).float()
+        y = mods[1](y).to(torch.float16).float()
+        y = mods[3](mods[2](y)).to(dtype).float() + x.float()
+    blk = blk.cuda()
+    got = FC.mbconv_native(x.cuda(), FC.MbPack(groups_of(blk.conv), True, dtype))
+    assert "16x16" in N.last_kernel(), N.last_kernel()
+    _check(got, y, dtype, "16x16 residual block")
+    # stem + first block from a 9 x 3 x 250 x 246 image (stem grid 125 x 123)
+    stem = ConvBNReLU6(3, 32, stride=2).eval()
+    blk = InvertedResidual(32, 16, 1, 1).eval()
+    randomize(list(stem.modules()) + list(blk.modules()))
+    img = torch.rand(9, 3, 250, 246).to(dtype)
+    with torch.no_grad():
+        y = stem(img.float()).to(torch.float16).float()
+        mods = list(blk.conv.children())
+        y = mods[0](y).to(torch.float16).float()
+        y = mods[2](mods[1](y))
+    stem, blk = stem.cuda(), blk.cuda()
+    pk = FC.MbPack(groups_of(blk.conv), False, dtype, stem_group=groups_of(stem)[0])
+    got = FC.mbconv_native(img.cuda(), pk)
+    assert "16x16" in N.last_kernel(), N.last_kernel()
+    _check(got, y, dtype, "16x16 stem block")
+
+
 @pytest.mark.parametrize("head,net,outs,depth", [("SSDFPN", "ResNet18", [3, 4, 5], [128, 256, 512]),
                                                  ("SSDBiFPN", "RegNetX002", [2, 3, 4], [56, 152, 368])])
 def test_fpn_bifpn_eval_on_device(head, net, outs, depth):
