@@ -584,7 +584,7 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
 
 template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = false>
 static void launch_one(const MbParams& p, size_t lds, unsigned grid, hipStream_t stream) {
-  if constexpr (S == 1 && KSMAX <= 3 && NFO <= 4) {  // the instantiations that exist with 16x16 tiles
+  if constexpr (S == 1 && KSMAX <= 3 && NFO <= 6) {  // the instantiations that exist with 16x16 tiles
     if (p.ts == 16) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 32, 16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -694,8 +694,13 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   {
     const int nfo16 = (d->Cout + 15) / 16, ks16 = ((stem ? 96 : d->Cin) + 31) / 32;
     const long tiles16 = (long)d->N * ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
-    const bool can16 = d->stride == 1 && nfo16 <= 4 && (stem || ks16 <= 1);
-    p.ts = (can16 && env_ts != 8 && (tiles16 >= 512 || env_ts == 16)) ? 16 : 8;
+    // measured on SSD-MobileNetV2@512 batch 64: the 16x16 tile wins down to ONE workgroup per CU (256 tiles: the
+    // 64-channel blocks at 32x32 go 55 -> 35 us), i.e. work per phase matters more than co-resident workgroups
+    static const int env_min = getenv("SSDK_MB_TS16_MIN") ? atoi(getenv("SSDK_MB_TS16_MIN")) : 256;
+    static const int env_ks = getenv("SSDK_MB_TS16_KS") ? atoi(getenv("SSDK_MB_TS16_KS")) : 3;
+    static const int env_nfo = getenv("SSDK_MB_TS16_NFO") ? atoi(getenv("SSDK_MB_TS16_NFO")) : 6;
+    const bool can16 = d->stride == 1 && nfo16 <= env_nfo && (stem || ks16 <= env_ks);
+    p.ts = (can16 && env_ts != 8 && (tiles16 >= env_min || env_ts == 16)) ? 16 : 8;
   }
   p.tiles_x = (p.Wo + p.ts - 1) / p.ts;
   p.tiles_y = (p.Ho + p.ts - 1) / p.ts;
@@ -732,7 +737,7 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
     // 64-channel chunks halve the phases per hidden channel but cost LDS (occupancy): measured per block on
     // SSD-MobileNetV2@512 they win from Cin = 96 on (long chunk loops, one workgroup per CU anyway) and lose below
     const bool want64 = env_hc == 64 || (env_hc == 0 && !stem && p.Cin >= 96);
-    const int hc = (want64 && p.ts == 8 && l64 <= 160 * 1024) ? 64 : 32;
+    const int hc = (want64 && p.ts == 8 && l64 <= 160 * 1024) ? 64 : 32;  // (16x16 tiles exist with 32 only)
     lds = layout(hc);
     if (p.ts == 16 && resident && lds > 80 * 1024) {  // two workgroups per CU beat resident weights
       const int nch = (d->Chid + hc - 1) / hc;
