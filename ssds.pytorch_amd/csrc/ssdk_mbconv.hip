@@ -46,7 +46,7 @@ struct MbParams {
   // conv on an im2col image of the tile built in LDS (K = 9*Cimg <= 32); H, W are the stem-output grid.
   int stem, Himg, Wimg, Cimg;
   int hc;                    // hidden channels per chunk (32 | 64)
-  int ts;                    // output tile side (8 | 16)
+  int ts, tsw;               // output tile rows x columns: 8x8 | 16x16 | 8x16
   unsigned long long* dbg;  // SSDK_MB_DBG=1: cycle stamps of workgroup 0 (debug builds of the schedule only)
 };
 
@@ -90,7 +90,7 @@ constexpr int sb_of(int hc) { return hc * 10; }
 // E (expanded) and D (depthwise output) are INTERNAL tensors: they are kept in fp16 whatever the model
 // dtype (values are ReLU6-bounded, fp16 carries 3 more mantissa bits than bf16), so P2 runs on packed
 // fp16 math (v_pk_fma_f16: 2 channels per instruction) and P3 on the f16 MFMA with fp16 projection weights.
-template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = false, int HC = 32, int TS = 8>
+template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = false, int HC = 32, int TS = 8, int TSW = TS>
 __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   constexpr int ES = es_of(HC);
   constexpr int NJ = HC / 16;   // n-frags of the expand GEMM per chunk
@@ -100,10 +100,12 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   // TS x TS output pixels per workgroup.  16 x 16 (stride-1 blocks on large maps) quarters the phases (barriers,
   // LDS round trips) per pixel, shrinks the halo overhead of the expand GEMM from 1.56x to 1.27x and lets the
   // depthwise phase reuse its LDS reads over 1 x 4 pixel strips.
-  static_assert(TS == 8 || (TS == 16 && S == 1 && HC == 32), "16x16 tiles: stride 1, 32-channel chunks");
-  constexpr int OP = TS * TS;                   // output pixels per tile
-  constexpr int RW = TS * S + (3 - S);          // 10 | 18 (s=1) or 17 (s=2) input columns / rows per tile
-  constexpr int P = RW * RW;                   // region pixels
+  // TS x TSW: 8x8 (any block), 16x16 (stride 1, 32-channel chunks) or 8x16 (stride 2: twice the work per phase of 8x8)
+  static_assert((TS == 8 && (TSW == 8 || (TSW == 16 && !STEM))) || (TS == 16 && TSW == 16 && S == 1 && HC == 32), "tile shape");
+  constexpr int OP = TS * TSW;                  // output pixels per tile
+  constexpr int RH = TS * S + (3 - S);          // input rows per tile: 10 | 18 (s=1) or 17 (s=2)
+  constexpr int RW = TSW * S + (3 - S);         // input columns per tile (= row stride of the region): .. | 33 (8x16, s=2)
+  constexpr int P = RH * RW;                   // region pixels
   constexpr int MF = (P + 15) / 16;            // m-frags of the expand GEMM
   constexpr int P16 = MF * 16;
   constexpr int MFW = (MF + kMbWaves - 1) / kMbWaves;                   // m-frags per wave (max)
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
     const int ttx = (int)(t % (u32)p.tiles_x);
     t /= (u32)p.tiles_x;
     toy0 = (int)(t % (u32)p.tiles_y) * TS;
-    tox0 = ttx * TS;
+    tox0 = ttx * TSW;
     tn = (int)(t / (u32)p.tiles_y);
   };
   const int KS = (Cin + 31) / 32;
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
     __syncthreads();
     MB_STAMP();
     // ---- P2: depthwise 3x3 stride S on the chunk, packed fp16 (4 channels per lane) -> sD ----------------
-    if constexpr (TS == 8) {
+    if constexpr (TS == 8 && TSW == 8) {
       const h2 zero = {(_Float16)0.f, (_Float16)0.f}, six = {(_Float16)6.f, (_Float16)6.f};
       h2 acc0[NI], acc1[NI];
 #pragma unroll
@@ -486,6 +488,30 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
         const h2 v0 = __builtin_elementwise_min(__builtin_elementwise_max(acc0[it] + as_h2(bv.x), zero), six);
         const h2 v1 = __builtin_elementwise_min(__builtin_elementwise_max(acc1[it] + as_h2(bv.y), zero), six);
         *reinterpret_cast<uint2*>(sD + (size_t)d_px * ES + cg * 8) =
+            make_uint2(__builtin_bit_cast(u32, v0), __builtin_bit_cast(u32, v1));
+      }
+    } else if constexpr (TS == 8) {  // 8x16 tile: the 8x8 mapping, two pixel groups of 64 per thread
+      static_assert(HC == 32, "8x16 tiles: 32-channel chunks");
+      const h2 zero = {(_Float16)0.f, (_Float16)0.f}, six = {(_Float16)6.f, (_Float16)6.f};
+#pragma unroll
+      for (int pp = 0; pp < OP / 64; ++pp) {
+        const u32 px = d_px + 64u * pp;
+        const u32 poy = px / (u32)TSW, pox = px % (u32)TSW;
+        h2 acc0 = zero, acc1 = zero;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int rp = ((int)poy * S + ky) * RW + (int)pox * S + kx;
+            const uint2 ev = *reinterpret_cast<const uint2*>(sE + (size_t)rp * ES + d_cg * 8);
+            const uint2 wv = *reinterpret_cast<const uint2*>(wcur + p.off_wd + (ky * 3 + kx) * (HC * 2) + d_cg * 8);
+            acc0 = __builtin_elementwise_fma(as_h2(ev.x), as_h2(wv.x), acc0);
+            acc1 = __builtin_elementwise_fma(as_h2(ev.y), as_h2(wv.y), acc1);
+          }
+        const uint2 bv = *reinterpret_cast<const uint2*>(wcur + p.off_sb + HC * 8 + d_cg * 8);
+        const h2 v0 = __builtin_elementwise_min(__builtin_elementwise_max(acc0 + as_h2(bv.x), zero), six);
+        const h2 v1 = __builtin_elementwise_min(__builtin_elementwise_max(acc1 + as_h2(bv.y), zero), six);
+        *reinterpret_cast<uint2*>(sD + (size_t)px * ES + d_cg * 8) =
             make_uint2(__builtin_bit_cast(u32, v0), __builtin_bit_cast(u32, v1));
       }
     } else {
@@ -555,10 +581,10 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
 #pragma unroll
   for (int mi = 0; mi < MPW; ++mi) {
     const int q = (int)(m_base + mi) * 16 + (int)fr;  // output pixel inside the tile
-    const int oy = oy0 + q / TS, ox = ox0 + q % TS;
+    const int oy = oy0 + q / TSW, ox = ox0 + q % TSW;
     if (oy < p.Ho && ox < p.Wo) {
       u16* yrow = p.y + (((size_t)n * p.Ho + oy) * p.Wo + ox) * Cout;
-      const unsigned char* xres = sX + (size_t)(((q / TS) * S + 1) * RW + (q % TS) * S + 1) * XS;
+      const unsigned char* xres = sX + (size_t)(((q / TSW) * S + 1) * RW + (q % TSW) * S + 1) * XS;
 #pragma unroll
       for (int jj = 0; jj < NFH; ++jj) {
         const int co = ((int)n_half + NSPLIT * jj) * 16 + (int)fg * 4;
@@ -592,6 +618,14 @@ static void launch_one(const MbParams& p, size_t lds, unsigned grid, hipStream_t
       return;
     }
   }
+  if constexpr (S == 2 && !STEM && KSMAX <= 1 && NFO <= 4) {  // the instantiations that exist with 8x16 tiles
+    if (p.ts == 8 && p.tsw == 16) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 32, 8, 16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 32, 8, 16>), dim3(grid), dim3(kMbThreads), lds, stream, p);
+      return;
+    }
+  }
   if (p.hc == 64) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 64>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -620,7 +654,7 @@ static int launch_mb(const MbParams& p, int ks, int nfo, size_t lds, unsigned gr
   if (resident && ks <= 1 && nfo <= 4) {  // small-channel, high-resolution blocks: persistent grid, resident weights
     if (nfo <= 2) launch_one<DT, S, 2, 1, false, true>(p, lds, grid, stream);
     else launch_one<DT, S, 4, 1, false, true>(p, lds, grid, stream);
-    return check_launch(p.ts == 16 ? "mbconv_kernel(resident, 16x16)" : "mbconv_kernel(resident)");
+    return check_launch(p.ts == 16 ? "mbconv_kernel(resident, 16x16)" : p.tsw == 16 ? "mbconv_kernel(resident, 8x16)" : "mbconv_kernel(resident)");
   }
   if (ks <= 1 && nfo <= 2) launch_one<DT, S, 2, 1>(p, lds, grid, stream);
   else if (ks <= 1 && nfo <= 4) launch_one<DT, S, 4, 1>(p, lds, grid, stream);
@@ -630,7 +664,7 @@ static int launch_mb(const MbParams& p, int ks, int nfo, size_t lds, unsigned gr
   else if (ks <= 3 && nfo <= 10) launch_one<DT, S, 10, 3>(p, lds, grid, stream);
   else if (nfo <= 10) launch_one<DT, S, 10, 5>(p, lds, grid, stream);
   else launch_one<DT, S, 20, 5>(p, lds, grid, stream);
-  return check_launch(p.ts == 16 ? "mbconv_kernel(16x16)" : "mbconv_kernel");
+  return check_launch(p.ts == 16 ? "mbconv_kernel(16x16)" : p.tsw == 16 ? "mbconv_kernel(8x16)" : "mbconv_kernel");
 }
 
 }  // namespace ssdk
@@ -702,12 +736,22 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
     const bool can16 = d->stride == 1 && nfo16 <= env_nfo && (stem || ks16 <= env_ks);
     p.ts = (can16 && env_ts != 8 && (tiles16 >= env_min || env_ts == 16)) ? 16 : 8;
   }
-  p.tiles_x = (p.Wo + p.ts - 1) / p.ts;
+  p.tsw = p.ts;
+  {  // 8x16 tiles for stride-2 blocks with <= 32 input channels and a long chunk loop (>= 6 chunks): twice the work per
+     // phase of 8x8 but one workgroup per CU instead of two -- measured 47 -> 41 us at 192 hidden channels, a LOSS at 96 / 144
+    static const int env_816 = getenv("SSDK_MB_8X16") ? atoi(getenv("SSDK_MB_8X16")) : 1;
+    const long tiles816 = (long)d->N * ((p.Wo + 15) / 16) * ((p.Ho + 7) / 8);
+    if (env_816 && p.ts == 8 && env_ts == 0 && d->stride == 2 && !stem && d->Cin <= 32 && (d->Cout + 15) / 16 <= 4 &&
+        ((tiles816 >= 256 && d->Chid >= 192) || env_816 == 2))
+      p.tsw = 16;
+  }
+  p.tiles_x = (p.Wo + p.tsw - 1) / p.tsw;
   p.tiles_y = (p.Ho + p.ts - 1) / p.ts;
   const int cpr = p.Cin / 8;
   p.xs = p.Cin * 2 + ((cpr % 2 == 0) ? 16 : 0);  // odd number of 16-byte slots per row
-  const int rw = p.ts * d->stride + (3 - d->stride);
-  const int p16 = ((rw * rw + 15) / 16) * 16;
+  const int rw = p.ts * d->stride + (3 - d->stride);  // region rows (stem: square)
+  const int rww = p.tsw * d->stride + (3 - d->stride);
+  const int p16 = ((rw * rww + 15) / 16) * 16;
   const int nfo_t = (d->Cout + 15) / 16;
   const int nfo_inst = nfo_t <= 2 ? 2 : nfo_t <= 4 ? 4 : nfo_t <= 6 ? 6 : nfo_t <= 10 ? 10 : 20;
   p.wes = p.xs;
@@ -727,7 +771,7 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
     resident = env_res && (ks_t <= 1 || stem) && nfo_inst <= 4 && (size_t)nch * p.wbuf <= 56 * 1024;
     const int pr = 2 * rw + 1;
     const size_t sx = stem ? (size_t)(((pr * (pr + 1) + 8) * 8 + 15) & ~15) : (size_t)p16 * p.xs;
-    return sx + (size_t)p16 * es + (size_t)(p.ts * p.ts) * es + (resident ? (size_t)nch : 2) * (size_t)p.wbuf;
+    return sx + (size_t)p16 * es + (size_t)(p.ts * p.tsw) * es + (resident ? (size_t)nch : 2) * (size_t)p.wbuf;
   };
   // SSDK_MB_HC = 32 | 64 forces the chunk width (A/B switch); 0 = the per-block rule below.
   size_t lds;
@@ -737,7 +781,7 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
     // 64-channel chunks halve the phases per hidden channel but cost LDS (occupancy): measured per block on
     // SSD-MobileNetV2@512 they win from Cin = 96 on (long chunk loops, one workgroup per CU anyway) and lose below
     const bool want64 = env_hc == 64 || (env_hc == 0 && !stem && p.Cin >= 96);
-    const int hc = (want64 && p.ts == 8 && l64 <= 160 * 1024) ? 64 : 32;  // (16x16 tiles exist with 32 only)
+    const int hc = (want64 && p.ts == 8 && p.tsw == 8 && l64 <= 160 * 1024) ? 64 : 32;  // (16x16 tiles exist with 32 only)
     lds = layout(hc);
     if (p.ts == 16 && resident && lds > 80 * 1024) {  // two workgroups per CU beat resident weights
       const int nch = (d->Chid + hc - 1) / hc;
@@ -787,8 +831,8 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
     unsigned long long h[64];
     (void)hipStreamSynchronize(stream);
     (void)hipMemcpy(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[mbconv dbg] Cin=%d Chid=%d Cout=%d s=%d stem=%d res=%d ts=%d tiles=%dx%d grid=%u lds=%zu :", d->Cin,
-            d->Chid, d->Cout, d->stride, p.stem, (int)resident, p.ts, p.tiles_x, p.tiles_y, grid, lds);
+    fprintf(stderr, "[mbconv dbg] Cin=%d Chid=%d Cout=%d s=%d stem=%d res=%d ts=%dx%d tiles=%dx%d grid=%u lds=%zu :", d->Cin,
+            d->Chid, d->Cout, d->stride, p.stem, (int)resident, p.ts, p.tsw, p.tiles_x, p.tiles_y, grid, lds);
     for (int i = 1; i < 60 && h[i]; ++i) fprintf(stderr, " %llu", h[i] - h[i - 1]);
     fprintf(stderr, "\n");
   }
