@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
         sev[jf] = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + (jf * 16 + fg * 4) * 4);
         bev[jf] = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + HC * 4 + (jf * 16 + fg * 4) * 4);
       }
-      if constexpr (TS == 16) {  // (measured: the same restructuring LOSES on the 8x8 stride-2 instances -- VGPRs / occupancy)
+      if constexpr (TS == 16 || TSW == 16) {  // (measured: the same restructuring LOSES on the 8x8 stride-2 instances -- VGPRs / occupancy)
         // 16x16 tiles: 3 m-frags per wave.  Weight fragments are shared by them and loaded once; all operand reads
         // are issued before the first MFMA and all results are written after the last one, so the three dependent
         // LDS -> MFMA -> LDS chains overlap instead of running back to back.
