@@ -1228,8 +1228,8 @@ static hipEvent_t g_fork[32], g_join;
 static bool g_side_ready = false;
 
 static bool side_init() {
-  // default off: measured neutral on SSD-MobileNetV2@512 (the concurrent kernels share the same CUs and the split-K
-  // hand-offs of the small heads slow down under concurrency); kept for wider / deeper heads (SSDK_SIDE_STREAM=1)
+  // default off: measured +0.6 % on SSD-MobileNetV2@512 with only the small heads (levels 2..5) on the side lane, neutral
+  // with all heads (the big levels compete for the same CUs) -- not worth a second stream by default (SSDK_SIDE_STREAM=1)
   static const int env = getenv("SSDK_SIDE_STREAM") ? atoi(getenv("SSDK_SIDE_STREAM")) : 0;
   if (!env) return false;
   if (!g_side_ready) {

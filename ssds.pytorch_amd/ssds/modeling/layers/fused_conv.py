@@ -545,7 +545,10 @@ class ConvPlan(object):
                 f.dtype = self.dtype_code
                 continue
             op.kind = N.OP_CONV
-            op.lane = 1 if L["nchw"] else 0  # heads are leaves: side stream when enabled
+            # small heads are leaves of latency-bound work: they may run on the executor's side stream next to the
+            # extras chain (SSDK_SIDE_STREAM=1); the big levels fill the chip on their own and stay in line
+            ho_, wo_ = _out_hw(L["h"], L["w"], L["pack"].k, L["pack"].stride)
+            op.lane = 1 if (L["nchw"] and L["n"] * ho_ * wo_ <= 4096) else 0
             y_ptr = self.arena.ptr(L["y"]) if L["y"] is not None else 0
             res_ptr = self._ptr(L["res"], self.patches, i, "conv.residual") if L["res"] is not None else None
             fill_desc(op.conv, self._ptr(L["x"], self.patches, i, "conv.x"), L["n"], L["h"], L["w"], L["pack"],
