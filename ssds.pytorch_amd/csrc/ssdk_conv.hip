@@ -958,6 +958,8 @@ extern "C" size_t ssdk_conv_workspace_bytes(int N, int Cin, int H, int W, int Co
   return need;
 }
 
+static thread_local bool g_underfill_ok = false;  // set by ssdk_run_ops around side-lane ops
+
 extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!d || !d->x || !d->w || !d->bias || !d->y) {
@@ -1120,6 +1122,13 @@ extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t worksp
   p.kt_per = p.KT;
   p.slabs = nullptr;
   p.counters = nullptr;
+  // Side-lane ops (small heads running next to the extras chain) prefer the halo kernel however few tiles they have:
+  // an underfilled grid is free there, and unlike the split-K kernels it has no agent-scope fences, which slow down
+  // every kernel running concurrently (measured: split-K heads on the side lane +0.6 %, halo heads +2.7 %).
+  if (g_underfill_ok) {
+    const int rc = launch_conv3x3_halo(p, d->dtype, stream, true);
+    if (rc != 1) return rc;
+  }
   {
     int ws = 1, wk = p.KT, mt = 0, ntl = 0;
     if (wave_plan(M, d->Cin, d->Cout, d->k, &ws, &wk, &mt, &ntl)) {
@@ -1155,7 +1164,7 @@ extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t worksp
     }
   }
   {
-    const int rc = launch_conv3x3_halo(p, d->dtype, stream);  // 3x3 stride-1 layers with enough tiles
+    const int rc = launch_conv3x3_halo(p, d->dtype, stream, false);  // 3x3 stride-1 layers with enough tiles
     if (rc != 1) return rc;
   }
   return d->dtype == SSDK_BF16 ? launch_gemm<SSDK_BF16>(p, stream) : launch_gemm<SSDK_F16>(p, stream);
@@ -1228,9 +1237,8 @@ static hipEvent_t g_fork[32], g_join;
 static bool g_side_ready = false;
 
 static bool side_init() {
-  // default off: measured +0.6 % on SSD-MobileNetV2@512 with only the small heads (levels 2..5) on the side lane, neutral
-  // with all heads (the big levels compete for the same CUs) -- not worth a second stream by default (SSDK_SIDE_STREAM=1)
-  static const int env = getenv("SSDK_SIDE_STREAM") ? atoi(getenv("SSDK_SIDE_STREAM")) : 0;
+  // measured on SSD-MobileNetV2@512: +2.7 % with the small heads (levels 2..5) on the side lane; SSDK_SIDE_STREAM=0 = in line
+  static const int env = getenv("SSDK_SIDE_STREAM") ? atoi(getenv("SSDK_SIDE_STREAM")) : 1;
   if (!env) return false;
   if (!g_side_ready) {
     if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) return false;
@@ -1280,7 +1288,11 @@ extern "C" int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t w
       wb = ws_side_bytes;
     }
     int rc;
-    if (ops[i].kind == SSDK_OP_CONV) rc = ssdk_conv(&ops[i].conv, w, wb, st);
+    if (ops[i].kind == SSDK_OP_CONV) {
+      g_underfill_ok = side;
+      rc = ssdk_conv(&ops[i].conv, w, wb, st);
+      g_underfill_ok = false;
+    }
     else if (ops[i].kind == SSDK_OP_MBCONV) rc = ssdk_mbconv(&ops[i].mb, st);
     else if (ops[i].kind == SSDK_OP_FUSE) rc = ssdk_fuse(&ops[i].fuse, st);
     else if (ops[i].kind == SSDK_OP_STEM7) rc = ssdk_conv_stem7(&ops[i].stem, st);

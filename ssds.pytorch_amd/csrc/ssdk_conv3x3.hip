@@ -410,7 +410,7 @@ static bool plan_patch(int N, int Ho, int Wo, HaloParams* hp) {
   return true;
 }
 
-int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream) {
+int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool allow_underfill) {
   static const int env = getenv("SSDK_CONV3X3_HALO") ? atoi(getenv("SSDK_CONV3X3_HALO")) : 1;
   if (!env || p.k != 3 || p.stride != 1 || p.pad != 1 || (p.Cin % 8) || p.ksplits > 1) return 1;
   if (p.Cout < 96 || p.Cin < 32) return 1;
@@ -431,7 +431,7 @@ int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream) {
   hp.x_bytes = (unsigned)xb;
   hp.w_bytes = (unsigned)wb;
   const long tiles = (long)hp.groups * hp.tiles_y * hp.tiles_x * hp.n_tiles;
-  if (env != 2 && tiles < 96) return 1;  // too few tiles to fill the chip: the split-K path is faster
+  if (env != 2 && !allow_underfill && tiles < 96) return 1;  // too few tiles to fill the chip: the split-K path is faster
   if (tiles >= (1l << 26)) return 1;  // keeps tile-id * divisor < 2^32 for the magic divisions
   static bool attr_done[2] = {false, false};
   const int di = dtype == SSDK_BF16 ? 0 : 1;

@@ -176,6 +176,6 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
 int launch_gconv3x3_g16(const ssdk_conv_desc* d, int Ho, int Wo, hipStream_t stream);
 
 // halo-tile 3x3 kernel (ssdk_conv3x3.hip); returns SSDK_OK, or 1 when the layer does not fit it
-int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream);
+int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool allow_underfill);
 
 }  // namespace ssdk
