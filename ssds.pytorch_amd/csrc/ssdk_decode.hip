@@ -398,11 +398,12 @@ static int make_plan(const ssdk_level* lv, int L, int B, int dtype, int K, Decod
     pl->n[l] = (u32)n;
     tiles_total += (n + vec + tile - 1) / tile;
   }
-  // unit size: enough workgroups to fill 256 CUs x 4 resident, but units as large as possible so that
-  // the per-unit prune/select and the K keys written per unit amortise.
+  // unit size: enough workgroups to keep 256 CUs streaming, but units as large as possible so that the per-unit
+  // prunes / final select and the K keys written per unit (and merged again by level_kernel) amortise.  Measured on
+  // SSD-MobileNetV2@512 batch 64: 32 tiles per unit (640 workgroups) 45 us, 21 tiles (1024 workgroups) 55 us.
   int tpu = env_int("SSDK_TILES_PER_UNIT", 0);
   if (tpu <= 0) {
-    const unsigned long long target_wgs = (unsigned long long)env_int("SSDK_TARGET_WGS", 1024);
+    const unsigned long long target_wgs = (unsigned long long)env_int("SSDK_TARGET_WGS", 640);
     unsigned long long t = (tiles_total * (unsigned long long)B + target_wgs - 1) / target_wgs;
     tpu = (int)(t < 4 ? 4 : (t > 64 ? 64 : t));
   }
