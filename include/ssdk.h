@@ -143,6 +143,24 @@ int ssdk_match_targets_by_scale(const float* targets, int B, int G, const float*
                                 int center_sampling, float* cls_target, float* box_target, float* depth,
                                 void* stream);
 
+/* Target assignment fused with the training losses of ONE level: replaces, for the whole batch,
+ * extract_targets (box.py:362-405) + FocalLoss (core/criterion.py:74-108) + SmoothL1Loss (criterion.py:111-151) +
+ * the depth masks and sums of ModelWithLossBasic.forward (pipeline/pipeline_anchor_apex.py:48-66).  The three
+ * target tensors are never materialised: a thread matches its anchor exactly as ssdk_match_targets[_by_scale]
+ * does, reads the C class logits and 4 box regressions of that anchor, and writes
+ *   d_conf = d(sum of masked focal terms)/d conf,  d_loc = d(sum of masked smooth-L1 terms)/d loc
+ * (same shape/dtype as conf [B, A*C, H, W] / loc [B, A*4, H, W], NCHW contiguous; fp32 arithmetic), and
+ *   sums[0] = sum_{depth>=0} focal,  sums[1] = sum_{depth>0} smooth-L1,  sums[2] = #(depth>0)
+ * reduced in a fixed order (bit-reproducible).  by_scale = 0: thr_a/thr_b = match/unmatch IoU thresholds and
+ * `radius` the centre-sampling radius; by_scale = 1: thr_a/thr_b = lower/upper scale multipliers and radius != 0
+ * turns centre sampling on.  The caller divides by the foreground count summed over levels (:69-71) and scales
+ * the gradients by the incoming scalar.  dtype = SSDK_F32 | SSDK_BF16 | SSDK_F16 of conf/loc/d_conf/d_loc. */
+size_t ssdk_match_loss_workspace_bytes(int B, int A, int H, int W);
+int ssdk_match_loss(const float* targets, int B, int G, const float* anchors, int A, int C, int H, int W,
+                    int stride, int by_scale, float thr_a, float thr_b, float radius, const void* conf,
+                    const void* loc, int dtype, float alpha, float gamma, float beta, void* d_conf,
+                    void* d_loc, float* sums, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Fused convolution + folded BatchNorm + activation (+ residual) for the detector network:
  * basic_layers.py:5-57 (SepConvBNReLU / ConvBNReLU / ConvBNReLUx2), the MobileNetV2 blocks behind
  * nets/mobilenet.py:56-99, and the bare multibox head convs ssd.py:100-103 / fpn.py:10-18.

@@ -10,7 +10,7 @@
 // by_scale = 1 selects box.snap_to_anchors_by_scale (reference box.py:229-359, FCOS-style): a ground-truth box
 // is a candidate for a grid point when the point lies inside it (or inside its centre region) and the box's
 // regression range (or sqrt-area) falls in [lo, hi] * sqrt(anchor area); the smallest candidate wins.
-#include "ssdk_common.h"
+#include "ssdk_conv_common.h"
 
 namespace ssdk {
 
@@ -26,12 +26,34 @@ struct MatchParams {
   float* cls_target;  // [B, A, C, H, W]
   float* box_target;  // [B, A, 4, H, W]
   float* depth;       // [B, A, 1, H, W]
+  // fused loss mode (match_loss_kernel): logits in, gradients + per-workgroup partial sums out
+  const void* conf;  // [B, A, C, H, W] logits
+  const void* loc;   // [B, A, 4, H, W]
+  void* d_conf;      // same shapes / dtype: d(sum cls loss)/d conf, d(sum loc loss)/d loc
+  void* d_loc;
+  float* partial;    // [gridDim.y * gridDim.x, 3]: cls sum, loc sum, #foreground
+  float alpha, gamma, beta;
 };
 
 struct GtRow {
   float x1, y1, x2, y2, area, label, pad0, pad1;
 };
 
+template <int DT>
+__device__ __forceinline__ float ld_elem(const void* p, size_t i) {
+  if constexpr (DT == SSDK_F32) return ((const float*)p)[i];
+  else return bits16_to_f32<DT>(((const u16*)p)[i]);
+}
+template <int DT>
+__device__ __forceinline__ void st_elem(void* p, size_t i, float v) {
+  if constexpr (DT == SSDK_F32) ((float*)p)[i] = v;
+  else ((u16*)p)[i] = f32_to_bits16<DT>(v);
+}
+
+// LOSS = 0: write the three target tensors.  LOSS = 1: never materialise them -- evaluate the focal and smooth-L1
+// terms of this anchor against the logits (criterion.py:74-151, masks of pipeline_anchor_apex.py:55-66), write the
+// closed-form gradients and reduce (cls sum, loc sum, #foreground) per workgroup in a fixed order.
+template <int LOSS, int DT>
 __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams p) {
   __shared__ GtRow gt[SSDK_MAX_GT];
   __shared__ float s_anchor[SSDK_MAX_ANCHORS * 4];
@@ -76,22 +98,21 @@ __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams 
   const u32 HW = (u32)(p.H * p.W);
   const u32 total = (u32)p.A * HW;
   const u32 t = blockIdx.x * kMatchThreads + tid;
-  if (t >= total) return;
+  float s_cls = 0.f, s_loc = 0.f, s_fg = 0.f;  // LOSS: this anchor's terms
+  if (t < total) {
   const u32 a = t / HW;
   const u32 yx = t % HW;
   const u32 iy = yx / (u32)p.W, ix = yx % (u32)p.W;
 
-  float* cls_o = p.cls_target + (((size_t)b * p.A + a) * p.C) * HW + yx;
-  float* box_o = p.box_target + (((size_t)b * p.A + a) * 4) * HW + yx;
+  const size_t cls_i = (((size_t)b * p.A + a) * p.C) * HW + yx;
+  const size_t box_i = (((size_t)b * p.A + a) * 4) * HW + yx;
+  float* cls_o = p.cls_target + cls_i;
+  float* box_o = p.box_target + box_i;
   float* dep_o = p.depth + ((size_t)b * p.A + a) * HW + yx;
 
-  if (ng == 0) {  // box.py:133-146
-    for (int c = 0; c < p.C; ++c) cls_o[(size_t)c * HW] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) box_o[(size_t)k * HW] = 0.f;
-    dep_o[0] = 0.f;
-    return;
-  }
+  float dep = 0.f, delta[4] = {0.f, 0.f, 0.f, 0.f};
+  int lab = p.C;
+  if (ng != 0) {  // (ng == 0: box.py:133-146, all-zero targets)
 
   const float fx = (float)(ix * (u32)p.stride), fy = (float)(iy * (u32)p.stride);  // box.py:151-156
   const float ax1 = fx + s_anchor[a * 4 + 0], ay1 = fy + s_anchor[a * 4 + 1];     // box.py:157-159
@@ -158,13 +179,12 @@ __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams 
   const float acx = ax1 + 0.5f * aw, acy = ay1 + 0.5f * ah;
   const float bw = q.x2 - q.x1 + 1.0f, bh = q.y2 - q.y1 + 1.0f;
   const float bcx = q.x1 + 0.5f * bw, bcy = q.y1 + 0.5f * bh;
-  box_o[0] = (bcx - acx) / aw;
-  box_o[(size_t)HW] = (bcy - acy) / ah;
-  box_o[(size_t)2 * HW] = logf(bw / aw);
-  box_o[(size_t)3 * HW] = logf(bh / ah);
+  delta[0] = (bcx - acx) / aw;
+  delta[1] = (bcy - acy) / ah;
+  delta[2] = logf(bw / aw);
+  delta[3] = logf(bh / ah);
 
-  float dep = -1.0f;  // box.py:177-182
-  int lab;
+  dep = -1.0f;  // box.py:177-182
   if (p.by_scale) {  // box.py:328-330, 340: no ignore band
     dep = inside ? q.label + 1.0f : 0.f;
     lab = inside ? (int)(long long)q.label : p.C;
@@ -175,9 +195,102 @@ __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams 
     // box.py:195-207: one-hot at the matched label unless background (overlap < unmatch threshold)
     lab = (best < p.lo) ? p.C : (int)(long long)q.label;
   }
-  dep_o[0] = dep;
+  }  // ng != 0
 
-  for (int c = 0; c < p.C; ++c) cls_o[(size_t)c * HW] = (c == lab) ? 1.0f : 0.f;
+  if constexpr (LOSS == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) box_o[(size_t)k * HW] = delta[k];
+    dep_o[0] = dep;
+    for (int c = 0; c < p.C; ++c) cls_o[(size_t)c * HW] = (c == lab) ? 1.0f : 0.f;
+  } else {
+    // focal loss on logits (criterion.py:74-108), masked by depth >= 0 (pipeline_anchor_apex.py:55-58):
+    //   t=1: L = -alpha (1-p)^g log p        dL/dz = alpha (1-p)^g (g p log p - (1-p))
+    //   t=0: L = -(1-alpha) p^g log(1-p)     dL/dz = (1-alpha) p^g (p - g (1-p) log(1-p))
+    const bool care = dep >= 0.f;
+    const bool g2 = p.gamma == 2.0f;
+    for (int c = 0; c < p.C; ++c) {
+      const size_t i = cls_i + (size_t)c * HW;
+      const float z = ld_elem<DT>(p.conf, i);
+      const float e = __expf(-fabsf(z));                 // exp(-|z|) in (0, 1]
+      const float inv = 1.0f / (1.0f + e);
+      const float pr = z >= 0.f ? inv : e * inv;         // sigmoid(z)
+      const float qr = z >= 0.f ? e * inv : inv;         // 1 - sigmoid(z), no cancellation
+      const float l1p = log1pf(e);
+      const float logp = -(l1p + (z < 0.f ? -z : 0.f));  // log sigmoid(z)
+      const float logq = -(l1p + (z > 0.f ? z : 0.f));   // log (1 - sigmoid(z))
+      const bool pos = c == lab;
+      const float u = pos ? qr : pr;                     // 1 - p_t
+      const float v = pos ? pr : qr;                     // p_t
+      const float lg = pos ? logp : logq;                // log p_t
+      const float w = pos ? p.alpha : 1.0f - p.alpha;
+      const float ug = g2 ? u * u : (u > 0.f ? __powf(u, p.gamma) : 0.f);
+      const float loss = -w * ug * lg;
+      float grad = w * ug * (p.gamma * v * lg - u);      // d/dz for t=1; the t=0 case is its mirror image
+      grad = pos ? grad : -grad;
+      s_cls += care ? loss : 0.f;
+      st_elem<DT>(p.d_conf, i, care ? grad : 0.f);
+    }
+    // smooth-L1 (criterion.py:111-151) masked by depth > 0 (pipeline_anchor_apex.py:62-66)
+    const bool fg = dep > 0.f;
+    const float rb = 1.0f / p.beta;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t i = box_i + (size_t)k * HW;
+      const float d = ld_elem<DT>(p.loc, i) - delta[k];
+      const float x = fabsf(d);
+      const bool lin = x >= p.beta;
+      const float loss = lin ? x - 0.5f * p.beta : 0.5f * x * x * rb;
+      const float grad = lin ? (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.f)) : d * rb;
+      s_loc += fg ? loss : 0.f;
+      st_elem<DT>(p.d_loc, i, fg ? grad : 0.f);
+    }
+    s_fg = fg ? 1.0f : 0.f;
+  }
+  }  // t < total
+
+  if constexpr (LOSS == 1) {  // fixed-order workgroup reduction -> one partial row per workgroup
+    __shared__ float red[kMatchThreads / 64][3];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      s_cls += __shfl_xor(s_cls, o);
+      s_loc += __shfl_xor(s_loc, o);
+      s_fg += __shfl_xor(s_fg, o);
+    }
+    if (lane == 0) {
+      red[wave][0] = s_cls;
+      red[wave][1] = s_loc;
+      red[wave][2] = s_fg;
+    }
+    __syncthreads();
+    if (tid < 3) {
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < kMatchThreads / 64; ++w) acc += red[w][tid];
+      p.partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + tid] = acc;
+    }
+  }
+}
+
+// sums the per-workgroup rows in index order (one workgroup, fixed tree): sums[0..2] = cls, loc, #foreground
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* partial, int rows, float* sums) {
+  __shared__ float red[4][3];
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int r = (int)tid; r < rows; r += 256) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[k] += partial[(size_t)r * 3 + k];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[k] += __shfl_xor(acc[k], o);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) red[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (tid < 3) sums[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
 }  // namespace ssdk
@@ -216,7 +329,7 @@ static int launch_match(const char* what, int by_scale, const float* targets, in
   p.depth = depth;
   const unsigned total = (unsigned)A * H * W;
   dim3 grid((total + kMatchThreads - 1) / kMatchThreads, (unsigned)B);
-  hipLaunchKernelGGL(match_kernel, grid, dim3(kMatchThreads), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL((match_kernel<0, SSDK_F32>), grid, dim3(kMatchThreads), 0, (hipStream_t)stream, p);
   return check_launch("match_kernel");
 }
 }  // namespace ssdk
@@ -237,4 +350,77 @@ extern "C" int ssdk_match_targets_by_scale(const float* targets, int B, int G, c
   return ssdk::launch_match("match_targets_by_scale", 1, targets, B, G, anchors, A, C, H, W, stride,
                             upper_scale, lower_scale, center_sampling ? 1.5f : 0.f, cls_target, box_target,
                             depth, stream);
+}
+
+// ---- fused target assignment + losses -----------------------------------------------------------
+extern "C" size_t ssdk_match_loss_workspace_bytes(int B, int A, int H, int W) {
+  if (B < 1 || A < 1 || H < 1 || W < 1) return 0;
+  const size_t wgs = ((size_t)A * H * W + ssdk::kMatchThreads - 1) / ssdk::kMatchThreads;
+  return wgs * (size_t)B * 3 * sizeof(float);
+}
+
+extern "C" int ssdk_match_loss(const float* targets, int B, int G, const float* anchors, int A, int C, int H,
+                               int W, int stride, int by_scale, float thr_a, float thr_b, float radius,
+                               const void* conf, const void* loc, int dtype, float alpha, float gamma,
+                               float beta, void* d_conf, void* d_loc, float* sums, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  using namespace ssdk;
+  if (!targets || !anchors || !conf || !loc || !d_conf || !d_loc || !sums || !workspace) {
+    set_error("match_loss: null pointer");
+    return SSDK_E_BADARG;
+  }
+  if (B < 1 || G < 0 || G > SSDK_MAX_GT || A < 1 || A > SSDK_MAX_ANCHORS || C < 1 || H < 1 || W < 1 ||
+      stride < 1 || !(beta > 0.f)) {
+    set_error("match_loss: bad dims B=%d G=%d (<=%d) A=%d (<=%d) C=%d H=%d W=%d stride=%d beta=%g", B, G,
+              SSDK_MAX_GT, A, SSDK_MAX_ANCHORS, C, H, W, stride, (double)beta);
+    return SSDK_E_BADARG;
+  }
+  if (dtype != SSDK_F32 && dtype != SSDK_BF16 && dtype != SSDK_F16) {
+    set_error("match_loss: dtype %d not supported", dtype);
+    return SSDK_E_BADARG;
+  }
+  if (workspace_bytes < ssdk_match_loss_workspace_bytes(B, A, H, W)) {
+    set_error("match_loss: workspace too small");
+    return SSDK_E_BADARG;
+  }
+  MatchParams p;
+  memset(&p, 0, sizeof(p));
+  p.targets = targets;
+  p.G = G;
+  p.A = A;
+  p.C = C;
+  p.H = H;
+  p.W = W;
+  p.stride = stride;
+  p.by_scale = by_scale ? 1 : 0;
+  if (by_scale) {  // thr_a / thr_b = lower / upper scale multipliers, radius != 0 = centre sampling (radius 1.5)
+    p.lo = thr_a;
+    p.hi = thr_b;
+    radius = radius > 0.f ? 1.5f : 0.f;
+  } else {  // thr_a / thr_b = match / unmatch IoU thresholds
+    p.hi = thr_a;
+    p.lo = thr_b;
+  }
+  p.use_radius = radius > 0.f;
+  p.radius_px = (float)((double)stride * (double)radius);
+  memcpy(p.anchors, anchors, sizeof(float) * 4 * A);
+  p.conf = conf;
+  p.loc = loc;
+  p.d_conf = d_conf;
+  p.d_loc = d_loc;
+  p.partial = (float*)workspace;
+  p.alpha = alpha;
+  p.gamma = gamma;
+  p.beta = beta;
+  const unsigned total = (unsigned)A * H * W;
+  dim3 grid((total + kMatchThreads - 1) / kMatchThreads, (unsigned)B);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SSDK_BF16) hipLaunchKernelGGL((match_kernel<1, SSDK_BF16>), grid, dim3(kMatchThreads), 0, st, p);
+  else if (dtype == SSDK_F16) hipLaunchKernelGGL((match_kernel<1, SSDK_F16>), grid, dim3(kMatchThreads), 0, st, p);
+  else hipLaunchKernelGGL((match_kernel<1, SSDK_F32>), grid, dim3(kMatchThreads), 0, st, p);
+  int rc = check_launch("match_loss_kernel");
+  if (rc != SSDK_OK) return rc;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)p.partial,
+                     (int)(grid.x * grid.y), sums);
+  return check_launch("loss_finalize_kernel");
 }

@@ -1,7 +1,8 @@
 """Losses on the DDP training path (reference ``ssds/core/criterion.py``): ``FocalLoss`` (:74-108) and
 ``SmoothL1Loss`` (:111-151), element-wise, un-reduced -- the caller masks by ``depth`` and normalises by
-the foreground count (pipeline_anchor_apex.py:55-71).  Plain torch autograd ops on the HIP device; the fused
-target-assign + loss kernel is SURVEY f-1 ("next")."""
+the foreground count (pipeline_anchor_apex.py:55-71).  These modules are the plain torch definition
+(used on CPU by the gloo tests and as the parity reference); on a HIP device ``ModelWithLossBasic`` replaces
+target assignment + both losses + masks + sums by one launch per level (``ssds/core/fused_loss.py``)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F

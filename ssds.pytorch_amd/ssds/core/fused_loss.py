@@ -1,0 +1,70 @@
+"""Target assignment fused with the focal / smooth-L1 losses of one level -- the HIP replacement for
+the per-level body of the reference's ``ModelWithLossBasic.forward`` (pipeline/pipeline_anchor_apex.py:48-66):
+``extract_targets`` (modeling/layers/box.py:362-405), ``FocalLoss`` / ``SmoothL1Loss`` (core/criterion.py:74-151),
+the depth masks and the three sums.  One launch per level reads the logits once and writes their gradients; the
+one-hot / box / depth target tensors and the element-wise loss tensors are never materialised."""
+import ctypes
+
+import torch
+
+from ssds import _native as N
+from ssds.modeling.layers.box import _anchor_array
+
+
+class _MatchLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, conf, loc, targets, anc, classes, stride, by_scale, thr_a, thr_b, radius, alpha, gamma, beta):
+        N.require_device(conf, "match_loss")
+        if loc.dtype != conf.dtype:
+            loc = loc.to(conf.dtype)
+        conf_c, loc_c = conf.contiguous(), loc.contiguous()
+        B, _, H, W = conf_c.shape
+        A = int(anc.shape[0])
+        if conf_c.shape[1] != A * classes or tuple(loc_c.shape) != (B, A * 4, H, W):
+            raise ValueError("match_loss: conf %s / loc %s do not fit %d anchors x %d classes" % (
+                tuple(conf.shape), tuple(loc.shape), A, classes))
+        t = targets.contiguous().float()
+        G = int(t.shape[1])
+        dev = conf_c.device
+        d_conf, d_loc = torch.empty_like(conf_c), torch.empty_like(loc_c)
+        sums = torch.empty(3, device=dev, dtype=torch.float32)
+        ws_bytes = int(N.lib.ssdk_match_loss_workspace_bytes(B, A, H, W))
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        with torch.cuda.device(dev):
+            rc = N.lib.ssdk_match_loss(
+                t.data_ptr(), B, G, anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), A, int(classes), H, W,
+                int(stride), int(by_scale), float(thr_a), float(thr_b), float(radius), conf_c.data_ptr(),
+                loc_c.data_ptr(), N.dtype_code(conf_c), float(alpha), float(gamma), float(beta), d_conf.data_ptr(),
+                d_loc.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws_bytes, N.stream_ptr(dev))
+        N.check(rc, "match_loss")
+        ctx.save_for_backward(d_conf, d_loc)
+        ctx.mark_non_differentiable(sums)
+        cls_sum, loc_sum = sums[0].clone(), sums[1].clone()
+        return cls_sum, loc_sum, sums
+
+    @staticmethod
+    def backward(ctx, g_cls, g_loc, _g_sums):
+        d_conf, d_loc = ctx.saved_tensors
+        # in place: the stored gradients are this node's own buffers and backward runs once
+        gc = d_conf.mul_(g_cls) if g_cls is not None else None  # 0-dim fp32 scale, fp32 arithmetic, dtype kept
+        gl = d_loc.mul_(g_loc) if g_loc is not None else None
+        return (gc, gl) + (None,) * 11
+
+
+def match_loss(conf, loc, targets, anchors, classes, stride, match, center_sampling_radius=0, alpha=0.25, gamma=2.0,
+               beta=0.11):
+    """conf [B, A*C, H, W] logits and loc [B, A*4, H, W] of one level, targets [B, G, 5] (x, y, w, h, label; -1 =
+    padding), ``anchors`` / ``match`` as for ``box.extract_targets``.  Returns (cls_sum, loc_sum, fg): the masked
+    focal sum and smooth-L1 sum (differentiable w.r.t. conf / loc) and the un-clamped foreground count, fp32
+    scalars on the device."""
+    by_scale = isinstance(match[0], list)
+    if not by_scale and not isinstance(match[0], float):
+        raise ValueError("unvalidate match param")
+    anc = _anchor_array(anchors, stride)
+    if by_scale:
+        thr_a, thr_b = match[list(anchors).index(stride)]
+    else:
+        thr_a, thr_b = match[0], match[1]
+    cls_sum, loc_sum, sums = _MatchLoss.apply(conf, loc, targets, anc, int(classes), int(stride), by_scale, thr_a,
+                                              thr_b, float(center_sampling_radius), alpha, gamma, beta)
+    return cls_sum, loc_sum, sums[2]

@@ -77,7 +77,7 @@ class DepthwiseConv2d(nn.Conv2d):
             return super(DepthwiseConv2d, self).forward(x)
         w = self.weight
         if torch.is_autocast_enabled():
-            dt = torch.get_autocast_gpu_dtype()
+            dt = torch.get_autocast_dtype("cuda")
             x, w = x.to(dt), w.to(dt)
         elif w.dtype != x.dtype:
             w = w.to(x.dtype)

@@ -10,11 +10,13 @@
 The reference skips a step on NaN/Inf with a per-rank ``continue`` before backward (:110-111, 126-127),
 which under DDP would leave the other ranks waiting in the all-reduce; here the decision is collective
 (one all-reduced flag) and taken after backward so every rank always joins the gradient all-reduce."""
+import os
 import time
 
 import torch
 import torch.distributed as dist
 
+from ssds.core import criterion as _crit
 from ssds.modeling.layers import box
 
 
@@ -32,10 +34,27 @@ class ModelWithLossBasic(torch.nn.Module):
         self.match = match
         self.center_radius = center_sampling_radius
 
+    def _fused(self, conf):
+        """The fused target-assign + loss kernel applies when the criteria are exactly the reference's FocalLoss /
+        SmoothL1Loss and the heads live on a HIP device (SSDK_FUSED_LOSS=0 keeps the unfused torch ops)."""
+        return (conf[0].is_cuda and type(self.cls_criterion) is _crit.FocalLoss
+                and type(self.loc_criterion) is _crit.SmoothL1Loss and os.environ.get("SSDK_FUSED_LOSS", "1") != "0")
+
     def forward(self, images, targets, anchors):
         loc, conf = self.model(images)
         cls_losses, loc_losses, fg_targets = [], [], []
+        fused = self._fused(conf)
+        if fused:
+            from ssds.core.fused_loss import match_loss
         for j, (stride, anchor) in enumerate(anchors.items()):
+            if fused:  # one launch: match + focal + smooth-L1 + masks + sums, gradients written in the same pass
+                cls_sum, loc_sum, fg = match_loss(
+                    conf[j], loc[j], targets, anchors, self.num_classes, stride, self.match, self.center_radius,
+                    self.cls_criterion.alpha, self.cls_criterion.gamma, self.loc_criterion.beta)
+                fg_targets.append(fg.clamp(min=1))
+                cls_losses.append(cls_sum)
+                loc_losses.append(loc_sum)
+                continue
             size = conf[j].shape[-2:]
             with torch.no_grad():
                 conf_target, loc_target, depth = box.extract_targets(

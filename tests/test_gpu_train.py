@@ -138,3 +138,63 @@ def test_batchnorm_training_kernels_match_torch(n, c, h, w, dtype_name, tol):
     fast.eval()
     ref.eval()
     close(fast(x), ref(x.float()), "eval path is nn.BatchNorm2d")
+
+
+@pytest.mark.parametrize("mode,dtype_name,gamma", [
+    ("iou", "float32", 2.0), ("iou", "bfloat16", 2.0), ("iou_radius", "float32", 1.5), ("scale", "float32", 2.0),
+    ("scale_center", "float16", 2.0)])
+def test_fused_match_loss_matches_unfused_losses(mode, dtype_name, gamma):
+    """ssdk_match_loss (target assignment + focal + smooth-L1 + masks + sums + gradients in one launch) against
+    extract_targets followed by the torch criteria and autograd, per level of ModelWithLossBasic.forward."""
+    import torch
+    from ssds.core import criterion
+    from ssds.core.fused_loss import match_loss
+    from ssds.modeling.layers import box
+
+    dtype = getattr(torch, dtype_name)
+    torch.manual_seed(3)
+    B, C, H, W, stride = 5, 7, 20, 24, 16
+    anchors = OrderedDict((s, box.generate_anchors(s, [1, 2, 0.5], [2.0, 2.828])) for s in (8, 16))
+    A = anchors[stride].shape[0]
+    g = torch.Generator().manual_seed(5)
+    G = 9
+    xy = torch.rand(B, G, 2, generator=g) * torch.tensor([W * stride * 0.7, H * stride * 0.7])
+    wh = 16 + torch.rand(B, G, 2, generator=g) * 140
+    lab = torch.randint(0, C, (B, G, 1), generator=g).float()
+    targets = torch.cat([xy, wh, lab], -1)
+    targets[0, 5:] = -1
+    targets[3] = -1  # an image without ground truth
+    targets = targets.cuda()
+    if mode.startswith("iou"):
+        match, radius = [0.5, 0.4], (1.5 if mode == "iou_radius" else 0)
+    else:
+        match, radius = [[-1, 6.0], [0.5, 4.0]], (1.5 if mode == "scale_center" else 0)
+    conf = (torch.randn(B, A * C, H, W) * 3).to(dtype).cuda().requires_grad_(True)
+    loc = torch.randn(B, A * 4, H, W).mul(0.3).to(dtype).cuda().requires_grad_(True)
+    fl, sl = criterion.FocalLoss(gamma=gamma), criterion.SmoothL1Loss()
+
+    ct, lt, depth = box.extract_targets(targets, anchors, C, stride, (H, W), match, radius)
+    c = conf.view_as(ct).float()
+    cls_ref = ((depth >= 0).expand_as(ct).float() * fl(c, ct, depth)).sum()
+    l = loc.view_as(lt).float()
+    loc_ref = ((depth > 0).expand_as(lt).float() * sl(l, lt)).sum()
+    fg_ref = (depth > 0).sum().float()
+    assert fg_ref > 0 and (mode.startswith("scale") or (depth < 0).any())
+    w_cls, w_loc = 0.37, 1.9
+    (w_cls * cls_ref + w_loc * loc_ref).backward()
+    gc_ref, gl_ref = conf.grad.clone(), loc.grad.clone()
+    conf.grad = loc.grad = None
+
+    cls_sum, loc_sum, fg = match_loss(conf, loc, targets, anchors, C, stride, match, radius, fl.alpha, fl.gamma, sl.beta)
+    assert float(fg) == float(fg_ref)  # exact: the same matching
+    assert abs(float(cls_sum) - float(cls_ref)) <= 2e-5 * abs(float(cls_ref))
+    assert abs(float(loc_sum) - float(loc_ref)) <= 2e-5 * abs(float(loc_ref))
+    (w_cls * cls_sum + w_loc * loc_sum).backward()
+    tol = 1e-5 if dtype == torch.float32 else (8e-3 if dtype == torch.bfloat16 else 1e-3)
+    for got, ref in ((conf.grad, gc_ref), (loc.grad, gl_ref)):
+        assert got.dtype == dtype and got.shape == ref.shape
+        err = (got.float() - ref.float()).abs()
+        assert float((err - tol * ref.float().abs()).max()) <= tol, float(err.max())
+    # bit-reproducible sums
+    again = match_loss(conf, loc, targets, anchors, C, stride, match, radius, fl.alpha, fl.gamma, sl.beta)
+    assert float(again[0]) == float(cls_sum) and float(again[1]) == float(loc_sum)
