@@ -161,6 +161,28 @@ int ssdk_match_loss(const float* targets, int B, int G, const float* anchors, in
                     const void* loc, int dtype, float alpha, float gamma, float beta, void* d_conf,
                     void* d_loc, float* sums, void* workspace, size_t workspace_bytes, void* stream);
 
+/* VOC-style mAP bookkeeping of the eval epoch: MeanAveragePrecision.__call__
+ * (core/evaluation_metrics.py:15-61, called per batch at pipeline/pipeline_anchor_basic.py:161-176) for one batch
+ * of decoder outputs.  scores [B, D], boxes [B, D, 4] (ltrb), classes [B, D] fp32 as returned by ssdk_decode_nms;
+ * targets [B, G, 5] fp32 (ltrb + label, label < 0 = padding; the caller has already converted xywh -> ltrb like
+ * pipeline_anchor_basic.py:175).  Per image and class, a detection with score > conf_threshold takes the
+ * same-class box of highest IoU (first maximum; IoU without the +1 of box.py, evaluation_metrics.py:16-26) and is
+ * a true positive iff that IoU >= iou_threshold and no earlier detection claimed the box (:51-56).
+ * Writes one record per detection slot: keys[b, i] = (class << 32) | ~ordered(score) (ascending key = class
+ * ascending, score descending; slots that are padding / below threshold / out-of-range class get class =
+ * num_classes) and tp[b, i]; adds the number of ground-truth boxes of each class to npos[num_classes] (int32,
+ * zeroed by the caller before the first batch).  D <= 2048, G <= SSDK_MAX_GT. */
+int ssdk_map_match(const float* scores, const float* boxes, const float* classes, int B, int D,
+                   const float* targets, int G, int num_classes, float conf_threshold, float iou_threshold,
+                   long long* keys, unsigned char* tp, int* npos, void* stream);
+
+/* MeanAveragePrecision.get_results (evaluation_metrics.py:63-142) on the records of a whole epoch sorted by key
+ * (stable): tp_sorted [N], seg_offsets[c] .. seg_offsets[c+1] = the records of class c (int64 [num_classes+1]).
+ * ap[c] (fp64) = area under the precision envelope in recall (VOC definition :100-112); NaN when npos[c] == 0
+ * (:124-128), 0 when the class has ground truth but no detections (:97-98). */
+int ssdk_map_average_precision(const unsigned char* tp_sorted, const long long* seg_offsets, const int* npos,
+                               int num_classes, double* ap, void* stream);
+
 /* Fused convolution + folded BatchNorm + activation (+ residual) for the detector network:
  * basic_layers.py:5-57 (SepConvBNReLU / ConvBNReLU / ConvBNReLUx2), the MobileNetV2 blocks behind
  * nets/mobilenet.py:56-99, and the bare multibox head convs ssd.py:100-103 / fpn.py:10-18.

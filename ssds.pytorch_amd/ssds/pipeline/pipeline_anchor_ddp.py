@@ -115,3 +115,23 @@ def train_anchor_based_epoch(model, data_loader, optimizer, anchors, epoch, devi
             print("Train: epoch {} | {}/{} | cls_loss {:.4f} | loc_loss {:.4f} | lr {:.5f} | skipped {} | "
                   "{:.1f}s".format(epoch, batch_idx + 1, n, float(cls_loss), float(loc_loss),
                                    optimizer.param_groups[0]["lr"], int(skipped), time.time() - start))
+
+
+@torch.no_grad()
+def eval_anchor_based_epoch(model, data_loader, decoder, anchors, num_classes, device):
+    """Eval epoch (reference pipeline_anchor_basic.py:150-182 without tqdm/TensorBoard): forward, decode + NMS and the
+    mAP bookkeeping all stay on the device; the host sees one number per class at the end.  Returns
+    (mAP, (precision, recall, ap))."""
+    from ssds.core.evaluation_metrics import MeanAveragePrecision
+
+    model.eval()
+    metric = MeanAveragePrecision(num_classes, decoder.conf_threshold, decoder.nms_threshold)
+    for images, targets in data_loader:
+        if images.device != device:
+            images, targets = images.to(device), targets.to(device)
+        targets = targets.float().clone()
+        loc, conf = model(images)
+        detections = decoder(loc, conf, anchors)
+        targets[:, :, 2:4] = targets[:, :, :2] + targets[:, :, 2:4]  # xywh -> ltrb (:175)
+        metric(detections, targets)
+    return metric.get_results()

@@ -281,3 +281,67 @@ def match_inputs(name, gen, table=None):
             targets[0, 3, 2:4] = targets[0, 2, 3:1:-1]  # transposed box: same area, different shape
     return dict(targets=targets, anchors=anchors, C=C, stride=stride, size=(H, W),
                 match=match, radius=radius)
+
+
+# eval-epoch mAP bookkeeping (MeanAveragePrecision): name -> (seed, batches, B, D, maxG, C, conf_thr, iou_thr)
+MAP_CASES = OrderedDict(
+    [
+        ("m_small", (71, 1, 2, 8, 4, 3, 0.3, 0.5)),
+        ("m_coco_like", (72, 3, 4, 100, 24, 80, 0.01, 0.5)),
+        ("m_crowded", (73, 2, 3, 64, 12, 2, 0.05, 0.6)),       # many detections per box: only the first is a TP
+        ("m_missing_cls", (74, 2, 2, 32, 6, 6, 0.2, 0.45)),    # classes without ground truth / without detections
+        ("m_wide", (75, 1, 2, 600, 40, 20, 0.02, 0.5)),        # D > one pass of the workgroup
+    ]
+)
+
+
+def map_inputs(name):
+    """Per batch: scores [B,D] (descending, zero padded), boxes [B,D,4] ltrb, classes [B,D], targets [B,G,5]
+    (ltrb + label, -1 padding) -- detections are jittered copies of the ground truth plus random false positives,
+    the shape of a Decoder output.  Scores are distinct within an epoch (ranking ties are outside the contract)."""
+    seed, batches, B, D, maxG, C, conf_thr, iou_thr = MAP_CASES[name]
+    rs = np.random.RandomState(seed)
+    pool = rs.permutation(200000)[: batches * B * D].astype(np.float64)
+    all_scores = (0.02 + 0.97 * (pool + 1) / 200001.0).astype(F32)
+    assert len(np.unique(all_scores)) == len(all_scores)
+    out, k = [], 0
+    for _ in range(batches):
+        scores = np.zeros((B, D), F32)
+        boxes = np.zeros((B, D, 4), F32)
+        classes = np.zeros((B, D), F32)
+        targets = np.full((B, maxG, 5), -1, F32)
+        for b in range(B):
+            g = maxG if b == 0 else rs.randint(0, maxG + 1)
+            gt_cls_hi = max(1, C - 2) if name == "m_missing_cls" else C  # the last classes never have ground truth
+            for j in range(g):
+                w, h = 20 + 200 * rs.random_sample(2)
+                x, y = rs.random_sample(2) * 300
+                targets[b, j] = [x, y, x + w, y + h, rs.randint(0, gt_cls_hi)]
+            n = rs.randint(D // 2, D + 1)
+            dets = []
+            for i in range(n):
+                if g > 0 and rs.random_sample() < 0.7:
+                    t = targets[b, rs.randint(0, g)]
+                    jit = (rs.random_sample(4) - 0.5) * (0.5 if name == "m_crowded" else 0.8) * (t[2] - t[0])
+                    bx = t[:4] + jit.astype(F32)
+                    cl = t[4] if rs.random_sample() < 0.85 else rs.randint(0, C)
+                else:
+                    w, h = 20 + 200 * rs.random_sample(2)
+                    x, y = rs.random_sample(2) * 300
+                    bx = np.array([x, y, x + w, y + h], F32)
+                    cl = rs.randint(1 if name == "m_missing_cls" else 0, C)  # class 0 is never detected there
+                if name == "m_missing_cls" and cl == 0:
+                    cl = 1
+                dets.append((all_scores[k], bx, cl))
+                k += 1
+            dets.sort(key=lambda d: -d[0])
+            for i, (s, bx, cl) in enumerate(dets):
+                scores[b, i], boxes[b, i], classes[b, i] = s, bx, cl
+        if name == "m_small":  # exact duplicates of one box: equal IoU on two same-class targets -> the first wins
+            targets[0, 1] = targets[0, 0]
+            boxes[0, 0] = targets[0, 0, :4]
+            classes[0, 0] = targets[0, 0, 4]
+            boxes[0, 1] = targets[0, 0, :4]
+            classes[0, 1] = targets[0, 0, 4]
+        out.append(dict(scores=scores, boxes=boxes, classes=classes, targets=targets))
+    return dict(batches=out, C=C, conf_thr=conf_thr, iou_thr=iou_thr)

@@ -175,6 +175,32 @@ def gen_match_scale():
     save("match_scale", **out)
 
 
+def gen_map():
+    """MeanAveragePrecision of the reference, unmodified.  numpy 2 removed ``np.float`` / ``np.NAN`` which
+    evaluation_metrics.py:90,126 still use: they are aliased here to what they were (``float`` / ``np.nan``)."""
+    if not hasattr(np, "float"):
+        np.float = float
+    if not hasattr(np, "NAN"):
+        np.NAN = np.nan
+    from ssds.core.evaluation_metrics import MeanAveragePrecision as RMap
+
+    out = {}
+    for name in cases.MAP_CASES:
+        d = cases.map_inputs(name)
+        m = RMap(d["C"], d["conf_thr"], d["iou_thr"])
+        for bt in d["batches"]:
+            m((t(bt["scores"]), t(bt["boxes"]), t(bt["classes"])), t(bt["targets"]))
+        mAP, (_, _, ap) = m.get_results()
+        lens = np.array([len(x) for x in m.score], np.int64)
+        out[name + "/lens"] = lens
+        out[name + "/score"] = np.array([v for x in m.score for v in x], F32)
+        out[name + "/matched"] = np.array([v for x in m.detect_ismatched for v in x], bool)
+        out[name + "/npos"] = np.array(m.npos, np.int64)
+        out[name + "/ap"] = np.array(ap, np.float64)
+        out[name + "/mAP"] = np.float64(mAP)
+    save("map", **out)
+
+
 if __name__ == "__main__":
     gen_anchors()
     gen_codec()
@@ -183,3 +209,4 @@ if __name__ == "__main__":
     gen_decoder()
     gen_match()
     gen_match_scale()
+    gen_map()

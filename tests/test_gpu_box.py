@@ -315,3 +315,81 @@ def test_preprocess_matches_reference_expression(src, dst):
         got = preprocess(torch.from_numpy(raw).cuda(), mean, std, getattr(torch, dst))
         assert got.shape == want.shape and got.is_contiguous()
         assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("name", list(cases.MAP_CASES))
+def test_mean_average_precision_vs_reference(name):
+    """ssdk_map_match + ssdk_map_average_precision (ssds.core.evaluation_metrics.MeanAveragePrecision) against the
+    reference's per-class lists (bit-exact flags, scores and counts) and AP / mAP (fp64, 1e-12)."""
+    import torch
+    from ssds.core.evaluation_metrics import MeanAveragePrecision
+
+    g = load("map")
+    d = cases.map_inputs(name)
+    m = MeanAveragePrecision(d["C"], d["conf_thr"], d["iou_thr"])
+    for bt in d["batches"]:
+        m(tuple(torch.from_numpy(bt[k]).cuda() for k in ("scores", "boxes", "classes")),
+          torch.from_numpy(bt["targets"]).cuda())
+    score, matched, npos = m.records()
+    np.testing.assert_array_equal(np.array([len(x) for x in score]), g[name + "/lens"])
+    np.testing.assert_array_equal(np.concatenate(score).astype(F32), g[name + "/score"])
+    np.testing.assert_array_equal(np.concatenate(matched), g[name + "/matched"])
+    np.testing.assert_array_equal(npos, g[name + "/npos"])
+    mAP, (prec, rec, ap) = m.get_results()
+    np.testing.assert_allclose(np.array(ap), g[name + "/ap"], rtol=1e-12, atol=1e-15, equal_nan=True)
+    np.testing.assert_allclose(mAP, float(g[name + "/mAP"]), rtol=1e-12)
+    assert len(prec) == len(rec)
+
+
+def test_mean_average_precision_full_size_vs_oracle():
+    """COCO-sized eval batches (B=64, 100 detections, 80 classes, 10 batches) against the numpy oracle, plus the
+    size-independent properties: perfect detections give mAP 1, no detections give 0."""
+    import torch
+    from oracle import map_oracle as MO
+    from ssds.core.evaluation_metrics import MeanAveragePrecision
+
+    rs = np.random.RandomState(9)
+    B, D, Gm, C = 64, 100, 30, 80
+    m, o = MeanAveragePrecision(C, 0.01, 0.5), MO.MeanAveragePrecision(C, 0.01, 0.5)
+    pool = rs.permutation(4000000)[: 10 * B * D]
+    for it in range(10):
+        tg = np.full((B, Gm, 5), -1, F32)
+        sc = np.zeros((B, D), F32)
+        bx = np.zeros((B, D, 4), F32)
+        cl = np.zeros((B, D), F32)
+        for b in range(B):
+            g = rs.randint(0, Gm + 1)
+            xy = rs.random_sample((g, 2)) * 400
+            wh = 16 + rs.random_sample((g, 2)) * 150
+            tg[b, :g] = np.concatenate([xy, xy + wh, rs.randint(0, C, (g, 1))], 1)
+            n = rs.randint(0, D + 1)
+            s = np.sort((0.011 + 0.98 * pool[(it * B + b) * D:(it * B + b) * D + n] / 4e6).astype(F32))[::-1]
+            src = rs.randint(0, max(g, 1), n)
+            hit = (rs.random_sample(n) < 0.6) & (g > 0)
+            jit = (rs.random_sample((n, 4)) - 0.5) * 40
+            rnd_xy = rs.random_sample((n, 2)) * 400
+            rnd = np.concatenate([rnd_xy, rnd_xy + 16 + rs.random_sample((n, 2)) * 150], 1)
+            sc[b, :n] = s
+            bx[b, :n] = np.where(hit[:, None], tg[b, src, :4] + jit, rnd)
+            cl[b, :n] = np.where(hit, tg[b, src, 4], rs.randint(0, C, n))
+        m(tuple(torch.from_numpy(x).cuda() for x in (sc, bx, cl)), torch.from_numpy(tg).cuda())
+        o((sc, bx, cl), tg)
+    score, matched, npos = m.records()
+    np.testing.assert_array_equal(npos, np.array(o.npos))
+    for c in range(C):
+        np.testing.assert_array_equal(score[c], np.array(o.score[c], F32))
+        np.testing.assert_array_equal(matched[c], np.array(o.detect_ismatched[c], bool))
+    mAP, (_, _, ap) = m.get_results()
+    omAP, oap = o.get_results()
+    np.testing.assert_allclose(np.array(ap), np.array(oap), rtol=1e-12, atol=1e-15, equal_nan=True)
+    np.testing.assert_allclose(mAP, omAP, rtol=1e-12)
+    assert 0.05 < mAP < 0.95
+
+    tg_t = torch.from_numpy(tg).cuda()
+    perfect = MeanAveragePrecision(C, 0.01, 0.5)
+    ps = torch.linspace(0.9, 0.5, Gm).repeat(B, 1).cuda() * (tg_t[..., 4] >= 0)
+    perfect((ps, tg_t[..., :4].contiguous(), tg_t[..., 4].clamp(min=0).contiguous()), tg_t)
+    assert abs(perfect.get_results()[0] - 1.0) < 1e-12
+    nothing = MeanAveragePrecision(C, 0.01, 0.5)
+    nothing((torch.zeros(B, D).cuda(), torch.zeros(B, D, 4).cuda(), torch.zeros(B, D).cuda()), tg_t)
+    assert nothing.get_results()[0] == 0.0

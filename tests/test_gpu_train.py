@@ -198,3 +198,40 @@ def test_fused_match_loss_matches_unfused_losses(mode, dtype_name, gamma):
     # bit-reproducible sums
     again = match_loss(conf, loc, targets, anchors, C, stride, match, radius, fl.alpha, fl.gamma, sl.beta)
     assert float(again[0]) == float(cls_sum) and float(again[1]) == float(loc_sum)
+
+
+def test_eval_epoch_on_device_matches_oracle_metric():
+    """eval_anchor_based_epoch: plan forward -> decode + NMS -> mAP records, checked against the numpy oracle fed
+    with the same detections."""
+    import torch
+    from oracle import map_oracle as MO
+    from ssds.dataset.synthetic import SyntheticDetectionLoader
+    from ssds.modeling import nets, ssds
+    from ssds.modeling.layers import box
+    from ssds.modeling.layers.decoder import Decoder
+    from ssds.pipeline.pipeline_anchor_ddp import eval_anchor_based_epoch
+
+    torch.manual_seed(0)
+    o, e, h = ssds.SSD.add_extras([[5, 7, "Conv:S"], [96, 320, 64]], [6, 6, 6], 5)
+    model = ssds.SSD(nets.MobileNetV2(outputs=o), e, h, 5)
+    for mod in model.modules():  # the heads start at the focal prior (every score 0.01): spread them out
+        if isinstance(mod, torch.nn.Conv2d) and mod.out_channels in (30, 24):
+            torch.nn.init.normal_(mod.weight, std=1.0)
+    model = model.cuda().eval()
+    anchors = OrderedDict((s, box.generate_anchors(s, [1, 2, 0.5], [2.0, 2.828])) for s in (16, 32, 64))
+    decoder = Decoder(0.005, 0.5, 50, 200, False, False)
+    loader = SyntheticDetectionLoader(4, (128, 128), 5, steps=3, device=torch.device("cuda"), max_gt=6)
+    batches = [loader.batch() for _ in range(3)]
+    mAP, (prec, rec, ap) = eval_anchor_based_epoch(model, batches, decoder, anchors, 5, torch.device("cuda"))
+
+    orc = MO.MeanAveragePrecision(5, decoder.conf_threshold, decoder.nms_threshold)
+    with torch.no_grad():
+        for images, targets in batches:
+            det = decoder(*model(images), anchors)
+            t = targets.float().clone()
+            t[:, :, 2:4] = t[:, :, :2] + t[:, :, 2:4]
+            orc(tuple(x.cpu().numpy() for x in det), t.cpu().numpy())
+    omAP, oap = orc.get_results()
+    assert sum(len(x) for x in orc.score) > 0
+    np.testing.assert_allclose(np.array(ap), np.array(oap), rtol=1e-12, atol=1e-15, equal_nan=True)
+    assert (np.isnan(mAP) and np.isnan(omAP)) or abs(mAP - omAP) < 1e-12

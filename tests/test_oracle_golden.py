@@ -188,3 +188,23 @@ def test_preprocess_oracle_matches_reference_expression():
     t = torch.Tensor(imgs.transpose(0, 3, 1, 2))
     np.testing.assert_array_equal(O.preprocess(imgs, 0, 255), ((t - 0) / 255).numpy())
     np.testing.assert_array_equal(O.preprocess(imgs.transpose(0, 3, 1, 2), 3.0, 2.0), ((t - 3.0) / 2.0).numpy())
+
+
+@pytest.mark.parametrize("name", list(cases.MAP_CASES))
+def test_map_oracle_vs_reference(name):
+    """oracle/map_oracle.py against the reference's MeanAveragePrecision lists and get_results()."""
+    from oracle import map_oracle as MO
+
+    g = load("map")
+    d = cases.map_inputs(name)
+    m = MO.MeanAveragePrecision(d["C"], d["conf_thr"], d["iou_thr"])
+    for bt in d["batches"]:
+        m((bt["scores"], bt["boxes"], bt["classes"]), bt["targets"])
+    np.testing.assert_array_equal(np.array([len(x) for x in m.score]), g[name + "/lens"])
+    np.testing.assert_array_equal(np.array([v for x in m.score for v in x], F32), g[name + "/score"])
+    np.testing.assert_array_equal(np.array([v for x in m.detect_ismatched for v in x], bool), g[name + "/matched"])
+    np.testing.assert_array_equal(np.array(m.npos), g[name + "/npos"])
+    assert g[name + "/matched"].sum() > 0
+    mAP, ap = m.get_results()
+    np.testing.assert_allclose(np.array(ap), g[name + "/ap"], rtol=1e-12, atol=0, equal_nan=True)
+    np.testing.assert_allclose(mAP, float(g[name + "/mAP"]), rtol=1e-12)
