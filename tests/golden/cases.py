@@ -345,3 +345,20 @@ def map_inputs(name):
             classes[0, 1] = targets[0, 0, 4]
         out.append(dict(scores=scores, boxes=boxes, classes=classes, targets=targets))
     return dict(batches=out, C=C, conf_thr=conf_thr, iou_thr=iou_thr)
+
+
+def loss_inputs():
+    """Seeded inputs of the criteria (core/criterion.py): logits / one-hot target [B,A,C,H,W], depth [B,A,1,H,W]
+    with positives, negatives and ignored anchors, predicted / target deltas [B,A,4,H,W]."""
+    rs = np.random.RandomState(81)
+    B, A, C, H, W = 3, 4, 5, 6, 7
+    logits = (rs.standard_normal((B, A, C, H, W)) * 2.5).astype(F32)
+    depth = rs.choice([-1.0, 0.0, 0.0, 0.0, 1.0, 2.0, 5.0], size=(B, A, 1, H, W)).astype(F32)
+    depth[2] = np.where(depth[2] > 0, 0, depth[2])  # an image without positives
+    label = rs.randint(0, C, (B, A, 1, H, W))
+    target = ((np.arange(C).reshape(1, 1, C, 1, 1) == label) & (depth > 0)).astype(F32)
+    pred = (rs.standard_normal((B, A, 4, H, W)) * 0.4).astype(F32)
+    tgt = (rs.standard_normal((B, A, 4, H, W)) * 0.4).astype(F32)
+    tgt[0, 0] = pred[0, 0]          # identical boxes
+    tgt[0, 1, :2] = pred[0, 1, :2] + 5.0  # disjoint boxes
+    return dict(logits=logits, target=target, depth=depth, pred=pred, tgt=tgt)

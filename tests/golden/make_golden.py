@@ -201,6 +201,33 @@ def gen_map():
     save("map", **out)
 
 
+def gen_losses():
+    """Every criterion of the reference's core/criterion.py on the seeded inputs: element-wise output and the
+    gradient of its sum (autograd)."""
+    from ssds.core import criterion as rcrit
+
+    d = cases.loss_inputs()
+    out = {}
+    specs = [("focal", rcrit.FocalLoss(0.25, 2), True), ("focal_g15", rcrit.FocalLoss(0.4, 1.5), True),
+             ("multibox", rcrit.MultiBoxLoss(3), True), ("smoothl1", rcrit.SmoothL1Loss(), False),
+             ("iou", rcrit.IOULoss("iou"), False), ("giou", rcrit.GIOULoss(), False),
+             ("diou", rcrit.DIOULoss(), False), ("ciou", rcrit.CIOULoss(), False)]
+    for name, crit, is_cls in specs:
+        if is_cls:
+            # the reference's MultiBoxLoss only runs for a batch of one (criterion.py:67-68 expands a [B] count
+            # over [B, anchors]): its fixture is image 0 alone
+            sl = slice(0, 1) if name == "multibox" else slice(None)
+            x = t(d["logits"][sl]).requires_grad_(True)
+            y = crit(x, t(d["target"][sl]), t(d["depth"][sl]))
+        else:
+            x = t(d["pred"]).requires_grad_(True)
+            y = crit(x, t(d["tgt"]))
+        y.sum().backward()
+        out[name + "/out"] = y.detach().numpy()
+        out[name + "/grad"] = x.grad.numpy()
+    save("losses", **out)
+
+
 if __name__ == "__main__":
     gen_anchors()
     gen_codec()
@@ -210,3 +237,4 @@ if __name__ == "__main__":
     gen_match()
     gen_match_scale()
     gen_map()
+    gen_losses()
