@@ -405,6 +405,7 @@ class ConvPlan(object):
         self.dtype_code = N._DTYPES[dtype]
         self.es = 2
         self.arena = _Arena(device)
+        self.pinned = set()  # arena buffers read by side-lane ops: never re-used (see head())
         self.layers = []   # dicts with everything the descriptor fillers need
         self.heads = []    # (layer index, n, split | None, cout, ho, wo, tag)
         self.keep = []     # packs kept alive
@@ -477,13 +478,21 @@ class ConvPlan(object):
         conv of one shared tower (``tag='loc' | 'conf'``)."""
         buf, n, c, h, w = val
         ho, wo = _out_hw(h, w, pack.k, pack.stride)
+        # small heads are leaves of latency-bound work: they run on the executor's side stream next to the main
+        # chain (SSDK_SIDE_STREAM); the big levels fill the chip on their own and stay in line.  A side-lane op
+        # reads its input while the main lane keeps going, so that buffer must never be handed out again inside
+        # this plan (the arena re-uses a buffer as soon as its last reader is RECORDED, which orders nothing
+        # across streams): it is pinned.
+        lane = 1 if n * ho * wo <= 4096 else 0
+        if lane and not isinstance(buf, ExtBuf):
+            self.pinned.add(buf)
         self.layers.append(dict(x=buf, n=n, h=h, w=w, pack=pack, act=act, y=None, res=None, res_mode=0, nchw=True,
-                                split=split, act2=act2))
+                                split=split, act2=act2, lane=lane))
         self.heads.append((len(self.layers) - 1, n, split, pack.cout, ho, wo, tag))
         self.keep.append(pack)
 
     def release(self, val):
-        if not isinstance(val[0], ExtBuf):
+        if not isinstance(val[0], ExtBuf) and val[0] not in self.pinned:
             self.arena.release(val[0])
 
     def _ptr(self, buf, patches, op_index, field):
@@ -545,10 +554,7 @@ class ConvPlan(object):
                 f.dtype = self.dtype_code
                 continue
             op.kind = N.OP_CONV
-            # small heads are leaves of latency-bound work: they may run on the executor's side stream next to the
-            # extras chain (SSDK_SIDE_STREAM=1); the big levels fill the chip on their own and stay in line
-            ho_, wo_ = _out_hw(L["h"], L["w"], L["pack"].k, L["pack"].stride)
-            op.lane = 1 if (L["nchw"] and L["n"] * ho_ * wo_ <= 4096) else 0
+            op.lane = L.get("lane", 0)  # side stream for the small heads, decided (and its input pinned) in head()
             y_ptr = self.arena.ptr(L["y"]) if L["y"] is not None else 0
             res_ptr = self._ptr(L["res"], self.patches, i, "conv.residual") if L["res"] is not None else None
             fill_desc(op.conv, self._ptr(L["x"], self.patches, i, "conv.x"), L["n"], L["h"], L["w"], L["pack"],
