@@ -22,7 +22,6 @@ namespace ssdk {
 constexpr int kScanThreads = 256;
 constexpr u32 kCap = 4096;         // LDS candidate slots per workgroup
 static_assert(kCap == kStreamCap, "stream buffers are kStreamCap keys");
-constexpr int kPrefetch = 4;       // 16-byte loads in flight per lane (8 measured the same)
 
 struct ScanLevel {
   const void* cls;
@@ -119,7 +118,7 @@ __device__ __forceinline__ void scan_vec(const u32x4& v, u32 idx0, u32 n, float 
     if ((pmask >> e) & 1u) buf[base + (u32)__popc(pmask & ((1u << e) - 1u))] = make_key(sv[e], idx0 + (u32)e);
 }
 
-template <int DT>
+template <int DT, int PF>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) {
   constexpr int NT = kScanThreads;
   constexpr int VEC = DType<DT>::vec;
@@ -144,15 +143,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) 
     }
   const u32 uu = u - ubase;
 
-  // image b of this level starts at byte b*n*ES; loads are 16-byte aligned vectors, `head` elements
-  // of the first vector belong to the previous image and are masked by the index test.
+  // image b of this level starts at byte b*n*ES; loads are 16-byte ALIGNED vectors: `head` elements of the first
+  // vector belong to the previous image and up to VEC-1 elements of the last one to the next image (or to the
+  // padding of the allocation -- an aligned 16-byte vector that holds one valid byte never crosses an allocation
+  // boundary); both are masked by the index test.
   const unsigned char* base = (const unsigned char*)cls + (size_t)b * n * ES;
   const u32 head = (u32)((uintptr_t)base & 15u) / ES;
   const unsigned char* abase = base - (size_t)head * ES;
-  const u32 nvec_full = (head + n) / VEC;        // complete vectors
-  const u32 tail = (head + n) % VEC;             // elements in the last partial vector
+  const u32 nvec = (head + n + VEC - 1) / VEC;   // vectors holding at least one element of this image (>= 1)
   const u32 vec0 = uu * p.tiles_per_unit * NT;   // first vector of this unit
-  const u32 nvec = nvec_full + (tail ? 1u : 0u);
   u32 ntiles = 0;
   if (vec0 < nvec) {
     ntiles = (nvec - vec0 + NT - 1) / NT;
@@ -171,43 +170,34 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) 
   float cut = p.thr;
   u32 cut_idx = 0xffffffffu;
 
+  // Branch-free: the address is clamped to the image's last vector and what lies outside the unit is masked through
+  // its index, so every tile issues exactly one load per lane and the compiler can count them (s_waitcnt vmcnt(PF-1)
+  // before a tile is consumed).  (The first version guarded the load with the tile / tail tests: the waits at the
+  // joins of those branches degenerated to vmcnt(0) right after the prefetch was issued -- one exposed memory
+  // latency per 4 KB tile, 0.9 us, instead of PF tiles in flight.)
+  const u32 vlast = nvec - 1u;
   auto load_vec = [&](u32 t) -> u32x4 {
-    u32x4 v = {0u, 0u, 0u, 0u};
     const u32 vi = vec0 + t * NT + tid;
-    if (t < ntiles) {
-      if (vi < nvec_full) {
-        v = *reinterpret_cast<const u32x4*>(abase + (size_t)vi * 16);
-      } else if (vi == nvec_full && tail) {  // last partial vector: never read past the tensor
-        const unsigned char* q = abase + (size_t)vi * 16;
-        u32 w[4] = {0u, 0u, 0u, 0u};
-        for (u32 e = 0; e < tail; ++e) {
-          if constexpr (ES == 4) w[e] = ((const u32*)q)[e];
-          else w[e >> 1] |= (u32)((const u16*)q)[e] << ((e & 1) * 16);
-        }
-        v = u32x4{w[0], w[1], w[2], w[3]};
-      }
-    }
-    return v;
+    return *reinterpret_cast<const u32x4*>(abase + (size_t)(vi < vlast ? vi : vlast) * 16);
   };
 
-  u32x4 pf[kPrefetch];
+  u32x4 pf[PF];
 #pragma unroll
-  for (int i = 0; i < kPrefetch; ++i) pf[i] = load_vec(i);
+  for (int i = 0; i < PF; ++i) pf[i] = load_vec(i);
 
-  for (u32 t0 = 0; t0 < ntiles; t0 += kPrefetch) {
+  for (u32 t0 = 0; t0 < ntiles; t0 += PF) {
 #pragma unroll
-    for (int i = 0; i < kPrefetch; ++i) {
-      const u32 t = t0 + i;
-      if (t < ntiles) {  // workgroup-uniform
-        const u32x4 v = pf[i];
-        pf[i] = load_vec(t + kPrefetch);
-        const u32 idx0 = (vec0 + t * NT + tid) * VEC - head;
-        scan_vec<DT>(v, idx0, n, cut, cut_idx, buf, ctl, limit, t);
-        u64 T;
-        if (stream_finish_tile<NT>(buf, sel, ss, ctl, t, K, &T)) {
-          cut = key_score(T);
-          cut_idx = key_index(T);
-        }
+    for (int i = 0; i < PF; ++i) {
+      const u32 t = t0 + i;  // tiles past ntiles (the last round of a unit) run masked: no keys, one barrier
+      const u32x4 v = pf[i];
+      pf[i] = load_vec(t + PF);
+      const u32 vi = vec0 + t * NT + tid;
+      const u32 idx0 = (t < ntiles && vi <= vlast) ? vi * VEC - head : 0xffff0000u;
+      scan_vec<DT>(v, idx0, n, cut, cut_idx, buf, ctl, limit, t);
+      u64 T;
+      if (stream_finish_tile<NT>(buf, sel, ss, ctl, t, K, &T)) {
+        cut = key_score(T);
+        cut_idx = key_index(T);
       }
     }
   }
@@ -480,9 +470,19 @@ static int launch_decode(const ssdk_level* lv, int L, int B, int dtype, float th
   const size_t lds = lds_bytes_for((u32)K);
   const dim3 grid((unsigned)(B * pl.units_per_image));
   if (g_prof_events) (void)hipEventRecord(g_prof_events[0], stream);
-  if (dtype == SSDK_F32) hipLaunchKernelGGL(scan_kernel<SSDK_F32>, grid, dim3(kScanThreads), lds, stream, sp);
-  else if (dtype == SSDK_BF16) hipLaunchKernelGGL(scan_kernel<SSDK_BF16>, grid, dim3(kScanThreads), lds, stream, sp);
-  else hipLaunchKernelGGL(scan_kernel<SSDK_F16>, grid, dim3(kScanThreads), lds, stream, sp);
+  static const int pf = [] {  // 16-byte loads in flight per lane: 4 (default) or 8 (SSDK_SCAN_PF=8)
+    const char* e = getenv("SSDK_SCAN_PF");
+    return (e && atoi(e) == 8) ? 8 : 4;
+  }();
+  if (pf == 8) {
+    if (dtype == SSDK_F32) hipLaunchKernelGGL((scan_kernel<SSDK_F32, 8>), grid, dim3(kScanThreads), lds, stream, sp);
+    else if (dtype == SSDK_BF16) hipLaunchKernelGGL((scan_kernel<SSDK_BF16, 8>), grid, dim3(kScanThreads), lds, stream, sp);
+    else hipLaunchKernelGGL((scan_kernel<SSDK_F16, 8>), grid, dim3(kScanThreads), lds, stream, sp);
+  } else {
+    if (dtype == SSDK_F32) hipLaunchKernelGGL((scan_kernel<SSDK_F32, 4>), grid, dim3(kScanThreads), lds, stream, sp);
+    else if (dtype == SSDK_BF16) hipLaunchKernelGGL((scan_kernel<SSDK_BF16, 4>), grid, dim3(kScanThreads), lds, stream, sp);
+    else hipLaunchKernelGGL((scan_kernel<SSDK_F16, 4>), grid, dim3(kScanThreads), lds, stream, sp);
+  }
   rc = check_launch("scan_kernel");
   if (rc) return rc;
   if (g_prof_events) (void)hipEventRecord(g_prof_events[1], stream);

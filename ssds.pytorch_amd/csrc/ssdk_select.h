@@ -253,7 +253,10 @@ __device__ __forceinline__ void stream_append(u64* buf, StreamCtl* c, u32 limit,
 template <int NT>
 __device__ __forceinline__ bool stream_finish_tile(u64* buf, u64* sel, SelScratch* s, StreamCtl* c,
                                                    u32 tile, u32 K, u64* T_out) {
-  __syncthreads();
+  // LDS-only synchronisation: the appends are LDS operations, so lgkmcnt(0) + s_barrier orders them for the flag
+  // read below.  (__syncthreads() also drains vmcnt, i.e. the caller's global prefetches, on every tile.)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   if (c->flag[tile & 1u] != tile + 1u) return false;
   const u32 n = c->cnt;
   (void)sel;
