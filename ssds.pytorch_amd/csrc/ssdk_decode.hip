@@ -176,8 +176,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) 
   // joins of those branches degenerated to vmcnt(0) right after the prefetch was issued -- one exposed memory
   // latency per 4 KB tile, 0.9 us, instead of PF tiles in flight.)
   const u32 vlast = nvec - 1u;
+  // (a prefetch past the unit's last tile re-reads that tile -- cache hits -- instead of the next unit's data)
   auto load_vec = [&](u32 t) -> u32x4 {
-    const u32 vi = vec0 + t * NT + tid;
+    const u32 vi = vec0 + (t < ntiles ? t : ntiles - 1u) * NT + tid;
     return *reinterpret_cast<const u32x4*>(abase + (size_t)(vi < vlast ? vi : vlast) * 16);
   };
 
