@@ -9,6 +9,11 @@ backbone + extras + multibox heads forward (bf16), decode of every level and NMS
 is quoted on `configs[1]` (SSD + MobileNetV2 @512x512 bf16, batch 64, one MI355X); with N > 1 every rank
 runs the same per-GPU batch (weak scaling, replicas only: inference has no collective -- SURVEY.md 8e).
 
+Serving-loop pipelining (default, --tail-stream 0 turns it off): the latency-bound end of the decode stage
+(level_kernel + nms_kernel, 64-384 workgroups) is enqueued on its own HIP stream and runs under the NEXT step's
+forward pass; the HBM-bound scan_kernel stays in line on the main stream, so its live event timing is
+un-overlapped.  All work of the K steps completes inside the timed region (device-wide synchronize on both sides).
+
 Prints ONE JSON line (rank 0).  Besides the driver's contract fields it carries
   roofline      HBM roofline of the dominant hand-written kernel (scan_kernel: the one pass over the conf
                 tensors), from hipEvents recorded live inside the timed region (ssdk_set_profiling ring)
@@ -41,6 +46,8 @@ def parse():
     ap.add_argument("--cfg", default=os.path.join(ROOT, "experiments", "cfgs", "ssd_mobilenetv2_512.yml"))
     ap.add_argument("--cpu-sample", type=int, default=4, help="images for the CPU baseline (0 = skip)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step as one captured hipGraph")
+    ap.add_argument("--tail-stream", type=int, default=1,
+                    help="1: level/NMS kernels of the decode stage on their own stream (overlap the next step's forward)")
     ap.add_argument("--layers", type=int, default=0, help="1: add the per-layer table (us, TFLOP/s, GB/s) to the JSON")
     ap.add_argument("--channels-last", type=int, default=int(os.environ.get("SSDK_CHANNELS_LAST", "0")))
     return ap.parse_args()
@@ -93,6 +100,8 @@ def main():
         model = model.to(memory_format=torch.channels_last)
     anchors = model_builder.create_anchors(cfg.MODEL, model, cfg.MODEL.IMAGE_SIZE)
     decoder = model_builder.create_decoder(cfg.POST_PROCESS)
+    if args.tail_stream and not args.graph:
+        decoder.enable_tail_stream()
     H, W = cfg.MODEL.IMAGE_SIZE
     B = args.batch
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -156,6 +165,8 @@ def main():
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) / n
 
+    if args.tail_stream and not args.graph:
+        decoder.disable_tail_stream()  # the stage times below are measured un-overlapped on one stream
     with torch.no_grad():
         loc, conf = model(x)
     fwd_ms = time_fn(lambda: model(x), max(3, min(10, args.steps)))
@@ -246,6 +257,7 @@ def main():
         "parallelism": "replicas x%d (no collective)" % n_gpus,
         "fused_head_conv": os.environ.get("SSDK_FUSED_CONV", "1") != "0",
         "hipgraph": bool(args.graph),
+        "decode_tail_stream": bool(args.tail_stream and not args.graph),
         "channels_last": bool(args.channels_last),
     }
     result["roofline"] = roofline

@@ -109,6 +109,14 @@ int ssdk_decode_nms(const ssdk_level* levels, int L, int B, int dtype, float thr
                     float* mid_scores, float* mid_boxes, float* mid_classes, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* (new) Tail stream of ssdk_decode_nms for the calling thread (NULL = off, the default): when set, scan_kernel still
+ * runs on the `stream` argument but level_kernel and nms_kernel are enqueued on the tail stream, ordered after the
+ * scan by an event -- the latency-bound end of the stage then overlaps the next batch's forward pass.  The caller
+ * owns the consequences: the outputs are complete on the TAIL stream, the workspace and the box tensors must stay
+ * untouched until the tail work has finished (alternate two workspaces and make the main stream wait for the tail
+ * event of the call that last used one; host mirror: ssds/modeling/layers/decoder.py). */
+int ssdk_set_decode_tail_stream(void* stream);
+
 /* Optional per-kernel timing for roofline accounting (bench.py): when enabled, ssdk_decode_nms records
  * hipEvents on the caller's stream around its three launches into a ring of 256 slots (no
  * synchronisation inside the timed region).  ssdk_get_timings(back, ms, 3) returns ms[0..2] = scan_kernel,

@@ -348,6 +348,32 @@ __global__ __launch_bounds__(kLevelThreads) void level_kernel(const LevelParams 
 // ------------------------------------------------------------------------------------------------
 hipEvent_t* g_prof_events = nullptr;  // [0] before scan, [1] after scan, [2] after level
 
+// Tail stream of the decode stage (ssdk_set_decode_tail_stream): level_kernel and nms_kernel are latency-bound work
+// on 64-384 workgroups; on their own stream they run under the next batch's forward pass instead of in front of it.
+// scan_kernel (the chip-filling, HBM-bound pass) stays on the caller's stream.
+thread_local hipStream_t g_tail_stream = nullptr;
+static hipEvent_t g_tail_fork[8];
+static bool g_tail_fork_ready = false;
+static unsigned g_tail_fork_i = 0;
+
+// everything enqueued on `from` so far happens before what is enqueued on `to` from now on
+int stream_fork(hipStream_t from, hipStream_t to) {
+  if (!g_tail_fork_ready) {
+    for (auto& e : g_tail_fork)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        set_error("decode: hipEventCreate failed");
+        return SSDK_E_LAUNCH;
+      }
+    g_tail_fork_ready = true;
+  }
+  hipEvent_t e = g_tail_fork[g_tail_fork_i++ & 7u];
+  if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) {
+    set_error("decode: stream fork failed");
+    return SSDK_E_LAUNCH;
+  }
+  return SSDK_OK;
+}
+
 struct DecodePlan {
   u32 tiles_per_unit, units_per_image;
   u32 units[SSDK_MAX_LEVELS], unit_base[SSDK_MAX_LEVELS], n[SSDK_MAX_LEVELS];
@@ -414,7 +440,7 @@ static int make_plan(const ssdk_level* lv, int L, int B, int dtype, int K, Decod
 
 static int launch_decode(const ssdk_level* lv, int L, int B, int dtype, float thr, int K, int rescore,
                          float* scores, float* boxes, float* classes, void* ws, size_t ws_bytes,
-                         hipStream_t stream) {
+                         hipStream_t stream, hipStream_t tail = nullptr) {
   DecodePlan pl;
   int rc = make_plan(lv, L, B, dtype, K, &pl);
   if (rc) return rc;
@@ -487,9 +513,15 @@ static int launch_decode(const ssdk_level* lv, int L, int B, int dtype, float th
   rc = check_launch("scan_kernel");
   if (rc) return rc;
   if (g_prof_events) (void)hipEventRecord(g_prof_events[1], stream);
-  hipLaunchKernelGGL(level_kernel, dim3((unsigned)L, (unsigned)B), dim3(kLevelThreads), lds, stream, lp);
+  hipStream_t st2 = stream;
+  if (tail && tail != stream) {  // the rest of the stage goes to the tail stream, ordered after the scan
+    rc = stream_fork(stream, tail);
+    if (rc) return rc;
+    st2 = tail;
+  }
+  hipLaunchKernelGGL(level_kernel, dim3((unsigned)L, (unsigned)B), dim3(kLevelThreads), lds, st2, lp);
   rc = check_launch("level_kernel");
-  if (g_prof_events) (void)hipEventRecord(g_prof_events[2], stream);
+  if (g_prof_events) (void)hipEventRecord(g_prof_events[2], st2);
   return rc;
 }
 
@@ -500,9 +532,10 @@ size_t decode_ws_bytes(const ssdk_level* lv, int L, int B, int dtype, int K) {
   return pl.cand_bytes + pl.cnt_bytes;
 }
 int decode_levels(const ssdk_level* lv, int L, int B, int dtype, float thr, int K, int rescore,
-                  float* scores, float* boxes, float* classes, void* ws, size_t ws_bytes, void* stream) {
+                  float* scores, float* boxes, float* classes, void* ws, size_t ws_bytes, void* stream,
+                  void* tail) {
   return launch_decode(lv, L, B, dtype, thr, K, rescore, scores, boxes, classes, ws, ws_bytes,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, (hipStream_t)tail);
 }
 
 }  // namespace ssdk
@@ -515,5 +548,10 @@ extern "C" int ssdk_decode(const ssdk_level* level, int B, int dtype, float thre
                            int rescore, float* scores, float* boxes, float* classes, void* workspace,
                            size_t workspace_bytes, void* stream) {
   return ssdk::decode_levels(level, 1, B, dtype, threshold, top_n, rescore, scores, boxes, classes,
-                             workspace, workspace_bytes, stream);
+                             workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int ssdk_set_decode_tail_stream(void* stream) {
+  ssdk::g_tail_stream = (hipStream_t)stream;
+  return SSDK_OK;
 }

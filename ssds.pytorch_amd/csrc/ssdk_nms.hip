@@ -22,7 +22,9 @@ namespace ssdk {
 // decode side (ssdk_decode.hip)
 size_t decode_ws_bytes(const ssdk_level* lv, int L, int B, int dtype, int K);
 int decode_levels(const ssdk_level* lv, int L, int B, int dtype, float thr, int K, int rescore,
-                  float* scores, float* boxes, float* classes, void* ws, size_t ws_bytes, void* stream);
+                  float* scores, float* boxes, float* classes, void* ws, size_t ws_bytes, void* stream,
+                  void* tail);
+extern thread_local hipStream_t g_tail_stream;  // ssdk_set_decode_tail_stream (ssdk_decode.hip)
 
 extern hipEvent_t* g_prof_events;  // set by ssdk_decode_nms while profiling (ssdk_decode.hip)
 
@@ -364,14 +366,15 @@ extern "C" int ssdk_decode_nms(const ssdk_level* levels, int L, int B, int dtype
   const bool prof = g_prof_on && g_ev_ready;
   hipEvent_t* ev = prof ? g_ev[g_prof_calls % kProfSlots] : nullptr;
   ssdk::g_prof_events = ev;
+  hipStream_t tail = ssdk::g_tail_stream ? ssdk::g_tail_stream : (hipStream_t)stream;
   int rc = ssdk::decode_levels(levels, L, B, dtype, threshold, top_n_per_level, rescore, ms, mb, mc,
-                               workspace, dec, stream);
+                               workspace, dec, stream, tail);
   ssdk::g_prof_events = nullptr;
   if (rc) return rc;
   rc = ssdk::launch_nms(ms, mb, mc, B, L * top_n_per_level, nms_threshold, ndetections, using_diou,
-                        out_scores, out_boxes, out_classes, (hipStream_t)stream);
+                        out_scores, out_boxes, out_classes, tail);
   if (prof) {
-    (void)hipEventRecord(ev[3], (hipStream_t)stream);
+    (void)hipEventRecord(ev[3], tail);
     ++g_prof_calls;
   }
   return rc;

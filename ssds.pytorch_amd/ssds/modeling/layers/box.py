@@ -4,6 +4,7 @@
 
 Reference lines each function replaces are cited in the docstrings.
 """
+import contextlib
 import ctypes
 
 import numpy as np
@@ -131,6 +132,36 @@ def extract_targets(
     return cls_t, box_t, depth
 
 
+class _TailPipe(object):
+    """Tail stream of the decode stage + two alternating workspaces.  A workspace is handed out again only after the
+    current stream has been made to wait for the tail work of the call that used it two calls ago."""
+
+    def __init__(self, stream=None):
+        self.stream = stream if stream is not None else torch.cuda.Stream()
+        self.ws = [None, None]
+        self.done = [None, None]
+        self.i = 0
+
+    def acquire(self, device, nbytes):
+        k = self.i & 1
+        if self.ws[k] is None or self.ws[k].numel() < nbytes:
+            self.ws[k] = torch.empty(int(nbytes) + int(nbytes) // 4, dtype=torch.uint8, device=device)
+        if self.done[k] is not None:
+            torch.cuda.current_stream(device).wait_event(self.done[k])
+        return self.ws[k]
+
+    def release(self):
+        k = self.i & 1
+        if self.done[k] is None:
+            self.done[k] = torch.cuda.Event()
+        self.done[k].record(self.stream)
+        self.i += 1
+
+    def wait(self):
+        """Make the current stream wait for everything enqueued on the tail stream so far."""
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
 def _heads(all_cls_head, all_box_head):
     N.require_device(all_cls_head, "decode")
     N.require_device(all_box_head, "decode")
@@ -196,9 +227,13 @@ def nms(all_scores, all_boxes, all_classes, nms=0.5, ndetections=100, using_diou
 
 
 def decode_nms(loc, conf, anchors, threshold, top_n_per_level, rescore, nms_threshold, ndetections,
-               using_diou, return_mid=False):
+               using_diou, return_mid=False, tail=None):
     """Decoder.__call__ of the reference (decoder.py:25-49) as one C-ABI call: decode of every level
-    (one scan launch + one per-level launch) and NMS, nothing returns to the host in between."""
+    (one scan launch + one per-level launch) and NMS, nothing returns to the host in between.
+
+    ``tail`` (a ``_TailPipe``, see ``Decoder.enable_tail_stream``): the latency-bound end of the stage (level
+    merge/sort/decode + NMS) runs on the pipe's stream, so it overlaps whatever the caller enqueues next on the
+    current stream; the outputs are then complete on that stream (``Decoder.wait()``)."""
     if len(loc) != len(conf) or len(loc) != len(anchors):
         raise ValueError("loc / conf / anchors disagree on the number of levels")
     L = len(loc)
@@ -214,26 +249,42 @@ def decode_nms(loc, conf, anchors, threshold, top_n_per_level, rescore, nms_thre
             raise N.SsdkError("all levels must share one dtype")
         levels[i] = N.make_level(c, l, stride, anchor)
     K, nd = int(top_n_per_level), int(ndetections)
-    os_ = torch.empty((B, nd), device=dev, dtype=torch.float32)
-    ob = torch.empty((B, nd, 4), device=dev, dtype=torch.float32)
-    oc = torch.empty((B, nd), device=dev, dtype=torch.float32)
-    mid = (None, None, None)
-    if return_mid:
-        mid = (torch.empty((B, L * K), device=dev, dtype=torch.float32),
-               torch.empty((B, L * K, 4), device=dev, dtype=torch.float32),
-               torch.empty((B, L * K), device=dev, dtype=torch.float32))
+    # with a tail stream the outputs are written there: allocate them on that stream so that the caching allocator
+    # orders their re-use after the tail work
+    with torch.cuda.stream(tail.stream) if tail is not None else contextlib.nullcontext():
+        os_ = torch.empty((B, nd), device=dev, dtype=torch.float32)
+        ob = torch.empty((B, nd, 4), device=dev, dtype=torch.float32)
+        oc = torch.empty((B, nd), device=dev, dtype=torch.float32)
+        mid = (None, None, None)
+        if return_mid:
+            mid = (torch.empty((B, L * K), device=dev, dtype=torch.float32),
+                   torch.empty((B, L * K, 4), device=dev, dtype=torch.float32),
+                   torch.empty((B, L * K), device=dev, dtype=torch.float32))
     with torch.cuda.device(dev):
         need = N.lib.ssdk_decode_nms_workspace_bytes(levels, L, B, dt, K, nd)
         if need == 0:
             N.check(-1, "decode_nms (workspace query)")
-        ws = N.workspace(dev, need + 256)
+        if tail is None:
+            ws = N.workspace(dev, need + 256)
+        else:
+            ws = tail.acquire(dev, need + 256)  # the current stream now waits for the tail work that last used it
+            N.lib.ssdk_set_decode_tail_stream(ctypes.c_void_p(tail.stream.cuda_stream))
         wptr = (ws.data_ptr() + 255) & ~255
-        rc = N.lib.ssdk_decode_nms(
-            levels, L, B, dt, float(threshold), K, int(bool(rescore)), float(nms_threshold), nd,
-            int(bool(using_diou)), os_.data_ptr(), ob.data_ptr(), oc.data_ptr(),
-            mid[0].data_ptr() if return_mid else None, mid[1].data_ptr() if return_mid else None,
-            mid[2].data_ptr() if return_mid else None, wptr, ws.numel() - (wptr - ws.data_ptr()),
-            N.stream_ptr(dev))
+        try:
+            rc = N.lib.ssdk_decode_nms(
+                levels, L, B, dt, float(threshold), K, int(bool(rescore)), float(nms_threshold), nd,
+                int(bool(using_diou)), os_.data_ptr(), ob.data_ptr(), oc.data_ptr(),
+                mid[0].data_ptr() if return_mid else None, mid[1].data_ptr() if return_mid else None,
+                mid[2].data_ptr() if return_mid else None, wptr, ws.numel() - (wptr - ws.data_ptr()),
+                N.stream_ptr(dev))
+        finally:
+            if tail is not None:
+                N.lib.ssdk_set_decode_tail_stream(None)
+        if tail is not None and rc == 0:
+            for c, l in heads:  # read by kernels on the tail stream: not to be recycled before those have run
+                c.record_stream(tail.stream)
+                l.record_stream(tail.stream)
+            tail.release()
     N.check(rc, "decode_nms")
     if return_mid:
         return (os_, ob, oc), mid

@@ -1,6 +1,6 @@
 """``Decoder`` -- same constructor/attributes/call contract as the reference's
 ``ssds/modeling/layers/decoder.py:15-49``; the body is one fused C-ABI call (``ssdk_decode_nms``)."""
-from .box import decode_nms
+from .box import _TailPipe, decode_nms
 
 
 class Decoder(object):
@@ -17,6 +17,24 @@ class Decoder(object):
         self.top_n_per_level = top_n_per_level
         self.rescore = rescore
         self.use_diou = use_diou
+        self._tail = None
+
+    def enable_tail_stream(self, stream=None):
+        """Serving-loop mode: the latency-bound end of the stage (per-level merge/sort/decode and NMS, 64-384
+        workgroups) runs on its own HIP stream and overlaps the NEXT batch's forward pass; the HBM-bound scan stays on
+        the caller's stream.  The returned tensors are then complete on that stream: call ``wait()`` (or synchronise
+        the device) before reading them from another stream.  Off by default."""
+        self._tail = _TailPipe(stream)
+        return self
+
+    def disable_tail_stream(self):
+        if self._tail is not None:
+            self._tail.wait()
+        self._tail = None
+
+    def wait(self):
+        if self._tail is not None:
+            self._tail.wait()
 
     def __call__(self, loc, conf, anchors):
         r"""
@@ -26,5 +44,5 @@ class Decoder(object):
         """
         return decode_nms(
             loc, conf, anchors, self.conf_threshold, self.top_n_per_level, self.rescore,
-            self.nms_threshold, self.top_n, self.use_diou,
+            self.nms_threshold, self.top_n, self.use_diou, tail=self._tail,
         )

@@ -393,3 +393,43 @@ def test_mean_average_precision_full_size_vs_oracle():
     nothing = MeanAveragePrecision(C, 0.01, 0.5)
     nothing((torch.zeros(B, D).cuda(), torch.zeros(B, D, 4).cuda(), torch.zeros(B, D).cuda()), tg_t)
     assert nothing.get_results()[0] == 0.0
+
+
+def test_decoder_tail_stream_matches_inline_decode():
+    """Decoder.enable_tail_stream(): level + NMS kernels on their own stream, two alternating workspaces; a loop of
+    different batches with other work enqueued in between must give exactly the inline results."""
+    import torch
+    from ssds.modeling.layers import box
+    from ssds.modeling.layers.decoder import Decoder
+
+    torch.manual_seed(4)
+    B, A, C = 8, 6, 20
+    sizes, strides = [16, 8, 4, 2], [16, 32, 64, 128]
+    anchors = OrderedDict((s, box.generate_anchors(s, [1, 2, 0.5], [2.0, 2.828])) for s in strides)
+    batches = []
+    for it in range(7):
+        conf = [torch.rand(B, A * C, h, h, device="cuda").pow(4).to(torch.bfloat16) for h in sizes]
+        loc = [torch.randn(B, A * 4, h, h, device="cuda").mul(0.2).to(torch.bfloat16) for h in sizes]
+        batches.append((loc, conf))
+    inline = Decoder(0.05, 0.5, 50, 100, True, True)
+    want = [tuple(t.clone() for t in inline(l, c, anchors)) for l, c in batches]
+    piped = Decoder(0.05, 0.5, 50, 100, True, True).enable_tail_stream()
+    filler = torch.randn(2048, 2048, device="cuda")
+    got = []
+    for l, c in batches:
+        # fresh copies that die right after the call: their memory may only be recycled after the tail work
+        l2, c2 = [t.clone() for t in l], [t.clone() for t in c]
+        got.append(piped(l2, c2, anchors))
+        del l2, c2
+        filler = filler @ filler.t() * 1e-3  # main-stream work the tail overlaps with (and allocator churn)
+        junk = [torch.full((B, A * C, h, h), 0.9, device="cuda", dtype=torch.bfloat16) for h in sizes]
+        del junk
+    piped.wait()
+    torch.cuda.synchronize()
+    for g, w in zip(got, want):
+        for a, b in zip(g, w):
+            assert torch.equal(a, b)
+    piped.disable_tail_stream()
+    again = piped(*batches[0], anchors)
+    for a, b in zip(again, want[0]):
+        assert torch.equal(a, b)
