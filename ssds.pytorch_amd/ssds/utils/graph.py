@@ -23,6 +23,9 @@ class GraphedInference(object):
             raise ValueError("GraphedInference needs model.eval()")
         if not example.is_cuda:
             raise ValueError("GraphedInference needs a HIP device tensor")
+        if getattr(decoder, "_tail", None) is not None:
+            # a capture must end with every forked stream joined; the tail stream is a cross-step overlap by design
+            raise ValueError("GraphedInference: call decoder.disable_tail_stream() first (a captured step is one graph)")
         self.model, self.decoder, self.anchors = model, decoder, anchors
         self.static_x = example.clone()
         side = torch.cuda.Stream(device=example.device)
