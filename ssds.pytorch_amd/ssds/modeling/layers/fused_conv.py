@@ -613,9 +613,10 @@ class ConvPlan(object):
         sub, name = field.split(".")
         setattr(getattr(self.ops[op_index], sub), name, ptr)
 
-    def run(self, *inputs):
-        """inputs: the tensors declared with ``add_input`` (the image: NCHW contiguous or channels_last; feature
-        maps: converted to channels_last if needed).  Returns (loc tuple, conf tuple), NCHW."""
+    def prepare(self, *inputs):
+        """Points the recorded ops at this call's inputs and freshly allocated head outputs.  inputs: the tensors
+        declared with ``add_input`` (the image: NCHW contiguous or channels_last; feature maps: converted to
+        channels_last if needed).  Returns (loc tuple, conf tuple), NCHW -- filled once ``launch`` has run every op."""
         if len(inputs) != len(self.inputs):
             raise N.SsdkError("plan expects {} inputs, got {}".format(len(self.inputs), len(inputs)))
         held = []
@@ -670,17 +671,31 @@ class ConvPlan(object):
                 t = torch.empty((n, cout, ho, wo), device=self.device, dtype=self.dtype)
                 self.ops[li].conv.y = t.data_ptr()
                 (loc if tag == "loc" else conf).append(t)
+        self._held = held  # converted inputs stay alive until the next prepare()
+        return tuple(loc), tuple(conf)
+
+    def launch(self, lo=0, hi=None, stream=None):
+        """Enqueue ops [lo, hi) of the plan on ``stream`` (default: the current stream) with ONE C call."""
+        hi = len(self.layers) if hi is None else hi
+        if hi <= lo:
+            return
+        ops = self.ops if lo == 0 else (N.Op * (hi - lo)).from_address(ctypes.addressof(self.ops) + lo * ctypes.sizeof(N.Op))
+        sp = N.stream_ptr(self.device) if stream is None else ctypes.c_void_p(stream.cuda_stream)
         with torch.cuda.device(self.device):
             if self.ws is not None:
                 wptr = (self.ws.data_ptr() + 255) & ~255
-                rc = N.lib.ssdk_run_ops(self.ops, len(self.layers), wptr, self.ws.numel() - (wptr - self.ws.data_ptr()),
-                                        N.stream_ptr(self.device))
+                rc = N.lib.ssdk_run_ops(ops, hi - lo, wptr, self.ws.numel() - (wptr - self.ws.data_ptr()), sp)
             else:
-                rc = N.lib.ssdk_run_ops(self.ops, len(self.layers), None, 0, N.stream_ptr(self.device))
+                rc = N.lib.ssdk_run_ops(ops, hi - lo, None, 0, sp)
         N.check(rc, "run_ops")
+        STATS["native_layers"] += hi - lo
+
+    def run(self, *inputs):
+        """prepare + launch of the whole plan on the current stream.  Returns (loc tuple, conf tuple), NCHW."""
+        out = self.prepare(*inputs)
+        self.launch()
         STATS["plan_runs"] += 1
-        STATS["native_layers"] += len(self.layers)
-        return tuple(loc), tuple(conf)
+        return out
 
 
 def sequential_groups(seq):

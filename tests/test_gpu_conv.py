@@ -647,3 +647,31 @@ def test_hipgraph_captured_inference_matches_eager():
             want = dec(*model(x), anchors)
         for a, b in zip(got, want):
             assert torch.equal(a, b)
+
+
+def test_tail_stream_decoder_under_forward_load():
+    """Decoder.enable_tail_stream() in a serving loop: level + NMS kernels of batch i run on the tail stream while
+    the plan of batch i+1 executes on the main stream.  540 batches must equal the in-line detections bit for bit."""
+    import torch
+    from collections import OrderedDict
+    from ssds.modeling import nets, ssds
+    from ssds.modeling.layers import box
+    from ssds.modeling.layers.decoder import Decoder
+
+    torch.manual_seed(8)
+    fl = [[5, 7, "Conv:S", "Conv:S", "Conv:S"], [96, 320, 256, 128, 128]]
+    nets_outputs, extras, hd = ssds.SSD.add_extras(fl, [6] * 5, 7)
+    model = ssds.SSD(nets.MobileNetV2(outputs=nets_outputs), extras, hd, 7).eval().cuda().to(torch.bfloat16)
+    anchors = OrderedDict((s, box.generate_anchors(s, [1, 2, 0.5], [2.0, 2.828])) for s in (16, 32, 64, 128, 256))
+    dec = Decoder(0.005, 0.6, 50, 100, True, True)
+    xs = [torch.rand(16, 3, 256, 256, device="cuda").to(torch.bfloat16) for _ in range(9)]
+    with torch.no_grad():
+        want = [tuple(t.clone() for t in dec(*model(x), anchors)) for x in xs]
+        piped = Decoder(0.005, 0.6, 50, 100, True, True).enable_tail_stream()
+        for rep in range(60):
+            got = [piped(*model(x), anchors) for x in xs]
+            piped.wait()
+            torch.cuda.synchronize()
+            for g, w in zip(got, want):
+                for a, b in zip(g, w):
+                    assert torch.equal(a, b)
