@@ -117,6 +117,13 @@ int ssdk_decode_nms(const ssdk_level* levels, int L, int B, int dtype, float thr
  * event of the call that last used one; host mirror: ssds/modeling/layers/decoder.py). */
 int ssdk_set_decode_tail_stream(void* stream);
 
+/* (new, debug) SSDK_LDS_POISON=1 in the environment fills every CU's LDS with NaN patterns in front of each kernel of
+ * ssdk_run_ops / ssdk_conv / ssdk_mbconv / ssdk_decode_nms, so that a kernel reading LDS it did not write shows up
+ * as NaNs in the parity tests instead of depending on the previous tenant of its CU.  ssdk_debug_lds_probe poisons
+ * once and returns in *count (device, zeroed by the caller) how many poisoned words a kernel that never wrote its LDS
+ * can see. */
+int ssdk_debug_lds_probe(unsigned* count, void* stream);
+
 /* Optional per-kernel timing for roofline accounting (bench.py): when enabled, ssdk_decode_nms records
  * hipEvents on the caller's stream around its three launches into a ring of 256 slots (no
  * synchronisation inside the timed region).  ssdk_get_timings(back, ms, 3) returns ms[0..2] = scan_kernel,

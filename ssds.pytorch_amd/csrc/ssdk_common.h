@@ -21,6 +21,7 @@ constexpr int kWave = 64;
 // ---- host-side error plumbing (ssdk_api.cpp) -------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+void lds_poison(hipStream_t stream);  // ssdk_debug.hip: no-op unless SSDK_LDS_POISON=1
 
 // ---- order-preserving float <-> u32 (total order on non-NaN floats) ---------------------------
 __host__ __device__ __forceinline__ u32 ord_f32(float f) {

@@ -962,6 +962,7 @@ static thread_local bool g_underfill_ok = false;  // set by ssdk_run_ops around 
 
 extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  ssdk::lds_poison(stream);
   if (!d || !d->x || !d->w || !d->bias || !d->y) {
     set_error("conv: null pointer (x, w, bias and y are mandatory)");
     return SSDK_E_BADARG;
@@ -1288,6 +1289,7 @@ extern "C" int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t w
       wb = ws_side_bytes;
     }
     int rc;
+    ssdk::lds_poison(st);
     if (ops[i].kind == SSDK_OP_CONV) {
       g_underfill_ok = side;
       rc = ssdk_conv(&ops[i].conv, w, wb, st);

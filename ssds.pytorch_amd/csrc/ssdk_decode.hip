@@ -496,6 +496,7 @@ static int launch_decode(const ssdk_level* lv, int L, int B, int dtype, float th
 
   const size_t lds = lds_bytes_for((u32)K);
   const dim3 grid((unsigned)(B * pl.units_per_image));
+  lds_poison(stream);
   if (g_prof_events) (void)hipEventRecord(g_prof_events[0], stream);
   static const int pf = [] {  // 16-byte loads in flight per lane: 4 (default) or 8 (SSDK_SCAN_PF=8)
     const char* e = getenv("SSDK_SCAN_PF");
@@ -519,6 +520,7 @@ static int launch_decode(const ssdk_level* lv, int L, int B, int dtype, float th
     if (rc) return rc;
     st2 = tail;
   }
+  lds_poison(st2);
   hipLaunchKernelGGL(level_kernel, dim3((unsigned)L, (unsigned)B), dim3(kLevelThreads), lds, st2, lp);
   rc = check_launch("level_kernel");
   if (g_prof_events) (void)hipEventRecord(g_prof_events[2], st2);

@@ -673,6 +673,7 @@ using namespace ssdk;
 
 extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  ssdk::lds_poison(stream);
   if (!d || !d->x || !d->y || !d->w_expand || !d->w_dw || !d->w_project || !d->scale_expand || !d->bias_expand ||
       !d->bias_dw || !d->scale_project || !d->bias_project) {
     set_error("mbconv: null pointer");

@@ -271,6 +271,7 @@ static int launch_nms(const float* scores, const float* boxes, const float* clas
   p.out_scores = os;
   p.out_boxes = ob;
   p.out_classes = oc;
+  lds_poison(stream);
   hipLaunchKernelGGL(nms_kernel, dim3((unsigned)B), dim3(kNmsThreads), nms_lds_bytes(N, ndet), stream, p);
   return check_launch("nms_kernel");
 }

@@ -145,6 +145,8 @@ def _load():
     lib.ssdk_match_loss.restype = i32
     lib.ssdk_match_loss.argtypes = [vp, i32, i32, c.POINTER(f32), i32, i32, i32, i32, i32, i32, f32, f32, f32,
                                     vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, sz, vp]
+    lib.ssdk_debug_lds_probe.restype = i32
+    lib.ssdk_debug_lds_probe.argtypes = [vp, vp]
     lib.ssdk_set_decode_tail_stream.restype = i32
     lib.ssdk_set_decode_tail_stream.argtypes = [vp]
     lib.ssdk_map_match.restype = i32
@@ -176,7 +178,7 @@ EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_p
            "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
            "ssdk_match_targets_by_scale", "ssdk_match_loss_workspace_bytes", "ssdk_match_loss",
-           "ssdk_map_match", "ssdk_map_average_precision", "ssdk_set_decode_tail_stream",
+           "ssdk_map_match", "ssdk_map_average_precision", "ssdk_set_decode_tail_stream", "ssdk_debug_lds_probe",
            "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_fuse", "ssdk_preprocess", "ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data",
            "ssdk_dwconv_bwd_weight_workspace_bytes", "ssdk_dwconv_bwd_weight", "ssdk_bn_workspace_bytes",
            "ssdk_bn_train_fwd", "ssdk_bn_train_bwd", "ssdk_conv_stem7", "ssdk_maxpool3x3s2", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
