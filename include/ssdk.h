@@ -169,12 +169,15 @@ int ssdk_match_targets_by_scale(const float* targets, int B, int G, const float*
  * reduced in a fixed order (bit-reproducible).  by_scale = 0: thr_a/thr_b = match/unmatch IoU thresholds and
  * `radius` the centre-sampling radius; by_scale = 1: thr_a/thr_b = lower/upper scale multipliers and radius != 0
  * turns centre sampling on.  The caller divides by the foreground count summed over levels (:69-71) and scales
- * the gradients by the incoming scalar.  dtype = SSDK_F32 | SSDK_BF16 | SSDK_F16 of conf/loc/d_conf/d_loc. */
+ * the gradients by the incoming scalar.  dtype = SSDK_F32 | SSDK_BF16 | SSDK_F16 of conf/loc/d_conf/d_loc.
+ * loc_loss: 0 = SmoothL1Loss(beta); 1..4 = IOULoss 'iou' | 'giou' | 'diou' | 'ciou' (criterion.py:154-293): one term per
+ * foreground anchor on the boxes the predicted / target deltas encode, differentiated in forward mode inside the
+ * kernel with torch's rules for max/min ties and clamp. */
 size_t ssdk_match_loss_workspace_bytes(int B, int A, int H, int W);
 int ssdk_match_loss(const float* targets, int B, int G, const float* anchors, int A, int C, int H, int W,
                     int stride, int by_scale, float thr_a, float thr_b, float radius, const void* conf,
-                    const void* loc, int dtype, float alpha, float gamma, float beta, void* d_conf,
-                    void* d_loc, float* sums, void* workspace, size_t workspace_bytes, void* stream);
+                    const void* loc, int dtype, float alpha, float gamma, float beta, int loc_loss,
+                    void* d_conf, void* d_loc, float* sums, void* workspace, size_t workspace_bytes, void* stream);
 
 /* VOC-style mAP bookkeeping of the eval epoch: MeanAveragePrecision.__call__
  * (core/evaluation_metrics.py:15-61, called per batch at pipeline/pipeline_anchor_basic.py:161-176) for one batch

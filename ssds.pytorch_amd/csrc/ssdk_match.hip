@@ -33,6 +33,7 @@ struct MatchParams {
   void* d_loc;
   float* partial;    // [gridDim.y * gridDim.x, 3]: cls sum, loc sum, #foreground
   float alpha, gamma, beta;
+  int loc_loss;  // 0: smooth-L1(beta); 1..4: IoU / GIoU / DIoU / CIoU on the deltas (criterion.py:154-239)
 };
 
 struct GtRow {
@@ -48,6 +49,97 @@ template <int DT>
 __device__ __forceinline__ void st_elem(void* p, size_t i, float v) {
   if constexpr (DT == SSDK_F32) ((float*)p)[i] = v;
   else ((u16*)p)[i] = f32_to_bits16<DT>(v);
+}
+
+// ---- forward-mode differentiation of the IoU-family losses ------------------------------------------------------
+// value + the four partials w.r.t. the predicted deltas (cx, cy, log w, log h); the rules are those of the torch ops
+// the reference composes (criterion.py:173-239): max/min split the gradient on ties, clamp passes it inside [lo, hi]
+// (NaN falls through, like torch.clamp), the (lt < rb) masks and CIoU's alpha are constants.
+struct D4 {
+  float v, g[4];
+};
+__device__ __forceinline__ D4 d_cst(float c) { return D4{c, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ D4 d_var(float x, int k) {
+  D4 r = d_cst(x);
+  r.g[k] = 1.f;
+  return r;
+}
+#define SSDK_D4(expr_v, expr_g) \
+  D4 r;                         \
+  r.v = (expr_v);               \
+  _Pragma("unroll") for (int k = 0; k < 4; ++k) r.g[k] = (expr_g); \
+  return r;
+__device__ __forceinline__ D4 operator+(const D4& a, const D4& b) { SSDK_D4(a.v + b.v, a.g[k] + b.g[k]) }
+__device__ __forceinline__ D4 operator-(const D4& a, const D4& b) { SSDK_D4(a.v - b.v, a.g[k] - b.g[k]) }
+__device__ __forceinline__ D4 operator*(const D4& a, const D4& b) { SSDK_D4(a.v * b.v, a.g[k] * b.v + b.g[k] * a.v) }
+__device__ __forceinline__ D4 operator/(const D4& a, const D4& b) {
+  SSDK_D4(a.v / b.v, (a.g[k] * b.v - b.g[k] * a.v) / (b.v * b.v))
+}
+__device__ __forceinline__ D4 d_scale(const D4& a, float c) { SSDK_D4(a.v * c, a.g[k] * c) }
+__device__ __forceinline__ D4 d_exp(const D4& a) {
+  const float e = expf(a.v);
+  SSDK_D4(e, a.g[k] * e)
+}
+__device__ __forceinline__ D4 d_atan(const D4& a) {
+  const float q = 1.0f / (1.0f + a.v * a.v);
+  SSDK_D4(atanf(a.v), a.g[k] * q)
+}
+__device__ __forceinline__ D4 d_max(const D4& a, const D4& b) {
+  if (a.v > b.v) return a;
+  if (b.v > a.v) return b;
+  SSDK_D4(a.v, 0.5f * (a.g[k] + b.g[k]))
+}
+__device__ __forceinline__ D4 d_min(const D4& a, const D4& b) {
+  if (a.v < b.v) return a;
+  if (b.v < a.v) return b;
+  SSDK_D4(a.v, 0.5f * (a.g[k] + b.g[k]))
+}
+__device__ __forceinline__ D4 d_clamp(const D4& a, float lo, float hi) {
+  if (a.v < lo) return d_cst(lo);
+  if (a.v > hi) return d_cst(hi);
+  return a;
+}
+#undef SSDK_D4
+
+// 1 - IoU-family overlap of the boxes encoded by the predicted and the target deltas; kind 1..4 = iou, giou, diou, ciou
+__device__ __forceinline__ D4 iou_family_loss(const float (&pd)[4], const float (&td)[4], int kind) {
+  constexpr float kEps = 1e-7f;
+  const D4 px = d_var(pd[0], 0), py = d_var(pd[1], 1);
+  const D4 pw = d_exp(d_var(pd[2], 2)), ph = d_exp(d_var(pd[3], 3));  // criterion.py:226-231 delta2ltrb
+  const D4 tx = d_cst(td[0]), ty = d_cst(td[1]), tw = d_cst(expf(td[2])), th = d_cst(expf(td[3]));
+  const D4 pl = px - d_scale(pw, 0.5f), pr = px + d_scale(pw, 0.5f), pt = py - d_scale(ph, 0.5f), pb = py + d_scale(ph, 0.5f);
+  const D4 tl = tx - d_scale(tw, 0.5f), tr = tx + d_scale(tw, 0.5f), tt = ty - d_scale(th, 0.5f), tb = ty + d_scale(th, 0.5f);
+  const D4 l = d_max(pl, tl), r = d_min(pr, tr), t = d_max(pt, tt), b = d_min(pb, tb);  // :183-184
+  const float m = (l.v < r.v && t.v < b.v) ? 1.0f : 0.0f;
+  const D4 inter = d_scale((r - l) * (b - t), m);                                        // :186
+  const D4 uni = pw * ph + tw * th - inter;                                              // :187-190
+  const D4 iou = (inter + d_cst(kEps)) / (uni + d_cst(kEps));                            // :191
+  D4 q;
+  if (kind == 1) {
+    q = d_clamp(iou, 0.0f, 1.0f);  // :193-195
+  } else {
+    const D4 ol = d_min(pl, tl), orr = d_max(pr, tr), ot = d_min(pt, tt), ob = d_max(pb, tb);  // :197-198
+    if (kind == 2) {
+      const float mo = (ol.v < orr.v && ot.v < ob.v) ? 1.0f : 0.0f;
+      const D4 hull = d_scale((orr - ol) * (ob - ot), mo) + d_cst(kEps);  // :201-205
+      q = d_clamp(iou - (hull - uni) / hull, -1.0f, 1.0f);                // :206-208
+    } else {
+      const D4 dx = px - tx, dy = py - ty, ow = orr - ol, oh = ob - ot;
+      D4 pen = (dx * dx + dy * dy) / (ow * ow + oh * oh + d_cst(kEps));  // :210-211
+      if (kind == 4) {                                                   // :218-231
+        const D4 da = d_atan(tw / th) - d_atan(pw / ph);
+        const D4 v = d_scale(da * da, 0.40528473456935116f);  // 4 / pi^2
+        const float alpha = v.v / (1.0f - iou.v + v.v);       // constant for the gradient (torch.no_grad)
+        pen = pen + d_scale(v, alpha);
+      }
+      q = d_clamp(iou - pen, -1.0f, 1.0f);  // :213-216, :232-234
+    }
+  }
+  D4 out;
+  out.v = 1.0f - q.v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out.g[k] = -q.g[k];
+  return out;
 }
 
 // LOSS = 0: write the three target tensors.  LOSS = 1: never materialise them -- evaluate the focal and smooth-L1
@@ -230,8 +322,23 @@ __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams 
       s_cls += care ? loss : 0.f;
       st_elem<DT>(p.d_conf, i, care ? grad : 0.f);
     }
-    // smooth-L1 (criterion.py:111-151) masked by depth > 0 (pipeline_anchor_apex.py:62-66)
+    // localisation loss masked by depth > 0 (pipeline_anchor_apex.py:62-66)
     const bool fg = dep > 0.f;
+    if (p.loc_loss != 0) {  // IoU family (criterion.py:154-239): one term per anchor
+      float pd[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pd[k] = ld_elem<DT>(p.loc, box_i + (size_t)k * HW);
+      if (fg) {
+        const D4 r = iou_family_loss(pd, delta, p.loc_loss);
+        s_loc += r.v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st_elem<DT>(p.d_loc, box_i + (size_t)k * HW, r.g[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st_elem<DT>(p.d_loc, box_i + (size_t)k * HW, 0.f);
+      }
+    } else {
+    // smooth-L1 (criterion.py:111-151)
     const float rb = 1.0f / p.beta;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -243,6 +350,7 @@ __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams 
       const float grad = lin ? (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.f)) : d * rb;
       s_loc += fg ? loss : 0.f;
       st_elem<DT>(p.d_loc, i, fg ? grad : 0.f);
+    }
     }
     s_fg = fg ? 1.0f : 0.f;
   }
@@ -362,7 +470,7 @@ extern "C" size_t ssdk_match_loss_workspace_bytes(int B, int A, int H, int W) {
 extern "C" int ssdk_match_loss(const float* targets, int B, int G, const float* anchors, int A, int C, int H,
                                int W, int stride, int by_scale, float thr_a, float thr_b, float radius,
                                const void* conf, const void* loc, int dtype, float alpha, float gamma,
-                               float beta, void* d_conf, void* d_loc, float* sums, void* workspace,
+                               float beta, int loc_loss, void* d_conf, void* d_loc, float* sums, void* workspace,
                                size_t workspace_bytes, void* stream) {
   using namespace ssdk;
   if (!targets || !anchors || !conf || !loc || !d_conf || !d_loc || !sums || !workspace) {
@@ -370,9 +478,9 @@ extern "C" int ssdk_match_loss(const float* targets, int B, int G, const float* 
     return SSDK_E_BADARG;
   }
   if (B < 1 || G < 0 || G > SSDK_MAX_GT || A < 1 || A > SSDK_MAX_ANCHORS || C < 1 || H < 1 || W < 1 ||
-      stride < 1 || !(beta > 0.f)) {
-    set_error("match_loss: bad dims B=%d G=%d (<=%d) A=%d (<=%d) C=%d H=%d W=%d stride=%d beta=%g", B, G,
-              SSDK_MAX_GT, A, SSDK_MAX_ANCHORS, C, H, W, stride, (double)beta);
+      stride < 1 || loc_loss < 0 || loc_loss > 4 || (loc_loss == 0 && !(beta > 0.f))) {
+    set_error("match_loss: bad dims B=%d G=%d (<=%d) A=%d (<=%d) C=%d H=%d W=%d stride=%d beta=%g loc_loss=%d", B, G,
+              SSDK_MAX_GT, A, SSDK_MAX_ANCHORS, C, H, W, stride, (double)beta, loc_loss);
     return SSDK_E_BADARG;
   }
   if (dtype != SSDK_F32 && dtype != SSDK_BF16 && dtype != SSDK_F16) {
@@ -412,6 +520,7 @@ extern "C" int ssdk_match_loss(const float* targets, int B, int G, const float* 
   p.alpha = alpha;
   p.gamma = gamma;
   p.beta = beta;
+  p.loc_loss = loc_loss;
   const unsigned total = (unsigned)A * H * W;
   dim3 grid((total + kMatchThreads - 1) / kMatchThreads, (unsigned)B);
   hipStream_t st = (hipStream_t)stream;

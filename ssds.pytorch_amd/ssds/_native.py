@@ -144,7 +144,7 @@ def _load():
     lib.ssdk_match_loss_workspace_bytes.argtypes = [i32] * 4
     lib.ssdk_match_loss.restype = i32
     lib.ssdk_match_loss.argtypes = [vp, i32, i32, c.POINTER(f32), i32, i32, i32, i32, i32, i32, f32, f32, f32,
-                                    vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, sz, vp]
+                                    vp, vp, i32, f32, f32, f32, i32, vp, vp, vp, vp, sz, vp]
     lib.ssdk_debug_lds_probe.restype = i32
     lib.ssdk_debug_lds_probe.argtypes = [vp, vp]
     lib.ssdk_set_decode_tail_stream.restype = i32

@@ -13,7 +13,8 @@ from ssds.modeling.layers.box import _anchor_array
 
 class _MatchLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, conf, loc, targets, anc, classes, stride, by_scale, thr_a, thr_b, radius, alpha, gamma, beta):
+    def forward(ctx, conf, loc, targets, anc, classes, stride, by_scale, thr_a, thr_b, radius, alpha, gamma, beta,
+                loc_loss):
         N.require_device(conf, "match_loss")
         if loc.dtype != conf.dtype:
             loc = loc.to(conf.dtype)
@@ -34,7 +35,8 @@ class _MatchLoss(torch.autograd.Function):
             rc = N.lib.ssdk_match_loss(
                 t.data_ptr(), B, G, anc.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), A, int(classes), H, W,
                 int(stride), int(by_scale), float(thr_a), float(thr_b), float(radius), conf_c.data_ptr(),
-                loc_c.data_ptr(), N.dtype_code(conf_c), float(alpha), float(gamma), float(beta), d_conf.data_ptr(),
+                loc_c.data_ptr(), N.dtype_code(conf_c), float(alpha), float(gamma), float(beta), int(loc_loss),
+                d_conf.data_ptr(),
                 d_loc.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws_bytes, N.stream_ptr(dev))
         N.check(rc, "match_loss")
         ctx.save_for_backward(d_conf, d_loc)
@@ -48,13 +50,17 @@ class _MatchLoss(torch.autograd.Function):
         # in place: the stored gradients are this node's own buffers and backward runs once
         gc = d_conf.mul_(g_cls) if g_cls is not None else None  # 0-dim fp32 scale, fp32 arithmetic, dtype kept
         gl = d_loc.mul_(g_loc) if g_loc is not None else None
-        return (gc, gl) + (None,) * 11
+        return (gc, gl) + (None,) * 12
+
+
+LOC_LOSS = {"smoothl1": 0, "iou": 1, "giou": 2, "diou": 3, "ciou": 4}
 
 
 def match_loss(conf, loc, targets, anchors, classes, stride, match, center_sampling_radius=0, alpha=0.25, gamma=2.0,
-               beta=0.11):
+               beta=0.11, loc_loss="smoothl1"):
     """conf [B, A*C, H, W] logits and loc [B, A*4, H, W] of one level, targets [B, G, 5] (x, y, w, h, label; -1 =
-    padding), ``anchors`` / ``match`` as for ``box.extract_targets``.  Returns (cls_sum, loc_sum, fg): the masked
+    padding), ``anchors`` / ``match`` as for ``box.extract_targets``; ``loc_loss``: ``smoothl1`` (``beta``) or the
+    ``IOULoss`` types ``iou | giou | diou | ciou``.  Returns (cls_sum, loc_sum, fg): the masked
     focal sum and smooth-L1 sum (differentiable w.r.t. conf / loc) and the un-clamped foreground count, fp32
     scalars on the device."""
     by_scale = isinstance(match[0], list)
@@ -66,5 +72,6 @@ def match_loss(conf, loc, targets, anchors, classes, stride, match, center_sampl
     else:
         thr_a, thr_b = match[0], match[1]
     cls_sum, loc_sum, sums = _MatchLoss.apply(conf, loc, targets, anc, int(classes), int(stride), by_scale, thr_a,
-                                              thr_b, float(center_sampling_radius), alpha, gamma, beta)
+                                              thr_b, float(center_sampling_radius), alpha, gamma, beta,
+                                              LOC_LOSS[loc_loss])
     return cls_sum, loc_sum, sums[2]

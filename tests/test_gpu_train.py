@@ -140,10 +140,12 @@ def test_batchnorm_training_kernels_match_torch(n, c, h, w, dtype_name, tol):
     close(fast(x), ref(x.float()), "eval path is nn.BatchNorm2d")
 
 
-@pytest.mark.parametrize("mode,dtype_name,gamma", [
-    ("iou", "float32", 2.0), ("iou", "bfloat16", 2.0), ("iou_radius", "float32", 1.5), ("scale", "float32", 2.0),
-    ("scale_center", "float16", 2.0)])
-def test_fused_match_loss_matches_unfused_losses(mode, dtype_name, gamma):
+@pytest.mark.parametrize("mode,dtype_name,gamma,loc_loss", [
+    ("iou", "float32", 2.0, "smoothl1"), ("iou", "bfloat16", 2.0, "smoothl1"), ("iou_radius", "float32", 1.5, "smoothl1"),
+    ("scale", "float32", 2.0, "smoothl1"), ("scale_center", "float16", 2.0, "smoothl1"),
+    ("iou", "float32", 2.0, "iou"), ("iou", "float32", 2.0, "giou"), ("iou", "float32", 2.0, "diou"),
+    ("iou", "float32", 2.0, "ciou"), ("scale", "bfloat16", 2.0, "giou")])
+def test_fused_match_loss_matches_unfused_losses(mode, dtype_name, gamma, loc_loss):
     """ssdk_match_loss (target assignment + focal + smooth-L1 + masks + sums + gradients in one launch) against
     extract_targets followed by the torch criteria and autograd, per level of ModelWithLossBasic.forward."""
     import torch
@@ -171,13 +173,16 @@ def test_fused_match_loss_matches_unfused_losses(mode, dtype_name, gamma):
         match, radius = [[-1, 6.0], [0.5, 4.0]], (1.5 if mode == "scale_center" else 0)
     conf = (torch.randn(B, A * C, H, W) * 3).to(dtype).cuda().requires_grad_(True)
     loc = torch.randn(B, A * 4, H, W).mul(0.3).to(dtype).cuda().requires_grad_(True)
-    fl, sl = criterion.FocalLoss(gamma=gamma), criterion.SmoothL1Loss()
+    fl = criterion.FocalLoss(gamma=gamma)
+    sl = criterion.SmoothL1Loss() if loc_loss == "smoothl1" else criterion.IOULoss(loc_loss)
+    beta = getattr(sl, "beta", 0.11)
 
     ct, lt, depth = box.extract_targets(targets, anchors, C, stride, (H, W), match, radius)
     c = conf.view_as(ct).float()
     cls_ref = ((depth >= 0).expand_as(ct).float() * fl(c, ct, depth)).sum()
     l = loc.view_as(lt).float()
-    loc_ref = ((depth > 0).expand_as(lt).float() * sl(l, lt)).sum()
+    loc_el = sl(l, lt)  # [B,A,4,H,W] (smooth-L1) or [B,A,1,H,W] (IoU family)
+    loc_ref = ((depth > 0).expand_as(loc_el).float() * loc_el).sum()
     fg_ref = (depth > 0).sum().float()
     assert fg_ref > 0 and (mode.startswith("scale") or (depth < 0).any())
     w_cls, w_loc = 0.37, 1.9
@@ -185,7 +190,8 @@ def test_fused_match_loss_matches_unfused_losses(mode, dtype_name, gamma):
     gc_ref, gl_ref = conf.grad.clone(), loc.grad.clone()
     conf.grad = loc.grad = None
 
-    cls_sum, loc_sum, fg = match_loss(conf, loc, targets, anchors, C, stride, match, radius, fl.alpha, fl.gamma, sl.beta)
+    cls_sum, loc_sum, fg = match_loss(conf, loc, targets, anchors, C, stride, match, radius, fl.alpha, fl.gamma, beta,
+                                      loc_loss)
     assert float(fg) == float(fg_ref)  # exact: the same matching
     assert abs(float(cls_sum) - float(cls_ref)) <= 2e-5 * abs(float(cls_ref))
     assert abs(float(loc_sum) - float(loc_ref)) <= 2e-5 * abs(float(loc_ref))
@@ -196,7 +202,7 @@ def test_fused_match_loss_matches_unfused_losses(mode, dtype_name, gamma):
         err = (got.float() - ref.float()).abs()
         assert float((err - tol * ref.float().abs()).max()) <= tol, float(err.max())
     # bit-reproducible sums
-    again = match_loss(conf, loc, targets, anchors, C, stride, match, radius, fl.alpha, fl.gamma, sl.beta)
+    again = match_loss(conf, loc, targets, anchors, C, stride, match, radius, fl.alpha, fl.gamma, beta, loc_loss)
     assert float(again[0]) == float(cls_sum) and float(again[1]) == float(loc_sum)
 
 
