@@ -77,3 +77,29 @@ def test_no_cpu_fallback():
         box.decode(cls, loc, 8, 0.05, 10, anc)
     with pytest.raises(N.SsdkError, match="no CPU fallback"):
         box.nms(torch.zeros(1, 4), torch.zeros(1, 4, 4), torch.zeros(1, 4))
+
+
+def test_no_cpu_fallback_for_training_and_eval_kernels():
+    """The fused loss, the mAP bookkeeping, target assignment and the fused conv entry points refuse host tensors."""
+    from collections import OrderedDict
+
+    import torch
+    from ssds import _native as N
+    from ssds.core.evaluation_metrics import MeanAveragePrecision
+    from ssds.core.fused_loss import match_loss
+    from ssds.modeling.layers import box
+
+    anchors = OrderedDict([(8, torch.tensor([[-4.0, -4, 11, 11]]))])
+    targets = torch.tensor([[[1.0, 1, 8, 8, 0]]])
+    with pytest.raises(N.SsdkError, match="no CPU fallback"):
+        match_loss(torch.zeros(1, 3, 2, 2), torch.zeros(1, 4, 2, 2), targets, anchors, 3, 8, [0.5, 0.4])
+    with pytest.raises(N.SsdkError, match="no CPU fallback"):
+        box.extract_targets(targets, anchors, 3, 8, (2, 2), [0.5, 0.4])
+    with pytest.raises(N.SsdkError, match="no CPU fallback"):
+        MeanAveragePrecision(3, 0.1, 0.5)((torch.zeros(1, 4), torch.zeros(1, 4, 4), torch.zeros(1, 4)), targets)
+    # bad arguments come back as error codes, not crashes
+    assert N.lib.ssdk_match_loss(None, 1, 1, None, 1, 1, 1, 1, 8, 0, 0.5, 0.4, 0.0, None, None, 0, 0.25, 2.0, 0.11, 0,
+                                 None, None, None, None, 0, None) == -1
+    assert N.lib.ssdk_map_match(None, None, None, 1, 4, None, 1, 3, 0.1, 0.5, None, None, None, None) == -1
+    assert N.lib.ssdk_map_average_precision(None, None, None, 3, None, None) == -1
+    assert N.lib.ssdk_match_loss_workspace_bytes(0, 1, 1, 1) == 0
