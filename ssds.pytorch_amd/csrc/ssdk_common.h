@@ -83,7 +83,24 @@ __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int d) {
 }
 
 // torch.min / torch.max semantics (NaN propagates) -- fminf/fmaxf would drop the NaN
-__device__ __forceinline__ float tmin(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
-__device__ __forceinline__ float tmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+// NaN-propagating min / max (torch.min / torch.max / clamp semantics) WITHOUT a compare-and-select: v_min / v_max
+// (which drop a NaN operand) plus a NaN mask built from integer arithmetic.  The obvious form
+// `(a != a) ? a : (b != b) ? b : (a < b ? a : b)` compiles to v_cmp ... v_cndmask through VCC, and on this stack a
+// select was observed to read a stale quarter of VCC (lanes 48-63) when waves of other queues share the SIMD
+// (1 % of the batches of a two-stream pipeline, 0 of 2 700 with this form).  The subtraction is opaque
+// to the optimiser on purpose: LLVM would otherwise turn the sign test back into a compare.
+__device__ __forceinline__ u32 nan_or_mask(float a, float b) {  // 0x7fc00000 when a or b is NaN, else 0
+  const u32 ba = __builtin_bit_cast(u32, a) & 0x7fffffffu, bb = __builtin_bit_cast(u32, b) & 0x7fffffffu;
+  u32 ta, tb;
+  asm("v_sub_u32 %0, 0x7f800000, %1" : "=v"(ta) : "v"(ba));  // negative iff |bits| > inf, i.e. NaN
+  asm("v_sub_u32 %0, 0x7f800000, %1" : "=v"(tb) : "v"(bb));
+  return (u32)((int)(ta | tb) >> 31) & 0x7fc00000u;
+}
+__device__ __forceinline__ float tmin(float a, float b) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(u32, __builtin_fminf(a, b)) | nan_or_mask(a, b));
+}
+__device__ __forceinline__ float tmax(float a, float b) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(u32, __builtin_fmaxf(a, b)) | nan_or_mask(a, b));
+}
 
 }  // namespace ssdk

@@ -248,8 +248,8 @@ __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams 
       const float x1 = tmax(ax1, q.x1), y1 = tmax(ay1, q.y1);  // box.py:163-165
       const float x2 = tmin(ax2, q.x2), y2 = tmin(ay2, q.y2);
       float w = x2 - x1 + 1.0f, h = y2 - y1 + 1.0f;
-      w = (w < 0.f) ? 0.f : w;
-      h = (h < 0.f) ? 0.f : h;
+      w = tmax(w, 0.f);
+      h = tmax(h, 0.f);
       const float inter = w * h;
       const float ov = inter / (aarea + q.area - inter);  // box.py:168 (no epsilon)
       if (g == 0 || ov > best) {  // box.py:171: first maximum wins

@@ -48,8 +48,8 @@ __device__ __forceinline__ bool suppressed_by(const float4 b, float ab, const fl
   const float ix1 = tmax(b.x, p.x), iy1 = tmax(b.y, p.y);
   const float ix2 = tmin(b.z, p.z), iy2 = tmin(b.w, p.w);
   float w = ix2 - ix1 + 1.0f, h = iy2 - iy1 + 1.0f;
-  w = (w < 0.0f) ? 0.0f : w;  // clamp(0) keeps NaN like torch
-  h = (h < 0.0f) ? 0.0f : h;
+  w = tmax(w, 0.0f);  // clamp(0) keeps NaN like torch
+  h = tmax(h, 0.0f);
   const float inter = w * h;
   const float iou = inter / (ab + ap - inter + 1e-7f);
   bool over = !(iou <= thr);
