@@ -208,3 +208,49 @@ def test_map_oracle_vs_reference(name):
     mAP, ap = m.get_results()
     np.testing.assert_allclose(np.array(ap), g[name + "/ap"], rtol=1e-12, atol=0, equal_nan=True)
     np.testing.assert_allclose(mAP, float(g[name + "/mAP"]), rtol=1e-12)
+
+
+def test_map_oracle_properties():
+    """Size-independent properties of the mAP bookkeeping (oracle/map_oracle.py): image order does not matter when
+    scores are distinct, detections at or below the score threshold do not count, perfect detections give AP 1,
+    splitting an epoch into batches changes nothing."""
+    from oracle import map_oracle as MO
+
+    d = cases.map_inputs("m_coco_like")
+    C, ct, it = d["C"], d["conf_thr"], d["iou_thr"]
+
+    def run(batches):
+        m = MO.MeanAveragePrecision(C, ct, it)
+        for bt in batches:
+            m((bt["scores"], bt["boxes"], bt["classes"]), bt["targets"])
+        return m.get_results()
+
+    base_map, base_ap = run(d["batches"])
+    # one image per call, in reverse order
+    singles = []
+    for bt in d["batches"]:
+        for b in range(bt["scores"].shape[0]):
+            singles.append({k: v[b:b + 1] for k, v in bt.items()})
+    rev_map, rev_ap = run(singles[::-1])
+    np.testing.assert_allclose(np.array(rev_ap), np.array(base_ap), rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(rev_map, base_map, rtol=1e-12)
+    # extra detections at the threshold are ignored (score > threshold, strictly)
+    padded = []
+    for bt in d["batches"]:
+        B, D = bt["scores"].shape
+        s = np.concatenate([bt["scores"], np.full((B, 5), ct, F32)], 1)
+        bx = np.concatenate([bt["boxes"], np.tile(np.array([0, 0, 50, 50], F32), (B, 5, 1))], 1)
+        cl = np.concatenate([bt["classes"], np.zeros((B, 5), F32)], 1)
+        padded.append(dict(scores=s, boxes=bx, classes=cl, targets=bt["targets"]))
+    pad_map, _ = run(padded)
+    assert pad_map == base_map
+    # perfect detections
+    perfect = []
+    for bt in d["batches"]:
+        t = bt["targets"]
+        valid = t[..., 4] >= 0
+        s = np.where(valid, np.linspace(0.9, 0.5, t.shape[1], dtype=F32)[None, :], 0).astype(F32)
+        perfect.append(dict(scores=s, boxes=t[..., :4].copy(), classes=np.where(valid, t[..., 4], 0).astype(F32), targets=t))
+    p_map, p_ap = run(perfect)
+    assert abs(p_map - 1.0) < 1e-12 and all(np.isnan(a) or abs(a - 1.0) < 1e-12 for a in p_ap)
+    assert 0.0 <= base_map <= 1.0
