@@ -187,3 +187,32 @@ def test_criteria_match_reference_outputs_and_gradients(name):
         full = crit(torch.from_numpy(d["logits"]), torch.from_numpy(d["target"]), torch.from_numpy(d["depth"]))
         np.testing.assert_allclose(full[0:1].numpy(), g[name + "/out"], rtol=1e-6, atol=1e-7)
         assert float(full[2].sum()) == 0.0  # no positives -> no mined negatives either
+
+
+def test_plan_arena_pins_buffers_read_by_side_lane_heads():
+    """Recording only (no kernel runs): a buffer read by a small head -- which the executor runs on its side stream,
+    concurrently with the main chain -- must never be handed out again by the plan's arena, while the input of a big
+    (in-line) head is recycled as usual."""
+    import torch.nn as nn
+
+    from ssds.modeling.layers import fused_conv as FC
+
+    dt = torch.bfloat16
+
+    def pack(cin, cout, k=3):
+        return FC.ConvPack(nn.Conv2d(cin, cout, k, 1, k // 2), None, "relu", dt)
+
+    for n, expect_lane in ((2, 1), (64, 0)):  # 2 x 16 x 16 = 512 pixels (side lane) / 64 x 16 x 16 = 16384 (in line)
+        plan = FC.ConvPlan(torch.device("cpu"), dt, (n, 32, 16, 16))
+        x = plan.add_input((n, 32, 16, 16))
+        a = plan.conv(x, pack(32, 32))
+        plan.head(a, FC.pack_heads(nn.Conv2d(32, 8, 3, 1, 1), nn.Conv2d(32, 12, 3, 1, 1), dt), split=8, act="none",
+                  act2="sigmoid")
+        assert plan.layers[-1]["lane"] == expect_lane
+        b = plan.conv(a, pack(32, 32))
+        plan.release(a)                 # the planner is done with `a` ...
+        c = plan.conv(b, pack(32, 32))  # ... so the next output may take its place -- unless a side-lane op reads it
+        if expect_lane:
+            assert a[0] in plan.pinned and c[0] != a[0]
+        else:
+            assert a[0] not in plan.pinned and c[0] == a[0]
