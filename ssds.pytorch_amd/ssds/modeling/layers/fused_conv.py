@@ -739,6 +739,12 @@ class FusedSequentialMixin(object):
         object.__setattr__(self, "_ssdk_packs", None)
         return nn.Sequential._apply(self, fn, *a, **kw)
 
+    def _load_from_state_dict(self, *a, **kw):
+        # reached for EVERY module of the tree whichever ancestor's load_state_dict() was called (a parent's
+        # load_state_dict never calls a child's): the folded weights of this block are stale from here on
+        object.__setattr__(self, "_ssdk_packs", None)
+        return nn.Sequential._load_from_state_dict(self, *a, **kw)
+
     def forward(self, x):
         if self.training or not fused_enabled() or not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16):
             return nn.Sequential.forward(self, x)

@@ -31,6 +31,10 @@ class SharedHead(FusedSequentialMixin, nn.Sequential):
         self.__dict__["_final_pack"] = None
         return super(SharedHead, self)._apply(fn, *a, **kw)
 
+    def _load_from_state_dict(self, *a, **kw):
+        self.__dict__["_final_pack"] = None
+        return super(SharedHead, self)._load_from_state_dict(*a, **kw)
+
     def forward(self, x, final_act="none"):
         for m in list(self.children())[:-1]:
             x = m(x)

@@ -17,7 +17,7 @@ from ssds.modeling.layers import fused_conv as FC
 from ssds.modeling.layers.layers_parser import parse_feature_layer
 from ssds.modeling.layers.planner import PlanUnsupported, build_ssd_plan
 
-from .ssdsbase import SSDSBase
+from .ssdsbase import SSDSBase, drop_child_packs
 
 
 class SSD(SSDSBase):
@@ -51,6 +51,7 @@ class SSD(SSDSBase):
         call it yourself after editing parameters in place."""
         self._plans = {}
         self._head_packs = None
+        drop_child_packs(self)
 
     def train(self, mode=True):
         self.invalidate_plans()
@@ -63,6 +64,11 @@ class SSD(SSDSBase):
     def load_state_dict(self, *a, **kw):
         self.invalidate_plans()
         return super(SSD, self).load_state_dict(*a, **kw)
+
+    def _load_from_state_dict(self, *a, **kw):
+        # also reached when an ANCESTOR's load_state_dict() runs (model-with-loss wrappers, DDP)
+        self.invalidate_plans()
+        return super(SSD, self)._load_from_state_dict(*a, **kw)
 
     def _native_ok(self, x):
         return (not self.training and FC.fused_enabled() and x.is_cuda

@@ -32,6 +32,16 @@ class SSDSBase(nn.Module):
                 nn.init.constant_(layer.bias, val=0)
 
 
+def drop_child_packs(root):
+    """Forget the folded weights cached by the fused blocks below ``root`` (FusedSequentialMixin._ssdk_packs,
+    SharedHead._final_pack): the per-layer fallback path must never run on weights older than the parameters."""
+    for m in root.modules():
+        if "_ssdk_packs" in m.__dict__:
+            m.__dict__["_ssdk_packs"] = None
+        if "_final_pack" in m.__dict__:
+            m.__dict__["_final_pack"] = None
+
+
 class NeckPlanMixin(object):
     """Eval forward of a detector whose backbone runs on PyTorch-ROCm and whose neck + towers run as one
     recorded plan (``ssds/modeling/layers/planner.py``) on the backbone's feature maps.  ``_build_neck_plan`` is
@@ -40,6 +50,7 @@ class NeckPlanMixin(object):
 
     def invalidate_plans(self):
         self.__dict__["_neck_plans"] = {}
+        drop_child_packs(self)
 
     def train(self, mode=True):
         self.invalidate_plans()
@@ -52,6 +63,12 @@ class NeckPlanMixin(object):
     def load_state_dict(self, *a, **kw):
         self.invalidate_plans()
         return super(NeckPlanMixin, self).load_state_dict(*a, **kw)
+
+    def _load_from_state_dict(self, *a, **kw):
+        # also reached when an ANCESTOR's load_state_dict() runs (model-with-loss wrappers, DDP): see
+        # FusedSequentialMixin._load_from_state_dict
+        self.invalidate_plans()
+        return super(NeckPlanMixin, self)._load_from_state_dict(*a, **kw)
 
     def _full_native(self, x):
         """Image -> (loc, conf) with backbone, neck and towers as ONE plan, or None (backbone without a planner,

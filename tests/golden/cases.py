@@ -362,3 +362,78 @@ def loss_inputs():
     tgt[0, 0] = pred[0, 0]          # identical boxes
     tgt[0, 1, :2] = pred[0, 1, :2] + 5.0  # disjoint boxes
     return dict(logits=logits, target=target, depth=depth, pred=pred, tgt=tgt)
+
+
+# ----------------------------------------------------------------------------- whole detector networks
+# (a13-a16: SSD / SSDFPN / SSDBiFPN of the reference around its own backbones, make_golden.gen_nets)
+# name: (seed, head class, backbone factory | "stub", FEATURE_LAYER, anchors per location, classes, (B, H, W))
+NET_CASES = OrderedDict(
+    [
+        ("ssd_mnv2", (91, "SSD", "MobileNetV2", [[5, 7, "Conv:S", "Conv:S"], [96, 320, 256, 128]], 6, 5, (2, 160, 160))),
+        ("fpn_r18", (92, "SSDFPN", "ResNet18", [[3, 4, 5, "Conv:S", "Conv:S"], [128, 256, 512, 512, 256]], 9, 4,
+                     (2, 128, 160))),
+        ("fpn_r50", (93, "SSDFPN", "ResNet50", [[3, 4, 5, "Conv:S", "Conv:S"], [512, 1024, 2048, 2048, 256]], 9, 3,
+                     (2, 128, 128))),
+        ("bifpn_regx008", (94, "SSDBiFPN", "RegNetX008", [[2, 3, 4, "Conv:S", "Conv:S"], [128, 288, 672, 672, 256]],
+                           9, 3, (2, 128, 160))),
+        ("bifpn_regx002_x2", (95, "SSDBiFPN", "RegNetX002", [[2, 3, 4, "Conv:S"], [56, 152, 368, 368], 2], 9, 3,
+                              (2, 64, 96))),
+        # a stub backbone that returns seeded feature maps: the neck / towers / heads alone, on awkward shapes
+        ("ssd_stub", (96, "SSD", "stub", [[0, 1, "Conv:S", "Conv:S"], [64, 136, 128, 64]], 6, 7, (3, 72, 56))),
+        ("fpn_stub", (97, "SSDFPN", "stub", [[0, 1, 2, "Conv:S"], [40, 112, 320, 320]], 9, 2, (2, 96, 128))),
+        ("bifpn_stub", (98, "SSDBiFPN", "stub", [[0, 1, 2, "Conv:S", "Conv:S"], [48, 96, 200, 200, 256]], 3, 6,
+                        (2, 64, 64))),
+    ]
+)
+# stub backbones: feature map l has stride 8 * 2**l and the channel count FEATURE_LAYER names for it
+
+
+def net_image(name):
+    seed, _, _, _, _, _, (B, H, W) = NET_CASES[name]
+    return np.random.RandomState(seed).random_sample((B, 3, H, W)).astype(F32)
+
+
+def stub_features(name):
+    seed, _, net, fl, _, _, (B, H, W) = NET_CASES[name]
+    assert net == "stub"
+    rs = np.random.RandomState(seed + 1000)
+    feats = []
+    for l, (layer, depth) in enumerate(zip(*fl[:2])):
+        if isinstance(layer, int):
+            s = 8 << l
+            feats.append((rs.standard_normal((B, depth, H // s, W // s)) * 0.7).astype(F32))
+    return feats
+
+
+def seeded_state(spec, seed):
+    """Deterministic parameter values for a ``state_dict`` schema ``spec`` = [(key, shape)] (the reference
+    model's), independent of key order: conv / linear weights ~ N(0, 1.5/fan_in), biases ~ N(0, 0.1^2), BatchNorm
+    weight ~ U(0.5, 1.5), BiFPN fusion weights ~ U(-0.2, 1) (negative ones are cut by the relu of bifpn.py:35-38).
+    BatchNorm running statistics are NOT generated here: make_golden.py calibrates them on the reference model
+    (one train-mode pass) and stores them in the fixture."""
+    keys = [k for k, _ in spec]
+    bn = {k[: -len("running_mean")] for k in keys if k.endswith("running_mean")}
+    out = OrderedDict()
+    for k, shape in spec:
+        rs = np.random.RandomState((seed * 7919 + zlib.crc32(k.encode())) & 0x7FFFFFFF)
+        shape = tuple(int(s) for s in shape)
+        pre = k[: k.rfind(".") + 1]
+        if k.endswith("num_batches_tracked"):
+            v = np.zeros(shape, np.int64)
+        elif k.endswith("running_mean"):
+            v = np.zeros(shape, F32)
+        elif k.endswith("running_var"):
+            v = np.ones(shape, F32)
+        elif pre in bn and k.endswith("weight"):
+            v = rs.uniform(0.5, 1.5, shape).astype(F32)
+        elif len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            v = (rs.standard_normal(shape) * np.sqrt(1.5 / fan_in)).astype(F32)
+        elif len(shape) == 2 and (k.endswith("w1") or k.endswith("w2")):
+            v = rs.uniform(-0.2, 1.0, shape).astype(F32)
+        elif len(shape) == 2:
+            v = (rs.standard_normal(shape) * 0.01).astype(F32)
+        else:
+            v = (rs.standard_normal(shape) * 0.1).astype(F32)
+        out[k] = v
+    return out

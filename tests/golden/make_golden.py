@@ -228,6 +228,90 @@ def gen_losses():
     save("losses", **out)
 
 
+class _Stub(torch.nn.Module):
+    """Backbone stand-in of the ``*_stub`` cases: returns the seeded feature maps whatever the image."""
+
+    def __init__(self, feats):
+        super().__init__()
+        self.feats = feats
+
+    def initialize(self):
+        pass
+
+    def forward(self, x):
+        return [f.clone() for f in self.feats]
+
+
+def _reference_nets():
+    """The reference's backbone modules, imported unmodified.  Its ``ssds/modeling/nets/__init__.py`` star-imports
+    every backbone family (densenet, shufflenet, inception ... all torchvision subclasses), so the package is
+    registered here as an empty namespace and only mobilenet / resnet / regnet are loaded, on top of
+    ``tv_shim`` (see there for what that means for parity)."""
+    import importlib
+    import types
+
+    import tv_shim
+
+    tv_shim.install()
+    import ssds.modeling  # noqa: F401  (the reference's, /root/reference first on sys.path)
+
+    pkg = types.ModuleType("ssds.modeling.nets")
+    pkg.__path__ = ["/root/reference/ssds/modeling/nets"]
+    sys.modules["ssds.modeling.nets"] = pkg
+    out = {}
+    for m in ("mobilenet", "resnet", "regnet"):
+        mod = importlib.import_module("ssds.modeling.nets." + m)
+        for n in mod.__all__:
+            out[n] = getattr(mod, n)
+    return out
+
+
+def gen_nets():
+    """SSD / SSDFPN / SSDBiFPN of the reference (ssd.py:42-74, fpn.py:58-101, bifpn.py:30-63,104-142) around its
+    own backbones, eval forward in fp32 on seeded weights.  Stored: the state_dict schema (keys + shapes), the
+    calibrated BatchNorm running statistics and the outputs; weights and inputs are regenerated from seeds
+    (cases.seeded_state / net_image / stub_features)."""
+    from ssds.modeling import ssds as rssds
+
+    rnets = _reference_nets()
+    for name, (seed, head, net, fl, A, C, (B, H, W)) in cases.NET_CASES.items():
+        cls = getattr(rssds, head)
+        nets_outputs, extras, hd = cls.add_extras(feature_layer=fl, mbox=[A] * len(fl[0]), num_classes=C)
+        if net == "stub":
+            backbone = _Stub([t(f) for f in cases.stub_features(name)])
+        else:
+            backbone = rnets[net](outputs=nets_outputs)
+            backbone.url = None  # no network: skip the ImageNet download of initialize()
+        model = cls(backbone=backbone, extras=extras, head=hd, num_classes=C)
+        sd = model.state_dict()
+        spec = [(k, tuple(v.shape)) for k, v in sd.items()]
+        model.load_state_dict({k: t(v) for k, v in cases.seeded_state(spec, seed).items()})
+        x = t(cases.net_image(name))
+        # BatchNorm calibration: train-mode passes with momentum None (cumulative average; the shared towers see
+        # every level) give running statistics that match the activations, like a trained model's
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.momentum = None
+        model.train()
+        with torch.no_grad():
+            model(x)
+            model(x)
+        model.eval()
+        with torch.no_grad():
+            loc, conf = model(x)
+        out = {"keys": np.array([k for k, _ in spec]),
+               "shapes": np.array([",".join(map(str, s)) for _, s in spec])}
+        for k, v in model.state_dict().items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                out["bn/" + k] = v.numpy().astype(F32)
+        for i, (l, c) in enumerate(zip(loc, conf)):
+            out["loc%d" % i], out["conf%d" % i] = l.numpy(), c.numpy()
+        act = [float(c.std()) for c in conf]
+        print("net", name, "levels", [tuple(l.shape[-2:]) for l in loc], "params", sum(v.numel() for v in sd.values()),
+              "conf std", ["%.3f" % a for a in act], "loc absmax", "%.2f" % max(float(l.abs().max()) for l in loc))
+        save("net_" + name, **out)
+
+
 if __name__ == "__main__":
     gen_anchors()
     gen_codec()
@@ -238,3 +322,4 @@ if __name__ == "__main__":
     gen_match_scale()
     gen_map()
     gen_losses()
+    gen_nets()

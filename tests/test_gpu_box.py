@@ -433,3 +433,100 @@ def test_decoder_tail_stream_matches_inline_decode():
     again = piped(*batches[0], anchors)
     for a, b in zip(again, want[0]):
         assert torch.equal(a, b)
+
+
+def test_extract_targets_by_iou_full_size_vs_oracle():
+    """BASELINE config 4 geometry (SSD-MobileNetV2@512 training: B=64, A=6, C=80, G=32 COCO-shaped targets of SURVEY
+    8d), IoU matching [0.5, 0.4] -- the branch every BASELINE config uses -- on every level: whole batch in one launch
+    vs the oracle on sampled images; all images obey the structural properties (one-hot rows <=> depth, ignore band
+    has no class bit, box targets finite)."""
+    import torch
+    from ssds.modeling.layers import box
+
+    rs = np.random.RandomState(78)
+    B, G, C, S = 64, 32, 80, 512
+    targets = np.full((B, G, 5), -1, np.float32)
+    for b in range(B):
+        n = rs.randint(1, G + 1) if b != 5 else 0  # one image without ground truth
+        wh = np.ceil(rs.uniform(0.02 * S, 0.4 * S, (n, 2)))
+        xy = np.floor(rs.uniform(0, 0.8 * S, (n, 2)))
+        wh = np.minimum(wh, S - xy)
+        targets[b, :n] = np.concatenate([xy, wh, rs.randint(0, C, (n, 1))], 1)
+    tdev = torch.from_numpy(targets).cuda()
+    for (m, stride) in zip([32, 16, 8, 4, 2, 1], [16, 32, 64, 128, 256, 512]):
+        anc = O.generate_anchors(stride, [1, 2, 0.5], [2.0, 2.828])
+        anchors = OrderedDict([(stride, torch.from_numpy(anc))])
+        ct, bt, dp = box.extract_targets(tdev, anchors, C, stride, (m, m), [0.5, 0.4], 0)
+        ctn, btn, dpn = ct.cpu().numpy(), bt.cpu().numpy(), dp.cpu().numpy()
+        assert ctn.shape == (B, 6, C, m, m) and btn.shape == (B, 6, 4, m, m) and dpn.shape == (B, 6, 1, m, m)
+        assert ((ctn == 0) | (ctn == 1)).all() and np.isfinite(btn).all()
+        np.testing.assert_array_equal(ctn.sum(2, keepdims=True), (dpn > 0).astype(np.float32))
+        lab = ctn.argmax(2)[:, :, None]
+        np.testing.assert_array_equal(np.where(dpn > 0, lab + 1, dpn), dpn)
+        assert set(np.unique(dpn[dpn <= 0])) <= {-1.0, 0.0}
+        assert (dpn[5] == 0).all() and (ctn[5] == 0).all()  # no ground truth: everything is background
+        if m >= 8:
+            assert (dpn > 0).any() and (dpn < 0).any(), "the case must exercise foreground and the ignore band"
+        for b in (0, 5, 31, 63):
+            oc, ob, od = O.extract_targets(targets[b:b + 1], OrderedDict([(stride, anc)]), C, stride, (m, m),
+                                           [0.5, 0.4], 0)
+            np.testing.assert_array_equal(dpn[b:b + 1], od)
+            np.testing.assert_array_equal(ctn[b:b + 1], oc)
+            np.testing.assert_allclose(btn[b:b + 1], ob, rtol=1e-5, atol=1e-5)
+
+
+FULL_SHAPES = {
+    # BASELINE config 3: FPN + ResNet50 @640, batch 32, A = 9 (6.138 M scores per image)
+    "fpn640": dict(B=32, A=9, C=80, size=640, maps=[80, 40, 20, 10, 5], strides=[8, 16, 32, 64, 128]),
+    # BASELINE config 5: BiFPN + RegNetX-800MF @896, 16 images per GPU, A = 9 (12.03 M scores per image)
+    "bifpn896": dict(B=16, A=9, C=80, size=896, maps=[112, 56, 28, 14, 7], strides=[8, 16, 32, 64, 128]),
+}
+
+
+@pytest.mark.parametrize("shape,dtype", [("fpn640", "bfloat16"), ("fpn640", "float16"), ("bifpn896", "float16"),
+                                         ("bifpn896", "bfloat16")])
+def test_full_size_fpn_bifpn_shapes_properties_and_sampled_oracle(shape, dtype):
+    """BASELINE config 3 / 5 head shapes (A = 9, five levels, up to 9 M scores per (image, level): many scan units per
+    level and multi-unit merges) in the dtypes the configs name: size-independent properties over the whole batch +
+    the oracle on sampled images, through the mid (per-level decode) outputs as well."""
+    import torch
+    from ssds.modeling.layers.box import decode_nms
+
+    cfg = FULL_SHAPES[shape]
+    tdt = getattr(torch, dtype)
+    B, A, C, S = cfg["B"], cfg["A"], cfg["C"], cfg["size"]
+    torch.manual_seed(4321)
+    conf = [torch.sigmoid(torch.randn(B, A * C, m, m, device="cuda") * 1.5 - 4.6).to(tdt) for m in cfg["maps"]]
+    loc = [(torch.randn(B, A * 4, m, m, device="cuda") * 0.5).to(tdt) for m in cfg["maps"]]
+    anchors = OrderedDict((s, torch.from_numpy(O.generate_anchors(s, [1, 2, 0.5], [2.0, 2.52, 3.175])))
+                          for s in cfg["strides"])
+    args = (0.01, 300, True, 0.6, 100, True)
+    (s, b, c), mid = decode_nms(loc, conf, anchors, *args, return_mid=True)
+    (s2, b2, c2), mid2 = decode_nms(loc, conf, anchors, *args, return_mid=True)
+    for x, y in zip((s, b, c) + tuple(mid), (s2, b2, c2) + tuple(mid2)):
+        assert torch.equal(x, y), "decode + NMS must be deterministic"
+    sn, bn, cn = s.cpu().numpy(), b.cpu().numpy(), c.cpu().numpy()
+    ms, mb, mc = (t.cpu().numpy() for t in mid)
+    L = len(cfg["maps"])
+    assert sn.shape == (B, 100) and ms.shape == (B, L * 300) and mb.shape == (B, L * 300, 4)
+    assert np.all(np.diff(sn, axis=1) <= 0) and np.all(sn[:, 0] > 0)
+    assert np.all((bn >= 0) & (bn <= S - 1)) and np.all((mb >= 0) & (mb <= S - 1))
+    assert np.all((cn >= 0) & (cn < C) & (cn == np.round(cn)))
+    # every final detection is one of the image's per-level candidates (score, box and class together)
+    for img in range(B):
+        cand = {(float(a), float(k)) + tuple(map(float, bx)) for a, k, bx in zip(ms[img], mc[img], mb[img])}
+        n = int((sn[img] > 0).sum())
+        assert all(((float(sn[img, i]), float(cn[img, i])) + tuple(map(float, bn[img, i]))) in cand for i in range(n))
+    oanch = OrderedDict((k, v.numpy()) for k, v in anchors.items())
+    odec = O.Decoder(0.01, 0.6, 100, 300, True, True)
+    for img in (0, B - 1):
+        ol = [l[img:img + 1].float().cpu().numpy() for l in loc]
+        oc = [x[img:img + 1].float().cpu().numpy() for x in conf]
+        wm = odec.decode_levels(ol, oc, oanch)
+        np.testing.assert_array_equal(mc[img:img + 1], wm[2])
+        np.testing.assert_allclose(mb[img:img + 1], wm[1], atol=BOX_ATOL, rtol=0)
+        np.testing.assert_allclose(ms[img:img + 1], wm[0], atol=1e-4, rtol=1e-4)
+        w = odec(ol, oc, oanch)
+        np.testing.assert_array_equal(cn[img:img + 1], w[2])
+        np.testing.assert_allclose(bn[img:img + 1], w[1], atol=BOX_ATOL, rtol=0)
+        np.testing.assert_allclose(sn[img:img + 1], w[0], atol=1e-4, rtol=1e-4)

@@ -216,3 +216,47 @@ def test_plan_arena_pins_buffers_read_by_side_lane_heads():
             assert a[0] in plan.pinned and c[0] != a[0]
         else:
             assert a[0] not in plan.pinned and c[0] == a[0]
+
+
+def test_loading_through_a_parent_drops_every_folded_weight_cache():
+    """a parent's load_state_dict() reaches children only through _load_from_state_dict, so the caches of
+    folded weights (plans, head packs, per-block packs) must be dropped there too -- otherwise the fallback path keeps
+    running the old weights after resume_checkpoint / an EMA swap."""
+    import torch
+    from ssds.modeling import ssds as S
+
+    class Wrapper(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.model = m
+
+    class Stub(torch.nn.Module):
+        def initialize(self):
+            pass
+
+        def forward(self, x):
+            return [x]
+
+    for cls, fl in ((S.SSD, [[0, "Conv:S"], [8, 16]]), (S.SSDFPN, [[0, "Conv:S"], [8, 8]]),
+                    (S.SSDBiFPN, [[0, 1, 2, "Conv:S"], [8, 8, 8, 8]])):
+        outs, extras, head = cls.add_extras(fl, [2] * len(fl[0]), 3)
+        model = cls(Stub(), extras, head, 3).eval()
+        marks = []
+        for m in model.modules():
+            if hasattr(m, "_packs"):  # FusedSequentialMixin
+                object.__setattr__(m, "_ssdk_packs", ("stale",))
+                marks.append(m)
+            if "_final_pack" in m.__dict__ or type(m).__name__ == "SharedHead":
+                m.__dict__["_final_pack"] = ("stale",)
+        assert marks, cls
+        model.__dict__["_plans"] = {"k": "stale"}
+        model.__dict__["_neck_plans"] = {"k": "stale"}
+        model.__dict__["_head_packs"] = ("stale",)
+        w = Wrapper(model)
+        w.load_state_dict(w.state_dict())
+        assert all(m.__dict__.get("_ssdk_packs") is None for m in marks)
+        assert all(m.__dict__.get("_final_pack") is None for m in model.modules())
+        if cls is S.SSD:
+            assert model.__dict__["_plans"] == {} and model.__dict__["_head_packs"] is None
+        else:
+            assert model.__dict__["_neck_plans"] == {}
