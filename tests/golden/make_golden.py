@@ -312,6 +312,85 @@ def gen_nets():
         save("net_" + name, **out)
 
 
+class _StubNet(torch.nn.Module):
+    """A small backbone with parameters (conv + BN, two output levels) and an unused classifier tail, like the
+    reference backbones have (mobilenet.py:91-99): what a reference checkpoint of a whole detector contains."""
+
+    def __init__(self, with_tail=True):
+        super().__init__()
+        self.conv1 = torch.nn.Conv2d(3, 16, 3, 2, 1, bias=False)
+        self.bn1 = torch.nn.BatchNorm2d(16)
+        self.layer1 = torch.nn.Sequential(torch.nn.Conv2d(16, 24, 3, 2, 1, bias=False), torch.nn.BatchNorm2d(24),
+                                          torch.nn.ReLU())
+        if with_tail:
+            self.classifier = torch.nn.Linear(24, 10)
+
+    def initialize(self):
+        pass
+
+    def forward(self, x):
+        a = torch.relu(self.bn1(self.conv1(x)))
+        return [a, self.layer1(a)]
+
+
+def gen_checkpoint():
+    """A checkpoint written by the reference's own ``save_checkpoints`` (core/checkpoint.py:18-35) from its own SSD
+    class, and the model's eval outputs on a seeded image.  Also checks the other direction here, where the reference
+    is importable: a checkpoint written by THIS repo's save_checkpoints is resumed by the reference's
+    ``resume_checkpoint`` (:59-133) into its model, bit for bit."""
+    import shutil
+
+    from ssds.core import checkpoint as rck
+    from ssds.modeling import ssds as rssds
+
+    fl = [[0, 1, "Conv:S"], [16, 24, 32]]
+    out_dir = os.path.join("tests", "golden", "ckpt_ref")  # relative: the index file stores the path it was given
+    os.chdir(os.path.dirname(os.path.dirname(HERE)))
+    shutil.rmtree(out_dir, ignore_errors=True)
+    torch.manual_seed(31)
+    _, extras, hd = rssds.SSD.add_extras(feature_layer=fl, mbox=[2, 2, 2], num_classes=3)
+    model = rssds.SSD(backbone=_StubNet(), extras=extras, head=hd, num_classes=3)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    for c in model.conf:
+        c.bias.data.normal_(-1.0, 0.5)
+        c.weight.data.normal_(0, 0.1)
+    rck.save_checkpoints(model, out_dir, "ssd_stubnet_ref", 7)
+    rck.save_checkpoints(model, out_dir, "ssd_stubnet_ref", 9)  # two lines in checkpoint_list.txt, same weights
+    assert rck.find_previous_checkpoint(out_dir)[0] == [7, 9]
+    x = torch.from_numpy(np.random.RandomState(32).random_sample((2, 3, 40, 56)).astype(F32))
+    model.eval()
+    with torch.no_grad():
+        loc, conf = model(x)
+    out = {"x": x.numpy(), "keys": np.array(list(model.state_dict()))}
+    for i, (l, c) in enumerate(zip(loc, conf)):
+        out["loc%d" % i], out["conf%d" % i] = l.numpy(), c.numpy()
+    save("checkpoint_ref", **out)
+
+    # the other direction: this repo writes, the reference resumes
+    import importlib.util
+    import tempfile
+
+    spec = importlib.util.spec_from_file_location(
+        "repo_checkpoint", os.path.join("ssds.pytorch_amd", "ssds", "core", "checkpoint.py"))
+    mine = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mine)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = mine.save_checkpoints(model, tmp, "ssd_stubnet_mine", 3)
+        assert rck.find_previous_checkpoint(tmp) == ([3], [path])
+        torch.manual_seed(99)
+        _, extras, hd = rssds.SSD.add_extras(feature_layer=fl, mbox=[2, 2, 2], num_classes=3)
+        other = rssds.SSD(backbone=_StubNet(), extras=extras, head=hd, num_classes=3)
+        assert rck.resume_checkpoint(other, path, "") is other
+        for (k, a), (_, b) in zip(model.state_dict().items(), other.state_dict().items()):
+            assert torch.equal(a, b), k
+    print("checkpoint: reference <-> repo round trips ok")
+
+
 if __name__ == "__main__":
     gen_anchors()
     gen_codec()
@@ -323,3 +402,4 @@ if __name__ == "__main__":
     gen_map()
     gen_losses()
     gen_nets()
+    gen_checkpoint()

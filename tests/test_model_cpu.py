@@ -260,3 +260,57 @@ def test_loading_through_a_parent_drops_every_folded_weight_cache():
             assert model.__dict__["_plans"] == {} and model.__dict__["_head_packs"] is None
         else:
             assert model.__dict__["_neck_plans"] == {}
+
+
+def test_checkpoint_written_by_the_reference_loads_here():
+    """SURVEY f-4: tests/golden/ckpt_ref/ was written by the REFERENCE's own ``save_checkpoints``
+    (core/checkpoint.py:18-35) from its own SSD class (make_golden.gen_checkpoint; the other direction -- a checkpoint
+    written here resumed by the reference's ``resume_checkpoint`` -- is asserted there, where the reference is
+    importable).  ``find_previous_checkpoint`` parses its index, ``resume_checkpoint`` loads it into this repo's SSD
+    (skipping the backbone's unused classifier tail) and the eval forward reproduces the reference model's outputs."""
+    import numpy as np
+    import torch
+    from ssds.core import checkpoint
+    from ssds.modeling import ssds as S
+
+    class StubNet(torch.nn.Module):  # the backbone of the fixture, without the unused tail
+        def __init__(self):
+            super().__init__()
+            self.conv1 = torch.nn.Conv2d(3, 16, 3, 2, 1, bias=False)
+            self.bn1 = torch.nn.BatchNorm2d(16)
+            self.layer1 = torch.nn.Sequential(torch.nn.Conv2d(16, 24, 3, 2, 1, bias=False), torch.nn.BatchNorm2d(24),
+                                              torch.nn.ReLU())
+
+        def initialize(self):
+            pass
+
+        def forward(self, x):
+            a = torch.relu(self.bn1(self.conv1(x)))
+            return [a, self.layer1(a)]
+
+    gdir = os.path.join(ROOT, "tests", "golden")
+    epochs, paths = checkpoint.find_previous_checkpoint(os.path.join(gdir, "ckpt_ref"))
+    assert epochs == [7, 9] and paths[1] == "tests/golden/ckpt_ref/ssd_stubnet_ref_epoch_9.pth"
+    fx = np.load(os.path.join(gdir, "checkpoint_ref.npz"))
+    torch.manual_seed(5)
+    _, extras, head = S.SSD.add_extras([[0, 1, "Conv:S"], [16, 24, 32]], [2, 2, 2], 3)
+    model = S.SSD(StubNet(), extras, head, 3)
+    ref_keys = [str(k) for k in fx["keys"]]
+    mine = list(model.state_dict())
+    assert [k for k in ref_keys if not k.startswith("backbone.classifier.")] == mine
+    assert checkpoint.resume_checkpoint(model, os.path.join(ROOT, paths[1]), "") is model
+    model.eval()
+    with torch.no_grad():
+        loc, conf = model(torch.from_numpy(fx["x"]))
+    for i, (l, c) in enumerate(zip(loc, conf)):
+        torch.testing.assert_close(l, torch.from_numpy(fx["loc%d" % i]), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(c, torch.from_numpy(fx["conf%d" % i]), rtol=1e-5, atol=1e-6)
+    # scope-filtered resume (cfg.TRAIN.RESUME_SCOPE, checkpoint.py:111-119): only the heads
+    torch.manual_seed(6)
+    _, extras, head = S.SSD.add_extras([[0, 1, "Conv:S"], [16, 24, 32]], [2, 2, 2], 3)
+    part = S.SSD(StubNet(), extras, head, 3)
+    before = {k: v.clone() for k, v in part.state_dict().items()}
+    checkpoint.resume_checkpoint(part, os.path.join(ROOT, paths[0]), "loc,conf")
+    for k, v in part.state_dict().items():
+        same_as_ckpt = torch.equal(v, model.state_dict()[k])
+        assert same_as_ckpt if k.startswith(("loc.", "conf.")) else torch.equal(v, before[k]), k
