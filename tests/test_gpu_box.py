@@ -438,8 +438,9 @@ def test_decoder_tail_stream_matches_inline_decode():
 def test_extract_targets_by_iou_full_size_vs_oracle():
     """BASELINE config 4 geometry (SSD-MobileNetV2@512 training: B=64, A=6, C=80, G=32 COCO-shaped targets of SURVEY
     8d), IoU matching [0.5, 0.4] -- the branch every BASELINE config uses -- on every level: whole batch in one launch
-    vs the oracle on sampled images; all images obey the structural properties (one-hot rows <=> depth, ignore band
-    has no class bit, box targets finite)."""
+    vs the oracle on sampled images; all images obey the structural properties (exactly one class bit wherever the
+    best overlap reaches the unmatch threshold -- the ignore band keeps its class bit, box.py:201-203 only clears the
+    background -- the bit of a foreground anchor is its depth - 1, box targets finite)."""
     import torch
     from ssds.modeling.layers import box
 
@@ -460,7 +461,7 @@ def test_extract_targets_by_iou_full_size_vs_oracle():
         ctn, btn, dpn = ct.cpu().numpy(), bt.cpu().numpy(), dp.cpu().numpy()
         assert ctn.shape == (B, 6, C, m, m) and btn.shape == (B, 6, 4, m, m) and dpn.shape == (B, 6, 1, m, m)
         assert ((ctn == 0) | (ctn == 1)).all() and np.isfinite(btn).all()
-        np.testing.assert_array_equal(ctn.sum(2, keepdims=True), (dpn > 0).astype(np.float32))
+        np.testing.assert_array_equal(ctn.sum(2, keepdims=True), (dpn != 0).astype(np.float32))
         lab = ctn.argmax(2)[:, :, None]
         np.testing.assert_array_equal(np.where(dpn > 0, lab + 1, dpn), dpn)
         assert set(np.unique(dpn[dpn <= 0])) <= {-1.0, 0.0}
