@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 100 /* 0.1.0 */
+#define SSDK_VERSION 200 /* 0.2.0: contexts, fused decode tail */
 
 #define SSDK_MAX_LEVELS 8    /* feature-map levels per decode_nms call            */
 #define SSDK_MAX_ANCHORS 16  /* anchors per location (A)                          */
@@ -98,9 +98,23 @@ int ssdk_nms(const float* scores, const float* boxes, const float* classes, int 
              float* out_boxes, float* out_classes, void* workspace, size_t workspace_bytes,
              void* stream);
 
-/* decoder.py:25-49 Decoder.__call__: decode every level -> concat -> nms, as <=3 launches.
- * mid_* (optional, may be NULL): the concatenated per-level decode output [B, L*top_n(,4)] that the
- * reference materialises with torch.cat (decoder.py:48); when NULL it lives in the workspace. */
+/* Contexts.  The two entry points that are more than one launch (ssdk_decode_nms: scan + tail; ssdk_run_ops: a whole
+ * recorded network with an optional side lane) need a few HIP objects -- a side stream, fork/join events, optional
+ * profiling events.  They live in a caller-owned context, never in library globals: a context belongs to the device
+ * that was current at ssdk_ctx_create() and is used by one host thread at a time; two threads, or two devices, use two
+ * contexts and share nothing (the library is re-entrant; its only other state is the per-thread error text).  The
+ * entry points WITHOUT a context argument use a context that belongs to the calling thread and the current device. */
+typedef struct ssdk_ctx ssdk_ctx;
+ssdk_ctx* ssdk_ctx_create(void);       /* NULL + ssdk_last_error() when there is no HIP device */
+void ssdk_ctx_destroy(ssdk_ctx* ctx);  /* the caller has synchronised the streams that used it */
+
+/* decoder.py:25-49 Decoder.__call__: decode every level -> concat -> nms, nothing returns to the host in between.
+ * Two launches: scan_kernel (one HBM pass over the conf tensors: threshold + exact top-k per scan unit, sorted) and
+ * tail_kernel (per image: merge of the units by rank, delta2box + centre rescoring of the winners, sort by rescored
+ * score, greedy class-aware (D)IoU NMS).  Geometries whose per-image candidate lists do not fit one CU's LDS run
+ * level_kernel + nms_kernel behind the scan instead (three launches, same results; SSDK_DECODE_FUSED=0 forces it).
+ * mid_* (optional, may be NULL): the concatenated per-level decode output [B, L*top_n(,4)] that the reference
+ * materialises with torch.cat (decoder.py:48); with the fused tail it only exists when asked for. */
 size_t ssdk_decode_nms_workspace_bytes(const ssdk_level* levels, int L, int B, int dtype,
                                        int top_n_per_level, int ndetections);
 int ssdk_decode_nms(const ssdk_level* levels, int L, int B, int dtype, float threshold,
@@ -108,14 +122,20 @@ int ssdk_decode_nms(const ssdk_level* levels, int L, int B, int dtype, float thr
                     int using_diou, float* out_scores, float* out_boxes, float* out_classes,
                     float* mid_scores, float* mid_boxes, float* mid_classes, void* workspace,
                     size_t workspace_bytes, void* stream);
+int ssdk_decode_nms_ctx(ssdk_ctx* ctx, const ssdk_level* levels, int L, int B, int dtype, float threshold,
+                        int top_n_per_level, int rescore, float nms_threshold, int ndetections,
+                        int using_diou, float* out_scores, float* out_boxes, float* out_classes,
+                        float* mid_scores, float* mid_boxes, float* mid_classes, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
-/* (new) Tail stream of ssdk_decode_nms for the calling thread (NULL = off, the default): when set, scan_kernel still
- * runs on the `stream` argument but level_kernel and nms_kernel are enqueued on the tail stream, ordered after the
- * scan by an event -- the latency-bound end of the stage then overlaps the next batch's forward pass.  The caller
- * owns the consequences: the outputs are complete on the TAIL stream, the workspace and the box tensors must stay
- * untouched until the tail work has finished (alternate two workspaces and make the main stream wait for the tail
- * event of the call that last used one; host mirror: ssds/modeling/layers/decoder.py). */
-int ssdk_set_decode_tail_stream(void* stream);
+/* (new) Tail stream of ssdk_decode_nms[_ctx] (NULL = off, the default): when set, scan_kernel still runs on the
+ * `stream` argument but everything behind it is enqueued on the tail stream, ordered after the scan by an event -- the
+ * latency-bound end of the stage then overlaps the next batch's forward pass.  The caller owns the consequences: the
+ * outputs are complete on the TAIL stream, the workspace and the box tensors must stay untouched until the tail work
+ * has finished (alternate two workspaces and make the main stream wait for the tail event of the call that last used
+ * one; host mirror: ssds/modeling/layers/decoder.py). */
+int ssdk_ctx_set_tail_stream(ssdk_ctx* ctx, void* stream);
+int ssdk_set_decode_tail_stream(void* stream); /* the calling thread's default context */
 
 /* (new, debug) SSDK_LDS_POISON=1 in the environment fills every CU's LDS with NaN patterns in front of each kernel of
  * ssdk_run_ops / ssdk_conv / ssdk_mbconv / ssdk_decode_nms, so that a kernel reading LDS it did not write shows up
@@ -124,18 +144,29 @@ int ssdk_set_decode_tail_stream(void* stream);
  * can see. */
 int ssdk_debug_lds_probe(unsigned* count, void* stream);
 
-/* Optional per-kernel timing for roofline accounting (bench.py): when enabled, ssdk_decode_nms records
- * hipEvents on the caller's stream around its three launches into a ring of 256 slots (no
- * synchronisation inside the timed region).  ssdk_get_timings(back, ms, 3) returns ms[0..2] = scan_kernel,
- * level_kernel, nms_kernel of the call `back` calls before the most recent one; it synchronises on that
- * call's last event. */
+/* Optional per-kernel timing for roofline accounting (bench.py): when enabled, ssdk_decode_nms[_ctx] records
+ * hipEvents around its launches into the context's ring of 256 slots (no synchronisation inside the timed region).
+ * ssdk_[ctx_]get_timings(back, ms, 3): ms[0] = scan_kernel, ms[1] = tail_kernel (or level_kernel on the 3-launch
+ * path), ms[2] = nms_kernel (0 on the fused path) of the call `back` calls before the most recent one; it
+ * synchronises on that call's last event. */
+int ssdk_ctx_set_profiling(ssdk_ctx* ctx, int enable);
+int ssdk_ctx_get_timings(ssdk_ctx* ctx, int back, float* ms, int n);
 int ssdk_set_profiling(int enable);
-/* Per-op timing of ssdk_run_ops: when enabled, an event is recorded before every op (and after the last) on the
- * caller's stream.  After synchronising, ssdk_get_op_timings fills ms[i] / kernels[i] (kernel name, may be NULL)
- * for the ops of the most recent profiled ssdk_run_ops call and returns their count. */
+int ssdk_get_timings(int back, float* ms, int n);
+/* (debug) SSDK_TAIL_STAMPS=1: shader-clock stamps of workgroup 0 at the phase boundaries of the most recent
+ * tail_kernel (out[0..5]: start, lists staged, winners decoded, sorted, walked, end) and scan_kernel (out[8..12]: start,
+ * cut found, streamed, selected, end; out[13] = fast-path flag << 32 | winners); n >= 48; synchronises the device. */
+int ssdk_ctx_get_tail_stamps(ssdk_ctx* ctx, unsigned long long* out, int n);
+/* Per-op timing of ssdk_run_ops[_ctx]: when enabled, an event is recorded before every op (and after the last) on the
+ * caller's stream.  After synchronising, ssdk_[ctx_]get_op_timings fills ms[i] / kernels[i] (kernel name, may be
+ * NULL) for the ops of the most recent profiled call and returns their count. */
+int ssdk_ctx_set_op_profiling(ssdk_ctx* ctx, int enable);
+int ssdk_ctx_get_op_timings(ssdk_ctx* ctx, float* ms, const char** kernels, int n_max);
 int ssdk_set_op_profiling(int enable);
 int ssdk_get_op_timings(float* ms, const char** kernels, int n_max);
-int ssdk_get_timings(int back, float* ms, int n);
+/* Side lane of ssdk_run_ops_ctx: 1 on, 0 off (everything in line on the caller's stream), -1 = the environment's
+ * choice (SSDK_SIDE_STREAM, default on). */
+int ssdk_ctx_set_side_lane(ssdk_ctx* ctx, int enable);
 
 /* box.py:362-405 extract_targets + box.py:116-226 snap_to_anchors_by_iou for ONE level and the whole
  * batch in one launch.  targets[B*G*5] device fp32 (x, y, w, h, label), rows with label <= -1 are
@@ -338,7 +369,7 @@ int ssdk_maxpool3x3s2(const ssdk_pool_desc* desc, void* stream);
 
 /* Plan executor: a recorded forward as a list of tagged ops (topological order), replayed with one host call.
  * lane 0 ops run in order on the caller's stream.  lane 1 ops (the multibox heads: leaves that depend only on
- * ops listed before them) are forked onto a library-owned side stream and run concurrently with the following
+ * ops listed before them) are forked onto the context's side stream and run concurrently with the following
  * lane 0 ops; they use the upper half of the workspace, and everything is joined back onto the caller's stream
  * before the call returns.  Buffers read or written by lane 1 ops must not be reused by later ops of the list. */
 enum { SSDK_OP_CONV = 0, SSDK_OP_MBCONV = 1, SSDK_OP_FUSE = 2, SSDK_OP_STEM7 = 3, SSDK_OP_POOL = 4 };
@@ -351,6 +382,7 @@ typedef struct ssdk_op {
   ssdk_pool_desc pool;
 } ssdk_op;
 int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t workspace_bytes, void* stream);
+int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* workspace, size_t workspace_bytes, void* stream);
 /* convenience wrapper: dense conv, NHWC in/out, single output */
 int ssdk_conv_bn_act(const void* x, const void* w, const float* scale, const float* bias, int N,
                      int Cin, int H, int W, int Cout, int k, int stride, int act, int dtype,

@@ -25,6 +25,7 @@
 //   scale, bias  fp32 [Cout]  (scale may be NULL = 1)
 //   y      NHWC [N][Ho][Wo][Cout] or NCHW [N][Cout][Ho][Wo]        same dtype
 #include "ssdk_conv_common.h"
+#include "ssdk_ctx.h"
 
 namespace ssdk {
 
@@ -1193,76 +1194,94 @@ extern "C" int ssdk_conv_sequence(const ssdk_conv_desc* descs, int n, void* work
 
 // Per-op timing of ssdk_run_ops (tools / bench.py layer table): one hipEvent before every op and one after the
 // last, on the caller's stream; read back with ssdk_get_op_timings after the stream has been synchronised.
-constexpr int kMaxProfOps = 128;
-static int g_op_prof = 0, g_op_n = 0;
-static hipEvent_t g_op_ev[kMaxProfOps + 1];
-static bool g_op_ev_ready = false;
-static const char* g_op_kernel[kMaxProfOps];
-
-extern "C" int ssdk_set_op_profiling(int enable) {
-  if (enable && !g_op_ev_ready) {
-    for (int i = 0; i <= kMaxProfOps; ++i)
-      if (hipEventCreate(&g_op_ev[i]) != hipSuccess) {
+// Events, like the side lane below, belong to the caller's context (ssdk_ctx.h).
+extern "C" int ssdk_ctx_set_op_profiling(ssdk_ctx* ctx, int enable) {
+  if (int rc = ssdk::ctx_enter(ctx)) return rc;
+  if (enable && !ctx->op_ev_ready) {
+    for (int i = 0; i <= kSsdkMaxProfOps; ++i)
+      if (hipEventCreate(&ctx->op_ev[i]) != hipSuccess) {
         set_error("set_op_profiling: hipEventCreate failed");
         return SSDK_E_LAUNCH;
       }
-    g_op_ev_ready = true;
+    ctx->op_ev_ready = true;
   }
-  g_op_prof = enable ? 1 : 0;
-  g_op_n = 0;
+  ctx->op_prof = enable ? 1 : 0;
+  ctx->op_n = 0;
   return SSDK_OK;
 }
+extern "C" int ssdk_set_op_profiling(int enable) { return ssdk_ctx_set_op_profiling(ssdk::default_ctx(), enable); }
 
-extern "C" int ssdk_get_op_timings(float* ms, const char** kernels, int n_max) {
-  if (!ms || n_max < g_op_n) {
-    set_error("get_op_timings: need room for %d ops", g_op_n);
+extern "C" int ssdk_ctx_get_op_timings(ssdk_ctx* ctx, float* ms, const char** kernels, int n_max) {
+  if (int rc = ssdk::ctx_enter(ctx)) return rc;
+  if (!ms || n_max < ctx->op_n) {
+    set_error("get_op_timings: need room for %d ops", ctx->op_n);
     return SSDK_E_BADARG;
   }
-  for (int i = 0; i < g_op_n; ++i) {
-    if (hipEventElapsedTime(&ms[i], g_op_ev[i], g_op_ev[i + 1]) != hipSuccess) {
+  for (int i = 0; i < ctx->op_n; ++i) {
+    if (hipEventElapsedTime(&ms[i], ctx->op_ev[i], ctx->op_ev[i + 1]) != hipSuccess) {
       set_error("get_op_timings: events of op %d not complete (synchronise the stream first)", i);
       return SSDK_E_LAUNCH;
     }
-    if (kernels) kernels[i] = g_op_kernel[i];
+    if (kernels) kernels[i] = ctx->op_kernel[i];
   }
-  return g_op_n;
+  return ctx->op_n;
+}
+extern "C" int ssdk_get_op_timings(float* ms, const char** kernels, int n_max) {
+  return ssdk_ctx_get_op_timings(ssdk::default_ctx(), ms, kernels, n_max);
 }
 
-// Fork/join onto a library-owned side stream: ops whose `lane` is 1 (the multibox heads: they only depend on
+// Fork/join onto a side stream owned by the CONTEXT: ops whose `lane` is 1 (the multibox heads: they only depend on
 // their feature map, not on each other or on the layers that follow) run concurrently with the main chain.
 // The tiny tail layers (extras at 8x8..1x1, heads of the last levels) are launch/latency bound; overlapped with
 // the big head GEMMs they disappear from the critical path.  Everything is joined back onto the caller's stream
 // before returning, so the caller sees ordinary stream semantics (and the whole call is graph-capturable).
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_fork[32], g_join;
-static bool g_side_ready = false;
-
-static bool side_init() {
+// A failed event / wait is an error (SSDK_E_LAUNCH): dropping one silently would drop an ordering edge.
+static bool side_wanted(const ssdk_ctx* ctx) {
   // measured on SSD-MobileNetV2@512: +2.7 % with the small heads (levels 2..5) on the side lane; SSDK_SIDE_STREAM=0 = in line
-  static const int env = getenv("SSDK_SIDE_STREAM") ? atoi(getenv("SSDK_SIDE_STREAM")) : 1;
-  if (!env) return false;
-  if (!g_side_ready) {
-    if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) return false;
-    for (int i = 0; i < 32; ++i)
-      if (hipEventCreateWithFlags(&g_fork[i], hipEventDisableTiming) != hipSuccess) return false;
-    if (hipEventCreateWithFlags(&g_join, hipEventDisableTiming) != hipSuccess) return false;
-    g_side_ready = true;
-  }
-  return true;
+  if (ctx->side_lane >= 0) return ctx->side_lane != 0;
+  const char* e = getenv("SSDK_SIDE_STREAM");
+  return !(e && *e) || atoi(e) != 0;
 }
 
-extern "C" int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t workspace_bytes, void* stream) {
+static int side_init(ssdk_ctx* ctx) {
+  if (ctx->side_ready) return SSDK_OK;
+  if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess) goto fail;
+  for (int i = 0; i < 32; ++i)
+    if (hipEventCreateWithFlags(&ctx->fork[i], hipEventDisableTiming) != hipSuccess) goto fail;
+  if (hipEventCreateWithFlags(&ctx->join, hipEventDisableTiming) != hipSuccess) goto fail;
+  ctx->side_ready = true;
+  return SSDK_OK;
+fail:
+  (void)hipGetLastError();
+  set_error("run_ops: cannot create the side stream / its events");
+  return SSDK_E_LAUNCH;
+}
+
+static int edge(hipStream_t from, hipEvent_t e, hipStream_t to) {  // work recorded on `from` so far precedes `to`
+  if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("run_ops: stream fork/join failed");
+    return SSDK_E_LAUNCH;
+  }
+  return SSDK_OK;
+}
+
+extern "C" int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  if (int rc = ssdk::ctx_enter(ctx)) return rc;
   if (!ops || n < 0) {
     set_error("run_ops: bad arguments");
     return SSDK_E_BADARG;
   }
   hipStream_t main_s = (hipStream_t)stream;
-  const bool prof = g_op_prof && g_op_ev_ready && n <= kMaxProfOps;
-  if (prof) g_op_n = 0;
+  const bool prof = ctx->op_prof && ctx->op_ev_ready && n <= kSsdkMaxProfOps;
+  if (prof) ctx->op_n = 0;
   int n_side = 0;
   for (int i = 0; i < n; ++i) n_side += ops[i].lane == 1 ? 1 : 0;
   // concurrent lanes need disjoint split-K scratch: the side lane gets the upper half of the workspace
-  const bool use_side = n_side > 0 && n_side <= 32 && !prof && side_init();
+  bool use_side = n_side > 0 && n_side <= 32 && !prof && side_wanted(ctx);
+  if (use_side)
+    if (int rc = side_init(ctx)) return rc;
   char* ws_main = (char*)workspace;
   size_t ws_main_bytes = workspace_bytes;
   char* ws_side = nullptr;
@@ -1275,55 +1294,61 @@ extern "C" int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t w
   }
   int forks = 0;
   for (int i = 0; i < n; ++i) {
-    if (prof) (void)hipEventRecord(g_op_ev[i], main_s);
+    if (prof && hipEventRecord(ctx->op_ev[i], main_s) != hipSuccess) {
+      set_error("run_ops: hipEventRecord failed");
+      return SSDK_E_LAUNCH;
+    }
     const bool side = use_side && ops[i].lane == 1;
     hipStream_t st = main_s;
     void* w = ws_main;
     size_t wb = ws_main_bytes;
+    int rc = SSDK_OK;
     if (side) {
-      (void)hipEventRecord(g_fork[forks], main_s);  // everything recorded so far (the op's producers) ...
-      (void)hipStreamWaitEvent(g_side, g_fork[forks], 0);  // ... happens before the side op
+      rc = edge(main_s, ctx->fork[forks], ctx->side);  // everything recorded so far (the op's producers) precedes it
       ++forks;
-      st = g_side;
+      st = ctx->side;
       w = ws_side;
       wb = ws_side_bytes;
     }
-    int rc;
-    ssdk::lds_poison(st);
-    if (ops[i].kind == SSDK_OP_CONV) {
-      g_underfill_ok = side;
-      rc = ssdk_conv(&ops[i].conv, w, wb, st);
-      g_underfill_ok = false;
-    }
-    else if (ops[i].kind == SSDK_OP_MBCONV) rc = ssdk_mbconv(&ops[i].mb, st);
-    else if (ops[i].kind == SSDK_OP_FUSE) rc = ssdk_fuse(&ops[i].fuse, st);
-    else if (ops[i].kind == SSDK_OP_STEM7) rc = ssdk_conv_stem7(&ops[i].stem, st);
-    else if (ops[i].kind == SSDK_OP_POOL) rc = ssdk_maxpool3x3s2(&ops[i].pool, st);
-    else {
-      set_error("unknown op kind %d", ops[i].kind);
-      rc = SSDK_E_BADARG;
+    if (!rc) {
+      ssdk::lds_poison(st);
+      if (ops[i].kind == SSDK_OP_CONV) {
+        g_underfill_ok = side;
+        rc = ssdk_conv(&ops[i].conv, w, wb, st);
+        g_underfill_ok = false;
+      }
+      else if (ops[i].kind == SSDK_OP_MBCONV) rc = ssdk_mbconv(&ops[i].mb, st);
+      else if (ops[i].kind == SSDK_OP_FUSE) rc = ssdk_fuse(&ops[i].fuse, st);
+      else if (ops[i].kind == SSDK_OP_STEM7) rc = ssdk_conv_stem7(&ops[i].stem, st);
+      else if (ops[i].kind == SSDK_OP_POOL) rc = ssdk_maxpool3x3s2(&ops[i].pool, st);
+      else {
+        set_error("unknown op kind %d", ops[i].kind);
+        rc = SSDK_E_BADARG;
+      }
     }
     if (rc) {
       char msg[400];
       snprintf(msg, sizeof(msg), "%s", ssdk_last_error());
       set_error("run_ops: op %d of %d: %s", i, n, msg);
-      if (forks) {  // never leave the side stream dangling
-        (void)hipEventRecord(g_join, g_side);
-        (void)hipStreamWaitEvent(main_s, g_join, 0);
-      }
+      if (forks) (void)edge(ctx->side, ctx->join, main_s);  // never leave the side stream dangling
       return rc;
     }
-    if (prof) g_op_kernel[i] = ssdk_last_kernel();
+    if (prof) ctx->op_kernel[i] = ssdk_last_kernel();
   }
-  if (forks) {
-    (void)hipEventRecord(g_join, g_side);
-    (void)hipStreamWaitEvent(main_s, g_join, 0);
-  }
+  if (forks)
+    if (int rc = edge(ctx->side, ctx->join, main_s)) return rc;
   if (prof) {
-    (void)hipEventRecord(g_op_ev[n], main_s);
-    g_op_n = n;
+    if (hipEventRecord(ctx->op_ev[n], main_s) != hipSuccess) {
+      set_error("run_ops: hipEventRecord failed");
+      return SSDK_E_LAUNCH;
+    }
+    ctx->op_n = n;
   }
   return SSDK_OK;
+}
+
+extern "C" int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t workspace_bytes, void* stream) {
+  return ssdk_run_ops_ctx(ssdk::default_ctx(), ops, n, workspace, workspace_bytes, stream);
 }
 
 extern "C" int ssdk_conv_bn_act(const void* x, const void* w, const float* scale, const float* bias, int N,

@@ -1,0 +1,29 @@
+// ssdk_decode.h -- host-side glue between the translation units of the decode stage:
+//   ssdk_decode.hip  scan_kernel, level_kernel        ssdk_tail.hip  tail_kernel (fused level merge + decode + NMS)
+//   ssdk_nms.hip     nms_kernel                       ssdk_ctx.cpp   ssdk_decode_nms[_ctx], contexts, profiling
+#pragma once
+#include "ssdk_common.h"
+
+namespace ssdk {
+
+struct DecodePlan {  // how the scan is cut into units
+  u32 tiles_per_unit, units_per_image;  // tiles_per_unit: the target size; tpu[l] what level l actually uses
+  u32 units[SSDK_MAX_LEVELS], unit_base[SSDK_MAX_LEVELS], n[SSDK_MAX_LEVELS], tpu[SSDK_MAX_LEVELS];
+  size_t cand_bytes, cnt_bytes;
+  bool fused;  // the geometry fits the fused tail kernel (only asked for when ndet > 0)
+};
+
+int make_plan(const ssdk_level* lv, int L, int B, int dtype, int K, DecodePlan* pl, int ndet);
+int launch_scan(const ssdk_level* lv, int L, int B, int dtype, float thr, int K, const DecodePlan& pl, void* ws,
+                size_t ws_bytes, hipStream_t stream, unsigned long long* stamps);
+int launch_level(const ssdk_level* lv, int L, int B, int dtype, int K, int rescore, const DecodePlan& pl, const void* ws,
+                 float* scores, float* boxes, float* classes, hipStream_t stream);
+size_t tail_fits(u32 units_per_image, int K, int L, int ndet);
+int launch_tail(const ssdk_level* lv, int L, int B, int dtype, int K, int rescore, const u32* units, const u32* unit_base,
+                u32 units_per_image, const void* cand, const void* cand_cnt, float nms_thr, int ndet, int diou,
+                float* os, float* ob, float* oc, float* ms, float* mb, float* mc, unsigned long long* stamps,
+                hipStream_t stream);
+int launch_nms(const float* scores, const float* boxes, const float* classes, int B, int N, float thr, int ndet,
+               int diou, float* os, float* ob, float* oc, hipStream_t stream);
+
+}  // namespace ssdk

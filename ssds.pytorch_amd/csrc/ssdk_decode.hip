@@ -4,7 +4,7 @@
 // ~25 ATen launches per (image, level) with nonzero() host syncs.  Here:
 //
 //   scan_kernel<DT>     ONE pass over the conf tensor (the HBM-bound part: 2 B/score in bf16).  Each
-//                       workgroup streams a "unit" (tiles_per_unit x 256 x 16 B) of one (image, level)
+//                       workgroup streams a "unit" (tpu x 256 x 16 B) of one (image, level)
 //                       with 16-byte coalesced loads, 4 loads in flight per lane, and keeps the exact
 //                       top-K of what it has seen in LDS (TopK stream, ssdk_select.h).  It emits <=K
 //                       64-bit keys (score bits | ~flat index) per unit.
@@ -16,6 +16,7 @@
 // Algorithmic HBM bytes: the conf tensor once + 4 deltas per winner + outputs.
 #include "ssdk_common.h"
 #include "ssdk_select.h"
+#include "ssdk_decode.h"
 
 namespace ssdk {
 
@@ -28,17 +29,19 @@ struct ScanLevel {
   u32 n;          // A*C*H*W scores per image
   u32 units;      // units per image for this level
   u32 unit_base;  // first unit id of this level inside an image
-  u32 pad;
+  u32 tpu;        // tiles per unit of this level
 };
 struct ScanParams {
   ScanLevel lv[SSDK_MAX_LEVELS];
   int L;
-  u32 units_per_image;
-  u32 tiles_per_unit;
+  u32 units_per_image, B;
   u32 K;
   float thr;
+  u32 hist_base, hist_sh;  // histogram window of the seeding phase: bin = (ord(score) - hist_base) >> hist_sh
+  int fast;                // 1: seeded barrier-free streaming first (SSDK_SCAN_FAST, default), 0: TopK stream only
   u64* cand;      // [B][units_per_image][K]
   u32* cand_cnt;  // [B][units_per_image]
+  unsigned long long* stamps;  // optional (debug): shader-clock stamps of workgroup 0 at the phase boundaries
 };
 
 struct LevelDesc {
@@ -118,6 +121,130 @@ __device__ __forceinline__ void scan_vec(const u32x4& v, u32 idx0, u32 n, float 
     if ((pmask >> e) & 1u) buf[base + (u32)__popc(pmask & ((1u << e) - 1u))] = make_key(sv[e], idx0 + (u32)e);
 }
 
+// ---- seeded, barrier-free streaming (the normal case) --------------------------------------------------------------
+// The per-tile barrier + prune protocol below (TopK stream) is exact for any input but spends most of a unit's time in
+// radix selects while the running cut is still low: with half of all scores above the threshold (SURVEY 8d's
+// untrained-head distribution) a unit prunes 4-5 times.  So a unit first looks at a SAMPLE of its own tiles (8 tiles
+// spread over the unit) through a 1024-bin LDS histogram of the score's leading bits, window [thr, 1.0]: the lower edge
+// of the bin in which the sample's count from the top reaches K is a valid lower bound of the unit's K-th largest
+// score (the sample alone already holds K scores at or above it).  With that cut each WAVE then streams its share of
+// the unit on its own -- no barrier, no LDS atomic: a wave-uniform counter and a private 1024-key buffer -- and keeps
+// every score >= cut: K * tiles / 8 keys per unit in expectation, which fit.  One exact select + sort at the end.
+// Whenever that does not work out (a wave's buffer overflows: heavy ties at the cut such as an all-equal image, an
+// unrepresentative sample) the unit falls back to the TopK stream, seeded with the same cut.  Both paths are exact.
+struct FastCtl {  // LDS
+  u32 wcount[kScanThreads / 64];
+  u32 overflow, cutbin, cum, total;
+  u32 cutord, nge, pad0, pad1;
+};
+
+// LDS image of scan_kernel: [buf: kCap keys][SelScratch][StreamCtl][FastCtl][ring: waves x PF x 1 KiB].  The K-key
+// staging area `sel` of the selects is only used once the ring has drained and lives on top of it.  53.5 KB with
+// PF = 4: three workgroups (12 waves) per CU.
+__host__ __device__ inline size_t scan_fixed_bytes() {
+  return ((size_t)kCap * 8 + sizeof(SelScratch) + sizeof(StreamCtl) + sizeof(FastCtl) + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t scan_lds_bytes(u32 K, int pf) {
+  const size_t ring = (size_t)(kScanThreads / 64) * pf * 1024, sel = (size_t)((K + 1) & ~1u) * 8;
+  return scan_fixed_bytes() + (ring > sel ? ring : sel);
+}
+
+constexpr u32 kWaveCap = kCap / (kScanThreads / 64);  // keys per wave buffer (1024)
+constexpr u32 kSample = 8;                             // sample tiles of the histogram phase
+constexpr u32 kHistBins = 1024;
+
+// one LDS add per (wave, distinct bin of the leading lane): heavy ties (an all-equal image puts every score of the
+// wave into ONE bin) would otherwise serialise 64 same-address atomics per instruction
+__device__ __forceinline__ void hist_add(u32* hist, bool pass, u32 bin) {
+  const u64 m = __ballot(pass);
+  if (m == 0ull) return;
+  const u32 lead = (u32)__ffsll((long long)m) - 1u;
+  const u32 b0 = (u32)__builtin_amdgcn_readlane((int)bin, (int)lead);
+  const u64 same = __ballot(pass && bin == b0);
+  if (lane_id() == lead) atomicAdd(&hist[b0], (u32)__popcll(same));
+  if (pass && bin != b0) atomicAdd(&hist[bin], 1u);
+}
+
+__device__ __forceinline__ u32 hist_bin(u32 ord_score, u32 hbase, u32 hsh) {
+  const u32 bin = (ord_score - hbase) >> hsh;
+  return bin < kHistBins - 1 ? bin : kHistBins - 1;
+}
+
+template <int DT, int E>
+__device__ __forceinline__ void hist_elems(const u32x4& v, u32 idx0, u32 n, float thr, u32 hbase, u32 hsh, u32* hist) {
+  if constexpr (E < DType<DT>::vec) {
+    const float s = vec_elem<DT, E>(v);
+    hist_add(hist, (idx0 + E < n) & (s >= thr), hist_bin(ord_f32(s), hbase, hsh));
+    hist_elems<DT, E + 1>(v, idx0, n, thr, hbase, hsh, hist);
+  }
+}
+
+template <int DT, int E>
+__device__ __forceinline__ void sample_top2(const u32x4& v, u32 idx0, u32 n, float thr, u32& m1, u32& m2) {
+  if constexpr (E < DType<DT>::vec) {
+    const float s = vec_elem<DT, E>(v);
+    const u32 o = ((idx0 + E < n) & (s >= thr)) ? ord_f32(s) : 0u;
+    const u32 lo = o < m1 ? o : m1;
+    m2 = lo > m2 ? lo : m2;
+    m1 = o > m1 ? o : m1;
+    sample_top2<DT, E + 1>(v, idx0, n, thr, m1, m2);
+  }
+}
+
+// the next float above f (finite f; -0 counts as +0)
+__device__ __forceinline__ float next_up(float f) {
+  const u32 b = __builtin_bit_cast(u32, f);
+  if ((b & 0x7fffffffu) == 0u) return __builtin_bit_cast(float, 1u);
+  return __builtin_bit_cast(float, (b & 0x80000000u) ? b - 1u : b + 1u);
+}
+
+// raw bits of element e (run-time) of a 16-byte vector, upcast to fp32
+template <int DT>
+__device__ __forceinline__ float vec_elem_dyn(const u32x4& v, u32 e) {
+  if constexpr (DT == SSDK_F32) {
+    const u32 w = e == 0 ? v[0] : (e == 1 ? v[1] : (e == 2 ? v[2] : v[3]));
+    return __builtin_bit_cast(float, w);
+  } else {
+    const u32 q = e >> 1;
+    const u32 w = q == 0 ? v[0] : (q == 1 ? v[1] : (q == 2 ? v[2] : v[3]));
+    const u32 h = (e & 1u) ? (w >> 16) : (w & 0xffffu);
+    if constexpr (DT == SSDK_BF16) return bf16_bits_to_f32(h);
+    else return f16_bits_to_f32(h);
+  }
+}
+
+template <int DT, int E, bool CHECK = true>
+__device__ __forceinline__ void fast_flags(const u32x4& v, u32 idx0, u32 n, float cut, u32& pmask) {
+  if constexpr (E < DType<DT>::vec) {
+    const float s = vec_elem<DT, E>(v);
+    if constexpr (CHECK) pmask |= ((idx0 + E < n) & (s >= cut)) ? (1u << E) : 0u;
+    else pmask |= (s >= cut) ? (1u << E) : 0u;  // a tile that lies inside the image: no index test
+    fast_flags<DT, E + 1, CHECK>(v, idx0, n, cut, pmask);
+  }
+}
+
+// Prefetch ring through LDS.  Written as ordinary loads into registers, the ring of PF tiles ends every round with
+// register copies that wait for ALL outstanding loads (vmcnt(0) at the loop's back edge): the pipeline drains every PF
+// tiles and the stream runs at the latency of single requests.  Here every wave owns PF slots of 1 KiB in LDS; a tile
+// is fetched straight into its slot (global_load_lds_dwordx4: 16 bytes per lane at slot + lane * 16) and taken out by
+// the same lane with a ds_read_b128 behind a hand-counted s_waitcnt vmcnt(PF-1) -- PF requests per lane stay in flight
+// from the first tile to the last.  (Both halves of the hand-off are one asm block, so the compiler can neither move
+// the read above the wait nor add waits of its own.)
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(1))) const unsigned char glb_u8;
+
+__device__ __forceinline__ void ring_issue(const void* g, unsigned char* slot) {
+  __builtin_amdgcn_global_load_lds((glb_u8*)g, (lds_u8*)slot, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ u32x4 ring_take(const unsigned char* slot_lane) {
+  u32x4 v;
+  const u32 a = (u32)(size_t)(const lds_u8*)slot_lane;
+  asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a), "n"(N) : "memory");
+  return v;
+}
+__device__ __forceinline__ void ring_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int DT, int PF>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) {
   constexpr int NT = kScanThreads;
@@ -125,14 +252,17 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) 
   constexpr int ES = DType<DT>::size;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* buf = reinterpret_cast<u64*>(smem);
-  u64* sel = buf + kCap;
-  SelScratch* ss = reinterpret_cast<SelScratch*>(sel + ((p.K + 1) & ~1u));
+  SelScratch* ss = reinterpret_cast<SelScratch*>(buf + kCap);
   StreamCtl* ctl = reinterpret_cast<StreamCtl*>(ss + 1);
+  FastCtl* fc = reinterpret_cast<FastCtl*>(ctl + 1);
+  unsigned char* stage = smem + scan_fixed_bytes();  // [wave][PF][1 KiB]
+  u64* sel = reinterpret_cast<u64*>(stage);          // (used only after the ring has drained)
 
-  const u32 tid = threadIdx.x;
-  const u32 b = blockIdx.x / p.units_per_image;
-  const u32 u = blockIdx.x % p.units_per_image;
-  u32 n = p.lv[0].n, ubase = 0;
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  // unit-major block order: the big units of every image are dispatched first, the small levels fill in behind them
+  const u32 u = blockIdx.x / p.B;
+  const u32 b = blockIdx.x % p.B;
+  u32 n = p.lv[0].n, ubase = 0, tpu = p.lv[0].tpu;
   const void* cls = p.lv[0].cls;
 #pragma unroll
   for (int i = 1; i < SSDK_MAX_LEVELS; ++i)
@@ -140,6 +270,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) 
       n = p.lv[i].n;
       ubase = p.lv[i].unit_base;
       cls = p.lv[i].cls;
+      tpu = p.lv[i].tpu;
     }
   const u32 uu = u - ubase;
 
@@ -151,62 +282,321 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) 
   const u32 head = (u32)((uintptr_t)base & 15u) / ES;
   const unsigned char* abase = base - (size_t)head * ES;
   const u32 nvec = (head + n + VEC - 1) / VEC;   // vectors holding at least one element of this image (>= 1)
-  const u32 vec0 = uu * p.tiles_per_unit * NT;   // first vector of this unit
+  const u32 vec0 = uu * tpu * NT;                // first vector of this unit
   u32 ntiles = 0;
   if (vec0 < nvec) {
     ntiles = (nvec - vec0 + NT - 1) / NT;
-    if (ntiles > p.tiles_per_unit) ntiles = p.tiles_per_unit;
+    if (ntiles > tpu) ntiles = tpu;
   }
-
-  if (tid == 0) {
-    ctl->cnt = 0;
-    ctl->flag[0] = 0;
-    ctl->flag[1] = 0;
-  }
-  __syncthreads();
-
   const u32 K = p.K;
-  const u32 limit = kCap - NT * VEC;
-  float cut = p.thr;
-  u32 cut_idx = 0xffffffffu;
+  const bool stamp = p.stamps != nullptr && blockIdx.x == 0 && tid == 0;
+  if (stamp) p.stamps[0] = clock64();
 
-  // Branch-free: the address is clamped to the image's last vector and what lies outside the unit is masked through
-  // its index, so every tile issues exactly one load per lane and the compiler can count them (s_waitcnt vmcnt(PF-1)
-  // before a tile is consumed).  (The first version guarded the load with the tile / tail tests: the waits at the
-  // joins of those branches degenerated to vmcnt(0) right after the prefetch was issued -- one exposed memory
-  // latency per 4 KB tile, 0.9 us, instead of PF tiles in flight.)
+  // Branch-free loads: the address is clamped to the image's last vector and what lies outside the unit is masked
+  // through its index, so every tile issues exactly one load per lane and the compiler can count them (s_waitcnt
+  // vmcnt(PF-1) before a tile is consumed).  A prefetch past the unit's last tile re-reads that tile (cache hits).
   const u32 vlast = nvec - 1u;
-  // (a prefetch past the unit's last tile re-reads that tile -- cache hits -- instead of the next unit's data)
   auto load_vec = [&](u32 t) -> u32x4 {
     const u32 vi = vec0 + (t < ntiles ? t : ntiles - 1u) * NT + tid;
     return *reinterpret_cast<const u32x4*>(abase + (size_t)(vi < vlast ? vi : vlast) * 16);
   };
+  auto first_index = [&](u32 t) -> u32 {  // flat index of this lane's first element of tile t (huge when masked)
+    const u32 vi = vec0 + t * NT + tid;
+    return (t < ntiles && vi <= vlast) ? vi * VEC - head : 0xffff0000u;
+  };
 
-  u32x4 pf[PF];
-#pragma unroll
-  for (int i = 0; i < PF; ++i) pf[i] = load_vec(i);
-
-  for (u32 t0 = 0; t0 < ntiles; t0 += PF) {
-#pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      const u32 t = t0 + i;  // tiles past ntiles (the last round of a unit) run masked: no keys, one barrier
-      const u32x4 v = pf[i];
-      pf[i] = load_vec(t + PF);
-      const u32 vi = vec0 + t * NT + tid;
-      const u32 idx0 = (t < ntiles && vi <= vlast) ? vi * VEC - head : 0xffff0000u;
-      scan_vec<DT>(v, idx0, n, cut, cut_idx, buf, ctl, limit, t);
-      u64 T;
-      if (stream_finish_tile<NT>(buf, sel, ss, ctl, t, K, &T)) {
-        cut = key_score(T);
-        cut_idx = key_index(T);
-      }
+  // ---- phase H: a cut from a sample of the unit's own tiles -------------------------------------------------------
+  // Every lane keeps the two largest scores of its share of 8 sample tiles (64 scores): 512 distinct scores of the
+  // unit per workgroup.  The K-th largest of those (K <= 512) is a valid lower bound of the unit's K-th largest
+  // score -- K scores at or above it have been seen -- and close to the K-th largest of the whole sample, since a lane
+  // rarely owns more than two of the sample's top K.  Found without LDS atomics and without a sort (below).
+  float cut0 = p.thr;
+  bool fast = false;
+  if (p.fast && ntiles > 0 && K <= 2 * NT) {  // (a wave offers 128 values: kw = K / 4 of them must exist)
+    if (tid == 0) {
+      fc->overflow = 0;
+      fc->cutord = 0;
+      fc->nge = 0;
+      fc->cum = 0;
     }
+    const u32 S = ntiles < kSample ? ntiles : kSample;
+    const u32 stride = ntiles / S;
+    u32x4 sv[kSample];
+#pragma unroll
+    for (u32 i = 0; i < kSample; ++i) sv[i] = load_vec((i < S ? i : S - 1u) * stride);
+    u32 m1 = 0, m2 = 0;  // ordered bits of the lane's largest / second largest sample score >= thr (0: none)
+#pragma unroll
+    for (u32 i = 0; i < kSample; ++i) {
+      const u32 idx0 = i < S ? first_index(i * stride) : 0xffff0000u;
+      sample_top2<DT, 0>(sv[i], idx0, n, p.thr, m1, m2);
+    }
+    if (stamp) p.stamps[8] = clock64();
+    // the kw-th largest of the wave's 128 values, kw = ceil(K / waves), bit by bit on ballots: every wave then holds
+    // kw scores >= its own value, i.e. K scores are >= the smallest of the waves' values
+    constexpr u32 NWh = NT / 64;
+    const u32 kw = (K + NWh - 1) / NWh;
+    u32 wv = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+      const u32 c = wv | (1u << bit);
+      const u32 cntc = (u32)__popcll(__ballot(m1 >= c)) + (u32)__popcll(__ballot(m2 >= c));
+      wv = cntc >= kw ? c : wv;  // wave-uniform
+    }
+    if (lane == 0) fc->wcount[wave] = wv;
+    if (stamp) p.stamps[9] = clock64();
+    __syncthreads();
+    if (tid == 0) {
+      u32 mn = ~0u;
+#pragma unroll
+      for (u32 w = 0; w < NWh; ++w) mn = fc->wcount[w] < mn ? fc->wcount[w] : mn;
+      fc->cutord = mn;
+    }
+    if (stamp) p.stamps[10] = clock64();
+    __syncthreads();
+    const u32 cutord = fc->cutord;
+    if (cutord) {
+      const float edge = unord_f32(cutord);
+      cut0 = edge > p.thr ? edge : p.thr;
+    }
+    // how many keys the streaming pass will collect, extrapolated from the sample: scores of the sample above the cut,
+    // plus the scores equal to it as far as the waves' tie budgets (below) let them in
+    const float cut_next = next_up(cut0);
+    u32 nge = 0, ngt = 0;
+#pragma unroll
+    for (u32 i = 0; i < kSample; ++i) {
+      const u32 idx0 = i < S ? first_index(i * stride) : 0xffff0000u;
+      u32 pm = 0, pg = 0;
+      fast_flags<DT, 0>(sv[i], idx0, n, cut0, pm);
+      fast_flags<DT, 0>(sv[i], idx0, n, cut_next, pg);
+      nge += (u32)__popc(pm);
+      ngt += (u32)__popc(pg);
+    }
+    u32 packed = (nge << 16) | ngt;  // (<= 64 scores per lane: both sums of a wave fit 16 bits)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) packed += __shfl_xor(packed, d);
+    if (lane == 0 && packed) {
+      atomicAdd(&fc->nge, packed >> 16);
+      atomicAdd(&fc->cum, packed & 0xffffu);
+    }
+    __syncthreads();
+    // per wave: its share of the scores above the cut plus the ties its budget lets in (at most K + 511); beyond ~7/8
+    // of a wave buffer the TopK stream (which prunes) is the better tool
+    constexpr u32 NWv = NT / 64;
+    const unsigned long long gt_w = (unsigned long long)fc->cum * ntiles / ((unsigned long long)S * NWv);
+    unsigned long long eq_w = (unsigned long long)(fc->nge - fc->cum) * ntiles / ((unsigned long long)S * NWv);
+    eq_w = eq_w < K + 511u ? eq_w : K + 511u;
+    fast = gt_w + eq_w <= (unsigned long long)(kWaveCap - kWaveCap / 8);
   }
 
-  const u32 cnt = stream_finalize<NT>(buf, sel, ss, ctl, K);
+  if (stamp) p.stamps[1] = clock64();
+  u32 cnt = 0;
+  bool done = false;
+  if (fast) {
+    // ---- phase S: every wave on its own ----------------------------------------------------------------------------
+    // Ties at the cut: of the scores EQUAL to the cut the unit's top K holds the lowest indices, at most K of them -- and
+    // within one wave's share of the unit those are a prefix of the wave's ties (its tiles come in index order).  So a
+    // wave takes ties only until it has seen K of them (whole vectors: up to K + 511), then compares against the next
+    // float above the cut.  An all-equal image (every score of the random-init network) costs each wave one vector.
+    u64* wbuf = buf + wave * kWaveCap;
+    u32 wcnt = 0, ties = 0;
+    float ccut = cut0;
+    bool ovf = false;
+    auto addr = [&](u32 t) -> const void* {
+      const u32 vi = vec0 + (t < ntiles ? t : ntiles - 1u) * NT + tid;
+      return abase + (size_t)(vi < vlast ? vi : vlast) * 16;
+    };
+    unsigned char* ring = stage + (size_t)wave * PF * 1024;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring_issue(addr(i), ring + i * 1024);
+    for (u32 t0 = 0; t0 < ntiles; t0 += PF) {
+      // the PF tiles of this round lie inside the image (no head elements of the previous image, no partial last
+      // vector, no masked tile behind the unit's end): their scores need no index test
+      const bool inside = vec0 + t0 * NT > 0u && t0 + PF <= ntiles && vec0 + (t0 + PF) * NT <= vlast;
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const u32 t = t0 + i;
+        const u32x4 v = ring_take<PF - 1>(ring + i * 1024 + lane * 16);  // the oldest of the PF requests has landed
+        ring_issue(addr(t + PF), ring + i * 1024);  // (past the unit's last tile: that tile again, cache hits)
+        u32 pmask = 0;
+        if (inside) fast_flags<DT, 0, false>(v, 0u, n, ccut, pmask);
+        else fast_flags<DT, 0, true>(v, first_index(t), n, ccut, pmask);
+        const u64 any = __ballot(pmask != 0u);
+        if (ovf || any == 0ull) continue;
+        const u32 idx0 = first_index(t);
+        // wave-level compaction in index order (lane-major, element-minor).  A wave-vector of 512 scores holds a
+        // handful of candidates, almost always at most one per lane: one ballot then gives every lane its slot.
+        u32 excl, tot;
+        const u32 c = (u32)__popc(pmask);
+        if (__ballot(c > 1u) == 0ull) {
+          excl = mbcnt(any);
+          tot = (u32)__popcll(any);
+        } else {
+          excl = 0;
+          tot = 0;
+#pragma unroll
+          for (int bit = 0; bit < 4; ++bit) {
+            const u64 mb = __ballot((c >> bit) & 1u);
+            excl += mbcnt(mb) << bit;
+            tot += (u32)__popcll(mb) << bit;
+          }
+        }
+        if (wcnt + tot > kWaveCap) {  // wave-uniform
+          ovf = true;
+          continue;
+        }
+        u32 at = wcnt + excl, left = pmask, mine = 0;
+        while (left) {  // one trip for nearly every lane that has anything
+          const u32 e = (u32)__ffs((int)left) - 1u;
+          left &= left - 1u;
+          const float sc = vec_elem_dyn<DT>(v, e);
+          mine += sc == cut0 ? 1u : 0u;
+          wbuf[at++] = make_key(sc, idx0 + e);
+        }
+        wcnt += tot;
+        if (ccut == cut0 && __ballot(mine != 0u) != 0ull) {  // wave-uniform: budget still open and ties in this vector
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
+          ties += mine;
+          if (ties >= K) ccut = next_up(cut0);
+        }
+      }
+    }
+    ring_drain();
+    for (u32 i = wcnt + lane; i < kWaveCap; i += 64) wbuf[i] = 0ull;  // padding: smaller than every key
+    if (lane == 0) {
+      fc->wcount[wave] = wcnt;
+      if (ovf) fc->overflow = 1u;
+    }
+    __syncthreads();
+    if (stamp) p.stamps[2] = clock64();
+    if (fc->overflow == 0u) {
+      u32 total = 0;
+#pragma unroll
+      for (int w = 0; w < NT / 64; ++w) total += fc->wcount[w];
+      cnt = total < K ? total : K;
+      if (total <= K) {
+        wg_compact_ge<NT>(buf, kCap, 1ull, K, sel, ss);  // every collected key is a winner: to the front
+      } else {
+        // exact top-K of the collected keys through the SAME 1024-bin window (every key is >= the cut, so the bins
+        // resolve them well): bins above the one holding the K-th key are winners outright, that bin itself is
+        // resolved by rank counting -- no radix passes over the buffer.
+        for (u32 i = tid; i < kHistBins; i += NT) ss->hist[i] = 0;
+        if (tid == 0) {
+          fc->cutbin = 0;
+          fc->cum = 0;
+          ss->sel_cnt = 0;
+          ss->small_cnt = 0;
+        }
+        __syncthreads();
+        constexpr u32 PER = kCap / NT;
+        u64 mykey[PER];
+        u32 mybin[PER];
+#pragma unroll
+        for (u32 j = 0; j < PER; ++j) {
+          mykey[j] = buf[tid + j * NT];
+          mybin[j] = hist_bin((u32)(mykey[j] >> 32), p.hist_base, p.hist_sh);
+          hist_add(ss->hist, mykey[j] != 0ull, mybin[j]);
+        }
+        __syncthreads();
+        constexpr int BPT = kHistBins / NT;
+        u32 local = 0;
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) local += ss->hist[tid * BPT + j];
+        const u32 incl = wg_incl_suffix_sum<NT>(local, ss->wsum);
+        const u32 excl = incl - local;
+        if (excl < K && K <= incl) {  // exactly one thread
+          u32 acc = excl;
+          for (int j = BPT - 1; j >= 0; --j) {
+            const u32 h = ss->hist[tid * BPT + j];
+            if (acc + h >= K) {
+              fc->cutbin = tid * BPT + j;
+              fc->cum = acc;  // keys in the bins above
+              ss->cb = h;
+              break;
+            }
+            acc += h;
+          }
+        }
+        __syncthreads();
+        const u32 cbin = fc->cutbin, above = fc->cum, cb = ss->cb, need = K - above;
+        if (cb > 512u) {  // heavy ties inside one bin: the generic exact select
+          const u64 T = wg_select_kth<NT>(buf, kCap, K, ss);
+          wg_compact_ge<NT>(buf, kCap, T, K, sel, ss);
+        } else {
+          u64* small = reinterpret_cast<u64*>(ss->hist);  // (the histogram has been read: cb <= 512 keys fit)
+          __syncthreads();
+#pragma unroll
+          for (u32 j = 0; j < PER; ++j) {
+            if (mykey[j] == 0ull) continue;
+            if (mybin[j] > cbin) sel[atomicAdd(&ss->sel_cnt, 1u)] = mykey[j];
+            else if (mybin[j] == cbin) small[atomicAdd(&ss->small_cnt, 1u)] = mykey[j];
+          }
+          __syncthreads();
+          for (u32 t = tid; t < cb; t += NT) {
+            const u64 me = small[t];
+            u32 r = 0;
+            for (u32 j = 0; j < cb; ++j) r += small[j] > me ? 1u : 0u;
+            if (r < need) sel[above + r] = me;
+          }
+          __syncthreads();
+          for (u32 i = tid; i < K; i += NT) buf[i] = sel[i];
+          __syncthreads();
+        }
+      }
+      done = true;
+    }
+    __syncthreads();
+  }
+
+  if (!done) {
+    // ---- TopK stream: exact for every input (ssdk_select.h), one barrier per tile ----------------------------------
+    if (tid == 0) {
+      ctl->cnt = 0;
+      ctl->flag[0] = 0;
+      ctl->flag[1] = 0;
+    }
+    __syncthreads();
+    const u32 limit = kCap - NT * VEC;
+    float cut = cut0;  // a valid lower bound of the unit's K-th score (or the threshold)
+    u32 cut_idx = 0xffffffffu;
+    auto addr = [&](u32 t) -> const void* {
+      const u32 vi = vec0 + (t < ntiles ? t : ntiles - 1u) * NT + tid;
+      return abase + (size_t)(vi < vlast ? vi : vlast) * 16;
+    };
+    unsigned char* ring = stage + (size_t)wave * PF * 1024;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) ring_issue(addr(i), ring + i * 1024);
+    for (u32 t0 = 0; t0 < ntiles; t0 += PF) {
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const u32 t = t0 + i;  // tiles past ntiles (the last round of a unit) run masked: no keys, one barrier
+        const u32x4 v = ring_take<PF - 1>(ring + i * 1024 + lane * 16);
+        ring_issue(addr(t + PF), ring + i * 1024);
+        scan_vec<DT>(v, first_index(t), n, cut, cut_idx, buf, ctl, limit, t);
+        u64 T;
+        if (stream_finish_tile<NT>(buf, sel, ss, ctl, t, K, &T)) {
+          cut = key_score(T);
+          cut_idx = key_index(T);
+        }
+      }
+    }
+    ring_drain();
+    cnt = stream_finalize<NT>(buf, sel, ss, ctl, K);
+  }
+
+  if (stamp) p.stamps[3] = clock64();
+  // The unit's winners leave SORTED (descending key = score desc, index asc): the fused tail kernel merges the units
+  // of a level by binary-search ranks instead of selecting again, and single-unit levels need no sort at all there.
+  const u32 nchunks = cnt ? (cnt + 127u) >> 7 : 1u;
+  for (u32 i = cnt + tid; i < nchunks * 128u; i += NT) buf[i] = 0ull;
+  __syncthreads();
   u64* out = p.cand + ((size_t)b * p.units_per_image + u) * K;
-  for (u32 i = tid; i < K; i += NT) out[i] = (i < cnt) ? buf[i] : 0ull;
+  wg_rank_sort_desc<NT>(buf, nchunks, [&](u32 rank, u64 key) { out[rank] = key; });
+  for (u32 i = cnt + tid; i < K; i += NT) out[i] = 0ull;
   if (tid == 0) p.cand_cnt[(size_t)b * p.units_per_image + u] = cnt;
+  if (stamp) {
+    p.stamps[4] = clock64();
+    p.stamps[5] = ((unsigned long long)(done ? 1u : 0u) << 32) | cnt;
+  }
 }
 
 // box.py:74-87 delta2box + box.py:459-471 for one winner; fp32, reference operation order.
@@ -346,46 +736,37 @@ __global__ __launch_bounds__(kLevelThreads) void level_kernel(const LevelParams 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-hipEvent_t* g_prof_events = nullptr;  // [0] before scan, [1] after scan, [2] after level
-
-// Tail stream of the decode stage (ssdk_set_decode_tail_stream): level_kernel and nms_kernel are latency-bound work
-// on 64-384 workgroups; on their own stream they run under the next batch's forward pass instead of in front of it.
-// scan_kernel (the chip-filling, HBM-bound pass) stays on the caller's stream.
-thread_local hipStream_t g_tail_stream = nullptr;
-static hipEvent_t g_tail_fork[8];
-static bool g_tail_fork_ready = false;
-static unsigned g_tail_fork_i = 0;
-
-// everything enqueued on `from` so far happens before what is enqueued on `to` from now on
-int stream_fork(hipStream_t from, hipStream_t to) {
-  if (!g_tail_fork_ready) {
-    for (auto& e : g_tail_fork)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
-        set_error("decode: hipEventCreate failed");
-        return SSDK_E_LAUNCH;
-      }
-    g_tail_fork_ready = true;
-  }
-  hipEvent_t e = g_tail_fork[g_tail_fork_i++ & 7u];
-  if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) {
-    set_error("decode: stream fork failed");
-    return SSDK_E_LAUNCH;
-  }
-  return SSDK_OK;
-}
-
-struct DecodePlan {
-  u32 tiles_per_unit, units_per_image;
-  u32 units[SSDK_MAX_LEVELS], unit_base[SSDK_MAX_LEVELS], n[SSDK_MAX_LEVELS];
-  size_t cand_bytes, cnt_bytes;
-};
-
 static int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
   return (s && *s) ? atoi(s) : dflt;
 }
 
-static int make_plan(const ssdk_level* lv, int L, int B, int dtype, int K, DecodePlan* pl) {
+// Level l is cut into round(tiles_l / target) units of equal size (at least one): every unit is close to `target`
+// tiles, so the workgroups that carry the bulk of the bytes are balanced (a CU's share of the HBM stream is what
+// bounds the kernel), and the small levels are one small unit each.  `exact`: every level uses exactly `target`
+// tiles per unit (SSDK_TILES_PER_UNIT, tests).
+static void plan_units(DecodePlan* pl, int L, int B, int K, u32 vec, u32 tile, u32 target, bool exact) {
+  pl->tiles_per_unit = target;
+  u32 base = 0;
+  for (int l = 0; l < L; ++l) {
+    const u32 tiles = (u32)(((unsigned long long)pl->n[l] + vec + tile - 1) / tile);
+    u32 units = exact ? (tiles + target - 1) / target : (tiles + target / 2) / target;
+    if (units < 1) units = 1;
+    pl->tpu[l] = exact ? target : (tiles + units - 1) / units;
+    pl->units[l] = (tiles + pl->tpu[l] - 1) / pl->tpu[l];
+    pl->unit_base[l] = base;
+    base += pl->units[l];
+  }
+  pl->units_per_image = base;
+  pl->cand_bytes = (size_t)B * base * K * sizeof(u64);
+  pl->cnt_bytes = (((size_t)B * base * sizeof(u32)) + 255) & ~(size_t)255;
+}
+
+// ndet > 0: the caller is ssdk_decode_nms and would like the fused tail kernel (ssdk_tail.hip), whose LDS stages all
+// unit lists of an image: units are made fatter until they fit, as long as that leaves the scan >= 256 workgroups;
+// pl->fused says whether the geometry qualifies.
+int make_plan(const ssdk_level* lv, int L, int B, int dtype, int K, DecodePlan* pl, int ndet) {
+  pl->fused = false;
   if (!lv || L < 1 || L > SSDK_MAX_LEVELS || B < 1) {
     set_error("decode: need 1 <= L <= %d levels and B >= 1 (L=%d, B=%d)", SSDK_MAX_LEVELS, L, B);
     return SSDK_E_BADARG;
@@ -416,55 +797,116 @@ static int make_plan(const ssdk_level* lv, int L, int B, int dtype, int K, Decod
     tiles_total += (n + vec + tile - 1) / tile;
   }
   // unit size: enough workgroups to keep 256 CUs streaming, but units as large as possible so that the per-unit
-  // prunes / final select and the K keys written per unit (and merged again by level_kernel) amortise.  Measured on
-  // SSD-MobileNetV2@512 batch 64: 32 tiles per unit (640 workgroups) 45 us, 21 tiles (1024 workgroups) 55 us.
+  // prunes / final select / sort and the K keys written per unit (and merged again behind the scan) amortise.
   int tpu = env_int("SSDK_TILES_PER_UNIT", 0);
-  if (tpu <= 0) {
+  const bool forced = tpu > 0;
+  if (!forced) {
     const unsigned long long target_wgs = (unsigned long long)env_int("SSDK_TARGET_WGS", 640);
     unsigned long long t = (tiles_total * (unsigned long long)B + target_wgs - 1) / target_wgs;
-    tpu = (int)(t < 4 ? 4 : (t > 64 ? 64 : t));
+    tpu = (int)(t < 4 ? 4 : (t > 4096 ? 4096 : t));
   }
-  pl->tiles_per_unit = (u32)tpu;
-  u32 base = 0;
-  for (int l = 0; l < L; ++l) {
-    const u32 tiles = (u32)(((unsigned long long)pl->n[l] + vec + tile - 1) / tile);
-    pl->units[l] = (tiles + tpu - 1) / tpu;
-    pl->unit_base[l] = base;
-    base += pl->units[l];
+  plan_units(pl, L, B, K, vec, tile, (u32)tpu, forced);
+  if (ndet > 0 && env_int("SSDK_DECODE_FUSED", 1) != 0) {
+    if (tail_fits(pl->units_per_image, K, L, ndet)) {
+      pl->fused = true;
+    } else if (!forced && tail_fits((u32)L, K, L, ndet)) {
+      DecodePlan best = *pl;
+      bool found = false;
+      for (unsigned long long t = (unsigned long long)tpu * 5 / 4 + 1; t <= (1ull << 22); t = t * 5 / 4 + 1) {
+        DecodePlan tryp = *pl;
+        plan_units(&tryp, L, B, K, vec, tile, (u32)t, false);
+        if ((unsigned long long)tryp.units_per_image * B < 256ull) break;  // starving the scan is worse than 3 launches
+        if (tail_fits(tryp.units_per_image, K, L, ndet)) {
+          best = tryp;
+          found = true;
+          break;
+        }
+      }
+      if (found) {
+        *pl = best;
+        pl->fused = true;
+      }
+    }
   }
-  pl->units_per_image = base;
-  pl->cand_bytes = (size_t)B * base * K * sizeof(u64);
-  pl->cnt_bytes = (((size_t)B * base * sizeof(u32)) + 255) & ~(size_t)255;
   return SSDK_OK;
 }
 
-static int launch_decode(const ssdk_level* lv, int L, int B, int dtype, float thr, int K, int rescore,
-                         float* scores, float* boxes, float* classes, void* ws, size_t ws_bytes,
-                         hipStream_t stream, hipStream_t tail = nullptr) {
-  DecodePlan pl;
-  int rc = make_plan(lv, L, B, dtype, K, &pl);
+static int check_levels(const ssdk_level* lv, int L) {
+  for (int l = 0; l < L; ++l)
+    if (!lv[l].cls || !lv[l].box || ((uintptr_t)lv[l].cls & 15)) {
+      set_error("decode: level %d has a null or non-16-byte-aligned head pointer", l);
+      return SSDK_E_BADARG;
+    }
+  return SSDK_OK;
+}
+
+// scan_kernel: cand[B][units_per_image][K] sorted keys + cand_cnt[B][units_per_image] into `ws`
+int launch_scan(const ssdk_level* lv, int L, int B, int dtype, float thr, int K, const DecodePlan& pl, void* ws,
+                size_t ws_bytes, hipStream_t stream, unsigned long long* stamps) {
+  int rc = check_levels(lv, L);
   if (rc) return rc;
-  if (!scores || !boxes || !classes) {
-    set_error("decode: null output pointer");
-    return SSDK_E_BADARG;
-  }
   if (!ws || ws_bytes < pl.cand_bytes + pl.cnt_bytes || ((uintptr_t)ws & 15)) {
     set_error("decode: workspace too small or misaligned (%zu < %zu)", ws_bytes, pl.cand_bytes + pl.cnt_bytes);
     return SSDK_E_WORKSPACE;
   }
   ScanParams sp;
-  LevelParams lp;
   memset(&sp, 0, sizeof(sp));
-  memset(&lp, 0, sizeof(lp));
   for (int l = 0; l < L; ++l) {
-    if (!lv[l].cls || !lv[l].box || ((uintptr_t)lv[l].cls & 15)) {
-      set_error("decode: level %d has a null or non-16-byte-aligned head pointer", l);
-      return SSDK_E_BADARG;
-    }
     sp.lv[l].cls = lv[l].cls;
     sp.lv[l].n = pl.n[l];
     sp.lv[l].units = pl.units[l];
     sp.lv[l].unit_base = pl.unit_base[l];
+    sp.lv[l].tpu = pl.tpu[l];
+  }
+  sp.L = L;
+  sp.units_per_image = pl.units_per_image;
+  sp.B = (u32)B;
+  sp.K = (u32)K;
+  sp.thr = thr;
+  sp.fast = env_int("SSDK_SCAN_FAST", 1) != 0 && thr == thr;
+  {  // histogram window of the seeding phase: [thr, max(1, 2 thr)] in 1023 bins of 2^sh ordered-float ulps + overflow
+    const u32 lo = ord_f32(thr);
+    const float top = thr < 0.5f ? 1.0f : (thr > 0.f ? 2.0f * thr : 1.0f);
+    const u32 hi = ord_f32(top) > lo ? ord_f32(top) : lo + 1u;
+    u32 sh = 0;
+    while (((hi - lo) >> sh) >= kHistBins - 1) ++sh;
+    sp.hist_sh = sh;
+    sp.hist_base = (lo >> sh) << sh;
+  }
+  sp.cand = (u64*)ws;
+  sp.cand_cnt = (u32*)((char*)ws + pl.cand_bytes);
+  sp.stamps = stamps;
+  const dim3 grid((unsigned)(B * pl.units_per_image));
+  lds_poison(stream);
+  const int pf = env_int("SSDK_SCAN_PF", 4) == 8 ? 8 : 4;  // 16-byte requests in flight per lane
+  const size_t lds = scan_lds_bytes((u32)K, pf);
+  auto go = [&](auto kern) {
+    if (lds > 64 * 1024)  // above the default dynamic-LDS limit (PF = 8): raise it for this instantiation
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(kScanThreads), lds, stream, sp);
+  };
+  if (pf == 8) {
+    if (dtype == SSDK_F32) go(scan_kernel<SSDK_F32, 8>);
+    else if (dtype == SSDK_BF16) go(scan_kernel<SSDK_BF16, 8>);
+    else go(scan_kernel<SSDK_F16, 8>);
+  } else {
+    if (dtype == SSDK_F32) go(scan_kernel<SSDK_F32, 4>);
+    else if (dtype == SSDK_BF16) go(scan_kernel<SSDK_BF16, 4>);
+    else go(scan_kernel<SSDK_F16, 4>);
+  }
+  return check_launch("scan_kernel");
+}
+
+// level_kernel on the scan's output: the zero-padded [B, L*K] per-level decode of box.decode
+int launch_level(const ssdk_level* lv, int L, int B, int dtype, int K, int rescore, const DecodePlan& pl, const void* ws,
+                 float* scores, float* boxes, float* classes, hipStream_t stream) {
+  if (!scores || !boxes || !classes) {
+    set_error("decode: null output pointer");
+    return SSDK_E_BADARG;
+  }
+  LevelParams lp;
+  memset(&lp, 0, sizeof(lp));
+  for (int l = 0; l < L; ++l) {
     lp.lv[l].box = lv[l].box;
     lp.lv[l].A = lv[l].A;
     lp.lv[l].C = lv[l].C;
@@ -475,85 +917,39 @@ static int launch_decode(const ssdk_level* lv, int L, int B, int dtype, float th
     lp.lv[l].unit_base = pl.unit_base[l];
     memcpy(lp.lv[l].anchors, lv[l].anchors, sizeof(float) * 4 * lv[l].A);
   }
-  sp.L = L;
-  sp.units_per_image = pl.units_per_image;
-  sp.tiles_per_unit = pl.tiles_per_unit;
-  sp.K = (u32)K;
-  sp.thr = thr;
-  sp.cand = (u64*)ws;
-  sp.cand_cnt = (u32*)((char*)ws + pl.cand_bytes);
   lp.L = L;
   lp.dtype = dtype;
   lp.rescore = rescore;
   lp.units_per_image = pl.units_per_image;
   lp.K = (u32)K;
   lp.out_stride = (u32)(L * K);
-  lp.cand = sp.cand;
-  lp.cand_cnt = sp.cand_cnt;
+  lp.cand = (const u64*)ws;
+  lp.cand_cnt = (const u32*)((const char*)ws + pl.cand_bytes);
   lp.scores = scores;
   lp.boxes = boxes;
   lp.classes = classes;
-
-  const size_t lds = lds_bytes_for((u32)K);
-  const dim3 grid((unsigned)(B * pl.units_per_image));
   lds_poison(stream);
-  if (g_prof_events) (void)hipEventRecord(g_prof_events[0], stream);
-  static const int pf = [] {  // 16-byte loads in flight per lane: 4 (default) or 8 (SSDK_SCAN_PF=8)
-    const char* e = getenv("SSDK_SCAN_PF");
-    return (e && atoi(e) == 8) ? 8 : 4;
-  }();
-  if (pf == 8) {
-    if (dtype == SSDK_F32) hipLaunchKernelGGL((scan_kernel<SSDK_F32, 8>), grid, dim3(kScanThreads), lds, stream, sp);
-    else if (dtype == SSDK_BF16) hipLaunchKernelGGL((scan_kernel<SSDK_BF16, 8>), grid, dim3(kScanThreads), lds, stream, sp);
-    else hipLaunchKernelGGL((scan_kernel<SSDK_F16, 8>), grid, dim3(kScanThreads), lds, stream, sp);
-  } else {
-    if (dtype == SSDK_F32) hipLaunchKernelGGL((scan_kernel<SSDK_F32, 4>), grid, dim3(kScanThreads), lds, stream, sp);
-    else if (dtype == SSDK_BF16) hipLaunchKernelGGL((scan_kernel<SSDK_BF16, 4>), grid, dim3(kScanThreads), lds, stream, sp);
-    else hipLaunchKernelGGL((scan_kernel<SSDK_F16, 4>), grid, dim3(kScanThreads), lds, stream, sp);
-  }
-  rc = check_launch("scan_kernel");
-  if (rc) return rc;
-  if (g_prof_events) (void)hipEventRecord(g_prof_events[1], stream);
-  hipStream_t st2 = stream;
-  if (tail && tail != stream) {  // the rest of the stage goes to the tail stream, ordered after the scan
-    rc = stream_fork(stream, tail);
-    if (rc) return rc;
-    st2 = tail;
-  }
-  lds_poison(st2);
-  hipLaunchKernelGGL(level_kernel, dim3((unsigned)L, (unsigned)B), dim3(kLevelThreads), lds, st2, lp);
-  rc = check_launch("level_kernel");
-  if (g_prof_events) (void)hipEventRecord(g_prof_events[2], st2);
-  return rc;
-}
-
-// shared with ssdk_nms.hip (fused decode_nms entry point lives there)
-size_t decode_ws_bytes(const ssdk_level* lv, int L, int B, int dtype, int K) {
-  DecodePlan pl;
-  if (make_plan(lv, L, B, dtype, K, &pl)) return 0;
-  return pl.cand_bytes + pl.cnt_bytes;
-}
-int decode_levels(const ssdk_level* lv, int L, int B, int dtype, float thr, int K, int rescore,
-                  float* scores, float* boxes, float* classes, void* ws, size_t ws_bytes, void* stream,
-                  void* tail) {
-  return launch_decode(lv, L, B, dtype, thr, K, rescore, scores, boxes, classes, ws, ws_bytes,
-                       (hipStream_t)stream, (hipStream_t)tail);
+  hipLaunchKernelGGL(level_kernel, dim3((unsigned)L, (unsigned)B), dim3(kLevelThreads), lds_bytes_for((u32)K), stream, lp);
+  return check_launch("level_kernel");
 }
 
 }  // namespace ssdk
 
 extern "C" size_t ssdk_decode_workspace_bytes(const ssdk_level* levels, int L, int B, int dtype, int top_n) {
-  return ssdk::decode_ws_bytes(levels, L, B, dtype, top_n);
+  ssdk::DecodePlan pl;
+  if (ssdk::make_plan(levels, L, B, dtype, top_n, &pl, 0)) return 0;
+  return pl.cand_bytes + pl.cnt_bytes;
 }
 
 extern "C" int ssdk_decode(const ssdk_level* level, int B, int dtype, float threshold, int top_n,
                            int rescore, float* scores, float* boxes, float* classes, void* workspace,
                            size_t workspace_bytes, void* stream) {
-  return ssdk::decode_levels(level, 1, B, dtype, threshold, top_n, rescore, scores, boxes, classes,
-                             workspace, workspace_bytes, stream, nullptr);
-}
-
-extern "C" int ssdk_set_decode_tail_stream(void* stream) {
-  ssdk::g_tail_stream = (hipStream_t)stream;
-  return SSDK_OK;
+  ssdk::DecodePlan pl;
+  int rc = ssdk::make_plan(level, 1, B, dtype, top_n, &pl, 0);
+  if (rc) return rc;
+  rc = ssdk::launch_scan(level, 1, B, dtype, threshold, top_n, pl, workspace, workspace_bytes, (hipStream_t)stream,
+                         nullptr);
+  if (rc) return rc;
+  return ssdk::launch_level(level, 1, B, dtype, top_n, rescore, pl, workspace, scores, boxes, classes,
+                            (hipStream_t)stream);
 }

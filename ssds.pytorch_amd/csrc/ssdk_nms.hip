@@ -16,17 +16,9 @@
 // bit-exact with the CPU reference.
 #include "ssdk_common.h"
 #include "ssdk_select.h"
+#include "ssdk_decode.h"
 
 namespace ssdk {
-
-// decode side (ssdk_decode.hip)
-size_t decode_ws_bytes(const ssdk_level* lv, int L, int B, int dtype, int K);
-int decode_levels(const ssdk_level* lv, int L, int B, int dtype, float thr, int K, int rescore,
-                  float* scores, float* boxes, float* classes, void* ws, size_t ws_bytes, void* stream,
-                  void* tail);
-extern thread_local hipStream_t g_tail_stream;  // ssdk_set_decode_tail_stream (ssdk_decode.hip)
-
-extern hipEvent_t* g_prof_events;  // set by ssdk_decode_nms while profiling (ssdk_decode.hip)
 
 constexpr int kNmsThreads = 256;
 
@@ -245,7 +237,7 @@ static size_t nms_lds_bytes(int N, int ndet) {
   return (size_t)((N + 1) & ~1) * 8 + kNmsRound * 8 + 66 * 8 + (size_t)ndet * (16 + 4 + 4) + 16 + sizeof(SelScratch) + 16;
 }
 
-static int launch_nms(const float* scores, const float* boxes, const float* classes, int B, int N,
+int launch_nms(const float* scores, const float* boxes, const float* classes, int B, int N,
                       float thr, int ndet, int diou, float* os, float* ob, float* oc, hipStream_t stream) {
   if (!scores || !boxes || !classes || !os || !ob || !oc) {
     set_error("nms: null pointer");
@@ -295,88 +287,3 @@ extern "C" int ssdk_nms(const float* scores, const float* boxes, const float* cl
                           out_scores, out_boxes, out_classes, (hipStream_t)stream);
 }
 
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
-// ---- optional per-kernel timing (bench.py roofline): events on the caller's stream ---------------
-// A ring of event quadruples so that a whole timed region can be profiled without any synchronisation
-// inside it; the host reads the slots back after its own final sync.
-constexpr int kProfSlots = 256;
-static int g_prof_on = 0;
-static hipEvent_t g_ev[kProfSlots][4];
-static int g_ev_ready = 0;
-static long long g_prof_calls = 0;
-
-extern "C" int ssdk_set_profiling(int enable) {
-  if (enable && !g_ev_ready) {
-    for (int s = 0; s < kProfSlots; ++s)
-      for (int i = 0; i < 4; ++i)
-        if (hipEventCreate(&g_ev[s][i]) != hipSuccess) {
-          ssdk::set_error("set_profiling: hipEventCreate failed");
-          return SSDK_E_LAUNCH;
-        }
-    g_ev_ready = 1;
-  }
-  g_prof_on = enable ? 1 : 0;
-  g_prof_calls = 0;
-  return SSDK_OK;
-}
-
-// ms[0] = scan_kernel, ms[1] = level_kernel, ms[2] = nms_kernel of the profiled ssdk_decode_nms call
-// `back` calls before the most recent one (0 = last).  Synchronises on that call's last event.
-extern "C" int ssdk_get_timings(int back, float* ms, int n) {
-  if (!ms || n < 3 || back < 0 || back >= kProfSlots || (long long)back >= g_prof_calls) {
-    ssdk::set_error("get_timings: slot %d not recorded (%lld profiled calls, ring of %d)", back, g_prof_calls,
-                    kProfSlots);
-    return SSDK_E_BADARG;
-  }
-  hipEvent_t* ev = g_ev[(g_prof_calls - 1 - back) % kProfSlots];
-  if (hipEventSynchronize(ev[3]) != hipSuccess) return SSDK_E_LAUNCH;
-  for (int i = 0; i < 3; ++i)
-    if (hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) != hipSuccess) return SSDK_E_LAUNCH;
-  return SSDK_OK;
-}
-
-extern "C" size_t ssdk_decode_nms_workspace_bytes(const ssdk_level* levels, int L, int B, int dtype,
-                                                  int top_n_per_level, int ndetections) {
-  (void)ndetections;
-  const size_t dec = ssdk::decode_ws_bytes(levels, L, B, dtype, top_n_per_level);
-  if (!dec) return 0;
-  const size_t n = (size_t)B * L * top_n_per_level;
-  return align256(dec) + align256(n * 4) + align256(n * 16) + align256(n * 4);
-}
-
-extern "C" int ssdk_decode_nms(const ssdk_level* levels, int L, int B, int dtype, float threshold,
-                               int top_n_per_level, int rescore, float nms_threshold, int ndetections,
-                               int using_diou, float* out_scores, float* out_boxes, float* out_classes,
-                               float* mid_scores, float* mid_boxes, float* mid_classes, void* workspace,
-                               size_t workspace_bytes, void* stream) {
-  const size_t dec = ssdk::decode_ws_bytes(levels, L, B, dtype, top_n_per_level);
-  if (!dec) return SSDK_E_BADARG;
-  const size_t need = ssdk_decode_nms_workspace_bytes(levels, L, B, dtype, top_n_per_level, ndetections);
-  if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255)) {
-    ssdk::set_error("decode_nms: workspace too small or not 256-byte aligned (%zu < %zu)", workspace_bytes, need);
-    return SSDK_E_WORKSPACE;
-  }
-  const size_t n = (size_t)B * L * top_n_per_level;
-  char* w = (char*)workspace + align256(dec);
-  float* ms = mid_scores ? mid_scores : (float*)w;
-  w += align256(n * 4);
-  float* mb = mid_boxes ? mid_boxes : (float*)w;
-  w += align256(n * 16);
-  float* mc = mid_classes ? mid_classes : (float*)w;
-  const bool prof = g_prof_on && g_ev_ready;
-  hipEvent_t* ev = prof ? g_ev[g_prof_calls % kProfSlots] : nullptr;
-  ssdk::g_prof_events = ev;
-  hipStream_t tail = ssdk::g_tail_stream ? ssdk::g_tail_stream : (hipStream_t)stream;
-  int rc = ssdk::decode_levels(levels, L, B, dtype, threshold, top_n_per_level, rescore, ms, mb, mc,
-                               workspace, dec, stream, tail);
-  ssdk::g_prof_events = nullptr;
-  if (rc) return rc;
-  rc = ssdk::launch_nms(ms, mb, mc, B, L * top_n_per_level, nms_threshold, ndetections, using_diou,
-                        out_scores, out_boxes, out_classes, tail);
-  if (prof) {
-    (void)hipEventRecord(ev[3], tail);
-    ++g_prof_calls;
-  }
-  return rc;
-}

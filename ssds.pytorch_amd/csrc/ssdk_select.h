@@ -222,6 +222,184 @@ __device__ void wg_bitonic_sort_desc(u64* a, u32 M) {  // M power of two
   }
 }
 
+// Same network with barriers only where a step crosses waves.  Thread i owns the pair (lo, lo | j) of every step; with
+// NT threads working on the pairs [0, M/2) a wave's 64 pairs of a step with j <= 64 lie inside the wave's own
+// 128-element block, which the same wave also wrote in the previous step if that step had j <= 64 too: LDS operations
+// of one wave are processed in order, so such steps need no s_barrier (45 barriers -> 5 for M = 512, 66 -> 14 for
+// M = 2048).  Pairs beyond NT per step (M/2 > NT) are visited in rounds that keep the same ownership rule.
+template <int NT>
+__device__ void wg_bitonic_sort_desc_mixed(u64* a, u32 M) {  // M power of two, M >= 2
+  const u32 tid = threadIdx.x;
+  const u32 half = M >> 1;
+  u32 prev_j = 0x40000000u;  // "written by other waves": the caller's stores, ordered by the first barrier
+  for (u32 k = 2; k <= M; k <<= 1) {
+    for (u32 j = k >> 1; j > 0; j >>= 1) {
+      // pair index p -> wave owning it in a round = (p % NT) / 64; block of elements touched = 128 * (p / 64)
+      if (prev_j > 64u || j > 64u || half > (u32)NT) __syncthreads();
+      else __builtin_amdgcn_wave_barrier();
+      for (u32 i = tid; i < half; i += NT) {
+        const u32 lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+        const u32 hi = lo | j;
+        const bool desc = (lo & k) == 0;
+        const u64 x = a[lo], y = a[hi];
+        if ((x < y) == desc) {
+          a[lo] = y;
+          a[hi] = x;
+        }
+      }
+      prev_j = j;
+    }
+  }
+  __syncthreads();
+}
+
+// ---- sorting by wave-local runs + rank merge ---------------------------------------------------
+// A wave sorts 128 keys in registers (2 per lane, element e = lane + 64 r): 28 compare-exchange steps, cross-lane
+// partners by shuffles, no LDS traffic and no barrier.  Sorted runs of 128 are then merged WITHOUT a merge network:
+// keys are unique, so the rank of a key in the union is its index in its own run plus, for every other run, the number
+// of larger keys there (8-step binary search; the searches over up to 8 sibling runs advance together, so a key costs
+// 8 LDS round trips per group of 8 siblings instead of 64).  Zero keys are padding: they sort to the end of a run and
+// take no rank.
+template <u32 J>
+__device__ __forceinline__ u64 xor_lane_u64(u64 v, u32 idx32) {  // value of lane (lane ^ J)
+  u32 lo = (u32)v, hi = (u32)(v >> 32);
+  if constexpr (J < 32) {  // ds_swizzle, bit-mask mode (and 0x1f, or 0, xor J): no address register, no index math
+    lo = (u32)__builtin_amdgcn_ds_swizzle((int)lo, (int)((J << 10) | 0x1fu));
+    hi = (u32)__builtin_amdgcn_ds_swizzle((int)hi, (int)((J << 10) | 0x1fu));
+  } else {
+    lo = (u32)__builtin_amdgcn_ds_bpermute((int)idx32, (int)lo);
+    hi = (u32)__builtin_amdgcn_ds_bpermute((int)idx32, (int)hi);
+  }
+  return ((u64)hi << 32) | lo;
+}
+
+template <u32 K2, u32 J>
+__device__ __forceinline__ void wave_sort128_step(u64& x0, u64& x1, u32 lane, u32 idx32) {
+  if constexpr (J == 64) {  // partner lives in the same lane; K2 == 128: one descending block
+    const bool gt = x0 > x1;
+    const u64 mx = gt ? x0 : x1, mn = gt ? x1 : x0;
+    x0 = mx;
+    x1 = mn;
+  } else {
+    const u64 y0 = xor_lane_u64<J>(x0, idx32), y1 = xor_lane_u64<J>(x1, idx32);
+    const bool lo = (lane & J) == 0;  // this element is the lower index of its pair
+    // block direction: descending iff (e & K2) == 0, e = lane + 64 r
+    const bool d0 = K2 < 64 ? (lane & K2) == 0 : true;
+    const bool d1 = K2 < 64 ? (lane & K2) == 0 : (K2 == 64 ? false : true);
+    const bool m0 = lo == d0, m1 = lo == d1;  // keep the larger of the pair?
+    const bool g0 = x0 > y0, g1 = x1 > y1;
+    x0 = (g0 == m0) ? x0 : y0;
+    x1 = (g1 == m1) ? x1 : y1;
+  }
+}
+template <u32 K2, u32 J>
+__device__ __forceinline__ void wave_sort128_merge(u64& x0, u64& x1, u32 lane, u32 idx32) {
+  wave_sort128_step<K2, J>(x0, x1, lane, idx32);
+  if constexpr (J > 1) wave_sort128_merge<K2, J / 2>(x0, x1, lane, idx32);
+}
+template <u32 K2>
+__device__ __forceinline__ void wave_sort128_stage(u64& x0, u64& x1, u32 lane, u32 idx32) {
+  wave_sort128_merge<K2, K2 / 2>(x0, x1, lane, idx32);
+  if constexpr (K2 < 128) wave_sort128_stage<K2 * 2>(x0, x1, lane, idx32);
+}
+__device__ __forceinline__ void wave_sort128_desc(u64& x0, u64& x1) {
+  const u32 lane = lane_id();
+  wave_sort128_stage<2>(x0, x1, lane, (lane ^ 32u) << 2);
+}
+
+// number of keys of the descending run `run[0..len)` that are larger than `key`, for W runs at once (runs r0 .. r0+W-1
+// of `stride` keys each at `base`; run `skip` and runs >= nruns count 0).  `steps` >= bits(len).
+template <int W>
+__device__ __forceinline__ u32 count_greater_xw(const u64* base, u32 stride, const u32* lens, u32 fixed_len, u32 r0,
+                                                u32 nruns, u32 skip, u64 key, int steps) {
+  // Branch-free: every probe is an unconditional read of an in-range slot (bitwise &, no short-circuit -- with `&&` the
+  // compiler sinks each load into its own branch and waits for it there, which serialises the W searches).
+  u32 pos[W], len[W];
+  const u64* run[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const u32 r = r0 + (u32)j;
+    const bool on = (r < nruns) & (r != skip);
+    const u32 rr = r < nruns ? r : r0;
+    run[j] = base + (size_t)rr * stride;
+    len[j] = on ? (lens ? lens[rr] : fixed_len) : 0u;
+    pos[j] = 0;
+  }
+  for (u32 step = 1u << (steps - 1); step > 0; step >>= 1) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const u32 probe = pos[j] + step;                       // "are the first `probe` keys all larger?"
+      const u32 at = (probe < stride ? probe : stride) - 1u;  // clamped: always a slot of this run
+      const u64 v = run[j][at];
+      pos[j] = ((probe <= len[j]) & (v > key)) ? probe : pos[j];
+    }
+  }
+  u32 sum = 0;
+#pragma unroll
+  for (int j = 0; j < W; ++j) sum += pos[j];
+  return sum;
+}
+
+// keys larger than `key` in all runs but `skip` (random LDS reads: the width follows the number of runs left, so a level
+// with two lists costs 1/4 of one with eight)
+__device__ __forceinline__ u32 count_greater_runs(const u64* base, u32 stride, const u32* lens, u32 fixed_len, u32 nruns,
+                                                  u32 skip, u64 key, int steps) {
+  u32 sum = 0, r0 = 0;
+  while (r0 < nruns) {
+    const u32 left = nruns - r0;
+    if (left >= 8) {
+      sum += count_greater_xw<8>(base, stride, lens, fixed_len, r0, nruns, skip, key, steps);
+      r0 += 8;
+    } else if (left >= 4) {
+      sum += count_greater_xw<4>(base, stride, lens, fixed_len, r0, nruns, skip, key, steps);
+      r0 += 4;
+    } else if (left >= 2) {
+      sum += count_greater_xw<2>(base, stride, lens, fixed_len, r0, nruns, skip, key, steps);
+      r0 += 2;
+    } else {
+      if (r0 != skip) sum += count_greater_xw<1>(base, stride, lens, fixed_len, r0, nruns, skip, key, steps);
+      r0 += 1;
+    }
+  }
+  return sum;
+}
+
+// a[0 .. nchunks*128) in LDS (zero = padding): every wave sorts its chunks of 128 in place (descending).  Needs a
+// barrier before (a[] complete) and one after (before anybody reads another wave's run).
+template <int NT>
+__device__ __forceinline__ void wg_sort_runs128(u64* a, u32 nchunks) {
+  const u32 lane = lane_id(), wave = threadIdx.x >> 6;
+  constexpr u32 NW = NT / 64;
+  for (u32 c = wave; c < nchunks; c += NW) {
+    u64 x0 = a[c * 128 + lane], x1 = a[c * 128 + 64 + lane];
+    wave_sort128_desc(x0, x1);
+    a[c * 128 + lane] = x0;
+    a[c * 128 + 64 + lane] = x1;
+  }
+}
+
+// every non-zero key k of the sorted runs with kmin <= k < kmax is handed to emit(rank, key), rank = its position in
+// the descending order of ALL keys.  Returns (per thread) how many keys it emitted.
+template <int NT, class Emit>
+__device__ __forceinline__ u32 wg_rank_emit(const u64* a, u32 nchunks, u64 kmin, u64 kmax, Emit emit) {
+  u32 mine = 0;
+  for (u32 i = threadIdx.x; i < nchunks * 128; i += NT) {
+    const u64 key = a[i];
+    if (key == 0ull || key < kmin || key >= kmax) continue;
+    emit((i & 127u) + count_greater_runs(a, 128, nullptr, 128, nchunks, i >> 7, key, 8), key);
+    ++mine;
+  }
+  return mine;
+}
+
+// sort + rank of everything (barrier before; none after)
+template <int NT, class Emit>
+__device__ __forceinline__ void wg_rank_sort_desc(u64* a, u32 nchunks, Emit emit) {
+  wg_sort_runs128<NT>(a, nchunks);
+  __syncthreads();
+  (void)wg_rank_emit<NT>(a, nchunks, 1ull, ~0ull, emit);
+}
+
 // ---- streaming accumulator --------------------------------------------------------------------
 constexpr u32 kStreamCap = 4096;    // LDS key slots of a stream (== kCap of the kernels that use it)
 constexpr u32 kApproxKeep = 1024;   // an intermediate prune may keep up to this many keys

@@ -149,6 +149,20 @@ def _load():
     lib.ssdk_debug_lds_probe.argtypes = [vp, vp]
     lib.ssdk_set_decode_tail_stream.restype = i32
     lib.ssdk_set_decode_tail_stream.argtypes = [vp]
+    lib.ssdk_ctx_create.restype = vp
+    lib.ssdk_ctx_create.argtypes = []
+    lib.ssdk_ctx_destroy.restype = None
+    lib.ssdk_ctx_destroy.argtypes = [vp]
+    for _n, _a in (("ssdk_ctx_set_tail_stream", [vp, vp]), ("ssdk_ctx_set_side_lane", [vp, i32]),
+                   ("ssdk_ctx_set_profiling", [vp, i32]), ("ssdk_ctx_get_timings", [vp, i32, c.POINTER(f32), i32]),
+                   ("ssdk_ctx_set_op_profiling", [vp, i32]),
+                   ("ssdk_ctx_get_op_timings", [vp, c.POINTER(f32), c.POINTER(c.c_char_p), i32]),
+                   ("ssdk_ctx_get_tail_stamps", [vp, c.POINTER(c.c_ulonglong), i32]),
+                   ("ssdk_run_ops_ctx", [vp, c.POINTER(Op), i32, vp, sz, vp]),
+                   ("ssdk_decode_nms_ctx", [vp, c.POINTER(Level), i32, i32, i32, f32, i32, i32, f32, i32, i32,
+                                            vp, vp, vp, vp, vp, vp, vp, sz, vp])):
+        getattr(lib, _n).restype = i32
+        getattr(lib, _n).argtypes = _a
     lib.ssdk_map_match.restype = i32
     lib.ssdk_map_match.argtypes = [vp, vp, vp, i32, i32, vp, i32, i32, f32, f32, vp, vp, vp, vp]
     lib.ssdk_map_average_precision.restype = i32
@@ -179,13 +193,76 @@ EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_p
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
            "ssdk_match_targets_by_scale", "ssdk_match_loss_workspace_bytes", "ssdk_match_loss",
            "ssdk_map_match", "ssdk_map_average_precision", "ssdk_set_decode_tail_stream", "ssdk_debug_lds_probe",
+           "ssdk_ctx_create", "ssdk_ctx_destroy", "ssdk_ctx_set_tail_stream", "ssdk_ctx_set_side_lane", "ssdk_ctx_set_profiling",
+           "ssdk_ctx_get_timings", "ssdk_ctx_set_op_profiling", "ssdk_ctx_get_op_timings", "ssdk_ctx_get_tail_stamps",
+           "ssdk_run_ops_ctx", "ssdk_decode_nms_ctx",
            "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_fuse", "ssdk_preprocess", "ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data",
            "ssdk_dwconv_bwd_weight_workspace_bytes", "ssdk_dwconv_bwd_weight", "ssdk_bn_workspace_bytes",
            "ssdk_bn_train_fwd", "ssdk_bn_train_bwd", "ssdk_conv_stem7", "ssdk_maxpool3x3s2", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 
 
+class Context(object):
+    """A caller-owned ``ssdk_ctx`` (include/ssdk.h "Contexts"): the HIP objects behind the multi-launch entry points
+    (side stream + fork/join events of the plan executor, tail-stream fork events and the profiling rings of the
+    decode stage).  Bound to the device that is current when it is created; used by one host thread at a time --
+    every ``Decoder`` and every ``ConvPlan`` owns one, so two threads / two devices share no state."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            self.ptr = lib.ssdk_ctx_create()
+        if not self.ptr:
+            raise SsdkError("ssdk_ctx_create failed: " + lib.ssdk_last_error().decode())
+        self.ptr = ctypes.c_void_p(self.ptr)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                lib.ssdk_ctx_destroy(self.ptr)
+                self.ptr = None
+        except Exception:  # interpreter shutdown
+            pass
+
+    def _call(self, fn, *a):
+        with torch.cuda.device(self.device):
+            return fn(self.ptr, *a)
+
+    def set_tail_stream(self, stream):
+        check(self._call(lib.ssdk_ctx_set_tail_stream, ctypes.c_void_p(stream.cuda_stream) if stream is not None else None),
+              "ctx_set_tail_stream")
+
+    def set_side_lane(self, on):
+        check(self._call(lib.ssdk_ctx_set_side_lane, -1 if on is None else int(bool(on))), "ctx_set_side_lane")
+
+    def set_profiling(self, on):
+        check(self._call(lib.ssdk_ctx_set_profiling, 1 if on else 0), "ctx_set_profiling")
+
+    def timings_ms(self, back=0):
+        """(scan_kernel, tail_kernel | level_kernel, nms_kernel | 0) ms of the profiled decode_nms call ``back`` calls ago."""
+        ms = (ctypes.c_float * 3)()
+        check(self._call(lib.ssdk_ctx_get_timings, int(back), ms, 3), "ctx_get_timings")
+        return float(ms[0]), float(ms[1]), float(ms[2])
+
+    def set_op_profiling(self, on):
+        check(self._call(lib.ssdk_ctx_set_op_profiling, 1 if on else 0), "ctx_set_op_profiling")
+
+    def op_timings(self):
+        ms = (ctypes.c_float * 128)()
+        names = (ctypes.c_char_p * 128)()
+        n = self._call(lib.ssdk_ctx_get_op_timings, ms, names, 128)
+        if n < 0:
+            raise SsdkError(lib.ssdk_last_error().decode())
+        return [(names[i].decode() if names[i] else "", float(ms[i])) for i in range(n)]
+
+    def tail_stamps(self):
+        out = (ctypes.c_ulonglong * 48)()
+        check(self._call(lib.ssdk_ctx_get_tail_stamps, out, 48), "ctx_get_tail_stamps")
+        return [int(out[i]) for i in range(48)]
+
+
 def op_timings():
-    """[(kernel name, ms)] of the most recent ssdk_run_ops call made while op profiling was on (stream synchronised)."""
+    """[(kernel name, ms)] of the most recent ssdk_run_ops call made while op profiling was on (stream synchronised);
+    the calling thread's default context (plans own their context: ``ConvPlan.ctx.op_timings()``)."""
     ms = (ctypes.c_float * 128)()
     names = (ctypes.c_char_p * 128)()
     n = lib.ssdk_get_op_timings(ms, names, 128)
@@ -273,8 +350,8 @@ def set_profiling(on):
 
 
 def timings_ms(back=0):
-    """(scan_kernel, level_kernel, nms_kernel) milliseconds of the profiled decode_nms call `back` calls
-    before the most recent one."""
+    """(scan_kernel, tail_kernel | level_kernel, nms_kernel | 0) milliseconds of the profiled decode_nms call `back`
+    calls before the most recent one (the calling thread's default context; a ``Decoder`` owns its own)."""
     ms = (ctypes.c_float * 3)()
     check(lib.ssdk_get_timings(int(back), ms, 3), "get_timings")
     return float(ms[0]), float(ms[1]), float(ms[2])

@@ -226,8 +226,22 @@ def nms(all_scores, all_boxes, all_classes, nms=0.5, ndetections=100, using_diou
     return os_, ob, oc
 
 
+_default_ctx = {}
+
+
+def _ctx_for(device):
+    """Module-level fallback context per (thread, device) for callers that use ``decode_nms`` without a ``Decoder``."""
+    import threading
+
+    key = (threading.get_ident(), device.index)
+    c = _default_ctx.get(key)
+    if c is None:
+        c = _default_ctx[key] = N.Context(device)
+    return c
+
+
 def decode_nms(loc, conf, anchors, threshold, top_n_per_level, rescore, nms_threshold, ndetections,
-               using_diou, return_mid=False, tail=None):
+               using_diou, return_mid=False, tail=None, ctx=None):
     """Decoder.__call__ of the reference (decoder.py:25-49) as one C-ABI call: decode of every level
     (one scan launch + one per-level launch) and NMS, nothing returns to the host in between.
 
@@ -260,6 +274,10 @@ def decode_nms(loc, conf, anchors, threshold, top_n_per_level, rescore, nms_thre
             mid = (torch.empty((B, L * K), device=dev, dtype=torch.float32),
                    torch.empty((B, L * K, 4), device=dev, dtype=torch.float32),
                    torch.empty((B, L * K), device=dev, dtype=torch.float32))
+    if ctx is None:
+        ctx = _ctx_for(dev)
+    if ctx.device != dev:
+        raise N.SsdkError("decode_nms: the context belongs to {}, the heads live on {}".format(ctx.device, dev))
     with torch.cuda.device(dev):
         need = N.lib.ssdk_decode_nms_workspace_bytes(levels, L, B, dt, K, nd)
         if need == 0:
@@ -268,18 +286,14 @@ def decode_nms(loc, conf, anchors, threshold, top_n_per_level, rescore, nms_thre
             ws = N.workspace(dev, need + 256)
         else:
             ws = tail.acquire(dev, need + 256)  # the current stream now waits for the tail work that last used it
-            N.lib.ssdk_set_decode_tail_stream(ctypes.c_void_p(tail.stream.cuda_stream))
+        ctx.set_tail_stream(tail.stream if tail is not None else None)
         wptr = (ws.data_ptr() + 255) & ~255
-        try:
-            rc = N.lib.ssdk_decode_nms(
-                levels, L, B, dt, float(threshold), K, int(bool(rescore)), float(nms_threshold), nd,
-                int(bool(using_diou)), os_.data_ptr(), ob.data_ptr(), oc.data_ptr(),
-                mid[0].data_ptr() if return_mid else None, mid[1].data_ptr() if return_mid else None,
-                mid[2].data_ptr() if return_mid else None, wptr, ws.numel() - (wptr - ws.data_ptr()),
-                N.stream_ptr(dev))
-        finally:
-            if tail is not None:
-                N.lib.ssdk_set_decode_tail_stream(None)
+        rc = N.lib.ssdk_decode_nms_ctx(
+            ctx.ptr, levels, L, B, dt, float(threshold), K, int(bool(rescore)), float(nms_threshold), nd,
+            int(bool(using_diou)), os_.data_ptr(), ob.data_ptr(), oc.data_ptr(),
+            mid[0].data_ptr() if return_mid else None, mid[1].data_ptr() if return_mid else None,
+            mid[2].data_ptr() if return_mid else None, wptr, ws.numel() - (wptr - ws.data_ptr()),
+            N.stream_ptr(dev))
         if tail is not None and rc == 0:
             for c, l in heads:  # read by kernels on the tail stream: not to be recycled before those have run
                 c.record_stream(tail.stream)

@@ -1,5 +1,7 @@
 """``Decoder`` -- same constructor/attributes/call contract as the reference's
 ``ssds/modeling/layers/decoder.py:15-49``; the body is one fused C-ABI call (``ssdk_decode_nms``)."""
+from ssds import _native as N
+
 from .box import _TailPipe, decode_nms
 
 
@@ -18,6 +20,27 @@ class Decoder(object):
         self.rescore = rescore
         self.use_diou = use_diou
         self._tail = None
+        self._ctx = {}  # device index -> N.Context: this decoder's HIP objects (never shared with another decoder)
+        self._prof = False
+
+    def context(self, device):
+        """The ``ssdk_ctx`` this decoder uses on ``device`` (created on first use)."""
+        c = self._ctx.get(device.index)
+        if c is None:
+            c = self._ctx[device.index] = N.Context(device)
+            if self._prof:
+                c.set_profiling(True)
+        return c
+
+    def set_profiling(self, on):
+        """Record hipEvents around the stage's launches (read back with ``timings_ms``; bench.py)."""
+        self._prof = bool(on)
+        for c in self._ctx.values():
+            c.set_profiling(self._prof)
+
+    def timings_ms(self, back=0, device=None):
+        c = next(iter(self._ctx.values())) if device is None else self._ctx[device.index]
+        return c.timings_ms(back)
 
     def enable_tail_stream(self, stream=None):
         """Serving-loop mode: the latency-bound end of the stage (per-level merge/sort/decode and NMS, 64-384
@@ -44,5 +67,5 @@ class Decoder(object):
         """
         return decode_nms(
             loc, conf, anchors, self.conf_threshold, self.top_n_per_level, self.rescore,
-            self.nms_threshold, self.top_n, self.use_diou, tail=self._tail,
+            self.nms_threshold, self.top_n, self.use_diou, tail=self._tail, ctx=self.context(conf[0].device),
         )

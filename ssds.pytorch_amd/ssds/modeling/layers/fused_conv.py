@@ -413,8 +413,15 @@ class ConvPlan(object):
         self.ops = None
         self.report = []
         self.in_shape = tuple(in_shape) if in_shape is not None else None
+        self._ctx = None  # this plan's side stream / events / op-profiling ring (include/ssdk.h "Contexts"): lazy
         if in_shape is not None:
             self.add_input(in_shape)
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = N.Context(self.device)
+        return self._ctx
 
     def add_input(self, shape):
         """Declare an external [N,C,H,W] input (channels_last memory at run time); returns its value."""
@@ -684,9 +691,10 @@ class ConvPlan(object):
         with torch.cuda.device(self.device):
             if self.ws is not None:
                 wptr = (self.ws.data_ptr() + 255) & ~255
-                rc = N.lib.ssdk_run_ops(ops, hi - lo, wptr, self.ws.numel() - (wptr - self.ws.data_ptr()), sp)
+                rc = N.lib.ssdk_run_ops_ctx(self.ctx.ptr, ops, hi - lo, wptr,
+                                            self.ws.numel() - (wptr - self.ws.data_ptr()), sp)
             else:
-                rc = N.lib.ssdk_run_ops(ops, hi - lo, None, 0, sp)
+                rc = N.lib.ssdk_run_ops_ctx(self.ctx.ptr, ops, hi - lo, None, 0, sp)
         N.check(rc, "run_ops")
         STATS["native_layers"] += hi - lo
 

@@ -23,22 +23,41 @@ loc = [torch.randn(B, A * 4, h, h, device="cuda").mul(0.1).to(torch.bfloat16) fo
 nbytes = sum(B * A * C * h * h * 2 for h in sizes)
 
 
+ctx = N.Context(torch.device("cuda", 0))
+STAGE_BYTES = nbytes + sum(B * A * 4 * h * h * 2 for h in sizes) + B * (2 * 24 * 6 * 300 + 24 * 100)
+
+
 def run(name, make, thr=0.01, reps=20):
     conf = [make(B, A * C, h, h).to(torch.bfloat16) for h in sizes]
     for _ in range(3):
-        box.decode_nms(loc, conf, anchors, thr, 300, True, 0.6, 100, True)
-    N.set_profiling(True)
+        box.decode_nms(loc, conf, anchors, thr, 300, True, 0.6, 100, True, ctx=ctx)
+    ctx.set_profiling(True)
     for _ in range(reps):
-        box.decode_nms(loc, conf, anchors, thr, 300, True, 0.6, 100, True)
+        box.decode_nms(loc, conf, anchors, thr, 300, True, 0.6, 100, True, ctx=ctx)
     torch.cuda.synchronize()
-    t = [N.timings_ms(i) for i in range(reps)]
-    N.set_profiling(False)
+    t = [ctx.timings_ms(i) for i in range(reps)]
+    ctx.set_profiling(False)
     scan = sum(x[0] for x in t) / reps
     lvl = sum(x[1] for x in t) / reps
     nms = sum(x[2] for x in t) / reps
-    print("%-28s scan %6.1f us (%5.2f TB/s)  level %5.1f us  nms %5.1f us" % (name, scan * 1e3, nbytes / scan / 1e9, lvl * 1e3, nms * 1e3), flush=True)
+    tot = scan + lvl + nms
+    extra = ""
+    if os.environ.get("SSDK_TAIL_STAMPS") and os.environ.get("SSDK_DECODE_FUSED", "1") != "0":
+        st = ctx.tail_stamps()
+        extra = "\n      tail phases (kcycles): " + " ".join("%.1f" % ((b - a) / 1e3) for a, b in zip(st[:6], st[1:6]))
+        extra += "  [C: presort-wait %.1f sort %.1f barrier %.1f bound %.1f rank %.1f | B1 %.1f B1wait %.1f]" % tuple(
+            (b - a) / 1e3 for a, b in ((st[2], st[16]), (st[16], st[17]), (st[17], st[18]), (st[18], st[19]), (st[19], st[20]),
+                                       (st[1], st[21]), (st[21], st[22])))
+        sc = st[24:]
+        extra += "\n      scan wg0 (kcycles): " + " ".join("%.1f" % ((b - a) / 1e3) for a, b in zip(sc[0:5], sc[1:5]))
+        extra += "  fast=%d winners=%d  [H: sample %.1f sort %.1f rank %.1f rest %.1f]" % (
+            sc[5] >> 32, sc[5] & 0xffffffff, (sc[8] - sc[0]) / 1e3, (sc[9] - sc[8]) / 1e3, (sc[10] - sc[9]) / 1e3, (sc[1] - sc[10]) / 1e3)
+    print("%-28s scan %6.1f us (%5.2f TB/s)  tail|level %5.1f us  nms %5.1f us  stage %6.1f us = %.3f of 8 TB/s%s" % (
+        name, scan * 1e3, nbytes / scan / 1e9, lvl * 1e3, nms * 1e3, tot * 1e3, STAGE_BYTES / tot / 1e9 / 8000, extra),
+        flush=True)
 
 
+run("SURVEY 8d heads sigmoid(N(-4.6,1.5))", lambda *s: torch.sigmoid(torch.randn(*s, device="cuda") * 1.5 - 4.6))
 run("all equal (focal prior)", lambda *s: torch.full(s, 0.01, device="cuda"))
 run("uniform, half above thr", lambda *s: torch.rand(*s, device="cuda") * 0.02)
 run("sparse, 0.1% above thr", lambda *s: torch.rand(*s, device="cuda") * 0.01001)
