@@ -531,3 +531,92 @@ def test_full_size_fpn_bifpn_shapes_properties_and_sampled_oracle(shape, dtype):
         np.testing.assert_array_equal(cn[img:img + 1], w[2])
         np.testing.assert_allclose(bn[img:img + 1], w[1], atol=BOX_ATOL, rtol=0)
         np.testing.assert_allclose(sn[img:img + 1], w[0], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("kind", ["constant", "ramp_up", "quantized", "sparse", "logit"])
+@pytest.mark.parametrize("tpu", ["1", "4", "0"])
+def test_decoder_every_path_agrees_with_the_oracle(kind, tpu, monkeypatch):
+    """Decoder.__call__ through each way the stage can run -- fused tail kernel (default) vs level_kernel + nms_kernel
+    (SSDK_DECODE_FUSED=0), seeded barrier-free scan (default) vs the TopK stream only (SSDK_SCAN_FAST=0) -- on inputs
+    full of ties, with many scan units per level (SSDK_TILES_PER_UNIT=1/4: the tail merges up to 32 sorted lists):
+    every path equals the oracle (final and per-level outputs), hence each other, bit for bit in classes / order."""
+    import torch
+    from ssds.modeling.layers.box import decode_nms
+
+    A, C = 3, 20
+    maps, strides = [(24, 28), (12, 14), (6, 7), (3, 4)], [8, 16, 32, 64]
+    rs = np.random.RandomState(11)
+    conf, loc = [], []
+    for li, (h, w) in enumerate(maps):
+        if kind == "logit":
+            c = cases.sigmoid(rs.standard_normal((2, A * C, h, w)).astype(F32) * F32(1.5) - F32(4.6))
+            l = (rs.standard_normal((2, A * 4, h, w)) * 0.5).astype(F32)
+        else:
+            c, l = _tie_case(kind, 2, A, C, h, w, 20 + li)
+        conf.append(torch.from_numpy(c).to(torch.bfloat16))
+        loc.append(torch.from_numpy(l).to(torch.bfloat16))
+    anchors = OrderedDict((s, torch.from_numpy(O.generate_anchors(s, [1, 2, 0.5], [2.0]))) for s in strides)
+    oanch = OrderedDict((k, v.numpy()) for k, v in anchors.items())
+    args = (0.05, 100, True, 0.5, 60, True)
+    odec = O.Decoder(args[0], args[3], args[4], args[1], args[2], args[5])
+    ol, oc = [t.float().numpy() for t in loc], [t.float().numpy() for t in conf]
+    wmid = odec.decode_levels(ol, oc, oanch)
+    want = odec(ol, oc, oanch)
+    monkeypatch.setenv("SSDK_TILES_PER_UNIT", tpu)
+    dl, dc = [t.cuda() for t in loc], [t.cuda() for t in conf]
+    for env in ({}, {"SSDK_DECODE_FUSED": "0"}, {"SSDK_SCAN_FAST": "0"}, {"SSDK_DECODE_FUSED": "0", "SSDK_SCAN_FAST": "0"}):
+        for k in ("SSDK_DECODE_FUSED", "SSDK_SCAN_FAST"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        (s, b, c), mid = decode_nms(dl, dc, anchors, *args, return_mid=True)
+        what = "%s tpu=%s %s" % (kind, tpu, env)
+        np.testing.assert_array_equal(mid[2].cpu().numpy(), wmid[2], err_msg=what + " mid classes")
+        np.testing.assert_allclose(mid[1].cpu().numpy(), wmid[1], atol=BOX_ATOL, rtol=0, err_msg=what + " mid boxes")
+        np.testing.assert_allclose(mid[0].cpu().numpy(), wmid[0], atol=1e-4, rtol=1e-4, equal_nan=True,
+                                   err_msg=what + " mid scores")
+        np.testing.assert_array_equal(c.cpu().numpy(), want[2], err_msg=what + " classes")
+        np.testing.assert_allclose(b.cpu().numpy(), want[1], atol=BOX_ATOL, rtol=0, err_msg=what + " boxes")
+        np.testing.assert_allclose(s.cpu().numpy(), want[0], atol=1e-4, rtol=1e-4, err_msg=what + " scores")
+
+
+def test_two_threads_two_decoders_share_nothing():
+    """SURVEY 8b "re-entrant": two host threads, each with its own Decoder (= its own ssdk_ctx: events, profiling ring,
+    tail-stream state) on its own stream, decode different batches concurrently; both equal their serial results."""
+    import threading
+
+    import torch
+    from ssds.modeling.layers.decoder import Decoder
+
+    A, C = 6, 20
+    maps, strides = [16, 8, 4], [16, 32, 64]
+    anchors = OrderedDict((s, torch.from_numpy(O.generate_anchors(s, [1, 2, 0.5], [2.0, 2.828]))) for s in strides)
+    data = []
+    for seed in (1, 2):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        conf = [torch.sigmoid(torch.randn(8, A * C, m, m, device="cuda", generator=g) * 1.5 - 3.0).to(torch.bfloat16) for m in maps]
+        loc = [(torch.randn(8, A * 4, m, m, device="cuda", generator=g) * 0.5).to(torch.bfloat16) for m in maps]
+        data.append((loc, conf))
+    want = [tuple(t.clone() for t in Decoder(0.05, 0.5, 50, 200, True, True)(l, c, anchors)) for l, c in data]
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(i):
+        try:
+            dec = Decoder(0.05, 0.5, 50, 200, True, True)
+            dec.set_profiling(True)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(200):
+                    got = dec(data[i][0], data[i][1], anchors)
+            st.synchronize()
+            for a, b in zip(got, want[i]):
+                assert torch.equal(a, b)
+            assert dec.timings_ms(0)[0] > 0
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
