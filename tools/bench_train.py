@@ -1,6 +1,7 @@
 """Training-step throughput (BASELINE config 4: SSD+MobileNetV2@512 DDP step, synthetic COCO-shaped targets).
     python tools/bench_train.py --steps 10            (1 GPU)
-    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py
+    python tools/bench_train.py --gpus N              (re-executes itself under torch.distributed.run with N ranks)
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py --gpus N
 Prints one JSON line on rank 0 (images/sec of the full step: fwd, target assignment, loss, bwd, all-reduce,
 optimizer)."""
 import argparse
@@ -25,7 +26,18 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--channels-last", type=int, default=0)
+ap.add_argument("--gpus", type=int, default=1)
 args = ap.parse_args()
+if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: become N ranks on this node
+    import socket
+
+    _s = socket.socket()
+    _s.bind(("127.0.0.1", 0))
+    _port = _s.getsockname()[1]
+    _s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                              "--master-addr", "127.0.0.1", "--master-port", str(_port), os.path.abspath(__file__)] + sys.argv[1:])
 world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
 lr = int(os.environ.get("LOCAL_RANK", "0"))
