@@ -675,3 +675,20 @@ def test_tail_stream_decoder_under_forward_load():
             for g, w in zip(got, want):
                 for a, b in zip(g, w):
                     assert torch.equal(a, b)
+
+
+def test_soak_three_queues_against_in_line_with_poisoned_lds():
+    """>= 5000 batches through main lane + side lane + tail stream, LDS poisoned in front of every
+    kernel (SSDK_LDS_POISON=1 is read once per process, hence the subprocess), every batch equal to the in-line path."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSDK_LDS_POISON="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_multiqueue.py"), "--batches", "5000"], env=env,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["batches"] >= 5000 and rec["mismatching_batches"] == 0 and rec["lds_poison"] == "1", rec
