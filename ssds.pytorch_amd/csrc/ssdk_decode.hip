@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) 
   // score -- K scores at or above it have been seen -- and close to the K-th largest of the whole sample, since a lane
   // rarely owns more than two of the sample's top K.  Found without LDS atomics and without a sort (below).
   float cut0 = p.thr;
-  bool fast = false;
+  bool fast = false, tie_rich = false;
   if (p.fast && ntiles > 0 && K <= 2 * NT) {  // (a wave offers 128 values: kw = K / 4 of them must exist)
     if (tid == 0) {
       fc->overflow = 0;
@@ -383,6 +383,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) 
     constexpr u32 NWv = NT / 64;
     const unsigned long long gt_w = (unsigned long long)fc->cum * ntiles / ((unsigned long long)S * NWv);
     unsigned long long eq_w = (unsigned long long)(fc->nge - fc->cum) * ntiles / ((unsigned long long)S * NWv);
+    tie_rich = eq_w * NWv >= K;  // the unit is expected to hold K scores equal to the cut: see the tie prefix below
     eq_w = eq_w < K + 511u ? eq_w : K + 511u;
     fast = gt_w + eq_w <= (unsigned long long)(kWaveCap - kWaveCap / 8);
   }
@@ -404,6 +405,56 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) 
       const u32 vi = vec0 + (t < ntiles ? t : ntiles - 1u) * NT + tid;
       return abase + (size_t)(vi < vlast ? vi : vlast) * 16;
     };
+    if (tie_rich) {
+      // Tie prefix: when the unit is rich in scores equal to the cut (an all-equal image: every score), the per-wave
+      // budgets would still collect waves x (K + 511) ties, one histogram bin, and the final select would have to
+      // order them by index.  The first K ties of the UNIT in index order are found directly instead: tile by tile,
+      // the waves exchange their tie counts (one barrier pair per tile; K ties are reached within the first tiles),
+      // each wave keeps the ties whose position in the unit's tie order is below K, and the streaming pass then
+      // compares against the next float above the cut everywhere.
+      u32 need = K;
+      for (u32 t = 0; t < ntiles && need > 0u; ++t) {  // workgroup-uniform
+        const u32x4 v = load_vec(t);
+        const u32 idx0 = first_index(t);
+        u32 ge = 0, gt = 0;
+        fast_flags<DT, 0, true>(v, idx0, n, cut0, ge);
+        fast_flags<DT, 0, true>(v, idx0, n, next_up(cut0), gt);
+        const u32 em = ge & ~gt;  // elements equal to the cut
+        const u32 c = (u32)__popc(em);
+        u32 excl = 0, tot = 0;
+#pragma unroll
+        for (int bit = 0; bit < 4; ++bit) {
+          const u64 mb = __ballot((c >> bit) & 1u);
+          excl += mbcnt(mb) << bit;
+          tot += (u32)__popcll(mb) << bit;
+        }
+        if (lane == 0) fc->wcount[wave] = tot;
+        __syncthreads();
+        u32 before = 0, all = 0;
+#pragma unroll
+        for (u32 w = 0; w < NT / 64; ++w) {
+          const u32 cw = fc->wcount[w];
+          before += w < wave ? cw : 0u;
+          all += cw;
+        }
+        // this lane's ties sit at positions before + excl .. before + excl + c - 1 of the tile's ties (index order)
+        u32 left = em, pos = before + excl;
+        const u32 room = need > before ? need - before : 0u;
+        const u32 take_w = tot < room ? tot : room;  // ties this wave keeps (wave-uniform)
+        u32 at = wcnt + excl;
+        while (left) {
+          const u32 e = (u32)__ffs((int)left) - 1u;
+          left &= left - 1u;
+          if (pos < need) wbuf[at] = make_key(vec_elem_dyn<DT>(v, e), idx0 + e);
+          ++pos;
+          ++at;
+        }
+        wcnt += take_w;
+        need = need > all ? need - all : 0u;
+        __syncthreads();
+      }
+      ccut = next_up(cut0);  // the unit's ties are settled: the stream only looks for scores above the cut
+    }
     unsigned char* ring = stage + (size_t)wave * PF * 1024;
 #pragma unroll
     for (int i = 0; i < PF; ++i) ring_issue(addr(i), ring + i * 1024);
