@@ -62,6 +62,9 @@ def parse():
                     help="1: the tail kernel of the decode stage on its own stream (overlaps the next step's forward)")
     ap.add_argument("--layers", type=int, default=0, help="1: add the per-layer table (us, TFLOP/s, GB/s) to the JSON")
     ap.add_argument("--channels-last", type=int, default=int(os.environ.get("SSDK_CHANNELS_LAST", "0")))
+    ap.add_argument("--main-priority", type=int, default=0,
+                    help="-1: run the forward + scan on a high-priority stream (the overlapped tail kernel then only takes "
+                         "CUs the forward leaves idle)")
     return ap.parse_args()
 
 
@@ -172,6 +175,8 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize(dev)
 
+    main_stream = torch.cuda.Stream(device=dev, priority=-1) if args.main_priority < 0 else torch.cuda.current_stream(dev)
+    torch.cuda.set_stream(main_stream)
     for _ in range(args.warmup):
         step()
     decoder.set_profiling(not args.graph)  # event ring: recorded inside the timed region (not capturable: eager only)

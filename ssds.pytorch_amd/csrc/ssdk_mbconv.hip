@@ -45,6 +45,7 @@ struct MbParams {
   // stem mode: x is the [N,Cimg,Himg,Wimg] image (1 = NCHW, 2 = NHWC); the "expand" GEMM is the 3x3/s2 stem
   // conv on an im2col image of the tile built in LDS (K = 9*Cimg <= 32); H, W are the stem-output grid.
   int stem, Himg, Wimg, Cimg;
+  int lean;                  // 1: the two-workgroups-per-CU instance of a 16x16 tile (see mb_lean4)
   int hc;                    // hidden channels per chunk (32 | 64)
   int ts, tsw;               // output tile rows x columns: 8x8 | 16x16 | 8x16
   unsigned long long* dbg;  // SSDK_MB_DBG=1: cycle stamps of workgroup 0 (debug builds of the schedule only)
@@ -79,6 +80,14 @@ __device__ __forceinline__ u32 pk_relu6_f16(float a, float b) {  // clamp to [0,
                                                             __builtin_amdgcn_fmed3f(b, 0.f, 6.f)));
 }
 
+// Instances whose registers fit 128 per lane (almost) without spilling also exist compiled for 4 waves per SIMD (LEAN4),
+// i.e. TWO workgroups per CU; the host picks them wherever the LDS (<= 80 KB) allows two workgroups as well: the block kernels are latency-bound (LDS -> MFMA -> LDS chains
+// between barriers), and a second workgroup fills the issue slots the first one leaves idle.  Today: the 16x16 tiles
+// with one expand k-step and two projection n-frags (Cin <= 32, Cout <= 32; round 1 held 160-193 registers there:
+// one workgroup per CU although the LDS allowed two).
+constexpr bool mb_lean4(int ts, int tsw, int nfo, int ksmax, bool stem) {
+  return ts == 16 && tsw == 16 && nfo == 2 && (ksmax == 1 || stem);
+}
 constexpr int kMbThreads = 512;  // 8 waves: two per SIMD, so LDS / MFMA latencies of one wave hide under the other
 constexpr int kMbWaves = kMbThreads / 64;
 constexpr int MAX_KS = 5;    // Cin <= 160
@@ -90,8 +99,9 @@ constexpr int sb_of(int hc) { return hc * 10; }
 // E (expanded) and D (depthwise output) are INTERNAL tensors: they are kept in fp16 whatever the model
 // dtype (values are ReLU6-bounded, fp16 carries 3 more mantissa bits than bf16), so P2 runs on packed
 // fp16 math (v_pk_fma_f16: 2 channels per instruction) and P3 on the f16 MFMA with fp16 projection weights.
-template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = false, int HC = 32, int TS = 8, int TSW = TS>
-__global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
+template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = false, int HC = 32, int TS = 8, int TSW = TS,
+          bool LEAN4 = false>
+__global__ __launch_bounds__(kMbThreads, LEAN4 ? 4 : 2) void mbconv_kernel(const MbParams p) {
   constexpr int ES = es_of(HC);
   constexpr int NJ = HC / 16;   // n-frags of the expand GEMM per chunk
   constexpr int KP = HC / 32;   // k-steps of the projection per chunk
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
       load_w(c * HC);
       store_w(c);
     }
-    fetch_x(tile);
+    if constexpr (!LEAN4) fetch_x(tile);
   } else {
     load_w(0);
     fetch_x(tile);
@@ -302,9 +312,13 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   // P3 role: 8x8 tiles: pixel frag wave & 3, interleaved half (wave >> 2) of the n-frags; 16x16: frags 2*wave, 2*wave+1, all n
   const u32 m_base = NSPLIT == 2 ? (wave & 3u) : wave * (u32)MPW, n_half = NSPLIT == 2 ? (wave >> 2) : 0u;
 
-  f32x4 sp4[NFH], bp4[NFH];  // projection BN (loop invariant: loaded once per workgroup)
+  // projection BN: loop invariant, kept in registers for the whole workgroup -- except in the lean instances (two
+  // workgroups per CU), which re-load it in the epilogue: 8 NFH registers less
+  static_assert(!LEAN4 || mb_lean4(TS, TSW, NFO, KSMAX, STEM), "lean instance");
+  constexpr bool LEAN = LEAN4;
+  f32x4 sp4[LEAN ? 1 : NFH], bp4[LEAN ? 1 : NFH];
 #pragma unroll
-  for (int jj = 0; jj < NFH; ++jj) {
+  for (int jj = 0; jj < (LEAN ? 0 : NFH); ++jj) {
     const int co = ((int)n_half + NSPLIT * jj) * 16 + (int)fg * 4;
     sp4[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
     bp4[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -325,8 +339,13 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
   ix0 = ox0 * S - 1;
   if constexpr (RESIDENT) {
     __syncthreads();  // previous tile: every wave is done with sX (residual reads) and sE/sD
-    put_x();
-    if (tile + gridDim.x < ntiles) fetch_x(tile + gridDim.x);  // next tile's input in flight under this tile
+    if constexpr (LEAN4) {
+      fetch_x(tile);  // lean instances: no register-held prefetch; the co-resident workgroup covers the latency
+      put_x();
+    } else {
+      put_x();
+      if (tile + gridDim.x < ntiles) fetch_x(tile + gridDim.x);  // next tile's input in flight under this tile
+    }
   }
   // validity of the region pixels this lane produces in P1 (bit i: m-frag wave + 8*i)
   u32 pvalid = 0;
@@ -358,7 +377,7 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
         sev[jf] = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + (jf * 16 + fg * 4) * 4);
         bev[jf] = *reinterpret_cast<const f32x4*>(wcur + p.off_sb + HC * 4 + (jf * 16 + fg * 4) * 4);
       }
-      if constexpr (TS == 16 || TSW == 16) {  // (measured: the same restructuring LOSES on the 8x8 stride-2 instances -- VGPRs / occupancy)
+      if constexpr ((TS == 16 || TSW == 16) && !LEAN4) {  // (measured: the same restructuring LOSES on the 8x8 stride-2 instances -- VGPRs / occupancy)
         // 16x16 tiles: 3 m-frags per wave.  Weight fragments are shared by them and loaded once; all operand reads
         // are issued before the first MFMA and all results are written after the last one, so the three dependent
         // LDS -> MFMA -> LDS chains overlap instead of running back to back.
@@ -590,8 +609,16 @@ __global__ __launch_bounds__(kMbThreads) void mbconv_kernel(const MbParams p) {
         const int co = ((int)n_half + NSPLIT * jj) * 16 + (int)fg * 4;
         if (co < Cout) {  // Cout is a multiple of 8, so 4-channel groups are all-or-nothing
           u32 h[4];
+          f32x4 spv, bpv;
+          if constexpr (LEAN) {
+            spv = *reinterpret_cast<const f32x4*>(p.sp + co);
+            bpv = *reinterpret_cast<const f32x4*>(p.bp + co);
+          } else {
+            spv = sp4[jj];
+            bpv = bp4[jj];
+          }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = mb_to16<DT>(fmaf(yacc[mi][jj][r], sp4[jj][r], bp4[jj][r]));
+          for (int r = 0; r < 4; ++r) h[r] = mb_to16<DT>(fmaf(yacc[mi][jj][r], spv[r], bpv[r]));
           if (p.residual) {
             const uint2 xv = *reinterpret_cast<const uint2*>(xres + co * 2);
             const u32 xr[4] = {xv.x & 0xffffu, xv.x >> 16, xv.y & 0xffffu, xv.y >> 16};
@@ -612,6 +639,15 @@ template <int DT, int S, int NFO, int KSMAX, bool STEM = false, bool RESIDENT = 
 static void launch_one(const MbParams& p, size_t lds, unsigned grid, hipStream_t stream) {
   if constexpr (S == 1 && KSMAX <= 3 && NFO <= 6) {  // the instantiations that exist with 16x16 tiles
     if (p.ts == 16) {
+      if constexpr (mb_lean4(16, 16, NFO, KSMAX, STEM)) {
+        if (p.lean) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 32, 16, 16, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipLaunchKernelGGL((mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 32, 16, 16, true>), dim3(grid), dim3(kMbThreads), lds,
+                             stream, p);
+          return;
+        }
+      }
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 32, 16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL((mbconv_kernel<DT, S, NFO, KSMAX, STEM, RESIDENT, 32, 16>), dim3(grid), dim3(kMbThreads), lds, stream, p);
@@ -649,12 +685,13 @@ static int launch_mb(const MbParams& p, int ks, int nfo, size_t lds, unsigned gr
       if (nfo <= 2) launch_one<DT, S, 2, 3, true>(p, lds, grid, stream);
       else launch_one<DT, S, 4, 3, true>(p, lds, grid, stream);
     }
-    return check_launch(p.ts == 16 ? "mbconv_kernel(stem, 16x16)" : "mbconv_kernel(stem)");
+    return check_launch(p.ts == 16 ? (p.lean ? "mbconv_kernel(stem, 16x16, 2 per CU)" : "mbconv_kernel(stem, 16x16)") : "mbconv_kernel(stem)");
   }
   if (resident && ks <= 1 && nfo <= 4) {  // small-channel, high-resolution blocks: persistent grid, resident weights
     if (nfo <= 2) launch_one<DT, S, 2, 1, false, true>(p, lds, grid, stream);
     else launch_one<DT, S, 4, 1, false, true>(p, lds, grid, stream);
-    return check_launch(p.ts == 16 ? "mbconv_kernel(resident, 16x16)" : p.tsw == 16 ? "mbconv_kernel(resident, 8x16)" : "mbconv_kernel(resident)");
+    return check_launch(p.ts == 16 ? (p.lean ? "mbconv_kernel(resident, 16x16, 2 per CU)" : "mbconv_kernel(resident, 16x16)")
+                                   : p.tsw == 16 ? "mbconv_kernel(resident, 8x16)" : "mbconv_kernel(resident)");
   }
   if (ks <= 1 && nfo <= 2) launch_one<DT, S, 2, 1>(p, lds, grid, stream);
   else if (ks <= 1 && nfo <= 4) launch_one<DT, S, 4, 1>(p, lds, grid, stream);
@@ -664,7 +701,7 @@ static int launch_mb(const MbParams& p, int ks, int nfo, size_t lds, unsigned gr
   else if (ks <= 3 && nfo <= 10) launch_one<DT, S, 10, 3>(p, lds, grid, stream);
   else if (nfo <= 10) launch_one<DT, S, 10, 5>(p, lds, grid, stream);
   else launch_one<DT, S, 20, 5>(p, lds, grid, stream);
-  return check_launch(p.ts == 16 ? "mbconv_kernel(16x16)" : p.tsw == 16 ? "mbconv_kernel(8x16)" : "mbconv_kernel");
+  return check_launch(p.ts == 16 ? (p.lean ? "mbconv_kernel(16x16, 2 per CU)" : "mbconv_kernel(16x16)") : p.tsw == 16 ? "mbconv_kernel(8x16)" : "mbconv_kernel");
 }
 
 }  // namespace ssdk
@@ -796,6 +833,11 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   if (lds > 160 * 1024) {
     set_error("mbconv: tile needs %zu bytes of LDS", lds);
     return SSDK_E_BADARG;
+  }
+  {  // two workgroups per CU need both halves of the CU: LDS here, registers through the LEAN4 instance
+    static const int env_lean = getenv("SSDK_MB_LEAN") ? atoi(getenv("SSDK_MB_LEAN")) : 1;
+    const long tiles = (long)d->N * p.tiles_x * p.tiles_y;
+    p.lean = (env_lean && p.ts == 16 && p.tsw == 16 && lds <= 80 * 1024 && tiles >= 512) ? 1 : 0;
   }
   p.dbg = nullptr;
   static const int env_dbg = getenv("SSDK_MB_DBG") ? atoi(getenv("SSDK_MB_DBG")) : 0;
