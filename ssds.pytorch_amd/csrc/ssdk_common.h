@@ -82,13 +82,11 @@ __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int d) {
   return ((u64)hi << 32) | lo;
 }
 
-// torch.min / torch.max semantics (NaN propagates) -- fminf/fmaxf would drop the NaN
-// NaN-propagating min / max (torch.min / torch.max / clamp semantics) WITHOUT a compare-and-select: v_min / v_max
-// (which drop a NaN operand) plus a NaN mask built from integer arithmetic.  The obvious form
-// `(a != a) ? a : (b != b) ? b : (a < b ? a : b)` compiles to v_cmp ... v_cndmask through VCC, and on this stack a
-// select was observed to read a stale quarter of VCC (lanes 48-63) when waves of other queues share the SIMD
-// (1 % of the batches of a two-stream pipeline, 0 of 2 700 with this form).  The subtraction is opaque
-// to the optimiser on purpose: LLVM would otherwise turn the sign test back into a compare.
+// NaN-propagating min / max (torch.min / torch.max / clamp semantics; fminf/fmaxf would drop the NaN): v_min / v_max
+// plus a NaN mask built from integer arithmetic, no compare-and-select.  The subtraction is opaque to the optimiser on
+// purpose: LLVM would otherwise turn the sign test back into a compare.  (Round 1 introduced this form on the theory
+// that a v_cndmask read a stale VCC under multi-queue load; tools/repro/vcc_select_repro.hip does not reproduce that
+// -- 0 wrong lanes of 1.3e9 -- and DESIGN.md 8.4 retracts it.  The form stays because it is branch- and VCC-free.)
 __device__ __forceinline__ u32 nan_or_mask(float a, float b) {  // 0x7fc00000 when a or b is NaN, else 0
   const u32 ba = __builtin_bit_cast(u32, a) & 0x7fffffffu, bb = __builtin_bit_cast(u32, b) & 0x7fffffffu;
   u32 ta, tb;
