@@ -307,8 +307,15 @@ __global__ __launch_bounds__(kMbThreads, LEAN4 ? 4 : 2) void mbconv_kernel(const
     put_x();
     store_w(0);
   }
-  const u32 d_px = tid >> 3, d_cg = tid & 7u;      // P2 role: output pixel, 4-channel group
-  const u32 d_oy = d_px >> 3, d_ox = d_px & 7u;
+  // P2 role: output pixel, 4-channel group.  ds_read_b64 is serviced 32 lanes at a time over 64 banks = 4 pixels x 8
+  // channel groups (64 B each); a pixel row is ES = 20 | 36 banks, so four NEIGHBOURING pixels wrap onto each other
+  // (2-way conflict on every tap: SQ_LDS_BANK_CONFLICT was 22 % of the 8x8 instances' time).  A half-wave therefore
+  // takes every SECOND pixel -- of a column in the 8x8 tile (pitch 2 rows = 16 banks mod 64 for both strides and both
+  // chunk widths), of a row in the 8x16 tile (stride 2: pitch 4 pixels = 16 banks) -- and its four 16-bank windows tile
+  // the 64 banks exactly.
+  const u32 d_cg = tid & 7u, d_sub = 2u * ((lane >> 3) & 3u) + (lane >> 5);
+  const u32 d_oy = TSW == 8 ? d_sub : wave, d_ox = TSW == 8 ? wave : d_sub;
+  const u32 d_px = TSW == 8 ? d_oy * 8u + d_ox : 8u * wave + d_sub;
   // P3 role: 8x8 tiles: pixel frag wave & 3, interleaved half (wave >> 2) of the n-frags; 16x16: frags 2*wave, 2*wave+1, all n
   const u32 m_base = NSPLIT == 2 ? (wave & 3u) : wave * (u32)MPW, n_half = NSPLIT == 2 ? (wave >> 2) : 0u;
 
