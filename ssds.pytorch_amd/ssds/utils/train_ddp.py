@@ -40,6 +40,10 @@ class Solver(object):
             from ssds.modeling.layers.batchnorm import use_fast_batchnorm
 
             use_fast_batchnorm(self.model)  # training BN on the ssdk kernels (local statistics, like the default)
+        if os.environ.get("SSDK_PW_GEMM", "1") != "0":
+            from ssds.modeling.layers.pointwise import use_pointwise_gemm
+
+            use_pointwise_gemm(self.model)  # 1x1 convolutions as batched GEMMs on the NCHW tensors (no layout changes)
         self.model.to(self.device)
         if render and local_rank == 0:
             print("Model architectures:\n{}\n".format(self.model))

@@ -140,6 +140,52 @@ def test_batchnorm_training_kernels_match_torch(n, c, h, w, dtype_name, tol):
     close(fast(x), ref(x.float()), "eval path is nn.BatchNorm2d")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype_name,tol", [("float32", 2e-4), ("bfloat16", 2e-2), ("float16", 4e-3)])
+@pytest.mark.parametrize("n,cin,cout,h,w,bias", [(4, 16, 96, 16, 24, False), (3, 24, 144, 9, 7, True), (64, 160, 960, 16, 16, False),
+                                                 (2, 320, 256, 5, 5, True)])
+def test_pointwise_gemm_conv_matches_torch(n, cin, cout, h, w, bias, dtype_name, tol):
+    """forward and all three gradients of the GEMM-backed 1x1 convolution vs nn.Conv2d in fp32 (operands rounded alike)."""
+    import torch
+    import torch.nn as nn
+    from ssds.modeling.layers.pointwise import PointwiseConv2d
+
+    dtype = getattr(torch, dtype_name)
+    torch.manual_seed(n + cin + cout)
+    pw = PointwiseConv2d(cin, cout, 1, bias=bias).cuda().to(dtype)
+    ref = nn.Conv2d(cin, cout, 1, bias=bias).cuda()
+    ref.load_state_dict({k: v.float() for k, v in pw.state_dict().items()})
+    x = torch.randn(n, cin, h, w, device="cuda").to(dtype)
+    xr = x.detach().float().clone().requires_grad_(True)
+    xp = x.detach().clone().requires_grad_(True)
+    yr = ref(xr)
+    g = torch.randn_like(yr).to(dtype)
+    yr.backward(g.float())
+    yp = pw(xp)
+    assert yp.dtype == dtype and yp.shape == yr.shape and yp.is_contiguous()
+    yp.backward(g)
+
+    def close(a, b, what):
+        err = float((a.float() - b.float()).abs().max()) / max(float(b.abs().max()), 1e-6)
+        assert err < tol, "%s: rel err %.3g" % (what, err)
+
+    close(yp, yr, "output")
+    close(xp.grad, xr.grad, "dx")
+    close(pw.weight.grad, ref.weight.grad, "dweight")
+    if bias:
+        close(pw.bias.grad, ref.bias.grad, "dbias")
+    # under autocast the module computes in the autocast dtype from fp32 parameters, like nn.Conv2d
+    pw32 = PointwiseConv2d(cin, cout, 1, bias=bias).cuda()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ya = pw32(x.float())
+    assert ya.dtype == torch.bfloat16
+    ya.float().sum().backward()
+    assert pw32.weight.grad.dtype == torch.float32
+    # channels-last input: nn.Conv2d.forward
+    ycl = pw(x.contiguous(memory_format=torch.channels_last))
+    close(ycl, yr, "channels-last fallback")
+
+
 @pytest.mark.parametrize("mode,dtype_name,gamma,loc_loss", [
     ("iou", "float32", 2.0, "smoothl1"), ("iou", "bfloat16", 2.0, "smoothl1"), ("iou_radius", "float32", 1.5, "smoothl1"),
     ("scale", "float32", 2.0, "smoothl1"), ("scale_center", "float16", 2.0, "smoothl1"),

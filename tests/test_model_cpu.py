@@ -314,3 +314,21 @@ def test_checkpoint_written_by_the_reference_loads_here():
     for k, v in part.state_dict().items():
         same_as_ckpt = torch.equal(v, model.state_dict()[k])
         assert same_as_ckpt if k.startswith(("loc.", "conf.")) else torch.equal(v, before[k]), k
+
+
+def test_pointwise_gemm_switch_keeps_state_dict_and_cpu_behaviour():
+    """use_pointwise_gemm re-classes dense 1x1 / stride-1 convolutions only; on CPU they are nn.Conv2d."""
+    import torch
+    import torch.nn as nn
+    from ssds.modeling.layers.pointwise import PointwiseConv2d, use_pointwise_gemm
+
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(8, 16, 1, bias=False), nn.BatchNorm2d(16), nn.Conv2d(16, 16, 3, padding=1, groups=16),
+                        nn.Conv2d(16, 8, 1, stride=2), nn.Conv2d(8, 4, 1))
+    keys = list(net.state_dict().keys())
+    x = torch.randn(2, 8, 6, 6)
+    y0 = net(x)
+    use_pointwise_gemm(net)
+    assert [type(m) is PointwiseConv2d for m in net] == [True, False, False, False, True]
+    assert list(net.state_dict().keys()) == keys
+    assert torch.equal(net(x), y0)

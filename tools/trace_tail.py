@@ -12,6 +12,6 @@ for r in rows:
         acc[k][0] += 1
         acc[k][1] += (e - s) / 1e3
         tot += (e - s) / 1e3
-for k, (n, us) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:18]:
+for k, (n, us) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:45]:
     print("%8.1f us %5.1f%% x%-4d %s" % (us, 100 * us / tot, n, k))
 print("kernel time in window: %.1f ms" % (tot / 1e3))
