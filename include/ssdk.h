@@ -346,6 +346,19 @@ int ssdk_bn_train_bwd(const void* x, const void* dy, const float* weight, const 
                       void* dx, float* dweight, float* dbias, void* workspace, size_t workspace_bytes, int N, int C,
                       int HW, int dtype, void* stream);
 
+/* The same with the activation that follows the BatchNorm in every Conv-BN-ReLU6 block of the backbone
+ * (nets/mobilenet.py:24-33; basic_layers.py:5-57) folded in: act = 0 none | 1 ReLU6 | 2 ReLU.
+ *   fwd: y = act(bn(x));  bwd: dy is the gradient w.r.t. act(bn(x)) -- it is masked where the pre-activation value (as
+ *        the forward pass rounded it to `dtype`) lies outside the open pass-through interval, exactly what
+ *        hardtanh_backward / threshold_backward do on the stored tensor; nothing extra is saved.  `bias` is needed
+ *        by the backward pass to rebuild the pre-activation. */
+int ssdk_bn_act_train_fwd(const void* x, const float* weight, const float* bias, float* running_mean, float* running_var,
+                          void* y, float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, int N,
+                          int C, int HW, float momentum, float eps, int act, int dtype, void* stream);
+int ssdk_bn_act_train_bwd(const void* x, const void* dy, const float* weight, const float* bias, const float* save_mean,
+                          const float* save_invstd, void* dx, float* dweight, float* dbias, void* workspace,
+                          size_t workspace_bytes, int N, int C, int HW, int act, int dtype, void* stream);
+
 /* ResNet stem (nets/resnet.py:41-46): 7x7 / stride 2 / pad 3 convolution on the 3-channel image + folded BN +
  * activation -> NHWC, and the 3x3 / stride 2 / pad 1 max pooling (NHWC -> NHWC, -inf padding like torch).
  *   x  image [N,3,H,W] (in_layout NCHW) or [N,H,W,3] (NHWC), activation dtype

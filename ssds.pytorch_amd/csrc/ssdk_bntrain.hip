@@ -10,6 +10,10 @@
 //                 torch (momentum, unbiased variance)
 //   backward  (1) per-channel sum(dy), sum(dy * xhat)            -> dbeta, dgamma
 //             (2) dx = a * dy + x * k1[c] + k0[c]   (the usual formula with the per-channel scalars folded)
+// An activation that follows the BatchNorm (ReLU6 / ReLU: every Conv-BN-ReLU6 of MobileNetV2) can ride along
+// (`act`): the forward apply clamps before it stores, and both backward passes mask dy where the rounded
+// pre-activation x*a+b left the open interval -- recomputed, nothing extra is saved.  This removes the clamp and
+// hardtanh_backward launches and one read + one write of every activation tensor in each direction.
 // A workgroup of a reduction pass owns (channel c, slice s): the planes n = s, s + SPLIT, ... of that channel, read
 // with 16-byte vectors; partials are combined by one thread per channel in index order (bit-reproducible).
 #include "ssdk_conv_common.h"
@@ -32,7 +36,15 @@ struct BnParams {
   float* coef;             // [C][4] per-channel scalars of the apply pass
   int N, C, HW, split, dtype;
   float momentum, eps;
+  int act;                 // 0 none | 1 ReLU6 | 2 ReLU fused behind the normalisation
 };
+
+// the activation's pass-through mask on the pre-activation value as the forward pass stored it (rounded to DT)
+template <int DT> __device__ __forceinline__ bool bn_act_open(float pre, int act) {
+  float v = pre;
+  if constexpr (DT != SSDK_F32) v = bits16_to_f32<DT>(f32_to_bits16<DT>(pre));
+  return act == 1 ? (v > 0.f && v < 6.f) : v > 0.f;   // hardtanh_backward / threshold_backward: open interval
+}
 
 template <int DT> struct BnVec { static constexpr int n = DT == SSDK_F32 ? 4 : 8; };
 
@@ -81,6 +93,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnParams p) {
   const bool vec = (p.HW % VN) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)p.dy)) & 15u) == 0;
   const float k = MODE == 0 ? bn_ld1<DT>(p.x, (size_t)c * p.HW) : p.save_mean[c];
   const float istd = MODE == 0 ? 1.f : p.save_invstd[c];
+  const bool masked = MODE == 1 && p.act != 0;
+  const float fa = masked ? (p.weight ? p.weight[c] : 1.f) * istd : 0.f;                 // forward y = x*fa + fb
+  const float fb = masked ? (p.bias ? p.bias[c] : 0.f) - p.save_mean[c] * fa : 0.f;
   float a = 0.f, b = 0.f;
   for (int n = s; n < p.N; n += p.split) {
     const size_t base = ((size_t)n * p.C + c) * p.HW;
@@ -96,8 +111,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnParams p) {
             a += d;
             b += d * d;
           } else {
-            a += gv[e];
-            b += gv[e] * d * istd;
+            const float g = (masked && !bn_act_open<DT>(xv[e] * fa + fb, p.act)) ? 0.f : gv[e];
+            a += g;
+            b += g * d * istd;
           }
         }
       }
@@ -108,7 +124,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnParams p) {
           a += d;
           b += d * d;
         } else {
-          const float g = bn_ld1<DT>(p.dy, base + i);
+          float g = bn_ld1<DT>(p.dy, base + i);
+          if (masked && !bn_act_open<DT>((d + k) * fa + fb, p.act)) g = 0.f;
           a += g;
           b += g * d * istd;
         }
@@ -147,8 +164,9 @@ __global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const BnParams p) {
     p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * unbiased;
   }
   const float g = p.weight ? p.weight[c] : 1.f, bt = p.bias ? p.bias[c] : 0.f;
-  p.coef[c * 4 + 0] = g * invstd;
-  p.coef[c * 4 + 1] = bt - mean * g * invstd;
+  const float a = g * invstd;   // (the backward passes rebuild exactly this a and b for the activation mask)
+  p.coef[c * 4 + 0] = a;
+  p.coef[c * 4 + 1] = bt - mean * a;
   p.coef[c * 4 + 2] = 0.f;
 }
 
@@ -171,6 +189,7 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const BnParams p) {
   p.coef[c * 4 + 0] = a;
   p.coef[c * 4 + 1] = -a * sg / M - k1 * mean;  // k0
   p.coef[c * 4 + 2] = k1;
+  p.coef[c * 4 + 3] = (p.bias ? p.bias[c] : 0.f) - mean * a;  // forward offset (activation mask of the apply pass)
 }
 
 // MODE 0: out = x*a + b.  MODE 1: out = dy*a + x*k1 + k0.   grid (chunks of a plane, N*C planes)
@@ -179,7 +198,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnParams p) {
   constexpr int VN = BnVec<DT>::n;
   const int plane = blockIdx.y;
   const int c = plane % p.C;
-  const float a = p.coef[c * 4 + 0], k0 = p.coef[c * 4 + 1], k1 = p.coef[c * 4 + 2];
+  const float a = p.coef[c * 4 + 0], k0 = p.coef[c * 4 + 1], k1 = p.coef[c * 4 + 2], fb = p.coef[c * 4 + 3];
+  const int act = p.act;
+  auto fwd = [&](float x) {  // MODE 0
+    float o = x * a + k0;
+    if (act) o = fmaxf(o, 0.f);   // (a NaN input stays NaN in torch's clamp; fmaxf drops it -- BatchNorm of a NaN
+    if (act == 1) o = fminf(o, 6.f);  //  batch has NaN statistics anyway, every output is NaN before it gets here)
+    return o;
+  };
+  auto bwd = [&](float x, float g) {  // MODE 1: the forward scale is the same `a`
+    if (act && !bn_act_open<DT>(x * a + fb, act)) g = 0.f;
+    return g * a + x * k1 + k0;
+  };
   const size_t base = (size_t)plane * p.HW;
   const bool vec = (p.HW % VN) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)p.dy) | ((uintptr_t)p.out)) & 15u) == 0;
   if (vec) {
@@ -189,7 +219,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnParams p) {
     bn_load<DT>(p.x, base + i, xv);
     if (MODE == 1) bn_load<DT>(p.dy, base + i, gv);
 #pragma unroll
-    for (int e = 0; e < VN; ++e) o[e] = MODE == 0 ? xv[e] * a + k0 : gv[e] * a + xv[e] * k1 + k0;
+    for (int e = 0; e < VN; ++e) o[e] = MODE == 0 ? fwd(xv[e]) : bwd(xv[e], gv[e]);
     if constexpr (DT == SSDK_F32) {
       *reinterpret_cast<f32x4*>((float*)p.out + base + i) = f32x4{o[0], o[1], o[2], o[3]};
     } else {
@@ -201,7 +231,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnParams p) {
       const int i = (blockIdx.x * 256 + threadIdx.x) * VN + e;
       if (i >= p.HW) return;
       const float xv = bn_ld1<DT>(p.x, base + i);
-      const float o = MODE == 0 ? xv * a + k0 : bn_ld1<DT>(p.dy, base + i) * a + xv * k1 + k0;
+      const float o = MODE == 0 ? fwd(xv) : bwd(xv, bn_ld1<DT>(p.dy, base + i));
       if constexpr (DT == SSDK_F32) ((float*)p.out)[base + i] = o;
       else ((u16*)p.out)[base + i] = (u16)f32_to_bits16<DT>(o);
     }
@@ -260,10 +290,14 @@ static int bn_common(BnParams& p, const char* what, int N, int C, int HW, int dt
   return SSDK_OK;
 }
 
-extern "C" int ssdk_bn_train_fwd(const void* x, const float* weight, const float* bias, float* running_mean,
-                                 float* running_var, void* y, float* save_mean, float* save_invstd, void* workspace,
-                                 size_t workspace_bytes, int N, int C, int HW, float momentum, float eps, int dtype,
-                                 void* stream) {
+extern "C" int ssdk_bn_act_train_fwd(const void* x, const float* weight, const float* bias, float* running_mean,
+                                     float* running_var, void* y, float* save_mean, float* save_invstd, void* workspace,
+                                     size_t workspace_bytes, int N, int C, int HW, float momentum, float eps, int act,
+                                     int dtype, void* stream) {
+  if (act < 0 || act > 2) {
+    set_error("bn_train_fwd: act must be 0 (none), 1 (ReLU6) or 2 (ReLU)");
+    return SSDK_E_BADARG;
+  }
   if (!x || !y || !save_mean || !save_invstd || (!running_mean) != (!running_var)) {
     set_error("bn_train_fwd: null pointer");
     return SSDK_E_BADARG;
@@ -283,13 +317,27 @@ extern "C" int ssdk_bn_train_fwd(const void* x, const float* weight, const float
   p.save_invstd = save_invstd;
   p.momentum = momentum;
   p.eps = eps;
+  p.act = act;
   bn_launch<0>(p, (hipStream_t)stream);
   return check_launch("bn_train_fwd");
 }
 
-extern "C" int ssdk_bn_train_bwd(const void* x, const void* dy, const float* weight, const float* save_mean,
-                                 const float* save_invstd, void* dx, float* dweight, float* dbias, void* workspace,
-                                 size_t workspace_bytes, int N, int C, int HW, int dtype, void* stream) {
+extern "C" int ssdk_bn_train_fwd(const void* x, const float* weight, const float* bias, float* running_mean,
+                                 float* running_var, void* y, float* save_mean, float* save_invstd, void* workspace,
+                                 size_t workspace_bytes, int N, int C, int HW, float momentum, float eps, int dtype,
+                                 void* stream) {
+  return ssdk_bn_act_train_fwd(x, weight, bias, running_mean, running_var, y, save_mean, save_invstd, workspace,
+                               workspace_bytes, N, C, HW, momentum, eps, 0, dtype, stream);
+}
+
+extern "C" int ssdk_bn_act_train_bwd(const void* x, const void* dy, const float* weight, const float* bias,
+                                     const float* save_mean, const float* save_invstd, void* dx, float* dweight,
+                                     float* dbias, void* workspace, size_t workspace_bytes, int N, int C, int HW, int act,
+                                     int dtype, void* stream) {
+  if (act < 0 || act > 2) {
+    set_error("bn_train_bwd: act must be 0 (none), 1 (ReLU6) or 2 (ReLU)");
+    return SSDK_E_BADARG;
+  }
   if (!x || !dy || !dx || !save_mean || !save_invstd) {
     set_error("bn_train_bwd: null pointer");
     return SSDK_E_BADARG;
@@ -302,10 +350,19 @@ extern "C" int ssdk_bn_train_bwd(const void* x, const void* dy, const float* wei
   p.dy = dy;
   p.out = dx;
   p.weight = weight;
+  p.bias = bias;
+  p.act = act;
   p.save_mean = const_cast<float*>(save_mean);
   p.save_invstd = const_cast<float*>(save_invstd);
   p.dweight = dweight;
   p.dbias = dbias;
   bn_launch<1>(p, (hipStream_t)stream);
   return check_launch("bn_train_bwd");
+}
+
+extern "C" int ssdk_bn_train_bwd(const void* x, const void* dy, const float* weight, const float* save_mean,
+                                 const float* save_invstd, void* dx, float* dweight, float* dbias, void* workspace,
+                                 size_t workspace_bytes, int N, int C, int HW, int dtype, void* stream) {
+  return ssdk_bn_act_train_bwd(x, dy, weight, nullptr, save_mean, save_invstd, dx, dweight, dbias, workspace,
+                               workspace_bytes, N, C, HW, 0, dtype, stream);
 }

@@ -114,6 +114,10 @@ def _load():
     lib.ssdk_bn_workspace_bytes.restype = sz
     lib.ssdk_bn_train_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, f32, f32, i32, vp]
     lib.ssdk_bn_train_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, vp]
+    lib.ssdk_bn_act_train_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, f32, f32, i32, i32, vp]
+    lib.ssdk_bn_act_train_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, vp]
+    lib.ssdk_bn_act_train_fwd.restype = i32
+    lib.ssdk_bn_act_train_bwd.restype = i32
     lib.ssdk_bn_train_fwd.restype = i32
     lib.ssdk_bn_train_bwd.restype = i32
     lib.ssdk_preprocess.argtypes = [vp, i32, i32, i32, i32, i32, i32, c.POINTER(f32), c.POINTER(f32), vp, i32, vp]
@@ -198,7 +202,7 @@ EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_p
            "ssdk_run_ops_ctx", "ssdk_decode_nms_ctx",
            "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_fuse", "ssdk_preprocess", "ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data",
            "ssdk_dwconv_bwd_weight_workspace_bytes", "ssdk_dwconv_bwd_weight", "ssdk_bn_workspace_bytes",
-           "ssdk_bn_train_fwd", "ssdk_bn_train_bwd", "ssdk_conv_stem7", "ssdk_maxpool3x3s2", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
+           "ssdk_bn_train_fwd", "ssdk_bn_train_bwd", "ssdk_bn_act_train_fwd", "ssdk_bn_act_train_bwd", "ssdk_conv_stem7", "ssdk_maxpool3x3s2", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 
 
 class Context(object):

@@ -3,7 +3,13 @@
 ``MIOpenBatchNorm{Fwd,Bwd}Spatial`` -- the largest item of the reference's DDP training step on SSD-MobileNetV2
 once the depthwise convolutions are off MIOpen's naive kernels.  Same parameters, buffers, ``state_dict`` and
 running-statistics semantics (momentum, unbiased variance, ``num_batches_tracked``); eval mode, CPU tensors and
-non-affine / non-tracking variants are plain ``nn.BatchNorm2d``."""
+non-affine / non-tracking variants are plain ``nn.BatchNorm2d``.
+
+``fuse_bn_activations`` additionally folds the ReLU6 / ReLU that follows a BatchNorm inside an ``nn.Sequential``
+(every Conv-BN-ReLU6 of the backbone, mobilenet.py:24-33) into those kernels: the clamp rides on the forward apply
+pass and its gradient mask on the two backward passes, so the ``clamp`` / ``hardtanh_backward`` launches and one
+read + write of each activation tensor per direction disappear.  The activation module stays in the ``Sequential``
+(same ``state_dict``, same module list) and simply lets a tensor through that already carries its clamp."""
 import torch
 import torch.nn as nn
 
@@ -17,7 +23,7 @@ def _ws(dev, n, c):
 
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act=0):
         x = x.contiguous()
         n, c = int(x.shape[0]), int(x.shape[1])
         hw = int(x.shape[2]) * int(x.shape[3])
@@ -28,17 +34,18 @@ class _BatchNormTrain(torch.autograd.Function):
         ws, need = _ws(dev, n, c)
         wp = (ws.data_ptr() + 15) & ~15
         with torch.cuda.device(dev):
-            N.check(N.lib.ssdk_bn_train_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(),
-                                            running_var.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), wp,
-                                            need, n, c, hw, float(momentum), float(eps), N.dtype_code(x),
-                                            N.stream_ptr(dev)), "bn_train_fwd")
-        ctx.save_for_backward(x, weight, mean, invstd)
+            N.check(N.lib.ssdk_bn_act_train_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(),
+                                                running_var.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), wp,
+                                                need, n, c, hw, float(momentum), float(eps), int(act), N.dtype_code(x),
+                                                N.stream_ptr(dev)), "bn_train_fwd")
+        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.act = int(act)
         ctx.mark_non_differentiable(running_mean, running_var)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, mean, invstd = ctx.saved_tensors
+        x, weight, bias, mean, invstd = ctx.saved_tensors
         gy = gy.contiguous()
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
@@ -51,13 +58,16 @@ class _BatchNormTrain(torch.autograd.Function):
         ws, need = _ws(dev, n, c)
         wp = (ws.data_ptr() + 15) & ~15
         with torch.cuda.device(dev):
-            N.check(N.lib.ssdk_bn_train_bwd(x.data_ptr(), gy.data_ptr(), weight.data_ptr(), mean.data_ptr(),
-                                            invstd.data_ptr(), gx.data_ptr(), gw.data_ptr(), gb.data_ptr(), wp, need, n, c,
-                                            hw, N.dtype_code(x), N.stream_ptr(dev)), "bn_train_bwd")
-        return gx, gw.to(weight.dtype), gb.to(weight.dtype), None, None, None, None
+            N.check(N.lib.ssdk_bn_act_train_bwd(x.data_ptr(), gy.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                                mean.data_ptr(), invstd.data_ptr(), gx.data_ptr(), gw.data_ptr(),
+                                                gb.data_ptr(), wp, need, n, c, hw, ctx.act, N.dtype_code(x),
+                                                N.stream_ptr(dev)), "bn_train_bwd")
+        return gx, gw.to(weight.dtype), gb.to(weight.dtype), None, None, None, None, None
 
 
 class FastBatchNorm2d(nn.BatchNorm2d):
+    _ssdk_act = 0  # 1 ReLU6 | 2 ReLU folded into the kernels (set per instance by fuse_bn_activations)
+
     def forward(self, x):
         if not (self.training and x.is_cuda and x.dim() == 4 and self.affine and self.track_running_stats
                 and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and self.weight.dtype == torch.float32):
@@ -65,7 +75,11 @@ class FastBatchNorm2d(nn.BatchNorm2d):
         self.num_batches_tracked.add_(1)  # nn.BatchNorm2d bookkeeping (batchnorm.py of torch)
         momentum = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
         with torch.autocast("cuda", enabled=False):
-            return _BatchNormTrain.apply(x, self.weight, self.bias, self.running_mean, self.running_var, momentum, self.eps)
+            y = _BatchNormTrain.apply(x, self.weight, self.bias, self.running_mean, self.running_var, momentum, self.eps,
+                                      self._ssdk_act)
+        if self._ssdk_act:
+            y._ssdk_act_applied = self._ssdk_act  # read by the activation module that follows (and by nothing else)
+        return y
 
 
 def use_fast_batchnorm(model):
@@ -74,3 +88,42 @@ def use_fast_batchnorm(model):
         if type(m) is nn.BatchNorm2d:
             m.__class__ = FastBatchNorm2d
     return model
+
+
+class _FusedAwayActivation(object):
+    """Mixin of the activation that follows a fused BatchNorm: a tensor that already carries the clamp passes through."""
+
+    def forward(self, x):
+        if getattr(x, "_ssdk_act_applied", 0) == self._ssdk_act_code:
+            return x
+        return super(_FusedAwayActivation, self).forward(x)
+
+
+class FusedAwayReLU6(_FusedAwayActivation, nn.ReLU6):
+    _ssdk_act_code = 1
+
+
+class FusedAwayReLU(_FusedAwayActivation, nn.ReLU):
+    _ssdk_act_code = 2
+
+
+def fuse_bn_activations(model):
+    """For every ``nn.Sequential`` of ``model`` in which a kernel-backed BatchNorm is directly followed by ``nn.ReLU6`` /
+    ``nn.ReLU``: fold the activation into the BatchNorm kernels (in place; call after ``use_fast_batchnorm``).  Whenever
+    the BatchNorm takes its plain path (eval mode, CPU, ...) the activation module runs as before."""
+    n = 0
+    for seq in model.modules():
+        if not isinstance(seq, nn.Sequential):
+            continue
+        mods = list(seq.children())
+        for bn, act in zip(mods, mods[1:]):
+            if type(bn) is not FastBatchNorm2d:
+                continue
+            if type(act) is nn.ReLU6:
+                bn._ssdk_act, act.__class__ = 1, FusedAwayReLU6
+            elif type(act) is nn.ReLU:
+                bn._ssdk_act, act.__class__ = 2, FusedAwayReLU
+            else:
+                continue
+            n += 1
+    return n

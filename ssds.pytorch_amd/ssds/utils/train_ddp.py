@@ -40,6 +40,10 @@ class Solver(object):
             from ssds.modeling.layers.batchnorm import use_fast_batchnorm
 
             use_fast_batchnorm(self.model)  # training BN on the ssdk kernels (local statistics, like the default)
+            if os.environ.get("SSDK_FUSE_BN_ACT", "1") != "0":
+                from ssds.modeling.layers.batchnorm import fuse_bn_activations
+
+                fuse_bn_activations(self.model)  # Conv-BN-ReLU6: the clamp and its gradient mask ride on the BN passes
         if os.environ.get("SSDK_PW_GEMM", "1") != "0":
             from ssds.modeling.layers.pointwise import use_pointwise_gemm
 

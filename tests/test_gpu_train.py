@@ -141,6 +141,46 @@ def test_batchnorm_training_kernels_match_torch(n, c, h, w, dtype_name, tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("act_name", ["ReLU6", "ReLU"])
+@pytest.mark.parametrize("dtype_name", ["float32", "bfloat16", "float16"])
+@pytest.mark.parametrize("n,c,h,w", [(4, 32, 16, 24), (3, 17, 9, 7), (64, 8, 32, 32)])
+def test_batchnorm_with_folded_activation_is_bit_identical_to_the_two_step_path(n, c, h, w, dtype_name, act_name):
+    """Conv-BN-ReLU6: the activation folded into the BatchNorm kernels (forward clamp, backward mask recomputed from
+    the rounded pre-activation) against the same kernels followed by torch's activation -- outputs, dx, dweight, dbias
+    and running statistics bit for bit; the two-step path itself is pinned to nn.BatchNorm2d by the test above."""
+    import copy
+    import torch
+    import torch.nn as nn
+    from ssds.modeling.layers.batchnorm import FastBatchNorm2d, FusedAwayReLU, FusedAwayReLU6, fuse_bn_activations
+
+    dtype = getattr(torch, dtype_name)
+    torch.manual_seed(n + c + h)
+    two = nn.Sequential(nn.Conv2d(c, c, 1), FastBatchNorm2d(c), getattr(nn, act_name)(inplace=True)).cuda().train()
+    two[1].weight.data.uniform_(0.5, 2.5)
+    two[1].bias.data.normal_(2.0, 2.0)  # pre-activations on both sides of 0 and of 6
+    one = copy.deepcopy(two)
+    assert fuse_bn_activations(one) == 1 and one[1]._ssdk_act == (1 if act_name == "ReLU6" else 2)
+    assert type(one[2]) is (FusedAwayReLU6 if act_name == "ReLU6" else FusedAwayReLU)
+    assert list(one.state_dict().keys()) == list(two.state_dict().keys())
+    x = (torch.randn(n, c, h, w, device="cuda") * 2 + 1).to(dtype)
+    g = torch.randn(n, c, h, w, device="cuda").to(dtype)
+    outs = []
+    for net in (two, one):
+        xi = x.detach().clone().requires_grad_(True)
+        y = net[2](net[1](xi))
+        y.backward(g)
+        outs.append((y.detach(), xi.grad, net[1].weight.grad, net[1].bias.grad, net[1].running_mean, net[1].running_var))
+    frac = float(((outs[0][0] > 0) & (outs[0][0] < 6)).float().mean())
+    assert 0.05 < frac < 0.95, "the case must exercise both sides of the clamp (%.2f pass)" % frac
+    for a, b, what in zip(outs[0], outs[1], ("output", "dx", "dweight", "dbias", "running_mean", "running_var")):
+        assert torch.equal(a, b), what
+    one.eval()  # plain nn.BatchNorm2d path: the activation module does its own work again
+    two.eval()
+    assert torch.equal(one[2](one[1](x.float())), two[2](two[1](x.float())))
+    assert float(one[2](one[1](x.float())).min()) >= 0.0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype_name,tol", [("float32", 2e-4), ("bfloat16", 2e-2), ("float16", 4e-3)])
 @pytest.mark.parametrize("n,cin,cout,h,w,bias", [(4, 16, 96, 16, 24, False), (3, 24, 144, 9, 7, True), (64, 160, 960, 16, 16, False),
                                                  (2, 320, 256, 5, 5, True)])

@@ -332,3 +332,34 @@ def test_pointwise_gemm_switch_keeps_state_dict_and_cpu_behaviour():
     assert [type(m) is PointwiseConv2d for m in net] == [True, False, False, False, True]
     assert list(net.state_dict().keys()) == keys
     assert torch.equal(net(x), y0)
+
+
+def test_fusing_bn_activations_changes_nothing_on_cpu():
+    """fuse_bn_activations marks BN -> ReLU6 pairs inside Sequentials only; on CPU (no kernels) the network computes
+    what it computed before, in train and eval mode, and keeps its state_dict."""
+    import os
+    import torch
+    from ssds.core import config
+    from ssds.modeling import model_builder
+    from ssds.modeling.layers.batchnorm import FastBatchNorm2d, fuse_bn_activations, use_fast_batchnorm
+
+    cfg = config.cfg_from_file(os.path.join(os.path.dirname(__file__), "..", "experiments", "cfgs", "ssd_mobilenetv2_512.yml"))
+    torch.manual_seed(0)
+    model = model_builder.create_model(cfg.MODEL)
+    keys = list(model.state_dict().keys())
+    x = torch.randn(2, 3, 128, 128)
+    model.eval()
+    with torch.no_grad():
+        ref = [t.clone() for t in model(x)[0]]
+    use_fast_batchnorm(model)
+    n = fuse_bn_activations(model)
+    assert n >= 35, n  # 17 inverted-residual blocks with two Conv-BN-ReLU6 each + stem + last conv + extras
+    assert list(model.state_dict().keys()) == keys
+    fused = [m for m in model.modules() if type(m) is FastBatchNorm2d and m._ssdk_act]
+    assert len(fused) == n
+    with torch.no_grad():
+        out = model(x)[0]
+    assert all(torch.equal(a, b) for a, b in zip(ref, out))
+    model.train()
+    y = model(x)
+    (y[0][0].float().sum() + y[1][0].float().sum()).backward()  # plain autograd path still differentiates
