@@ -369,7 +369,7 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
 }
 
 // Patch shape for an (N, Ho, Wo) output: maximise the fraction of the 256 tile rows that are real pixels.
-static bool plan_patch(int N, int Ho, int Wo, HaloParams* hp) {
+static bool plan_patch(int N, int Ho, int Wo, bool nchw, HaloParams* hp) {
   int best_imgs = 0, best_th = 0, best_tw = 0;
   double best_u = 0.0;
   auto consider = [&](int imgs, int th, int tw) {
@@ -379,6 +379,10 @@ static bool plan_patch(int N, int Ho, int Wo, HaloParams* hp) {
     const long tiles = groups * ((Ho + th - 1) / th) * ((Wo + tw - 1) / tw);
     double u = (double)N * Ho * Wo / ((double)tiles * 256.0);
     if (tw % 8 == 0 && Wo % 8 == 0) u *= 1.02;  // prefer shapes that keep the NCHW stores vectorised
+    // NCHW output: a channel's pixels are contiguous along a map row, so among equally full patches the WIDEST wins --
+    // full-width patches store th*Wo contiguous pixels per channel (the 32x32 head level: 512-byte runs instead of the
+    // 16-byte runs of an 8-wide patch, each 64-byte line shared by four workgroups)
+    if (nchw) u *= 1.0 + 0.01 * (double)tw / (double)Wo;
     if (u > best_u) {
       best_u = u;
       best_imgs = imgs;
@@ -416,7 +420,7 @@ int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool
   if (p.Cout < 96 || p.Cin < 32) return 1;
   HaloParams hp;
   hp.c = p;
-  if (!plan_patch(p.N, p.Ho, p.Wo, &hp)) return 1;
+  if (!plan_patch(p.N, p.Ho, p.Wo, p.out_layout == LAYOUT_NCHW, &hp)) return 1;
   hp.n_tiles = (p.Cout + H3_BN - 1) / H3_BN;
   auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
   hp.mg_ntiles = magic(hp.n_tiles);
