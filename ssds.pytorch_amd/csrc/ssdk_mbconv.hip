@@ -456,17 +456,19 @@ __global__ __launch_bounds__(kMbThreads, LEAN4 ? 4 : 2) void mbconv_kernel(const
           const unsigned char* prow = sX + (size_t)(((spix / RW) * 2) * PC + (spix % RW) * 2 + 2 * (int)fg) * 8;
 #pragma unroll
           for (int ks = 0; ks < KSMAX; ++ks) {
-            if (ks < KS) {
+            if (ks < KS) {  // the k-step's operand reads first, then its MFMAs (one exposed LDS latency per k-step, not 1 + NJ)
               const int k = ks * 32 + (int)fg * 8;
-              u32x4 xf = {0u, 0u, 0u, 0u};
-              if constexpr (STEM) xf = *reinterpret_cast<const u32x4*>(prow + (size_t)ks * PC * 8);
-              else if (k < Cin) xf = *reinterpret_cast<const u32x4*>(xrow + k * 2);
+              u32x4 xf = {0u, 0u, 0u, 0u}, wv[NJ];
 #pragma unroll
-              for (int jf = 0; jf < NJ; ++jf) {
-                u32x4 wv = {0u, 0u, 0u, 0u};
-                if (k < Cin) wv = *reinterpret_cast<const u32x4*>(wcur + (size_t)(jf * 16 + fr) * WES + k * 2);
-                e[jf] = mb_mfma<DT>(wv, xf, e[jf]);  // D[hc = fg*4+r][pixel = fr]
+              for (int jf = 0; jf < NJ; ++jf) wv[jf] = u32x4{0u, 0u, 0u, 0u};
+              if constexpr (STEM) xf = *reinterpret_cast<const u32x4*>(prow + (size_t)ks * PC * 8);
+              if (k < Cin) {
+                if constexpr (!STEM) xf = *reinterpret_cast<const u32x4*>(xrow + k * 2);
+#pragma unroll
+                for (int jf = 0; jf < NJ; ++jf) wv[jf] = *reinterpret_cast<const u32x4*>(wcur + (size_t)(jf * 16 + fr) * WES + k * 2);
               }
+#pragma unroll
+              for (int jf = 0; jf < NJ; ++jf) e[jf] = mb_mfma<DT>(wv[jf], xf, e[jf]);  // D[hc = fg*4+r][pixel = fr]
             }
           }
           const bool ok = (pvalid >> i) & 1u;
@@ -581,20 +583,38 @@ __global__ __launch_bounds__(kMbThreads, LEAN4 ? 4 : 2) void mbconv_kernel(const
     __syncthreads();
     MB_STAMP();
     // ---- P3: project: wave (m_fr, n_half) owns pixels [16 m_fr, +16) x n-frags n_half, n_half+2, ... ----
+    // Operand reads go out in batches ahead of the MFMAs that consume them (written read -> MFMA -> read -> MFMA, every
+    // MFMA waited for its own ds_read: ~10 exposed LDS latencies per chunk); a weight fragment serves both pixel
+    // fragments of the wave.
+    {
+      u32x4 df[MPW][KP];
 #pragma unroll
-    for (int mi = 0; mi < MPW; ++mi) {
-      u32x4 df[KP];
+      for (int mi = 0; mi < MPW; ++mi)
 #pragma unroll
-      for (int kp = 0; kp < KP; ++kp)
-        df[kp] = *reinterpret_cast<const u32x4*>(sD + (size_t)((m_base + mi) * 16 + fr) * ES + kp * 64 + fg * 16);
+        for (int kp = 0; kp < KP; ++kp)
+          df[mi][kp] = *reinterpret_cast<const u32x4*>(sD + (size_t)((m_base + mi) * 16 + fr) * ES + kp * 64 + fg * 16);
+      constexpr int WB = NFO >= 20 ? 4 : 8;                  // weight fragments in flight (x4 registers)
+      constexpr int JB = (WB / KP) < 1 ? 1 : (WB / KP);     // n-frags per batch
 #pragma unroll
-      for (int jj = 0; jj < NFH; ++jj) {
-        const int j = (int)n_half + NSPLIT * jj;
+      for (int j0 = 0; j0 < NFH; j0 += JB) {
+        u32x4 wf[JB][KP];
 #pragma unroll
-        for (int kp = 0; kp < KP; ++kp) {
-          const u32x4 wf = *reinterpret_cast<const u32x4*>(wcur + p.off_wp + (size_t)(j * 16 + fr) * ES + kp * 64 + fg * 16);
-          yacc[mi][jj] = mb_mfma<SSDK_F16>(wf, df[kp], yacc[mi][jj]);  // D[co = fg*4+r][px = fr]
-        }
+        for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+          for (int kp = 0; kp < KP; ++kp)
+            if (j0 + jb < NFH) {
+              const int j = (int)n_half + NSPLIT * (j0 + jb);
+              wf[jb][kp] = *reinterpret_cast<const u32x4*>(wcur + p.off_wp + (size_t)(j * 16 + fr) * ES + kp * 64 + fg * 16);
+            }
+        __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink every read next to its MFMA again)
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+          for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi)
+              if (j0 + jb < NFH)
+                yacc[mi][j0 + jb] = mb_mfma<SSDK_F16>(wf[jb][kp], df[mi][kp], yacc[mi][j0 + jb]);  // D[co = fg*4+r][px = fr]
       }
     }
     // No barrier here.  The next chunk's P1 writes sE (P2 of this chunk finished reading it before the
