@@ -335,8 +335,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) 
     // kw scores >= its own value, i.e. K scores are >= the smallest of the waves' values
     constexpr u32 NWh = NT / 64;
     const u32 kw = (K + NWh - 1) / NWh;
+    // (16-bit scores upcast to fp32 carry zeros below their mantissa: those bits of the answer are zero, no trips for them)
+    constexpr int kLowBit = DT == SSDK_BF16 ? 16 : DT == SSDK_F16 ? 13 : 0;
     u32 wv = 0;
-    for (int bit = 31; bit >= 0; --bit) {
+    for (int bit = 31; bit >= kLowBit; --bit) {
       const u32 c = wv | (1u << bit);
       const u32 cntc = (u32)__popcll(__ballot(m1 >= c)) + (u32)__popcll(__ballot(m2 >= c));
       wv = cntc >= kw ? c : wv;  // wave-uniform
