@@ -45,11 +45,12 @@ class _MatchLoss(torch.autograd.Function):
         return cls_sum, loc_sum, sums
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g_cls, g_loc, _g_sums):
         d_conf, d_loc = ctx.saved_tensors
-        # in place: the stored gradients are this node's own buffers and backward runs once
-        gc = d_conf.mul_(g_cls) if g_cls is not None else None  # 0-dim fp32 scale, fp32 arithmetic, dtype kept
-        gl = d_loc.mul_(g_loc) if g_loc is not None else None
+        # out of place: the saved gradients stay what the kernel wrote, so backward(retain_graph=True) may run again
+        gc = d_conf * g_cls if g_cls is not None else None  # 0-dim fp32 scale, fp32 arithmetic, dtype kept
+        gl = d_loc * g_loc if g_loc is not None else None
         return (gc, gl) + (None,) * 12
 
 

@@ -298,6 +298,11 @@ def decode_nms(loc, conf, anchors, threshold, top_n_per_level, rescore, nms_thre
             for c, l in heads:  # read by kernels on the tail stream: not to be recycled before those have run
                 c.record_stream(tail.stream)
                 l.record_stream(tail.stream)
+            # the outputs belong to the tail stream's pool but are consumed (after Decoder.wait()) on the caller's
+            # stream: their memory must not return to the tail stream while the consumer's kernels still read it
+            cur = torch.cuda.current_stream(dev)
+            for t in (os_, ob, oc) + tuple(m for m in mid if m is not None):
+                t.record_stream(cur)
             tail.release()
     N.check(rc, "decode_nms")
     if return_mid:

@@ -290,6 +290,15 @@ def test_fused_match_loss_matches_unfused_losses(mode, dtype_name, gamma, loc_lo
     # bit-reproducible sums
     again = match_loss(conf, loc, targets, anchors, C, stride, match, radius, fl.alpha, fl.gamma, beta, loc_loss)
     assert float(again[0]) == float(cls_sum) and float(again[1]) == float(loc_sum)
+    # the node keeps the gradients the kernel wrote: a second backward over a retained graph scales them afresh
+    first = conf.grad.clone()
+    conf.grad = loc.grad = None
+    loss = w_cls * again[0] + w_loc * again[1]
+    loss.backward(retain_graph=True)
+    once = conf.grad.clone()
+    conf.grad = loc.grad = None
+    loss.backward()
+    assert torch.equal(conf.grad, once) and torch.equal(once, first)
 
 
 def test_eval_epoch_on_device_matches_oracle_metric():
