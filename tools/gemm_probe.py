@@ -23,6 +23,8 @@ SHAPES = {
     "pw_320_1280": (64, 320, 16, 16, 1280, 1, 1, "relu"),
     "extras_1x1": (64, 320, 16, 16, 256, 1, 1, "relu"),
     "extras_3x3s2": (64, 256, 16, 16, 512, 3, 2, "relu"),
+    "extras_3x3s2_b8": (8, 256, 16, 16, 512, 3, 2, "relu"),   # 16 workgroups: the same k-loop with an L2-resident operand set
+    "extras_3x3s2_b2": (2, 256, 16, 16, 512, 3, 2, "relu"),   # 4 workgroups
 }
 
 
