@@ -13,12 +13,14 @@ batch (weak scaling, replicas only: inference has no collective -- SURVEY.md 8e)
 Other BASELINE configs through the same file: `--cfg experiments/cfgs/fpn_resnet50_640.yml --batch 32` (config 3),
 `--cfg experiments/cfgs/bifpn_regnetx008_896.yml --batch 16 --dtype fp16 --graph 1` (config 5).
 
-Serving-loop pipelining (default, --tail-stream 0 turns it off): the latency-bound end of the decode stage
-(tail_kernel: level merge + box decode + NMS, one workgroup per image) is enqueued on its own HIP stream and runs
-under the NEXT step's forward pass; the HBM-bound scan_kernel stays in line on the main stream, so its live event
-timing is un-overlapped.  All work of the K steps completes inside the timed region (device-wide synchronize on both
-sides).  After the timed loop the last step is re-run IN LINE (one stream: no tail stream, no side lane) and its three
-outputs must equal the timed loop's bit for bit: `verified` in the JSON line.
+The whole step runs in line on one stream by default.  Serving-loop pipelining is an option (--tail-stream 1): the
+latency-bound end of the decode stage (tail_kernel: level merge + box decode + NMS, one workgroup per image) is then
+enqueued on its own HIP stream and runs under the NEXT step's forward pass while the HBM-bound scan_kernel stays in
+line on the main stream.  It was the default in round 1 (+3 % with the three-launch decode stage); with the fused
+tail kernel it is within noise of the in-line step (37.01 vs 37.06 k img/s on the same box), so the simpler path is
+the one that is timed.  All work of the K steps completes inside the timed region (device-wide synchronize on both
+sides).  After the timed loop the last step is re-run on one stream without the side lane and its three outputs must
+equal the timed loop's bit for bit: `verified` in the JSON line.
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract fields it carries
   roofline      HBM roofline of the dominant hand-written kernel of the decode stage (scan_kernel: the one pass over
@@ -58,7 +60,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="compute dtype of the network")
     ap.add_argument("--cpu-sample", type=int, default=4, help="images for the CPU baseline (0 = skip)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the step as one captured hipGraph")
-    ap.add_argument("--tail-stream", type=int, default=1,
+    ap.add_argument("--tail-stream", type=int, default=0,
                     help="1: the tail kernel of the decode stage on its own stream (overlaps the next step's forward)")
     ap.add_argument("--layers", type=int, default=0, help="1: add the per-layer table (us, TFLOP/s, GB/s) to the JSON")
     ap.add_argument("--channels-last", type=int, default=int(os.environ.get("SSDK_CHANNELS_LAST", "0")))
