@@ -292,6 +292,11 @@ typedef struct ssdk_mbconv_desc {
                    (mobilenet.py:78-89, expand_ratio 1) in one launch */
 } ssdk_mbconv_desc;
 int ssdk_mbconv(const ssdk_mbconv_desc* desc, void* stream);
+/* Two kernels implement ssdk_mbconv: the LDS-tiled one (every geometry) and, for the high-resolution blocks (Cin <= 32,
+ * hidden in {96, 144, 192}, Cout <= 64, no stem), a register-flow one that is picked automatically where the map is
+ * large enough to pay (ssdk_mbflow.hip).  Process-wide override for tests and A/B runs: -1 never, 0 automatic (default),
+ * 1 wherever the register-flow kernel exists.  ssdk_last_kernel() names the kernel that ran. */
+int ssdk_mbconv_set_variant(int variant);
 
 /* Weighted feature fusion of the BiFPN (bifpn.py:41-62), NHWC, one launch:
  *   y = w0 * a + w1 * R_b(b) [+ w2 * R_c(c)]      a, y: [N][H][W][C]

@@ -733,6 +733,9 @@ static int launch_mb(const MbParams& p, int ks, int nfo, size_t lds, unsigned gr
 
 }  // namespace ssdk
 
+namespace ssdk {
+int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream);  // ssdk_mbflow.hip: 0 = launched, 1 = not one of its blocks
+}
 using namespace ssdk;
 
 extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
@@ -759,6 +762,7 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
               "channels %% 8 == 0)", d->Cin, d->Chid, d->Cout, d->stride, d->residual);
     return SSDK_E_BADARG;
   }
+  if (!stem && launch_mbflow(d, stream) == 0) return check_launch("mbflow_kernel");  // high-resolution blocks: ssdk_mbflow.hip
   MbParams p;
   p.x = (const u16*)d->x;
   p.y = (u16*)d->y;

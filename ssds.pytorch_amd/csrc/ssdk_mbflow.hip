@@ -1,0 +1,418 @@
+// ssdk_mbflow.hip -- MobileNetV2 inverted-residual block (torchvision InvertedResidual behind nets/mobilenet.py:56,
+// 84-89: 1x1 expand + BN + ReLU6 -> 3x3 depthwise (stride 1|2) + BN + ReLU6 -> 1x1 project + BN [+ x]) for the
+// HIGH-RESOLUTION blocks (Cin <= 32, hidden <= 192, Cout <= 64), with the expanded tensor kept in REGISTERS.
+//
+// Why a second kernel: ssdk_mbconv.hip moves the 6x-expanded tile through LDS twice (expand MFMA -> sE -> depthwise ->
+// sD -> project MFMA) between workgroup barriers; on the 128^2 / 256^2 maps those round trips ARE the run time (SQ
+// counters: LDS pipe busy 55-67 %, waves parked at barriers 42-54 %).  Here a WAVE owns a 16-pixel-wide column strip
+// of the map and walks down its rows; nothing is shared between waves, there is no barrier after the weights are
+// staged, and the only LDS traffic is broadcast reads of weights:
+//   * expand:  D[hc][px] = We[hc][k] * x[k][px] on the matrix cores.  The MFMA output layout puts one PIXEL in a lane
+//     (lane = fg*16 + fr: pixel fr of the strip, channels 16c + 4fg .. +3 of chunk c), which is exactly what a
+//     depthwise convolution wants: the horizontal taps are DPP row shifts (v_mov_b32 row_shr:1 / row_shl:1 inside the
+//     16-lane rows), the vertical taps are the next rows the wave computes.
+//   * depthwise: every expanded row is folded, as it appears, into the packed-fp16 accumulators of the (up to three)
+//     output rows it contributes to; an output row is complete when its last input row has passed.
+//   * project: the finished depthwise row already has the B-operand layout of the f16 MFMA (one pixel per lane, eight
+//     hidden channels per lane and k-step) up to a permutation of k, which is applied to the projection weights once,
+//     when they are staged:  k-step t, lane group fg, element j  <->  hidden channel (2t + j/4)*16 + 4fg + j%4.
+// x is read straight from global memory as the expand GEMM's B operand (16 bytes = 8 input channels of one pixel per
+// lane, one row ahead); the strips overlap by two pixels (halo), segments of rows by two rows.
+//
+// Numerics are those of ssdk_mbconv.hip: E = fp16(clamp(bn(expand), 0, 6)) (round toward zero), depthwise in packed
+// fp16 in the order (ky, kx), D = clamp(acc + bias, 0, 6), projection on the f16 MFMA with fp32 accumulation, output
+// rounded to the model dtype before the residual is added.  Stride 2: lane fr of a strip holds input column
+// 2*ox0 - 1 + fr, outputs sit in the odd lanes 1..13 (7 per strip).
+#include <atomic>
+#include <type_traits>
+
+#include "ssdk_common.h"
+
+namespace ssdk {
+
+typedef __bf16 fl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fl_f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 fl_h2 __attribute__((ext_vector_type(2)));
+
+struct FlowParams {
+  const u16* x;
+  u16* y;
+  const u16* we;
+  const float* se;
+  const float* be;
+  const u16* wd;
+  const u16* bd;
+  const u16* wp;
+  const float* sp;
+  const float* bp;
+  int N, H, W, Cin, Chid, Cout, Ho, Wo, residual;
+  int strips, segs, rs;  // strips per row, row segments per image, output rows per segment
+};
+
+template <int DT>
+__device__ __forceinline__ f32x4 fl_mfma(const u32x4& a, const u32x4& b, f32x4 c) {
+  if constexpr (DT == SSDK_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(fl_bf16x8, a), __builtin_bit_cast(fl_bf16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(fl_f16x8, a), __builtin_bit_cast(fl_f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ fl_h2 fl_as_h2(u32 w) { return __builtin_bit_cast(fl_h2, w); }
+__device__ __forceinline__ u32 fl_as_u32(fl_h2 v) { return __builtin_bit_cast(u32, v); }
+template <int DT> __device__ __forceinline__ u32 fl_to16(float v) {
+  if constexpr (DT == SSDK_BF16) {
+    u32 b = __builtin_bit_cast(u32, v);
+    if ((b & 0x7fffffffu) > 0x7f800000u) return (b >> 16) | 0x40u;
+    return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
+  } else {
+    _Float16 h = (_Float16)v;
+    return (u32)__builtin_bit_cast(u16, h);
+  }
+}
+typedef float fl_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 fl_bf16x2 __attribute__((ext_vector_type(2)));
+template <int DT> __device__ __forceinline__ u32 fl_pack2(float a, float b) {
+  const fl_f32x2 v = {a, b};
+  if constexpr (DT == SSDK_BF16) return __builtin_bit_cast(u32, __builtin_convertvector(v, fl_bf16x2));
+  else return __builtin_bit_cast(u32, __builtin_convertvector(v, fl_h2));
+}
+template <int DT> __device__ __forceinline__ float fl_from16(u32 h) {
+  if constexpr (DT == SSDK_BF16) return bf16_bits_to_f32(h);
+  else return f16_bits_to_f32(h);
+}
+// neighbour pixel inside the 16-lane row; the row's first / last lane gets 0 (those lanes are halo pixels)
+__device__ __forceinline__ u32 fl_from_left(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }   // row_shr:1
+__device__ __forceinline__ u32 fl_from_right(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }  // row_shl:1
+
+constexpr int kFlowThreads = 256;
+
+// LDS image of the weights (bytes), all 16-byte aligned; NCH = hidden chunks of 16, T = projection k-steps, NFO = Cout / 16
+template <int NCH, int NFO>
+struct FlowLds {
+  static constexpr int T = (NCH + 1) / 2;
+  static constexpr int we = 0;                             // [NCH][64 lanes] u32x4
+  static constexpr int sb = we + NCH * 1024;               // [NCH][4 fg][se f32x4 | be f32x4]
+  static constexpr int wd = sb + NCH * 4 * 32;             // [NCH][9 taps][4 fg] 8 bytes
+  static constexpr int bd = wd + NCH * 9 * 4 * 8;          // [NCH][4 fg] 8 bytes
+  static constexpr int wp = (bd + NCH * 4 * 8 + 15) & ~15; // [NFO][T][64 lanes] u32x4
+  static constexpr int spb = wp + NFO * T * 1024;          // [NFO][4 fg][sp f32x4 | bp f32x4]
+  static constexpr int bytes = spb + NFO * 4 * 32;
+};
+
+template <int DT, int S, int NCH, int NFO>
+__global__ __launch_bounds__(kFlowThreads, 2) void mbflow_kernel(const FlowParams p) {
+  using L = FlowLds<NCH, NFO>;
+  constexpr int T = L::T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u32 fr = lane & 15u, fg = lane >> 4;
+  const int Cin = p.Cin, Chid = p.Chid, Cout = p.Cout;
+
+  // ---- stage the weights once per workgroup in the layouts the lanes read them in ----------------------------------
+  for (u32 i = tid; i < (u32)(NCH * 64); i += kFlowThreads) {  // expand weights as A fragments: row hc = 16c + fr, k = 8fg ..
+    const u32 c = i >> 6, l = i & 63u, hc = c * 16 + (l & 15u), k0 = (l >> 4) * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (hc < (u32)Chid && k0 < (u32)Cin) v = *reinterpret_cast<const u32x4*>(p.we + (size_t)hc * Cin + k0);
+    *reinterpret_cast<u32x4*>(smem + L::we + i * 16) = v;
+  }
+  for (u32 i = tid; i < (u32)(NCH * 4); i += kFlowThreads) {  // expand BN, depthwise bias: 4 channels 16c + 4g ..
+    const u32 hc = (i >> 2) * 16 + (i & 3u) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    uint2 d = make_uint2(0u, 0u);
+    if (hc < (u32)Chid) {
+      s = *reinterpret_cast<const f32x4*>(p.se + hc);
+      b = *reinterpret_cast<const f32x4*>(p.be + hc);
+      d = *reinterpret_cast<const uint2*>(p.bd + hc);
+    }
+    *reinterpret_cast<f32x4*>(smem + L::sb + i * 32) = s;
+    *reinterpret_cast<f32x4*>(smem + L::sb + i * 32 + 16) = b;
+    *reinterpret_cast<uint2*>(smem + L::bd + i * 8) = d;
+  }
+  for (u32 i = tid; i < (u32)(NCH * 9 * 4); i += kFlowThreads) {  // depthwise taps [c][tap][g]
+    const u32 g = i & 3u, tap = (i >> 2) % 9u, c = (i >> 2) / 9u, hc = c * 16 + g * 4;
+    uint2 d = make_uint2(0u, 0u);
+    if (hc < (u32)Chid) d = *reinterpret_cast<const uint2*>(p.wd + (size_t)tap * Chid + hc);
+    *reinterpret_cast<uint2*>(smem + L::wd + i * 8) = d;
+  }
+  for (u32 i = tid; i < (u32)(NFO * T * 64 * 2); i += kFlowThreads) {  // projection weights, k permuted (see the header): 8 bytes per item
+    const u32 half = i & 1u, l = (i >> 1) & 63u, ft = i >> 7, t = ft % (u32)T, f = ft / (u32)T;
+    const u32 co = f * 16 + (l & 15u), hc = (2 * t + half) * 16 + (l >> 4) * 4;
+    uint2 d = make_uint2(0u, 0u);
+    if (co < (u32)Cout && hc < (u32)Chid) d = *reinterpret_cast<const uint2*>(p.wp + (size_t)co * Chid + hc);
+    *reinterpret_cast<uint2*>(smem + L::wp + (ft * 64 + l) * 16 + half * 8) = d;
+  }
+  for (u32 i = tid; i < (u32)(NFO * 4); i += kFlowThreads) {  // projection BN: 4 output channels 16f + 4g ..
+    const u32 co = (i >> 2) * 16 + (i & 3u) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    if (co < (u32)Cout) {
+      s = *reinterpret_cast<const f32x4*>(p.sp + co);
+      b = *reinterpret_cast<const f32x4*>(p.bp + co);
+    }
+    *reinterpret_cast<f32x4*>(smem + L::spb + i * 32) = s;
+    *reinterpret_cast<f32x4*>(smem + L::spb + i * 32 + 16) = b;
+  }
+  __syncthreads();
+
+  // ---- this wave's work item: (image, row segment, strip) -----------------------------------------------------------
+  const u32 item = blockIdx.x * (kFlowThreads / 64) + wave;
+  const u32 per_img = (u32)(p.strips * p.segs);
+  if (item >= (u32)p.N * per_img) return;
+  const int n = (int)(item / per_img), rem = (int)(item % per_img);
+  const int seg = rem / p.strips, strip = rem % p.strips;
+  constexpr int OW = S == 1 ? 14 : 7;             // output pixels per strip
+  const int ox0 = strip * OW;
+  const int ix = ox0 * S - 1 + (int)fr;            // this lane's input column
+  const bool col_ok = (unsigned)ix < (unsigned)p.W;
+  const int oy0 = seg * p.rs, oy1 = (oy0 + p.rs < p.Ho ? oy0 + p.rs : p.Ho) - 1;  // output rows [oy0, oy1]
+  // output pixel of this lane (if any): stride 1: lanes 1..14, stride 2: odd lanes 1..13
+  const int oxl = S == 1 ? ox0 + (int)fr - 1 : ox0 + ((int)fr - 1) / 2;
+  const bool out_lane = (S == 1 ? (fr >= 1u && fr <= 14u) : ((fr & 1u) && fr <= 13u)) && oxl < p.Wo;
+
+  const u16* ximg = p.x + (size_t)n * p.H * p.W * Cin;
+  const bool k_ok = fg * 8u < (u32)Cin;
+  auto load_x = [&](int iy) -> u32x4 {  // B operand of the expand GEMM: 8 input channels of pixel (iy, ix)
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (k_ok && col_ok && (unsigned)iy < (unsigned)p.H) v = *reinterpret_cast<const u32x4*>(ximg + ((size_t)iy * p.W + ix) * Cin + fg * 8);
+    return v;
+  };
+
+  fl_h2 accA[NCH * 2], accB[NCH * 2], accC[NCH * 2];
+  const fl_h2 zero2 = {(_Float16)0.f, (_Float16)0.f}, six2 = {(_Float16)6.f, (_Float16)6.f};
+
+  // One input row.  FIN / MID / INI: the row is the last (ky = 2) / middle (ky = 1) / first (ky = 0) row of the output
+  // row accumulated in fin / mid / ini; the FIN row is completed, projected and stored as output row `oy_fin`.
+  auto row = [&](const u32x4& xf, int iy, auto FINc, auto MIDc, auto INIc, fl_h2 (&fin)[NCH * 2], fl_h2 (&mid)[NCH * 2],
+                 fl_h2 (&ini)[NCH * 2], int oy_fin) {
+    constexpr bool FIN = decltype(FINc)::value, MID = decltype(MIDc)::value, INI = decltype(INIc)::value;
+    const float hi = (col_ok && (unsigned)iy < (unsigned)p.H) ? 6.f : 0.f;  // zero padding of the EXPANDED tensor
+    const bool store_row = FIN && oy_fin >= oy0 && oy_fin <= oy1;               // wave-uniform
+    u32x4 resv[NFO];
+    if (FIN && store_row && p.residual) {  // issued early; consumed in the epilogue
+#pragma unroll
+      for (int f = 0; f < NFO; ++f) {
+        const int co = f * 16 + (int)fg * 4;
+        uint2 r = make_uint2(0u, 0u);
+        if (out_lane && co < Cout) r = *reinterpret_cast<const uint2*>(ximg + ((size_t)oy_fin * p.W + oxl) * Cin + co);
+        resv[f] = u32x4{r.x, r.y, 0u, 0u};
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      // the weights are loop invariant: without this the compiler keeps ALL of them in registers across the rows
+      // (hundreds of VGPRs, spilled); they are to be re-read from LDS (broadcast reads, cheap) where they are used
+      asm volatile("" ::: "memory");
+      const u32x4 wa = *reinterpret_cast<const u32x4*>(smem + L::we + (c * 64 + (int)lane) * 16);
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(smem + L::sb + (c * 4 + (int)fg) * 32);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + L::sb + (c * 4 + (int)fg) * 32 + 16);
+      const f32x4 e = fl_mfma<DT>(wa, xf, f32x4{0.f, 0.f, 0.f, 0.f});  // D[hc = 16c + 4fg + r][px = fr]
+      const u32 e0 = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(fmaf(e[0], sv[0], bv[0]), 0.f, hi),
+                                                                        __builtin_amdgcn_fmed3f(fmaf(e[1], sv[1], bv[1]), 0.f, hi)));
+      const u32 e1 = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(fmaf(e[2], sv[2], bv[2]), 0.f, hi),
+                                                                        __builtin_amdgcn_fmed3f(fmaf(e[3], sv[3], bv[3]), 0.f, hi)));
+      const fl_h2 c0 = fl_as_h2(e0), c1 = fl_as_h2(e1);
+      const fl_h2 l0 = fl_as_h2(fl_from_left(e0)), l1 = fl_as_h2(fl_from_left(e1));
+      const fl_h2 r0 = fl_as_h2(fl_from_right(e0)), r1 = fl_as_h2(fl_from_right(e1));
+      auto taps = [&](int ky, fl_h2& a0, fl_h2& a1, bool init) {
+        const unsigned char* w = smem + L::wd + ((c * 9 + ky * 3) * 4 + (int)fg) * 8;
+        const uint2 w0 = *reinterpret_cast<const uint2*>(w), w1 = *reinterpret_cast<const uint2*>(w + 32),
+                    w2 = *reinterpret_cast<const uint2*>(w + 64);
+        fl_h2 s0 = init ? zero2 : a0, s1 = init ? zero2 : a1;
+        s0 = __builtin_elementwise_fma(l0, fl_as_h2(w0.x), s0);
+        s1 = __builtin_elementwise_fma(l1, fl_as_h2(w0.y), s1);
+        s0 = __builtin_elementwise_fma(c0, fl_as_h2(w1.x), s0);
+        s1 = __builtin_elementwise_fma(c1, fl_as_h2(w1.y), s1);
+        s0 = __builtin_elementwise_fma(r0, fl_as_h2(w2.x), s0);
+        s1 = __builtin_elementwise_fma(r1, fl_as_h2(w2.y), s1);
+        // pin the results here: the updates of the rows that finish LATER are only used by the next row's code, and the
+        // compiler otherwise sinks them below this row's (conditional) projection -- with every chunk's E values and
+        // weights kept alive until then (400 live registers)
+        asm volatile("" : "+v"(s0), "+v"(s1));
+        a0 = s0;
+        a1 = s1;
+      };
+      if constexpr (INI) taps(0, ini[2 * c], ini[2 * c + 1], true);
+      if constexpr (MID) taps(1, mid[2 * c], mid[2 * c + 1], false);
+      if constexpr (FIN) taps(2, fin[2 * c], fin[2 * c + 1], false);
+      // chunks are independent: left alone, the scheduler hoists every chunk's weight reads and MFMA to the top of the
+      // row (and of the next rows) and spills hundreds of registers; one chunk ahead is all the overlap needed
+      if (c & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (FIN) {
+      if (store_row) {
+        // ---- the output row is complete: bias + ReLU6 in place, then it IS the projection's B operand --------------
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const uint2 bdv = *reinterpret_cast<const uint2*>(smem + L::bd + (c * 4 + (int)fg) * 8);
+          fin[2 * c] = __builtin_elementwise_min(__builtin_elementwise_max(fin[2 * c] + fl_as_h2(bdv.x), zero2), six2);
+          fin[2 * c + 1] = __builtin_elementwise_min(__builtin_elementwise_max(fin[2 * c + 1] + fl_as_h2(bdv.y), zero2), six2);
+        }
+        asm volatile("" ::: "memory");
+        f32x4 yacc[NFO];
+#pragma unroll
+        for (int f = 0; f < NFO; ++f) yacc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          u32x4 db;
+          db[0] = fl_as_u32(fin[4 * t]);
+          db[1] = fl_as_u32(fin[4 * t + 1]);
+          if (2 * t + 1 < NCH) {
+            db[2] = fl_as_u32(fin[(4 * t + 2 < NCH * 2) ? 4 * t + 2 : 0]);
+            db[3] = fl_as_u32(fin[(4 * t + 3 < NCH * 2) ? 4 * t + 3 : 0]);
+          } else {
+            db[2] = 0u;
+            db[3] = 0u;
+          }
+#pragma unroll
+          for (int f = 0; f < NFO; ++f) {
+            const u32x4 wf = *reinterpret_cast<const u32x4*>(smem + L::wp + ((f * T + t) * 64 + (int)lane) * 16);
+            yacc[f] = fl_mfma<SSDK_F16>(wf, db, yacc[f]);  // D[co = 16f + 4fg + r][px = fr]
+          }
+        }
+        if (out_lane) {
+          u16* yrow = p.y + (((size_t)n * p.Ho + oy_fin) * p.Wo + oxl) * Cout;
+#pragma unroll
+          for (int f = 0; f < NFO; ++f) {
+            const int co = f * 16 + (int)fg * 4;
+            if (co < Cout) {
+              const f32x4 spv = *reinterpret_cast<const f32x4*>(smem + L::spb + (f * 4 + (int)fg) * 32);
+              const f32x4 bpv = *reinterpret_cast<const f32x4*>(smem + L::spb + (f * 4 + (int)fg) * 32 + 16);
+              // (hardware packed conversions: round to nearest even like the integer sequence of ssdk_mbconv.hip)
+              u32 h01 = fl_pack2<DT>(fmaf(yacc[f][0], spv[0], bpv[0]), fmaf(yacc[f][1], spv[1], bpv[1]));
+              u32 h23 = fl_pack2<DT>(fmaf(yacc[f][2], spv[2], bpv[2]), fmaf(yacc[f][3], spv[3], bpv[3]));
+              if (p.residual) {  // the block's output is rounded to the model dtype first, then x is added (torch's tensor add)
+                const u32 x01 = resv[f][0], x23 = resv[f][1];
+                h01 = fl_pack2<DT>(fl_from16<DT>(h01 & 0xffffu) + fl_from16<DT>(x01 & 0xffffu), fl_from16<DT>(h01 >> 16) + fl_from16<DT>(x01 >> 16));
+                h23 = fl_pack2<DT>(fl_from16<DT>(h23 & 0xffffu) + fl_from16<DT>(x23 & 0xffffu), fl_from16<DT>(h23 >> 16) + fl_from16<DT>(x23 >> 16));
+              }
+              *reinterpret_cast<uint2*>(yrow + co) = make_uint2(h01, h23);
+            }
+          }
+        }
+      }
+    }
+  };
+
+  const auto Y = std::true_type{};
+  const auto No = std::false_type{};
+  // The row loop is a plain counted loop over groups of 3 (stride 1) / 4 (stride 2) rows, so that the three
+  // accumulator sets rotate through fixed registers; the up to 2 / 3 surplus rows at the end of a segment compute
+  // into accumulators nobody stores (their output rows lie past oy1).
+  if constexpr (S == 1) {
+    // input rows oy0-1 .. oy1+1; input row r is the first row of output r+1, the middle of r, the last of r-1
+    const int rend = oy1 + 1;
+    u32x4 xn = load_x(oy0 - 1);
+    for (int r = oy0 - 1; r <= rend; r += 3) {
+      u32x4 xc = xn;
+      xn = load_x(r + 1);
+      row(xc, r, Y, Y, Y, accA, accB, accC, r - 1);
+      xc = xn;
+      xn = load_x(r + 2);
+      row(xc, r + 1, Y, Y, Y, accB, accC, accA, r);
+      xc = xn;
+      xn = load_x(r + 3);
+      row(xc, r + 2, Y, Y, Y, accC, accA, accB, r + 1);
+    }
+  } else {
+    // input rows 2*oy0-1 .. 2*oy1+1; odd row 2m+1: last row of output m, first of m+1; even row 2m: middle of m
+    const int rend = 2 * oy1 + 1;
+    u32x4 xn = load_x(2 * oy0 - 1);
+    for (int r = 2 * oy0 - 1; r <= rend; r += 4) {
+      u32x4 xc = xn;
+      xn = load_x(r + 1);
+      row(xc, r, Y, No, Y, accA, accC, accB, (r - 1) / 2);          // odd: finishes A, starts B
+      xc = xn;
+      xn = load_x(r + 2);
+      row(xc, r + 1, No, Y, No, accC, accB, accC, 0);               // even: middle of B
+      xc = xn;
+      xn = load_x(r + 3);
+      row(xc, r + 2, Y, No, Y, accB, accC, accA, (r + 1) / 2);      // odd: finishes B, starts A
+      xc = xn;
+      xn = load_x(r + 4);
+      row(xc, r + 3, No, Y, No, accC, accA, accC, 0);               // even: middle of A
+    }
+  }
+}
+
+template <int DT, int S, int NCH, int NFO>
+static void flow_launch(const FlowParams& p, unsigned grid, hipStream_t stream) {
+  constexpr int lds = FlowLds<NCH, NFO>::bytes;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<DT, S, NCH, NFO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((mbflow_kernel<DT, S, NCH, NFO>), dim3(grid), dim3(kFlowThreads), lds, stream, p);
+}
+
+template <int DT, int S>
+static bool flow_dispatch(const FlowParams& p, int nch, int nfo, unsigned grid, hipStream_t stream) {
+#define SSDK_FLOW(NCH_, NFO_)                                   \
+  if (nch == NCH_ && nfo == NFO_) {                             \
+    flow_launch<DT, S, NCH_, NFO_>(p, grid, stream);            \
+    return true;                                                \
+  }
+  SSDK_FLOW(6, 2)
+  SSDK_FLOW(9, 2)
+  SSDK_FLOW(12, 2)
+  SSDK_FLOW(12, 4)
+#undef SSDK_FLOW
+  return false;
+}
+
+static std::atomic<int> g_flow_variant{0};  // ssdk_mbconv_set_variant: 0 auto, 1 register-flow wherever it exists, -1 never
+
+// Returns 1 when the block is not one of this kernel's (the caller then runs ssdk_mbconv.hip's), 0 after a launch.
+int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
+  static const int env = getenv("SSDK_MB_FLOW") ? atoi(getenv("SSDK_MB_FLOW")) : 0;  // automatic selection off until it wins
+  const int variant = g_flow_variant.load(std::memory_order_relaxed);
+  if ((!env && variant <= 0) || variant < 0 || d->stem || d->Cin > 32 || (d->Cin % 8) || d->Chid > 192 || (d->Chid % 16) || d->Cout > 64 || (d->Cout % 8)) return 1;
+  const int nch = d->Chid / 16, nfo = d->Cout <= 32 ? 2 : 4;
+  if (!((nch == 6 || nch == 9 || nch == 12) && (nfo == 2 || nch == 12))) return 1;
+  FlowParams p;
+  p.x = (const u16*)d->x;
+  p.y = (u16*)d->y;
+  p.we = (const u16*)d->w_expand;
+  p.se = d->scale_expand;
+  p.be = d->bias_expand;
+  p.wd = (const u16*)d->w_dw;
+  p.bd = (const u16*)d->bias_dw;
+  p.wp = (const u16*)d->w_project;
+  p.sp = d->scale_project;
+  p.bp = d->bias_project;
+  p.N = d->N;
+  p.H = d->H;
+  p.W = d->W;
+  p.Cin = d->Cin;
+  p.Chid = d->Chid;
+  p.Cout = d->Cout;
+  p.Ho = (d->H + 2 - 3) / d->stride + 1;
+  p.Wo = (d->W + 2 - 3) / d->stride + 1;
+  p.residual = d->residual;
+  const int ow = d->stride == 1 ? 14 : 7;
+  p.strips = (p.Wo + ow - 1) / ow;
+  // rows per segment: long segments amortise the two halo rows, short ones give the chip enough waves (>= ~3 per SIMD)
+  static const int env_rs = getenv("SSDK_MB_FLOW_RS") ? atoi(getenv("SSDK_MB_FLOW_RS")) : 0;
+  int rs = 64;
+  while (rs > 8 && (long)d->N * p.strips * ((p.Ho + rs - 1) / rs) < 3072) rs >>= 1;
+  // small maps (64x64 at batch 64) would need segments of 8 rows: 10 + 2 rows computed for 8, on top of the strip halo --
+  // the LDS-tiled kernel is the better tool there
+  static const int env_min_rs = getenv("SSDK_MB_FLOW_MINRS") ? atoi(getenv("SSDK_MB_FLOW_MINRS")) : 16;
+  if (rs < env_min_rs && env_rs <= 0 && variant <= 0) return 1;
+  if (env_rs > 0) rs = env_rs;
+  if (rs > p.Ho) rs = p.Ho;
+  p.rs = rs;
+  p.segs = (p.Ho + rs - 1) / rs;
+  const long items = (long)d->N * p.strips * p.segs;
+  const unsigned grid = (unsigned)((items + 3) / 4);
+  bool ok;
+  if (d->dtype == SSDK_BF16) ok = d->stride == 1 ? flow_dispatch<SSDK_BF16, 1>(p, nch, nfo, grid, stream) : flow_dispatch<SSDK_BF16, 2>(p, nch, nfo, grid, stream);
+  else ok = d->stride == 1 ? flow_dispatch<SSDK_F16, 1>(p, nch, nfo, grid, stream) : flow_dispatch<SSDK_F16, 2>(p, nch, nfo, grid, stream);
+  return ok ? 0 : 1;
+}
+
+}  // namespace ssdk
+
+extern "C" int ssdk_mbconv_set_variant(int variant) {
+  if (variant < -1 || variant > 1) {
+    ssdk::set_error("mbconv_set_variant: -1 (LDS-tiled kernel only), 0 (automatic) or 1 (register-flow kernel wherever it exists)");
+    return SSDK_E_BADARG;
+  }
+  ssdk::g_flow_variant.store(variant, std::memory_order_relaxed);
+  return SSDK_OK;
+}

@@ -454,10 +454,13 @@ MB = [  # cin, cout, stride, h, w  (hidden = 6*cin)
 ]
 
 
-@pytest.mark.parametrize("cin,cout,stride,h,w", MB)
-def test_fused_inverted_residual_block(cin, cout, stride, h, w):
-    """The one-kernel MobileNetV2 block against the torch fp32 block on bf16-rounded weights."""
+@pytest.mark.parametrize("variant", ["tiled", "flow"])
+@pytest.mark.parametrize("cin,cout,stride,h,w", MB + [(16, 24, 2, 61, 45), (24, 24, 1, 33, 30), (24, 32, 2, 40, 29), (32, 32, 1, 31, 17)])
+def test_fused_inverted_residual_block(cin, cout, stride, h, w, variant):
+    """The one-kernel MobileNetV2 block against the torch fp32 block on bf16-rounded weights: the LDS-tiled kernel
+    and, where it exists (Cin <= 32), the register-flow kernel (ragged strips, several row segments)."""
     import torch
+    from ssds import _native as N
     from ssds.modeling.layers import fused_conv as FC
     from ssds.modeling.layers.planner import groups_of
     from ssds.modeling.nets.mobilenet import InvertedResidual
@@ -487,9 +490,15 @@ def test_fused_inverted_residual_block(cin, cout, stride, h, w):
     groups = groups_of(blk.conv)
     assert FC.MbPack.supported(groups, blk.use_res_connect)
     pk = FC.MbPack(groups, blk.use_res_connect, dtype)
-    got = FC.mbconv_native(x.cuda(), pk)
+    N.check(N.lib.ssdk_mbconv_set_variant(1 if variant == "flow" else -1), "set_variant")
+    try:
+        got = FC.mbconv_native(x.cuda(), pk)
+        name = N.last_kernel()
+    finally:
+        N.check(N.lib.ssdk_mbconv_set_variant(0), "set_variant")
+    assert ("mbflow" in name) == (variant == "flow" and cin <= 32), name
     assert got.is_contiguous(memory_format=torch.channels_last)
-    _check(got, y, dtype, "mbconv %d->%d s%d" % (cin, cout, stride))
+    _check(got, y, dtype, "mbconv %d->%d s%d (%s)" % (cin, cout, stride, name))
 
 
 @pytest.mark.parametrize("layout", ["nchw", "nhwc"])
