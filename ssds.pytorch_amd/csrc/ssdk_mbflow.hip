@@ -99,7 +99,7 @@ struct FlowLds {
   static constexpr int bytes = spb + NFO * 4 * 32;
 };
 
-template <int DT, int S, int NCH, int NFO>
+template <int DT, int S, int NCH, int NFO, int NS>
 __global__ __launch_bounds__(kFlowThreads, 2) void mbflow_kernel(const FlowParams p) {
   using L = FlowLds<NCH, NFO>;
   constexpr int T = L::T;
@@ -153,89 +153,121 @@ __global__ __launch_bounds__(kFlowThreads, 2) void mbflow_kernel(const FlowParam
   }
   __syncthreads();
 
-  // ---- this wave's work item: (image, row segment, strip) -----------------------------------------------------------
+  // ---- this wave's work item: (image, row segment, group of NS neighbouring strips) ---------------------------------
+  // NS strips per wave share every weight read (the LDS pipe was the co-bottleneck with one strip) and give the wave two
+  // independent MFMA -> BN -> DPP -> FMA chains to interleave.
   const u32 item = blockIdx.x * (kFlowThreads / 64) + wave;
-  const u32 per_img = (u32)(p.strips * p.segs);
+  const int groups = (p.strips + NS - 1) / NS;
+  const u32 per_img = (u32)(groups * p.segs);
   if (item >= (u32)p.N * per_img) return;
   const int n = (int)(item / per_img), rem = (int)(item % per_img);
-  const int seg = rem / p.strips, strip = rem % p.strips;
+  const int seg = rem / groups, grp = rem % groups;
   constexpr int OW = S == 1 ? 14 : 7;             // output pixels per strip
-  const int ox0 = strip * OW;
-  const int ix = ox0 * S - 1 + (int)fr;            // this lane's input column
-  const bool col_ok = (unsigned)ix < (unsigned)p.W;
   const int oy0 = seg * p.rs, oy1 = (oy0 + p.rs < p.Ho ? oy0 + p.rs : p.Ho) - 1;  // output rows [oy0, oy1]
-  // output pixel of this lane (if any): stride 1: lanes 1..14, stride 2: odd lanes 1..13
-  const int oxl = S == 1 ? ox0 + (int)fr - 1 : ox0 + ((int)fr - 1) / 2;
-  const bool out_lane = (S == 1 ? (fr >= 1u && fr <= 14u) : ((fr & 1u) && fr <= 13u)) && oxl < p.Wo;
+  int ix[NS], oxl[NS];
+  bool col_ok[NS], out_lane[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int strip = grp * NS + s;
+    const int ox0 = strip * OW;
+    ix[s] = ox0 * S - 1 + (int)fr;                 // this lane's input column in strip s
+    col_ok[s] = strip < p.strips && (unsigned)ix[s] < (unsigned)p.W;
+    // output pixel of this lane (if any): stride 1: lanes 1..14, stride 2: odd lanes 1..13
+    oxl[s] = S == 1 ? ox0 + (int)fr - 1 : ox0 + ((int)fr - 1) / 2;
+    out_lane[s] = strip < p.strips && (S == 1 ? (fr >= 1u && fr <= 14u) : ((fr & 1u) && fr <= 13u)) && oxl[s] < p.Wo;
+  }
 
   const u16* ximg = p.x + (size_t)n * p.H * p.W * Cin;
   const bool k_ok = fg * 8u < (u32)Cin;
-  auto load_x = [&](int iy) -> u32x4 {  // B operand of the expand GEMM: 8 input channels of pixel (iy, ix)
+  auto load_x = [&](int iy, int s) -> u32x4 {  // B operand of the expand GEMM: 8 input channels of pixel (iy, ix[s])
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (k_ok && col_ok && (unsigned)iy < (unsigned)p.H) v = *reinterpret_cast<const u32x4*>(ximg + ((size_t)iy * p.W + ix) * Cin + fg * 8);
+    if (k_ok && col_ok[s] && (unsigned)iy < (unsigned)p.H)
+      v = *reinterpret_cast<const u32x4*>(ximg + ((size_t)iy * p.W + ix[s]) * Cin + fg * 8);
     return v;
   };
 
-  fl_h2 accA[NCH * 2], accB[NCH * 2], accC[NCH * 2];
+  fl_h2 accA[NS][NCH * 2], accB[NS][NCH * 2], accC[NS][NCH * 2];
   const fl_h2 zero2 = {(_Float16)0.f, (_Float16)0.f}, six2 = {(_Float16)6.f, (_Float16)6.f};
 
   // One input row.  FIN / MID / INI: the row is the last (ky = 2) / middle (ky = 1) / first (ky = 0) row of the output
   // row accumulated in fin / mid / ini; the FIN row is completed, projected and stored as output row `oy_fin`.
-  auto row = [&](const u32x4& xf, int iy, auto FINc, auto MIDc, auto INIc, fl_h2 (&fin)[NCH * 2], fl_h2 (&mid)[NCH * 2],
-                 fl_h2 (&ini)[NCH * 2], int oy_fin) {
+  auto row = [&](const u32x4 (&xf)[NS], int iy, auto FINc, auto MIDc, auto INIc, fl_h2 (&fin)[NS][NCH * 2],
+                 fl_h2 (&mid)[NS][NCH * 2], fl_h2 (&ini)[NS][NCH * 2], int oy_fin) {
     constexpr bool FIN = decltype(FINc)::value, MID = decltype(MIDc)::value, INI = decltype(INIc)::value;
-    const float hi = (col_ok && (unsigned)iy < (unsigned)p.H) ? 6.f : 0.f;  // zero padding of the EXPANDED tensor
+    float hi[NS];  // zero padding of the EXPANDED tensor: pixels outside the image clamp to [0, 0]
+#pragma unroll
+    for (int s = 0; s < NS; ++s) hi[s] = (col_ok[s] && (unsigned)iy < (unsigned)p.H) ? 6.f : 0.f;
     const bool store_row = FIN && oy_fin >= oy0 && oy_fin <= oy1;               // wave-uniform
-    u32x4 resv[NFO];
+    uint2 resv[NS][NFO];
     if (FIN && store_row && p.residual) {  // issued early; consumed in the epilogue
 #pragma unroll
-      for (int f = 0; f < NFO; ++f) {
-        const int co = f * 16 + (int)fg * 4;
-        uint2 r = make_uint2(0u, 0u);
-        if (out_lane && co < Cout) r = *reinterpret_cast<const uint2*>(ximg + ((size_t)oy_fin * p.W + oxl) * Cin + co);
-        resv[f] = u32x4{r.x, r.y, 0u, 0u};
-      }
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int f = 0; f < NFO; ++f) {
+          const int co = f * 16 + (int)fg * 4;
+          uint2 r = make_uint2(0u, 0u);
+          if (out_lane[s] && co < Cout) r = *reinterpret_cast<const uint2*>(ximg + ((size_t)oy_fin * p.W + oxl[s]) * Cin + co);
+          resv[s][f] = r;
+        }
     }
+    // Software pipeline over the chunks: while the VALU works on chunk c (BN, clamp, DPP shifts, taps) the matrix pipe
+    // already runs the expand MFMAs of chunk c+1, and the A fragment of chunk c+2 is on its way from LDS.
+    asm volatile("" ::: "memory");  // (the weights are loop invariant: they are to be RE-READ from LDS, broadcast reads,
+                                    //  not kept in hundreds of registers across the rows)
+    f32x4 e_cur[NS], e_nxt[NS];
+    u32x4 wa = *reinterpret_cast<const u32x4*>(smem + L::we + (int)lane * 16);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) e_cur[s] = fl_mfma<DT>(wa, xf[s], f32x4{0.f, 0.f, 0.f, 0.f});  // D[hc = 16c + 4fg + r][px = fr]
+    if (NCH > 1) wa = *reinterpret_cast<const u32x4*>(smem + L::we + (64 + (int)lane) * 16);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      // the weights are loop invariant: without this the compiler keeps ALL of them in registers across the rows
-      // (hundreds of VGPRs, spilled); they are to be re-read from LDS (broadcast reads, cheap) where they are used
       asm volatile("" ::: "memory");
-      const u32x4 wa = *reinterpret_cast<const u32x4*>(smem + L::we + (c * 64 + (int)lane) * 16);
       const f32x4 sv = *reinterpret_cast<const f32x4*>(smem + L::sb + (c * 4 + (int)fg) * 32);
       const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + L::sb + (c * 4 + (int)fg) * 32 + 16);
-      const f32x4 e = fl_mfma<DT>(wa, xf, f32x4{0.f, 0.f, 0.f, 0.f});  // D[hc = 16c + 4fg + r][px = fr]
-      const u32 e0 = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(fmaf(e[0], sv[0], bv[0]), 0.f, hi),
-                                                                        __builtin_amdgcn_fmed3f(fmaf(e[1], sv[1], bv[1]), 0.f, hi)));
-      const u32 e1 = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(fmaf(e[2], sv[2], bv[2]), 0.f, hi),
-                                                                        __builtin_amdgcn_fmed3f(fmaf(e[3], sv[3], bv[3]), 0.f, hi)));
-      const fl_h2 c0 = fl_as_h2(e0), c1 = fl_as_h2(e1);
-      const fl_h2 l0 = fl_as_h2(fl_from_left(e0)), l1 = fl_as_h2(fl_from_left(e1));
-      const fl_h2 r0 = fl_as_h2(fl_from_right(e0)), r1 = fl_as_h2(fl_from_right(e1));
-      auto taps = [&](int ky, fl_h2& a0, fl_h2& a1, bool init) {
-        const unsigned char* w = smem + L::wd + ((c * 9 + ky * 3) * 4 + (int)fg) * 8;
-        const uint2 w0 = *reinterpret_cast<const uint2*>(w), w1 = *reinterpret_cast<const uint2*>(w + 32),
-                    w2 = *reinterpret_cast<const uint2*>(w + 64);
-        fl_h2 s0 = init ? zero2 : a0, s1 = init ? zero2 : a1;
-        s0 = __builtin_elementwise_fma(l0, fl_as_h2(w0.x), s0);
-        s1 = __builtin_elementwise_fma(l1, fl_as_h2(w0.y), s1);
-        s0 = __builtin_elementwise_fma(c0, fl_as_h2(w1.x), s0);
-        s1 = __builtin_elementwise_fma(c1, fl_as_h2(w1.y), s1);
-        s0 = __builtin_elementwise_fma(r0, fl_as_h2(w2.x), s0);
-        s1 = __builtin_elementwise_fma(r1, fl_as_h2(w2.y), s1);
-        // pin the results here: the updates of the rows that finish LATER are only used by the next row's code, and the
-        // compiler otherwise sinks them below this row's (conditional) projection -- with every chunk's E values and
-        // weights kept alive until then (400 live registers)
-        asm volatile("" : "+v"(s0), "+v"(s1));
-        a0 = s0;
-        a1 = s1;
-      };
-      if constexpr (INI) taps(0, ini[2 * c], ini[2 * c + 1], true);
-      if constexpr (MID) taps(1, mid[2 * c], mid[2 * c + 1], false);
-      if constexpr (FIN) taps(2, fin[2 * c], fin[2 * c + 1], false);
-      // chunks are independent: left alone, the scheduler hoists every chunk's weight reads and MFMA to the top of the
-      // row (and of the next rows) and spills hundreds of registers; one chunk ahead is all the overlap needed
-      if (c & 1) __builtin_amdgcn_sched_barrier(0);
+      uint2 wt[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const uint2*>(smem + L::wd + ((c * 9 + t) * 4 + (int)fg) * 8);
+      if (c + 1 < NCH) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) e_nxt[s] = fl_mfma<DT>(wa, xf[s], f32x4{0.f, 0.f, 0.f, 0.f});
+        if (c + 2 < NCH) wa = *reinterpret_cast<const u32x4*>(smem + L::we + ((c + 2) * 64 + (int)lane) * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const f32x4 e = e_cur[s];
+        const u32 e0 = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(fmaf(e[0], sv[0], bv[0]), 0.f, hi[s]),
+                                                                          __builtin_amdgcn_fmed3f(fmaf(e[1], sv[1], bv[1]), 0.f, hi[s])));
+        const u32 e1 = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(fmaf(e[2], sv[2], bv[2]), 0.f, hi[s]),
+                                                                          __builtin_amdgcn_fmed3f(fmaf(e[3], sv[3], bv[3]), 0.f, hi[s])));
+        const fl_h2 c0 = fl_as_h2(e0), c1 = fl_as_h2(e1);
+        const fl_h2 l0 = fl_as_h2(fl_from_left(e0)), l1 = fl_as_h2(fl_from_left(e1));
+        const fl_h2 r0 = fl_as_h2(fl_from_right(e0)), r1 = fl_as_h2(fl_from_right(e1));
+        auto taps = [&](int ky, fl_h2& a0, fl_h2& a1, bool init) {
+          const uint2 w0 = wt[ky * 3], w1 = wt[ky * 3 + 1], w2 = wt[ky * 3 + 2];
+          fl_h2 s0 = init ? zero2 : a0, s1 = init ? zero2 : a1;
+          s0 = __builtin_elementwise_fma(l0, fl_as_h2(w0.x), s0);
+          s1 = __builtin_elementwise_fma(l1, fl_as_h2(w0.y), s1);
+          s0 = __builtin_elementwise_fma(c0, fl_as_h2(w1.x), s0);
+          s1 = __builtin_elementwise_fma(c1, fl_as_h2(w1.y), s1);
+          s0 = __builtin_elementwise_fma(r0, fl_as_h2(w2.x), s0);
+          s1 = __builtin_elementwise_fma(r1, fl_as_h2(w2.y), s1);
+          // pin the results here: the updates of the rows that finish LATER are only used by the next row's code, and the
+          // compiler otherwise sinks them below this row's (conditional) projection -- with every chunk's E values and
+          // weights kept alive until then (400 live registers)
+          asm volatile("" : "+v"(s0), "+v"(s1));
+          a0 = s0;
+          a1 = s1;
+        };
+        if constexpr (INI) taps(0, ini[s][2 * c], ini[s][2 * c + 1], true);
+        if constexpr (MID) taps(1, mid[s][2 * c], mid[s][2 * c + 1], false);
+        if constexpr (FIN) taps(2, fin[s][2 * c], fin[s][2 * c + 1], false);
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) e_cur[s] = e_nxt[s];
+      // chunks are independent: left alone, the scheduler hoists every chunk's weight reads to the top of the row and
+      // runs out of registers
+      __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (FIN) {
       if (store_row) {
@@ -243,48 +275,60 @@ __global__ __launch_bounds__(kFlowThreads, 2) void mbflow_kernel(const FlowParam
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
           const uint2 bdv = *reinterpret_cast<const uint2*>(smem + L::bd + (c * 4 + (int)fg) * 8);
-          fin[2 * c] = __builtin_elementwise_min(__builtin_elementwise_max(fin[2 * c] + fl_as_h2(bdv.x), zero2), six2);
-          fin[2 * c + 1] = __builtin_elementwise_min(__builtin_elementwise_max(fin[2 * c + 1] + fl_as_h2(bdv.y), zero2), six2);
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            fin[s][2 * c] = __builtin_elementwise_min(__builtin_elementwise_max(fin[s][2 * c] + fl_as_h2(bdv.x), zero2), six2);
+            fin[s][2 * c + 1] = __builtin_elementwise_min(__builtin_elementwise_max(fin[s][2 * c + 1] + fl_as_h2(bdv.y), zero2), six2);
+          }
         }
         asm volatile("" ::: "memory");
-        f32x4 yacc[NFO];
+        f32x4 yacc[NS][NFO];
 #pragma unroll
-        for (int f = 0; f < NFO; ++f) yacc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int f = 0; f < NFO; ++f) yacc[s][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          u32x4 db;
-          db[0] = fl_as_u32(fin[4 * t]);
-          db[1] = fl_as_u32(fin[4 * t + 1]);
-          if (2 * t + 1 < NCH) {
-            db[2] = fl_as_u32(fin[(4 * t + 2 < NCH * 2) ? 4 * t + 2 : 0]);
-            db[3] = fl_as_u32(fin[(4 * t + 3 < NCH * 2) ? 4 * t + 3 : 0]);
-          } else {
-            db[2] = 0u;
-            db[3] = 0u;
+          u32x4 db[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            db[s][0] = fl_as_u32(fin[s][4 * t]);
+            db[s][1] = fl_as_u32(fin[s][4 * t + 1]);
+            if (2 * t + 1 < NCH) {
+              db[s][2] = fl_as_u32(fin[s][(4 * t + 2 < NCH * 2) ? 4 * t + 2 : 0]);
+              db[s][3] = fl_as_u32(fin[s][(4 * t + 3 < NCH * 2) ? 4 * t + 3 : 0]);
+            } else {
+              db[s][2] = 0u;
+              db[s][3] = 0u;
+            }
           }
 #pragma unroll
           for (int f = 0; f < NFO; ++f) {
             const u32x4 wf = *reinterpret_cast<const u32x4*>(smem + L::wp + ((f * T + t) * 64 + (int)lane) * 16);
-            yacc[f] = fl_mfma<SSDK_F16>(wf, db, yacc[f]);  // D[co = 16f + 4fg + r][px = fr]
+#pragma unroll
+            for (int s = 0; s < NS; ++s) yacc[s][f] = fl_mfma<SSDK_F16>(wf, db[s], yacc[s][f]);  // D[co = 16f + 4fg + r][px = fr]
           }
         }
-        if (out_lane) {
-          u16* yrow = p.y + (((size_t)n * p.Ho + oy_fin) * p.Wo + oxl) * Cout;
 #pragma unroll
-          for (int f = 0; f < NFO; ++f) {
-            const int co = f * 16 + (int)fg * 4;
-            if (co < Cout) {
-              const f32x4 spv = *reinterpret_cast<const f32x4*>(smem + L::spb + (f * 4 + (int)fg) * 32);
-              const f32x4 bpv = *reinterpret_cast<const f32x4*>(smem + L::spb + (f * 4 + (int)fg) * 32 + 16);
-              // (hardware packed conversions: round to nearest even like the integer sequence of ssdk_mbconv.hip)
-              u32 h01 = fl_pack2<DT>(fmaf(yacc[f][0], spv[0], bpv[0]), fmaf(yacc[f][1], spv[1], bpv[1]));
-              u32 h23 = fl_pack2<DT>(fmaf(yacc[f][2], spv[2], bpv[2]), fmaf(yacc[f][3], spv[3], bpv[3]));
-              if (p.residual) {  // the block's output is rounded to the model dtype first, then x is added (torch's tensor add)
-                const u32 x01 = resv[f][0], x23 = resv[f][1];
-                h01 = fl_pack2<DT>(fl_from16<DT>(h01 & 0xffffu) + fl_from16<DT>(x01 & 0xffffu), fl_from16<DT>(h01 >> 16) + fl_from16<DT>(x01 >> 16));
-                h23 = fl_pack2<DT>(fl_from16<DT>(h23 & 0xffffu) + fl_from16<DT>(x23 & 0xffffu), fl_from16<DT>(h23 >> 16) + fl_from16<DT>(x23 >> 16));
+        for (int s = 0; s < NS; ++s) {
+          if (out_lane[s]) {
+            u16* yrow = p.y + (((size_t)n * p.Ho + oy_fin) * p.Wo + oxl[s]) * Cout;
+#pragma unroll
+            for (int f = 0; f < NFO; ++f) {
+              const int co = f * 16 + (int)fg * 4;
+              if (co < Cout) {
+                const f32x4 spv = *reinterpret_cast<const f32x4*>(smem + L::spb + (f * 4 + (int)fg) * 32);
+                const f32x4 bpv = *reinterpret_cast<const f32x4*>(smem + L::spb + (f * 4 + (int)fg) * 32 + 16);
+                // (hardware packed conversions: round to nearest even like the integer sequence of ssdk_mbconv.hip)
+                u32 h01 = fl_pack2<DT>(fmaf(yacc[s][f][0], spv[0], bpv[0]), fmaf(yacc[s][f][1], spv[1], bpv[1]));
+                u32 h23 = fl_pack2<DT>(fmaf(yacc[s][f][2], spv[2], bpv[2]), fmaf(yacc[s][f][3], spv[3], bpv[3]));
+                if (p.residual) {  // the block's output is rounded to the model dtype first, then x is added (torch's tensor add)
+                  const u32 x01 = resv[s][f].x, x23 = resv[s][f].y;
+                  h01 = fl_pack2<DT>(fl_from16<DT>(h01 & 0xffffu) + fl_from16<DT>(x01 & 0xffffu), fl_from16<DT>(h01 >> 16) + fl_from16<DT>(x01 >> 16));
+                  h23 = fl_pack2<DT>(fl_from16<DT>(h23 & 0xffffu) + fl_from16<DT>(x23 & 0xffffu), fl_from16<DT>(h23 >> 16) + fl_from16<DT>(x23 >> 16));
+                }
+                *reinterpret_cast<uint2*>(yrow + co) = make_uint2(h01, h23);
               }
-              *reinterpret_cast<uint2*>(yrow + co) = make_uint2(h01, h23);
             }
           }
         }
@@ -294,50 +338,56 @@ __global__ __launch_bounds__(kFlowThreads, 2) void mbflow_kernel(const FlowParam
 
   const auto Y = std::true_type{};
   const auto No = std::false_type{};
+  auto load_row = [&](u32x4 (&dst)[NS], int iy) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) dst[s] = load_x(iy, s);
+  };
   // The row loop is a plain counted loop over groups of 3 (stride 1) / 4 (stride 2) rows, so that the three
   // accumulator sets rotate through fixed registers; the up to 2 / 3 surplus rows at the end of a segment compute
-  // into accumulators nobody stores (their output rows lie past oy1).
+  // into accumulators nobody stores (their output rows lie past oy1).  x is fetched one row ahead.
+  u32x4 xa[NS], xb[NS];
   if constexpr (S == 1) {
     // input rows oy0-1 .. oy1+1; input row r is the first row of output r+1, the middle of r, the last of r-1
     const int rend = oy1 + 1;
-    u32x4 xn = load_x(oy0 - 1);
-    for (int r = oy0 - 1; r <= rend; r += 3) {
-      u32x4 xc = xn;
-      xn = load_x(r + 1);
-      row(xc, r, Y, Y, Y, accA, accB, accC, r - 1);
-      xc = xn;
-      xn = load_x(r + 2);
-      row(xc, r + 1, Y, Y, Y, accB, accC, accA, r);
-      xc = xn;
-      xn = load_x(r + 3);
-      row(xc, r + 2, Y, Y, Y, accC, accA, accB, r + 1);
+    load_row(xa, oy0 - 1);
+    for (int r = oy0 - 1; r <= rend; r += 6) {
+      load_row(xb, r + 1);
+      row(xa, r, Y, Y, Y, accA, accB, accC, r - 1);
+      load_row(xa, r + 2);
+      row(xb, r + 1, Y, Y, Y, accB, accC, accA, r);
+      load_row(xb, r + 3);
+      row(xa, r + 2, Y, Y, Y, accC, accA, accB, r + 1);
+      load_row(xa, r + 4);
+      row(xb, r + 3, Y, Y, Y, accA, accB, accC, r + 2);
+      load_row(xb, r + 5);
+      row(xa, r + 4, Y, Y, Y, accB, accC, accA, r + 3);
+      load_row(xa, r + 6);
+      row(xb, r + 5, Y, Y, Y, accC, accA, accB, r + 4);
     }
   } else {
     // input rows 2*oy0-1 .. 2*oy1+1; odd row 2m+1: last row of output m, first of m+1; even row 2m: middle of m
     const int rend = 2 * oy1 + 1;
-    u32x4 xn = load_x(2 * oy0 - 1);
+    load_row(xa, 2 * oy0 - 1);
     for (int r = 2 * oy0 - 1; r <= rend; r += 4) {
-      u32x4 xc = xn;
-      xn = load_x(r + 1);
-      row(xc, r, Y, No, Y, accA, accC, accB, (r - 1) / 2);          // odd: finishes A, starts B
-      xc = xn;
-      xn = load_x(r + 2);
-      row(xc, r + 1, No, Y, No, accC, accB, accC, 0);               // even: middle of B
-      xc = xn;
-      xn = load_x(r + 3);
-      row(xc, r + 2, Y, No, Y, accB, accC, accA, (r + 1) / 2);      // odd: finishes B, starts A
-      xc = xn;
-      xn = load_x(r + 4);
-      row(xc, r + 3, No, Y, No, accC, accA, accC, 0);               // even: middle of A
+      load_row(xb, r + 1);
+      row(xa, r, Y, No, Y, accA, accC, accB, (r - 1) / 2);          // odd: finishes A, starts B
+      load_row(xa, r + 2);
+      row(xb, r + 1, No, Y, No, accC, accB, accC, 0);               // even: middle of B
+      load_row(xb, r + 3);
+      row(xa, r + 2, Y, No, Y, accB, accC, accA, (r + 1) / 2);      // odd: finishes B, starts A
+      load_row(xa, r + 4);
+      row(xb, r + 3, No, Y, No, accC, accA, accC, 0);               // even: middle of A
     }
   }
 }
 
+constexpr int kFlowNS = 2;  // strips per wave
+
 template <int DT, int S, int NCH, int NFO>
 static void flow_launch(const FlowParams& p, unsigned grid, hipStream_t stream) {
   constexpr int lds = FlowLds<NCH, NFO>::bytes;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<DT, S, NCH, NFO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  hipLaunchKernelGGL((mbflow_kernel<DT, S, NCH, NFO>), dim3(grid), dim3(kFlowThreads), lds, stream, p);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<DT, S, NCH, NFO, kFlowNS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL((mbflow_kernel<DT, S, NCH, NFO, kFlowNS>), dim3(grid), dim3(kFlowThreads), lds, stream, p);
 }
 
 template <int DT, int S>
@@ -388,8 +438,9 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
   p.strips = (p.Wo + ow - 1) / ow;
   // rows per segment: long segments amortise the two halo rows, short ones give the chip enough waves (>= ~3 per SIMD)
   static const int env_rs = getenv("SSDK_MB_FLOW_RS") ? atoi(getenv("SSDK_MB_FLOW_RS")) : 0;
+  const int groups = (p.strips + kFlowNS - 1) / kFlowNS;
   int rs = 64;
-  while (rs > 8 && (long)d->N * p.strips * ((p.Ho + rs - 1) / rs) < 3072) rs >>= 1;
+  while (rs > 8 && (long)d->N * groups * ((p.Ho + rs - 1) / rs) < 2048) rs >>= 1;
   // small maps (64x64 at batch 64) would need segments of 8 rows: 10 + 2 rows computed for 8, on top of the strip halo --
   // the LDS-tiled kernel is the better tool there
   static const int env_min_rs = getenv("SSDK_MB_FLOW_MINRS") ? atoi(getenv("SSDK_MB_FLOW_MINRS")) : 16;
@@ -398,7 +449,7 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
   if (rs > p.Ho) rs = p.Ho;
   p.rs = rs;
   p.segs = (p.Ho + rs - 1) / rs;
-  const long items = (long)d->N * p.strips * p.segs;
+  const long items = (long)d->N * groups * p.segs;
   const unsigned grid = (unsigned)((items + 3) / 4);
   bool ok;
   if (d->dtype == SSDK_BF16) ok = d->stride == 1 ? flow_dispatch<SSDK_BF16, 1>(p, nch, nfo, grid, stream) : flow_dispatch<SSDK_BF16, 2>(p, nch, nfo, grid, stream);

@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+for v in 0 1 0 1; do SSDK_MB_FLOW=$v timeout 200 python bench.py --layers 1 --cpu-sample 0 --steps 20 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('FLOW=$v', d['value'], d['verified'], [(r['kernel'][:8], round(r['us'],1)) for r in d['layers'][:5]])"; done
