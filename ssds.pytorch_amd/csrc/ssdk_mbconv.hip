@@ -762,7 +762,7 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
               "channels %% 8 == 0)", d->Cin, d->Chid, d->Cout, d->stride, d->residual);
     return SSDK_E_BADARG;
   }
-  if (!stem && launch_mbflow(d, stream) == 0) return check_launch("mbflow_kernel");  // high-resolution blocks: ssdk_mbflow.hip
+  if (launch_mbflow(d, stream) == 0) return check_launch(stem ? "mbflow_kernel(stem)" : "mbflow_kernel");  // high-resolution blocks: ssdk_mbflow.hip
   MbParams p;
   p.x = (const u16*)d->x;
   p.y = (u16*)d->y;

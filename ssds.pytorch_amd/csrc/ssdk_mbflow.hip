@@ -48,6 +48,9 @@ struct FlowParams {
   const float* bp;
   int N, H, W, Cin, Chid, Cout, Ho, Wo, residual;
   int strips, segs, rs;  // strips per row, row segments per image, output rows per segment
+  // STEM instances: x is the image [N][Cimg<=3][Himg][Wimg] (layout 1, NCHW) or [N][Himg][Wimg][Cimg] (2, NHWC); the
+  // "expand" GEMM is the 3x3 / stride 2 / pad 1 stem convolution, K = (ci, ky, kx) = 27 of 32; H, W = its output grid
+  int Himg, Wimg, Cimg, layout;
 };
 
 template <int DT>
@@ -99,8 +102,8 @@ struct FlowLds {
   static constexpr int bytes = spb + NFO * 4 * 32;
 };
 
-template <int DT, int S, int NCH, int NFO, int NS>
-__global__ __launch_bounds__(kFlowThreads, 2) void mbflow_kernel(const FlowParams p) {
+template <int DT, int S, int NCH, int NFO, int NS, bool STEM = false>
+__global__ __launch_bounds__(kFlowThreads, STEM ? 3 : 2) void mbflow_kernel(const FlowParams p) {
   using L = FlowLds<NCH, NFO>;
   constexpr int T = L::T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -112,7 +115,18 @@ __global__ __launch_bounds__(kFlowThreads, 2) void mbflow_kernel(const FlowParam
   for (u32 i = tid; i < (u32)(NCH * 64); i += kFlowThreads) {  // expand weights as A fragments: row hc = 16c + fr, k = 8fg ..
     const u32 c = i >> 6, l = i & 63u, hc = c * 16 + (l & 15u), k0 = (l >> 4) * 8;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (hc < (u32)Chid && k0 < (u32)Cin) v = *reinterpret_cast<const u32x4*>(p.we + (size_t)hc * Cin + k0);
+    if constexpr (STEM) {  // p.we: [Chid][ky 3][kx padded to 8][ci padded to 4]; this kernel's k = ci*9 + ky*3 + kx
+      if (hc < (u32)Chid) {
+#pragma unroll
+        for (u32 j = 0; j < 8; ++j) {
+          const u32 k = k0 + j, ci = k / 9u, ky = (k % 9u) / 3u, kx = k % 3u;
+          const u32 h = (k < 27u && ci < (u32)p.Cimg) ? (u32)p.we[(size_t)hc * 96 + (ky * 8 + kx) * 4 + ci] : 0u;
+          v[j >> 1] |= h << ((j & 1u) * 16u);
+        }
+      }
+    } else {
+      if (hc < (u32)Chid && k0 < (u32)Cin) v = *reinterpret_cast<const u32x4*>(p.we + (size_t)hc * Cin + k0);
+    }
     *reinterpret_cast<u32x4*>(smem + L::we + i * 16) = v;
   }
   for (u32 i = tid; i < (u32)(NCH * 4); i += kFlowThreads) {  // expand BN, depthwise bias: 4 channels 16c + 4g ..
@@ -177,13 +191,74 @@ __global__ __launch_bounds__(kFlowThreads, 2) void mbflow_kernel(const FlowParam
     out_lane[s] = strip < p.strips && (S == 1 ? (fr >= 1u && fr <= 14u) : ((fr & 1u) && fr <= 13u)) && oxl[s] < p.Wo;
   }
 
-  const u16* ximg = p.x + (size_t)n * p.H * p.W * Cin;
+  const u16* ximg = STEM ? p.x + (size_t)n * p.Cimg * p.Himg * p.Wimg : p.x + (size_t)n * p.H * p.W * Cin;
   const bool k_ok = fg * 8u < (u32)Cin;
+  // STEM: the B operand is an im2col row of the image, k = ci*9 + ky*3 + kx (lane group fg holds k = 8fg .. 8fg+7):
+  // eight 2-byte loads per lane at offsets that do not depend on the row or the strip (uniform base + per-lane offset)
+  int voff[STEM ? 8 : 1];
+  u32 kmw[STEM ? 4 : 1], kyM[STEM ? 3 : 1], xm[STEM ? NS : 1];
+  bool strip_inner[STEM ? NS : 1];
+  const int pstr = STEM ? (p.layout == 1 ? 1 : p.Cimg) : 0, cstr = STEM ? (p.layout == 1 ? p.Himg * p.Wimg : 1) : 0;
+  if constexpr (STEM) {
+    u32 kvalid = 0;
+    kyM[0] = kyM[1] = kyM[2] = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const u32 k = fg * 8u + (u32)j, ci = k / 9u, ky = (k % 9u) / 3u, kx = k % 3u;
+      const bool kv = k < 27u && ci < (u32)p.Cimg;
+      voff[j] = kv ? (2 * (int)fr * pstr + (int)ci * cstr + ((int)ky * p.Wimg + (int)kx) * pstr) : 0;
+      kvalid |= kv ? (1u << j) : 0u;
+      kyM[0] |= (kv && ky == 0u) ? (1u << j) : 0u;
+      kyM[1] |= (kv && ky == 1u) ? (1u << j) : 0u;
+      kyM[2] |= (kv && ky == 2u) ? (1u << j) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kmw[q] = (((kvalid >> (2 * q)) & 1u) ? 0xffffu : 0u) | (((kvalid >> (2 * q + 1)) & 1u) ? 0xffff0000u : 0u);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      u32 m = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const u32 kx = (fg * 8u + (u32)j) % 3u;
+        if (((kvalid >> j) & 1u) && col_ok[s] && (unsigned)(2 * ix[s] - 1 + (int)kx) < (unsigned)p.Wimg) m |= 1u << j;
+      }
+      xm[s] = m;
+      strip_inner[s] = __ballot(m != kvalid) == 0ull;  // every lane of the strip may load all its k unmasked
+    }
+  }
   auto load_x = [&](int iy, int s) -> u32x4 {  // B operand of the expand GEMM: 8 input channels of pixel (iy, ix[s])
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (k_ok && col_ok[s] && (unsigned)iy < (unsigned)p.H)
-      v = *reinterpret_cast<const u32x4*>(ximg + ((size_t)iy * p.W + ix[s]) * Cin + fg * 8);
-    return v;
+    if constexpr (STEM) {
+      if ((unsigned)iy >= (unsigned)p.H) return v;  // (wave-uniform) the whole row is padding of the block's input
+      const int strip = grp * NS + s;
+      // element offset of (image row 2iy-1, image column 2*ix-1 of the strip's lane 0, channel 0) -- may be negative at the edges
+      const int base = ((2 * iy - 1) * p.Wimg + (2 * (strip * 14 - 1) - 1)) * pstr;
+      const bool rows_inner = 2 * iy - 1 >= 0 && 2 * iy + 1 < p.Himg;
+      u32 h[8];
+      if (rows_inner && strip_inner[s]) {  // wave-uniform
+        const u16* b = ximg + base;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (u32)b[voff[j]];
+      } else {
+        u32 rowmask = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) rowmask |= ((unsigned)(2 * iy - 1 + ky) < (unsigned)p.Himg) ? kyM[ky] : 0u;
+        const u32 vm = xm[s] & rowmask;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool ok = (vm >> j) & 1u;
+          const u32 t = (u32)ximg[ok ? base + voff[j] : 0];
+          h[j] = ok ? t : 0u;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = (h[2 * q] | (h[2 * q + 1] << 16)) & kmw[q];
+      return v;
+    } else {
+      if (k_ok && col_ok[s] && (unsigned)iy < (unsigned)p.H)
+        v = *reinterpret_cast<const u32x4*>(ximg + ((size_t)iy * p.W + ix[s]) * Cin + fg * 8);
+      return v;
+    }
   };
 
   fl_h2 accA[NS][NCH * 2], accB[NS][NCH * 2], accC[NS][NCH * 2];
@@ -199,7 +274,7 @@ __global__ __launch_bounds__(kFlowThreads, 2) void mbflow_kernel(const FlowParam
     for (int s = 0; s < NS; ++s) hi[s] = (col_ok[s] && (unsigned)iy < (unsigned)p.H) ? 6.f : 0.f;
     const bool store_row = FIN && oy_fin >= oy0 && oy_fin <= oy1;               // wave-uniform
     uint2 resv[NS][NFO];
-    if (FIN && store_row && p.residual) {  // issued early; consumed in the epilogue
+    if (!STEM && FIN && store_row && p.residual) {  // issued early; consumed in the epilogue
 #pragma unroll
       for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -322,7 +397,7 @@ __global__ __launch_bounds__(kFlowThreads, 2) void mbflow_kernel(const FlowParam
                 // (hardware packed conversions: round to nearest even like the integer sequence of ssdk_mbconv.hip)
                 u32 h01 = fl_pack2<DT>(fmaf(yacc[s][f][0], spv[0], bpv[0]), fmaf(yacc[s][f][1], spv[1], bpv[1]));
                 u32 h23 = fl_pack2<DT>(fmaf(yacc[s][f][2], spv[2], bpv[2]), fmaf(yacc[s][f][3], spv[3], bpv[3]));
-                if (p.residual) {  // the block's output is rounded to the model dtype first, then x is added (torch's tensor add)
+                if (!STEM && p.residual) {  // the block's output is rounded to the model dtype first, then x is added (torch's tensor add)
                   const u32 x01 = resv[s][f].x, x23 = resv[s][f].y;
                   h01 = fl_pack2<DT>(fl_from16<DT>(h01 & 0xffffu) + fl_from16<DT>(x01 & 0xffffu), fl_from16<DT>(h01 >> 16) + fl_from16<DT>(x01 >> 16));
                   h23 = fl_pack2<DT>(fl_from16<DT>(h23 & 0xffffu) + fl_from16<DT>(x23 & 0xffffu), fl_from16<DT>(h23 >> 16) + fl_from16<DT>(x23 >> 16));
@@ -411,9 +486,15 @@ static std::atomic<int> g_flow_variant{0};  // ssdk_mbconv_set_variant: 0 auto, 
 int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
   static const int env = getenv("SSDK_MB_FLOW") ? atoi(getenv("SSDK_MB_FLOW")) : 0;  // automatic selection off until it wins
   const int variant = g_flow_variant.load(std::memory_order_relaxed);
-  if ((!env && variant <= 0) || variant < 0 || d->stem || d->Cin > 32 || (d->Cin % 8) || d->Chid > 192 || (d->Chid % 16) || d->Cout > 64 || (d->Cout % 8)) return 1;
-  const int nch = d->Chid / 16, nfo = d->Cout <= 32 ? 2 : 4;
-  if (!((nch == 6 || nch == 9 || nch == 12) && (nfo == 2 || nch == 12))) return 1;
+  if ((!env && variant <= 0) || variant < 0) return 1;
+  const bool stem = d->stem != 0;
+  if (stem) {  // network stem + expand-free first block: 3x3/s2 conv (<= 3 channels -> 32) as the "expand" GEMM, dw stride 1, 32 -> 16
+    if (d->Cin > 3 || d->Chid != 32 || d->Cout != 16 || d->stride != 1 || d->residual) return 1;
+  } else if (d->Cin > 32 || (d->Cin % 8) || d->Chid > 192 || (d->Chid % 16) || d->Cout > 64 || (d->Cout % 8)) {
+    return 1;
+  }
+  const int nch = d->Chid / 16, nfo = stem ? 1 : (d->Cout <= 32 ? 2 : 4);
+  if (!stem && !((nch == 6 || nch == 9 || nch == 12) && (nfo == 2 || nch == 12))) return 1;
   FlowParams p;
   p.x = (const u16*)d->x;
   p.y = (u16*)d->y;
@@ -429,10 +510,19 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
   p.H = d->H;
   p.W = d->W;
   p.Cin = d->Cin;
+  p.Himg = d->H;
+  p.Wimg = d->W;
+  p.Cimg = d->Cin;
+  p.layout = d->stem;
+  if (stem) {  // the block's input grid is the stem convolution's output
+    p.H = (d->H + 2 - 3) / 2 + 1;
+    p.W = (d->W + 2 - 3) / 2 + 1;
+    p.Cin = 32;
+  }
   p.Chid = d->Chid;
   p.Cout = d->Cout;
-  p.Ho = (d->H + 2 - 3) / d->stride + 1;
-  p.Wo = (d->W + 2 - 3) / d->stride + 1;
+  p.Ho = (p.H + 2 - 3) / d->stride + 1;
+  p.Wo = (p.W + 2 - 3) / d->stride + 1;
   p.residual = d->residual;
   const int ow = d->stride == 1 ? 14 : 7;
   p.strips = (p.Wo + ow - 1) / ow;
@@ -452,6 +542,17 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
   const long items = (long)d->N * groups * p.segs;
   const unsigned grid = (unsigned)((items + 3) / 4);
   bool ok;
+  if (stem) {
+    constexpr int lds = FlowLds<2, 1>::bytes;
+    if (d->dtype == SSDK_BF16) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<SSDK_BF16, 1, 2, 1, kFlowNS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL((mbflow_kernel<SSDK_BF16, 1, 2, 1, kFlowNS, true>), dim3(grid), dim3(kFlowThreads), lds, stream, p);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<SSDK_F16, 1, 2, 1, kFlowNS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL((mbflow_kernel<SSDK_F16, 1, 2, 1, kFlowNS, true>), dim3(grid), dim3(kFlowThreads), lds, stream, p);
+    }
+    return 0;
+  }
   if (d->dtype == SSDK_BF16) ok = d->stride == 1 ? flow_dispatch<SSDK_BF16, 1>(p, nch, nfo, grid, stream) : flow_dispatch<SSDK_BF16, 2>(p, nch, nfo, grid, stream);
   else ok = d->stride == 1 ? flow_dispatch<SSDK_F16, 1>(p, nch, nfo, grid, stream) : flow_dispatch<SSDK_F16, 2>(p, nch, nfo, grid, stream);
   return ok ? 0 : 1;

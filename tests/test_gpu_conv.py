@@ -501,9 +501,10 @@ def test_fused_inverted_residual_block(cin, cout, stride, h, w, variant):
     _check(got, y, dtype, "mbconv %d->%d s%d (%s)" % (cin, cout, stride, name))
 
 
+@pytest.mark.parametrize("variant", ["tiled", "flow"])
 @pytest.mark.parametrize("layout", ["nchw", "nhwc"])
-@pytest.mark.parametrize("h,w", [(64, 64), (37, 45)])
-def test_fused_stem_block(layout, h, w):
+@pytest.mark.parametrize("h,w", [(64, 64), (37, 45), (130, 121)])
+def test_fused_stem_block(layout, h, w, variant):
     """Stem (3x3/s2, BN, ReLU6) + expand-free first block (dw 3x3, pw 32->16) as ONE launch from the image."""
     import torch
     from ssds.modeling.layers import fused_conv as FC
@@ -533,8 +534,15 @@ def test_fused_stem_block(layout, h, w):
     assert FC.MbPack.stem_supported(sg, bg)
     pk = FC.MbPack(bg, False, dtype, stem_group=sg[0])
     xin = x.cuda() if layout == "nchw" else x.cuda().contiguous(memory_format=torch.channels_last)
-    got = FC.mbconv_native(xin, pk)
-    _check(got, y, dtype, "stem block " + layout)
+    from ssds import _native as N
+    N.check(N.lib.ssdk_mbconv_set_variant(1 if variant == "flow" else -1), "set_variant")
+    try:
+        got = FC.mbconv_native(xin, pk)
+        name = N.last_kernel()
+    finally:
+        N.check(N.lib.ssdk_mbconv_set_variant(0), "set_variant")
+    assert ("mbflow" in name) == (variant == "flow"), name
+    _check(got, y, dtype, "stem block %s (%s)" % (layout, name))
 
 
 @pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
