@@ -51,6 +51,9 @@ struct FlowParams {
   // STEM instances: x is the image [N][Cimg<=3][Himg][Wimg] (layout 1, NCHW) or [N][Himg][Wimg][Cimg] (2, NHWC); the
   // "expand" GEMM is the 3x3 / stride 2 / pad 1 stem convolution, K = (ci, ky, kx) = 27 of 32; H, W = its output grid
   int Himg, Wimg, Cimg, layout;
+  // STEM: row segments that touch the top / bottom of the image run in their own launch (the YE instance masks rows per
+  // value; the interior instance has a branch-free gather): bit s of seg_mask = segment s belongs to THIS launch
+  unsigned long long seg_mask;
 };
 
 template <int DT>
@@ -102,8 +105,8 @@ struct FlowLds {
   static constexpr int bytes = spb + NFO * 4 * 32;
 };
 
-template <int DT, int S, int NCH, int NFO, int NS, bool STEM = false>
-__global__ __launch_bounds__(kFlowThreads, STEM ? 3 : 2) void mbflow_kernel(const FlowParams p) {
+template <int DT, int S, int NCH, int NFO, int NS, bool STEM = false, bool YE = false>
+__global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_kernel(const FlowParams p) {
   using L = FlowLds<NCH, NFO>;
   constexpr int T = L::T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -170,12 +173,21 @@ __global__ __launch_bounds__(kFlowThreads, STEM ? 3 : 2) void mbflow_kernel(cons
   // ---- this wave's work item: (image, row segment, group of NS neighbouring strips) ---------------------------------
   // NS strips per wave share every weight read (the LDS pipe was the co-bottleneck with one strip) and give the wave two
   // independent MFMA -> BN -> DPP -> FMA chains to interleave.
-  const u32 item = blockIdx.x * (kFlowThreads / 64) + wave;
+  // (readfirstlane: the compiler cannot see that tid >> 6 is wave-uniform; with it the item's coordinates, row pointers
+  //  and row predicates live in SGPRs and the address arithmetic leaves the VALU)
+  const u32 item = blockIdx.x * (kFlowThreads / 64) + (u32)__builtin_amdgcn_readfirstlane((int)wave);
   const int groups = (p.strips + NS - 1) / NS;
-  const u32 per_img = (u32)(groups * p.segs);
+  const int nseg = STEM ? __builtin_popcountll(p.seg_mask) : p.segs;
+  const u32 per_img = (u32)(groups * nseg);
   if (item >= (u32)p.N * per_img) return;
   const int n = (int)(item / per_img), rem = (int)(item % per_img);
-  const int seg = rem / groups, grp = rem % groups;
+  int seg = rem / groups;
+  const int grp = rem % groups;
+  if constexpr (STEM) {  // the seg-th set bit of the mask
+    unsigned long long m = p.seg_mask;
+    for (int i = 0; i < seg; ++i) m &= m - 1;
+    seg = __builtin_ctzll(m);
+  }
   constexpr int OW = S == 1 ? 14 : 7;             // output pixels per strip
   const int oy0 = seg * p.rs, oy1 = (oy0 + p.rs < p.Ho ? oy0 + p.rs : p.Ho) - 1;  // output rows [oy0, oy1]
   int ix[NS], oxl[NS];
@@ -195,9 +207,11 @@ __global__ __launch_bounds__(kFlowThreads, STEM ? 3 : 2) void mbflow_kernel(cons
   const bool k_ok = fg * 8u < (u32)Cin;
   // STEM: the B operand is an im2col row of the image, k = ci*9 + ky*3 + kx (lane group fg holds k = 8fg .. 8fg+7):
   // eight 2-byte loads per lane at offsets that do not depend on the row or the strip (uniform base + per-lane offset)
-  int voff[STEM ? 8 : 1];
-  u32 kmw[STEM ? 4 : 1], kyM[STEM ? 3 : 1], xm[STEM ? NS : 1];
-  bool strip_inner[STEM ? NS : 1];
+  // Per-lane byte offsets of the eight values, fixed for the whole kernel, with the column validity folded in: a value
+  // that falls left / right of the image (or a k >= 27) carries an offset far outside the buffer, and a buffer load
+  // out of range returns 0 without touching memory -- the steady-state loop needs no masks and no branches.
+  constexpr u32 kOOR = 0x40000000u;
+  u32 xoff[STEM ? NS : 1][STEM ? 8 : 1], xoff0[(STEM && !YE) ? NS : 1][(STEM && !YE) ? 8 : 1], kmw[STEM ? 4 : 1], kyM[STEM ? 3 : 1];
   const int pstr = STEM ? (p.layout == 1 ? 1 : p.Cimg) : 0, cstr = STEM ? (p.layout == 1 ? p.Himg * p.Wimg : 1) : 0;
   if constexpr (STEM) {
     u32 kvalid = 0;
@@ -206,58 +220,69 @@ __global__ __launch_bounds__(kFlowThreads, STEM ? 3 : 2) void mbflow_kernel(cons
     for (int j = 0; j < 8; ++j) {
       const u32 k = fg * 8u + (u32)j, ci = k / 9u, ky = (k % 9u) / 3u, kx = k % 3u;
       const bool kv = k < 27u && ci < (u32)p.Cimg;
-      voff[j] = kv ? (2 * (int)fr * pstr + (int)ci * cstr + ((int)ky * p.Wimg + (int)kx) * pstr) : 0;
+      const u32 vo = (u32)(2 * (int)fr * pstr + (int)ci * cstr + ((int)ky * p.Wimg + (int)kx) * pstr) * 2u;
       kvalid |= kv ? (1u << j) : 0u;
       kyM[0] |= (kv && ky == 0u) ? (1u << j) : 0u;
       kyM[1] |= (kv && ky == 1u) ? (1u << j) : 0u;
       kyM[2] |= (kv && ky == 2u) ? (1u << j) : 0u;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        xoff[s][j] = (kv && col_ok[s] && (unsigned)(2 * ix[s] - 1 + (int)kx) < (unsigned)p.Wimg) ? vo : kOOR;
+        if constexpr (!YE) xoff0[s][j] = ky == 0u ? kOOR : xoff[s][j];  // stem row 0: its ky = 0 taps lie above the image
+      }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) kmw[q] = (((kvalid >> (2 * q)) & 1u) ? 0xffffu : 0u) | (((kvalid >> (2 * q + 1)) & 1u) ? 0xffff0000u : 0u);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      u32 m = 0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const u32 kx = (fg * 8u + (u32)j) % 3u;
-        if (((kvalid >> j) & 1u) && col_ok[s] && (unsigned)(2 * ix[s] - 1 + (int)kx) < (unsigned)p.Wimg) m |= 1u << j;
-      }
-      xm[s] = m;
-      strip_inner[s] = __ballot(m != kvalid) == 0ull;  // every lane of the strip may load all its k unmasked
-    }
   }
-  auto load_x = [&](int iy, int s) -> u32x4 {  // B operand of the expand GEMM: 8 input channels of pixel (iy, ix[s])
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if constexpr (STEM) {
-      if ((unsigned)iy >= (unsigned)p.H) return v;  // (wave-uniform) the whole row is padding of the block's input
-      const int strip = grp * NS + s;
-      // element offset of (image row 2iy-1, image column 2*ix-1 of the strip's lane 0, channel 0) -- may be negative at the edges
-      const int base = ((2 * iy - 1) * p.Wimg + (2 * (strip * 14 - 1) - 1)) * pstr;
-      const bool rows_inner = 2 * iy - 1 >= 0 && 2 * iy + 1 < p.Himg;
-      u32 h[8];
-      if (rows_inner && strip_inner[s]) {  // wave-uniform
-        const u16* b = ximg + base;
+  // STEM: the buffer is this image, opened `xmargin` bytes EARLY so that the (row, strip) offset in the SGPR is never
+  // negative (row 0 starts one image row and three pixels before the image); nothing in front of the image is ever
+  // read: the values that would lie there carry out-of-range offsets.
+  const int xmargin = STEM ? (p.Wimg + 8) * pstr * 2 : 0;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<const unsigned char*>(ximg) - xmargin), 0, STEM ? p.Cimg * p.Himg * p.Wimg * 2 + xmargin : 0, 0x00020000);
+  // The loaded words of one strip row, NOT yet packed (STEM: eight 16-bit values in eight registers): packing them
+  // here would put the s_waitcnt right behind the loads, and the row is fetched one row AHEAD of its use.
+  constexpr int XW = STEM ? 8 : 4;
+  struct XRow {
+    u32 w[XW];
+  };
+  auto load_x = [&](int iy, int s) -> XRow {  // B operand of the expand GEMM: 8 input channels of pixel (iy, ix[s])
+    XRow out;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) h[j] = (u32)b[voff[j]];
-      } else {
+    for (int q = 0; q < XW; ++q) out.w[q] = 0u;
+    if constexpr (STEM) {
+      const int strip = grp * NS + s;
+      // element offset of (image row 2iy-1, image column 2*ix-1 of the strip's lane 0, channel 0)
+      const int base = ((2 * iy - 1) * p.Wimg + (2 * (strip * 14 - 1) - 1)) * pstr;
+      if constexpr (YE) {  // items that touch the top / bottom of the image: rows outside it are masked per value
         u32 rowmask = 0;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) rowmask |= ((unsigned)(2 * iy - 1 + ky) < (unsigned)p.Himg) ? kyM[ky] : 0u;
-        const u32 vm = xm[s] & rowmask;
+        for (int ky = 0; ky < 3; ++ky)
+          rowmask |= ((unsigned)iy < (unsigned)p.H && (unsigned)(2 * iy - 1 + ky) < (unsigned)p.Himg) ? kyM[ky] : 0u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const bool ok = (vm >> j) & 1u;
-          const u32 t = (u32)ximg[ok ? base + voff[j] : 0];
-          h[j] = ok ? t : 0u;
+          const u32 off = (((rowmask >> j) & 1u) && xoff[s][j] != kOOR) ? xoff[s][j] + (u32)(base * 2 + xmargin) : kOOR;
+          out.w[j] = (u32)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, (int)off, 0, 0);
         }
-      }
+      } else {
+        // per-lane offset in a VGPR (fixed) + the row / strip offset in an SGPR, no branch: a row outside the block's grid
+        // puts the whole row out of range through the SGPR, stem row 0 swaps in the offsets without the ky = 0 taps
+        const bool row_in = (unsigned)iy < (unsigned)p.H, top = iy == 0;  // wave-uniform
+        const int soff = row_in ? base * 2 + xmargin : (int)kOOR;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = (h[2 * q] | (h[2 * q + 1] << 16)) & kmw[q];
-      return v;
+        for (int j = 0; j < 8; ++j)
+          out.w[j] = (u32)__builtin_amdgcn_raw_buffer_load_b16(xrsrc, (int)(top ? xoff0[s][j] : xoff[s][j]), soff, 0);
+      }
+      return out;
     } else {
-      if (k_ok && col_ok[s] && (unsigned)iy < (unsigned)p.H)
-        v = *reinterpret_cast<const u32x4*>(ximg + ((size_t)iy * p.W + ix[s]) * Cin + fg * 8);
-      return v;
+      if (k_ok && col_ok[s] && (unsigned)iy < (unsigned)p.H) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(ximg + ((size_t)iy * p.W + ix[s]) * Cin + fg * 8);
+        out.w[0] = v[0];
+        out.w[1] = v[1];
+        out.w[2] = v[2];
+        out.w[3] = v[3];
+      }
+      return out;
     }
   };
 
@@ -266,9 +291,20 @@ __global__ __launch_bounds__(kFlowThreads, STEM ? 3 : 2) void mbflow_kernel(cons
 
   // One input row.  FIN / MID / INI: the row is the last (ky = 2) / middle (ky = 1) / first (ky = 0) row of the output
   // row accumulated in fin / mid / ini; the FIN row is completed, projected and stored as output row `oy_fin`.
-  auto row = [&](const u32x4 (&xf)[NS], int iy, auto FINc, auto MIDc, auto INIc, fl_h2 (&fin)[NS][NCH * 2],
+  auto row = [&](const XRow (&xraw)[NS], int iy, auto FINc, auto MIDc, auto INIc, fl_h2 (&fin)[NS][NCH * 2],
                  fl_h2 (&mid)[NS][NCH * 2], fl_h2 (&ini)[NS][NCH * 2], int oy_fin) {
     constexpr bool FIN = decltype(FINc)::value, MID = decltype(MIDc)::value, INI = decltype(INIc)::value;
+    u32x4 xf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if constexpr (STEM) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xf[s][q] = (xraw[s].w[2 * q] | (xraw[s].w[2 * q + 1] << 16)) & kmw[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xf[s][q] = xraw[s].w[q];
+      }
+    }
     float hi[NS];  // zero padding of the EXPANDED tensor: pixels outside the image clamp to [0, 0]
 #pragma unroll
     for (int s = 0; s < NS; ++s) hi[s] = (col_ok[s] && (unsigned)iy < (unsigned)p.H) ? 6.f : 0.f;
@@ -413,45 +449,47 @@ __global__ __launch_bounds__(kFlowThreads, STEM ? 3 : 2) void mbflow_kernel(cons
 
   const auto Y = std::true_type{};
   const auto No = std::false_type{};
-  auto load_row = [&](u32x4 (&dst)[NS], int iy) {
+  auto load_row = [&](XRow (&dst)[NS], int iy) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) dst[s] = load_x(iy, s);
   };
   // The row loop is a plain counted loop over groups of 3 (stride 1) / 4 (stride 2) rows, so that the three
   // accumulator sets rotate through fixed registers; the up to 2 / 3 surplus rows at the end of a segment compute
   // into accumulators nobody stores (their output rows lie past oy1).  x is fetched one row ahead.
-  u32x4 xa[NS], xb[NS];
-  if constexpr (S == 1) {
-    // input rows oy0-1 .. oy1+1; input row r is the first row of output r+1, the middle of r, the last of r-1
-    const int rend = oy1 + 1;
-    load_row(xa, oy0 - 1);
-    for (int r = oy0 - 1; r <= rend; r += 6) {
-      load_row(xb, r + 1);
-      row(xa, r, Y, Y, Y, accA, accB, accC, r - 1);
-      load_row(xa, r + 2);
-      row(xb, r + 1, Y, Y, Y, accB, accC, accA, r);
-      load_row(xb, r + 3);
-      row(xa, r + 2, Y, Y, Y, accC, accA, accB, r + 1);
-      load_row(xa, r + 4);
-      row(xb, r + 3, Y, Y, Y, accA, accB, accC, r + 2);
-      load_row(xb, r + 5);
-      row(xa, r + 4, Y, Y, Y, accB, accC, accA, r + 3);
-      load_row(xa, r + 6);
-      row(xb, r + 5, Y, Y, Y, accC, accA, accB, r + 4);
-    }
-  } else {
-    // input rows 2*oy0-1 .. 2*oy1+1; odd row 2m+1: last row of output m, first of m+1; even row 2m: middle of m
-    const int rend = 2 * oy1 + 1;
-    load_row(xa, 2 * oy0 - 1);
-    for (int r = 2 * oy0 - 1; r <= rend; r += 4) {
-      load_row(xb, r + 1);
-      row(xa, r, Y, No, Y, accA, accC, accB, (r - 1) / 2);          // odd: finishes A, starts B
-      load_row(xa, r + 2);
-      row(xb, r + 1, No, Y, No, accC, accB, accC, 0);               // even: middle of B
-      load_row(xb, r + 3);
-      row(xa, r + 2, Y, No, Y, accB, accC, accA, (r + 1) / 2);      // odd: finishes B, starts A
-      load_row(xa, r + 4);
-      row(xb, r + 3, No, Y, No, accC, accA, accC, 0);               // even: middle of A
+  XRow xa[NS], xb[NS];
+  {
+    if constexpr (S == 1) {
+      // input rows oy0-1 .. oy1+1; input row r is the first row of output r+1, the middle of r, the last of r-1
+      const int rend = oy1 + 1;
+      load_row(xa, oy0 - 1);
+      for (int r = oy0 - 1; r <= rend; r += 6) {
+        load_row(xb, r + 1);
+        row(xa, r, Y, Y, Y, accA, accB, accC, r - 1);
+        load_row(xa, r + 2);
+        row(xb, r + 1, Y, Y, Y, accB, accC, accA, r);
+        load_row(xb, r + 3);
+        row(xa, r + 2, Y, Y, Y, accC, accA, accB, r + 1);
+        load_row(xa, r + 4);
+        row(xb, r + 3, Y, Y, Y, accA, accB, accC, r + 2);
+        load_row(xb, r + 5);
+        row(xa, r + 4, Y, Y, Y, accB, accC, accA, r + 3);
+        load_row(xa, r + 6);
+        row(xb, r + 5, Y, Y, Y, accC, accA, accB, r + 4);
+      }
+    } else {
+      // input rows 2*oy0-1 .. 2*oy1+1; odd row 2m+1: last row of output m, first of m+1; even row 2m: middle of m
+      const int rend = 2 * oy1 + 1;
+      load_row(xa, 2 * oy0 - 1);
+      for (int r = 2 * oy0 - 1; r <= rend; r += 4) {
+        load_row(xb, r + 1);
+        row(xa, r, Y, No, Y, accA, accC, accB, (r - 1) / 2);          // odd: finishes A, starts B
+        load_row(xa, r + 2);
+        row(xb, r + 1, No, Y, No, accC, accB, accC, 0);               // even: middle of B
+        load_row(xb, r + 3);
+        row(xa, r + 2, Y, No, Y, accB, accC, accA, (r + 1) / 2);      // odd: finishes B, starts A
+        load_row(xa, r + 4);
+        row(xb, r + 3, No, Y, No, accC, accA, accC, 0);               // even: middle of A
+      }
     }
   }
 }
@@ -484,7 +522,7 @@ static std::atomic<int> g_flow_variant{0};  // ssdk_mbconv_set_variant: 0 auto, 
 
 // Returns 1 when the block is not one of this kernel's (the caller then runs ssdk_mbconv.hip's), 0 after a launch.
 int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
-  static const int env = getenv("SSDK_MB_FLOW") ? atoi(getenv("SSDK_MB_FLOW")) : 0;  // automatic selection off until it wins
+  static const int env = getenv("SSDK_MB_FLOW") ? atoi(getenv("SSDK_MB_FLOW")) : 1;
   const int variant = g_flow_variant.load(std::memory_order_relaxed);
   if ((!env && variant <= 0) || variant < 0) return 1;
   const bool stem = d->stem != 0;
@@ -524,6 +562,7 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
   p.Ho = (p.H + 2 - 3) / d->stride + 1;
   p.Wo = (p.W + 2 - 3) / d->stride + 1;
   p.residual = d->residual;
+  p.seg_mask = 0;
   const int ow = d->stride == 1 ? 14 : 7;
   p.strips = (p.Wo + ow - 1) / ow;
   // rows per segment: long segments amortise the two halo rows, short ones give the chip enough waves (>= ~3 per SIMD)
@@ -543,13 +582,35 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
   const unsigned grid = (unsigned)((items + 3) / 4);
   bool ok;
   if (stem) {
+    // The interior instance copes with everything above the image and with rows outside the block's grid; only a real
+    // stem row whose LAST tap row falls below the image (odd image heights) needs the masking instance.
+    if (p.segs > 64) return 1;
+    unsigned long long edge = 0;
+    for (int sgi = 0; sgi < p.segs; ++sgi) {
+      const int o0 = sgi * p.rs, o1 = (o0 + p.rs < p.Ho ? o0 + p.rs : p.Ho) - 1;
+      const int last_row = o1 + 1 < p.H - 1 ? o1 + 1 : p.H - 1;  // last real stem row the segment reads
+      if (2 * last_row + 1 >= p.Himg) edge |= 1ull << sgi;          // its ky = 2 tap lies below the image (odd heights)
+    }
+    const unsigned long long all = p.segs == 64 ? ~0ull : ((1ull << p.segs) - 1ull);
     constexpr int lds = FlowLds<2, 1>::bytes;
+    auto go = [&](auto DTc, auto YEc, unsigned long long mask) {
+      constexpr int DTv = decltype(DTc)::value;
+      constexpr bool YEv = decltype(YEc)::value;
+      if (!mask) return;
+      FlowParams q = p;
+      q.seg_mask = mask;
+      const long it = (long)d->N * groups * __builtin_popcountll(mask);
+      const unsigned g = (unsigned)((it + 3) / 4);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<DTv, 1, 2, 1, kFlowNS, true, YEv>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL((mbflow_kernel<DTv, 1, 2, 1, kFlowNS, true, YEv>), dim3(g), dim3(kFlowThreads), lds, stream, q);
+    };
     if (d->dtype == SSDK_BF16) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<SSDK_BF16, 1, 2, 1, kFlowNS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipLaunchKernelGGL((mbflow_kernel<SSDK_BF16, 1, 2, 1, kFlowNS, true>), dim3(grid), dim3(kFlowThreads), lds, stream, p);
+      go(std::integral_constant<int, SSDK_BF16>{}, std::false_type{}, all & ~edge);
+      go(std::integral_constant<int, SSDK_BF16>{}, std::true_type{}, edge);
     } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<SSDK_F16, 1, 2, 1, kFlowNS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      hipLaunchKernelGGL((mbflow_kernel<SSDK_F16, 1, 2, 1, kFlowNS, true>), dim3(grid), dim3(kFlowThreads), lds, stream, p);
+      go(std::integral_constant<int, SSDK_F16>{}, std::false_type{}, all & ~edge);
+      go(std::integral_constant<int, SSDK_F16>{}, std::true_type{}, edge);
     }
     return 0;
   }
