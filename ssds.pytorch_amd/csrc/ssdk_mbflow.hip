@@ -568,12 +568,14 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
   // rows per segment: long segments amortise the two halo rows, short ones give the chip enough waves (>= ~3 per SIMD)
   static const int env_rs = getenv("SSDK_MB_FLOW_RS") ? atoi(getenv("SSDK_MB_FLOW_RS")) : 0;
   const int groups = (p.strips + kFlowNS - 1) / kFlowNS;
+  // (measured: ~5000 items of 16-32 rows beat ~2500 of 32-64 rows; below 16 rows the two halo rows of a segment cost
+  //  too much, and a map that then yields fewer than 2048 items -- 64x64 at batch 64 -- stays with the LDS-tiled kernel)
   int rs = 64;
-  while (rs > 8 && (long)d->N * groups * ((p.Ho + rs - 1) / rs) < 2048) rs >>= 1;
-  // small maps (64x64 at batch 64) would need segments of 8 rows: 10 + 2 rows computed for 8, on top of the strip halo --
-  // the LDS-tiled kernel is the better tool there
-  static const int env_min_rs = getenv("SSDK_MB_FLOW_MINRS") ? atoi(getenv("SSDK_MB_FLOW_MINRS")) : 16;
-  if (rs < env_min_rs && env_rs <= 0 && variant <= 0) return 1;
+  while (rs > 16 && (long)d->N * groups * ((p.Ho + rs - 1) / rs) < 4096) rs >>= 1;
+  if ((long)d->N * groups * ((p.Ho + rs - 1) / rs) < 2048 && env_rs <= 0 && variant <= 0) return 1;
+  if (variant > 0) {  // forced (tests): short segments so that small maps still exercise several segments
+    while (rs > 8 && (long)d->N * groups * ((p.Ho + rs - 1) / rs) < 2048) rs >>= 1;
+  }
   if (env_rs > 0) rs = env_rs;
   if (rs > p.Ho) rs = p.Ho;
   p.rs = rs;
