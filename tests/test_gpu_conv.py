@@ -545,6 +545,52 @@ def test_fused_stem_block(layout, h, w, variant):
     _check(got, y, dtype, "stem block %s (%s)" % (layout, name))
 
 
+@pytest.mark.parametrize("cin,cout,stride,h,w", [(16, 24, 2, 70, 45), (24, 24, 1, 47, 33), (32, 64, 2, 36, 36)])
+def test_register_flow_block_fp16(cin, cout, stride, h, w):
+    """The register-flow kernel in fp16 (expand on the f16 MFMA), ragged strips and several row segments, against the
+    torch fp32 block with fp16-rounded intermediates; and the same block through the LDS-tiled kernel."""
+    import torch
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+    from ssds.modeling.layers.planner import groups_of
+    from ssds.modeling.nets.mobilenet import InvertedResidual
+
+    dtype = torch.float16
+    torch.manual_seed(cin + cout + stride)
+    blk = InvertedResidual(cin, cout, stride, 6).eval()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data = (m.weight.data * 2).to(dtype).float()
+    x = torch.randn(5, cin, h, w).to(dtype)
+    with torch.no_grad():
+        y = x.float()
+        mods = list(blk.conv.children())
+        y = mods[0](y).to(dtype).float()
+        y = mods[1](y).to(dtype).float()
+        y = mods[3](mods[2](y))
+        if blk.use_res_connect:
+            y = y.to(dtype).float() + x.float()
+    blk = blk.cuda()
+    pk = FC.MbPack(groups_of(blk.conv), blk.use_res_connect, dtype)
+    outs = {}
+    for variant, code in (("flow", 1), ("tiled", -1)):
+        N.check(N.lib.ssdk_mbconv_set_variant(code), "set_variant")
+        try:
+            outs[variant] = FC.mbconv_native(x.cuda(), pk)
+            name = N.last_kernel()
+        finally:
+            N.check(N.lib.ssdk_mbconv_set_variant(0), "set_variant")
+        assert ("mbflow" in name) == (variant == "flow"), name
+        _check(outs[variant], y, dtype, "fp16 block %d->%d s%d (%s)" % (cin, cout, stride, name))
+    # the two kernels run the same arithmetic in the same order: they agree far inside the tolerance against torch
+    assert float((outs["flow"].float() - outs["tiled"].float()).abs().max()) <= 2e-2 * max(1.0, float(y.abs().max()))
+
+
 @pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
 def test_fused_blocks_16x16_tiles(dtype_name):
     """Stride-1 blocks on maps large enough for >= 512 tiles run on the 16x16-tile instantiations (strip-tiled
