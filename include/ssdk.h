@@ -385,12 +385,32 @@ typedef struct ssdk_pool_desc {
 } ssdk_pool_desc;
 int ssdk_maxpool3x3s2(const ssdk_pool_desc* desc, void* stream);
 
+/* One SSD "extra" layer on a small map (ssd.py:88-99 / basic_layers.py:40-57: Conv 1x1 + BN + act, then Conv 3x3 / stride
+ * 2 / pad 1 + BN + act) as ONE launch with the intermediate map in LDS: on the 8x8 ... 2x2 maps the two convolutions
+ * are microseconds of work behind two launches, split-K fences and latency-bound k-loops.
+ *   x [N][H][W][Cin] NHWC, w1 [Cmid][Cin] (KRSC 1x1), w2 [Cout][3][3][Cmid], scale / bias fp32 (folded BN),
+ *   y [N][Ho][Wo][Cout] NHWC with Ho = (H - 1) / 2 + 1; dtype SSDK_BF16 | SSDK_F16; act SSDK_ACT_NONE | RELU | RELU6.
+ * Covered: H*W <= 16 or == 64, Cin % 128 == 0, Cmid 64 | 128, Cout 128 | 256 (anything else: SSDK_E_BADARG -- run the
+ * two convolutions through ssdk_conv). */
+typedef struct ssdk_xpair_desc {
+  const void* x;
+  void* y;
+  const void* w1;
+  const float* scale1;
+  const float* bias1;
+  const void* w2;
+  const float* scale2;
+  const float* bias2;
+  int32_t N, H, W, Cin, Cmid, Cout, act1, act2, dtype, pad;
+} ssdk_xpair_desc;
+int ssdk_xpair(const ssdk_xpair_desc* desc, void* stream);
+
 /* Plan executor: a recorded forward as a list of tagged ops (topological order), replayed with one host call.
  * lane 0 ops run in order on the caller's stream.  lane 1 ops (the multibox heads: leaves that depend only on
  * ops listed before them) are forked onto the context's side stream and run concurrently with the following
  * lane 0 ops; they use the upper half of the workspace, and everything is joined back onto the caller's stream
  * before the call returns.  Buffers read or written by lane 1 ops must not be reused by later ops of the list. */
-enum { SSDK_OP_CONV = 0, SSDK_OP_MBCONV = 1, SSDK_OP_FUSE = 2, SSDK_OP_STEM7 = 3, SSDK_OP_POOL = 4 };
+enum { SSDK_OP_CONV = 0, SSDK_OP_MBCONV = 1, SSDK_OP_FUSE = 2, SSDK_OP_STEM7 = 3, SSDK_OP_POOL = 4, SSDK_OP_XPAIR = 5 };
 typedef struct ssdk_op {
   int32_t kind, lane;
   ssdk_conv_desc conv;
@@ -398,6 +418,7 @@ typedef struct ssdk_op {
   ssdk_fuse_desc fuse;
   ssdk_stem_desc stem;
   ssdk_pool_desc pool;
+  ssdk_xpair_desc xpair;
 } ssdk_op;
 int ssdk_run_ops(const ssdk_op* ops, int n, void* workspace, size_t workspace_bytes, void* stream);
 int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* workspace, size_t workspace_bytes, void* stream);

@@ -1321,6 +1321,7 @@ extern "C" int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* 
       else if (ops[i].kind == SSDK_OP_FUSE) rc = ssdk_fuse(&ops[i].fuse, st);
       else if (ops[i].kind == SSDK_OP_STEM7) rc = ssdk_conv_stem7(&ops[i].stem, st);
       else if (ops[i].kind == SSDK_OP_POOL) rc = ssdk_maxpool3x3s2(&ops[i].pool, st);
+      else if (ops[i].kind == SSDK_OP_XPAIR) rc = ssdk_xpair(&ops[i].xpair, st);
       else {
         set_error("unknown op kind %d", ops[i].kind);
         rc = SSDK_E_BADARG;

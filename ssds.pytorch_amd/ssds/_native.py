@@ -79,12 +79,17 @@ class PoolDesc(ctypes.Structure):
         "N", "H", "W", "C", "dtype", "pad")]
 
 
+class XpairDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("x", "y", "w1", "scale1", "bias1", "w2", "scale2", "bias2")] + [
+        (n, ctypes.c_int32) for n in ("N", "H", "W", "Cin", "Cmid", "Cout", "act1", "act2", "dtype", "pad")]
+
+
 class Op(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("lane", ctypes.c_int32), ("conv", ConvDesc), ("mb", MbConvDesc),
-                ("fuse", FuseDesc), ("stem", StemDesc), ("pool", PoolDesc)]
+                ("fuse", FuseDesc), ("stem", StemDesc), ("pool", PoolDesc), ("xpair", XpairDesc)]
 
 
-OP_CONV, OP_MBCONV, OP_FUSE, OP_STEM7, OP_POOL = 0, 1, 2, 3, 4
+OP_CONV, OP_MBCONV, OP_FUSE, OP_STEM7, OP_POOL, OP_XPAIR = 0, 1, 2, 3, 4, 5
 FUSE_SAME, FUSE_UP2, FUSE_POOL2 = 0, 1, 2
 NCHW, NHWC = 0, 1
 
@@ -181,6 +186,8 @@ def _load():
     lib.ssdk_conv_sequence.restype = i32
     lib.ssdk_mbconv.argtypes = [c.POINTER(MbConvDesc), vp]
     lib.ssdk_mbconv.restype = i32
+    lib.ssdk_xpair.argtypes = [c.POINTER(XpairDesc), vp]
+    lib.ssdk_xpair.restype = i32
     lib.ssdk_mbconv_set_variant.argtypes = [i32]
     lib.ssdk_mbconv_set_variant.restype = i32
     lib.ssdk_run_ops.argtypes = [c.POINTER(Op), i32, vp, sz, vp]
@@ -202,7 +209,7 @@ EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_p
            "ssdk_ctx_create", "ssdk_ctx_destroy", "ssdk_ctx_set_tail_stream", "ssdk_ctx_set_side_lane", "ssdk_ctx_set_profiling",
            "ssdk_ctx_get_timings", "ssdk_ctx_set_op_profiling", "ssdk_ctx_get_op_timings", "ssdk_ctx_get_tail_stamps",
            "ssdk_run_ops_ctx", "ssdk_decode_nms_ctx",
-           "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_mbconv_set_variant", "ssdk_fuse", "ssdk_preprocess", "ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data",
+           "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_mbconv_set_variant", "ssdk_xpair", "ssdk_fuse", "ssdk_preprocess", "ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data",
            "ssdk_dwconv_bwd_weight_workspace_bytes", "ssdk_dwconv_bwd_weight", "ssdk_bn_workspace_bytes",
            "ssdk_bn_train_fwd", "ssdk_bn_train_bwd", "ssdk_bn_act_train_fwd", "ssdk_bn_act_train_bwd", "ssdk_conv_stem7", "ssdk_maxpool3x3s2", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 

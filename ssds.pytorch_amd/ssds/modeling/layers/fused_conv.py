@@ -236,6 +236,41 @@ def fill_mb_desc(d, x_ptr, y_ptr, n, h, w, pk, dtype_code):
     return d
 
 
+def xpair_supported(p1, p2, h, w):
+    """An SSD extra layer (1x1 + BN + act, then 3x3 / stride 2 / pad 1 + BN + act) that csrc/ssdk_xpair.hip runs as one
+    launch: small map, channel counts of its instances."""
+    return (p1.kind == "dense" and p2.kind == "dense" and p1.k == 1 and p1.stride == 1 and p2.k == 3 and p2.stride == 2
+            and p1.cout == p2.cin and (h * w <= 16 or h * w == 64) and p1.cin % 128 == 0 and p1.cout in (64, 128)
+            and p2.cout in (128, 256) and (9 * (p1.cout // 32)) % (4 // (p2.cout // 64)) == 0
+            and p1.act in ("none", "relu", "relu6") and p2.act in ("none", "relu", "relu6")
+            and p1.scale is not None and p2.scale is not None and os.environ.get("SSDK_XPAIR", "1") != "0")
+
+
+def fill_xpair_desc(d, x_ptr, y_ptr, n, h, w, p1, p2, dtype_code):
+    d.x, d.y = x_ptr, y_ptr
+    d.w1, d.scale1, d.bias1 = p1.w.data_ptr(), p1.scale.data_ptr(), p1.bias.data_ptr()
+    d.w2, d.scale2, d.bias2 = p2.w.data_ptr(), p2.scale.data_ptr(), p2.bias.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Cmid, d.Cout = n, h, w, p1.cin, p1.cout, p2.cout
+    d.act1, d.act2, d.dtype = N.ACT[p1.act], N.ACT[p2.act], dtype_code
+    return d
+
+
+def xpair_native(x, p1, p2):
+    """Conv 1x1 + BN + act -> Conv 3x3 / stride 2 + BN + act on a small map in one launch; x channels_last."""
+    N.require_device(x, "xpair")
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    n, c, h, w = (int(v) for v in x.shape)
+    ho, wo = _out_hw(h, w, 3, 2)
+    y = torch.empty((n, p2.cout, ho, wo), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+    d = fill_xpair_desc(N.XpairDesc(), x.data_ptr(), y.data_ptr(), n, h, w, p1, p2, N.dtype_code(x))
+    with torch.cuda.device(x.device):
+        rc = N.lib.ssdk_xpair(ctypes.byref(d), N.stream_ptr(x.device))
+    N.check(rc, "xpair")
+    STATS["native_layers"] += 2
+    return y
+
+
 def fuse_native(a, b, c=None, weights=(1.0, 1.0, 0.0), mode_b=N.FUSE_SAME, mode_c=N.FUSE_SAME):
     """y = w0*a + w1*R_b(b) [+ w2*R_c(c)] (BiFPN weighted fusion, csrc/ssdk_fuse.hip); channels_last tensors."""
     N.require_device(a, "fuse")
@@ -457,6 +492,15 @@ class ConvPlan(object):
         self.keep.append(pk)
         return (out, n, pk.cout, ho, wo)
 
+    def xpair(self, val, p1, p2):
+        buf, n, c, h, w = val
+        assert c == p1.cin, (c, p1.cin)
+        ho, wo = _out_hw(h, w, 3, 2)
+        out = self.arena.get(n * p2.cout * ho * wo * self.es)
+        self.layers.append(dict(kind="xpair", x=buf, n=n, h=h, w=w, pack=p1, pack2=p2, y=out))
+        self.keep.extend([p1, p2])
+        return (out, n, p2.cout, ho, wo)
+
     def stem7(self, val, pack):
         buf, n, c, h, w = val
         ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
@@ -480,7 +524,7 @@ class ConvPlan(object):
                                 mode_c=mode_c, n=n, h=h, w_=w, ch=ch, y=out))
         return (out, n, ch, h, w)
 
-    def head(self, val, pack, split=None, act="none", act2=None, tag="both"):
+    def head(self, val, pack, split=None, act="none", act2=None, tag="both", lane=None, position=None):
         """An NCHW output of the plan: loc|conf of one SSD level as one split GEMM (``tag='both'``) or the last
         conv of one shared tower (``tag='loc' | 'conf'``)."""
         buf, n, c, h, w = val
@@ -490,12 +534,17 @@ class ConvPlan(object):
         # reads its input while the main lane keeps going, so that buffer must never be handed out again inside
         # this plan (the arena re-uses a buffer as soon as its last reader is RECORDED, which orders nothing
         # across streams): it is pinned.
-        lane = 1 if n * ho * wo <= 4096 else 0
+        if lane is None:
+            lane = 1 if n * ho * wo <= 4096 else 0
         if lane and not isinstance(buf, ExtBuf):
             self.pinned.add(buf)
         self.layers.append(dict(x=buf, n=n, h=h, w=w, pack=pack, act=act, y=None, res=None, res_mode=0, nchw=True,
                                 split=split, act2=act2, lane=lane))
-        self.heads.append((len(self.layers) - 1, n, split, pack.cout, ho, wo, tag))
+        entry = (len(self.layers) - 1, n, split, pack.cout, ho, wo, tag)
+        if position is None:
+            self.heads.append(entry)
+        else:  # recorded out of level order (lane balancing): the outputs keep the level order
+            self.heads.insert(position, entry)
         self.keep.append(pack)
 
     def release(self, val):
@@ -530,6 +579,11 @@ class ConvPlan(object):
                 op.kind = N.OP_MBCONV
                 fill_mb_desc(op.mb, self._ptr(L["x"], self.patches, i, "mb.x"), self.arena.ptr(L["y"]), L["n"], L["h"],
                              L["w"], L["pack"], self.dtype_code)
+                continue
+            if kind == "xpair":
+                op.kind = N.OP_XPAIR
+                fill_xpair_desc(op.xpair, self._ptr(L["x"], self.patches, i, "xpair.x"), self.arena.ptr(L["y"]), L["n"], L["h"],
+                                L["w"], L["pack"], L["pack2"], self.dtype_code)
                 continue
             if kind == "stem7":
                 op.kind = N.OP_STEM7
@@ -596,6 +650,14 @@ class ConvPlan(object):
                                  bytes=float(byt), kind="fuse"))
                 continue
             pk, n, h, w = L["pack"], L["n"], L["h"], L["w"]
+            if L.get("kind") == "xpair":
+                p2 = L["pack2"]
+                ho, wo = _out_hw(h, w, 3, 2)
+                macs = n * (h * w * pk.cin * pk.cout + ho * wo * 9 * p2.cin * p2.cout)
+                byt = es * (n * (h * w * pk.cin + ho * wo * p2.cout) + pk.cin * pk.cout + 9 * p2.cin * p2.cout)
+                rows.append(dict(name="extra %d>%d>%d k1,k3s2 @%dx%d" % (pk.cin, pk.cout, p2.cout, h, w), flops=2.0 * macs,
+                                 bytes=float(byt), kind="conv"))
+                continue
             if L.get("kind") == "mb":
                 hs, ws = _out_hw(h, w, 3, 2) if pk.stem else (h, w)
                 ho, wo = _out_hw(hs, ws, 3, pk.stride)

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 import os
 
-from .fused_conv import ConvPack, ConvPlan, MbPack, StemPack, conv_kind, pack_heads, sequential_groups
+from .fused_conv import ConvPack, ConvPlan, MbPack, StemPack, conv_kind, pack_heads, sequential_groups, xpair_supported
 
 
 class PlanUnsupported(Exception):
@@ -45,6 +45,13 @@ def record_chain(plan, val, module, residual=None, keep_input=False):
     the chain input) is added in the epilogue of the LAST conv.  Intermediate buffers are released as soon
     as they have been read; the chain input is released at the end unless ``keep_input``."""
     groups = groups_of(module)
+    if residual is None and len(groups) == 2:  # an SSD extra layer on a small map: one launch (csrc/ssdk_xpair.hip)
+        p1, p2 = (ConvPack(conv, bn, act, plan.dtype) for conv, bn, act in groups)
+        if xpair_supported(p1, p2, val[3], val[4]):
+            out = plan.xpair(val, p1, p2)
+            if not keep_input:
+                plan.release(val)
+            return out
     cur = val
     for i, (conv, bn, act) in enumerate(groups):
         pack = ConvPack(conv, bn, act, plan.dtype)
@@ -105,13 +112,14 @@ def build_ssd_plan(model, x):
     """SSD (ssds/ssd.py) on a planned backbone (MobileNet, ResNet) -> finalized ConvPlan for inputs shaped like ``x``."""
     plan = ConvPlan(x.device, x.dtype, x.shape)
 
-    def head(i, f):
+    def head(i, f, lane=None, position=None):
         # recorded right behind its feature map: the executor forks it onto the side stream, where it overlaps
         # the rest of the backbone / the extras chain (feature maps are never released, so that is safe)
         l, c = model.loc[i], model.conf[i]
         if conv_kind(l) != "dense" or conv_kind(c) != "dense":
             raise PlanUnsupported("head conv not covered")
-        plan.head(f, pack_heads(l, c, plan.dtype), split=l.out_channels, act="none", act2="sigmoid", tag="both")
+        plan.head(f, pack_heads(l, c, plan.dtype), split=l.out_channels, act="none", act2="sigmoid", tag="both", lane=lane,
+                  position=position)
 
     from ssds.modeling.nets.mobilenet import MobileNetEx
 
@@ -121,9 +129,19 @@ def build_ssd_plan(model, x):
         feats = record_backbone(plan, plan.input_value(), model.backbone)
         for i, f in enumerate(feats):
             head(i, f)
-    for extra in model.extras:
+    # The heads of the extras' levels are a serial chain on the side lane (each waits for its feature map); the extras
+    # themselves are short, so the main lane would idle while the side lane works through four heads.  The first of
+    # them (the largest: 8x8 at 512 input) therefore runs on the MAIN lane behind the last extra layer.
+    balance = os.environ.get("SSDK_HEAD_BALANCE", "1") != "0" and len(model.extras) > 1
+    deferred = None
+    for j, extra in enumerate(model.extras):
         feats.append(record_chain(plan, feats[-1], extra, keep_input=True))
-        head(len(feats) - 1, feats[-1])
+        if balance and j == 0:
+            deferred = (len(feats) - 1, feats[-1])
+        else:
+            head(len(feats) - 1, feats[-1])
+    if deferred is not None:
+        head(deferred[0], deferred[1], lane=0, position=deferred[0])
     return plan.finalize()
 
 

@@ -545,6 +545,44 @@ def test_fused_stem_block(layout, h, w, variant):
     _check(got, y, dtype, "stem block %s (%s)" % (layout, name))
 
 
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cmid,cout,h,w,n", [(512, 128, 256, 8, 8, 5), (256, 128, 256, 4, 4, 64), (256, 64, 128, 2, 2, 7),
+                                                (256, 128, 256, 3, 5, 3), (128, 64, 128, 1, 1, 4)])
+def test_extra_layer_pair_in_one_launch(cin, cmid, cout, h, w, n, dtype_name):
+    """An SSD extra layer (Conv 1x1 + BN + ReLU -> Conv 3x3 / stride 2 + BN + ReLU) on a small map as one launch
+    (ssdk_xpair) against the torch fp32 layers with the intermediate map rounded to the model dtype, and against the two
+    single-layer launches it replaces."""
+    import torch
+    from ssds.modeling.layers import fused_conv as FC
+    from ssds.modeling.layers.basic_layers import ConvBNReLU
+    from ssds.modeling.layers.planner import groups_of
+
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    torch.manual_seed(cin + cmid + h)
+    layer = torch.nn.Sequential(ConvBNReLU(cin, cmid, 1), ConvBNReLU(cmid, cout, 3, stride=2)).eval()
+    for m in layer.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data = (m.weight.data * 2).to(dtype).float()
+    x = torch.randn(n, cin, h, w).to(dtype)
+    with torch.no_grad():
+        y = layer[1](layer[0](x.float()).to(dtype).float())
+    layer = layer.cuda()
+    (c1, b1, a1), (c2, b2, a2) = groups_of(layer)
+    p1, p2 = FC.ConvPack(c1, b1, a1, dtype), FC.ConvPack(c2, b2, a2, dtype)
+    assert FC.xpair_supported(p1, p2, h, w)
+    xc = x.cuda().contiguous(memory_format=torch.channels_last)
+    got = FC.xpair_native(xc, p1, p2)
+    assert got.shape == y.shape and got.is_contiguous(memory_format=torch.channels_last)
+    _check(got, y, dtype, "extra layer %d>%d>%d @%dx%d" % (cin, cmid, cout, h, w))
+    two = FC.conv_native(FC.conv_native(xc, p1), p2)
+    assert float((got.float() - two.float()).abs().max()) <= 2e-2 * max(1.0, float(y.abs().max()))
+
+
 @pytest.mark.parametrize("cin,cout,stride,h,w", [(16, 24, 2, 70, 45), (24, 24, 1, 47, 33), (32, 64, 2, 36, 36)])
 def test_register_flow_block_fp16(cin, cout, stride, h, w):
     """The register-flow kernel in fp16 (expand on the f16 MFMA), ragged strips and several row segments, against the
