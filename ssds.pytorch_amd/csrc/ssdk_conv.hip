@@ -29,6 +29,8 @@
 
 namespace ssdk {
 
+int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream);  // ssdk_smallmap.hip: 0 launched, 1 not its layer
+
 // 16-byte chunk swizzle inside a 64-byte LDS row: makes the 16-lane groups of ds_read_b128 conflict free
 // (rows r, r+4, r+8, r+12 share the same bank phase; S permutes their chunk index).
 __device__ __forceinline__ u32 swz(u32 row, u32 chunk) {
@@ -1124,6 +1126,7 @@ extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t worksp
   p.kt_per = p.KT;
   p.slabs = nullptr;
   p.counters = nullptr;
+  if (launch_conv_smallmap(p, d->dtype, stream) == 0) return check_launch("conv_smallmap_kernel");  // maps of <= 16 pixels
   // Side-lane ops (small heads running next to the extras chain) prefer the halo kernel however few tiles they have:
   // an underfilled grid is free there, and unlike the split-K kernels it has no agent-scope fences, which slow down
   // every kernel running concurrently (measured: split-K heads on the side lane +0.6 %, halo heads +2.7 %).

@@ -1,0 +1,158 @@
+// ssdk_smallmap.hip -- 3x3 / stride 1 / pad 1 convolution on maps of at most 64 pixels (the multibox heads of the 8x8, 4x4,
+// 2x2 and 1x1 levels, ssd.py:100-103; any dense layer of that shape), one of the kernels behind ssdk_conv.
+//
+// Why: with M = N * H * W of a few hundred rows and K = 9 * Cin of a few thousand these layers are all weights.  As
+// 128-row implicit-GEMM tiles with split-K (conv_gemm_kernel) or one wave per 16 x 64 tile (conv_wave_kernel) they take
+// 20-40 us each -- k-loops of one wave per SIMD plus split-K fences -- for well under a microsecond of MFMA work.
+// Here a workgroup owns 64 PIXELS (= 64 / (H*W) whole images) x 64 output channels:
+//   * the feature maps of its images are staged once in LDS (64 rows of Cin, + a zero row for the padding);
+//   * a wave owns 16 output channels and all four pixel fragments: per k-step (tap, 32-channel slice) ONE weight
+//     fragment from global memory (A operand, six k-steps in flight through registers) serves four MFMAs whose B
+//     operands are gathered from the LDS map with a per-(pixel, tap) row offset;
+//   * a weight is read once per 64 pixels instead of once per 16, there is no split-K, no fence, no barrier after staging.
+// What remains is the weight stream itself (64 x 9 x Cin x 2 bytes per workgroup).
+#include "ssdk_conv_common.h"
+
+namespace ssdk {
+
+constexpr int kSmThreads = 256;
+
+// CS = Cin / 32 is a template parameter: the k-loop is unrolled completely, because a loop back edge makes the compiler
+// drain the load counter at the top of every iteration (s_waitcnt vmcnt(0)) however the body is written
+template <int DT, int CS>
+__global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const u32 fr = lane & 15u, fg = lane >> 4;
+  const int P = p.Ho * p.Wo, G = 64 / P, Cin = p.Cin;   // pixels per image, images per workgroup
+  const int img0 = (int)blockIdx.x * G;
+  const int RS = Cin * 2 + 16;                           // LDS row stride (bytes); row 64 = zeros
+  const u16* x = (const u16*)p.x;
+
+  // ---- stage the maps: 64 rows x Cin, 16-byte pieces, rows of images past N are zero -------------------------------
+  {
+    const int cpr = Cin / 8;
+    for (int q = (int)tid; q < 65 * cpr; q += (int)blockDim.x) {
+      const int row = q / cpr, c = q % cpr;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < 64 && img0 + row / P < p.N) v = *reinterpret_cast<const u32x4*>(x + ((size_t)img0 * P + row) * Cin + c * 8);
+      *reinterpret_cast<u32x4*>(smem + (size_t)row * RS + c * 16) = v;
+    }
+  }
+  // LDS byte offset of the input pixel behind (output pixel = fragment m, lane fr; tap), the zero row outside the map
+  u32 rowoff[4][9];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int px = m * 16 + (int)fr, g = px / P, q = px % P, oy = q / p.Wo, ox = q % p.Wo;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int iy = oy - 1 + t / 3, ix = ox - 1 + t % 3;
+      const bool ok = (unsigned)iy < (unsigned)p.Ho && (unsigned)ix < (unsigned)p.Wo;
+      rowoff[m][t] = (u32)((ok ? g * P + iy * p.Wo + ix : 64) * RS) + fg * 16u;
+    }
+  }
+  __syncthreads();
+
+  const int co_row0 = ((int)blockIdx.y * (int)(blockDim.x >> 6) + (int)wave) * 16;  // 1, 2 or 4 waves per workgroup
+  int co_a = co_row0 + (int)fr;
+  co_a = co_a < p.Cout ? co_a : p.Cout - 1;  // rows past Cout: computed on a valid row, never stored
+  const u16* wrow = (const u16*)p.w + (size_t)co_a * 9 * Cin + fg * 8;
+  static_assert(CS % 2 == 0, "even number of slices");
+  f32x4 acc[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // k-loop: 32-channel slices outside, the nine taps inside (static: the row offsets are plain registers).  Weight
+  // fragments run TWO slices = 18 k-steps ahead of the MFMAs through 18 register stages; the loop body has no branch, so
+  // the compiler counts the loads in flight (s_waitcnt vmcnt(17)) instead of draining them -- a k-step is four MFMAs
+  // (~70 cycles), an L2 round trip 2-4k cycles, and with a branch in the body every k-step waited for its own load
+  // (1.2k cycles per k-step measured).
+  u32x4 rw[2][9];
+  auto issue = [&](int buf, int t, int slc) {
+    const int s2 = slc < CS ? slc : CS - 1;  // past the end: a harmless re-read
+    rw[buf][t] = *reinterpret_cast<const u32x4*>(wrow + (size_t)(t * CS + s2) * 32);
+  };
+#pragma unroll
+  for (int t = 0; t < 9; ++t) issue(0, t, 0);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) issue(1, t, 1);
+#pragma unroll
+  for (int sl0 = 0; sl0 < CS; sl0 += 2) {
+#pragma unroll
+    for (int bsl = 0; bsl < 2; ++bsl) {
+      const int sl = sl0 + bsl;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const u32x4 b = *reinterpret_cast<const u32x4*>(smem + rowoff[m][t] + sl * 64);
+          acc[m] = mfma16<DT>(rw[bsl][t], b, acc[m]);  // D[co = 4fg + r][px = fr]
+        }
+        issue(bsl, t, sl + 2);
+        __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks every load down to its use, 18 k-steps later)
+      }
+    }
+  }
+
+  // ---- epilogue: lane = (pixel fr of fragment m, channels co0 + 4fg .. +3) -----------------------------------------
+  const int co0 = co_row0 + (int)fg * 4;
+  const bool nchw = p.out_layout == LAYOUT_NCHW;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = co0 + r;
+    if (co >= p.Cout) continue;
+    const float sc = p.scale ? p.scale[co] : 1.f, bi = p.bias[co];
+    const ActSel as = act_sel(co >= p.split ? p.act2 : p.act);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int px = m * 16 + (int)fr, b = img0 + px / P, q = px % P;
+      if (b >= p.N) continue;
+      float v = acc[m][r] * sc + bi;
+      if (as.mode) {
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * v));
+        v = as.mode == 1 ? sg : v * sg;
+      }
+      v = __builtin_fminf(__builtin_fmaxf(v, as.lo), as.hi);
+      const u16 h = (u16)(pack2_16<DT>(v, 0.f) & 0xffffu);
+      if (!nchw) ((u16*)p.y)[((size_t)b * P + q) * p.Cout + co] = h;
+      else if (co < p.split) ((u16*)p.y)[((size_t)b * p.split + co) * P + q] = h;
+      else ((u16*)p.y2)[((size_t)b * (p.Cout - p.split) + (co - p.split)) * P + q] = h;
+    }
+  }
+}
+
+// 1: not one of this kernel's layers (the caller goes on), 0: launched
+int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
+  static const int env = getenv("SSDK_CONV_SMALLMAP") ? atoi(getenv("SSDK_CONV_SMALLMAP")) : 1;
+  static const int env_maxp = getenv("SSDK_CONV_SMALLMAP_MAXP") ? atoi(getenv("SSDK_CONV_SMALLMAP_MAXP")) : 64;
+  const int P = p.Ho * p.Wo;
+  if (!env || p.k != 3 || p.stride != 1 || p.pad != 1 || p.H != p.Ho || p.W != p.Wo || P > env_maxp || P > 64 || (64 % P) || (p.Cin != 128 && p.Cin != 256 && p.Cin != 512) ||
+      p.in_layout != LAYOUT_NHWC || p.res || p.post != SSDK_ACT_NONE || p.Cout < 16)
+    return 1;
+  const int G = 64 / P;
+  // waves (= 16-channel fragments) per workgroup
+  const int groups = (p.N + G - 1) / G, nfr = (p.Cout + 15) / 16;
+  static const int env_nw = getenv("SSDK_CONV_SMALLMAP_NW") ? atoi(getenv("SSDK_CONV_SMALLMAP_NW")) : 4;
+  int nw = env_nw == 1 || env_nw == 2 ? env_nw : 4;  // (finer splits measured slower: 30 / 34 / 23 us against 28 / 27 / 19)
+  const dim3 grid((unsigned)groups, (unsigned)((nfr + nw - 1) / nw));
+  const size_t lds = (size_t)65 * (p.Cin * 2 + 16);
+  const int cs = p.Cin / 32;
+#define SSDK_SM(DT, CS_)                                                                                                   \
+  do {                                                                                                                     \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_>),                              \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
+    hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_>), grid, dim3(64 * nw), lds, stream, p);                              \
+  } while (0)
+  if (dtype == SSDK_BF16) {
+    if (cs == 4) SSDK_SM(SSDK_BF16, 4);
+    else if (cs == 8) SSDK_SM(SSDK_BF16, 8);
+    else SSDK_SM(SSDK_BF16, 16);
+  } else {
+    if (cs == 4) SSDK_SM(SSDK_F16, 4);
+    else if (cs == 8) SSDK_SM(SSDK_F16, 8);
+    else SSDK_SM(SSDK_F16, 16);
+  }
+#undef SSDK_SM
+  return 0;
+}
+
+}  // namespace ssdk
