@@ -1240,10 +1240,13 @@ extern "C" int ssdk_get_op_timings(float* ms, const char** kernels, int n_max) {
 // before returning, so the caller sees ordinary stream semantics (and the whole call is graph-capturable).
 // A failed event / wait is an error (SSDK_E_LAUNCH): dropping one silently would drop an ordering edge.
 static bool side_wanted(const ssdk_ctx* ctx) {
-  // measured on SSD-MobileNetV2@512: +2.7 % with the small heads (levels 2..5) on the side lane; SSDK_SIDE_STREAM=0 = in line
+  // Round 1 (small heads on split-K / one-wave kernels of 20-65 us each): +2.7 % with levels 2..5 on the side lane.
+  // Round 2 (conv_smallmap_kernel, fused extras): the same heads take 17-53 us and the in-line plan is 1.1 % FASTER
+  // than the forked one (fork / join events, two queues competing for the same CUs) -- off by default;
+  // SSDK_SIDE_STREAM=1 or ssdk_ctx_set_side_lane(ctx, 1) turns it on.
   if (ctx->side_lane >= 0) return ctx->side_lane != 0;
   const char* e = getenv("SSDK_SIDE_STREAM");
-  return !(e && *e) || atoi(e) != 0;
+  return e && *e && atoi(e) != 0;
 }
 
 static int side_init(ssdk_ctx* ctx) {

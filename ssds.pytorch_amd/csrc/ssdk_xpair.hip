@@ -37,10 +37,16 @@ __device__ __forceinline__ float xp_act(float v, int act) {
 }
 
 // MF1 = pixel fragments of the input map (ceil(H*W / 16)), NPW = mid-channel fragments per wave (Cmid = 64 * NPW),
-// NF2 = output-channel fragments of the workgroup's quarter (Cout = 64 * NF2); KSPLIT = 4 / NF2 waves share a fragment
-template <int DT, int MF1, int NPW, int NF2>
+// NF2 = output-channel fragments of the workgroup's quarter (Cout = 64 * NF2; KSPLIT = 4 / NF2 waves share a fragment and
+// split the 32-channel slices), CS1 = Cin / 32.  Both k-loops are unrolled completely and have no branch: only then does
+// the compiler count the loads in flight (s_waitcnt vmcnt(n)) instead of draining them at every loop back edge / merge.
+template <int DT, int MF1, int NPW, int NF2, int CS1>
 __global__ __launch_bounds__(kXpThreads) void xpair_kernel(const XpairParams p) {
   constexpr int KSPLIT = 4 / NF2;
+  constexpr int CSM = 2 * NPW;          // 32-channel slices of the intermediate map
+  constexpr int SPW = CSM / KSPLIT;     // slices per wave in phase 2
+  constexpr int RB = SPW >= 2 ? 2 : 1;  // weight ring: RB slices x 9 taps ahead
+  static_assert(CSM % KSPLIT == 0 && CS1 % 4 == 0, "shape");
   constexpr int PF = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -69,7 +75,6 @@ __global__ __launch_bounds__(kXpThreads) void xpair_kernel(const XpairParams p) 
     }
 #pragma unroll
     for (int a = 0; a < NPW; ++a) wa[a] = p.w1 + (size_t)((wave + 4u * (u32)a) * 16u + fr) * Cin + fg * 8;
-    const int KS1 = Cin / 32;  // a multiple of PF (checked on the host)
     u32x4 ra[PF][NPW], rb[PF][MF1];
     auto issue = [&](int slot, int ks) {
 #pragma unroll
@@ -79,16 +84,14 @@ __global__ __launch_bounds__(kXpThreads) void xpair_kernel(const XpairParams p) 
     };
 #pragma unroll
     for (int s = 0; s < PF; ++s) issue(s, s);
-    for (int k0 = 0; k0 < KS1; k0 += PF) {
 #pragma unroll
-      for (int s = 0; s < PF; ++s) {
+    for (int ks = 0; ks < CS1; ++ks) {
 #pragma unroll
-        for (int a = 0; a < NPW; ++a)
+      for (int a = 0; a < NPW; ++a)
 #pragma unroll
-          for (int m = 0; m < MF1; ++m) acc[a][m] = mfma16<DT>(ra[s][a], rb[s][m], acc[a][m]);  // D[cm = 4fg + r][px = fr]
-        const int nk = k0 + s + PF;
-        issue(s, nk < KS1 ? nk : KS1 - 1);  // past the end: a harmless re-read of the last k-step
-      }
+        for (int m = 0; m < MF1; ++m) acc[a][m] = mfma16<DT>(ra[ks % PF][a], rb[ks % PF][m], acc[a][m]);  // D[cm = 4fg + r][px = fr]
+      if (ks + PF < CS1) issue(ks % PF, ks + PF);  // (compile-time condition)
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int a = 0; a < NPW; ++a) {
@@ -106,13 +109,11 @@ __global__ __launch_bounds__(kXpThreads) void xpair_kernel(const XpairParams p) 
       }
     }
   }
-  __syncthreads();
 
-  // ---- phase 2: the 3x3 / stride 2 convolution for this workgroup's 64 * NF2 / ... output channels --------------------
+  // ---- phase 2: the 3x3 / stride 2 convolution for this workgroup's quarter of the output channels -------------------
   const int nf = (int)wave % NF2, kpart = (int)wave / NF2;
   const int co_row = cq * (NF2 * 16) + nf * 16 + (int)fr;  // A operand row of this lane
-  const int CS = Cmid / 32;                                  // 32-channel slices per tap
-  const int steps = 9 * CS / KSPLIT, kbeg = kpart * steps;   // this wave's k-steps: (tap, slice) pairs, tap-major
+  const int sl_beg = kpart * SPW;                            // this wave's slices [sl_beg, sl_beg + SPW)
   u32 rowoff[9];  // LDS byte offset of the input pixel behind (output pixel fr, tap), the zero row if outside the map
   {
     const int opx = (int)fr < OP ? (int)fr : 0, oy = opx / p.Wo, ox = opx % p.Wo;
@@ -124,28 +125,24 @@ __global__ __launch_bounds__(kXpThreads) void xpair_kernel(const XpairParams p) 
     }
   }
   f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-  const u16* w2row = p.w2 + (size_t)co_row * 9 * Cmid + fg * 8;
-  constexpr int PF2 = 6;
-  u32x4 rw[PF2];
-  auto issue2 = [&](int slot, int st) {  // k-step st of this wave: tap = (kbeg + st) / CS, slice = (kbeg + st) % CS
-    const int g = kbeg + (st < steps ? st : steps - 1);
-    rw[slot] = *reinterpret_cast<const u32x4*>(w2row + (size_t)(g / CS) * Cmid + (g % CS) * 32);
+  const u16* w2row = p.w2 + (size_t)co_row * 9 * Cmid + fg * 8 + (size_t)sl_beg * 32;
+  u32x4 rw[RB][9];
+  auto issue2 = [&](int buf, int t, int s) {  // weights of (tap t, slice sl_beg + s)
+    rw[buf][t] = *reinterpret_cast<const u32x4*>(w2row + (size_t)t * Cmid + s * 32);
   };
 #pragma unroll
-  for (int s = 0; s < PF2; ++s) issue2(s, s);
-  for (int s0 = 0; s0 < steps; s0 += PF2) {
+  for (int b2 = 0; b2 < RB; ++b2)
 #pragma unroll
-    for (int s = 0; s < PF2; ++s) {
-      const int st = s0 + s;
-      if (st < steps) {  // wave-uniform
-        const int g = kbeg + st, tap = g / CS, sl = g % CS;
-        u32 ro = rowoff[0];
+    for (int t = 0; t < 9; ++t) issue2(b2, t, b2);  // in flight under the rest of phase 1 of the other waves
+  __syncthreads();  // the intermediate map is complete
 #pragma unroll
-        for (int t = 1; t < 9; ++t) ro = tap == t ? rowoff[t] : ro;
-        const u32x4 bfrag = *reinterpret_cast<const u32x4*>(smem + ro + sl * 64);
-        acc2 = mfma16<DT>(rw[s], bfrag, acc2);  // D[co = 4fg + r][opx = fr]
-      }
-      issue2(s, st + PF2);
+  for (int s = 0; s < SPW; ++s) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const u32x4 bfrag = *reinterpret_cast<const u32x4*>(smem + rowoff[t] + (sl_beg + s) * 64);
+      acc2 = mfma16<DT>(rw[s % RB][t], bfrag, acc2);  // D[co = 4fg + r][opx = fr]
+      if (s + RB < SPW) issue2(s % RB, t, s + RB);  // (compile-time condition)
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if constexpr (KSPLIT > 1) {
@@ -168,9 +165,9 @@ __global__ __launch_bounds__(kXpThreads) void xpair_kernel(const XpairParams p) 
   }
 }
 
-template <int DT, int MF1, int NPW, int NF2>
+template <int DT, int MF1, int NPW, int NF2, int CS1>
 static void xp_launch(const XpairParams& p, size_t lds, hipStream_t stream) {
-  hipLaunchKernelGGL((xpair_kernel<DT, MF1, NPW, NF2>), dim3((unsigned)p.N * 4u), dim3(kXpThreads), lds, stream, p);
+  hipLaunchKernelGGL((xpair_kernel<DT, MF1, NPW, NF2, CS1>), dim3((unsigned)p.N * 4u), dim3(kXpThreads), lds, stream, p);
 }
 
 }  // namespace ssdk
@@ -213,19 +210,18 @@ extern "C" int ssdk_xpair(const ssdk_xpair_desc* d, void* stream_) {
   p.act1 = d->act1;
   p.act2 = d->act2;
   const size_t lds = (size_t)(P + 1) * (d->Cmid * 2 + 16) + 4 * 64 * 16;
-  const int mf1 = (P + 15) / 16, npw = d->Cmid / 64, nf2 = d->Cout / 64;
-#define SSDK_XP(DT)                                                                     \
-  do {                                                                                  \
-    if (mf1 == 4 && npw == 2 && nf2 == 4) xp_launch<DT, 4, 2, 4>(p, lds, stream);      \
-    else if (mf1 == 1 && npw == 2 && nf2 == 4) xp_launch<DT, 1, 2, 4>(p, lds, stream); \
-    else if (mf1 == 1 && npw == 1 && nf2 == 2) xp_launch<DT, 1, 1, 2>(p, lds, stream); \
-    else if (mf1 == 4 && npw == 1 && nf2 == 2) xp_launch<DT, 4, 1, 2>(p, lds, stream); \
-    else if (mf1 == 1 && npw == 2 && nf2 == 2) xp_launch<DT, 1, 2, 2>(p, lds, stream); \
-    else if (mf1 == 1 && npw == 1 && nf2 == 4) xp_launch<DT, 1, 1, 4>(p, lds, stream); \
-    else {                                                                              \
-      set_error("xpair: no instance for %d pixel fragments, Cmid=%d, Cout=%d", mf1, d->Cmid, d->Cout); \
-      return SSDK_E_BADARG;                                                             \
-    }                                                                                   \
+  const int mf1 = (P + 15) / 16, npw = d->Cmid / 64, nf2 = d->Cout / 64, cs1 = d->Cin / 32;
+  // the instances that exist (every one is a fully unrolled kernel): the three extras of SSD-MobileNetV2@512 and a 128-wide one
+#define SSDK_XP(DT)                                                                                     \
+  do {                                                                                                  \
+    if (mf1 == 4 && npw == 2 && nf2 == 4 && cs1 == 16) xp_launch<DT, 4, 2, 4, 16>(p, lds, stream);      \
+    else if (mf1 == 1 && npw == 2 && nf2 == 4 && cs1 == 8) xp_launch<DT, 1, 2, 4, 8>(p, lds, stream);   \
+    else if (mf1 == 1 && npw == 1 && nf2 == 2 && cs1 == 8) xp_launch<DT, 1, 1, 2, 8>(p, lds, stream);   \
+    else if (mf1 == 1 && npw == 1 && nf2 == 2 && cs1 == 4) xp_launch<DT, 1, 1, 2, 4>(p, lds, stream);   \
+    else {                                                                                              \
+      set_error("xpair: no instance for %d pixel fragments, Cin=%d, Cmid=%d, Cout=%d", mf1, d->Cin, d->Cmid, d->Cout); \
+      return SSDK_E_BADARG;                                                                             \
+    }                                                                                                   \
   } while (0)
   if (d->dtype == SSDK_BF16) SSDK_XP(SSDK_BF16);
   else SSDK_XP(SSDK_F16);

@@ -240,8 +240,9 @@ def xpair_supported(p1, p2, h, w):
     """An SSD extra layer (1x1 + BN + act, then 3x3 / stride 2 / pad 1 + BN + act) that csrc/ssdk_xpair.hip runs as one
     launch: small map, channel counts of its instances."""
     return (p1.kind == "dense" and p2.kind == "dense" and p1.k == 1 and p1.stride == 1 and p2.k == 3 and p2.stride == 2
-            and p1.cout == p2.cin and (h * w <= 16 or h * w == 64) and p1.cin % 128 == 0 and p1.cout in (64, 128)
-            and p2.cout in (128, 256) and (9 * (p1.cout // 32)) % (4 // (p2.cout // 64)) == 0
+            and p1.cout == p2.cin
+            and ((h * w + 15) // 16, p1.cin, p1.cout, p2.cout) in ((4, 512, 128, 256), (1, 256, 128, 256), (1, 256, 64, 128),
+                                                                   (1, 128, 64, 128))
             and p1.act in ("none", "relu", "relu6") and p2.act in ("none", "relu", "relu6")
             and p1.scale is not None and p2.scale is not None and os.environ.get("SSDK_XPAIR", "1") != "0")
 
