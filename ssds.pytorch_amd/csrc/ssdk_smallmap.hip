@@ -19,36 +19,39 @@ constexpr int kSmThreads = 256;
 
 // CS = Cin / 32 is a template parameter: the k-loop is unrolled completely, because a loop back edge makes the compiler
 // drain the load counter at the top of every iteration (s_waitcnt vmcnt(0)) however the body is written
-template <int DT, int CS>
+// MFR = pixel fragments per workgroup (4: 64 pixels, 8: 128 pixels -- half the weight traffic per pixel, for the level
+// whose grid still fills the chip then)
+template <int DT, int CS, int MFR>
 __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvParams p) {
+  constexpr int ROWS = 16 * MFR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const u32 fr = lane & 15u, fg = lane >> 4;
-  const int P = p.Ho * p.Wo, G = 64 / P, Cin = p.Cin;   // pixels per image, images per workgroup
+  const int P = p.Ho * p.Wo, G = ROWS / P, Cin = p.Cin;  // pixels per image, images per workgroup
   const int img0 = (int)blockIdx.x * G;
-  const int RS = Cin * 2 + 16;                           // LDS row stride (bytes); row 64 = zeros
+  const int RS = Cin * 2 + 16;                           // LDS row stride (bytes); row ROWS = zeros
   const u16* x = (const u16*)p.x;
 
   // ---- stage the maps: 64 rows x Cin, 16-byte pieces, rows of images past N are zero -------------------------------
   {
     const int cpr = Cin / 8;
-    for (int q = (int)tid; q < 65 * cpr; q += (int)blockDim.x) {
+    for (int q = (int)tid; q < (ROWS + 1) * cpr; q += (int)blockDim.x) {
       const int row = q / cpr, c = q % cpr;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < 64 && img0 + row / P < p.N) v = *reinterpret_cast<const u32x4*>(x + ((size_t)img0 * P + row) * Cin + c * 8);
+      if (row < ROWS && img0 + row / P < p.N) v = *reinterpret_cast<const u32x4*>(x + ((size_t)img0 * P + row) * Cin + c * 8);
       *reinterpret_cast<u32x4*>(smem + (size_t)row * RS + c * 16) = v;
     }
   }
   // LDS byte offset of the input pixel behind (output pixel = fragment m, lane fr; tap), the zero row outside the map
-  u32 rowoff[4][9];
+  u32 rowoff[MFR][9];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
+  for (int m = 0; m < MFR; ++m) {
     const int px = m * 16 + (int)fr, g = px / P, q = px % P, oy = q / p.Wo, ox = q % p.Wo;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int iy = oy - 1 + t / 3, ix = ox - 1 + t % 3;
       const bool ok = (unsigned)iy < (unsigned)p.Ho && (unsigned)ix < (unsigned)p.Wo;
-      rowoff[m][t] = (u32)((ok ? g * P + iy * p.Wo + ix : 64) * RS) + fg * 16u;
+      rowoff[m][t] = (u32)((ok ? g * P + iy * p.Wo + ix : ROWS) * RS) + fg * 16u;
     }
   }
   __syncthreads();
@@ -58,9 +61,9 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   co_a = co_a < p.Cout ? co_a : p.Cout - 1;  // rows past Cout: computed on a valid row, never stored
   const u16* wrow = (const u16*)p.w + (size_t)co_a * 9 * Cin + fg * 8;
   static_assert(CS % 2 == 0, "even number of slices");
-  f32x4 acc[4];
+  f32x4 acc[MFR];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MFR; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
   // k-loop: 32-channel slices outside, the nine taps inside (static: the row offsets are plain registers).  Weight
   // fragments run TWO slices = 18 k-steps ahead of the MFMAs through 18 register stages; the loop body has no branch, so
   // the compiler counts the loads in flight (s_waitcnt vmcnt(17)) instead of draining them -- a k-step is four MFMAs
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MFR; ++m) {
           const u32x4 b = *reinterpret_cast<const u32x4*>(smem + rowoff[m][t] + sl * 64);
           acc[m] = mfma16<DT>(rw[bsl][t], b, acc[m]);  // D[co = 4fg + r][px = fr]
         }
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
     const float sc = p.scale ? p.scale[co] : 1.f, bi = p.bias[co];
     const ActSel as = act_sel(co >= p.split ? p.act2 : p.act);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MFR; ++m) {
       const int px = m * 16 + (int)fr, b = img0 + px / P, q = px % P;
       if (b >= p.N) continue;
       float v = acc[m][r] * sc + bi;
@@ -128,19 +131,27 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   if (!env || p.k != 3 || p.stride != 1 || p.pad != 1 || p.H != p.Ho || p.W != p.Wo || P > env_maxp || P > 64 || (64 % P) || (p.Cin != 128 && p.Cin != 256 && p.Cin != 512) ||
       p.in_layout != LAYOUT_NHWC || p.res || p.post != SSDK_ACT_NONE || p.Cout < 16)
     return 1;
-  const int G = 64 / P;
+  // 128 pixels per workgroup where the grid then still has a workgroup per CU (the 8x8 level at batch 64: 32 x 8), else 64
+  const int nfr64 = (p.Cout + 63) / 64;
+  const int mfr = (2 * P <= 128 && (128 % P) == 0 && (long)((p.N + 128 / P - 1) / (128 / P)) * nfr64 >= 256) ? 8 : 4;
+  const int G = 16 * mfr / P;
   // waves (= 16-channel fragments) per workgroup
   const int groups = (p.N + G - 1) / G, nfr = (p.Cout + 15) / 16;
   static const int env_nw = getenv("SSDK_CONV_SMALLMAP_NW") ? atoi(getenv("SSDK_CONV_SMALLMAP_NW")) : 4;
   int nw = env_nw == 1 || env_nw == 2 ? env_nw : 4;  // (finer splits measured slower: 30 / 34 / 23 us against 28 / 27 / 19)
   const dim3 grid((unsigned)groups, (unsigned)((nfr + nw - 1) / nw));
-  const size_t lds = (size_t)65 * (p.Cin * 2 + 16);
+  const size_t lds = (size_t)(16 * mfr + 1) * (p.Cin * 2 + 16);
   const int cs = p.Cin / 32;
-#define SSDK_SM(DT, CS_)                                                                                                   \
+#define SSDK_SM1(DT, CS_, MFR_)                                                                                            \
   do {                                                                                                                     \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_>),                              \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_, MFR_>),                        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
-    hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_>), grid, dim3(64 * nw), lds, stream, p);                              \
+    hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_, MFR_>), grid, dim3(64 * nw), lds, stream, p);                        \
+  } while (0)
+#define SSDK_SM(DT, CS_)                 \
+  do {                                   \
+    if (mfr == 8) SSDK_SM1(DT, CS_, 8);  \
+    else SSDK_SM1(DT, CS_, 4);           \
   } while (0)
   if (dtype == SSDK_BF16) {
     if (cs == 4) SSDK_SM(SSDK_BF16, 4);
@@ -152,6 +163,7 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
     else SSDK_SM(SSDK_F16, 16);
   }
 #undef SSDK_SM
+#undef SSDK_SM1
   return 0;
 }
 

@@ -85,7 +85,7 @@ def test_dense_conv(cin, cout, k, stride, h, w, n, act, dtype_name):
     _check(y2, _ref(x, conv, bn, act), dtype, "dense nchw")
 
 
-HALO, G256 = "conv3x3_halo_kernel", "conv_gemm256_kernel"
+HALO, G256, SMALLMAP = "conv3x3_halo_kernel", "conv_gemm256_kernel", "conv_smallmap_kernel"
 LARGE = [
     # cin, cout, k, stride, h, w, n, act, kernel the layer must be dispatched to
     (96, 504, 3, 1, 32, 32, 8, "none", HALO),      # SSD head L0: 16x16 patches, last slab holds 32 channels
@@ -94,7 +94,13 @@ LARGE = [
     (64, 720, 3, 1, 19, 19, 16, "relu", HALO),     # odd map: ragged patches, scalar NCHW stores
     (256, 256, 3, 1, 40, 40, 8, "relu", HALO),     # FPN tower P4: 6x40 patches
     (128, 256, 3, 1, 10, 10, 128, "relu", HALO),   # two whole maps per tile
-    (512, 504, 3, 1, 8, 8, 96, "none", HALO),      # SSD head L2: four whole maps per tile
+    (384, 504, 3, 1, 8, 8, 96, "none", HALO),      # four whole maps per tile (Cin the small-map kernel has no instance for)
+    (512, 504, 3, 1, 8, 8, 96, "none", SMALLMAP),  # SSD head L2: 128 pixels (two maps) x 64 channels per workgroup
+    (512, 504, 3, 1, 8, 8, 5, "sigmoid", SMALLMAP),   # few images: 64 pixels per workgroup, a ragged last group
+    (256, 504, 3, 1, 4, 4, 66, "none", SMALLMAP),  # SSD head L3: four maps per workgroup, two surplus images
+    (256, 504, 3, 1, 2, 2, 35, "relu", SMALLMAP),  # SSD head L4: sixteen maps per workgroup
+    (128, 504, 3, 1, 1, 1, 64, "silu", SMALLMAP),  # SSD head L5: 1x1 maps, only the centre tap sees data
+    (256, 40, 3, 1, 2, 4, 9, "relu6", SMALLMAP),   # 2x4 map, a single partial channel range
     (64, 256, 1, 1, 64, 64, 8, "relu", G256),      # wide 1x1
     (96, 320, 3, 2, 64, 64, 32, "relu6", G256),    # 3x3 stride 2, partial 64-channel slab
     (72, 200, 1, 1, 90, 50, 8, "silu", G256),      # ragged everything
@@ -105,7 +111,8 @@ LARGE = [
 @pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
 def test_large_tile_kernels(cin, cout, k, stride, h, w, n, act, kernel, dtype_name):
     """The 256-row tile kernels (halo-tile 3x3, 256x256 flat-K) only take layers with enough tiles to fill the
-    chip; these shapes are sized to reach them, and the dispatch is asserted."""
+    chip, the small-map kernel the 3x3 layers on maps of <= 64 pixels; these shapes are sized to reach them, and the
+    dispatch is asserted."""
     import torch
     import torch.nn as nn
     from ssds import _native as N
