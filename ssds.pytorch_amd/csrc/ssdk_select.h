@@ -222,37 +222,6 @@ __device__ void wg_bitonic_sort_desc(u64* a, u32 M) {  // M power of two
   }
 }
 
-// Same network with barriers only where a step crosses waves.  Thread i owns the pair (lo, lo | j) of every step; with
-// NT threads working on the pairs [0, M/2) a wave's 64 pairs of a step with j <= 64 lie inside the wave's own
-// 128-element block, which the same wave also wrote in the previous step if that step had j <= 64 too: LDS operations
-// of one wave are processed in order, so such steps need no s_barrier (45 barriers -> 5 for M = 512, 66 -> 14 for
-// M = 2048).  Pairs beyond NT per step (M/2 > NT) are visited in rounds that keep the same ownership rule.
-template <int NT>
-__device__ void wg_bitonic_sort_desc_mixed(u64* a, u32 M) {  // M power of two, M >= 2
-  const u32 tid = threadIdx.x;
-  const u32 half = M >> 1;
-  u32 prev_j = 0x40000000u;  // "written by other waves": the caller's stores, ordered by the first barrier
-  for (u32 k = 2; k <= M; k <<= 1) {
-    for (u32 j = k >> 1; j > 0; j >>= 1) {
-      // pair index p -> wave owning it in a round = (p % NT) / 64; block of elements touched = 128 * (p / 64)
-      if (prev_j > 64u || j > 64u || half > (u32)NT) __syncthreads();
-      else __builtin_amdgcn_wave_barrier();
-      for (u32 i = tid; i < half; i += NT) {
-        const u32 lo = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-        const u32 hi = lo | j;
-        const bool desc = (lo & k) == 0;
-        const u64 x = a[lo], y = a[hi];
-        if ((x < y) == desc) {
-          a[lo] = y;
-          a[hi] = x;
-        }
-      }
-      prev_j = j;
-    }
-  }
-  __syncthreads();
-}
-
 // ---- sorting by wave-local runs + rank merge ---------------------------------------------------
 // A wave sorts 128 keys in registers (2 per lane, element e = lane + 64 r): 28 compare-exchange steps, cross-lane
 // partners by shuffles, no LDS traffic and no barrier.  Sorted runs of 128 are then merged WITHOUT a merge network:

@@ -36,11 +36,11 @@ with torch.no_grad():
     t_all = timeit(lambda: model(x))
     print("backbone %.2f ms, full forward %.2f ms (neck+towers %.2f ms)" % (t_bb, t_all, t_all - t_bb))
     plan = list(model._neck_plans.values())[0]
-    N.lib.ssdk_set_op_profiling(1)
+    plan.ctx.set_op_profiling(True)  # per-op hipEvents live in the plan's own context
     model(x)
     torch.cuda.synchronize()
-    t = N.op_timings()
-    N.lib.ssdk_set_op_profiling(0)
+    t = plan.ctx.op_timings()
+    plan.ctx.set_op_profiling(False)
     tot = {}
     for row, (kern, ms) in zip(plan.layer_table(), t):
         key = (row["name"], kern.replace("_kernel", ""))
