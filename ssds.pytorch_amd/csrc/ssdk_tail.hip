@@ -243,10 +243,16 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
       for (u32 v = 1; v < L; ++v)
         if (u >= S->lv[v].unit_base) l = v;
       const u32 u0 = S->lv[l].unit_base, nruns = S->lv[l].units, nq = uq[u];
+      // Only the surviving PREFIXES of the sibling lists can hold keys above one of ours (everything behind a prefix is
+      // below the level's bound, our keys are at or above it): the searches run over uq[], and not at all when no sibling
+      // has a prefix -- an all-equal image (the reference-init network: every score ties, the first list of a level IS
+      // its top K) then costs a wave 5 stores instead of 5 x nruns x 9 dependent LDS reads (36k -> 2k cycles).
+      u32 others = 0;
+      for (u32 v = u0; v < u0 + nruns; ++v) others += v != u ? uq[v] : 0u;  // wave-uniform
       for (u32 i = lane; i < nq; i += 64) {
         const u64 key = ukeys[(size_t)u * K + i];
         u32 rank = i;
-        if (nruns > 1) rank += count_greater_runs(ukeys + (size_t)u0 * K, K, ucnt + u0, 0, nruns, u - u0, key, steps);
+        if (others) rank += count_greater_runs(ukeys + (size_t)u0 * K, K, uq + u0, 0, nruns, u - u0, key, steps);
         if (rank < K) wl[l * K + rank] = key;
       }
     }
