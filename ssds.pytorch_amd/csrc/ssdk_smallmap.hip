@@ -21,9 +21,11 @@ constexpr int kSmThreads = 256;
 // drain the load counter at the top of every iteration (s_waitcnt vmcnt(0)) however the body is written
 // MFR = pixel fragments per workgroup (4: 64 pixels, 8: 128 pixels -- half the weight traffic per pixel, for the level
 // whose grid still fills the chip then)
-template <int DT, int CS, int MFR>
+// TAPS = 9, or 1 for 1x1 maps: only the centre tap ever sees data there (the other eight multiply the padding), so K is Cin
+template <int DT, int CS, int MFR, int TAPS>
 __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvParams p) {
   constexpr int ROWS = 16 * MFR;
+  constexpr int TAP0 = TAPS == 9 ? 0 : 4;  // first tap visited
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const u32 fr = lane & 15u, fg = lane >> 4;
@@ -43,13 +45,13 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
     }
   }
   // LDS byte offset of the input pixel behind (output pixel = fragment m, lane fr; tap), the zero row outside the map
-  u32 rowoff[MFR][9];
+  u32 rowoff[MFR][TAPS];
 #pragma unroll
   for (int m = 0; m < MFR; ++m) {
     const int px = m * 16 + (int)fr, g = px / P, q = px % P, oy = q / p.Wo, ox = q % p.Wo;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int iy = oy - 1 + t / 3, ix = ox - 1 + t % 3;
+    for (int t = 0; t < TAPS; ++t) {
+      const int iy = oy - 1 + (t + TAP0) / 3, ix = ox - 1 + (t + TAP0) % 3;
       const bool ok = (unsigned)iy < (unsigned)p.Ho && (unsigned)ix < (unsigned)p.Wo;
       rowoff[m][t] = (u32)((ok ? g * P + iy * p.Wo + ix : ROWS) * RS) + fg * 16u;
     }
@@ -69,22 +71,22 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   // the compiler counts the loads in flight (s_waitcnt vmcnt(17)) instead of draining them -- a k-step is four MFMAs
   // (~70 cycles), an L2 round trip 2-4k cycles, and with a branch in the body every k-step waited for its own load
   // (1.2k cycles per k-step measured).
-  u32x4 rw[2][9];
+  u32x4 rw[2][TAPS];
   auto issue = [&](int buf, int t, int slc) {
     const int s2 = slc < CS ? slc : CS - 1;  // past the end: a harmless re-read
-    rw[buf][t] = *reinterpret_cast<const u32x4*>(wrow + (size_t)(t * CS + s2) * 32);
+    rw[buf][t] = *reinterpret_cast<const u32x4*>(wrow + (size_t)((t + TAP0) * CS + s2) * 32);
   };
 #pragma unroll
-  for (int t = 0; t < 9; ++t) issue(0, t, 0);
+  for (int t = 0; t < TAPS; ++t) issue(0, t, 0);
 #pragma unroll
-  for (int t = 0; t < 9; ++t) issue(1, t, 1);
+  for (int t = 0; t < TAPS; ++t) issue(1, t, 1);
 #pragma unroll
   for (int sl0 = 0; sl0 < CS; sl0 += 2) {
 #pragma unroll
     for (int bsl = 0; bsl < 2; ++bsl) {
       const int sl = sl0 + bsl;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
+      for (int t = 0; t < TAPS; ++t) {
 #pragma unroll
         for (int m = 0; m < MFR; ++m) {
           const u32x4 b = *reinterpret_cast<const u32x4*>(smem + rowoff[m][t] + sl * 64);
@@ -138,20 +140,21 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   // waves (= 16-channel fragments) per workgroup
   const int groups = (p.N + G - 1) / G, nfr = (p.Cout + 15) / 16;
   static const int env_nw = getenv("SSDK_CONV_SMALLMAP_NW") ? atoi(getenv("SSDK_CONV_SMALLMAP_NW")) : 4;
-  int nw = env_nw == 1 || env_nw == 2 ? env_nw : 4;  // (finer splits measured slower: 30 / 34 / 23 us against 28 / 27 / 19)
+  const int nw = env_nw == 1 || env_nw == 2 ? env_nw : 4;  // (fewer waves per workgroup = more workgroups: measured slower on every level)
   const dim3 grid((unsigned)groups, (unsigned)((nfr + nw - 1) / nw));
   const size_t lds = (size_t)(16 * mfr + 1) * (p.Cin * 2 + 16);
   const int cs = p.Cin / 32;
-#define SSDK_SM1(DT, CS_, MFR_)                                                                                            \
+#define SSDK_SM1(DT, CS_, MFR_, TAPS_)                                                                                     \
   do {                                                                                                                     \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_, MFR_>),                        \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_, MFR_, TAPS_>),                 \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
-    hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_, MFR_>), grid, dim3(64 * nw), lds, stream, p);                        \
+    hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_, MFR_, TAPS_>), grid, dim3(64 * nw), lds, stream, p);                 \
   } while (0)
-#define SSDK_SM(DT, CS_)                 \
-  do {                                   \
-    if (mfr == 8) SSDK_SM1(DT, CS_, 8);  \
-    else SSDK_SM1(DT, CS_, 4);           \
+#define SSDK_SM(DT, CS_)                       \
+  do {                                         \
+    if (P == 1) SSDK_SM1(DT, CS_, 4, 1);       \
+    else if (mfr == 8) SSDK_SM1(DT, CS_, 8, 9); \
+    else SSDK_SM1(DT, CS_, 4, 9);              \
   } while (0)
   if (dtype == SSDK_BF16) {
     if (cs == 4) SSDK_SM(SSDK_BF16, 4);
