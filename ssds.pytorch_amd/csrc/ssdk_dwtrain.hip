@@ -316,6 +316,13 @@ static constexpr size_t dwt_lds_dy(int s) {  // tile of dy behind a DT_TH x DT_T
   return (size_t)((DT_TH + 1) / s + 2) * (((DT_TW + 1) / s + 2) | 1) * sizeof(float);
 }
 
+// ssdk_dwplane.hip: the whole-row kernels (0: launched, 1: not taken)
+int launch_dwp_fwd(const void* x, const void* w, void* y, int N, int C, int H, int W, int stride, int dtype, hipStream_t stream);
+int launch_dwp_dgrad(const void* dy, const void* w, void* dx, int N, int C, int H, int W, int stride, int dtype, hipStream_t stream);
+size_t dwp_wgrad_workspace_bytes(int N, int C, int H, int W, int stride);
+int launch_dwp_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int C, int H, int W,
+                     int stride, int dtype, hipStream_t stream);
+
 }  // namespace ssdk
 
 using namespace ssdk;
@@ -324,6 +331,7 @@ extern "C" int ssdk_dwconv_fwd(const void* x, const void* w, void* y, int N, int
                                void* stream) {
   const int rc = dwt_check("dwconv_fwd", x, w, y, N, C, H, W, stride, dtype);
   if (rc) return rc;
+  if (launch_dwp_fwd(x, w, y, N, C, H, W, stride, dtype, (hipStream_t)stream) == 0) return check_launch("dwp_fwd_kernel");
   DwtParams p = dwt_params(x, w, y, N, C, H, W, stride, dtype, false);
   const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)(N * C));
   SSDK_DWT_LAUNCH(dw_fwd_kernel, grid, dwt_lds_in(1), dwt_lds_in(2));
@@ -334,6 +342,7 @@ extern "C" int ssdk_dwconv_bwd_data(const void* dy, const void* w, void* dx, int
                                     int dtype, void* stream) {
   const int rc = dwt_check("dwconv_bwd_data", dy, w, dx, N, C, H, W, stride, dtype);
   if (rc) return rc;
+  if (launch_dwp_dgrad(dy, w, dx, N, C, H, W, stride, dtype, (hipStream_t)stream) == 0) return check_launch("dwp_dgrad_kernel");
   DwtParams p = dwt_params(dy, w, dx, N, C, H, W, stride, dtype, true);
   const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)(N * C));
   SSDK_DWT_LAUNCH(dw_dgrad_kernel, grid, dwt_lds_dy(1), dwt_lds_dy(2));
@@ -342,7 +351,9 @@ extern "C" int ssdk_dwconv_bwd_data(const void* dy, const void* w, void* dx, int
 
 extern "C" size_t ssdk_dwconv_bwd_weight_workspace_bytes(int N, int C, int H, int W, int stride) {
   const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-  return (size_t)N * C * ((Wo + DT_TW - 1) / DT_TW) * ((Ho + DT_TH - 1) / DT_TH) * 9 * sizeof(float);
+  const size_t tiled = (size_t)N * C * ((Wo + DT_TW - 1) / DT_TW) * ((Ho + DT_TH - 1) / DT_TH) * 9 * sizeof(float);
+  const size_t rows = dwp_wgrad_workspace_bytes(N, C, H, W, stride);  // either kernel family may take the call
+  return tiled > rows ? tiled : rows;
 }
 
 extern "C" int ssdk_dwconv_bwd_weight(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
@@ -353,6 +364,8 @@ extern "C" int ssdk_dwconv_bwd_weight(const void* x, const void* dy, float* dw, 
     set_error("dwconv_bwd_weight: workspace too small");
     return SSDK_E_BADARG;
   }
+  if (launch_dwp_wgrad(x, dy, dw, workspace, workspace_bytes, N, C, H, W, stride, dtype, (hipStream_t)stream) == 0)
+    return check_launch("dwp_wgrad_kernel");
   DwtParams p = dwt_params(x, dy, workspace, N, C, H, W, stride, dtype, false);
   const int tiles = p.tiles_x * p.tiles_y;
   const dim3 grid((unsigned)tiles, (unsigned)(N * C));

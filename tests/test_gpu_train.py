@@ -58,7 +58,12 @@ def test_model_with_loss_matches_cpu_oracle_step():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype_name,tol", [("float32", 1e-4), ("bfloat16", 2e-2), ("float16", 4e-3)])
-@pytest.mark.parametrize("c,stride,h,w,n", [(32, 1, 20, 24, 3), (96, 2, 33, 31, 2), (144, 2, 64, 70, 2), (8, 1, 5, 130, 1)])
+@pytest.mark.parametrize("c,stride,h,w,n", [(32, 1, 20, 24, 3), (96, 2, 33, 31, 2), (144, 2, 64, 70, 2), (8, 1, 5, 130, 1),
+                                            # the plane sizes of MobileNetV2@300 (whole-row kernels: bands of one plane, several
+                                            # images per workgroup with a ragged last group), then a row too wide for them
+                                            (3, 1, 150, 150, 2), (3, 2, 150, 150, 2), (5, 1, 75, 75, 2), (5, 2, 75, 75, 2),
+                                            (6, 1, 38, 38, 7), (6, 2, 38, 38, 7), (4, 1, 19, 19, 27), (4, 2, 19, 19, 27),
+                                            (2, 1, 10, 10, 70), (3, 1, 1, 1, 2), (2, 2, 3, 3000, 1)])
 def test_depthwise_autograd_kernels_match_torch(c, stride, h, w, n, dtype_name, tol):
     """forward / input gradient / weight gradient of the training depthwise kernels vs torch fp32 autograd."""
     import torch
