@@ -329,7 +329,9 @@ int ssdk_preprocess(const void* x, int src_dtype, int src_layout, int N, int H, 
  * behind torch.nn.functional.conv2d(groups = C) in the DDP step, pipeline_anchor_apex.py:75-171).
  *   fwd:        x [N,C,H,W], w [C,1,3,3] -> y [N,C,Ho,Wo]
  *   bwd_data:   dy [N,C,Ho,Wo], w -> dx [N,C,H,W]           (H, W are the INPUT dims in all three calls)
- *   bwd_weight: x, dy -> dw fp32 [C,1,3,3]; two-stage fixed-order reduction (bit-reproducible) through `workspace` */
+ *   bwd_weight: x, dy -> dw fp32 [C,1,3,3]; two-stage fixed-order reduction (bit-reproducible) through `workspace`
+ * Any plane size; pointers need only the alignment of their element type (rows are read and written as unaligned
+ * 16-byte runs). */
 int ssdk_dwconv_fwd(const void* x, const void* w, void* y, int N, int C, int H, int W, int stride, int dtype, void* stream);
 int ssdk_dwconv_bwd_data(const void* dy, const void* w, void* dx, int N, int C, int H, int W, int stride, int dtype,
                          void* stream);

@@ -1,5 +1,7 @@
 // ssdk_dwtrain.hip -- depthwise 3x3 convolution for the TRAINING step (forward, input gradient, weight gradient),
-// NCHW, fp32 | bf16 | f16, fp32 accumulation, on gfx950.
+// NCHW, fp32 | bf16 | f16, fp32 accumulation, on gfx950: the C-ABI entry points, and the TILED kernels (round 1).
+// Since round 2 the entry points try the whole-row kernels of ssdk_dwplane.hip first (3-5x faster on the plane sizes
+// the backbones have); the tiled kernels below take rows too wide for that kernel's LDS budget and SSDK_DW_PLANE=0.
 //
 // Why: the DDP training step of SSD-MobileNetV2 (reference pipeline_anchor_apex.py:75-171 on torchvision's
 // InvertedResidual blocks) spends more than half of its GPU time in MIOpen's `naive_conv_*_wrw/bwd/fwd` kernels,

@@ -1,5 +1,5 @@
 """Depthwise 3x3 convolution with hand-written HIP forward / input-gradient / weight-gradient kernels
-(``csrc/ssdk_dwtrain.hip``) behind ``torch.autograd`` -- the training-step replacement for what PyTorch-ROCm
+(``csrc/ssdk_dwplane.hip``: whole-row bands of the planes; ``csrc/ssdk_dwtrain.hip``: the tiled fallback) behind ``torch.autograd`` -- the training-step replacement for what PyTorch-ROCm
 dispatches to MIOpen's ``naive_conv_*`` kernels (more than half of the GPU time of the reference's DDP step on
 SSD-MobileNetV2: pipeline_anchor_apex.py:75-171 over torchvision ``InvertedResidual`` blocks, mobilenet.py:56).
 
