@@ -238,6 +238,199 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const BnParams p) {
   }
 }
 
+// ---- round 2: the same two passes over FLAT element ranges ---------------------------------------------------------------
+// The kernels above keep one 16-byte load in flight per thread (the reduction's loop) or handle one vector per thread and
+// 256 * 8 elements per workgroup (the apply pass), use vectors only when the plane size is a multiple of the vector width
+// (never at 300 px: 150^2 ... 10^2), and leave most of a workgroup idle on small planes (16 x 16: 32 of 256 threads).
+// Measured: ~4 TB/s on the large planes, far less on the small ones; BatchNorm was 7.2 of the 22 ms of kernel time of the
+// training step once the depthwise kernels were rewritten (profiles/r02_train_kernel_split_v2.txt).
+// Here every access is a 16-byte vector at the element type's own alignment (unaligned access mode, as in
+// ssdk_dwplane.hip), four per thread in flight, over index spaces that do not care about plane boundaries:
+//   reduce: workgroup (c, s) runs over the vectors of ALL its planes n = s, s + split, ... as one list (+ the < 8 tail
+//           elements of each plane one by one);
+//   apply:  a workgroup owns 8192 consecutive elements -- a chunk of one large plane, or several whole small planes, whose
+//           channel is recovered per vector from the element's offset (a vector that straddles two planes takes its
+//           coefficients element by element).
+typedef u32x4 bn_u32x4_a2 __attribute__((aligned(2)));
+typedef u32x4 bn_u32x4_a4 __attribute__((aligned(4)));
+constexpr int kBnU = 4;            // vectors per thread in flight
+constexpr int kBnChunk = 8192;     // elements per workgroup of the apply pass
+
+template <int DT> __device__ __forceinline__ u32x4 bn_load_raw(const void* src, size_t i) {
+  if constexpr (DT == SSDK_F32) return *reinterpret_cast<const bn_u32x4_a4*>((const u32*)src + i);
+  else return *reinterpret_cast<const bn_u32x4_a2*>((const u16*)src + i);
+}
+template <int DT> __device__ __forceinline__ void bn_unpack(const u32x4 q, float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const u32 t = q[e];  // (a scalar first: __builtin_bit_cast of a vector element reads element 0)
+    if constexpr (DT == SSDK_F32) {
+      v[e] = __builtin_bit_cast(float, t);
+    } else {
+      v[2 * e] = bits16_to_f32<DT>(t & 0xffffu);
+      v[2 * e + 1] = bits16_to_f32<DT>(t >> 16);
+    }
+  }
+}
+template <int DT> __device__ __forceinline__ void bn_store_raw(void* dst, size_t i, const float (&o)[8]) {
+  if constexpr (DT == SSDK_F32) {
+    const u32x4 q = {__builtin_bit_cast(u32, o[0]), __builtin_bit_cast(u32, o[1]), __builtin_bit_cast(u32, o[2]), __builtin_bit_cast(u32, o[3])};
+    *reinterpret_cast<bn_u32x4_a4*>((u32*)dst + i) = q;
+  } else {
+    const u32x4 q = {pack2_16<DT>(o[0], o[1]), pack2_16<DT>(o[2], o[3]), pack2_16<DT>(o[4], o[5]), pack2_16<DT>(o[6], o[7])};
+    *reinterpret_cast<bn_u32x4_a2*>((u16*)dst + i) = q;
+  }
+}
+template <int DT> __device__ __forceinline__ void bn_st1(void* p, size_t i, float v) {
+  if constexpr (DT == SSDK_F32) ((float*)p)[i] = v;
+  else ((u16*)p)[i] = (u16)f32_to_bits16<DT>(v);
+}
+// v / d for 0 <= v < 2^20, rcp = 1.0f / d (exact: the +0.5 keeps the product half a step away from every integer)
+__device__ __forceinline__ int bn_div_small(int v, float rcp) { return (int)(((float)v + 0.5f) * rcp); }
+
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_flat_kernel(const BnParams p) {
+  __shared__ float red[4][2];
+  constexpr int VN = BnVec<DT>::n;
+  const int c = blockIdx.x, s = blockIdx.y;
+  const float k = MODE == 0 ? bn_ld1<DT>(p.x, (size_t)c * p.HW) : p.save_mean[c];
+  const float istd = MODE == 0 ? 1.f : p.save_invstd[c];
+  const bool masked = MODE == 1 && p.act != 0;
+  const float fa = masked ? (p.weight ? p.weight[c] : 1.f) * istd : 0.f;  // forward y = x*fa + fb
+  const float fb = masked ? (p.bias ? p.bias[c] : 0.f) - p.save_mean[c] * fa : 0.f;
+  const int act = p.act;
+  float a = 0.f, b = 0.f;
+  auto acc = [&](float x, float g) {
+    const float d = x - k;
+    if (MODE == 0) {
+      a += d;
+      b += d * d;
+    } else {
+      if (masked && !bn_act_open<DT>(x * fa + fb, act)) g = 0.f;
+      a += g;
+      b += g * d * istd;
+    }
+  };
+  const u32 np = (u32)((p.N - s + p.split - 1) / p.split);  // planes of this workgroup: n = s + j * split
+  const u32 vpp = (u32)p.HW / VN, tail = (u32)p.HW - vpp * VN;
+  const u32 W = np * vpp;
+  const size_t nstride = (size_t)p.split * p.C * p.HW, first = ((size_t)s * p.C + c) * p.HW;
+  for (u32 v0 = threadIdx.x; v0 < W; v0 += 256 * kBnU) {
+    u32x4 xr[kBnU], gr[kBnU];
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) {
+      const u32 v = v0 + u * 256;
+      xr[u] = u32x4{0u, 0u, 0u, 0u};
+      gr[u] = u32x4{0u, 0u, 0u, 0u};
+      if (v < W) {
+        const u32 j = v / vpp;
+        const size_t off = first + j * nstride + (size_t)(v - j * vpp) * VN;
+        xr[u] = bn_load_raw<DT>(p.x, off);
+        if (MODE == 1) gr[u] = bn_load_raw<DT>(p.dy, off);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // all the loads of the trip in flight before the first one is waited for
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) {
+      if (v0 + u * 256 >= W) continue;
+      float xv[8], gv[8];
+      bn_unpack<DT>(xr[u], xv);
+      bn_unpack<DT>(gr[u], gv);
+#pragma unroll
+      for (int e = 0; e < VN; ++e) acc(xv[e], gv[e]);
+    }
+  }
+  if (tail) {
+    for (u32 t = threadIdx.x; t < np * tail; t += 256) {
+      const u32 j = t / tail;
+      const size_t off = first + j * nstride + (size_t)vpp * VN + (t - j * tail);
+      acc(bn_ld1<DT>(p.x, off), MODE == 1 ? bn_ld1<DT>(p.dy, off) : 0.f);
+    }
+  }
+  block_sum2(a, b, red);
+  if (threadIdx.x == 0) {
+    p.partial[((size_t)c * p.split + s) * 2 + 0] = a;
+    p.partial[((size_t)c * p.split + s) * 2 + 1] = b;
+  }
+}
+
+struct BnFlat {
+  int G, chunks;       // whole planes per workgroup (chunks == 1) | chunks of kBnChunk elements per plane (G == 1)
+  float rcpHW, rcpC;
+};
+
+// MODE 0: out = x*a + b (+ activation).  MODE 1: out = dy*a + x*k1 + k0 (dy masked by the activation).
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void bn_apply_flat_kernel(const BnParams p, const BnFlat f) {
+  constexpr int VN = BnVec<DT>::n;
+  const int act = p.act;
+  const long NC = (long)p.N * p.C;
+  const u32 bid = blockIdx.x;
+  const long P0 = (long)(bid / (u32)f.chunks) * f.G;                     // first plane of this workgroup
+  const int lo = (int)(bid % (u32)f.chunks) * kBnChunk;                   // element range [lo, hi) from the start of plane P0
+  const long left = NC - P0;
+  const int hi = f.chunks > 1 ? (p.HW - lo < kBnChunk ? p.HW : lo + kBnChunk) : (int)(left < f.G ? left : f.G) * p.HW;
+  const int c0 = (int)(P0 % p.C);
+  const size_t base = (size_t)P0 * p.HW;
+  auto channel = [&](int le) {  // channel of the element at offset le from the start of plane P0
+    if (f.chunks > 1) return c0;
+    const int cc = c0 + bn_div_small(le, f.rcpHW);
+    return cc - bn_div_small(cc, f.rcpC) * p.C;
+  };
+  auto one = [&](float x, float g, const float4 k) {  // k = (a, k0, k1, fb)
+    if (MODE == 0) {
+      float o = x * k.x + k.y;
+      if (act) o = fmaxf(o, 0.f);
+      if (act == 1) o = fminf(o, 6.f);
+      return o;
+    }
+    if (act && !bn_act_open<DT>(x * k.x + k.w, act)) g = 0.f;
+    return g * k.x + x * k.z + k.y;
+  };
+  const float4* coef = reinterpret_cast<const float4*>(p.coef);
+  const int nvec = (hi - lo) / VN;
+  for (int vb = 0; vb < nvec; vb += 256 * kBnU) {
+    u32x4 xr[kBnU], gr[kBnU];
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) {
+      const int v = vb + u * 256 + (int)threadIdx.x;
+      xr[u] = u32x4{0u, 0u, 0u, 0u};
+      gr[u] = u32x4{0u, 0u, 0u, 0u};
+      if (v < nvec) {
+        const size_t off = base + lo + (size_t)v * VN;
+        xr[u] = bn_load_raw<DT>(p.x, off);
+        if (MODE == 1) gr[u] = bn_load_raw<DT>(p.dy, off);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < kBnU; ++u) {
+      const int v = vb + u * 256 + (int)threadIdx.x;
+      if (v >= nvec) continue;
+      const int le = lo + v * VN;
+      float xv[8], gv[8], o[8];
+      bn_unpack<DT>(xr[u], xv);
+      bn_unpack<DT>(gr[u], gv);
+      const int pl = f.chunks > 1 ? 0 : bn_div_small(le, f.rcpHW);
+      if (f.chunks > 1 || le + VN <= (pl + 1) * p.HW) {  // one plane: one set of coefficients
+        const float4 k = coef[channel(le)];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) o[e] = one(xv[e], gv[e], k);
+      } else {  // the vector straddles planes (plane sizes that are not a multiple of the vector width)
+#pragma unroll
+        for (int e = 0; e < VN; ++e) o[e] = one(xv[e], gv[e], coef[channel(le + e)]);
+      }
+      bn_store_raw<DT>(p.out, base + le, o);
+    }
+  }
+  const int rest = (hi - lo) - nvec * VN;  // < VN elements at the end of the range
+  if ((int)threadIdx.x < rest) {
+    const int le = lo + nvec * VN + (int)threadIdx.x;
+    const float x = bn_ld1<DT>(p.x, base + le), g = MODE == 1 ? bn_ld1<DT>(p.dy, base + le) : 0.f;
+    bn_st1<DT>(p.out, base + le, one(x, g, coef[channel(le)]));
+  }
+}
+
 static int bn_split(int N, int C) {
   int s = (1024 + C - 1) / C;
   if (s > N) s = N;
@@ -247,15 +440,31 @@ static int bn_split(int N, int C) {
 
 template <int MODE>
 static void bn_launch(const BnParams& p, hipStream_t st) {
+  // 0: never, 1: always, 2 (default): where the per-plane kernels cannot use vectors (plane size not a multiple of the
+  // vector width, or a misaligned tensor) -- there they work element by element.  On the vector-friendly planes of the
+  // 512 px step the flat kernels measured SLOWER than the per-plane ones (27.6 against 25.6 ms per step), so those keep them.
+  static const int env_flat = getenv("SSDK_BN_FLAT") ? atoi(getenv("SSDK_BN_FLAT")) : 2;
   const dim3 rgrid((unsigned)p.C, (unsigned)p.split);
   const int vn = p.dtype == SSDK_F32 ? 4 : 8;
-  const dim3 agrid((unsigned)((p.HW + 256 * vn - 1) / (256 * vn)), (unsigned)((long)p.N * p.C));
+  // the flat kernels: 32-bit element offsets inside a workgroup's range, the coefficient table read as float4
+  const bool vec_ok = (p.HW % vn) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)p.dy) | ((uintptr_t)p.out)) & 15u) == 0;
+  const bool flat = (env_flat == 1 || (env_flat == 2 && !vec_ok)) && (long)p.N * p.HW < (1l << 30) && p.HW < (1 << 20) && p.C < (1 << 19);
+  BnFlat f;
+  f.G = p.HW >= kBnChunk ? 1 : kBnChunk / p.HW;
+  f.chunks = p.HW >= kBnChunk ? (p.HW + kBnChunk - 1) / kBnChunk : 1;
+  f.rcpHW = 1.0f / (float)p.HW;
+  f.rcpC = 1.0f / (float)p.C;
+  const long NC = (long)p.N * p.C;
+  const long fgrid = f.chunks > 1 ? NC * f.chunks : (NC + f.G - 1) / f.G;
+  const dim3 agrid((unsigned)((p.HW + 256 * vn - 1) / (256 * vn)), (unsigned)NC);
 #define SSDK_BN(DT)                                                                                         \
   do {                                                                                                      \
-    hipLaunchKernelGGL((bn_reduce_kernel<DT, MODE>), rgrid, dim3(256), 0, st, p);                           \
+    if (flat) hipLaunchKernelGGL((bn_reduce_flat_kernel<DT, MODE>), rgrid, dim3(256), 0, st, p);            \
+    else hipLaunchKernelGGL((bn_reduce_kernel<DT, MODE>), rgrid, dim3(256), 0, st, p);                      \
     if (MODE == 0) hipLaunchKernelGGL((bn_fwd_finalize_kernel<DT>), dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p); \
     else hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p);  \
-    hipLaunchKernelGGL((bn_apply_kernel<DT, MODE>), agrid, dim3(256), 0, st, p);                             \
+    if (flat && fgrid < (1l << 31)) hipLaunchKernelGGL((bn_apply_flat_kernel<DT, MODE>), dim3((unsigned)fgrid), dim3(256), 0, st, p, f); \
+    else hipLaunchKernelGGL((bn_apply_kernel<DT, MODE>), agrid, dim3(256), 0, st, p);                        \
   } while (0)
   if (p.dtype == SSDK_F32) SSDK_BN(SSDK_F32);
   else if (p.dtype == SSDK_BF16) SSDK_BN(SSDK_BF16);
@@ -268,7 +477,8 @@ static void bn_launch(const BnParams& p, hipStream_t st) {
 using namespace ssdk;
 
 extern "C" size_t ssdk_bn_workspace_bytes(int N, int C) {
-  return ((size_t)C * bn_split(N, C) * 2 + (size_t)C * 4) * sizeof(float);
+  // partial sums [C][split][2], rounded up to a multiple of 4 floats (the coefficient table behind it stays 16-byte aligned)
+  return ((((size_t)C * bn_split(N, C) * 2 + 3) & ~(size_t)3) + (size_t)C * 4) * sizeof(float);
 }
 
 static int bn_common(BnParams& p, const char* what, int N, int C, int HW, int dtype, void* workspace, size_t workspace_bytes) {
@@ -286,7 +496,7 @@ static int bn_common(BnParams& p, const char* what, int N, int C, int HW, int dt
   p.dtype = dtype;
   p.split = bn_split(N, C);
   p.partial = (float*)workspace;
-  p.coef = p.partial + (size_t)C * p.split * 2;
+  p.coef = p.partial + (((size_t)C * p.split * 2 + 3) & ~(size_t)3);
   return SSDK_OK;
 }
 

@@ -103,7 +103,10 @@ def test_depthwise_autograd_kernels_match_torch(c, stride, h, w, n, dtype_name, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype_name,tol", [("float32", 2e-4), ("bfloat16", 2e-2), ("float16", 4e-3)])
-@pytest.mark.parametrize("n,c,h,w", [(4, 32, 16, 24), (3, 17, 9, 7), (64, 8, 32, 32), (2, 144, 13, 13)])
+@pytest.mark.parametrize("n,c,h,w", [(4, 32, 16, 24), (3, 17, 9, 7), (64, 8, 32, 32), (2, 144, 13, 13),
+                                     # planes larger than one workgroup's chunk (ragged last chunk, a tail shorter than a vector),
+                                     # many small planes per workgroup with vectors that straddle planes, 1 x 1 planes
+                                     (2, 6, 150, 150), (1, 4, 100, 100), (70, 3, 10, 10), (5, 7, 19, 19), (9, 5, 1, 1)])
 def test_batchnorm_training_kernels_match_torch(n, c, h, w, dtype_name, tol):
     """forward (output, running statistics) and backward (dx, dweight, dbias) vs nn.BatchNorm2d in fp32."""
     import torch
@@ -148,7 +151,7 @@ def test_batchnorm_training_kernels_match_torch(n, c, h, w, dtype_name, tol):
 @pytest.mark.gpu
 @pytest.mark.parametrize("act_name", ["ReLU6", "ReLU"])
 @pytest.mark.parametrize("dtype_name", ["float32", "bfloat16", "float16"])
-@pytest.mark.parametrize("n,c,h,w", [(4, 32, 16, 24), (3, 17, 9, 7), (64, 8, 32, 32)])
+@pytest.mark.parametrize("n,c,h,w", [(4, 32, 16, 24), (3, 17, 9, 7), (64, 8, 32, 32), (2, 6, 150, 150), (70, 3, 10, 10)])
 def test_batchnorm_with_folded_activation_is_bit_identical_to_the_two_step_path(n, c, h, w, dtype_name, act_name):
     """Conv-BN-ReLU6: the activation folded into the BatchNorm kernels (forward clamp, backward mask recomputed from
     the rounded pre-activation) against the same kernels followed by torch's activation -- outputs, dx, dweight, dbias

@@ -27,6 +27,7 @@ ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--channels-last", type=int, default=0)
 ap.add_argument("--gpus", type=int, default=1)
+ap.add_argument("--size", type=int, default=0, help="square input size instead of the config's (300: planes that are not a multiple of 8)")
 args = ap.parse_args()
 if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: become N ranks on this node
     import socket
@@ -48,6 +49,8 @@ if world > 1:
     dist.init_process_group("nccl", device_id=dev)
 cfg = config.cfg_from_file(os.path.join(ROOT, "experiments", "cfgs", "ssd_mobilenetv2_512.yml"))
 cfg.TRAIN.BATCH_SIZE = args.batch
+if args.size:
+    cfg.MODEL.IMAGE_SIZE = [args.size, args.size]
 cfg.EXP_DIR = "/tmp/ssdk_bench_train"
 torch.manual_seed(1234)
 solver = Solver(cfg, lr, dev)
@@ -83,7 +86,7 @@ if world > 1:
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t)
 if rank == 0:
-    print(json.dumps({"metric": "images/sec (DDP training step) SSD-MobileNetV2@512", "value": round(world * args.batch * args.steps / el, 1),
+    print(json.dumps({"metric": "images/sec (DDP training step) SSD-MobileNetV2@%d" % cfg.MODEL.IMAGE_SIZE[0], "value": round(world * args.batch * args.steps / el, 1),
                       "n_gpus": world, "ms_per_step": round(el / args.steps * 1e3, 2), "batch_per_gpu": args.batch,
                       "cls_loss": float(c), "loc_loss": float(l), "dtype": "bf16 autocast", "data": "synthetic"}))
 if world > 1:
