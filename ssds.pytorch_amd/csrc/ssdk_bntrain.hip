@@ -440,15 +440,18 @@ static int bn_split(int N, int C) {
 
 template <int MODE>
 static void bn_launch(const BnParams& p, hipStream_t st) {
-  // 0: never, 1: always, 2 (default): where the per-plane kernels cannot use vectors (plane size not a multiple of the
-  // vector width, or a misaligned tensor) -- there they work element by element.  On the vector-friendly planes of the
-  // 512 px step the flat kernels measured SLOWER than the per-plane ones (27.6 against 25.6 ms per step), so those keep them.
+  // 0: the per-plane kernels, 1: the flat kernels, 2 (default): the flat reduction always, the flat apply pass only where
+  // the per-plane one cannot use vectors (plane size not a multiple of the vector width, or a misaligned tensor: there it
+  // works element by element).  Per launch on the 512 px step, bf16 (profiles/r02_train_kernel_split_v2.txt against a trace
+  // with SSDK_BN_FLAT=1): reduction 21.2 -> 18.1 us forward, 38.8 -> 36.6 us backward; apply 26.3 -> 25.8 us forward but
+  // 38.0 -> 45.0 us backward (eight vectors in flight per thread, 84 VGPRs) -- hence the split.
   static const int env_flat = getenv("SSDK_BN_FLAT") ? atoi(getenv("SSDK_BN_FLAT")) : 2;
   const dim3 rgrid((unsigned)p.C, (unsigned)p.split);
   const int vn = p.dtype == SSDK_F32 ? 4 : 8;
-  // the flat kernels: 32-bit element offsets inside a workgroup's range, the coefficient table read as float4
   const bool vec_ok = (p.HW % vn) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)p.dy) | ((uintptr_t)p.out)) & 15u) == 0;
-  const bool flat = (env_flat == 1 || (env_flat == 2 && !vec_ok)) && (long)p.N * p.HW < (1l << 30) && p.HW < (1 << 20) && p.C < (1 << 19);
+  const bool fits = (long)p.N * p.HW < (1l << 30) && p.HW < (1 << 20) && p.C < (1 << 19);
+  const bool flat_r = env_flat != 0 && fits;
+  const bool flat = (env_flat == 1 || (env_flat == 2 && !vec_ok)) && fits;
   BnFlat f;
   f.G = p.HW >= kBnChunk ? 1 : kBnChunk / p.HW;
   f.chunks = p.HW >= kBnChunk ? (p.HW + kBnChunk - 1) / kBnChunk : 1;
@@ -459,7 +462,7 @@ static void bn_launch(const BnParams& p, hipStream_t st) {
   const dim3 agrid((unsigned)((p.HW + 256 * vn - 1) / (256 * vn)), (unsigned)NC);
 #define SSDK_BN(DT)                                                                                         \
   do {                                                                                                      \
-    if (flat) hipLaunchKernelGGL((bn_reduce_flat_kernel<DT, MODE>), rgrid, dim3(256), 0, st, p);            \
+    if (flat_r) hipLaunchKernelGGL((bn_reduce_flat_kernel<DT, MODE>), rgrid, dim3(256), 0, st, p);          \
     else hipLaunchKernelGGL((bn_reduce_kernel<DT, MODE>), rgrid, dim3(256), 0, st, p);                      \
     if (MODE == 0) hipLaunchKernelGGL((bn_fwd_finalize_kernel<DT>), dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p); \
     else hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p);  \
