@@ -339,6 +339,14 @@ size_t ssdk_dwconv_bwd_weight_workspace_bytes(int N, int C, int H, int W, int st
 int ssdk_dwconv_bwd_weight(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int C,
                            int H, int W, int stride, int dtype, void* stream);
 
+/* How the whole-row depthwise kernels cut one pass into workgroups (host only: no launch, usable without a device; the
+ * CPU tests check the plan's invariants with it).  pass 0 forward | 1 input gradient | 2 weight gradient.
+ * out[12] = images per workgroup, bands per plane, rows per band, 8-pixel segments per row, LDS row stride, staged rows
+ * per piece, 16-byte chunks per staged row, units per piece, workgroups, partial-sum groups of the weight gradient, LDS
+ * bytes, rows of the thread space.  Returns 0, or 1 when the tiled kernels take the pass (rows too wide for LDS). */
+int ssdk_dwconv_plan(int pass, int N, int C, int H, int W, int stride, int dtype, int* out);
+
+
 /* BatchNorm2d with batch statistics for the TRAINING step (replaces MIOpenBatchNorm{Fwd,Bwd}Spatial), NCHW
  * contiguous data of dtype SSDK_F32 | SSDK_BF16 | SSDK_F16, fp32 parameters / statistics, HW = H*W.
  *   fwd: y = (x - mean_c) * invstd_c * weight_c + bias_c;  save_mean / save_invstd fp32 [C] (for backward);

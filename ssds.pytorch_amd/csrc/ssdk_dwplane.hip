@@ -648,3 +648,17 @@ int launch_dwp_wgrad(const void* x, const void* dy, float* dw, void* workspace, 
 }
 
 }  // namespace ssdk
+
+// How the whole-row kernels would cut one pass (host only: no launch, no device needed).  pass 0 forward, 1 input
+// gradient, 2 weight gradient.  out[12] = G, T, TR, seg, LD, SR, CH, UP, workgroups, groups (partial sums of the weight
+// gradient), LDS bytes, rows of the thread space.  Returns 0, or 1 when the tiled kernels would take the pass.
+extern "C" int ssdk_dwconv_plan(int pass, int N, int C, int H, int W, int stride, int dtype, int* out) {
+  if (!out || pass < 0 || pass > 2 || N < 1 || C < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2)) return SSDK_E_BADARG;
+  const ssdk::DwpPlan pl = ssdk::dwp_plan(pass, N, C, H, W, stride, dtype != SSDK_F32);
+  if (!pl.ok) return 1;
+  const ssdk::DwpParams& p = pl.p;
+  const int v[12] = {p.G, p.T, p.TR, p.seg, p.LD, p.SR, p.CH, p.UP, p.nwg, pl.groups, (int)pl.lds, p.Ht};
+  for (int i = 0; i < 12; ++i) out[i] = v[i];
+  return 0;
+}
+

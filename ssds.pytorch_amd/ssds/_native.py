@@ -113,7 +113,8 @@ def _load():
     lib.ssdk_dwconv_bwd_weight_workspace_bytes.argtypes = [i32] * 5
     lib.ssdk_dwconv_bwd_weight_workspace_bytes.restype = sz
     lib.ssdk_dwconv_bwd_weight.argtypes = [vp, vp, vp, vp, sz, i32, i32, i32, i32, i32, i32, vp]
-    for _n in ("ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data", "ssdk_dwconv_bwd_weight"):
+    lib.ssdk_dwconv_plan.argtypes = [i32] * 7 + [ctypes.POINTER(i32)]
+    for _n in ("ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data", "ssdk_dwconv_bwd_weight", "ssdk_dwconv_plan"):
         getattr(lib, _n).restype = i32
     lib.ssdk_bn_workspace_bytes.argtypes = [i32, i32]
     lib.ssdk_bn_workspace_bytes.restype = sz
@@ -210,7 +211,7 @@ EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_p
            "ssdk_ctx_get_timings", "ssdk_ctx_set_op_profiling", "ssdk_ctx_get_op_timings", "ssdk_ctx_get_tail_stamps",
            "ssdk_run_ops_ctx", "ssdk_decode_nms_ctx",
            "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_mbconv_set_variant", "ssdk_xpair", "ssdk_fuse", "ssdk_preprocess", "ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data",
-           "ssdk_dwconv_bwd_weight_workspace_bytes", "ssdk_dwconv_bwd_weight", "ssdk_bn_workspace_bytes",
+           "ssdk_dwconv_bwd_weight_workspace_bytes", "ssdk_dwconv_bwd_weight", "ssdk_dwconv_plan", "ssdk_bn_workspace_bytes",
            "ssdk_bn_train_fwd", "ssdk_bn_train_bwd", "ssdk_bn_act_train_fwd", "ssdk_bn_act_train_bwd", "ssdk_conv_stem7", "ssdk_maxpool3x3s2", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 
 
