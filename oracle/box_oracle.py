@@ -13,6 +13,9 @@ the build container (``tests/golden/make_golden.py``) and
 ``tests/test_oracle_golden.py`` checks this restatement against them, plus the
 known-answer vectors of SURVEY.md section 4.
 
+``oracle/ssdk_cpu.c`` is a second, independent restatement of the same functions in C behind the C-ABI's own
+prototypes (``tests/test_oracle_c.py`` pins it with the same fixtures and cross-checks the two).
+
 Conventions shared with the HIP kernels (the "contract"):
 
 * all arithmetic is IEEE fp32 in the operation order of the reference, no FMA
