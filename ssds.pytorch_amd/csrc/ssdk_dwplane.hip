@@ -528,7 +528,8 @@ static DwpPlan dwp_plan(int kind, int N, int C, int H, int W, int stride, bool h
   if (tr > tr_lds) tr = tr_lds;
   if (tr > p.Ht) tr = p.Ht;
   if (tr < p.Ht && dgrad2) tr &= ~1;
-  if (tr < 1 || rows_lds < 3 || (long)N * C * p.Ht > 1000000000l) return pl;
+  // (32-bit offsets inside a plane, 32-bit workgroup counts)
+  if (tr < 1 || rows_lds < 3 || (long)N * C * p.Ht > 1000000000l || (long)H * W >= (1l << 31)) return pl;
   auto staged_rows = [&](int t) { return dgrad2 ? (t >> 1) + 2 : S * (t - 1) + 3; };
   if (tr >= p.Ht) {  // whole planes: as many images per workgroup as fit
     p.T = 1;
@@ -653,7 +654,9 @@ int launch_dwp_wgrad(const void* x, const void* dy, float* dw, void* workspace, 
 // gradient, 2 weight gradient.  out[12] = G, T, TR, seg, LD, SR, CH, UP, workgroups, groups (partial sums of the weight
 // gradient), LDS bytes, rows of the thread space.  Returns 0, or 1 when the tiled kernels would take the pass.
 extern "C" int ssdk_dwconv_plan(int pass, int N, int C, int H, int W, int stride, int dtype, int* out) {
-  if (!out || pass < 0 || pass > 2 || N < 1 || C < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2)) return SSDK_E_BADARG;
+  if (!out || pass < 0 || pass > 2 || N < 1 || C < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2) ||
+      (dtype != SSDK_F32 && dtype != SSDK_BF16 && dtype != SSDK_F16))
+    return SSDK_E_BADARG;
   const ssdk::DwpPlan pl = ssdk::dwp_plan(pass, N, C, H, W, stride, dtype != SSDK_F32);
   if (!pl.ok) return 1;
   const ssdk::DwpParams& p = pl.p;
