@@ -226,6 +226,18 @@ class MbPack(object):
         self.wp = cp.weight.detach().float().permute(0, 2, 3, 1).contiguous().to(torch.float16)
 
 
+    def fp16_safe(self):
+        """The block kernel keeps the expanded tensor, the depthwise weights / bias / output and the projection weights
+        in fp16 (11-bit mantissa: more precise than bf16 inside its range, but the range is 65504).  Everything the
+        kernel rounds to fp16 is bounded here from the folded weights: the expanded tensor is clamped to [0, 6], so a
+        depthwise output is at most 6 * sum|w| + |b| before its own clamp.  False -> the planner records the block as
+        three layer launches (bf16 / fp32 accumulators) instead."""
+        if not (torch.isfinite(self.wd).all() and torch.isfinite(self.bd).all() and torch.isfinite(self.wp).all()):
+            return False
+        bound = 6.0 * self.wd.float().abs().sum((0, 1)) + self.bd.float().abs()  # per channel
+        return bool(bound.max() < 3.0e4)
+
+
 def fill_mb_desc(d, x_ptr, y_ptr, n, h, w, pk, dtype_code):
     d.x, d.y = x_ptr, y_ptr
     d.w_expand, d.scale_expand, d.bias_expand = pk.e.w.data_ptr(), pk.e.scale.data_ptr(), pk.e.bias.data_ptr()

@@ -76,8 +76,10 @@ def record_mobilenet(plan, val, net, on_output=None):
     if fused_block and isinstance(first_blk, InvertedResidual) and not first_blk.use_res_connect:
         sg, bg = groups_of(net.conv1), groups_of(first_blk.conv)
         if MbPack.stem_supported(sg, bg):  # stem conv + expand-free first block: ONE launch from the image
-            cur = plan.mbconv(val, MbPack(bg, False, plan.dtype, stem_group=sg[0]))
-            stem_fused = True
+            pk = MbPack(bg, False, plan.dtype, stem_group=sg[0])
+            if pk.fp16_safe():  # (folded weights outside the fp16 range of the kernel's internals: layer by layer)
+                cur = plan.mbconv(val, pk)
+                stem_fused = True
     if not stem_fused:
         cur = record_chain(plan, val, net.conv1, keep_input=True)  # the image is not an arena buffer
     outputs = []
@@ -92,8 +94,9 @@ def record_mobilenet(plan, val, net, on_output=None):
             if isinstance(blk, InvertedResidual):
                 res = cur if blk.use_res_connect else None
                 groups = groups_of(blk.conv)
-                if fused_block and MbPack.supported(groups, blk.use_res_connect):
-                    nxt = plan.mbconv(cur, MbPack(groups, blk.use_res_connect, plan.dtype))  # whole block, 1 launch
+                pk = MbPack(groups, blk.use_res_connect, plan.dtype) if fused_block and MbPack.supported(groups, blk.use_res_connect) else None
+                if pk is not None and pk.fp16_safe():
+                    nxt = plan.mbconv(cur, pk)  # whole block, 1 launch
                     if not is_out_input:
                         plan.release(cur)
                     cur = nxt

@@ -387,3 +387,30 @@ def test_ssd_mobilenetv2_plan_recording_fuses_extras_and_keeps_head_order():
     xp = [L for L in plan.layers if L.get("kind") == "xpair"]
     assert [(L["h"], L["pack"].cin, L["pack"].cout, L["pack2"].cout) for L in xp] == [(8, 512, 128, 256), (4, 256, 128, 256),
                                                                                       (2, 256, 64, 128)]
+
+
+def test_blocks_whose_folded_weights_leave_the_fp16_range_are_not_fused():
+    """The block kernel's internal tensors are fp16 (include/ssdk.h, ssdk_mbconv): a block whose folded depthwise weights
+    could push an intermediate past 65504 -- a BatchNorm with a tiny running variance and a large gain -- is recorded as three
+    layer launches instead; the other blocks stay fused.  Recording only (CPU)."""
+    import os
+    import torch
+    from ssds.core import config
+    from ssds.modeling import model_builder
+    from ssds.modeling.layers import planner
+
+    cfg = config.cfg_from_file(os.path.join(os.path.dirname(__file__), "..", "experiments", "cfgs", "ssd_mobilenetv2_512.yml"))
+    torch.manual_seed(0)
+    model = model_builder.create_model(cfg.MODEL).eval()
+    blk = model.backbone.layer3[1]                      # an ordinary residual block
+    dw_bn = [m for m in blk.conv.modules() if isinstance(m, torch.nn.BatchNorm2d)][1]
+    dw_bn.running_var.fill_(1e-12)                      # sigma = sqrt(eps): gamma / sigma ~ 3e6,
+    dw_bn.weight.data.fill_(1e4)                        # 6 * sum|w'| is far outside fp16
+    model = model.to(torch.bfloat16)
+    x = torch.zeros(2, 3, 512, 512, dtype=torch.bfloat16)
+    plan = planner.build_ssd_plan(model, x)
+    kinds = [L.get("kind") or ("head" if L.get("nchw") else "conv") for L in plan.layers]
+    assert kinds.count("mb") == 16 and kinds.count("conv") == 2 + 3   # that block: expand, depthwise, project
+    dw_bn.running_var.fill_(float("nan"))               # a broken checkpoint: not fused either (and no exception here)
+    plan = planner.build_ssd_plan(model, x)
+    assert [L.get("kind") for L in plan.layers].count("mb") == 16
