@@ -290,13 +290,13 @@ typedef struct ssdk_mbconv_desc {
                    "expand" conv is the network stem (3x3, stride 2, pad 1, BN, ReLU6; w_expand
                    [Chid][3][8][4] = (ky, kx zero-padded to 8, ci zero-padded to 4)): stem + first depthwise-separable block
                    (mobilenet.py:78-89, expand_ratio 1) in one launch */
+  int32_t variant; /* Two kernels implement ssdk_mbconv: the LDS-tiled one (every geometry) and, for the high-resolution
+                      blocks (Cin <= 32, hidden in {96, 144, 192}, Cout <= 64, or the stem block), a register-flow one
+                      (ssdk_mbflow.hip).  0: automatic (register-flow where the map is large enough to pay), 1: register-flow
+                      wherever it exists, -1: LDS-tiled only (tests, A/B runs).  Part of the descriptor: the library keeps
+                      no process-wide switch.  ssdk_last_kernel() names the kernel that ran. */
 } ssdk_mbconv_desc;
 int ssdk_mbconv(const ssdk_mbconv_desc* desc, void* stream);
-/* Two kernels implement ssdk_mbconv: the LDS-tiled one (every geometry) and, for the high-resolution blocks (Cin <= 32,
- * hidden in {96, 144, 192}, Cout <= 64, no stem), a register-flow one that is picked automatically where the map is
- * large enough to pay (ssdk_mbflow.hip).  Process-wide override for tests and A/B runs: -1 never, 0 automatic (default),
- * 1 wherever the register-flow kernel exists.  ssdk_last_kernel() names the kernel that ran. */
-int ssdk_mbconv_set_variant(int variant);
 
 /* Weighted feature fusion of the BiFPN (bifpn.py:41-62), NHWC, one launch:
  *   y = w0 * a + w1 * R_b(b) [+ w2 * R_c(c)]      a, y: [N][H][W][C]

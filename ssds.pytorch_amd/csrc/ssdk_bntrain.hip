@@ -119,13 +119,16 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnParams p) {
       }
     } else {
       for (int i = threadIdx.x; i < p.HW; i += 256) {
-        const float d = bn_ld1<DT>(p.x, base + i) - k;
+        const float xs = bn_ld1<DT>(p.x, base + i);
+        const float d = xs - k;
         if (MODE == 0) {
           a += d;
           b += d * d;
         } else {
           float g = bn_ld1<DT>(p.dy, base + i);
-          if (masked && !bn_act_open<DT>((d + k) * fa + fb, p.act)) g = 0.f;
+          // the mask is evaluated on x itself like the vector branch, the flat kernels and the forward clamp
+          // ((x - k) + k is not always x in floating point)
+          if (masked && !bn_act_open<DT>(xs * fa + fb, p.act)) g = 0.f;
           a += g;
           b += g * d * istd;
         }

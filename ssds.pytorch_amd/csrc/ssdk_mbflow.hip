@@ -518,12 +518,10 @@ static bool flow_dispatch(const FlowParams& p, int nch, int nfo, unsigned grid, 
   return false;
 }
 
-static std::atomic<int> g_flow_variant{0};  // ssdk_mbconv_set_variant: 0 auto, 1 register-flow wherever it exists, -1 never
-
 // Returns 1 when the block is not one of this kernel's (the caller then runs ssdk_mbconv.hip's), 0 after a launch.
 int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
   static const int env = getenv("SSDK_MB_FLOW") ? atoi(getenv("SSDK_MB_FLOW")) : 1;
-  const int variant = g_flow_variant.load(std::memory_order_relaxed);
+  const int variant = d->variant;  // 0 auto, 1 register-flow wherever it exists, -1 never (ssdk_mbconv_desc)
   if ((!env && variant <= 0) || variant < 0) return 1;
   const bool stem = d->stem != 0;
   if (stem) {  // network stem + expand-free first block: 3x3/s2 conv (<= 3 channels -> 32) as the "expand" GEMM, dw stride 1, 32 -> 16
@@ -622,12 +620,3 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
 }
 
 }  // namespace ssdk
-
-extern "C" int ssdk_mbconv_set_variant(int variant) {
-  if (variant < -1 || variant > 1) {
-    ssdk::set_error("mbconv_set_variant: -1 (LDS-tiled kernel only), 0 (automatic) or 1 (register-flow kernel wherever it exists)");
-    return SSDK_E_BADARG;
-  }
-  ssdk::g_flow_variant.store(variant, std::memory_order_relaxed);
-  return SSDK_OK;
-}

@@ -24,6 +24,16 @@ from ssds import _native as N
 
 _ACT_OF = {nn.ReLU: "relu", nn.ReLU6: "relu6", nn.SiLU: "silu", nn.Sigmoid: "sigmoid"}
 
+
+def _act_name(m):
+    """Activation name of module ``m`` or None.  Looked up along the MRO: the training Solver swaps the classes of
+    activations behind a kernel-backed BatchNorm to subclasses (batchnorm.FusedAwayReLU6 / FusedAwayReLU), and a model
+    that went through it must still record its eval plan."""
+    for klass in type(m).__mro__:
+        if klass in _ACT_OF:
+            return _ACT_OF[klass]
+    return None
+
 STATS = {"native_layers": 0, "plan_runs": 0, "torch_fallback_layers": 0}
 
 
@@ -253,6 +263,8 @@ def xpair_supported(p1, p2, h, w):
     launch: small map, channel counts of its instances."""
     return (p1.kind == "dense" and p2.kind == "dense" and p1.k == 1 and p1.stride == 1 and p2.k == 3 and p2.stride == 2
             and p1.cout == p2.cin
+            # exactly what ssdk_xpair() accepts: maps of <= 16 pixels (one fragment) or exactly 64 (four full fragments)
+            and (h * w <= 16 or h * w == 64)
             and ((h * w + 15) // 16, p1.cin, p1.cout, p2.cout) in ((4, 512, 128, 256), (1, 256, 128, 256), (1, 256, 64, 128),
                                                                    (1, 128, 64, 128))
             and p1.act in ("none", "relu", "relu6") and p2.act in ("none", "relu", "relu6")
@@ -307,8 +319,9 @@ def fuse_native(a, b, c=None, weights=(1.0, 1.0, 0.0), mode_b=N.FUSE_SAME, mode_
     return y
 
 
-def mbconv_native(x, pk):
-    """One fused inverted-residual block; x channels_last [N,Cin,H,W] -> channels_last [N,Cout,Ho,Wo]."""
+def mbconv_native(x, pk, variant=0):
+    """One fused inverted-residual block; x channels_last [N,Cin,H,W] -> channels_last [N,Cout,Ho,Wo].
+    ``variant``: 0 automatic, 1 register-flow kernel wherever it exists, -1 LDS-tiled kernel only (ssdk_mbconv_desc)."""
     N.require_device(x, "mbconv")
     stem = pk.stem
     if stem and x.is_contiguous():
@@ -323,6 +336,7 @@ def mbconv_native(x, pk):
     y = torch.empty((n, pk.cout, ho, wo), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
     d = fill_mb_desc(N.MbConvDesc(), x.data_ptr(), y.data_ptr(), n, h, w, pk, N.dtype_code(x))
     d.stem = stem
+    d.variant = int(variant)
     with torch.cuda.device(x.device):
         rc = N.lib.ssdk_mbconv(ctypes.byref(d), N.stream_ptr(x.device))
     N.check(rc, "mbconv")
@@ -792,8 +806,9 @@ def sequential_groups(seq):
         bn, act, j = None, "none", i + 1
         if j < len(mods) and isinstance(mods[j], nn.BatchNorm2d):
             bn, j = mods[j], j + 1
-        if j < len(mods) and type(mods[j]) in _ACT_OF:
-            act, j = _ACT_OF[type(mods[j])], j + 1
+        a = _act_name(mods[j]) if j < len(mods) else None
+        if a is not None:
+            act, j = a, j + 1
         out.append((conv, bn, act))
         i = j
     return out

@@ -497,12 +497,8 @@ def test_fused_inverted_residual_block(cin, cout, stride, h, w, variant):
     groups = groups_of(blk.conv)
     assert FC.MbPack.supported(groups, blk.use_res_connect)
     pk = FC.MbPack(groups, blk.use_res_connect, dtype)
-    N.check(N.lib.ssdk_mbconv_set_variant(1 if variant == "flow" else -1), "set_variant")
-    try:
-        got = FC.mbconv_native(x.cuda(), pk)
-        name = N.last_kernel()
-    finally:
-        N.check(N.lib.ssdk_mbconv_set_variant(0), "set_variant")
+    got = FC.mbconv_native(x.cuda(), pk, variant=1 if variant == "flow" else -1)
+    name = N.last_kernel()
     assert ("mbflow" in name) == (variant == "flow" and cin <= 32), name
     assert got.is_contiguous(memory_format=torch.channels_last)
     _check(got, y, dtype, "mbconv %d->%d s%d (%s)" % (cin, cout, stride, name))
@@ -542,12 +538,8 @@ def test_fused_stem_block(layout, h, w, variant):
     pk = FC.MbPack(bg, False, dtype, stem_group=sg[0])
     xin = x.cuda() if layout == "nchw" else x.cuda().contiguous(memory_format=torch.channels_last)
     from ssds import _native as N
-    N.check(N.lib.ssdk_mbconv_set_variant(1 if variant == "flow" else -1), "set_variant")
-    try:
-        got = FC.mbconv_native(xin, pk)
-        name = N.last_kernel()
-    finally:
-        N.check(N.lib.ssdk_mbconv_set_variant(0), "set_variant")
+    got = FC.mbconv_native(xin, pk, variant=1 if variant == "flow" else -1)
+    name = N.last_kernel()
     assert ("mbflow" in name) == (variant == "flow"), name
     _check(got, y, dtype, "stem block %s (%s)" % (layout, name))
 
@@ -624,12 +616,8 @@ def test_register_flow_block_fp16(cin, cout, stride, h, w):
     pk = FC.MbPack(groups_of(blk.conv), blk.use_res_connect, dtype)
     outs = {}
     for variant, code in (("flow", 1), ("tiled", -1)):
-        N.check(N.lib.ssdk_mbconv_set_variant(code), "set_variant")
-        try:
-            outs[variant] = FC.mbconv_native(x.cuda(), pk)
-            name = N.last_kernel()
-        finally:
-            N.check(N.lib.ssdk_mbconv_set_variant(0), "set_variant")
+        outs[variant] = FC.mbconv_native(x.cuda(), pk, variant=code)
+        name = N.last_kernel()
         assert ("mbflow" in name) == (variant == "flow"), name
         _check(outs[variant], y, dtype, "fp16 block %d->%d s%d (%s)" % (cin, cout, stride, name))
     # the two kernels run the same arithmetic in the same order: they agree far inside the tolerance against torch

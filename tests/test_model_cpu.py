@@ -414,3 +414,49 @@ def test_blocks_whose_folded_weights_leave_the_fp16_range_are_not_fused():
     dw_bn.running_var.fill_(float("nan"))               # a broken checkpoint: not fused either (and no exception here)
     plan = planner.build_ssd_plan(model, x)
     assert [L.get("kind") for L in plan.layers].count("mb") == 16
+
+
+@pytest.mark.parametrize("px", [300, 320, 416, 448, 512])
+def test_xpair_ops_are_only_recorded_on_maps_the_c_entry_accepts(px):
+    """ssdk_xpair() takes maps of <= 16 pixels or exactly 64 (csrc/ssdk_xpair.hip); a 7x7 map (416 / 448 px inputs) rounds
+    up to four fragments as well but is NOT an instance: it has to be recorded as two conv ops.  Recording only (CPU)."""
+    import os
+    import torch
+    from ssds.core import config
+    from ssds.modeling import model_builder
+    from ssds.modeling.layers import planner
+
+    cfg = config.cfg_from_file(os.path.join(os.path.dirname(__file__), "..", "experiments", "cfgs", "ssd_mobilenetv2_512.yml"))
+    torch.manual_seed(0)
+    model = model_builder.create_model(cfg.MODEL).eval().to(torch.bfloat16)
+    plan = planner.build_ssd_plan(model, torch.zeros(1, 3, px, px, dtype=torch.bfloat16))
+    xp = [L for L in plan.layers if L.get("kind") == "xpair"]
+    for L in xp:
+        assert L["h"] * L["w"] <= 16 or L["h"] * L["w"] == 64, (px, L["h"], L["w"])
+    if px == 512:
+        assert len(xp) == 3
+    if px in (416, 448):  # 26 -> 13 -> 7 -> 4 -> 2 -> 1 / 28 -> 14 -> 7 -> ...: the 7x7 extra is two launches
+        assert all(L["h"] != 7 for L in xp)
+
+
+def test_a_model_that_went_through_the_training_solver_still_records_its_eval_plan():
+    """fuse_bn_activations swaps activation classes to FusedAway* subclasses; the eval planner has to recognise them (it
+    used to match activations by exact type and silently fell back to torch for the whole network)."""
+    import os
+    import torch
+    from ssds.core import config
+    from ssds.modeling import model_builder
+    from ssds.modeling.layers import planner
+    from ssds.modeling.layers.batchnorm import fuse_bn_activations, use_fast_batchnorm
+
+    cfg = config.cfg_from_file(os.path.join(os.path.dirname(__file__), "..", "experiments", "cfgs", "ssd_mobilenetv2_512.yml"))
+    torch.manual_seed(0)
+    model = model_builder.create_model(cfg.MODEL)
+    use_fast_batchnorm(model)
+    assert fuse_bn_activations(model) >= 35
+    model = model.eval().to(torch.bfloat16)
+    plan = planner.build_ssd_plan(model, torch.zeros(2, 3, 512, 512, dtype=torch.bfloat16))
+    kinds = [L.get("kind") or ("head" if L.get("nchw") else "conv") for L in plan.layers]
+    assert kinds.count("mb") == 17 and kinds.count("xpair") == 3 and kinds.count("head") == 6
+    acts = [L["pack"].act for L in plan.layers if L.get("kind") == "xpair"]
+    assert acts == ["relu"] * 3 or all(a in ("relu", "relu6") for a in acts)
