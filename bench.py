@@ -19,8 +19,9 @@ enqueued on its own HIP stream and runs under the NEXT step's forward pass while
 line on the main stream.  It was the default in round 1 (+3 % with the three-launch decode stage); with the fused
 tail kernel it is within noise of the in-line step (37.01 vs 37.06 k img/s on the same box), so the simpler path is
 the one that is timed.  All work of the K steps completes inside the timed region (device-wide synchronize on both
-sides).  After the timed loop the last step is re-run on one stream without the side lane and its three outputs must
-equal the timed loop's bit for bit: `verified` in the JSON line.
+sides).  After the timed loop the last step is re-run in line (bit-equal outputs required) and, on rank 0 of an N=1 run,
+the numpy oracle decodes the GPU's own head outputs of a sample of images (must reproduce the timed detections) and the
+fp32 CPU forward of the same module is compared with the GPU's heads: all three together are `verified`.
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract fields it carries
   roofline      HBM roofline of the dominant hand-written kernel of the decode stage (scan_kernel: the one pass over
@@ -67,7 +68,62 @@ def parse():
     ap.add_argument("--main-priority", type=int, default=0,
                     help="-1: run the forward + scan on a high-priority stream (the overlapped tail kernel then only takes "
                          "CUs the forward leaves idle)")
+    ap.add_argument("--stub-cpu", type=int, default=0,
+                    help="(tests/test_ddp_cpu.py) 1: exercise ONLY the launcher / rank / timing logic on CPU under gloo with a "
+                         "sleeping step -- no model, no kernels, prints a line marked data='stub'; never a measurement")
     return ap.parse_args()
+
+
+def timed_region(step, steps, warmup, barrier, world, reduce_max, before_timed=None):
+    """The driver's contract: `warmup` untimed steps, then exactly `steps` steps bracketed by barrier (+ device
+    synchronize, inside `barrier`) on both sides; the elapsed time is the MAX over ranks.  Returns (seconds, last out)."""
+    out = None
+    for _ in range(warmup):
+        step()
+    if before_timed is not None:
+        before_timed()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        elapsed = reduce_max(elapsed)
+    return elapsed, out
+
+
+def stub_main(args):
+    """--stub-cpu 1: the same launcher / env / barrier / MAX-over-ranks / rank-0-print path as the real bench, on CPU under
+    gloo; rank r sleeps (r + 1) * 2 ms per step so that the MAX reduction is observable (tests/test_ddp_cpu.py)."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def reduce_max(v):
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed, _ = timed_region(lambda: time.sleep(0.002 * (rank + 1)), args.steps, args.warmup, barrier, world, reduce_max)
+    if rank == 0:
+        print(json.dumps({"metric": "stub (launcher / rank logic only)", "value": round(world * args.batch * args.steps / elapsed, 2),
+                          "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "stub",
+                          "config": {"workload": "CPU stub of the rank logic", "batch_per_gpu": args.batch,
+                                     "global_batch": args.batch * world}}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def relaunch_under_torchrun(args):
@@ -112,6 +168,8 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args)
+    if args.stub_cpu:
+        return stub_main(args)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -179,19 +237,14 @@ def main():
 
     main_stream = torch.cuda.Stream(device=dev, priority=-1) if args.main_priority < 0 else torch.cuda.current_stream(dev)
     torch.cuda.set_stream(main_stream)
-    for _ in range(args.warmup):
-        step()
-    decoder.set_profiling(not args.graph)  # event ring: recorded inside the timed region (not capturable: eager only)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    def reduce_max(v):
+        t = torch.tensor([v], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    # event ring: recorded inside the timed region (not capturable: eager only)
+    elapsed, out = timed_region(step, args.steps, args.warmup, barrier, world, reduce_max,
+                                before_timed=lambda: decoder.set_profiling(not args.graph))
     timed_out = [o.clone() for o in out]
 
     # ---- per-kernel times recorded live in the timed region -------------------------------------------
@@ -259,6 +312,8 @@ def main():
 
     # ---- per-layer table (separate, untimed pass: one hipEvent per op of the recorded plan) ------------------
     layers, heads, body = None, None, None
+    if (plan is None or isinstance(plan, str)) and plans:
+        plan = plans[0]  # FPN / BiFPN: the recorded plan of backbone + neck + shared towers (NeckPlanMixin)
     if plan is not None and not isinstance(plan, str):
         plan.ctx.set_op_profiling(True)
         acc = None
@@ -276,7 +331,7 @@ def main():
             layers.append({"layer": row["name"], "kernel": kern.replace("_kernel", ""), "us": round(ms * 1e3, 1),
                            "TFLOPs": round(row["flops"] / (ms * 1e-3) / 1e12, 1),
                            "GBps": round(row["bytes"] / (ms * 1e-3) / 1e9, 0), "kind": row["kind"]})
-        hl = [(r, l) for r, l in zip(plan.layer_table(), layers) if r["kind"] == "head"]
+        hl = [(r, l) for r, l in zip(plan.layer_table(), layers) if r["kind"] in ("head", "tower")]
         h_flops = sum(r["flops"] for r, _ in hl)
         h_ms = sum(l["us"] for _, l in hl) * 1e-3
         bl = [(r, l) for r, l in zip(plan.layer_table(), layers) if r["kind"] in ("mbconv", "conv", "dw", "gconv", "stem", "pool", "fuse")]
@@ -290,7 +345,9 @@ def main():
         if h_ms > 0:
             heads = {"flops": h_flops, "ms": round(h_ms, 4), "achieved_TFLOPs": round(h_flops / (h_ms * 1e-3) / 1e12, 1),
                      "peak_TFLOPs": MFMA_PEAK_TFLOPS, "frac": round(h_flops / (h_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                     "note": "3x3 head convs of all levels (loc|conf as one GEMM per level / tower), dense MFMA peak"}
+                     "note": "3x3 head convs of all levels (SSD: loc|conf as one GEMM per level; FPN / BiFPN: the 4+1 convs "
+                             "of both shared towers on every level, fpn.py:10-18), summed algorithmic FLOPs / summed per-op "
+                             "time, dense MFMA peak"}
 
     conf_bytes = sum(c.numel() * c.element_size() for c in conf)  # the scan kernel reads conf exactly once
     loc_bytes = sum(l.numel() * l.element_size() for l in loc)
@@ -360,7 +417,7 @@ def main():
         "hipgraph": bool(args.graph),
         "decode_tail_stream": use_tail,
         "channels_last": bool(args.channels_last),
-        "verification": "last step recomputed on one stream (no tail stream, no side lane): scores, boxes and classes "
+        "verification": "last step recomputed in line on one stream with a fresh Decoder: scores, boxes and classes "
                         "equal the timed loop's bit for bit",
     }
     result["roofline"] = roofline
@@ -372,11 +429,16 @@ def main():
     if layers is not None and args.layers:
         result["layers"] = layers
 
-    # ---- CPU baseline (rank 0, N = 1): torch fp32 forward + numpy oracle decoder, bounded sample ----------
+    # ---- CPU leg (rank 0, N = 1), bounded sample of S images of the timed batch: -------------------------------------
+    #   (1) checker: the numpy oracle's Decoder on the GPU's OWN head outputs of those images must reproduce the timed
+    #       loop's detections (classes / order bit-exact, boxes 1e-3, scores 1e-4), and the GPU's heads must agree with
+    #       the fp32 CPU forward of the same module (a wrong backbone decorrelates `loc`: cosine ~0; 16-bit rounding noise
+    #       through the untrained network keeps it >= ~0.85) -- both go into `verified`;
+    #   (2) baseline: torch fp32 forward + oracle decode + NMS of the same images, timed.
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         from oracle import box_oracle as O  # checker / baseline only
 
-        S = args.cpu_sample
+        S = min(args.cpu_sample, B)
         config.reset_cfg()
         cfg2 = config.cfg_from_file(args.cfg)
         cpu_model = model_builder.create_model(cfg2.MODEL).eval()
@@ -392,6 +454,28 @@ def main():
             cl, cc = cpu_model(xs)
             odec([t.numpy() for t in cl], [t.numpy() for t in cc], oanch)
             cpu_s = time.perf_counter() - t0
+        g_loc = [t[:S].float().cpu() for t in loc]
+        g_conf = [t[:S].float().cpu() for t in conf]
+        ws, wb, wc = odec([t.numpy() for t in g_loc], [t.numpy() for t in g_conf], oanch)
+        ts, tb, tc = (t[:S].float().cpu().numpy() for t in timed_out)
+        oracle_ok = bool(np.array_equal(tc, wc) and np.allclose(tb, wb, atol=1e-3, rtol=0)
+                         and np.allclose(ts, ws, atol=1e-4, rtol=1e-4))
+        cos, rel = [], []
+        for gl, rl in zip(g_loc, cl):
+            den = float(gl.norm() * rl.norm())
+            cos.append(round(float((gl * rl).sum()) / den, 4) if den > 0 else 1.0)
+            rel.append(round(float((gl - rl).norm() / rl.norm().clamp_min(1e-12)), 4))
+        conf_err = max(float((gc - rc).abs().max()) for gc, rc in zip(g_conf, cc))
+        heads_ok = bool(min(cos) >= 0.7 and conf_err <= 2e-2)
+        result["verified"] = bool(verified and oracle_ok and heads_ok)
+        result["config"]["verification"] += (
+            "; numpy oracle Decoder on the GPU's own head outputs of %d images reproduces the timed detections "
+            "(classes bit-exact, boxes 1e-3, scores 1e-4): %s; GPU heads vs the fp32 CPU forward of the same module on "
+            "those images: loc cosine per level %s (relative error %s), max |conf error| %.2e: %s"
+            % (S, oracle_ok, cos, rel, conf_err, heads_ok))
+        if not (oracle_ok and heads_ok):
+            print(json.dumps(result["config"]), file=sys.stderr)
+            raise SystemExit("bench.py: the timed outputs disagree with the oracle / the fp32 CPU forward -- no number reported")
         result["cpu_baseline"] = {
             "value": round(S / cpu_s, 3),
             "unit": "images/sec",

@@ -497,15 +497,17 @@ class ConvPlan(object):
         n, c, h, w = e.shape
         return (e, n, c, h, w)
 
-    def conv(self, val, pack, act=None, residual=None, res_mode=0):
+    def conv(self, val, pack, act=None, residual=None, res_mode=0, role=None):
         """res_mode bit 0: the residual value is half resolution (nearest x2 upsample, FPN top-down);
-        bit 1: the activation follows the add (ResNet blocks)."""
+        bit 1: the activation follows the add (ResNet blocks).  ``role='tower'`` marks the 3x3 convs of the shared
+        head towers (fpn.py:10-18) for the per-layer table: they are head convolutions, not neck."""
         buf, n, c, h, w = val
         assert c == pack.cin, (c, pack.cin)
         ho, wo = _out_hw(h, w, pack.k, pack.stride)
         out = self.arena.get(n * pack.cout * ho * wo * self.es)
         self.layers.append(dict(x=buf, n=n, h=h, w=w, pack=pack, act=pack.act if act is None else act, y=out,
-                                res=residual[0] if residual is not None else None, res_mode=res_mode, nchw=False))
+                                res=residual[0] if residual is not None else None, res_mode=res_mode, nchw=False,
+                                role=role))
         self.keep.append(pack)
         return (out, n, pack.cout, ho, wo)
 
@@ -700,7 +702,8 @@ class ConvPlan(object):
             ho, wo = _out_hw(h, w, pk.k, pk.stride)
             macs = n * ho * wo * pk.cout * (pk.cin // pk.groups) * pk.k * pk.k
             byt = es * (n * (h * w * pk.cin + ho * wo * pk.cout) + pk.cout * (pk.cin // pk.groups) * pk.k * pk.k)
-            kind = "head" if L["nchw"] else ("dw" if pk.kind == "dw" else ("gconv" if pk.groups > 1 else "conv"))
+            kind = "head" if L["nchw"] else ("tower" if L.get("role") == "tower" else
+                                             ("dw" if pk.kind == "dw" else ("gconv" if pk.groups > 1 else "conv")))
             rows.append(dict(name="%s %d>%d k%d s%d @%dx%d" % (kind, pk.cin, pk.cout, pk.k, pk.stride, h, w),
                              flops=2.0 * macs, bytes=float(byt), kind=kind))
         return rows

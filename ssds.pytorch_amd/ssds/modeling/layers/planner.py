@@ -276,7 +276,7 @@ def _record_towers(plan, xx, loc_packs, conf_packs):
     for (body, final), act, tag in ((loc_packs, "none", "loc"), (conf_packs, "sigmoid", "conf")):
         cur = xx
         for pk in body:
-            nxt = plan.conv(cur, pk)
+            nxt = plan.conv(cur, pk, role="tower")
             if cur is not xx:
                 plan.release(cur)
             cur = nxt

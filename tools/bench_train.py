@@ -28,6 +28,10 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--channels-last", type=int, default=0)
 ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--size", type=int, default=0, help="square input size instead of the config's (300: planes that are not a multiple of 8)")
+ap.add_argument("--cpu", type=int, default=0,
+                help="(tests/test_ddp_cpu.py) 1: ONLY the launcher / rank / barrier / MAX-time / rank-0-print logic of this "
+                     "script on CPU under gloo, with a stub step (sleep + one real all-reduce); no model, never a measurement "
+                     "(the training step itself has no CPU path: its kernels need a HIP device)")
 args = ap.parse_args()
 if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: become N ranks on this node
     import socket
@@ -42,35 +46,54 @@ if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # no launcher: become N ra
 world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
 lr = int(os.environ.get("LOCAL_RANK", "0"))
-torch.cuda.set_device(lr)
-dev = torch.device("cuda", lr)
-if world > 1:
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=dev)
+if args.cpu:
+    dev = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+else:
+    torch.cuda.set_device(lr)
+    dev = torch.device("cuda", lr)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 cfg = config.cfg_from_file(os.path.join(ROOT, "experiments", "cfgs", "ssd_mobilenetv2_512.yml"))
 cfg.TRAIN.BATCH_SIZE = args.batch
 if args.size:
     cfg.MODEL.IMAGE_SIZE = [args.size, args.size]
 cfg.EXP_DIR = "/tmp/ssdk_bench_train"
 torch.manual_seed(1234)
-solver = Solver(cfg, lr, dev)
-if args.channels_last:
-    solver.model.to(memory_format=torch.channels_last)
-mwl = solver.wrap()
-mwl.train()
-inner = mwl.module.model if hasattr(mwl, "module") else mwl.model
-anchors = model_builder.create_anchors(cfg.MODEL, inner, cfg.MODEL.IMAGE_SIZE)
-mwl.train()
-loader = SyntheticDetectionLoader(args.batch, cfg.MODEL.IMAGE_SIZE, cfg.MODEL.NUM_CLASSES, 1, dev, seed=1234 + rank)
-images, targets = loader.batch()
-if args.channels_last:
-    images = images.contiguous(memory_format=torch.channels_last)
+if args.cpu:
+    _grad = torch.ones(1 << 16)
+
+    def train_step(*_a):  # noqa: F811 -- stub: rank r "computes" for 2 (r + 1) ms, then one real (gloo) all-reduce
+        time.sleep(0.002 * (rank + 1))
+        if world > 1:
+            dist.all_reduce(_grad)
+        return 0.0, 0.0, False
+
+    mwl = images = targets = anchors = None
+    solver = argparse.Namespace(optimizer=None)
+else:
+    solver = Solver(cfg, lr, dev)
+    if args.channels_last:
+        solver.model.to(memory_format=torch.channels_last)
+    mwl = solver.wrap()
+    mwl.train()
+    inner = mwl.module.model if hasattr(mwl, "module") else mwl.model
+    anchors = model_builder.create_anchors(cfg.MODEL, inner, cfg.MODEL.IMAGE_SIZE)
+    mwl.train()
+    loader = SyntheticDetectionLoader(args.batch, cfg.MODEL.IMAGE_SIZE, cfg.MODEL.NUM_CLASSES, 1, dev, seed=1234 + rank)
+    images, targets = loader.batch()
+    if args.channels_last:
+        images = images.contiguous(memory_format=torch.channels_last)
 
 
 def sync():
     if world > 1:
-        dist.barrier(device_ids=[lr])
-    torch.cuda.synchronize()
+        dist.barrier(device_ids=None if args.cpu else [lr])
+    if not args.cpu:
+        torch.cuda.synchronize()
 
 
 for _ in range(args.warmup):
@@ -88,6 +111,7 @@ if world > 1:
 if rank == 0:
     print(json.dumps({"metric": "images/sec (DDP training step) SSD-MobileNetV2@%d" % cfg.MODEL.IMAGE_SIZE[0], "value": round(world * args.batch * args.steps / el, 1),
                       "n_gpus": world, "ms_per_step": round(el / args.steps * 1e3, 2), "batch_per_gpu": args.batch,
-                      "cls_loss": float(c), "loc_loss": float(l), "dtype": "bf16 autocast", "data": "synthetic"}))
+                      "cls_loss": float(c), "loc_loss": float(l), "dtype": "bf16 autocast",
+                      "data": "synthetic" if not args.cpu else "stub (CPU / gloo run of the rank logic)"}))
 if world > 1:
     dist.destroy_process_group()
