@@ -456,22 +456,50 @@ def main():
             cpu_s = time.perf_counter() - t0
         g_loc = [t[:S].float().cpu() for t in loc]
         g_conf = [t[:S].float().cpu() for t in conf]
-        ws, wb, wc = odec([t.numpy() for t in g_loc], [t.numpy() for t in g_conf], oanch)
-        ts, tb, tc = (t[:S].float().cpu().numpy() for t in timed_out)
-        oracle_ok = bool(np.array_equal(tc, wc) and np.allclose(tb, wb, atol=1e-3, rtol=0)
-                         and np.allclose(ts, ws, atol=1e-4, rtol=1e-4))
-        cos, rel = [], []
+        # Two stages, because the bench's own input ties EVERY raw score (reference init): the NMS order is then decided by
+        # centre-rescored scores that differ in the last ulp, i.e. by the <= 1-ulp difference between the device's and
+        # numpy's expf -- comparing final detections with an oracle that starts from the heads would compare two
+        # arbitrary orders.  (a) per-level decode (order = raw score desc, flat index asc: exact under ties) of the GPU's
+        # own heads: oracle vs device, classes bit-exact, boxes 1e-3, scores 1e-4; (b) the oracle's NMS on the DEVICE's
+        # per-level output (same bits in -> same order) must give the device's final detections bit for bit; and the
+        # sample decoded on its own must equal the timed batch's rows bit for bit (images are independent).
+        from ssds.modeling.layers.box import decode_nms
+
+        with torch.no_grad():
+            (fs, fb, fc), (ms_, mb_, mc_) = decode_nms(
+                [t[:S].contiguous() for t in loc], [t[:S].contiguous() for t in conf], anchors, decoder.conf_threshold,
+                decoder.top_n_per_level, decoder.rescore, decoder.nms_threshold, decoder.top_n, decoder.use_diou,
+                return_mid=True)
+        torch.cuda.synchronize(dev)
+        same_rows = all(torch.equal(a, b[:S]) for a, b in zip((fs, fb, fc), timed_out))
+        wm = odec.decode_levels([t.numpy() for t in g_loc], [t.numpy() for t in g_conf], oanch)
+        mid_ok = bool(np.array_equal(mc_.cpu().numpy(), wm[2]) and np.allclose(mb_.cpu().numpy(), wm[1], atol=1e-3, rtol=0)
+                      and np.allclose(ms_.cpu().numpy(), wm[0], atol=1e-4, rtol=1e-4, equal_nan=True))
+        wn = O.nms(ms_.cpu().numpy(), mb_.cpu().numpy(), mc_.cpu().numpy(), decoder.nms_threshold, decoder.top_n,
+                   decoder.use_diou)
+        nms_ok = all(np.array_equal(a.cpu().numpy(), b) for a, b in zip((fs, fb, fc), wn))
+        oracle_ok = bool(same_rows and mid_ok and nms_ok)
+        if not oracle_ok:
+            print("oracle check failed: sample rows equal the timed batch's %s, per-level decode vs oracle %s, oracle NMS on "
+                  "the device's per-level output %s" % (same_rows, mid_ok, nms_ok), file=sys.stderr)
+        # loc deltas are compared per level as rms(gpu - cpu) against rms(cpu) with an absolute floor of 1e-3 (a delta of
+        # 1e-3 moves a box edge by 1e-3 anchor sizes): with the reference's untrained init the activations behind the
+        # first level decay below the fp16 range of the fused blocks' internal tensors (exact zeros against ~1e-9 on the
+        # CPU), which is no error
+        rel, ok_l = [], []
         for gl, rl in zip(g_loc, cl):
-            den = float(gl.norm() * rl.norm())
-            cos.append(round(float((gl * rl).sum()) / den, 4) if den > 0 else 1.0)
-            rel.append(round(float((gl - rl).norm() / rl.norm().clamp_min(1e-12)), 4))
+            err, ref = float((gl - rl).pow(2).mean().sqrt()), float(rl.pow(2).mean().sqrt())
+            rel.append(float("%.3g" % (err / max(ref, 1e-30))))
+            ok_l.append(err <= 0.35 * ref + 1e-3)
+        cos = ["%.1e" % float(rl.pow(2).mean().sqrt()) for rl in cl]  # rms of the CPU reference per level, for the record
         conf_err = max(float((gc - rc).abs().max()) for gc, rc in zip(g_conf, cc))
-        heads_ok = bool(min(cos) >= 0.7 and conf_err <= 2e-2)
+        heads_ok = bool(all(ok_l) and conf_err <= 2e-2)
         result["verified"] = bool(verified and oracle_ok and heads_ok)
         result["config"]["verification"] += (
-            "; numpy oracle Decoder on the GPU's own head outputs of %d images reproduces the timed detections "
-            "(classes bit-exact, boxes 1e-3, scores 1e-4): %s; GPU heads vs the fp32 CPU forward of the same module on "
-            "those images: loc cosine per level %s (relative error %s), max |conf error| %.2e: %s"
+            "; numpy oracle on the GPU's own head outputs of %d images: per-level decode (classes bit-exact, boxes 1e-3, "
+            "scores 1e-4), oracle NMS on the device's per-level output = the timed detections bit for bit: %s; GPU heads "
+            "vs the fp32 CPU forward of the same module on "
+            "those images: loc rms per level %s, relative rms error %s (bar: 0.35 rms + 1e-3), max |conf error| %.2e: %s"
             % (S, oracle_ok, cos, rel, conf_err, heads_ok))
         if not (oracle_ok and heads_ok):
             print(json.dumps(result["config"]), file=sys.stderr)

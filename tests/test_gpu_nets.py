@@ -33,7 +33,7 @@ CAP = {"bfloat16": 0.9, "float16": 0.3}  # absolute cap on the median error (a w
 SLACK = {"bfloat16": (0.06, 0.2), "float16": (0.015, 0.05)}
 
 
-def _check_against_floor(plan_out, torch_out, want, what, dtype):
+def _check_against_floor(plan_out, torch_out, want, what, dtype, tail_factor=2.0):
     """Untrained deep networks amplify rounding noise (torch's own bf16 execution of MobileNetV2 is 0.1-0.6 RMS away
     from fp32 at the deeper levels), so the bar is relative to the noise floor of the SAME module executed by
     PyTorch-ROCm in the SAME dtype: the plan must be as close to the reference's fp32 outputs as that, up to a factor
@@ -46,7 +46,7 @@ def _check_against_floor(plan_out, torch_out, want, what, dtype):
             sp, st = _stats(p, w), _stats(t, w)
             report.append("%s%d plan %.4f/%.4f/%.4f floor %.4f/%.4f/%.4f" % ((tag, i) + sp + st))
             m_abs, p_abs = SLACK[dtype]
-            if not (sp[0] <= 2.0 * st[0] + m_abs and sp[1] <= 2.0 * st[1] + p_abs and sp[0] <= CAP[dtype]):
+            if not (sp[0] <= 2.0 * st[0] + m_abs and sp[1] <= tail_factor * st[1] + p_abs and sp[0] <= CAP[dtype]):
                 bad.append(report[-1])
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
