@@ -154,9 +154,12 @@ extern "C" int ssdk_ctx_get_timings(ssdk_ctx* ctx, int back, float* ms, int n) {
               kSsdkProfSlots);
     return SSDK_E_BADARG;
   }
-  hipEvent_t* ev = ctx->prof_ev[(ctx->prof_calls - 1 - back) % kSsdkProfSlots];
-  if (hipEventSynchronize(ev[3]) != hipSuccess) return SSDK_E_LAUNCH;
-  for (int i = 0; i < 3; ++i)
+  const long long slot = (ctx->prof_calls - 1 - back) % kSsdkProfSlots;
+  hipEvent_t* ev = ctx->prof_ev[slot];
+  const int n_iv = ctx->prof_fused[slot] ? 2 : 3;  // the fused path has two launches: scan, tail
+  if (hipEventSynchronize(ev[n_iv]) != hipSuccess) return SSDK_E_LAUNCH;
+  ms[2] = 0.0f;
+  for (int i = 0; i < n_iv; ++i)
     if (hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) != hipSuccess) return SSDK_E_LAUNCH;
   return SSDK_OK;
 }
@@ -220,9 +223,13 @@ extern "C" int ssdk_decode_nms_ctx(ssdk_ctx* ctx, const ssdk_level* levels, int 
     const char* e = getenv("SSDK_TAIL_STAMPS");
     return e && atoi(e) != 0;
   }();
-  if (want_stamps && !ctx->stamps && hipMalloc((void**)&ctx->stamps, 48 * sizeof(unsigned long long)) != hipSuccess) {
-    (void)hipGetLastError();
-    ctx->stamps = nullptr;
+  if (want_stamps && !ctx->stamps) {
+    if (hipMalloc((void**)&ctx->stamps, 48 * sizeof(unsigned long long)) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->stamps = nullptr;
+    } else {
+      (void)hipMemset(ctx->stamps, 0, 48 * sizeof(unsigned long long));
+    }
   }
   if (prof && (rc = record(ev[0], main_s))) return rc;
   rc = launch_scan(levels, L, B, dtype, threshold, K, pl, workspace, dec, main_s, ctx->stamps ? ctx->stamps + 24 : nullptr);
@@ -236,11 +243,14 @@ extern "C" int ssdk_decode_nms_ctx(ssdk_ctx* ctx, const ssdk_level* levels, int 
     st2 = ctx->tail_stream;
   }
   if (pl.fused) {
+    u32 hbase, hsh;
+    hist_window(threshold, &hbase, &hsh);
     rc = launch_tail(levels, L, B, dtype, K, rescore, pl.units, pl.unit_base, pl.units_per_image, workspace,
-                     (const char*)workspace + pl.cand_bytes, nms_threshold, ndetections, using_diou, out_scores,
+                     (const char*)workspace + pl.cand_bytes, hbase, hsh, nms_threshold, ndetections, using_diou, out_scores,
                      out_boxes, out_classes, mid_scores, mid_boxes, mid_classes, ctx->stamps, st2);
     if (rc) return rc;
-    if (prof && ((rc = record(ev[2], st2)) || (rc = record(ev[3], st2)))) return rc;
+    if (prof && (rc = record(ev[2], st2))) return rc;
+    ctx->prof_fused[ctx->prof_calls % kSsdkProfSlots] = true;  // no third launch: ms[2] reads 0, not an empty interval
   } else {
     char* w = (char*)workspace + align256(dec);
     float* ms = mid_scores ? mid_scores : (float*)w;
@@ -255,6 +265,7 @@ extern "C" int ssdk_decode_nms_ctx(ssdk_ctx* ctx, const ssdk_level* levels, int 
                     st2);
     if (rc) return rc;
     if (prof && (rc = record(ev[3], st2))) return rc;
+    if (prof) ctx->prof_fused[ctx->prof_calls % kSsdkProfSlots] = false;
   }
   if (prof) ++ctx->prof_calls;
   return SSDK_OK;

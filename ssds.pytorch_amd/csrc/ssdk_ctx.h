@@ -20,6 +20,7 @@ struct ssdk_ctx {
   int prof_on;
   bool prof_ready;
   hipEvent_t prof_ev[kSsdkProfSlots][4];
+  bool prof_fused[kSsdkProfSlots];  // the slot's call ran scan + fused tail (two launches, three events)
   long long prof_calls;
   unsigned long long* stamps;   // device, 8 words (SSDK_TAIL_STAMPS=1 only)
   // ---- plan executor (ssdk_run_ops_ctx) ----

@@ -14,35 +14,11 @@
 //                       writes the zero-padded [B, top_n] outputs (box.py:430-432, 473-475).
 //
 // Algorithmic HBM bytes: the conf tensor once + 4 deltas per winner + outputs.
-#include "ssdk_common.h"
-#include "ssdk_select.h"
-#include "ssdk_decode.h"
+#include "ssdk_scan.h"
 
 namespace ssdk {
 
-constexpr int kScanThreads = 256;
-constexpr u32 kCap = 4096;         // LDS candidate slots per workgroup
-static_assert(kCap == kStreamCap, "stream buffers are kStreamCap keys");
 
-struct ScanLevel {
-  const void* cls;
-  u32 n;          // A*C*H*W scores per image
-  u32 units;      // units per image for this level
-  u32 unit_base;  // first unit id of this level inside an image
-  u32 tpu;        // tiles per unit of this level
-};
-struct ScanParams {
-  ScanLevel lv[SSDK_MAX_LEVELS];
-  int L;
-  u32 units_per_image, B;
-  u32 K;
-  float thr;
-  u32 hist_base, hist_sh;  // histogram window of the seeding phase: bin = (ord(score) - hist_base) >> hist_sh
-  int fast;                // 1: seeded barrier-free streaming first (SSDK_SCAN_FAST, default), 0: TopK stream only
-  u64* cand;      // [B][units_per_image][K]
-  u32* cand_cnt;  // [B][units_per_image]
-  unsigned long long* stamps;  // optional (debug): shader-clock stamps of workgroup 0 at the phase boundaries
-};
 
 struct LevelDesc {
   const void* box;
@@ -74,101 +50,7 @@ __host__ __device__ inline size_t lds_bytes_for(u32 K) {
          sizeof(LevelLds);
 }
 
-// One 16-byte vector per lane: every element that beats the running cut (score, index) becomes a 64-bit key.
-// The wave appends all of them with ONE LDS atomic: per-lane counts -> wave exclusive scan (shuffles) ->
-// the last lane reserves the wave's range -> every lane writes its keys at base + prefix + local rank.
-// (The first version did ballot + atomic per element slot: 8 dependent LDS-atomic round trips per tile.)
-template <int DT, int E>
-__device__ __forceinline__ void scan_flags(const u32x4& v, u32 idx0, u32 n, float cut, u32 cut_idx, u32& pmask,
-                                           float (&sv)[DType<DT>::vec]) {
-  if constexpr (E < DType<DT>::vec) {
-    const float s = vec_elem<DT, E>(v);
-    const u32 idx = idx0 + E;  // wraps to a huge value for the (masked) head elements
-    const bool pass = (idx < n) & ((s > cut) | ((s == cut) & (idx < cut_idx)));
-    pmask |= pass ? (1u << E) : 0u;
-    sv[E] = s;
-    scan_flags<DT, E + 1>(v, idx0, n, cut, cut_idx, pmask, sv);
-  }
-}
 
-template <int DT>
-__device__ __forceinline__ void scan_vec(const u32x4& v, u32 idx0, u32 n, float cut, u32 cut_idx, u64* buf,
-                                         StreamCtl* ctl, u32 limit, u32 tile) {
-  constexpr int VEC = DType<DT>::vec;
-  u32 pmask = 0;
-  float sv[VEC];
-  scan_flags<DT, 0>(v, idx0, n, cut, cut_idx, pmask, sv);
-  if (__ballot(pmask != 0u) == 0ull) return;  // nothing in this wave beats the cut (the common case later on)
-  // exclusive prefix of the per-lane counts (0..8) without a shuffle chain: one ballot per count bit, the lanes
-  // below me that have the bit set (mbcnt) weigh 2^bit.  (The first version ran a 6-step __shfl_up scan = six
-  // dependent ds_bpermute round trips per 16-byte vector.)
-  const u32 cnt = (u32)__popc(pmask);
-  u32 excl = 0, total = 0;
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const u64 mb = __ballot((cnt >> b) & 1u);
-    excl += mbcnt(mb) << b;
-    total += (u32)__popcll(mb) << b;
-  }
-  u32 base = 0;
-  if (lane_id() == 0) {
-    base = atomicAdd(&ctl->cnt, total);
-    if (base <= limit && base + total > limit) ctl->flag[tile & 1u] = tile + 1u;  // the unique crosser
-  }
-  base = (u32)__builtin_amdgcn_readfirstlane((int)base) + excl;
-#pragma unroll
-  for (int e = 0; e < VEC; ++e)
-    if ((pmask >> e) & 1u) buf[base + (u32)__popc(pmask & ((1u << e) - 1u))] = make_key(sv[e], idx0 + (u32)e);
-}
-
-// ---- seeded, barrier-free streaming (the normal case) --------------------------------------------------------------
-// The per-tile barrier + prune protocol below (TopK stream) is exact for any input but spends most of a unit's time in
-// radix selects while the running cut is still low: with half of all scores above the threshold (SURVEY 8d's
-// untrained-head distribution) a unit prunes 4-5 times.  So a unit first looks at a SAMPLE of its own tiles (8 tiles
-// spread over the unit) through a 1024-bin LDS histogram of the score's leading bits, window [thr, 1.0]: the lower edge
-// of the bin in which the sample's count from the top reaches K is a valid lower bound of the unit's K-th largest
-// score (the sample alone already holds K scores at or above it).  With that cut each WAVE then streams its share of
-// the unit on its own -- no barrier, no LDS atomic: a wave-uniform counter and a private 1024-key buffer -- and keeps
-// every score >= cut: K * tiles / 8 keys per unit in expectation, which fit.  One exact select + sort at the end.
-// Whenever that does not work out (a wave's buffer overflows: heavy ties at the cut such as an all-equal image, an
-// unrepresentative sample) the unit falls back to the TopK stream, seeded with the same cut.  Both paths are exact.
-struct FastCtl {  // LDS
-  u32 wcount[kScanThreads / 64];
-  u32 overflow, cutbin, cum, total;
-  u32 cutord, nge, pad0, pad1;
-};
-
-// LDS image of scan_kernel: [buf: kCap keys][SelScratch][StreamCtl][FastCtl][ring: waves x PF x 1 KiB].  The K-key
-// staging area `sel` of the selects is only used once the ring has drained and lives on top of it.  53.5 KB with
-// PF = 4: three workgroups (12 waves) per CU.
-__host__ __device__ inline size_t scan_fixed_bytes() {
-  return ((size_t)kCap * 8 + sizeof(SelScratch) + sizeof(StreamCtl) + sizeof(FastCtl) + 15) & ~(size_t)15;
-}
-__host__ __device__ inline size_t scan_lds_bytes(u32 K, int pf) {
-  const size_t ring = (size_t)(kScanThreads / 64) * pf * 1024, sel = (size_t)((K + 1) & ~1u) * 8;
-  return scan_fixed_bytes() + (ring > sel ? ring : sel);
-}
-
-constexpr u32 kWaveCap = kCap / (kScanThreads / 64);  // keys per wave buffer (1024)
-constexpr u32 kSample = 8;                             // sample tiles of the histogram phase
-constexpr u32 kHistBins = 1024;
-
-// one LDS add per (wave, distinct bin of the leading lane): heavy ties (an all-equal image puts every score of the
-// wave into ONE bin) would otherwise serialise 64 same-address atomics per instruction
-__device__ __forceinline__ void hist_add(u32* hist, bool pass, u32 bin) {
-  const u64 m = __ballot(pass);
-  if (m == 0ull) return;
-  const u32 lead = (u32)__ffsll((long long)m) - 1u;
-  const u32 b0 = (u32)__builtin_amdgcn_readlane((int)bin, (int)lead);
-  const u64 same = __ballot(pass && bin == b0);
-  if (lane_id() == lead) atomicAdd(&hist[b0], (u32)__popcll(same));
-  if (pass && bin != b0) atomicAdd(&hist[bin], 1u);
-}
-
-__device__ __forceinline__ u32 hist_bin(u32 ord_score, u32 hbase, u32 hsh) {
-  const u32 bin = (ord_score - hbase) >> hsh;
-  return bin < kHistBins - 1 ? bin : kHistBins - 1;
-}
 
 template <int DT, int E>
 __device__ __forceinline__ void hist_elems(const u32x4& v, u32 idx0, u32 n, float thr, u32 hbase, u32 hsh, u32* hist) {
@@ -223,27 +105,6 @@ __device__ __forceinline__ void fast_flags(const u32x4& v, u32 idx0, u32 n, floa
   }
 }
 
-// Prefetch ring through LDS.  Written as ordinary loads into registers, the ring of PF tiles ends every round with
-// register copies that wait for ALL outstanding loads (vmcnt(0) at the loop's back edge): the pipeline drains every PF
-// tiles and the stream runs at the latency of single requests.  Here every wave owns PF slots of 1 KiB in LDS; a tile
-// is fetched straight into its slot (global_load_lds_dwordx4: 16 bytes per lane at slot + lane * 16) and taken out by
-// the same lane with a ds_read_b128 behind a hand-counted s_waitcnt vmcnt(PF-1) -- PF requests per lane stay in flight
-// from the first tile to the last.  (Both halves of the hand-off are one asm block, so the compiler can neither move
-// the read above the wait nor add waits of its own.)
-typedef __attribute__((address_space(3))) unsigned char lds_u8;
-typedef __attribute__((address_space(1))) const unsigned char glb_u8;
-
-__device__ __forceinline__ void ring_issue(const void* g, unsigned char* slot) {
-  __builtin_amdgcn_global_load_lds((glb_u8*)g, (lds_u8*)slot, 16, 0, 0);
-}
-template <int N>
-__device__ __forceinline__ u32x4 ring_take(const unsigned char* slot_lane) {
-  u32x4 v;
-  const u32 a = (u32)(size_t)(const lds_u8*)slot_lane;
-  asm volatile("s_waitcnt vmcnt(%2)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a), "n"(N) : "memory");
-  return v;
-}
-__device__ __forceinline__ void ring_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int DT, int PF>
 __global__ __launch_bounds__(kScanThreads) void scan_kernel(const ScanParams p) {
@@ -815,9 +676,10 @@ static void plan_units(DecodePlan* pl, int L, int B, int K, u32 vec, u32 tile, u
   pl->cnt_bytes = (((size_t)B * base * sizeof(u32)) + 255) & ~(size_t)255;
 }
 
-// ndet > 0: the caller is ssdk_decode_nms and would like the fused tail kernel (ssdk_tail.hip), whose LDS stages all
-// unit lists of an image: units are made fatter until they fit, as long as that leaves the scan >= 256 workgroups;
-// pl->fused says whether the geometry qualifies.
+// ndet > 0: the caller is ssdk_decode_nms and would like the fused tail kernel (ssdk_tail.hip); pl->fused says whether
+// the geometry qualifies (it reads the unit lists from the workspace, so any number of units does).  Units are cut for
+// the 16-bit scan (ssdk_scan16.hip) whenever dtype and K allow it -- the threshold is not known when the workspace is
+// sized, and scan_kernel takes any unit size.
 int make_plan(const ssdk_level* lv, int L, int B, int dtype, int K, DecodePlan* pl, int ndet) {
   pl->fused = false;
   if (!lv || L < 1 || L > SSDK_MAX_LEVELS || B < 1) {
@@ -853,35 +715,31 @@ int make_plan(const ssdk_level* lv, int L, int B, int dtype, int K, DecodePlan* 
   // prunes / final select / sort and the K keys written per unit (and merged again behind the scan) amortise.
   int tpu = env_int("SSDK_TILES_PER_UNIT", 0);
   const bool forced = tpu > 0;
+  const bool plan16 = scan16_applies(dtype, 1.0f, K);
   if (!forced) {
     const unsigned long long target_wgs = (unsigned long long)env_int("SSDK_TARGET_WGS", 640);
     unsigned long long t = (tiles_total * (unsigned long long)B + target_wgs - 1) / target_wgs;
     tpu = (int)(t < 4 ? 4 : (t > 4096 ? 4096 : t));
+    // scan16_kernel buffers ~K * tiles / 8 candidate vectors per unit: longer units would overflow into the fallback
+    if (plan16 && tpu > (int)scan16_max_tiles_per_unit(K)) tpu = (int)scan16_max_tiles_per_unit(K);
+  } else if (plan16 && tpu > 255) {
+    tpu = 255;  // (a vector's number inside its unit is stored in 16 bits)
   }
   plan_units(pl, L, B, K, vec, tile, (u32)tpu, forced);
-  if (ndet > 0 && env_int("SSDK_DECODE_FUSED", 1) != 0) {
-    if (tail_fits(pl->units_per_image, K, L, ndet)) {
-      pl->fused = true;
-    } else if (!forced && tail_fits((u32)L, K, L, ndet)) {
-      DecodePlan best = *pl;
-      bool found = false;
-      for (unsigned long long t = (unsigned long long)tpu * 5 / 4 + 1; t <= (1ull << 22); t = t * 5 / 4 + 1) {
-        DecodePlan tryp = *pl;
-        plan_units(&tryp, L, B, K, vec, tile, (u32)t, false);
-        if ((unsigned long long)tryp.units_per_image * B < 256ull) break;  // starving the scan is worse than 3 launches
-        if (tail_fits(tryp.units_per_image, K, L, ndet)) {
-          best = tryp;
-          found = true;
-          break;
-        }
-      }
-      if (found) {
-        *pl = best;
-        pl->fused = true;
-      }
-    }
-  }
+  if (ndet > 0 && env_int("SSDK_DECODE_FUSED", 1) != 0) pl->fused = tail_fits(K, L, ndet) != 0;
   return SSDK_OK;
+}
+
+// histogram window shared by the scans' seeding / select phases and the tail's per-level select: [thr, max(1, 2 thr)] in
+// 1023 bins of 2^sh ordered-float ulps + one overflow bin (bf16 heads, thr = 0.01: sh = 16, one bin per bf16 value)
+void hist_window(float thr, u32* base, u32* shift) {
+  const u32 lo = ord_f32(thr);
+  const float top = thr < 0.5f ? 1.0f : (thr > 0.f ? 2.0f * thr : 1.0f);
+  const u32 hi = ord_f32(top) > lo ? ord_f32(top) : lo + 1u;
+  u32 sh = 0;
+  while (((hi - lo) >> sh) >= kHistBins - 1) ++sh;
+  *shift = sh;
+  *base = (lo >> sh) << sh;
 }
 
 static int check_levels(const ssdk_level* lv, int L) {
@@ -917,20 +775,21 @@ int launch_scan(const ssdk_level* lv, int L, int B, int dtype, float thr, int K,
   sp.K = (u32)K;
   sp.thr = thr;
   sp.fast = env_int("SSDK_SCAN_FAST", 1) != 0 && thr == thr;
-  {  // histogram window of the seeding phase: [thr, max(1, 2 thr)] in 1023 bins of 2^sh ordered-float ulps + overflow
-    const u32 lo = ord_f32(thr);
-    const float top = thr < 0.5f ? 1.0f : (thr > 0.f ? 2.0f * thr : 1.0f);
-    const u32 hi = ord_f32(top) > lo ? ord_f32(top) : lo + 1u;
-    u32 sh = 0;
-    while (((hi - lo) >> sh) >= kHistBins - 1) ++sh;
-    sp.hist_sh = sh;
-    sp.hist_base = (lo >> sh) << sh;
-  }
+  hist_window(thr, &sp.hist_base, &sp.hist_sh);
   sp.cand = (u64*)ws;
   sp.cand_cnt = (u32*)((char*)ws + pl.cand_bytes);
   sp.stamps = stamps;
   const dim3 grid((unsigned)(B * pl.units_per_image));
   lds_poison(stream);
+  if (scan16_applies(dtype, thr, K)) {  // 16-bit heads, positive threshold: packed compares, vector buffers (ssdk_scan16.hip)
+    bool fits = true;
+    for (int l = 0; l < L; ++l) fits = fits && pl.tpu[l] <= 255u;
+    if (fits) {
+      sp.thr16 = scan16_threshold_pattern(dtype, thr);
+      sp.inf16 = dtype == SSDK_BF16 ? 0x7f80u : 0x7c00u;
+      return launch_scan16(sp, dtype, B, pl.units_per_image, stream);
+    }
+  }
   const int pf = env_int("SSDK_SCAN_PF", 4) == 8 ? 8 : 4;  // 16-byte requests in flight per lane
   const size_t lds = scan_lds_bytes((u32)K, pf);
   auto go = [&](auto kern) {

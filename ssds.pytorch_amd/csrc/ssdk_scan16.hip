@@ -1,0 +1,578 @@
+// ssdk_scan16.hip -- threshold + exact top-K of one unit of one (image, level) for 16-bit heads (bf16 / f16) and a
+// positive threshold: what every BASELINE configuration runs.  Replaces box.py:435-446 like scan_kernel (ssdk_decode.hip);
+// same unit geometry, same workspace contract (<= K keys per unit -- here UNORDERED -- plus their count), same exact
+// fallback.  What is different, and why (round-2 counters: 58 VALU instructions per 16-byte vector, 47 % of wave cycles
+// parked, sample tiles fetched twice):
+//
+//   * scores are compared as packed 16-bit INTEGERS.  For positive finite bf16 / f16 values the bit pattern orders like
+//     the value, negative values are negative integers (below every positive cut) and positive NaNs are the patterns above
+//     +inf, so "does this 16-byte vector hold a score >= cut" is three v_pk_max_i16 over its four dwords, one more against
+//     (cut-1, cut-1) and one compare: 5 VALU instructions per vector.
+//   * the stream buffers candidate VECTORS, not keys: one ballot, one ds_write_b128 + one ds_write_b16 (the vector's number
+//     inside the unit) for the lanes that have anything.  Keys (score bits | ~flat index) are built once, behind the
+//     stream, from the few hundred buffered vectors -- with the exact tests of the reference there (index inside the image,
+//     fp32 compare semantics: NaN never passes, box.py:440).
+//   * the cut comes from a sample of the unit's OWN tiles which are then NOT streamed again: the eight sample vectors of
+//     a lane stay in registers, give the cut (top-2 per 16-bit half-lane by packed min / max, a 1024-bin histogram of those
+//     1024 values, the bin in which their count from the top reaches K) and are filtered from the registers.  Every byte of
+//     the conf tensor is fetched once.
+//   * the unit's winners leave unordered: the consumer (tail2_kernel) selects per LEVEL with a histogram anyway and no
+//     longer merges sorted runs, so the per-unit sort (9 k cycles of 83 k) is gone and the per-unit select is one
+//     histogram pass over the extracted keys.
+//
+// Ties at the cut (the reference-init network: every score of a level is the same bf16 value) keep the round-2 rule: of
+// the scores EQUAL to the cut only the first K in index order can be winners; they are collected by a short prefix walk
+// and the stream then looks for cut + 1.  A unit whose sample misleads (buffers overflow) or holds a NaN among its
+// largest patterns runs the exact TopK stream instead (unit_topk_stream, ssdk_scan.h).
+#include "ssdk_scan.h"
+
+namespace ssdk {
+
+constexpr u32 kVc = 448;  // candidate vectors per wave buffer: 4 x 448 x (16 + 2) B = 32 256 B, the fallback's 32 KiB key buffer
+
+struct S16Ctl {  // LDS
+  u32 wcount[kScanThreads / 64];
+  u32 cutbin, above, cb, pad0;
+  u32 cut16, eq, nan, ovf;
+  u32 kcnt, ocnt, scnt, pad1;
+  u32 sub[32];
+};
+
+// LDS image: [X: kCap keys = 32 KiB | vbuf + ibuf][SelScratch][StreamCtl][S16Ctl][ring: waves x PF x 1 KiB | kbuf | sel]
+__host__ __device__ inline size_t scan16_fixed_bytes() {
+  return ((size_t)kCap * 8 + sizeof(SelScratch) + sizeof(StreamCtl) + sizeof(S16Ctl) + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t scan16_lds_bytes(int pf) {
+  return scan16_fixed_bytes() + (size_t)(kScanThreads / 64) * pf * 1024;  // (>= K keys of `sel`: K <= 512)
+}
+static_assert((size_t)(kScanThreads / 64) * kVc * 18 <= (size_t)kCap * 8, "vector buffers must fit the key buffer");
+
+__device__ __forceinline__ u32 pk_max_i16(u32 a, u32 b) {
+  u32 r;
+  asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ u32 pk_min_i16(u32 a, u32 b) {
+  u32 r;
+  asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// LDS-only barrier: __syncthreads() would also drain the global loads the ring keeps in flight
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int DT>
+__device__ __forceinline__ float f32_of16(u32 h) {
+  if constexpr (DT == SSDK_BF16) return bf16_bits_to_f32(h);
+  else return f16_bits_to_f32(h);
+}
+template <int DT>
+__device__ __forceinline__ u32 ord_of16(u32 h) {  // ord_f32 of a NON-NEGATIVE 16-bit score
+  if constexpr (DT == SSDK_BF16) return (h << 16) | 0x80000000u;
+  else return __builtin_bit_cast(u32, f16_bits_to_f32(h)) | 0x80000000u;
+}
+// smallest non-negative 16-bit pattern whose value is >= the positive float with ordered bits `o`
+template <int DT>
+__device__ __forceinline__ u32 ceil16_of_ord(u32 o) {
+  const u32 bits = o & 0x7fffffffu;
+  if constexpr (DT == SSDK_BF16) {
+    return (bits >> 16) + ((bits & 0xffffu) ? 1u : 0u);
+  } else {
+    const float f = __builtin_bit_cast(float, bits);
+    _Float16 h = (_Float16)f;  // round to nearest even
+    u32 hb = (u32)__builtin_bit_cast(u16, h);
+    if ((float)h < f) hb += 1u;  // (positive: the next pattern is the next value up; max finite + 1 = inf)
+    return hb;
+  }
+}
+
+__device__ __forceinline__ u32 half_of(const u32x4& v, int e) {  // compile-time e
+  const u32 w = v[e >> 1];
+  return (e & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+// zero the halves of a vector whose elements lie outside the image (head of the first vector, tail of the last one)
+__device__ __forceinline__ u32x4 mask_outside(const u32x4& v, u32 idx0, u32 n) {
+  u32x4 r;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const u32 lo = (idx0 + 2u * d < n) ? 0x0000ffffu : 0u;
+    const u32 hi = (idx0 + 2u * d + 1u < n) ? 0xffff0000u : 0u;
+    r[d] = v[d] & (lo | hi);
+  }
+  return r;
+}
+
+// does the vector hold a 16-bit pattern >= cut (signed compare)?  cm1 = (cut-1) in both halves
+__device__ __forceinline__ bool any_ge(const u32x4& v, u32 cm1) {
+  const u32 mm = pk_max_i16(pk_max_i16(v[0], v[1]), pk_max_i16(v[2], v[3]));
+  return pk_max_i16(mm, cm1) != cm1;
+}
+
+// the lanes whose vector passes append it (and its number inside the unit) to the wave's buffer, in lane order
+__device__ __forceinline__ void append_vec(const u32x4& v, bool pass, u32 lid, u32x4* vb, u16* ib, u32& wcnt, bool& ovf) {
+  const u64 any = __ballot(pass);
+  if (any == 0ull) return;
+  const u32 tot = (u32)__popcll(any);
+  if (wcnt + tot > kVc) {  // wave-uniform
+    ovf = true;
+    return;
+  }
+  if (pass) {
+    const u32 pos = wcnt + mbcnt(any);
+    vb[pos] = v;
+    ib[pos] = (u16)lid;
+  }
+  wcnt += tot;
+}
+
+// K-th bin from the top of ss->hist (kHistBins bins): sc->cutbin / above / cb, or cutbin stays ~0 when fewer than K
+// values were counted.  Ends with a barrier.
+__device__ __forceinline__ void hist_kth_bin(SelScratch* ss, S16Ctl* sc, u32 K) {
+  constexpr int NT = kScanThreads, BPT = kHistBins / NT;
+  const u32 tid = threadIdx.x;
+  u32 local = 0;
+#pragma unroll
+  for (int j = 0; j < BPT; ++j) local += ss->hist[tid * BPT + j];
+  const u32 incl = wg_incl_suffix_sum<NT>(local, ss->wsum);
+  const u32 excl = incl - local;
+  if (excl < K && K <= incl) {  // at most one thread
+    u32 acc = excl;
+    for (int j = BPT - 1; j >= 0; --j) {
+      const u32 h = ss->hist[tid * BPT + j];
+      if (acc + h >= K) {
+        sc->cutbin = tid * BPT + j;
+        sc->above = acc;
+        sc->cb = h;
+        break;
+      }
+      acc += h;
+    }
+  }
+  __syncthreads();
+}
+
+template <int DT, int PF>
+__global__ __launch_bounds__(kScanThreads) void scan16_kernel(const ScanParams p) {
+  constexpr int NT = kScanThreads;
+  constexpr u32 NW = NT / 64;
+  constexpr u32 ULP_SH = DT == SSDK_BF16 ? 16u : 13u;  // ordered-fp32 bits below one ulp of the head's dtype
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64* buf = reinterpret_cast<u64*>(smem);  // the fallback's key buffer; the fast path's vector buffers live on it
+  u32x4* vbuf = reinterpret_cast<u32x4*>(smem);
+  u16* ibuf = reinterpret_cast<u16*>(smem + (size_t)NW * kVc * 16);
+  SelScratch* ss = reinterpret_cast<SelScratch*>(buf + kCap);
+  StreamCtl* ctl = reinterpret_cast<StreamCtl*>(ss + 1);
+  S16Ctl* sc = reinterpret_cast<S16Ctl*>(ctl + 1);
+  unsigned char* stage = smem + scan16_fixed_bytes();  // [wave][PF][1 KiB]
+  u64* kbuf = reinterpret_cast<u64*>(stage);           // extracted keys (once the ring has drained)
+  constexpr u32 kcap = NW * PF * 1024u / 8u;
+  u64* tiebuf = reinterpret_cast<u64*>(ss->hist);      // <= K <= 512 tie keys, parked while the ring is live
+
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u32 u = blockIdx.x / p.B;  // unit-major block order (see scan_kernel)
+  const u32 b = blockIdx.x % p.B;
+  u32 n = p.lv[0].n, ubase = 0, tpu = p.lv[0].tpu;
+  const void* cls = p.lv[0].cls;
+#pragma unroll
+  for (int i = 1; i < SSDK_MAX_LEVELS; ++i)
+    if (i < p.L && u >= p.lv[i].unit_base) {
+      n = p.lv[i].n;
+      ubase = p.lv[i].unit_base;
+      cls = p.lv[i].cls;
+      tpu = p.lv[i].tpu;
+    }
+  const ScanUnit U = make_scan_unit<DT>(cls, n, b, u - ubase, tpu);
+  const u32 K = p.K;
+  u64* out = p.cand + ((size_t)b * p.units_per_image + u) * K;
+  u32* out_cnt = p.cand_cnt + (size_t)b * p.units_per_image + u;
+  const bool stamp = p.stamps != nullptr && blockIdx.x == 0 && tid == 0;
+  if (stamp) p.stamps[0] = clock64();
+  const u32 ntiles = U.ntiles;
+  if (ntiles == 0) {  // (a plan never produces an empty unit; kept for forced unit sizes)
+    for (u32 i = tid; i < K; i += NT) out[i] = 0ull;
+    if (tid == 0) *out_cnt = 0;
+    return;
+  }
+
+  // ---- sample tiles: S tiles spread over the unit, one 16-byte vector per lane and tile, kept in registers --------------
+  const u32 S = ntiles < kSample ? ntiles : kSample;
+  const u32 sstride = ntiles / S;
+  u32x4 sv[kSample];
+#pragma unroll
+  for (u32 i = 0; i < kSample; ++i) sv[i] = *reinterpret_cast<const u32x4*>(U.addr((i < S ? i : S - 1u) * sstride, tid));
+
+  // ---- the stream's tiles: everything that is not a sample tile -----------------------------------------------------------
+  // iterator over the non-sample tiles: (t, ns) = current tile, next sample tile at or after it (~0: none left)
+  const u32 M = ntiles - S;
+  const u32 send = S * sstride;
+  auto adv = [&](u32& t, u32& ns) {
+    ++t;
+    if (t == ns) {
+      ++t;
+      ns += sstride;
+      if (ns >= send) ns = ~0u;
+    }
+  };
+  u32 ti = sstride == 1u ? S : 1u, nsi = sstride == 1u ? ~0u : sstride;  // issue side
+  u32 tc = ti, nsc = nsi;                                                   // consume side
+  // ---- phase H: the cut ------------------------------------------------------------------------------------------------
+  for (u32 i = tid; i < kHistBins; i += NT) ss->hist[i] = 0;
+  if (tid == 0) {
+    sc->cutbin = ~0u;
+    sc->above = 0;
+    sc->cb = 0;
+    sc->eq = 0;
+    sc->nan = 0;
+    sc->ovf = 0;
+    sc->kcnt = 0;
+    sc->ocnt = 0;
+    sc->scnt = 0;
+  }
+  if (tid < 32) sc->sub[tid] = 0;
+  u32 m1 = 0, m2 = 0;  // per 16-bit half-lane: largest / second largest pattern of its 4 x S sample scores
+#pragma unroll
+  for (u32 i = 0; i < kSample; ++i) {
+    if (i < S) {  // wave-uniform
+      const u32 idx0 = U.first_index<8>(i * sstride, tid);
+      const bool full = (idx0 < n) & (idx0 + 7u < n);
+      if (__ballot(!full) != 0ull) sv[i] = mask_outside(sv[i], idx0, n);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const u32 x = sv[i][d];
+        const u32 lo = pk_min_i16(m1, x);
+        m1 = pk_max_i16(m1, x);
+        m2 = pk_max_i16(m2, lo);
+      }
+    } else {
+      sv[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  // the ring is primed here, behind the last use of the sample loads (the compiler waits for ALL outstanding loads before
+  // it touches the first sample vector): the first stream tiles travel while the cut is computed
+  unsigned char* ring = stage + (size_t)wave * PF * 1024;
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    ring_issue(U.addr(ti, tid), ring + i * 1024);  // (past the unit's last tile: that tile again, cache hits)
+    adv(ti, nsi);
+  }
+  if (stamp) p.stamps[8] = clock64();
+  const u32 inf16 = p.inf16, thr16 = p.thr16;
+  const u32 sv4[4] = {m1 & 0xffffu, m1 >> 16, m2 & 0xffffu, m2 >> 16};  // (all >= 0: negative patterns lost against the 0 seed)
+  lds_barrier();  // histogram zeroed, control words initialised
+  if (__ballot((sv4[0] > inf16) | (sv4[1] > inf16)) != 0ull && lane == 0) sc->nan = 1u;  // a NaN among the largest patterns
+#pragma unroll
+  for (int j = 0; j < 4; ++j) hist_add(ss->hist, sv4[j] >= thr16, hist_bin(ord_of16<DT>(sv4[j]), p.hist_base, p.hist_sh));
+  __syncthreads();
+  if (stamp) p.stamps[9] = clock64();
+  hist_kth_bin(ss, sc, K);  // (ends with a barrier)
+  u32 cut16 = thr16, eq = 0;
+  {
+    const u32 cutbin = sc->cutbin;
+    if (cutbin != ~0u) {  // workgroup-uniform
+      const u32 c0 = ceil16_of_ord<DT>(p.hist_base + (cutbin << p.hist_sh));
+      cut16 = c0 > thr16 ? c0 : thr16;
+      const bool exact = cutbin < kHistBins - 1 && p.hist_sh <= ULP_SH;  // the bin holds ONE representable value
+      if (exact) {
+        eq = sc->cb;
+      } else if (cutbin < kHistBins - 1 && p.hist_sh - ULP_SH <= 5u) {
+        // several representable values per bin (f16: 8): the K-th largest of the sample values, exactly, from a
+        // 2^(sh - ulp)-bin histogram of the bin's members -- an all-equal f16 image must find its tie value too
+        const u32 span = 1u << (p.hist_sh - ULP_SH);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (sv4[j] >= cut16 && hist_bin(ord_of16<DT>(sv4[j]), p.hist_base, p.hist_sh) == cutbin) {
+            const u32 k = sv4[j] - cut16;
+            atomicAdd(&sc->sub[k < 31u ? k : 31u], 1u);
+          }
+        __syncthreads();
+        if (tid == 0) {
+          const u32 need = K - sc->above;
+          u32 acc = 0, add = 0, e = 0;
+          for (int j = (int)(span < 32u ? span : 32u) - 1; j >= 0; --j) {
+            const u32 h = sc->sub[j];
+            if (acc + h >= need) {
+              add = (u32)j;
+              e = h;
+              break;
+            }
+            acc += h;
+          }
+          sc->cut16 = cut16 + add;
+          sc->eq = e;
+        }
+        __syncthreads();
+        cut16 = sc->cut16;
+        eq = sc->eq;
+      }
+    }
+  }
+  cut16 = (u32)__builtin_amdgcn_readfirstlane((int)cut16);
+  eq = (u32)__builtin_amdgcn_readfirstlane((int)eq);
+  const bool tie_rich = eq >= K && cut16 < inf16;  // the cut value itself fills K of the 1024 sample slots
+  if (stamp) p.stamps[10] = clock64();
+
+  // ---- tie prefix (tie-rich units only): the first K scores EQUAL to the cut, in index order ------------------------------
+  u32 ntie = 0;
+  u32 ccut = cut16;  // what the filters compare against
+  if (tie_rich) {
+    u32 need = K;
+    for (u32 t = 0; t < ntiles && need > 0u; ++t) {  // workgroup-uniform
+      const u32x4 v = *reinterpret_cast<const u32x4*>(U.addr(t, tid));
+      const u32 idx0 = U.first_index<8>(t, tid);
+      u32 em = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) em |= ((half_of(v, e) == cut16) & (idx0 + (u32)e < n)) ? (1u << e) : 0u;
+      const u32 c = (u32)__popc(em);
+      u32 excl = 0, tot = 0;
+#pragma unroll
+      for (int bit = 0; bit < 4; ++bit) {
+        const u64 mb = __ballot((c >> bit) & 1u);
+        excl += mbcnt(mb) << bit;
+        tot += (u32)__popcll(mb) << bit;
+      }
+      if (lane == 0) sc->wcount[wave] = tot;
+      __syncthreads();
+      u32 before = 0, all = 0;
+#pragma unroll
+      for (u32 w = 0; w < NW; ++w) {
+        const u32 cw = sc->wcount[w];
+        before += w < wave ? cw : 0u;
+        all += cw;
+      }
+      u32 left = em, pos = before + excl;  // positions of this lane's ties among the tile's ties (index order)
+      const u32 base = K - need;
+      while (left) {
+        const u32 e = (u32)__ffs((int)left) - 1u;
+        left &= left - 1u;
+        if (pos < need) tiebuf[base + pos] = ((u64)ord_of16<DT>(cut16) << 32) | (u64)(~(idx0 + e));
+        ++pos;
+      }
+      need = need > all ? need - all : 0u;
+      __syncthreads();
+    }
+    ntie = K - need;
+    ccut = cut16 + 1u;  // the unit's ties are settled: everything else must beat the cut
+  }
+  if (stamp) p.stamps[1] = clock64();
+
+  // ---- filter: the sample vectors from their registers, then the stream -----------------------------------------------------
+  const u32 cm1 = (ccut - 1u) | ((ccut - 1u) << 16);
+  u32x4* vb = vbuf + (size_t)wave * kVc;
+  u16* ib = ibuf + (size_t)wave * kVc;
+  u32 wcnt = 0;
+  bool ovf = false;
+#pragma unroll
+  for (u32 i = 0; i < kSample; ++i)
+    if (i < S && !ovf) append_vec(sv[i], any_ge(sv[i], cm1), i * sstride * NT + tid, vb, ib, wcnt, ovf);
+  for (u32 q0 = 0; q0 < M; q0 += PF) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const u32x4 v = ring_take<PF - 1>(ring + i * 1024 + lane * 16);  // the oldest of the PF requests has landed
+      ring_issue(U.addr(ti, tid), ring + i * 1024);
+      adv(ti, nsi);
+      if (q0 + (u32)i < M) {  // wave-uniform (the last round of a unit runs its surplus slots masked)
+        const u32 lid = tc * NT + tid;
+        adv(tc, nsc);
+        // a lane behind the image's last vector re-read that vector (clamped address): it must not count twice
+        if (!ovf) append_vec(v, any_ge(v, cm1) & (U.vec0 + lid <= U.vlast), lid, vb, ib, wcnt, ovf);
+      }
+    }
+  }
+  ring_drain();
+  if (lane == 0) {
+    sc->wcount[wave] = wcnt;
+    if (ovf) sc->ovf = 1u;
+  }
+  // the tie keys leave the histogram's storage before it is used again
+  u64 tk0 = 0, tk1 = 0;
+  if (tid < ntie) tk0 = tiebuf[tid];
+  if (tid + NT < ntie) tk1 = tiebuf[tid + NT];
+  __syncthreads();
+  if (stamp) p.stamps[2] = clock64();
+
+  u32 cnt = 0;
+  bool done = false;
+  if ((sc->ovf | sc->nan) == 0u) {
+    // ---- extraction: keys of the buffered vectors' elements that pass, with the reference's tests ---------------------
+    for (u32 i = tid; i < kHistBins; i += NT) ss->hist[i] = 0;
+    if (tid < ntie) kbuf[tid] = tk0;
+    if (tid + NT < ntie) kbuf[tid + NT] = tk1;
+    if (tid == 0) sc->kcnt = ntie;
+    __syncthreads();
+    if (tid == 0 && ntie) atomicAdd(&ss->hist[hist_bin(ord_of16<DT>(cut16), p.hist_base, p.hist_sh)], ntie);
+    u32 wc[NW], TV = 0;
+#pragma unroll
+    for (u32 w = 0; w < NW; ++w) {
+      wc[w] = sc->wcount[w];
+      TV += wc[w];
+    }
+    for (u32 j0 = 0; j0 < TV; j0 += NT) {  // workgroup-uniform trip count
+      const u32 j = j0 + tid;
+      const bool have = j < TV;
+      u32 w = 0, pos = j;
+#pragma unroll
+      for (u32 q = 0; q + 1 < NW; ++q)
+        if (w == q && pos >= wc[q]) {
+          pos -= wc[q];
+          w = q + 1;
+        }
+      const u32 slot = have ? w * kVc + pos : 0u;
+      const u32x4 v = vbuf[slot];
+      const u32 idx0 = (U.vec0 + (u32)ibuf[slot]) * 8u - U.head;
+      u32 pm = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const u32 h = half_of(v, e);
+        const bool ok = ((int)(short)(u16)h >= (int)ccut) & (h <= inf16) & (idx0 + (u32)e < n);
+        pm |= (have && ok) ? (1u << e) : 0u;
+      }
+      const u32 c = (u32)__popc(pm);
+      u32 excl = 0, tot = 0;
+#pragma unroll
+      for (int bit = 0; bit < 4; ++bit) {
+        const u64 mb = __ballot((c >> bit) & 1u);
+        excl += mbcnt(mb) << bit;
+        tot += (u32)__popcll(mb) << bit;
+      }
+      if (tot == 0u) continue;  // wave-uniform
+      u32 base = 0;
+      if (lane == 0) base = atomicAdd(&sc->kcnt, tot);
+      base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+      if (base + tot > kcap) {  // wave-uniform: more candidates than the key buffer holds
+        if (lane == 0) sc->ovf = 1u;
+        continue;
+      }
+      u32 at = base + excl, left = pm;
+      while (left) {
+        const u32 e = (u32)__ffs((int)left) - 1u;
+        left &= left - 1u;
+        const u32 w16 = e < 2u ? v[0] : (e < 4u ? v[1] : (e < 6u ? v[2] : v[3]));
+        const u32 h = (e & 1u) ? (w16 >> 16) : (w16 & 0xffffu);
+        const u32 o = ord_of16<DT>(h);
+        kbuf[at++] = ((u64)o << 32) | (u64)(~(idx0 + e));
+        atomicAdd(&ss->hist[hist_bin(o, p.hist_base, p.hist_sh)], 1u);
+      }
+    }
+    __syncthreads();
+    if (stamp) p.stamps[11] = clock64();
+    if (sc->ovf == 0u) {
+      // ---- select: exact top-K of the extracted keys, unordered, straight to the workspace --------------------------
+      const u32 nk = sc->kcnt;
+      if (nk <= K) {
+        for (u32 i = tid; i < nk; i += NT) out[i] = kbuf[i];
+        cnt = nk;
+      } else {
+        if (tid == 0) sc->cutbin = ~0u;
+        __syncthreads();
+        hist_kth_bin(ss, sc, K);
+        const u32 cbin = sc->cutbin, above = sc->above, cb = sc->cb, need = K - above;
+        if (cb > 512u) {  // heavy ties inside one bin: the generic exact select
+          const u64 T = wg_select_kth<NT>(kbuf, nk, K, ss);
+          for (u32 i = tid; i < nk; i += NT) {
+            const u64 k = kbuf[i];
+            if (k >= T) out[atomicAdd(&sc->ocnt, 1u)] = k;
+          }
+        } else {
+          u64* small = reinterpret_cast<u64*>(ss->hist);  // (the histogram has been read: cb <= 512 keys fit)
+          for (u32 i = tid; i < nk; i += NT) {
+            const u64 k = kbuf[i];
+            const u32 kb = hist_bin((u32)(k >> 32), p.hist_base, p.hist_sh);
+            if (kb > cbin) out[atomicAdd(&sc->ocnt, 1u)] = k;
+            else if (kb == cbin) small[atomicAdd(&sc->scnt, 1u)] = k;
+          }
+          __syncthreads();
+          for (u32 t = tid; t < cb; t += NT) {
+            const u64 me = small[t];
+            u32 r = 0;
+            for (u32 j = 0; j < cb; ++j) r += small[j] > me ? 1u : 0u;
+            if (r < need) out[above + r] = me;
+          }
+        }
+        cnt = K;
+      }
+      done = true;
+    }
+  }
+  if (!done) {
+    // ---- the exact TopK stream over the whole unit (a misleading sample, NaNs, adversarial inputs) ----------------------
+    const float c16 = f32_of16<DT>(cut16 <= inf16 ? cut16 : inf16);
+    const float cut0 = (sc->nan == 0u && c16 > p.thr) ? c16 : p.thr;  // the sample's cut stays a valid lower bound
+    cnt = unit_topk_stream<DT, PF>(U, cut0, K, buf, ss, ctl, stage);
+    for (u32 i = tid; i < cnt; i += NT) out[i] = buf[i];
+  }
+  for (u32 i = cnt + tid; i < K; i += NT) out[i] = 0ull;
+  if (tid == 0) *out_cnt = cnt;
+  if (stamp) {
+    p.stamps[3] = clock64();
+    p.stamps[4] = clock64();
+    p.stamps[5] = ((unsigned long long)(done ? 1u : 0u) << 32) | cnt;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------------
+static float host_f16_to_f32(u32 h) {
+  const u32 e = (h >> 10) & 31u, m = h & 1023u;
+  float v;
+  if (e == 0) v = (float)m * (1.0f / 16777216.0f);  // m * 2^-24
+  else if (e == 31) v = m ? __builtin_nanf("") : __builtin_inff();
+  else {
+    const u32 bits = ((e + 112u) << 23) | (m << 13);
+    memcpy(&v, &bits, 4);
+  }
+  return v;
+}
+
+// smallest non-negative 16-bit pattern of `dtype` whose value is >= thr (thr > 0, finite or +inf)
+u32 scan16_threshold_pattern(int dtype, float thr) {
+  if (dtype == SSDK_BF16) {
+    u32 bits;
+    memcpy(&bits, &thr, 4);
+    return (bits >> 16) + ((bits & 0xffffu) ? 1u : 0u);
+  }
+  u32 lo = 0, hi = 0x7c00u;  // patterns 0 .. +inf are ordered like their values
+  while (lo < hi) {
+    const u32 mid = (lo + hi) >> 1;
+    if (host_f16_to_f32(mid) >= thr) hi = mid;
+    else lo = mid + 1;
+  }
+  return lo;
+}
+
+bool scan16_applies(int dtype, float thr, int K) {
+  const char* e = getenv("SSDK_SCAN16");  // (read on every call: tests switch kernels inside one process)
+  const int env = (e && *e) ? atoi(e) : 1;
+  return env != 0 && (dtype == SSDK_BF16 || dtype == SSDK_F16) && thr > 0.0f && thr == thr && K >= 1 && K <= 512;
+}
+
+// tiles per unit above which the per-wave vector buffers are expected to overflow: a unit of T tiles keeps about
+// K * T / kSample vectors (the sample's K-th value sits at rank ~K * T / 8 of the unit); 3/4 of the four buffers
+u32 scan16_max_tiles_per_unit(int K) {
+  const u32 t = (u32)(3ull * (kScanThreads / 64) * kVc * kSample / 4ull / (unsigned)K);
+  return t < 4u ? 4u : (t > 255u ? 255u : t);  // (<= 255: a vector's number inside the unit is stored in 16 bits)
+}
+
+int launch_scan16(const ScanParams& sp, int dtype, int B, u32 units_per_image, hipStream_t stream) {
+  const int pf = getenv("SSDK_SCAN_PF") && atoi(getenv("SSDK_SCAN_PF")) == 8 ? 8 : 4;  // 16-byte requests in flight per lane
+  const size_t lds = scan16_lds_bytes(pf);
+  const dim3 grid((unsigned)((size_t)B * units_per_image));
+  auto go = [&](auto kern) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, dim3(kScanThreads), lds, stream, sp);
+  };
+  if (pf == 8) {
+    if (dtype == SSDK_BF16) go(scan16_kernel<SSDK_BF16, 8>);
+    else go(scan16_kernel<SSDK_F16, 8>);
+  } else {
+    if (dtype == SSDK_BF16) go(scan16_kernel<SSDK_BF16, 4>);
+    else go(scan16_kernel<SSDK_F16, 4>);
+  }
+  return check_launch("scan16_kernel");
+}
+
+}  // namespace ssdk

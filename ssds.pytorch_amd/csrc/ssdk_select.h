@@ -51,8 +51,11 @@ __device__ __forceinline__ u32 wg_incl_suffix_sum(u32 v, u32* wsum) {
 // key plus everything above it is at most approx_max keys, and return the bin's lowest possible key: pruning with
 // `key >= T` then keeps a superset of the top K (K .. approx_max keys) at a third of the cost -- the ties inside the
 // bin (bf16 scores: hundreds per value) are only resolved by the exact select at the end of the stream.
-template <int NT>
-__device__ u64 wg_select_kth(const u64* buf, u32 n, u32 K, SelScratch* s, u32 approx_max = 0) {
+// `fetch(i)`, i < n: the i-th key of the set (any storage: LDS, or global memory behind a predicate).  A source may
+// return 0 for "no key here": zero is below every real key (real keys carry the sign-flipped score bit), so it never
+// changes which key is the K-th LARGEST as long as K real keys exist.
+template <int NT, class Fetch>
+__device__ u64 wg_select_kth_f(Fetch fetch, u32 n, u32 K, SelScratch* s, u32 approx_max = 0) {
   const u32 tid = threadIdx.x, lane = tid & 63u;
   constexpr int BPT = 1024 / NT;
   if (tid == 0) {
@@ -65,7 +68,7 @@ __device__ u64 wg_select_kth(const u64* buf, u32 n, u32 K, SelScratch* s, u32 ap
   for (int pass = 0; pass < 8; ++pass) {  // uniform loop; every exit condition is workgroup-uniform
     u64 o = 0, a = ~0ull;
     for (u32 i = tid; i < n; i += NT) {
-      u64 k = buf[i];
+      u64 k = fetch(i);
       if ((k & pfx_mask) == pfx_val) {
         o |= k;
         a &= k;
@@ -98,7 +101,7 @@ __device__ u64 wg_select_kth(const u64* buf, u32 n, u32 K, SelScratch* s, u32 ap
     }
     for (u32 i0 = 0; i0 < n; i0 += NT) {  // uniform trip count: the wave-level aggregation below needs all lanes
       const u32 i = i0 + tid;
-      const u64 k = i < n ? buf[i] : 0ull;
+      const u64 k = i < n ? fetch(i) : 0ull;
       const bool c = i < n && (k & pfx_mask) == pfx_val;
       const u32 bin = (u32)(k >> shift) & nbmask;
       const u64 m = __ballot(c);
@@ -145,7 +148,7 @@ __device__ u64 wg_select_kth(const u64* buf, u32 n, u32 K, SelScratch* s, u32 ap
       if (tid == 0) s->small_cnt = 0;
       __syncthreads();
       for (u32 i = tid; i < n; i += NT) {
-        u64 k = buf[i];
+        u64 k = fetch(i);
         if ((k & pfx_mask) == pfx_val) small[atomicAdd(&s->small_cnt, 1u)] = k;
       }
       __syncthreads();
@@ -162,6 +165,11 @@ __device__ u64 wg_select_kth(const u64* buf, u32 n, u32 K, SelScratch* s, u32 ap
   }
   __syncthreads();
   return T;
+}
+
+template <int NT>
+__device__ u64 wg_select_kth(const u64* buf, u32 n, u32 K, SelScratch* s, u32 approx_max = 0) {
+  return wg_select_kth_f<NT>([buf](u32 i) { return buf[i]; }, n, K, s, approx_max);
 }
 
 // keep the K keys >= T at the front of buf (sel is a K-entry LDS staging area)

@@ -1,21 +1,25 @@
-// ssdk_tail.hip -- everything of Decoder.__call__ (reference ssds/modeling/layers/decoder.py:25-49) behind the scan,
-// as ONE launch: per image one workgroup of 16 waves
+// ssdk_tail.hip -- everything of Decoder.__call__ (reference ssds/modeling/layers/decoder.py:25-49) behind the scan, as ONE
+// launch: per image one workgroup of 16 waves that
 //
-//   A. stages the SORTED per-unit top-K lists that scan_kernel left in the workspace (ssdk_decode.hip) in LDS;
-//   B. merges the units of every level WITHOUT selecting or sorting again: the rank of a key inside its level is its
-//      index in its own list plus, for every sibling list, the number of larger keys there (binary search; keys are
-//      unique).  A key of rank r < K is the r-th output of box.decode for that level (box.py:446 topk, sorted): its
-//      thread gathers the 4 deltas, applies delta2box (box.py:74-87) and the centre rescoring (box.py:464-471) and
-//      leaves (score, box, class) in LDS at position l*K + r -- the slot torch.cat gives it (decoder.py:48);
-//   C. sorts the L*K candidates with score > 0 (box.py:496; NaN drops out) by (rescored score desc, position asc)
-//      (box.py:505, stable-order contract) -- bitonic network with barriers only on the steps that cross waves;
-//   D. walks them 64 at a time exactly like nms_kernel (ssdk_nms.hip): kept-list test split over the 16 waves,
-//      suppression rows of 4 pivots per wave, in-order resolve on bitmasks by wave 0 (box.py:512-544);
-//   E. writes the zero-padded [ndetections] outputs (box.py:489-491).
+//   B1. selects the top K of every LEVEL from the <= K unordered keys each scan unit left in the workspace (box.py:446
+//       topk over the whole level) and puts them in order -- by COUNTING, not by sorting or merging: a 1024-bin histogram
+//       of the score per level (the same window the scan uses: one bin per bf16 value between the threshold and 1), the
+//       bin in which the count from the top reaches K, a counting-sort scatter of the bins above it (their start offsets
+//       are the histogram's suffix sums), a rank count inside the boundary bin and inside every bin that holds more than
+//       one key.  With tie-free scores a bin holds one to three keys, so the "sort" is one LDS atomic per key;
+//   B2. decodes the winners: gather of the 4 deltas, delta2box (box.py:74-87), centre rescoring (box.py:464-471), into
+//       LDS at position l*K + r -- the slot torch.cat gives the r-th output of level l (decoder.py:48);
+//   C.  orders the walk of box.nms lazily (box.py:505): the exact top 256 of the candidates with score > 0 (box.py:496)
+//       by adaptive radix select on (rescored score, position) keys, ranked by counting; more rounds only while fewer
+//       than `ndetections` boxes survived;
+//   D.  walks them 64 at a time like nms_kernel (ssdk_nms.hip): kept-list test split over the 16 waves, suppression rows
+//       of 4 pivots per wave, in-order resolve on bitmasks by wave 0 (box.py:512-544);
+//   E.  writes the zero-padded [ndetections] outputs (box.py:489-491).
 //
-// The 24*L*K-byte per-level decode output that level_kernel wrote and nms_kernel read back never leaves the CU (it is
-// still written when the caller asks for it: `mid_*`, decoder.py:48), and two dependent launches become one.
-// Arithmetic and tie order are those of level_kernel / nms_kernel: same helpers, same fp32 sequences.
+// Round 2's kernel merged SORTED unit lists by binary-search ranks (10 k cycles), sorted all L*K candidates as 128-key
+// register runs and ranked a 512-key head among them (41 k cycles of 83 k).  Nothing is sorted here: the scan emits its
+// winners unordered (ssdk_scan16.hip), B1 is ~5 k cycles and C ~5 k.  Arithmetic and tie order are unchanged: same
+// helpers, same fp32 sequences, keys are unique (score bits | ~index), so "top K" and "rank" are well defined.
 #include "ssdk_common.h"
 #include "ssdk_select.h"
 #include "ssdk_decode.h"
@@ -23,7 +27,9 @@
 namespace ssdk {
 
 constexpr int kTailThreads = 1024;
-constexpr u32 kHeadMax = 512;  // candidates of the walk's head that are ordered first (phase C)
+constexpr u32 kRound = 256;      // candidates ordered + walked per NMS round
+constexpr u32 kTailBins = 1024;  // score bins per level (B1)
+constexpr u32 kRegKeys = 8;      // keys per lane of a wave's first unit kept in registers (K <= 512)
 
 struct TailLevel {
   const void* box;
@@ -36,6 +42,7 @@ struct TailParams {
   int L, dtype, rescore;
   u32 units_per_image, K;
   u32 M;  // power of two >= L*K: length of the NMS key array
+  u32 hist_base, hist_sh;  // score window of B1: bin = (ord(score) - hist_base) >> hist_sh, clamped (ssdk_decode.hip)
   const u64* cand;
   const u32* cand_cnt;
   float thr;
@@ -121,21 +128,36 @@ __device__ __forceinline__ float tail_bcast(float v, u32 j) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)j));
 }
 
+__device__ __forceinline__ u32 tail_bin(u64 key, u32 base, u32 sh) {
+  const u32 o = (u32)(key >> 32);
+  const u32 bin = o < base ? 0u : (o - base) >> sh;  // (every candidate is at or above the threshold, i.e. >= base)
+  return bin < kTailBins - 1 ? bin : kTailBins - 1;
+}
+
 struct alignas(16) TailLds {  // fixed-size part of the LDS image (the arrays follow, see tail_lds_bytes)
   TailLevel lv[SSDK_MAX_LEVELS];
   u64 rows[64];
   u64 blk_dead;
-  u32 nvalid, nk, nhead, pad1;
-  u64 lbound[SSDK_MAX_LEVELS];  // per level: lower bound of its K-th key (phase B1)
-  u32 hp[32];                   // phase C: head candidates of run r
-  u64 hk[kHeadMax];             // phase C: the head candidates, gathered
+  u64 lb[SSDK_MAX_LEVELS];      // per level: a lower bound of its K-th key (largest minimum of its FULL unit lists)
+  u32 nvalid, nk, topcnt, pad0;
+  int cutbin[SSDK_MAX_LEVELS];  // -1: the level offers <= K keys, every one is a winner
+  u32 ln[SSDK_MAX_LEVELS];      // keys the level's units offer (at or above lb)
+  u32 above[SSDK_MAX_LEVELS];   // winners in the bins above the boundary bin
+  u32 nw[SSDK_MAX_LEVELS];      // winners of the level: min(K, ln)
+  u32 bcnt[SSDK_MAX_LEVELS];    // keys in the boundary list
+  u32 generic[SSDK_MAX_LEVELS]; // the boundary bin holds more than K keys: adaptive radix select over the units' keys
+  SelScratch ss;
 };
 
-__host__ __device__ inline size_t tail_lds_bytes(u32 units_per_image, u32 K, u32 L, u32 M, u32 ndet) {
+__host__ __device__ inline size_t tail_r1_bytes(u32 L, u32 M) {  // histograms of B1, later the NMS keys + one round
+  const size_t a = (size_t)L * kTailBins * 4, b = (size_t)(M < 128u ? 128u : M) * 8 + 2 * (size_t)kRound * 8;
+  return ((a > b ? a : b) + 15) & ~(size_t)15;
+}
+__host__ __device__ inline size_t tail_lds_bytes(u32 K, u32 L, u32 M, u32 ndet) {
   size_t n = sizeof(TailLds);
-  n += (((size_t)units_per_image * K * 8) + 15) & ~(size_t)15;  // ukeys
-  n += 2 * ((((size_t)units_per_image * 4) + 15) & ~(size_t)15);  // ucnt, uq
-  n += 2 * (size_t)(M < 128u ? 128u : M) * 8;     // nkeys, sorted (whole runs of 128 keys)
+  n += tail_r1_bytes(L, M);
+  n += (size_t)L * kTailBins * 2;                 // gstart
+  n += 2 * ((((size_t)L * K * 8) + 15) & ~(size_t)15);  // wkeys, wl (the boundary lists live on wl until it is written)
   n += (size_t)L * K * 16;                        // rec_box
   n += (((size_t)L * K * 8) + 15) & ~(size_t)15;  // rec_score, rec_cls
   n += (size_t)ndet * 16 + ((((size_t)ndet * 8) + 15) & ~(size_t)15);  // kbox, karea, kcls
@@ -148,23 +170,26 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TailLds* S = reinterpret_cast<TailLds*>(smem);
   const u32 K = p.K, L = (u32)p.L, upi = p.units_per_image, M = p.M, ndet = (u32)p.ndet;
+  const u32 LK = L * K;
+  const u32 Mp = M < 128u ? 128u : M;
   unsigned char* q = smem + sizeof(TailLds);
-  u64* ukeys = reinterpret_cast<u64*>(q);
-  q += (((size_t)upi * K * 8) + 15) & ~(size_t)15;
-  u32* ucnt = reinterpret_cast<u32*>(q);
-  q += (((size_t)upi * 4) + 15) & ~(size_t)15;
-  u32* uq = reinterpret_cast<u32*>(q);  // keys of unit u that can still reach rank < K (a prefix of its list)
-  q += (((size_t)upi * 4) + 15) & ~(size_t)15;
-  const u32 Mp = M < 128u ? 128u : M;  // whole runs of 128 keys
-  u64* nkeys = reinterpret_cast<u64*>(q);
-  q += (size_t)Mp * 8;
-  u64* sorted = reinterpret_cast<u64*>(q);
-  q += (size_t)Mp * 8;
+  u32* hist = reinterpret_cast<u32*>(q);                    // [L][kTailBins]   (B1)
+  u64* nkeys = reinterpret_cast<u64*>(q);                   // [Mp]             (B2 .. D, on top of the histograms)
+  u64* top_u = nkeys + Mp;                                  // [kRound] the round's keys, unordered
+  u64* sorted = top_u + kRound;                             // [kRound] ... in walk order
+  q += tail_r1_bytes(L, M);
+  u16* gstart = reinterpret_cast<u16*>(q);                  // [L][kTailBins] first slot of a bin's group
+  q += (size_t)L * kTailBins * 2;
+  u64* wkeys = reinterpret_cast<u64*>(q);                   // [L][K] winners grouped by bin (descending), boundary winners in order
+  q += (((size_t)LK * 8) + 15) & ~(size_t)15;
+  u64* wl = reinterpret_cast<u64*>(q);                      // [L][K] winners in order (rank r of level l at l*K + r)
+  u64* bkeys = wl;                                          // [L][K] boundary lists (dead before wl is written)
+  q += (((size_t)LK * 8) + 15) & ~(size_t)15;
   float4* rec_box = reinterpret_cast<float4*>(q);
-  q += (size_t)L * K * 16;
+  q += (size_t)LK * 16;
   float* rec_score = reinterpret_cast<float*>(q);
-  float* rec_cls = rec_score + (size_t)L * K;
-  q += (((size_t)L * K * 8) + 15) & ~(size_t)15;
+  float* rec_cls = rec_score + (size_t)LK;
+  q += (((size_t)LK * 8) + 15) & ~(size_t)15;
   float4* kbox = reinterpret_cast<float4*>(q);
   q += (size_t)ndet * 16;
   float* karea = reinterpret_cast<float*>(q);
@@ -174,300 +199,384 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
   const u32 b = blockIdx.x;
   const bool stamp = p.stamps != nullptr && b == 0 && tid == 0;
   if (stamp) p.stamps[0] = clock64();
+  const u32 hbase = p.hist_base, hsh = p.hist_sh;
 
-  // ---- A: geometry + unit lists into LDS -----------------------------------------------------------------------
+  // ---- A: geometry, counters, histograms ---------------------------------------------------------------------------------
   {
     const u32* src = reinterpret_cast<const u32*>(&p.lv[0]);
     u32* dst = reinterpret_cast<u32*>(&S->lv[0]);
     for (u32 i = tid; i < (u32)(sizeof(TailLevel) / 4) * L; i += NT) dst[i] = src[i];
   }
+  for (u32 i = tid; i < L * kTailBins; i += NT) hist[i] = 0;
+  if (tid < SSDK_MAX_LEVELS) {
+    S->lb[tid] = 0ull;
+    S->ln[tid] = 0;
+    S->bcnt[tid] = 0;
+    S->generic[tid] = 0;
+    S->above[tid] = 0;
+    S->nw[tid] = 0;
+    S->cutbin[tid] = -1;
+  }
   if (tid == 0) {
     S->blk_dead = 0ull;
     S->nvalid = 0;
     S->nk = 0;
-    S->nhead = 0;
+    S->topcnt = 0;
   }
-  {
-    const u64* src = p.cand + (size_t)b * upi * K;
-    const u32 total = upi * K;
-    for (u32 i = tid; i < total; i += NT) ukeys[i] = src[i];
-    for (u32 i = tid; i < upi; i += NT) ucnt[i] = p.cand_cnt[(size_t)b * upi + i];
-  }
-  __syncthreads();
-  // A cheap lower bound of every level's K-th key: with j = ceil(K / nruns), every full list of the level holds j keys
-  // >= its own j-th, so K keys are >= the smallest of those j-th keys and nothing below it can reach rank < K.  (Lists
-  // of a level are statistically alike: the bound discards ~(nruns-1)/nruns of the keys before any search.)
-  if (tid < L) {
-    const u32 u0 = S->lv[tid].unit_base, nruns = S->lv[tid].units;
-    const u32 j = (K + nruns - 1) / nruns;
-    u64 bound = ~0ull, single = 0ull;
-    for (u32 v = u0; v < u0 + nruns; ++v) {
-      const u64 kj = ukeys[(size_t)v * K + j - 1];  // (0 behind the end of a short list: no bound then)
-      bound = kj < bound ? kj : bound;
-      const u64 kk = ukeys[(size_t)v * K + K - 1];  // a full list alone proves K keys >= its last one (ties in index
-      single = kk > single ? kk : single;           // order, e.g. an all-equal image: the first list IS the level's top K)
+  // the unit lists: wave w owns units w, w + 16, ...; the keys of its FIRST unit stay in registers for the passes below
+  const u64* cand = p.cand + (size_t)b * upi * K;
+  const u32* ccnt = p.cand_cnt + (size_t)b * upi;
+  u64 kreg[kRegKeys];
+  u32 cnt0 = 0;
+  if (wave < upi) {
+    cnt0 = ccnt[wave];
+#pragma unroll
+    for (u32 c = 0; c < kRegKeys; ++c) {
+      const u32 i = c * 64 + lane;
+      kreg[c] = i < cnt0 ? cand[(size_t)wave * K + i] : 0ull;
     }
-    bound = bound > single ? bound : single;
-    S->lbound[tid] = nruns > 1 ? bound : 0ull;
+  } else {
+#pragma unroll
+    for (u32 c = 0; c < kRegKeys; ++c) kreg[c] = 0ull;
   }
-  __syncthreads();
-  // lists are sorted: the keys of a list at or above its level's bound are a PREFIX of it; uq[u] = its length
-  if (tid < upi) {
+  auto level_of = [&](u32 u) -> u32 {
     u32 l = 0;
-    for (u32 t = 1; t < L; ++t)
-      if (tid >= S->lv[t].unit_base) l = t;
-    const u64 bound = S->lbound[l];
-    const u64* lst = ukeys + (size_t)tid * K;
-    u32 lo = 0, hi = ucnt[tid];
-    while (lo < hi) {  // first index whose key is below the bound
-      const u32 mid = (lo + hi) >> 1;
-      if (lst[mid] >= bound) lo = mid + 1;
-      else hi = mid;
+    for (u32 v = 1; v < L; ++v)
+      if (u >= p.lv[v].unit_base) l = v;
+    return l;
+  };
+  // f(level, key) for every key of this wave's units (every lane of the wave runs the same trips)
+  auto for_each_key = [&](auto f) {
+    if (wave < upi) {
+      const u32 l = level_of(wave);
+#pragma unroll
+      for (u32 c = 0; c < kRegKeys; ++c)
+        if (c * 64 < cnt0) f(l, kreg[c], c * 64 + lane < cnt0);
     }
-    uq[tid] = lo;
+    for (u32 u = wave + NW; u < upi; u += NW) {
+      const u32 l = level_of(u), cnt = ccnt[u];
+      for (u32 i0 = 0; i0 < cnt; i0 += 64) {
+        const u32 i = i0 + lane;
+        const u64 key = i < cnt ? cand[(size_t)u * K + i] : 0ull;
+        f(l, key, i < cnt);
+      }
+    }
+  };
+  __syncthreads();
+  // A full list proves that K keys are >= its smallest one: the largest such minimum over a level's units is a lower bound
+  // of the level's K-th key.  (An all-equal image -- the reference-init network -- leaves the first K indices in EVERY
+  // unit: only the first unit's keys survive this bound and no selection is needed at all.)
+  {
+    auto unit_min = [&](u32 u, u32 cnt, auto get) {
+      if (cnt < K) return;  // wave-uniform
+      u64 mn = ~0ull;
+      for (u32 i0 = 0; i0 < cnt; i0 += 64) {
+        const u64 k = get(i0);
+        mn = (i0 + lane < cnt && k < mn) ? k : mn;
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        const u64 o = shfl_xor_u64(mn, d);
+        mn = o < mn ? o : mn;
+      }
+      if (lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(&S->lb[level_of(u)]), mn);
+    };
+    if (wave < upi) {
+      u64 mn = ~0ull;
+#pragma unroll
+      for (u32 c = 0; c < kRegKeys; ++c) mn = (c * 64 + lane < cnt0 && kreg[c] < mn) ? kreg[c] : mn;
+      if (cnt0 >= K) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+          const u64 o = shfl_xor_u64(mn, d);
+          mn = o < mn ? o : mn;
+        }
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(&S->lb[level_of(wave)]), mn);
+      }
+    }
+    for (u32 u = wave + NW; u < upi; u += NW) {
+      const u32 cnt = ccnt[u];
+      unit_min(u, cnt, [&](u32 i0) { return i0 + lane < cnt ? cand[(size_t)u * K + i0 + lane] : ~0ull; });
+    }
   }
   __syncthreads();
   if (stamp) p.stamps[1] = clock64();
 
-  // ---- B: merged rank inside the level (B1), decode of the winners (B2) ----------------------------------------------
-  const u32 LK = L * K;
+  // ---- B1: per level, the top K of its units' keys, in order ---------------------------------------------------------------
+  // pass 1: histogram of the keys at or above the level's bound
+  for_each_key([&](u32 l, u64 key, bool have) {
+    const bool in = have && key >= S->lb[l];
+    if (in) atomicAdd(&hist[l * kTailBins + tail_bin(key, hbase, hsh)], 1u);
+    const u64 m = __ballot(in);
+    if (lane == 0 && m) atomicAdd(&S->ln[l], (u32)__popcll(m));
+  });
+  __syncthreads();
+  if (stamp) p.stamps[21] = clock64();
+  // one wave per level: the bin in which the count from the top reaches K, and every bin's first slot (suffix sums)
+  if (wave < L) {
+    const u32 l = wave;
+    u32* h = hist + l * kTailBins;
+    u16* gs = gstart + l * kTailBins;
+    constexpr u32 BPL = kTailBins / 64;
+    u32 c[BPL], local = 0;
+#pragma unroll
+    for (u32 j = 0; j < BPL; ++j) {
+      c[j] = h[lane * BPL + j];
+      local += c[j];
+    }
+    u32 incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const u32 y = __shfl_down(incl, d);
+      if (lane + d < 64) incl += y;
+    }
+    const u32 excl = incl - local;  // keys in the bins above this lane's
+    const u32 nl = (u32)__builtin_amdgcn_readfirstlane((int)incl);
+    if (nl <= K) {
+      if (lane == 0) {
+        S->cutbin[l] = -1;
+        S->above[l] = nl;
+        S->nw[l] = nl;
+      }
+    } else if (excl < K && K <= incl) {  // exactly one lane
+      u32 acc = excl;
+      for (int j = (int)BPL - 1; j >= 0; --j) {
+        if (acc + c[j] >= K) {
+          S->cutbin[l] = (int)(lane * BPL + (u32)j);
+          S->above[l] = acc;
+          S->nw[l] = K;
+          S->generic[l] = c[j] > K ? 1u : 0u;
+          break;
+        }
+        acc += c[j];
+      }
+    }
+    u32 run = excl;
+#pragma unroll
+    for (int j = (int)BPL - 1; j >= 0; --j) {
+      h[lane * BPL + j] = run;  // cursor of the counting-sort scatter (meaningful for the bins above the boundary bin)
+      gs[lane * BPL + j] = (u16)(run < 0xffffu ? run : 0xffffu);
+      run += c[j];
+    }
+  }
+  __syncthreads();
+  // pass 2: scatter.  Bins above the boundary bin: next free slot of the bin's group; boundary bin: the boundary list.
+  for_each_key([&](u32 l, u64 key, bool have) {
+    if (!(have && key >= S->lb[l])) return;
+    const int bin = (int)tail_bin(key, hbase, hsh), cb = S->cutbin[l];
+    if (bin > cb) wkeys[l * K + atomicAdd(&hist[l * kTailBins + (u32)bin], 1u)] = key;
+    else if (bin == cb && !S->generic[l]) bkeys[l * K + atomicAdd(&S->bcnt[l], 1u)] = key;
+  });
+  __syncthreads();
+  if (stamp) p.stamps[22] = clock64();
+  // a boundary bin with more than K keys (heavy ties that the bound above did not remove, coarse bins): the
+  // (K - above)-th largest of ITS keys by adaptive radix select straight over the units' lists, then those >= it
+  for (u32 l = 0; l < L; ++l) {
+    if (!S->generic[l]) continue;  // workgroup-uniform
+    const u32 u0 = S->lv[l].unit_base, nu = S->lv[l].units, need = K - S->above[l];
+    const int cb = S->cutbin[l];
+    const u64 lbl = S->lb[l];
+    auto fetch = [&](u32 i) -> u64 {
+      const u32 u = u0 + i / K, j = i % K;
+      if (j >= ccnt[u]) return 0ull;
+      const u64 key = cand[(size_t)u * K + j];
+      return (key >= lbl && (int)tail_bin(key, hbase, hsh) == cb) ? key : 0ull;
+    };
+    const u64 T = wg_select_kth_f<NT>(fetch, nu * K, need, &S->ss);
+    for (u32 i = tid; i < nu * K; i += NT) {
+      const u64 key = fetch(i);
+      if (key != 0ull && key >= T) bkeys[l * K + atomicAdd(&S->bcnt[l], 1u)] = key;
+    }
+    __syncthreads();
+  }
+  // boundary lists: a key whose rank inside its list is below the level's remaining need is a winner -- at its FINAL slot
+  for (u32 f = tid; f < LK; f += NT) {
+    const u32 l = f / K, i = f - l * K, bc = S->bcnt[l];
+    if (i >= bc) continue;
+    const u64 me = bkeys[l * K + i];
+    u32 r = 0;
+    for (u32 j = 0; j < bc; ++j) r += bkeys[l * K + j] > me ? 1u : 0u;
+    const u32 ab = S->above[l];
+    if (ab + r < S->nw[l]) wkeys[l * K + ab + r] = me;
+  }
+  __syncthreads();
+  // groups of the bins above: one key -> it is in place; more (ties in score, coarse bins) -> rank inside the group.
+  // (wl shares its storage with the boundary lists: their last reader is behind the barrier above)
+  for (u32 f = tid; f < LK; f += NT) {
+    const u32 l = f / K, s = f - l * K;
+    if (s >= S->nw[l]) {  // a slot without a winner: fewer than K candidates in the level
+      wl[f] = 0ull;
+      continue;
+    }
+    const u64 key = wkeys[f];
+    u32 dst = s;
+    if (s < S->above[l]) {
+      const u32 bin = tail_bin(key, hbase, hsh);
+      const u32 g0 = gstart[l * kTailBins + bin], g1 = hist[l * kTailBins + bin];
+      if (g1 - g0 > 1u) {
+        u32 r = 0;
+        for (u32 j = g0; j < g1; ++j) r += wkeys[l * K + j] > key ? 1u : 0u;
+        dst = g0 + r;
+      }
+    }
+    wl[l * K + dst] = key;  // (the slots s < nw of a level are a permutation of themselves)
+  }
+  __syncthreads();
+  if (stamp) p.stamps[2] = clock64();
+
+  // ---- B2: decode of the winners -------------------------------------------------------------------------------------------
   float* mid_s = p.mid_scores ? p.mid_scores + (size_t)b * LK : nullptr;
   float4* mid_b = p.mid_boxes ? reinterpret_cast<float4*>(p.mid_boxes) + (size_t)b * LK : nullptr;
   float* mid_c = p.mid_classes ? p.mid_classes + (size_t)b * LK : nullptr;
-  u64* wl = sorted;  // work list of B2: wl[l*K + r] = the raw key of rank r in level l (0: no such candidate)
-  {
-    int steps = 1;  // binary-search steps that resolve a list of up to K keys
-    while ((1u << steps) <= K) ++steps;
-    for (u32 u = wave; u < upi; u += NW) {  // a unit per wave and trip: its surviving keys are its first uq[u]
-      u32 l = 0;
-      for (u32 v = 1; v < L; ++v)
-        if (u >= S->lv[v].unit_base) l = v;
-      const u32 u0 = S->lv[l].unit_base, nruns = S->lv[l].units, nq = uq[u];
-      // Only the surviving PREFIXES of the sibling lists can hold keys above one of ours (everything behind a prefix is
-      // below the level's bound, our keys are at or above it): the searches run over uq[], and not at all when no sibling
-      // has a prefix -- an all-equal image (the reference-init network: every score ties, the first list of a level IS
-      // its top K) then costs a wave 5 stores instead of 5 x nruns x 9 dependent LDS reads (36k -> 2k cycles).
-      u32 others = 0;
-      for (u32 v = u0; v < u0 + nruns; ++v) others += v != u ? uq[v] : 0u;  // wave-uniform
-      for (u32 i = lane; i < nq; i += 64) {
-        const u64 key = ukeys[(size_t)u * K + i];
-        u32 rank = i;
-        if (others) rank += count_greater_runs(ukeys + (size_t)u0 * K, K, uq + u0, 0, nruns, u - u0, key, steps);
-        if (rank < K) wl[l * K + rank] = key;
+  for (u32 pos = tid; pos < Mp; pos += NT) {
+    u64 nkey = 0ull;
+    if (pos < LK) {
+      const u64 key = wl[pos];
+      float s = 0.f, c = 0.f;
+      float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (key != 0ull) {
+        tail_decode_one(S->lv[pos / K], p.dtype, p.rescore, b, key_index(key), key_score(key), &s, &bx, &c);
+        rec_score[pos] = s;
+        rec_box[pos] = bx;
+        rec_cls[pos] = c;
+        nkey = (s > 0.0f) ? make_key(s, pos) : 0ull;  // box.py:496 (NaN drops out too)
+      }
+      if (mid_s) {
+        mid_s[pos] = s;
+        mid_b[pos] = bx;
+        mid_c[pos] = c;
       }
     }
-    // slots without a winner (fewer than K candidates in the level) and the padding up to Mp
-    for (u32 pos = tid; pos < Mp; pos += NT) {
-      bool empty = pos >= LK;
-      if (!empty) {
-        const u32 l = pos / K, r = pos - l * K;
-        u32 n = 0;
-        for (u32 v = S->lv[l].unit_base; v < S->lv[l].unit_base + S->lv[l].units; ++v) n += ucnt[v];
-        empty = r >= (n < K ? n : K);
-        if (empty && mid_s) {
-          mid_s[pos] = 0.0f;
-          mid_b[pos] = make_float4(0.f, 0.f, 0.f, 0.f);
-          mid_c[pos] = 0.0f;
-        }
-      }
-      if (empty) {
-        nkeys[pos] = 0ull;
-        wl[pos] = 0ull;
-      }
-    }
+    nkeys[pos] = nkey;
+    const u64 m = __ballot(nkey != 0ull);
+    if (lane == 0 && m) atomicAdd(&S->nvalid, (u32)__popcll(m));
   }
-  if (stamp) p.stamps[21] = clock64();
   __syncthreads();
-  if (stamp) p.stamps[22] = clock64();
-  // B2: one winner per thread and trip (the 4 delta loads of a thread's winners are independent of each other)
-  for (u32 pos = tid; pos < LK; pos += NT) {
-    const u64 key = wl[pos];
-    if (key == 0ull) continue;
-    const u32 l = pos / K;
-    float s, c;
-    float4 bx;
-    tail_decode_one(S->lv[l], p.dtype, p.rescore, b, key_index(key), key_score(key), &s, &bx, &c);
-    rec_score[pos] = s;
-    rec_box[pos] = bx;
-    rec_cls[pos] = c;
-    nkeys[pos] = (s > 0.0f) ? make_key(s, pos) : 0ull;  // box.py:496 (NaN drops out too)
-    if (mid_s) {
-      mid_s[pos] = s;
-      mid_b[pos] = bx;
-      mid_c[pos] = c;
-    }
-  }
-  if (stamp) p.stamps[2] = clock64();
-
-  // ---- C: order of the walk (box.py:505): wave-local sorted runs of 128 (ssdk_select.h), then ranks -- but only for
-  // the head of the order: the walk usually stops (ndet survivors) after a few hundred candidates, and a rank costs
-  // 8 random LDS reads per run.  With j = ceil(320 / runs), the runs that hold j candidates each have j keys >= their
-  // j-th: keys at or above the smallest of those j-th keys (a prefix of the order, whatever its length) are ranked
-  // now, the rest only if the walk ever gets there.
-  __syncthreads();  // phase B's stores
-  const u32 nruns_c = Mp >> 7;
   if (stamp) p.stamps[16] = clock64();
-  wg_sort_runs128<NT>(nkeys, nruns_c);
-  if (stamp) p.stamps[17] = clock64();
-  __syncthreads();
-  if (stamp) p.stamps[18] = clock64();
-  u64 head_bound = ~0ull;
-  {
-    u32 j = (320u + nruns_c - 1) / nruns_c;
-    j = j < 128u ? j : 128u;
-    u32 full = 0;  // runs that hold at least j candidates
-    for (u32 r = 0; r < nruns_c; ++r) {
-      const u64 kj = nkeys[r * 128 + j - 1];
-      if (kj != 0ull) {
-        ++full;
-        head_bound = kj < head_bound ? kj : head_bound;
-      }
-    }
-    if (full * j < 128u) head_bound = 1ull;  // too few candidates for a head: rank everything now
-  }
-  if (stamp) p.stamps[19] = clock64();
-  // the head candidates are a prefix of every sorted run: hp[r] = its length
-  if (tid < nruns_c) {
-    const u64* run = nkeys + tid * 128;
-    u32 lo = 0, hi = 128;
-    while (lo < hi) {
-      const u32 mid = (lo + hi) >> 1;
-      if (run[mid] >= head_bound && run[mid] != 0ull) lo = mid + 1;
-      else hi = mid;
-    }
-    S->hp[tid] = lo;
-  }
-  __syncthreads();
-  u32 nh = 0;
-  for (u32 r = 0; r < nruns_c; ++r) nh += S->hp[r];
-  const bool small_head = nh <= kHeadMax;
-  if (small_head) {
-    // gather them, sort the (at most 4) runs of 128 they fill, rank among those: 3 sibling runs instead of 15
-    const u32 hch = nh ? (nh + 127u) >> 7 : 1u;
-    for (u32 r = wave; r < nruns_c; r += NW) {  // run r's head keys go behind those of the runs before it
-      u32 off = 0;
-      for (u32 q2 = 0; q2 < r; ++q2) off += S->hp[q2];
-      const u32 n_r = S->hp[r];
-      for (u32 i = lane; i < n_r; i += 64) S->hk[off + i] = nkeys[r * 128 + i];
-    }
-    for (u32 t = nh + tid; t < hch * 128u; t += NT) S->hk[t] = 0ull;
-    __syncthreads();
-    wg_sort_runs128<NT>(S->hk, hch);
-    __syncthreads();
-    (void)wg_rank_emit<NT>(S->hk, hch, 1ull, ~0ull, [&](u32 rank, u64 key) { sorted[rank] = key; });
-  } else {
-    (void)wg_rank_emit<NT>(nkeys, nruns_c, head_bound, ~0ull, [&](u32 rank, u64 key) { sorted[rank] = key; });
-  }
-  {
-    if (stamp) p.stamps[20] = clock64();
-    u32 nz = 0;
-    for (u32 i = tid; i < Mp; i += NT) nz += nkeys[i] != 0ull ? 1u : 0u;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) nz += __shfl_xor(nz, d);
-    if (lane == 0 && nz) atomicAdd(&S->nvalid, nz);
-    if (tid == 0) S->nhead = nh;
-  }
-  __syncthreads();
-  const u32 nvalid = S->nvalid;
-  u32 nsorted = S->nhead;  // sorted[0 .. nsorted) is final
-  if (stamp) p.stamps[3] = clock64();
 
-  // ---- D: greedy walk, 64 candidates per block -------------------------------------------------------------------
+  // ---- C + D: lazy order of the walk, greedy walk ---------------------------------------------------------------------------
   float* os = p.out_scores + (size_t)b * ndet;
   float4* ob = reinterpret_cast<float4*>(p.out_boxes) + (size_t)b * ndet;
   float* oc = p.out_classes + (size_t)b * ndet;
   const float thr = p.thr;
   const int diou = p.diou;
+  u32 left = S->nvalid;
   u32 nk = 0;
-  for (u32 base = 0; base < nvalid && nk < ndet; base += 64) {  // workgroup-uniform
-    if (base + 64 > nsorted && nsorted < nvalid) {  // the walk outlived the ranked head: rank the rest (rare)
-      (void)wg_rank_emit<NT>(nkeys, nruns_c, 1ull, head_bound, [&](u32 rank, u64 key) { sorted[rank] = key; });
+  bool first = true;
+  while (left > 0 && nk < ndet) {  // workgroup-uniform
+    const u32 r = left < kRound ? left : kRound;
+    u64 T = 1ull;  // every remaining (non-zero) key
+    if (left > r) T = wg_select_kth<NT>(nkeys, Mp, r, &S->ss);  // r-th largest of the remaining keys (box.py:505)
+    if (stamp && first) p.stamps[17] = clock64();
+    if (tid == 0) S->topcnt = 0;
+    __syncthreads();
+    for (u32 i = tid; i < Mp; i += NT) {
+      const u64 k = nkeys[i];
+      if (k != 0ull && k >= T) {
+        top_u[atomicAdd(&S->topcnt, 1u)] = k;
+        nkeys[i] = 0ull;
+      }
+    }
+    __syncthreads();
+    {  // rank by counting: 4 threads per key, a quarter of the round each
+      const u32 i = tid >> 2, part = tid & 3u;
+      const u64 me = i < r ? top_u[i] : ~0ull;
+      u32 g = 0;
+      const u32 j1 = (part + 1u) * (kRound / 4) < r ? (part + 1u) * (kRound / 4) : r;
+      for (u32 j = part * (kRound / 4); j < j1; ++j) g += top_u[j] > me ? 1u : 0u;
+      g += __shfl_xor(g, 1);
+      g += __shfl_xor(g, 2);
+      if (part == 0 && i < r) sorted[g] = me;
+    }
+    __syncthreads();
+    if (stamp && first) p.stamps[3] = clock64();
+    first = false;
+    for (u32 base = 0; base < r && nk < ndet; base += 64) {  // workgroup-uniform
+      const u32 i = base + lane;
+      const bool valid = i < r;
+      float score = 0.f, cls = -1.f, area = 0.f;
+      float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) {
+        const u64 k = sorted[i];
+        const u32 pos = key_index(k);
+        score = key_score(k);
+        box = rec_box[pos];
+        cls = rec_cls[pos];
+        area = (box.z - box.x + 1.0f) * (box.w - box.y + 1.0f);  // box.py:507
+      }
+      bool alive = valid;
+      for (u32 k = wave; k < nk; k += NW) {
+        const float ck = kcls[k];
+        if (__ballot(alive && cls == ck) == 0ull) continue;
+        const bool sup = (cls == ck) && tail_suppressed_by(box, area, kbox[k], karea[k], thr, diou);
+        alive = alive && !sup;
+      }
+      const u64 dead = __ballot(valid && !alive);
+      if (lane == 0 && dead) atomicOr(&S->blk_dead, dead);
+      constexpr u32 PPW = 64 / NW;
+      for (u32 jj = 0; jj < PPW; ++jj) {
+        const u32 j = wave * PPW + jj;
+        const float cj = tail_bcast(cls, j);
+        const u64 m = __ballot(valid && lane > j && cls == cj);
+        u64 row = 0;
+        if (m != 0ull) {
+          float4 pj;
+          pj.x = tail_bcast(box.x, j);
+          pj.y = tail_bcast(box.y, j);
+          pj.z = tail_bcast(box.z, j);
+          pj.w = tail_bcast(box.w, j);
+          const float aj = tail_bcast(area, j);
+          row = __ballot(((m >> lane) & 1ull) && tail_suppressed_by(box, area, pj, aj, thr, diou));
+        }
+        if (lane == 0) S->rows[j] = row;
+      }
       __syncthreads();
-      nsorted = nvalid;
-    }
-    const u32 i = base + lane;
-    const bool valid = i < nvalid;
-    float score = 0.f, cls = -1.f, area = 0.f;
-    float4 box = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) {
-      const u64 k = sorted[i];
-      const u32 pos = key_index(k);
-      score = key_score(k);
-      box = rec_box[pos];
-      cls = rec_cls[pos];
-      area = (box.z - box.x + 1.0f) * (box.w - box.y + 1.0f);  // box.py:507
-    }
-    bool alive = valid;
-    for (u32 k = wave; k < nk; k += NW) {
-      const float ck = kcls[k];
-      if (__ballot(alive && cls == ck) == 0ull) continue;
-      const bool sup = (cls == ck) && tail_suppressed_by(box, area, kbox[k], karea[k], thr, diou);
-      alive = alive && !sup;
-    }
-    const u64 dead = __ballot(valid && !alive);
-    if (lane == 0 && dead) atomicOr(&S->blk_dead, dead);
-    constexpr u32 PPW = 64 / NW;
-    for (u32 jj = 0; jj < PPW; ++jj) {
-      const u32 j = wave * PPW + jj;
-      const float cj = tail_bcast(cls, j);
-      const u64 m = __ballot(valid && lane > j && cls == cj);
-      u64 row = 0;
-      if (m != 0ull) {
-        float4 pj;
-        pj.x = tail_bcast(box.x, j);
-        pj.y = tail_bcast(box.y, j);
-        pj.z = tail_bcast(box.z, j);
-        pj.w = tail_bcast(box.w, j);
-        const float aj = tail_bcast(area, j);
-        row = __ballot(((m >> lane) & 1ull) && tail_suppressed_by(box, area, pj, aj, thr, diou));
+      if (wave == 0) {
+        u64 am = __ballot(valid) & ~S->blk_dead;
+        const u64 myrow = S->rows[lane];
+        const u32 row_lo = (u32)myrow, row_hi = (u32)(myrow >> 32);
+        // In-order resolve on bitmasks: only pivots that are still alive AND suppress somebody need a step (a pivot
+        // without a row changes nothing).  The truncation to `ndet` survivors (box.py:512) commutes with it: whatever a
+        // pivot beyond the cut suppresses lies behind it, i.e. beyond the cut as well.
+        const u64 has_row = __ballot(myrow != 0ull);
+        u64 todo = am & has_row;
+        while (todo) {
+          const u32 j = (u32)__ffsll((long long)todo) - 1u;
+          const u64 rj = (u64)(u32)__builtin_amdgcn_readlane((int)row_lo, (int)j) |
+                         ((u64)(u32)__builtin_amdgcn_readlane((int)row_hi, (int)j) << 32);
+          am &= ~rj;
+          todo = am & has_row & ~((2ull << j) - 1ull);  // alive pivots with a row after j
+        }
+        if (nk + (u32)__popcll(am) > ndet) {  // keep the first ndet - nk alive candidates
+          const u32 room = ndet - nk;
+          const u64 over = __ballot(((am >> lane) & 1ull) && mbcnt(am) >= room);
+          am &= ~over;
+        }
+        const bool keep = (am >> lane) & 1ull;
+        const u32 slot = nk + mbcnt(am);
+        if (keep && slot < ndet) {
+          kbox[slot] = box;
+          karea[slot] = area;
+          kcls[slot] = cls;
+          os[slot] = score;
+          ob[slot] = box;
+          oc[slot] = cls;
+        }
+        u32 nk2 = nk + (u32)__popcll(am);
+        if (nk2 > ndet) nk2 = ndet;
+        if (lane == 0) {
+          S->nk = nk2;
+          S->blk_dead = 0ull;
+        }
       }
-      if (lane == 0) S->rows[j] = row;
+      __syncthreads();
+      nk = S->nk;
     }
-    __syncthreads();
-    if (wave == 0) {
-      u64 am = __ballot(valid) & ~S->blk_dead;
-      const u64 myrow = S->rows[lane];
-      const u32 row_lo = (u32)myrow, row_hi = (u32)(myrow >> 32);
-      // In-order resolve on bitmasks: only pivots that are still alive AND suppress somebody need a step (a pivot
-      // without a row changes nothing).  The truncation to `ndet` survivors (box.py:512) commutes with it: whatever a
-      // pivot beyond the cut suppresses lies behind it, i.e. beyond the cut as well.
-      const u64 has_row = __ballot(myrow != 0ull);
-      u64 todo = am & has_row;
-      while (todo) {
-        const u32 j = (u32)__ffsll((long long)todo) - 1u;
-        const u64 rj = (u64)(u32)__builtin_amdgcn_readlane((int)row_lo, (int)j) |
-                       ((u64)(u32)__builtin_amdgcn_readlane((int)row_hi, (int)j) << 32);
-        am &= ~rj;
-        todo = am & has_row & ~((2ull << j) - 1ull);  // alive pivots with a row after j
-      }
-      if (nk + (u32)__popcll(am) > ndet) {  // keep the first ndet - nk alive candidates
-        const u32 room = ndet - nk;
-        const u64 over = __ballot(((am >> lane) & 1ull) && mbcnt(am) >= room);
-        am &= ~over;
-      }
-      const bool keep = (am >> lane) & 1ull;
-      const u32 slot = nk + mbcnt(am);
-      if (keep && slot < ndet) {
-        kbox[slot] = box;
-        karea[slot] = area;
-        kcls[slot] = cls;
-        os[slot] = score;
-        ob[slot] = box;
-        oc[slot] = cls;
-      }
-      u32 nk2 = nk + (u32)__popcll(am);
-      if (nk2 > ndet) nk2 = ndet;
-      if (lane == 0) {
-        S->nk = nk2;
-        S->blk_dead = 0ull;
-      }
-    }
-    __syncthreads();
-    nk = S->nk;
+    left -= r;
   }
   if (stamp) p.stamps[4] = clock64();
 
-  // ---- E: zero padding (box.py:489-491) ------------------------------------------------------------------------
+  // ---- E: zero padding (box.py:489-491) ------------------------------------------------------------------------------------
   for (u32 i = nk + tid; i < ndet; i += NT) {
     os[i] = 0.f;
     ob[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -477,7 +586,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// host side (called from ssdk_decode_nms, ssdk_nms.hip)
+// host side (called from ssdk_decode_nms, ssdk_ctx.cpp)
 // ------------------------------------------------------------------------------------------------------------------
 constexpr size_t kTailLdsMax = 160 * 1024;
 
@@ -487,20 +596,21 @@ static u32 tail_pow2(u32 n) {
   return m;
 }
 
-// LDS bytes the fused tail needs for this geometry, or 0 when it cannot take it (then level_kernel + nms_kernel run)
-size_t tail_fits(u32 units_per_image, int K, int L, int ndet) {
-  if (K < 1 || L < 1 || ndet < 1) return 0;
+// LDS bytes the fused tail needs for this geometry, or 0 when it cannot take it (then level_kernel + nms_kernel run).
+// Independent of the number of scan units: their lists are read from the workspace, not staged.
+size_t tail_fits(int K, int L, int ndet) {
+  if (K < 1 || K > (int)(kRegKeys * 64) || L < 1 || L > SSDK_MAX_LEVELS || ndet < 1) return 0;
   const u32 M = tail_pow2((u32)(L * K));
   if (M > 4096) return 0;
-  const size_t need = tail_lds_bytes(units_per_image, (u32)K, (u32)L, M, (u32)ndet);
+  const size_t need = tail_lds_bytes((u32)K, (u32)L, M, (u32)ndet);
   return need <= kTailLdsMax ? need : 0;
 }
 
 int launch_tail(const ssdk_level* lv, int L, int B, int dtype, int K, int rescore, const u32* units, const u32* unit_base,
-                u32 units_per_image, const void* cand, const void* cand_cnt, float nms_thr, int ndet, int diou,
-                float* os, float* ob, float* oc, float* ms, float* mb, float* mc, unsigned long long* stamps,
-                hipStream_t stream) {
-  const size_t lds = tail_fits(units_per_image, K, L, ndet);
+                u32 units_per_image, const void* cand, const void* cand_cnt, u32 hist_base, u32 hist_sh, float nms_thr,
+                int ndet, int diou, float* os, float* ob, float* oc, float* ms, float* mb, float* mc,
+                unsigned long long* stamps, hipStream_t stream) {
+  const size_t lds = tail_fits(K, L, ndet);
   if (!lds) {
     set_error("decode_nms: geometry does not fit the fused tail kernel");
     return SSDK_E_BADARG;
@@ -528,6 +638,8 @@ int launch_tail(const ssdk_level* lv, int L, int B, int dtype, int K, int rescor
   p.units_per_image = units_per_image;
   p.K = (u32)K;
   p.M = tail_pow2((u32)(L * K));
+  p.hist_base = hist_base;
+  p.hist_sh = hist_sh;
   p.cand = (const u64*)cand;
   p.cand_cnt = (const u32*)cand_cnt;
   p.thr = nms_thr;
@@ -540,15 +652,12 @@ int launch_tail(const ssdk_level* lv, int L, int B, int dtype, int K, int rescor
   p.mid_boxes = mb;
   p.mid_classes = mc;
   p.stamps = stamps;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)kTailLdsMax) != hipSuccess) {
-      (void)hipGetLastError();
-      set_error("decode_nms: cannot raise the dynamic LDS limit of tail_kernel");
-      return SSDK_E_LAUNCH;
-    }
-    attr = true;
+  // (the attribute belongs to the current device's function object: set on every launch, like the other kernels do)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kTailLdsMax) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("decode_nms: cannot raise the dynamic LDS limit of tail_kernel");
+    return SSDK_E_LAUNCH;
   }
   lds_poison(stream);
   hipLaunchKernelGGL(tail_kernel, dim3((unsigned)B), dim3(kTailThreads), lds, stream, p);

@@ -620,3 +620,115 @@ def test_two_threads_two_decoders_share_nothing():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errors, errors
+
+
+def _decoder_vs_oracle(loc, conf, anchors, args, what, check_mid=True):
+    """decode_nms on device tensors against the numpy oracle on the same (upcast) values: per-level and final outputs."""
+    import torch
+    from ssds.modeling.layers.box import decode_nms
+
+    oanch = OrderedDict((k, v.numpy()) for k, v in anchors.items())
+    odec = O.Decoder(args[0], args[3], args[4], args[1], args[2], args[5])
+    ol, oc = [t.float().cpu().numpy() for t in loc], [t.float().cpu().numpy() for t in conf]
+    (s, b, c), mid = decode_nms(loc, conf, anchors, *args, return_mid=True)
+    if check_mid:
+        wm = odec.decode_levels(ol, oc, oanch)
+        np.testing.assert_array_equal(mid[2].cpu().numpy(), wm[2], err_msg=what + " mid classes")
+        np.testing.assert_allclose(mid[1].cpu().numpy(), wm[1], atol=BOX_ATOL, rtol=0, err_msg=what + " mid boxes")
+        np.testing.assert_allclose(mid[0].cpu().numpy(), wm[0], atol=1e-4, rtol=1e-4, equal_nan=True,
+                                   err_msg=what + " mid scores")
+    want = odec(ol, oc, oanch)
+    np.testing.assert_array_equal(c.cpu().numpy(), want[2], err_msg=what + " classes")
+    np.testing.assert_allclose(b.cpu().numpy(), want[1], atol=BOX_ATOL, rtol=0, err_msg=what + " boxes")
+    np.testing.assert_allclose(s.cpu().numpy(), want[0], atol=1e-4, rtol=1e-4, err_msg=what + " scores")
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("kind", ["nan_inf_negative", "misleading_sample", "all_equal", "two_values", "dense_above"])
+@pytest.mark.parametrize("tpu", ["0", "3", "40"])
+def test_scan16_special_values_ties_and_fallback(kind, dtype, tpu, monkeypatch):
+    """The 16-bit scan (ssdk_scan16.hip) compares bit patterns as signed 16-bit integers and trusts a sample of the unit
+    for its cut; everything that could break those two assumptions, against the oracle (box.py:435-446 semantics):
+      nan_inf_negative   NaNs (never pass `>= thr`, box.py:440), +inf (passes), negative scores and -0.0;
+      misleading_sample  the sample tiles hold nothing, every other tile is dense: the wave buffers overflow and the unit
+                         falls back to the exact TopK stream;
+      all_equal          one value everywhere (f16: in the middle of a histogram bin -> the in-bin refinement);
+      two_values         60 % of the scores at one value, the rest at a second, larger one in the LAST part of the map
+                         (ties at the cut in some units, nothing but ties above the cut in others);
+      dense_above        every score above the threshold and distinct per position (more candidates than any buffer)."""
+    import torch
+
+    tdt = getattr(torch, dtype)
+    monkeypatch.setenv("SSDK_TILES_PER_UNIT", tpu) if tpu != "0" else monkeypatch.delenv("SSDK_TILES_PER_UNIT", raising=False)
+    rs = np.random.RandomState(5)
+    A, C, B = 3, 40, 3
+    maps, strides = [(40, 48), (20, 24), (5, 6)], [8, 16, 64]
+    conf, loc = [], []
+    for h, w in maps:
+        n = A * C * h * w
+        base = cases.sigmoid(rs.standard_normal((B, n)).astype(F32) * F32(1.5) - F32(4.6))
+        if kind == "nan_inf_negative":
+            c = base.copy()
+            for bi in range(B):
+                idx = rs.choice(n, size=max(8, n // 50), replace=False)
+                vals = np.array([np.nan, np.inf, -np.inf, -0.0, -0.5, -3.0, 2.5, np.nan], F32)
+                c[bi, idx] = vals[np.arange(idx.size) % vals.size]
+            c[0, :4] = np.nan  # inside the first sample vector of the first unit
+        elif kind == "misleading_sample":
+            c = np.full((B, n), 0.001, F32)
+            tile = 256 * 8
+            t = np.arange(n) // tile
+            ntiles = (n + tile - 1) // tile
+            stride = max(ntiles // 8, 1)
+            dense = (t % stride != 0) | (t >= 8 * stride)  # (exact for a single unit; harmless otherwise)
+            c[:, dense] = (0.02 + 0.9 * rs.random_sample((B, int(dense.sum())))).astype(F32)
+        elif kind == "all_equal":
+            c = np.full((B, n), 0.3337, F32)
+        elif kind == "two_values":
+            c = np.full((B, n), 0.25, F32)
+            c[:, int(n * 0.6):] = 0.75
+        else:
+            c = (0.02 + 0.97 * rs.random_sample((B, n))).astype(F32)
+        conf.append(torch.from_numpy(c.reshape(B, A * C, h, w)).to(tdt).cuda())
+        loc.append(torch.from_numpy((rs.standard_normal((B, A * 4, h, w)) * 0.5).astype(F32)).to(tdt).cuda())
+    anchors = OrderedDict((s, torch.from_numpy(O.generate_anchors(s, [1, 2, 0.5], [2.0]))) for s in strides)
+    for args in ((0.01, 300, True, 0.6, 100, True), (0.05, 37, False, 0.5, 20, False), (0.2, 512, True, 0.6, 100, True)):
+        _decoder_vs_oracle(loc, conf, anchors, args, "%s %s tpu=%s K=%d" % (kind, dtype, tpu, args[1]))
+
+
+@pytest.mark.parametrize("tpu", ["1", "0"])
+def test_tail_generic_select_when_one_bin_holds_more_than_k_keys(tpu, monkeypatch):
+    """fp32 heads whose scores sit in a band narrower than one bin of the tail's per-level histogram (and differ from one
+    another): the boundary bin holds every candidate of every unit, far more than K -- the tail's adaptive radix select
+    over the units' lists decides (ssdk_tail.hip, `generic`), with many units per level (SSDK_TILES_PER_UNIT=1) and with
+    the planner's own unit size."""
+    import torch
+
+    monkeypatch.setenv("SSDK_TILES_PER_UNIT", tpu) if tpu != "0" else monkeypatch.delenv("SSDK_TILES_PER_UNIT", raising=False)
+    rs = np.random.RandomState(3)
+    A, C, B = 3, 20, 2
+    maps, strides = [(24, 28), (12, 14), (3, 4)], [8, 16, 64]
+    conf, loc = [], []
+    for h, w in maps:
+        n = A * C * h * w
+        c = (F32(0.5) + rs.permutation(n).astype(F32) * F32(2.0 ** -22))[None].repeat(B, 0)  # distinct, all inside one bin
+        c[1] = c[1][::-1]
+        conf.append(torch.from_numpy(np.ascontiguousarray(c).reshape(B, A * C, h, w)).cuda())
+        loc.append(torch.from_numpy((rs.standard_normal((B, A * 4, h, w)) * 0.5).astype(F32)).cuda())
+    anchors = OrderedDict((s, torch.from_numpy(O.generate_anchors(s, [1, 2, 0.5], [2.0]))) for s in strides)
+    for args in ((0.05, 100, True, 0.5, 60, True), (0.01, 300, False, 0.6, 100, True)):
+        _decoder_vs_oracle(loc, conf, anchors, args, "narrow band tpu=%s K=%d" % (tpu, args[1]))
+
+
+def test_sixteen_bit_heads_with_a_non_positive_threshold_take_the_generic_scan():
+    """thr <= 0 lets negative scores through, which the 16-bit integer compare cannot order: scan_kernel runs instead."""
+    import torch
+
+    rs = np.random.RandomState(8)
+    A, C, B, h, w = 3, 10, 2, 16, 20
+    c = (rs.standard_normal((B, A * C, h, w)) * 0.3).astype(F32)
+    conf = [torch.from_numpy(c).to(torch.bfloat16).cuda()]
+    loc = [torch.from_numpy((rs.standard_normal((B, A * 4, h, w)) * 0.5).astype(F32)).to(torch.bfloat16).cuda()]
+    anchors = OrderedDict([(8, torch.from_numpy(O.generate_anchors(8, [1, 2, 0.5], [2.0])))])
+    _decoder_vs_oracle(loc, conf, anchors, (-0.1, 100, False, 0.5, 50, True), "thr < 0")
+    _decoder_vs_oracle(loc, conf, anchors, (0.0, 100, False, 0.5, 50, True), "thr = 0")

@@ -44,14 +44,20 @@ def run(name, make, thr=0.01, reps=20):
     extra = ""
     if os.environ.get("SSDK_TAIL_STAMPS") and os.environ.get("SSDK_DECODE_FUSED", "1") != "0":
         st = ctx.tail_stamps()
-        extra = "\n      tail phases (kcycles): " + " ".join("%.1f" % ((b - a) / 1e3) for a, b in zip(st[:6], st[1:6]))
-        extra += "  [C: presort-wait %.1f sort %.1f barrier %.1f bound %.1f rank %.1f | B1 %.1f B1wait %.1f]" % tuple(
-            (b - a) / 1e3 for a, b in ((st[2], st[16]), (st[16], st[17]), (st[17], st[18]), (st[18], st[19]), (st[19], st[20]),
-                                       (st[1], st[21]), (st[21], st[22])))
+        d = lambda a, b: (st[b] - st[a]) / 1e3  # noqa: E731
+        extra = ("\n      tail (kcycles): A+bound %.1f | B1 hist %.1f cut+scatter %.1f resolve+order %.1f | B2 decode %.1f | "
+                 "C select %.1f rank %.1f | D walk %.1f | E %.1f  = %.1f" % (
+                     d(0, 1), d(1, 21), d(21, 22), d(22, 2), d(2, 16), d(16, 17), d(17, 3), d(3, 4), d(4, 5), d(0, 5)))
         sc = st[24:]
-        extra += "\n      scan wg0 (kcycles): " + " ".join("%.1f" % ((b - a) / 1e3) for a, b in zip(sc[0:5], sc[1:5]))
-        extra += "  fast=%d winners=%d  [H: sample %.1f sort %.1f rank %.1f rest %.1f]" % (
-            sc[5] >> 32, sc[5] & 0xffffffff, (sc[8] - sc[0]) / 1e3, (sc[9] - sc[8]) / 1e3, (sc[10] - sc[9]) / 1e3, (sc[1] - sc[10]) / 1e3)
+        e = lambda a, b: (sc[b] - sc[a]) / 1e3  # noqa: E731
+        if sc[11]:  # scan16_kernel
+            extra += ("\n      scan16 wg0 (kcycles): H top2 %.1f hist %.1f cut %.1f tie-prefix %.1f | stream %.1f | extract %.1f "
+                      "select %.1f = %.1f  fast=%d winners=%d" % (
+                          e(0, 8), e(8, 9), e(9, 10), e(10, 1), e(1, 2), e(2, 11), e(11, 3), e(0, 4), sc[5] >> 32,
+                          sc[5] & 0xffffffff))
+        else:
+            extra += "\n      scan wg0 (kcycles): " + " ".join("%.1f" % ((b - a) / 1e3) for a, b in zip(sc[0:5], sc[1:5]))
+            extra += "  fast=%d winners=%d" % (sc[5] >> 32, sc[5] & 0xffffffff)
     print("%-28s scan %6.1f us (%5.2f TB/s)  tail|level %5.1f us  nms %5.1f us  stage %6.1f us = %.3f of 8 TB/s%s" % (
         name, scan * 1e3, nbytes / scan / 1e9, lvl * 1e3, nms * 1e3, tot * 1e3, STAGE_BYTES / tot / 1e9 / 8000, extra),
         flush=True)
