@@ -170,11 +170,11 @@ extern "C" int ssdk_get_timings(int back, float* ms, int n) { return ssdk_ctx_ge
 // streamed, selected, end; out[13] = fast-path flag << 32 | winners).  Synchronises the device.
 extern "C" int ssdk_ctx_get_tail_stamps(ssdk_ctx* ctx, unsigned long long* out, int n) {
   if (int rc = ctx_enter(ctx)) return rc;
-  if (!ctx->stamps || !out || n < 48) {
+  if (!ctx->stamps || !out || n < 48 || n > kSsdkStampWords) {
     set_error("get_tail_stamps: no stamps (set SSDK_TAIL_STAMPS=1 before the first call)");
     return SSDK_E_BADARG;
   }
-  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, ctx->stamps, 48 * sizeof(*out), hipMemcpyDeviceToHost) != hipSuccess)
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, ctx->stamps, (size_t)n * sizeof(*out), hipMemcpyDeviceToHost) != hipSuccess)
     return SSDK_E_LAUNCH;
   return SSDK_OK;
 }
@@ -224,11 +224,11 @@ extern "C" int ssdk_decode_nms_ctx(ssdk_ctx* ctx, const ssdk_level* levels, int 
     return e && atoi(e) != 0;
   }();
   if (want_stamps && !ctx->stamps) {
-    if (hipMalloc((void**)&ctx->stamps, 48 * sizeof(unsigned long long)) != hipSuccess) {
+    if (hipMalloc((void**)&ctx->stamps, kSsdkStampWords * sizeof(unsigned long long)) != hipSuccess) {
       (void)hipGetLastError();
       ctx->stamps = nullptr;
     } else {
-      (void)hipMemset(ctx->stamps, 0, 48 * sizeof(unsigned long long));
+      (void)hipMemset(ctx->stamps, 0, kSsdkStampWords * sizeof(unsigned long long));
     }
   }
   if (prof && (rc = record(ev[0], main_s))) return rc;

@@ -9,6 +9,9 @@
 
 constexpr int kSsdkProfSlots = 256;
 constexpr int kSsdkMaxProfOps = 128;
+// debug stamps (SSDK_TAIL_STAMPS=1): [0, 24) tail_kernel phases of workgroup 0, [24, 48) scan kernel phases of workgroup 0,
+// [48, 48 + 2 * 4096) wall-clock (100 MHz) start / end of the first 4096 scan workgroups
+constexpr int kSsdkStampWords = 48 + 2 * 4096;
 
 struct ssdk_ctx {
   int device;
@@ -22,7 +25,7 @@ struct ssdk_ctx {
   hipEvent_t prof_ev[kSsdkProfSlots][4];
   bool prof_fused[kSsdkProfSlots];  // the slot's call ran scan + fused tail (two launches, three events)
   long long prof_calls;
-  unsigned long long* stamps;   // device, 8 words (SSDK_TAIL_STAMPS=1 only)
+  unsigned long long* stamps;   // device, kSsdkStampWords words (SSDK_TAIL_STAMPS=1 only)
   // ---- plan executor (ssdk_run_ops_ctx) ----
   int side_lane;                // -1: environment default (SSDK_SIDE_STREAM, on), 0 off, 1 on
   hipStream_t side;

@@ -172,6 +172,12 @@ struct ScanUnit {
     const u32 vi = vec0 + t * kScanThreads + tid;
     return (t < ntiles && vi <= vlast) ? vi * VEC - head : 0xffff0000u;
   }
+  // address of the lane's vector of tile t < ntiles as uniform base + 32-bit lane offset (the saddr form of global_load:
+  // no 64-bit per-lane arithmetic), clamped to the image's last vector
+  __device__ __forceinline__ const void* addr_in_unit(u32 t, u32 tid) const {
+    const u32 rel = t * kScanThreads + tid, rel_last = vlast - vec0;
+    return abase + (size_t)vec0 * 16 + (size_t)((rel < rel_last ? rel : rel_last) * 16u);
+  }
   // branch-free address: clamped to the unit's last tile and the image's last vector (what lies outside is masked by index)
   __device__ __forceinline__ const void* addr(u32 t, u32 tid) const {
     const u32 vi = vec0 + (t < ntiles ? t : ntiles - 1u) * kScanThreads + tid;

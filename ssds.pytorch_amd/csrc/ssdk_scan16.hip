@@ -28,7 +28,10 @@
 
 namespace ssdk {
 
-constexpr u32 kVc = 448;  // candidate vectors per wave buffer: 4 x 448 x (16 + 2) B = 32 256 B, the fallback's 32 KiB key buffer
+constexpr u32 kVq = 128;   // slots of a wave's circular queue of candidate vectors (a round of 64 is extracted as soon as it is full)
+constexpr u32 kSeg = 512;  // keys per wave segment of the key buffer
+// REG (template parameter of the kernel, SSDK_SCAN_REG = 8 | 16 | 32): tiles of a unit whose vectors are the SAMPLE and stay
+// in registers (4 VGPRs each); the rest of the unit streams through the LDS ring behind the cut
 
 struct S16Ctl {  // LDS
   u32 wcount[kScanThreads / 64];
@@ -38,14 +41,15 @@ struct S16Ctl {  // LDS
   u32 sub[32];
 };
 
-// LDS image: [X: kCap keys = 32 KiB | vbuf + ibuf][SelScratch][StreamCtl][S16Ctl][ring: waves x PF x 1 KiB | kbuf | sel]
+// LDS image: [X: kCap keys = 32 KiB of the fallback | kbuf 4 x 512 keys, tiebuf 512 keys, vq 4 x 128 x (16 + 2) B]
+//            [SelScratch][StreamCtl][S16Ctl][ring: waves x PF x 1 KiB | sel of the fallback]
 __host__ __device__ inline size_t scan16_fixed_bytes() {
   return ((size_t)kCap * 8 + sizeof(SelScratch) + sizeof(StreamCtl) + sizeof(S16Ctl) + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t scan16_lds_bytes(int pf) {
   return scan16_fixed_bytes() + (size_t)(kScanThreads / 64) * pf * 1024;  // (>= K keys of `sel`: K <= 512)
 }
-static_assert((size_t)(kScanThreads / 64) * kVc * 18 <= (size_t)kCap * 8, "vector buffers must fit the key buffer");
+static_assert((size_t)(kScanThreads / 64) * (kSeg * 8 + kVq * 18) + 512 * 8 <= (size_t)kCap * 8, "the fast path's buffers must fit the key buffer");
 
 __device__ __forceinline__ u32 pk_max_i16(u32 a, u32 b) {
   u32 r;
@@ -112,21 +116,16 @@ __device__ __forceinline__ bool any_ge(const u32x4& v, u32 cm1) {
   return pk_max_i16(mm, cm1) != cm1;
 }
 
-// the lanes whose vector passes append it (and its number inside the unit) to the wave's buffer, in lane order
-__device__ __forceinline__ void append_vec(const u32x4& v, bool pass, u32 lid, u32x4* vb, u16* ib, u32& wcnt, bool& ovf) {
+// the lanes whose vector passes append it (and its number inside the unit) to the wave's circular queue, in lane order
+__device__ __forceinline__ void append_vec(const u32x4& v, bool pass, u32 lid, u32x4* vq, u16* iq, u32& wcnt) {
   const u64 any = __ballot(pass);
   if (any == 0ull) return;
-  const u32 tot = (u32)__popcll(any);
-  if (wcnt + tot > kVc) {  // wave-uniform
-    ovf = true;
-    return;
-  }
   if (pass) {
-    const u32 pos = wcnt + mbcnt(any);
-    vb[pos] = v;
-    ib[pos] = (u16)lid;
+    const u32 pos = (wcnt + mbcnt(any)) & (kVq - 1u);
+    vq[pos] = v;
+    iq[pos] = (u16)lid;
   }
-  wcnt += tot;
+  wcnt += (u32)__popcll(any);
 }
 
 // K-th bin from the top of ss->hist (kHistBins bins): sc->cutbin / above / cb, or cutbin stays ~0 when fewer than K
@@ -155,22 +154,22 @@ __device__ __forceinline__ void hist_kth_bin(SelScratch* ss, S16Ctl* sc, u32 K) 
   __syncthreads();
 }
 
-template <int DT, int PF>
-__global__ __launch_bounds__(kScanThreads) void scan16_kernel(const ScanParams p) {
+template <int DT, int PF, int REG>
+__global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParams p) {
   constexpr int NT = kScanThreads;
   constexpr u32 NW = NT / 64;
+  constexpr u32 kReg = (u32)REG;
   constexpr u32 ULP_SH = DT == SSDK_BF16 ? 16u : 13u;  // ordered-fp32 bits below one ulp of the head's dtype
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* buf = reinterpret_cast<u64*>(smem);  // the fallback's key buffer; the fast path's vector buffers live on it
-  u32x4* vbuf = reinterpret_cast<u32x4*>(smem);
-  u16* ibuf = reinterpret_cast<u16*>(smem + (size_t)NW * kVc * 16);
+  u64* kbuf = reinterpret_cast<u64*>(smem);                                 // [NW][kSeg] extracted keys, one segment per wave
+  u64* tiebuf = kbuf + (size_t)NW * kSeg;                                   // [512] the unit's tie keys (tie-rich units)
+  u32x4* vqb = reinterpret_cast<u32x4*>(tiebuf + 512);                      // [NW][kVq] candidate vectors waiting for extraction
+  u16* iqb = reinterpret_cast<u16*>(smem + ((size_t)NW * kSeg + 512) * 8 + (size_t)NW * kVq * 16);  // [NW][kVq] their numbers
   SelScratch* ss = reinterpret_cast<SelScratch*>(buf + kCap);
   StreamCtl* ctl = reinterpret_cast<StreamCtl*>(ss + 1);
   S16Ctl* sc = reinterpret_cast<S16Ctl*>(ctl + 1);
   unsigned char* stage = smem + scan16_fixed_bytes();  // [wave][PF][1 KiB]
-  u64* kbuf = reinterpret_cast<u64*>(stage);           // extracted keys (once the ring has drained)
-  constexpr u32 kcap = NW * PF * 1024u / 8u;
-  u64* tiebuf = reinterpret_cast<u64*>(ss->hist);      // <= K <= 512 tie keys, parked while the ring is live
 
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u32 u = blockIdx.x / p.B;  // unit-major block order (see scan_kernel)
@@ -191,6 +190,8 @@ __global__ __launch_bounds__(kScanThreads) void scan16_kernel(const ScanParams p
   u32* out_cnt = p.cand_cnt + (size_t)b * p.units_per_image + u;
   const bool stamp = p.stamps != nullptr && blockIdx.x == 0 && tid == 0;
   if (stamp) p.stamps[0] = clock64();
+  const bool wall = p.stamps != nullptr && blockIdx.x < 4096u && tid == 0;  // (p.stamps = ctx stamps + 24: timeline at +24)
+  if (wall) p.stamps[24 + 2 * blockIdx.x] = wall_clock64();
   const u32 ntiles = U.ntiles;
   if (ntiles == 0) {  // (a plan never produces an empty unit; kept for forced unit sizes)
     for (u32 i = tid; i < K; i += NT) out[i] = 0ull;
@@ -198,12 +199,16 @@ __global__ __launch_bounds__(kScanThreads) void scan16_kernel(const ScanParams p
     return;
   }
 
-  // ---- sample tiles: S tiles spread over the unit, one 16-byte vector per lane and tile, kept in registers --------------
-  const u32 S = ntiles < kSample ? ntiles : kSample;
+  // ---- sample tiles: S <= REG tiles spread over the unit, one 16-byte vector per lane and tile, kept in registers: they
+  // give the cut (the K-th largest of the sample sits at rank ~K * tiles / S of the unit) and are filtered from the
+  // registers afterwards, so no byte is fetched twice; the other tiles stream through the LDS ring.
+  const u32 S = ntiles < kReg ? ntiles : kReg;
   const u32 sstride = ntiles / S;
-  u32x4 sv[kSample];
+  u32x4 sv[kReg];
 #pragma unroll
-  for (u32 i = 0; i < kSample; ++i) sv[i] = *reinterpret_cast<const u32x4*>(U.addr((i < S ? i : S - 1u) * sstride, tid));
+  for (u32 i = 0; i < kReg; ++i)
+    if (i < S) sv[i] = *reinterpret_cast<const u32x4*>(U.addr_in_unit(i * sstride, tid));  // wave-uniform predicate
+    else sv[i] = u32x4{0u, 0u, 0u, 0u};
 
   // ---- the stream's tiles: everything that is not a sample tile -----------------------------------------------------------
   // iterator over the non-sample tiles: (t, ns) = current tile, next sample tile at or after it (~0: none left)
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(kScanThreads) void scan16_kernel(const ScanParams p
   if (tid < 32) sc->sub[tid] = 0;
   u32 m1 = 0, m2 = 0;  // per 16-bit half-lane: largest / second largest pattern of its 4 x S sample scores
 #pragma unroll
-  for (u32 i = 0; i < kSample; ++i) {
+  for (u32 i = 0; i < kReg; ++i) {
     if (i < S) {  // wave-uniform
       const u32 idx0 = U.first_index<8>(i * sstride, tid);
       const bool full = (idx0 < n) & (idx0 + 7u < n);
@@ -247,17 +252,17 @@ __global__ __launch_bounds__(kScanThreads) void scan16_kernel(const ScanParams p
         m1 = pk_max_i16(m1, x);
         m2 = pk_max_i16(m2, lo);
       }
-    } else {
-      sv[i] = u32x4{0u, 0u, 0u, 0u};
     }
   }
   // the ring is primed here, behind the last use of the sample loads (the compiler waits for ALL outstanding loads before
   // it touches the first sample vector): the first stream tiles travel while the cut is computed
   unsigned char* ring = stage + (size_t)wave * PF * 1024;
+  if (M > 0u) {  // workgroup-uniform
 #pragma unroll
-  for (int i = 0; i < PF; ++i) {
-    ring_issue(U.addr(ti, tid), ring + i * 1024);  // (past the unit's last tile: that tile again, cache hits)
-    adv(ti, nsi);
+    for (int i = 0; i < PF; ++i) {
+      ring_issue(U.addr(ti, tid), ring + i * 1024);  // (past the unit's last tile: that tile again, cache hits)
+      adv(ti, nsi);
+    }
   }
   if (stamp) p.stamps[8] = clock64();
   const u32 inf16 = p.inf16, thr16 = p.thr16;
@@ -359,143 +364,167 @@ __global__ __launch_bounds__(kScanThreads) void scan16_kernel(const ScanParams p
   }
   if (stamp) p.stamps[1] = clock64();
 
-  // ---- filter: the sample vectors from their registers, then the stream -----------------------------------------------------
+  // ---- filter + extraction, interleaved.  A vector that holds a 16-bit pattern >= cut joins the wave's queue; as soon as
+  // 64 are waiting, the wave turns them into keys (one vector per lane, dense) in its own segment of the key buffer and
+  // counts them in the select histogram -- in the shadow of the ring's loads, which is where this wave would otherwise
+  // sit in s_waitcnt.  Tests of the reference there: value >= cut as a NUMBER (NaN never passes, box.py:440), index inside
+  // the image.  No cross-wave traffic, no barrier until the stream is over.
   const u32 cm1 = (ccut - 1u) | ((ccut - 1u) << 16);
-  u32x4* vb = vbuf + (size_t)wave * kVc;
-  u16* ib = ibuf + (size_t)wave * kVc;
-  u32 wcnt = 0;
+  for (u32 i = tid; i < kHistBins; i += NT) ss->hist[i] = 0;  // (phase H is done with it; the barrier is below)
+  u32x4* vq = vqb + (size_t)wave * kVq;
+  u16* iq = iqb + (size_t)wave * kVq;
+  u64* seg = kbuf + (size_t)wave * kSeg;
+  u32 wcnt = 0, xdone = 0, kc = 0;  // vectors queued / extracted, keys in the segment (wave-uniform)
   bool ovf = false;
+  auto extract = [&](u32 nround) {  // the next min(64, nround) queued vectors
+    const bool have = lane < nround;
+    const u32 slot = (xdone + lane) & (kVq - 1u);
+    const u32x4 v = vq[slot];
+    const u32 idx0 = (U.vec0 + (u32)iq[slot]) * 8u - U.head;
+    xdone += nround < 64u ? nround : 64u;
+    u32 pm = 0;  // elements that pass
 #pragma unroll
-  for (u32 i = 0; i < kSample; ++i)
-    if (i < S && !ovf) append_vec(sv[i], any_ge(sv[i], cm1), i * sstride * NT + tid, vb, ib, wcnt, ovf);
-  for (u32 q0 = 0; q0 < M; q0 += PF) {
-#pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      const u32x4 v = ring_take<PF - 1>(ring + i * 1024 + lane * 16);  // the oldest of the PF requests has landed
-      ring_issue(U.addr(ti, tid), ring + i * 1024);
-      adv(ti, nsi);
-      if (q0 + (u32)i < M) {  // wave-uniform (the last round of a unit runs its surplus slots masked)
-        const u32 lid = tc * NT + tid;
-        adv(tc, nsc);
-        // a lane behind the image's last vector re-read that vector (clamped address): it must not count twice
-        if (!ovf) append_vec(v, any_ge(v, cm1) & (U.vec0 + lid <= U.vlast), lid, vb, ib, wcnt, ovf);
+    for (int d = 0; d < 4; ++d) {
+      const u32 w16 = v[d];
+      if (pk_max_i16(w16, cm1) != cm1) {  // one of the two halves is >= cut: the exact tests on both
+        const u32 lo = w16 & 0xffffu, hi = w16 >> 16;
+        pm |= (((int)(short)(u16)lo >= (int)ccut) & (lo <= inf16) & (idx0 + 2u * d < n)) ? (1u << (2 * d)) : 0u;
+        pm |= (((int)(short)(u16)hi >= (int)ccut) & (hi <= inf16) & (idx0 + 2u * d + 1u < n)) ? (2u << (2 * d)) : 0u;
       }
     }
-  }
-  ring_drain();
-  if (lane == 0) {
-    sc->wcount[wave] = wcnt;
-    if (ovf) sc->ovf = 1u;
-  }
-  // the tie keys leave the histogram's storage before it is used again
-  u64 tk0 = 0, tk1 = 0;
-  if (tid < ntie) tk0 = tiebuf[tid];
-  if (tid + NT < ntie) tk1 = tiebuf[tid + NT];
-  __syncthreads();
-  if (stamp) p.stamps[2] = clock64();
-
-  u32 cnt = 0;
-  bool done = false;
-  if ((sc->ovf | sc->nan) == 0u) {
-    // ---- extraction: keys of the buffered vectors' elements that pass, with the reference's tests ---------------------
-    for (u32 i = tid; i < kHistBins; i += NT) ss->hist[i] = 0;
-    if (tid < ntie) kbuf[tid] = tk0;
-    if (tid + NT < ntie) kbuf[tid + NT] = tk1;
-    if (tid == 0) sc->kcnt = ntie;
-    __syncthreads();
-    if (tid == 0 && ntie) atomicAdd(&ss->hist[hist_bin(ord_of16<DT>(cut16), p.hist_base, p.hist_sh)], ntie);
-    u32 wc[NW], TV = 0;
-#pragma unroll
-    for (u32 w = 0; w < NW; ++w) {
-      wc[w] = sc->wcount[w];
-      TV += wc[w];
-    }
-    for (u32 j0 = 0; j0 < TV; j0 += NT) {  // workgroup-uniform trip count
-      const u32 j = j0 + tid;
-      const bool have = j < TV;
-      u32 w = 0, pos = j;
-#pragma unroll
-      for (u32 q = 0; q + 1 < NW; ++q)
-        if (w == q && pos >= wc[q]) {
-          pos -= wc[q];
-          w = q + 1;
-        }
-      const u32 slot = have ? w * kVc + pos : 0u;
-      const u32x4 v = vbuf[slot];
-      const u32 idx0 = (U.vec0 + (u32)ibuf[slot]) * 8u - U.head;
-      u32 pm = 0;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const u32 h = half_of(v, e);
-        const bool ok = ((int)(short)(u16)h >= (int)ccut) & (h <= inf16) & (idx0 + (u32)e < n);
-        pm |= (have && ok) ? (1u << e) : 0u;
-      }
-      const u32 c = (u32)__popc(pm);
-      u32 excl = 0, tot = 0;
+    pm = have ? pm : 0u;
+    const u32 c = (u32)__popc(pm);
+    const u64 any = __ballot(c != 0u);
+    if (any == 0ull) return;
+    u32 excl, tot;
+    if (__ballot(c > 1u) == 0ull) {  // the usual case: one candidate per vector
+      excl = mbcnt(any);
+      tot = (u32)__popcll(any);
+    } else {
+      excl = 0;
+      tot = 0;
 #pragma unroll
       for (int bit = 0; bit < 4; ++bit) {
         const u64 mb = __ballot((c >> bit) & 1u);
         excl += mbcnt(mb) << bit;
         tot += (u32)__popcll(mb) << bit;
       }
-      if (tot == 0u) continue;  // wave-uniform
-      u32 base = 0;
-      if (lane == 0) base = atomicAdd(&sc->kcnt, tot);
-      base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-      if (base + tot > kcap) {  // wave-uniform: more candidates than the key buffer holds
-        if (lane == 0) sc->ovf = 1u;
-        continue;
-      }
-      u32 at = base + excl, left = pm;
-      while (left) {
-        const u32 e = (u32)__ffs((int)left) - 1u;
-        left &= left - 1u;
-        const u32 w16 = e < 2u ? v[0] : (e < 4u ? v[1] : (e < 6u ? v[2] : v[3]));
-        const u32 h = (e & 1u) ? (w16 >> 16) : (w16 & 0xffffu);
-        const u32 o = ord_of16<DT>(h);
-        kbuf[at++] = ((u64)o << 32) | (u64)(~(idx0 + e));
-        atomicAdd(&ss->hist[hist_bin(o, p.hist_base, p.hist_sh)], 1u);
-      }
     }
-    __syncthreads();
+    if (kc + tot > kSeg) {  // wave-uniform: more candidates than the segment holds (a misleading sample)
+      ovf = true;
+      return;
+    }
+    u32 at = kc + excl, left = pm;
+    while (left) {
+      const u32 e = (u32)__ffs((int)left) - 1u;
+      left &= left - 1u;
+      const u32 w16 = e < 2u ? v[0] : (e < 4u ? v[1] : (e < 6u ? v[2] : v[3]));
+      const u32 h = (e & 1u) ? (w16 >> 16) : (w16 & 0xffffu);
+      const u32 o = ord_of16<DT>(h);
+      seg[at++] = ((u64)o << 32) | (u64)(~(idx0 + e));
+      atomicAdd(&ss->hist[hist_bin(o, p.hist_base, p.hist_sh)], 1u);
+    }
+    kc += tot;
+  };
+  lds_barrier();  // histogram zeroed (and, in a tie-rich unit, the tie keys written)
+  if (tid == 0 && ntie) atomicAdd(&ss->hist[hist_bin(ord_of16<DT>(cut16), p.hist_base, p.hist_sh)], ntie);
+#pragma unroll
+  for (u32 i = 0; i < kReg; ++i)
+    if (i < S && !ovf) {  // wave-uniform
+      append_vec(sv[i], any_ge(sv[i], cm1), i * sstride * NT + tid, vq, iq, wcnt);
+      if (wcnt - xdone >= 64u) extract(64u);
+    }
+  for (u32 q = 0; q < M; ++q) {
+    unsigned char* slot = ring + (size_t)(q & (u32)(PF - 1)) * 1024;
+    const u32x4 v = ring_take<PF - 1>(slot + lane * 16);  // the oldest of the PF requests has landed
+    ring_issue(U.addr(ti, tid), slot);                    // (past the unit's last tile: that tile again, cache hits)
+    adv(ti, nsi);
+    const u32 lid = tc * NT + tid;
+    adv(tc, nsc);
+    if (ovf) continue;
+    // a lane behind the image's last vector re-read that vector (clamped address): it must not count twice
+    append_vec(v, any_ge(v, cm1) & (U.vec0 + lid <= U.vlast), lid, vq, iq, wcnt);
+    if (wcnt - xdone >= 64u) extract(64u);
+  }
+  if (M > 0u) ring_drain();
+  while (!ovf && xdone < wcnt) extract(wcnt - xdone);  // (at most two trips)
+  if (lane == 0) {
+    sc->wcount[wave] = kc;
+    if (ovf) sc->ovf = 1u;
+  }
+  __syncthreads();
+  if (stamp) p.stamps[2] = clock64();
+
+  u32 cnt = 0;
+  bool done = false;
+  if ((sc->ovf | sc->nan) == 0u) {
     if (stamp) p.stamps[11] = clock64();
-    if (sc->ovf == 0u) {
-      // ---- select: exact top-K of the extracted keys, unordered, straight to the workspace --------------------------
-      const u32 nk = sc->kcnt;
-      if (nk <= K) {
-        for (u32 i = tid; i < nk; i += NT) out[i] = kbuf[i];
-        cnt = nk;
-      } else {
-        if (tid == 0) sc->cutbin = ~0u;
-        __syncthreads();
-        hist_kth_bin(ss, sc, K);
-        const u32 cbin = sc->cutbin, above = sc->above, cb = sc->cb, need = K - above;
-        if (cb > 512u) {  // heavy ties inside one bin: the generic exact select
-          const u64 T = wg_select_kth<NT>(kbuf, nk, K, ss);
-          for (u32 i = tid; i < nk; i += NT) {
-            const u64 k = kbuf[i];
-            if (k >= T) out[atomicAdd(&sc->ocnt, 1u)] = k;
-          }
-        } else {
-          u64* small = reinterpret_cast<u64*>(ss->hist);  // (the histogram has been read: cb <= 512 keys fit)
-          for (u32 i = tid; i < nk; i += NT) {
-            const u64 k = kbuf[i];
-            const u32 kb = hist_bin((u32)(k >> 32), p.hist_base, p.hist_sh);
-            if (kb > cbin) out[atomicAdd(&sc->ocnt, 1u)] = k;
-            else if (kb == cbin) small[atomicAdd(&sc->scnt, 1u)] = k;
-          }
-          __syncthreads();
-          for (u32 t = tid; t < cb; t += NT) {
-            const u64 me = small[t];
-            u32 r = 0;
-            for (u32 j = 0; j < cb; ++j) r += small[j] > me ? 1u : 0u;
-            if (r < need) out[above + r] = me;
-          }
-        }
-        cnt = K;
-      }
-      done = true;
+    // ---- select: exact top-K of the extracted keys (+ the tie keys), unordered, straight to the workspace ----------
+    u32 nk = ntie, before = 0;
+#pragma unroll
+    for (u32 w = 0; w < NW; ++w) {
+      const u32 cw = sc->wcount[w];
+      before += w < wave ? cw : 0u;
+      nk += cw;
     }
+    if (nk <= K) {
+      for (u32 i = lane; i < kc; i += 64) out[before + i] = seg[i];
+      for (u32 i = tid; i < ntie; i += NT) out[nk - ntie + i] = tiebuf[i];
+      cnt = nk;
+    } else {
+      if (tid == 0) sc->cutbin = ~0u;
+      __syncthreads();
+      hist_kth_bin(ss, sc, K);
+      const u32 cbin = sc->cutbin, above = sc->above, cb = sc->cb, need = K - above;
+      if (cb > 512u) {  // heavy ties inside one bin: the generic exact select over one contiguous array (rare)
+        // segments compacted in place, wave by wave (registers in between), the tie keys behind them
+        u32 off = sc->wcount[0];
+        for (u32 w = 1; w <= NW; ++w) {
+          const u32 cw = w < NW ? sc->wcount[w] : ntie;
+          const u64* src = w < NW ? kbuf + (size_t)w * kSeg : tiebuf;
+          u64 t0 = 0, t1 = 0;
+          if (tid < cw) t0 = src[tid];
+          if (tid + NT < cw) t1 = src[tid + NT];
+          __syncthreads();
+          if (tid < cw) kbuf[off + tid] = t0;
+          if (tid + NT < cw) kbuf[off + tid + NT] = t1;
+          __syncthreads();
+          off += cw;
+        }
+        const u64 T = wg_select_kth<NT>(kbuf, nk, K, ss);
+        for (u32 i = tid; i < nk; i += NT) {
+          const u64 k = kbuf[i];
+          if (k >= T) out[atomicAdd(&sc->ocnt, 1u)] = k;
+        }
+      } else {
+        u64* small = reinterpret_cast<u64*>(ss->hist);  // (the histogram has been read: cb <= 512 keys fit)
+        auto classify = [&](u64 k, bool have) {  // all lanes of the wave
+          const u32 kb = hist_bin((u32)(k >> 32), p.hist_base, p.hist_sh);
+          const bool win = have && kb > cbin, edge = have && kb == cbin;
+          const u64 mw = __ballot(win), me = __ballot(edge);
+          u32 bw = 0, be = 0;
+          if (lane == 0) {
+            if (mw) bw = atomicAdd(&sc->ocnt, (u32)__popcll(mw));
+            if (me) be = atomicAdd(&sc->scnt, (u32)__popcll(me));
+          }
+          bw = (u32)__builtin_amdgcn_readfirstlane((int)bw);
+          be = (u32)__builtin_amdgcn_readfirstlane((int)be);
+          if (win) out[bw + mbcnt(mw)] = k;
+          if (edge) small[be + mbcnt(me)] = k;
+        };
+        for (u32 i0 = 0; i0 < kc; i0 += 64) classify(i0 + lane < kc ? seg[i0 + lane] : 0ull, i0 + lane < kc);
+        for (u32 i0 = 0; i0 < ntie; i0 += NT) classify(i0 + tid < ntie ? tiebuf[i0 + tid] : 0ull, i0 + tid < ntie);
+        __syncthreads();
+        for (u32 t = tid; t < cb; t += NT) {
+          const u64 me = small[t];
+          u32 r = 0;
+          for (u32 j = 0; j < cb; ++j) r += small[j] > me ? 1u : 0u;
+          if (r < need) out[above + r] = me;
+        }
+      }
+      cnt = K;
+    }
+    done = true;
   }
   if (!done) {
     // ---- the exact TopK stream over the whole unit (a misleading sample, NaNs, adversarial inputs) ----------------------
@@ -506,6 +535,7 @@ __global__ __launch_bounds__(kScanThreads) void scan16_kernel(const ScanParams p
   }
   for (u32 i = cnt + tid; i < K; i += NT) out[i] = 0ull;
   if (tid == 0) *out_cnt = cnt;
+  if (wall) p.stamps[24 + 2 * blockIdx.x + 1] = wall_clock64();
   if (stamp) {
     p.stamps[3] = clock64();
     p.stamps[4] = clock64();
@@ -550,11 +580,18 @@ bool scan16_applies(int dtype, float thr, int K) {
   return env != 0 && (dtype == SSDK_BF16 || dtype == SSDK_F16) && thr > 0.0f && thr == thr && K >= 1 && K <= 512;
 }
 
-// tiles per unit above which the per-wave vector buffers are expected to overflow: a unit of T tiles keeps about
-// K * T / kSample vectors (the sample's K-th value sits at rank ~K * T / 8 of the unit); 3/4 of the four buffers
+static int scan16_reg() {
+  const char* e = getenv("SSDK_SCAN_REG");
+  const int r = (e && *e) ? atoi(e) : 8;
+  return r == 32 ? 32 : (r == 16 ? 16 : 8);
+}
+
+// tiles per unit above which the per-wave key segments are expected to overflow: a unit of T tiles extracts about
+// K * max(T / REG, 1.1) keys (the sample's K-th value sits at rank ~K * T / REG of the unit); 3/4 of the four segments.
+// (<= 255: a vector's number inside the unit is stored in 16 bits.)
 u32 scan16_max_tiles_per_unit(int K) {
-  const u32 t = (u32)(3ull * (kScanThreads / 64) * kVc * kSample / 4ull / (unsigned)K);
-  return t < 4u ? 4u : (t > 255u ? 255u : t);  // (<= 255: a vector's number inside the unit is stored in 16 bits)
+  const u32 t = (u32)(3ull * (kScanThreads / 64) * kSeg * (unsigned)scan16_reg() / 4ull / (unsigned)K);
+  return t < 4u ? 4u : (t > 255u ? 255u : t);
 }
 
 int launch_scan16(const ScanParams& sp, int dtype, int B, u32 units_per_image, hipStream_t stream) {
@@ -565,13 +602,22 @@ int launch_scan16(const ScanParams& sp, int dtype, int B, u32 units_per_image, h
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(kScanThreads), lds, stream, sp);
   };
-  if (pf == 8) {
-    if (dtype == SSDK_BF16) go(scan16_kernel<SSDK_BF16, 8>);
-    else go(scan16_kernel<SSDK_F16, 8>);
-  } else {
-    if (dtype == SSDK_BF16) go(scan16_kernel<SSDK_BF16, 4>);
-    else go(scan16_kernel<SSDK_F16, 4>);
-  }
+  const int reg = scan16_reg();
+#define SSDK_S16(DT_)                                      \
+  do {                                                     \
+    if (pf == 8) {                                         \
+      if (reg == 32) go(scan16_kernel<DT_, 8, 32>);        \
+      else if (reg == 16) go(scan16_kernel<DT_, 8, 16>);   \
+      else go(scan16_kernel<DT_, 8, 8>);                   \
+    } else {                                               \
+      if (reg == 32) go(scan16_kernel<DT_, 4, 32>);        \
+      else if (reg == 16) go(scan16_kernel<DT_, 4, 16>);   \
+      else go(scan16_kernel<DT_, 4, 8>);                   \
+    }                                                      \
+  } while (0)
+  if (dtype == SSDK_BF16) SSDK_S16(SSDK_BF16);
+  else SSDK_S16(SSDK_F16);
+#undef SSDK_S16
   return check_launch("scan16_kernel");
 }
 

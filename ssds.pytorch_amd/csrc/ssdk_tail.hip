@@ -27,7 +27,10 @@
 namespace ssdk {
 
 constexpr int kTailThreads = 1024;
-constexpr u32 kRound = 256;      // candidates ordered + walked per NMS round
+constexpr u32 kRound = 256;      // candidates ordered + walked per NMS round (target; a round takes whole score bins)
+constexpr u32 kRoundMax = 512;   // ... and at most this many
+constexpr u32 kCBins = 2048;     // score bins of the walk order (C): one per bf16 value from 2^-11 up to 32
+constexpr u32 kCBase = 0xba00u;  // ord(score) >> 16 of 2^-11
 constexpr u32 kTailBins = 1024;  // score bins per level (B1)
 constexpr u32 kRegKeys = 8;      // keys per lane of a wave's first unit kept in registers (K <= 512)
 
@@ -35,6 +38,7 @@ struct TailLevel {
   const void* box;
   int A, C, H, W, stride;
   u32 units, unit_base, pad;
+  u32 mW, mH, mC, pad2;  // floor(2^32 / d): quotient by multiply-high + one correction (tail_divmod)
   float anchors[SSDK_MAX_ANCHORS * 4];
 };
 struct TailParams {
@@ -58,13 +62,26 @@ struct TailParams {
 
 // shared with level_kernel / nms_kernel (ssdk_decode.hip / ssdk_nms.hip); restated here because those live in other
 // translation units as static inline device code
+// q = n / d, r = n % d with m = floor(2^32 / d) (d >= 1; d = 1 is passed as m = 0xffffffff): the multiply-high
+// under-estimates the quotient by at most one
+__device__ __forceinline__ u32 tail_divmod(u32 n, u32 d, u32 m, u32* r) {
+  u32 q = __umulhi(n, m);
+  u32 rem = n - q * d;
+  if (rem >= d) {
+    ++q;
+    rem -= d;
+  }
+  *r = rem;
+  return q;
+}
+
 __device__ __forceinline__ void tail_decode_one(const TailLevel& d, int dtype, int rescore, u32 b, u32 idx, float score,
                                                 float* o_score, float4* o_box, float* o_cls) {
   const u32 W = d.W, H = d.H, C = d.C;
-  const u32 x = idx % W;
-  const u32 y = (idx / W) % H;
-  const u32 c = (idx / W / H) % C;   // box.py:448
-  const u32 a = idx / C / H / W;     // box.py:454
+  u32 x, y, c;
+  const u32 t1 = tail_divmod(idx, W, d.mW, &x);   // x = idx % W
+  const u32 t2 = tail_divmod(t1, H, d.mH, &y);    // y = (idx / W) % H
+  const u32 a = tail_divmod(t2, C, d.mC, &c);     // c = (idx / W / H) % C (box.py:448), a = idx / C / H / W (box.py:454)
   const size_t hw = (size_t)H * W;
   const size_t boff = ((size_t)b * d.A * 4 + (size_t)a * 4) * hw + (size_t)y * W + x;
   const float d0 = load_as_f32(d.box, boff, dtype);
@@ -140,6 +157,7 @@ struct alignas(16) TailLds {  // fixed-size part of the LDS image (the arrays fo
   u64 blk_dead;
   u64 lb[SSDK_MAX_LEVELS];      // per level: a lower bound of its K-th key (largest minimum of its FULL unit lists)
   u32 nvalid, nk, topcnt, pad0;
+  u32 ccut, chead, cpad0, cpad1;  // C: lowest bin of the round, keys in it and above
   int cutbin[SSDK_MAX_LEVELS];  // -1: the level offers <= K keys, every one is a winner
   u32 ln[SSDK_MAX_LEVELS];      // keys the level's units offer (at or above lb)
   u32 above[SSDK_MAX_LEVELS];   // winners in the bins above the boundary bin
@@ -150,7 +168,7 @@ struct alignas(16) TailLds {  // fixed-size part of the LDS image (the arrays fo
 };
 
 __host__ __device__ inline size_t tail_r1_bytes(u32 L, u32 M) {  // histograms of B1, later the NMS keys + one round
-  const size_t a = (size_t)L * kTailBins * 4, b = (size_t)(M < 128u ? 128u : M) * 8 + 2 * (size_t)kRound * 8;
+  const size_t a = (size_t)L * kTailBins * 4, b = (size_t)(M < 128u ? 128u : M) * 8 + (size_t)kCBins * 4 + 2 * (size_t)kRoundMax * 8;
   return ((a > b ? a : b) + 15) & ~(size_t)15;
 }
 __host__ __device__ inline size_t tail_lds_bytes(u32 K, u32 L, u32 M, u32 ndet) {
@@ -175,8 +193,9 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
   unsigned char* q = smem + sizeof(TailLds);
   u32* hist = reinterpret_cast<u32*>(q);                    // [L][kTailBins]   (B1)
   u64* nkeys = reinterpret_cast<u64*>(q);                   // [Mp]             (B2 .. D, on top of the histograms)
-  u64* top_u = nkeys + Mp;                                  // [kRound] the round's keys, unordered
-  u64* sorted = top_u + kRound;                             // [kRound] ... in walk order
+  u32* chist = reinterpret_cast<u32*>(nkeys + Mp);          // [kCBins] score bins of the walk order (C)
+  u64* top_u = reinterpret_cast<u64*>(chist + kCBins);      // [kRoundMax] the round's keys, unordered
+  u64* sorted = top_u + kRoundMax;                          // [kRoundMax] ... in walk order
   q += tail_r1_bytes(L, M);
   u16* gstart = reinterpret_cast<u16*>(q);                  // [L][kTailBins] first slot of a bin's group
   q += (size_t)L * kTailBins * 2;
@@ -464,28 +483,97 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
   u32 nk = 0;
   bool first = true;
   while (left > 0 && nk < ndet) {  // workgroup-uniform
-    const u32 r = left < kRound ? left : kRound;
-    u64 T = 1ull;  // every remaining (non-zero) key
-    if (left > r) T = wg_select_kth<NT>(nkeys, Mp, r, &S->ss);  // r-th largest of the remaining keys (box.py:505)
-    if (stamp && first) p.stamps[17] = clock64();
-    if (tid == 0) S->topcnt = 0;
+    // The round = the candidates of the highest score bins that together hold >= min(256, left) keys: one histogram pass
+    // (one bin per bf16 value: with tie-free scores the boundary bin adds a handful of keys) instead of an exact select.
+    // More than 512 that way (massive ties in the rescored scores) -> the exact 256 by adaptive radix select.
+    for (u32 i = tid; i < kCBins; i += NT) chist[i] = 0;
     __syncthreads();
+    auto cbin_of = [&](u64 k) -> u32 {
+      const u32 o = (u32)(k >> 48);
+      const u32 bin = o < kCBase ? 0u : o - kCBase;
+      return bin < kCBins - 1 ? bin : kCBins - 1;
+    };
     for (u32 i = tid; i < Mp; i += NT) {
       const u64 k = nkeys[i];
-      if (k != 0ull && k >= T) {
-        top_u[atomicAdd(&S->topcnt, 1u)] = k;
-        nkeys[i] = 0ull;
-      }
+      if (k != 0ull) atomicAdd(&chist[cbin_of(k)], 1u);
     }
     __syncthreads();
-    {  // rank by counting: 4 threads per key, a quarter of the round each
-      const u32 i = tid >> 2, part = tid & 3u;
+    const u32 want = left < kRound ? left : kRound;
+    if (wave == 0) {
+      constexpr u32 BPL = kCBins / 64;
+      u32 local = 0;
+      u32 c[BPL];
+#pragma unroll
+      for (u32 j = 0; j < BPL; j += 4) {
+        const u32x4 q4 = *reinterpret_cast<const u32x4*>(&chist[lane * BPL + j]);
+        c[j] = q4[0];
+        c[j + 1] = q4[1];
+        c[j + 2] = q4[2];
+        c[j + 3] = q4[3];
+        local += q4[0] + q4[1] + q4[2] + q4[3];
+      }
+      u32 incl = local;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const u32 y = __shfl_down(incl, d);
+        if (lane + d < 64) incl += y;
+      }
+      const u32 excl = incl - local;
+      if (excl < want && want <= incl) {  // exactly one lane (left = number of non-zero keys >= want)
+        u32 acc = excl;
+        for (int j = (int)BPL - 1; j >= 0; --j) {
+          acc += c[j];
+          if (acc >= want) {
+            S->ccut = lane * BPL + (u32)j;
+            S->chead = acc;
+            break;
+          }
+        }
+      }
+    }
+    if (tid == 0) S->topcnt = 0;
+    __syncthreads();
+    u32 r = S->chead;
+    if (r > kRoundMax || (S->ccut == 0u && r > want)) {
+      // (bin 0 collects everything below 2^-11: a round that reaches it is not ordered by bins any more)
+      r = want;
+      u64 T = 1ull;  // every remaining (non-zero) key
+      if (left > r) T = wg_select_kth<NT>(nkeys, Mp, r, &S->ss);  // r-th largest of the remaining keys (box.py:505)
+      for (u32 i = tid; i < Mp; i += NT) {
+        const u64 k = nkeys[i];
+        if (k != 0ull && k >= T) {
+          top_u[atomicAdd(&S->topcnt, 1u)] = k;
+          nkeys[i] = 0ull;
+        }
+      }
+    } else {
+      const u32 cc = S->ccut;
+      for (u32 i = tid; i < Mp; i += NT) {  // (Mp is a multiple of 64: whole waves)
+        const u64 k = nkeys[i];
+        const bool take = k != 0ull && cbin_of(k) >= cc;
+        const u64 m = __ballot(take);
+        if (m == 0ull) continue;
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&S->topcnt, (u32)__popcll(m));
+        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+        if (take) {
+          top_u[base + mbcnt(m)] = k;
+          nkeys[i] = 0ull;
+        }
+      }
+    }
+    if (stamp && first) p.stamps[17] = clock64();
+    __syncthreads();
+    {  // rank by counting: 4 threads per key (2 above 256 keys), a part of the round each
+      const u32 parts = r <= 256u ? 4u : 2u, sh = r <= 256u ? 2u : 1u;
+      const u32 i = tid >> sh, part = tid & (parts - 1u);
+      const u32 span = (r + parts - 1u) / parts;
       const u64 me = i < r ? top_u[i] : ~0ull;
       u32 g = 0;
-      const u32 j1 = (part + 1u) * (kRound / 4) < r ? (part + 1u) * (kRound / 4) : r;
-      for (u32 j = part * (kRound / 4); j < j1; ++j) g += top_u[j] > me ? 1u : 0u;
+      const u32 j1 = (part + 1u) * span < r ? (part + 1u) * span : r;
+      for (u32 j = part * span; j < j1; ++j) g += top_u[j] > me ? 1u : 0u;
       g += __shfl_xor(g, 1);
-      g += __shfl_xor(g, 2);
+      if (parts == 4u) g += __shfl_xor(g, 2);
       if (part == 0 && i < r) sorted[g] = me;
     }
     __syncthreads();
@@ -630,6 +718,10 @@ int launch_tail(const ssdk_level* lv, int L, int B, int dtype, int K, int rescor
     p.lv[l].stride = lv[l].stride;
     p.lv[l].units = units[l];
     p.lv[l].unit_base = unit_base[l];
+    auto magic = [](int d) -> u32 { return d <= 1 ? 0xffffffffu : (u32)((1ull << 32) / (unsigned)d); };
+    p.lv[l].mW = magic(lv[l].W);
+    p.lv[l].mH = magic(lv[l].H);
+    p.lv[l].mC = magic(lv[l].C);
     memcpy(p.lv[l].anchors, lv[l].anchors, sizeof(float) * 4 * lv[l].A);
   }
   p.L = L;

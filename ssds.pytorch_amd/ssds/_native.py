@@ -266,10 +266,12 @@ class Context(object):
             raise SsdkError(lib.ssdk_last_error().decode())
         return [(names[i].decode() if names[i] else "", float(ms[i])) for i in range(n)]
 
-    def tail_stamps(self):
-        out = (ctypes.c_ulonglong * 48)()
-        check(self._call(lib.ssdk_ctx_get_tail_stamps, out, 48), "ctx_get_tail_stamps")
-        return [int(out[i]) for i in range(48)]
+    def tail_stamps(self, n=48):
+        """Debug stamps (SSDK_TAIL_STAMPS=1): [0, 24) tail_kernel, [24, 48) scan kernel phases of workgroup 0 (shader clock);
+        n = 48 + 2 * W also returns wall-clock (100 MHz) start / end pairs of the first W <= 4096 scan workgroups."""
+        out = (ctypes.c_ulonglong * n)()
+        check(self._call(lib.ssdk_ctx_get_tail_stamps, out, n), "ctx_get_tail_stamps")
+        return [int(out[i]) for i in range(n)]
 
 
 def op_timings():

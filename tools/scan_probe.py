@@ -55,6 +55,19 @@ def run(name, make, thr=0.01, reps=20):
                       "select %.1f = %.1f  fast=%d winners=%d" % (
                           e(0, 8), e(8, 9), e(9, 10), e(10, 1), e(1, 2), e(2, 11), e(11, 3), e(0, 4), sc[5] >> 32,
                           sc[5] & 0xffffffff))
+            W = 1024
+            tl = ctx.tail_stamps(48 + 2 * W)[48:]
+            se = [(tl[2 * i], tl[2 * i + 1]) for i in range(W) if tl[2 * i + 1]]
+            if se:
+                t0 = min(a for a, _ in se)
+                st_ = sorted((a - t0) / 100.0 for a, _ in se)
+                en_ = sorted((b - t0) / 100.0 for _, b in se)
+                du_ = sorted((b - a) / 100.0 for a, b in se)
+                q = lambda v, f: v[min(len(v) - 1, int(f * len(v)))]  # noqa: E731
+                extra += ("\n      scan timeline of %d workgroups (us from the first start): starts p50 %.1f p90 %.1f max %.1f | ends p10 "
+                          "%.1f p50 %.1f p90 %.1f max %.1f | durations p10 %.1f p50 %.1f p90 %.1f max %.1f" % (
+                              len(se), q(st_, .5), q(st_, .9), st_[-1], q(en_, .1), q(en_, .5), q(en_, .9), en_[-1],
+                              q(du_, .1), q(du_, .5), q(du_, .9), du_[-1]))
         else:
             extra += "\n      scan wg0 (kcycles): " + " ".join("%.1f" % ((b - a) / 1e3) for a, b in zip(sc[0:5], sc[1:5]))
             extra += "  fast=%d winners=%d" % (sc[5] >> 32, sc[5] & 0xffffffff)
