@@ -517,8 +517,7 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
         __syncthreads();
         for (u32 t = tid; t < cb; t += NT) {
           const u64 me = small[t];
-          u32 r = 0;
-          for (u32 j = 0; j < cb; ++j) r += small[j] > me ? 1u : 0u;
+          const u32 r = lds_count_greater(small, 0, cb, me);
           if (r < need) out[above + r] = me;
         }
       }
@@ -582,7 +581,7 @@ bool scan16_applies(int dtype, float thr, int K) {
 
 static int scan16_reg() {
   const char* e = getenv("SSDK_SCAN_REG");
-  const int r = (e && *e) ? atoi(e) : 8;
+  const int r = (e && *e) ? atoi(e) : 16;
   return r == 32 ? 32 : (r == 16 ? 16 : 8);
 }
 

@@ -172,6 +172,21 @@ __device__ u64 wg_select_kth(const u64* buf, u32 n, u32 K, SelScratch* s, u32 ap
   return wg_select_kth_f<NT>([buf](u32 i) { return buf[i]; }, n, K, s, approx_max);
 }
 
+// number of keys of a[j0 .. j1) (LDS) that are greater than `me`: the reads go out eight at a time, so the LDS latency is
+// paid once per eight keys instead of once per key (a plain loop waits for every read before it compares)
+__device__ __forceinline__ u32 lds_count_greater(const u64* a, u32 j0, u32 j1, u64 me) {
+  u32 g = 0, j = j0;
+  for (; j + 8 <= j1; j += 8) {
+    u64 k[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) k[t] = a[j + t];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) g += k[t] > me ? 1u : 0u;
+  }
+  for (; j < j1; ++j) g += a[j] > me ? 1u : 0u;
+  return g;
+}
+
 // keep the K keys >= T at the front of buf (sel is a K-entry LDS staging area)
 template <int NT>
 __device__ void wg_compact_ge(u64* buf, u32 n, u64 T, u32 K, u64* sel, SelScratch* s) {

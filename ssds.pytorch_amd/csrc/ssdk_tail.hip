@@ -75,19 +75,32 @@ __device__ __forceinline__ u32 tail_divmod(u32 n, u32 d, u32 m, u32* r) {
   return q;
 }
 
-__device__ __forceinline__ void tail_decode_one(const TailLevel& d, int dtype, int rescore, u32 b, u32 idx, float score,
-                                                float* o_score, float4* o_box, float* o_cls) {
+struct TailGather {  // a winner's position inside its level and its four raw deltas (loaded, not yet used)
+  float d0, d1, d2, d3;
+  u32 x, y, c, a;
+};
+
+__device__ __forceinline__ TailGather tail_gather(const TailLevel& d, int dtype, u32 b, u32 idx) {
   const u32 W = d.W, H = d.H, C = d.C;
-  u32 x, y, c;
-  const u32 t1 = tail_divmod(idx, W, d.mW, &x);   // x = idx % W
-  const u32 t2 = tail_divmod(t1, H, d.mH, &y);    // y = (idx / W) % H
-  const u32 a = tail_divmod(t2, C, d.mC, &c);     // c = (idx / W / H) % C (box.py:448), a = idx / C / H / W (box.py:454)
+  TailGather g;
+  const u32 t1 = tail_divmod(idx, W, d.mW, &g.x);   // x = idx % W
+  const u32 t2 = tail_divmod(t1, H, d.mH, &g.y);    // y = (idx / W) % H
+  g.a = tail_divmod(t2, C, d.mC, &g.c);             // c = (idx / W / H) % C (box.py:448), a = idx / C / H / W (box.py:454)
   const size_t hw = (size_t)H * W;
-  const size_t boff = ((size_t)b * d.A * 4 + (size_t)a * 4) * hw + (size_t)y * W + x;
-  const float d0 = load_as_f32(d.box, boff, dtype);
-  const float d1 = load_as_f32(d.box, boff + hw, dtype);
-  const float d2 = load_as_f32(d.box, boff + 2 * hw, dtype);
-  const float d3 = load_as_f32(d.box, boff + 3 * hw, dtype);
+  const size_t boff = ((size_t)b * d.A * 4 + (size_t)g.a * 4) * hw + (size_t)g.y * W + g.x;
+  g.d0 = load_as_f32(d.box, boff, dtype);
+  g.d1 = load_as_f32(d.box, boff + hw, dtype);
+  g.d2 = load_as_f32(d.box, boff + 2 * hw, dtype);
+  g.d3 = load_as_f32(d.box, boff + 3 * hw, dtype);
+  return g;
+}
+
+// box.py:74-87 delta2box + box.py:459-471 for one winner; fp32, reference operation order (as level_kernel)
+__device__ __forceinline__ void tail_decode(const TailLevel& d, const TailGather& g, int rescore, float score, float* o_score,
+                                            float4* o_box, float* o_cls) {
+  const u32 W = d.W, H = d.H;
+  const float d0 = g.d0, d1 = g.d1, d2 = g.d2, d3 = g.d3;
+  const u32 x = g.x, y = g.y, a = g.a, c = g.c;
   const float fs = (float)d.stride;
   const float g0 = (float)x * fs + d.anchors[a * 4 + 0];  // box.py:459-462
   const float g1 = (float)y * fs + d.anchors[a * 4 + 1];
@@ -99,37 +112,51 @@ __device__ __forceinline__ void tail_decode_one(const TailLevel& d, int dtype, i
   const float pw = expf(d2) * aw;                       // box.py:80
   const float ph = expf(d3) * ah;
   const float Mx = (float)W * fs - 1.0f, My = (float)H * fs - 1.0f;  // box.py:83
-  const float x1 = tmax(0.0f, tmin(pcx - 0.5f * pw, Mx));           // box.py:84-87
-  const float y1 = tmax(0.0f, tmin(pcy - 0.5f * ph, My));
-  const float x2 = tmax(0.0f, tmin(pcx + 0.5f * pw - 1.0f, Mx));
-  const float y2 = tmax(0.0f, tmin(pcy + 0.5f * ph - 1.0f, My));
+  // torch.max(m, torch.min(t, M)) propagates a NaN t (box.py:84-87); v_min / v_max drop it, so it is put back explicitly
+  // (two instructions instead of the NaN-masking min / max of ssdk_common.h, 14 of which made this function VALU-bound)
+  auto clamp = [](float t, float M) {
+    const float r = __builtin_fmaxf(0.0f, __builtin_fminf(t, M));
+    return t != t ? t : r;
+  };
+  const float x1 = clamp(pcx - 0.5f * pw, Mx);
+  const float y1 = clamp(pcy - 0.5f * ph, My);
+  const float x2 = clamp(pcx + 0.5f * pw - 1.0f, Mx);
+  const float y2 = clamp(pcy + 0.5f * ph - 1.0f, My);
   float s = score;
   if (rescore) {  // box.py:464-471
     const float gcx = (g0 + g2) / 2.0f, gcy = (g1 + g3) / 2.0f;
     const float ltx = fabsf(gcx - x1), lty = fabsf(gcy - y1);
     const float rbx = fabsf(x2 - gcx), rby = fabsf(y2 - gcy);
-    const float rx = tmin(ltx, rbx) / tmax(ltx, rbx);
-    const float ry = tmin(lty, rby) / tmax(lty, rby);
+    // torch.min / torch.max of a NaN operand is NaN -> the score is NaN; the operands are NaN exactly when a corner is
+    const bool bad = (x1 != x1) | (y1 != y1) | (x2 != x2) | (y2 != y2);
+    const float rx = __builtin_fminf(ltx, rbx) / __builtin_fmaxf(ltx, rbx);
+    const float ry = __builtin_fminf(lty, rby) / __builtin_fmaxf(lty, rby);
     s = s * sqrtf(rx * ry);
+    s = bad ? __builtin_nanf("") : s;
   }
   *o_score = s;
   *o_box = make_float4(x1, y1, x2, y2);
   *o_cls = (float)c;
 }
 
+// FAST: no box of the image holds a NaN (the usual case, known per image: TailLds.hasnan) -- v_min / v_max are then exactly
+// torch.min / torch.max; otherwise the NaN-propagating forms of ssdk_common.h (8 of them, ~9 instructions each)
+template <bool FAST>
 __device__ __forceinline__ bool tail_suppressed_by(const float4 b, float ab, const float4 p, float ap, float thr,
                                                    int diou) {  // box.py:518-533, as nms_kernel
-  const float ix1 = tmax(b.x, p.x), iy1 = tmax(b.y, p.y);
-  const float ix2 = tmin(b.z, p.z), iy2 = tmin(b.w, p.w);
+  auto mx = [](float a, float c) { return FAST ? __builtin_fmaxf(a, c) : tmax(a, c); };
+  auto mn = [](float a, float c) { return FAST ? __builtin_fminf(a, c) : tmin(a, c); };
+  const float ix1 = mx(b.x, p.x), iy1 = mx(b.y, p.y);
+  const float ix2 = mn(b.z, p.z), iy2 = mn(b.w, p.w);
   float w = ix2 - ix1 + 1.0f, h = iy2 - iy1 + 1.0f;
-  w = tmax(w, 0.0f);
-  h = tmax(h, 0.0f);
+  w = mx(w, 0.0f);
+  h = mx(h, 0.0f);
   const float inter = w * h;
   const float iou = inter / (ab + ap - inter + 1e-7f);
   bool over = !(iou <= thr);
   if (over && diou) {
-    const float ox1 = tmin(b.x, p.x), oy1 = tmin(b.y, p.y);
-    const float ox2 = tmax(b.z, p.z), oy2 = tmax(b.w, p.w);
+    const float ox1 = mn(b.x, p.x), oy1 = mn(b.y, p.y);
+    const float ox2 = mx(b.z, p.z), oy2 = mx(b.w, p.w);
     const float dx = b.x - p.x, dy = b.y - p.y;
     const float inter_diag = dx * dx + dy * dy;
     const float ow = ox2 - ox1, oh = oy2 - oy1;
@@ -156,7 +183,7 @@ struct alignas(16) TailLds {  // fixed-size part of the LDS image (the arrays fo
   u64 rows[64];
   u64 blk_dead;
   u64 lb[SSDK_MAX_LEVELS];      // per level: a lower bound of its K-th key (largest minimum of its FULL unit lists)
-  u32 nvalid, nk, topcnt, pad0;
+  u32 nvalid, nk, topcnt, hasnan;  // hasnan: a candidate of the walk has a NaN coordinate (rescoring off, NaN deltas)
   u32 ccut, chead, cpad0, cpad1;  // C: lowest bin of the round, keys in it and above
   int cutbin[SSDK_MAX_LEVELS];  // -1: the level offers <= K keys, every one is a winner
   u32 ln[SSDK_MAX_LEVELS];      // keys the level's units offer (at or above lb)
@@ -241,6 +268,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
     S->nvalid = 0;
     S->nk = 0;
     S->topcnt = 0;
+    S->hasnan = 0;
   }
   // the unit lists: wave w owns units w, w + 16, ...; the keys of its FIRST unit stay in registers for the passes below
   const u64* cand = p.cand + (size_t)b * upi * K;
@@ -248,12 +276,13 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
   u64 kreg[kRegKeys];
   u32 cnt0 = 0;
   if (wave < upi) {
-    cnt0 = ccnt[wave];
+    // (a unit's list is zero-padded to K by the scan: the keys are requested without waiting for the count)
 #pragma unroll
     for (u32 c = 0; c < kRegKeys; ++c) {
       const u32 i = c * 64 + lane;
-      kreg[c] = i < cnt0 ? cand[(size_t)wave * K + i] : 0ull;
+      kreg[c] = i < K ? cand[(size_t)wave * K + i] : 0ull;
     }
+    cnt0 = ccnt[wave];
   } else {
 #pragma unroll
     for (u32 c = 0; c < kRegKeys; ++c) kreg[c] = 0ull;
@@ -413,8 +442,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
     const u32 l = f / K, i = f - l * K, bc = S->bcnt[l];
     if (i >= bc) continue;
     const u64 me = bkeys[l * K + i];
-    u32 r = 0;
-    for (u32 j = 0; j < bc; ++j) r += bkeys[l * K + j] > me ? 1u : 0u;
+    const u32 r = lds_count_greater(bkeys + l * K, 0, bc, me);
     const u32 ab = S->above[l];
     if (ab + r < S->nw[l]) wkeys[l * K + ab + r] = me;
   }
@@ -432,11 +460,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
     if (s < S->above[l]) {
       const u32 bin = tail_bin(key, hbase, hsh);
       const u32 g0 = gstart[l * kTailBins + bin], g1 = hist[l * kTailBins + bin];
-      if (g1 - g0 > 1u) {
-        u32 r = 0;
-        for (u32 j = g0; j < g1; ++j) r += wkeys[l * K + j] > key ? 1u : 0u;
-        dst = g0 + r;
-      }
+      if (g1 - g0 > 1u) dst = g0 + lds_count_greater(wkeys + l * K, g0, g1, key);
     }
     wl[l * K + dst] = key;  // (the slots s < nw of a level are a permutation of themselves)
   }
@@ -447,28 +471,39 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
   float* mid_s = p.mid_scores ? p.mid_scores + (size_t)b * LK : nullptr;
   float4* mid_b = p.mid_boxes ? reinterpret_cast<float4*>(p.mid_boxes) + (size_t)b * LK : nullptr;
   float* mid_c = p.mid_classes ? p.mid_classes + (size_t)b * LK : nullptr;
-  for (u32 pos = tid; pos < Mp; pos += NT) {
-    u64 nkey = 0ull;
-    if (pos < LK) {
-      const u64 key = wl[pos];
-      float s = 0.f, c = 0.f;
-      float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (key != 0ull) {
-        tail_decode_one(S->lv[pos / K], p.dtype, p.rescore, b, key_index(key), key_score(key), &s, &bx, &c);
-        rec_score[pos] = s;
-        rec_box[pos] = bx;
-        rec_cls[pos] = c;
-        nkey = (s > 0.0f) ? make_key(s, pos) : 0ull;  // box.py:496 (NaN drops out too)
+  for (u32 pos0 = tid; pos0 < Mp; pos0 += 2 * NT) {  // two winners per thread and trip: their 8 delta loads fly together
+    const u32 pos1 = pos0 + NT;
+    const u64 key0 = pos0 < LK ? wl[pos0] : 0ull, key1 = pos1 < LK ? wl[pos1] : 0ull;
+    TailGather g0{}, g1{};
+    if (key0 != 0ull) g0 = tail_gather(S->lv[pos0 / K], p.dtype, b, key_index(key0));
+    if (key1 != 0ull) g1 = tail_gather(S->lv[pos1 / K], p.dtype, b, key_index(key1));
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32 pos = h ? pos1 : pos0;
+      const u64 key = h ? key1 : key0;
+      if (pos >= Mp) continue;  // (whole waves: Mp is a multiple of 64 and NT)
+      u64 nkey = 0ull;
+      if (pos < LK) {
+        float s = 0.f, c = 0.f;
+        float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (key != 0ull) {
+          tail_decode(S->lv[pos / K], h ? g1 : g0, p.rescore, key_score(key), &s, &bx, &c);
+          rec_score[pos] = s;
+          rec_box[pos] = bx;
+          rec_cls[pos] = c;
+          nkey = (s > 0.0f) ? make_key(s, pos) : 0ull;  // box.py:496 (NaN drops out too)
+          if (nkey != 0ull && ((bx.x != bx.x) | (bx.y != bx.y) | (bx.z != bx.z) | (bx.w != bx.w))) S->hasnan = 1u;
+        }
+        if (mid_s) {
+          mid_s[pos] = s;
+          mid_b[pos] = bx;
+          mid_c[pos] = c;
+        }
       }
-      if (mid_s) {
-        mid_s[pos] = s;
-        mid_b[pos] = bx;
-        mid_c[pos] = c;
-      }
+      nkeys[pos] = nkey;
+      const u64 m = __ballot(nkey != 0ull);
+      if (lane == 0 && m) atomicAdd(&S->nvalid, (u32)__popcll(m));
     }
-    nkeys[pos] = nkey;
-    const u64 m = __ballot(nkey != 0ull);
-    if (lane == 0 && m) atomicAdd(&S->nvalid, (u32)__popcll(m));
   }
   __syncthreads();
   if (stamp) p.stamps[16] = clock64();
@@ -480,6 +515,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
   const float thr = p.thr;
   const int diou = p.diou;
   u32 left = S->nvalid;
+  const bool fastnms = S->hasnan == 0u;  // workgroup-uniform
   u32 nk = 0;
   bool first = true;
   while (left > 0 && nk < ndet) {  // workgroup-uniform
@@ -488,6 +524,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
     // More than 512 that way (massive ties in the rescored scores) -> the exact 256 by adaptive radix select.
     for (u32 i = tid; i < kCBins; i += NT) chist[i] = 0;
     __syncthreads();
+    if (stamp && first) p.stamps[6] = clock64();
     auto cbin_of = [&](u64 k) -> u32 {
       const u32 o = (u32)(k >> 48);
       const u32 bin = o < kCBase ? 0u : o - kCBase;
@@ -498,6 +535,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
       if (k != 0ull) atomicAdd(&chist[cbin_of(k)], 1u);
     }
     __syncthreads();
+    if (stamp && first) p.stamps[7] = clock64();
     const u32 want = left < kRound ? left : kRound;
     if (wave == 0) {
       constexpr u32 BPL = kCBins / 64;
@@ -533,6 +571,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
     }
     if (tid == 0) S->topcnt = 0;
     __syncthreads();
+    if (stamp && first) p.stamps[8] = clock64();
     u32 r = S->chead;
     if (r > kRoundMax || (S->ccut == 0u && r > want)) {
       // (bin 0 collects everything below 2^-11: a round that reaches it is not ordered by bins any more)
@@ -547,34 +586,54 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
         }
       }
     } else {
+      // per-wave counts -> one barrier -> every wave knows its first slot (16 waves adding to one LDS word one after the
+      // other cost more than the whole rest of the round)
       const u32 cc = S->ccut;
-      for (u32 i = tid; i < Mp; i += NT) {  // (Mp is a multiple of 64: whole waves)
-        const u64 k = nkeys[i];
-        const bool take = k != 0ull && cbin_of(k) >= cc;
-        const u64 m = __ballot(take);
-        if (m == 0ull) continue;
-        u32 base = 0;
-        if (lane == 0) base = atomicAdd(&S->topcnt, (u32)__popcll(m));
-        base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-        if (take) {
-          top_u[base + mbcnt(m)] = k;
-          nkeys[i] = 0ull;
+      constexpr u32 TRIPS = 4096 / NT;  // Mp <= 4096 (tail_fits)
+      u64 held[TRIPS];
+      u32 mine = 0;
+#pragma unroll
+      for (u32 t = 0; t < TRIPS; ++t) {
+        const u32 i = tid + t * NT;
+        held[t] = 0ull;
+        if (t * NT < Mp) {  // workgroup-uniform (Mp is a multiple of 64: whole waves)
+          const u64 k = i < Mp ? nkeys[i] : 0ull;
+          const bool take = k != 0ull && cbin_of(k) >= cc;
+          if (take) {
+            held[t] = k;
+            nkeys[i] = 0ull;
+          }
+          mine += (u32)__popcll(__ballot(take));
         }
+      }
+      if (lane == 0) S->rows[wave] = mine;  // (rows[] is free until the walk)
+      __syncthreads();
+      u32 base = 0;
+      for (u32 w = 0; w < wave; ++w) base += (u32)S->rows[w];
+#pragma unroll
+      for (u32 t = 0; t < TRIPS; ++t) {
+        const u64 m = __ballot(held[t] != 0ull);
+        if (held[t] != 0ull) top_u[base + mbcnt(m)] = held[t];
+        base += (u32)__popcll(m);
       }
     }
     if (stamp && first) p.stamps[17] = clock64();
     __syncthreads();
+    if (stamp && first) p.stamps[9] = clock64();
     {  // rank by counting: 4 threads per key (2 above 256 keys), a part of the round each
       const u32 parts = r <= 256u ? 4u : 2u, sh = r <= 256u ? 2u : 1u;
       const u32 i = tid >> sh, part = tid & (parts - 1u);
       const u32 span = (r + parts - 1u) / parts;
       const u64 me = i < r ? top_u[i] : ~0ull;
-      u32 g = 0;
       const u32 j1 = (part + 1u) * span < r ? (part + 1u) * span : r;
-      for (u32 j = part * span; j < j1; ++j) g += top_u[j] > me ? 1u : 0u;
+      u32 g = lds_count_greater(top_u, part * span < j1 ? part * span : j1, j1, me);
       g += __shfl_xor(g, 1);
       if (parts == 4u) g += __shfl_xor(g, 2);
       if (part == 0 && i < r) sorted[g] = me;
+    }
+    if (stamp && first) {
+      p.stamps[10] = clock64();
+      p.stamps[11] = r;
     }
     __syncthreads();
     if (stamp && first) p.stamps[3] = clock64();
@@ -596,7 +655,8 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
       for (u32 k = wave; k < nk; k += NW) {
         const float ck = kcls[k];
         if (__ballot(alive && cls == ck) == 0ull) continue;
-        const bool sup = (cls == ck) && tail_suppressed_by(box, area, kbox[k], karea[k], thr, diou);
+        const bool sup = (cls == ck) && (fastnms ? tail_suppressed_by<true>(box, area, kbox[k], karea[k], thr, diou)
+                                                 : tail_suppressed_by<false>(box, area, kbox[k], karea[k], thr, diou));
         alive = alive && !sup;
       }
       const u64 dead = __ballot(valid && !alive);
@@ -614,7 +674,8 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
           pj.z = tail_bcast(box.z, j);
           pj.w = tail_bcast(box.w, j);
           const float aj = tail_bcast(area, j);
-          row = __ballot(((m >> lane) & 1ull) && tail_suppressed_by(box, area, pj, aj, thr, diou));
+          row = __ballot(((m >> lane) & 1ull) && (fastnms ? tail_suppressed_by<true>(box, area, pj, aj, thr, diou)
+                                                          : tail_suppressed_by<false>(box, area, pj, aj, thr, diou)));
         }
         if (lane == 0) S->rows[j] = row;
       }
@@ -662,7 +723,10 @@ __global__ __launch_bounds__(kTailThreads) void tail_kernel(const TailParams p) 
     }
     left -= r;
   }
-  if (stamp) p.stamps[4] = clock64();
+  if (stamp) {
+    p.stamps[4] = clock64();
+    p.stamps[12] = nk;
+  }
 
   // ---- E: zero padding (box.py:489-491) ------------------------------------------------------------------------------------
   for (u32 i = nk + tid; i < ndet; i += NT) {
