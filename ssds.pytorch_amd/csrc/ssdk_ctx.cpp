@@ -242,22 +242,24 @@ extern "C" int ssdk_decode_nms_ctx(ssdk_ctx* ctx, const ssdk_level* levels, int 
     if (rc) return rc;
     st2 = ctx->tail_stream;
   }
-  if (pl.fused) {
+  char* w = (char*)workspace + align256(dec);
+  float* ms = mid_scores ? mid_scores : (float*)w;
+  w += align256(n * 4);
+  float* mb = mid_boxes ? mid_boxes : (float*)w;
+  w += align256(n * 16);
+  float* mc = mid_classes ? mid_classes : (float*)w;
+  if (pl.fused) {  // levelsel_kernel (B x L workgroups: select + order + decode per level) + nmswalk_kernel (per image)
     u32 hbase, hsh;
     hist_window(threshold, &hbase, &hsh);
-    rc = launch_tail(levels, L, B, dtype, K, rescore, pl.units, pl.unit_base, pl.units_per_image, workspace,
-                     (const char*)workspace + pl.cand_bytes, hbase, hsh, nms_threshold, ndetections, using_diou, out_scores,
-                     out_boxes, out_classes, mid_scores, mid_boxes, mid_classes, ctx->stamps, st2);
+    rc = launch_levelsel(levels, L, B, dtype, K, rescore, pl.units, pl.unit_base, pl.units_per_image, workspace,
+                         (const char*)workspace + pl.cand_bytes, hbase, hsh, ms, mb, mc, ctx->stamps, st2);
     if (rc) return rc;
     if (prof && (rc = record(ev[2], st2))) return rc;
-    ctx->prof_fused[ctx->prof_calls % kSsdkProfSlots] = true;  // no third launch: ms[2] reads 0, not an empty interval
+    rc = launch_nmswalk(ms, mb, mc, B, L * K, nms_threshold, ndetections, using_diou, out_scores, out_boxes, out_classes,
+                        ctx->stamps, st2);
+    if (rc) return rc;
+    if (prof && (rc = record(ev[3], st2))) return rc;
   } else {
-    char* w = (char*)workspace + align256(dec);
-    float* ms = mid_scores ? mid_scores : (float*)w;
-    w += align256(n * 4);
-    float* mb = mid_boxes ? mid_boxes : (float*)w;
-    w += align256(n * 16);
-    float* mc = mid_classes ? mid_classes : (float*)w;
     rc = launch_level(levels, L, B, dtype, K, rescore, pl, workspace, ms, mb, mc, st2);
     if (rc) return rc;
     if (prof && (rc = record(ev[2], st2))) return rc;
@@ -265,8 +267,8 @@ extern "C" int ssdk_decode_nms_ctx(ssdk_ctx* ctx, const ssdk_level* levels, int 
                     st2);
     if (rc) return rc;
     if (prof && (rc = record(ev[3], st2))) return rc;
-    if (prof) ctx->prof_fused[ctx->prof_calls % kSsdkProfSlots] = false;
   }
+  if (prof) ctx->prof_fused[ctx->prof_calls % kSsdkProfSlots] = false;
   if (prof) ++ctx->prof_calls;
   return SSDK_OK;
 }

@@ -45,11 +45,11 @@ def run(name, make, thr=0.01, reps=20):
     if os.environ.get("SSDK_TAIL_STAMPS") and os.environ.get("SSDK_DECODE_FUSED", "1") != "0":
         st = ctx.tail_stamps()
         d = lambda a, b: (st[b] - st[a]) / 1e3  # noqa: E731
-        extra = ("\n      tail (kcycles): A+bound %.1f | B1 hist %.1f cut+scatter %.1f resolve+order %.1f | B2 decode %.1f | "
-                 "C select %.1f rank %.1f | D walk %.1f | E %.1f  = %.1f" % (
-                     d(0, 1), d(1, 21), d(21, 22), d(22, 2), d(2, 16), d(16, 17), d(17, 3), d(3, 4), d(4, 5), d(0, 5)))
-        extra += ("\n      C detail: zero+bar %.1f hist+bar %.1f scan+bar %.1f compact %.1f bar %.1f rank %.1f bar %.1f  (round of %d, kept %d)" % (
-            d(16, 6), d(6, 7), d(7, 8), d(8, 17), d(17, 9), d(9, 10), d(10, 3), st[11], st[12]))
+        extra = ("\n      levelsel wg(0,0) (kcycles): load+bound %.1f | hist %.1f cut+scatter %.1f resolve+order %.1f | decode %.1f = %.1f"
+                 "\n      nmswalk wg0 (kcycles): keys %.1f | C zero+hist %.1f scan %.1f scatter %.1f order+gather %.1f | D walk %.1f | E %.1f"
+                 " = %.1f  (round of %d, kept %d)" % (
+                     d(0, 1), d(1, 21), d(21, 22), d(22, 2), d(2, 16), d(0, 16),
+                     d(3, 6), d(6, 7), d(7, 8), d(8, 17), d(17, 9), d(9, 4), d(4, 5), d(3, 5), st[11], st[12]))
         sc = st[24:]
         e = lambda a, b: (sc[b] - sc[a]) / 1e3  # noqa: E731
         if sc[11]:  # scan16_kernel
