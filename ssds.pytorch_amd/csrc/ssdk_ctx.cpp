@@ -139,7 +139,7 @@ extern "C" int ssdk_ctx_set_profiling(ssdk_ctx* ctx, int enable) {
         }
     ctx->prof_ready = true;
   }
-  ctx->prof_on = enable ? 1 : 0;
+  ctx->prof_on = enable == 2 ? 2 : (enable ? 1 : 0);  // 2: one interval around the whole stage, no event between its launches
   ctx->prof_calls = 0;
   return SSDK_OK;
 }
@@ -156,10 +156,12 @@ extern "C" int ssdk_ctx_get_timings(ssdk_ctx* ctx, int back, float* ms, int n) {
   }
   const long long slot = (ctx->prof_calls - 1 - back) % kSsdkProfSlots;
   hipEvent_t* ev = ctx->prof_ev[slot];
-  const int n_iv = ctx->prof_fused[slot] ? 2 : 3;  // the fused path has two launches: scan, tail
-  if (hipEventSynchronize(ev[n_iv]) != hipSuccess) return SSDK_E_LAUNCH;
-  ms[2] = 0.0f;
-  for (int i = 0; i < n_iv; ++i)
+  if (hipEventSynchronize(ev[3]) != hipSuccess) return SSDK_E_LAUNCH;
+  if (ctx->prof_fused[slot]) {  // stage mode: ms[0] = the whole stage (scan .. last launch), one interval
+    ms[1] = ms[2] = 0.0f;
+    return hipEventElapsedTime(&ms[0], ev[0], ev[3]) == hipSuccess ? SSDK_OK : SSDK_E_LAUNCH;
+  }
+  for (int i = 0; i < 3; ++i)
     if (hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) != hipSuccess) return SSDK_E_LAUNCH;
   return SSDK_OK;
 }
@@ -216,8 +218,9 @@ extern "C" int ssdk_decode_nms_ctx(ssdk_ctx* ctx, const ssdk_level* levels, int 
     return SSDK_E_BADARG;
   }
   hipStream_t main_s = (hipStream_t)stream;
-  const bool prof = ctx->prof_on && ctx->prof_ready;
-  hipEvent_t* ev = prof ? ctx->prof_ev[ctx->prof_calls % kSsdkProfSlots] : nullptr;
+  const bool prof_any = ctx->prof_on && ctx->prof_ready;
+  const bool prof = prof_any && ctx->prof_on == 1;  // per-launch events
+  hipEvent_t* ev = prof_any ? ctx->prof_ev[ctx->prof_calls % kSsdkProfSlots] : nullptr;
 
   static const bool want_stamps = [] {
     const char* e = getenv("SSDK_TAIL_STAMPS");
@@ -231,7 +234,7 @@ extern "C" int ssdk_decode_nms_ctx(ssdk_ctx* ctx, const ssdk_level* levels, int 
       (void)hipMemset(ctx->stamps, 0, kSsdkStampWords * sizeof(unsigned long long));
     }
   }
-  if (prof && (rc = record(ev[0], main_s))) return rc;
+  if (prof_any && (rc = record(ev[0], main_s))) return rc;
   rc = launch_scan(levels, L, B, dtype, threshold, K, pl, workspace, dec, main_s, ctx->stamps ? ctx->stamps + 24 : nullptr);
   if (rc) return rc;
   if (prof && (rc = record(ev[1], main_s))) return rc;
@@ -268,8 +271,11 @@ extern "C" int ssdk_decode_nms_ctx(ssdk_ctx* ctx, const ssdk_level* levels, int 
     if (rc) return rc;
     if (prof && (rc = record(ev[3], st2))) return rc;
   }
-  if (prof) ctx->prof_fused[ctx->prof_calls % kSsdkProfSlots] = false;
-  if (prof) ++ctx->prof_calls;
+  if (prof_any && !prof && (rc = record(ev[3], st2))) return rc;
+  if (prof_any) {
+    ctx->prof_fused[ctx->prof_calls % kSsdkProfSlots] = !prof;
+    ++ctx->prof_calls;
+  }
   return SSDK_OK;
 }
 

@@ -23,7 +23,7 @@ struct ssdk_ctx {
   int prof_on;
   bool prof_ready;
   hipEvent_t prof_ev[kSsdkProfSlots][4];
-  bool prof_fused[kSsdkProfSlots];  // the slot's call ran scan + fused tail (two launches, three events)
+  bool prof_fused[kSsdkProfSlots];  // the slot was recorded in stage mode (prof_on == 2): events 0 and 3 only
   long long prof_calls;
   unsigned long long* stamps;   // device, kSsdkStampWords words (SSDK_TAIL_STAMPS=1 only)
   // ---- plan executor (ssdk_run_ops_ctx) ----

@@ -96,7 +96,17 @@ struct TailGather {  // a winner's position inside its level and its four raw de
   u32 x, y, c, a;
 };
 
-__device__ __forceinline__ TailGather tail_gather(const TailLevel& d, int dtype, u32 b, u32 idx) {
+// DT is a template parameter on purpose: with a run-time dtype every load sat in its own branch and the compiler waited for
+// it there (s_waitcnt vmcnt(0) behind each of the 8 loads of a thread's two winners: 7.5 k of the 11 k cycles of B2)
+template <int DT>
+__device__ __forceinline__ float tail_load(const void* p, size_t i) {
+  if constexpr (DT == SSDK_F32) return ((const float*)p)[i];
+  else if constexpr (DT == SSDK_BF16) return bf16_bits_to_f32(((const u16*)p)[i]);
+  else return f16_bits_to_f32(((const u16*)p)[i]);
+}
+
+template <int DT>
+__device__ __forceinline__ TailGather tail_gather(const TailLevel& d, u32 b, u32 idx) {
   const u32 W = d.W, H = d.H, C = d.C;
   TailGather g;
   const u32 t1 = tail_divmod(idx, W, d.mW, &g.x);   // x = idx % W
@@ -104,10 +114,10 @@ __device__ __forceinline__ TailGather tail_gather(const TailLevel& d, int dtype,
   g.a = tail_divmod(t2, C, d.mC, &g.c);             // c = (idx / W / H) % C (box.py:448), a = idx / C / H / W (box.py:454)
   const size_t hw = (size_t)H * W;
   const size_t boff = ((size_t)b * d.A * 4 + (size_t)g.a * 4) * hw + (size_t)g.y * W + g.x;
-  g.d0 = load_as_f32(d.box, boff, dtype);
-  g.d1 = load_as_f32(d.box, boff + hw, dtype);
-  g.d2 = load_as_f32(d.box, boff + 2 * hw, dtype);
-  g.d3 = load_as_f32(d.box, boff + 3 * hw, dtype);
+  g.d0 = tail_load<DT>(d.box, boff);
+  g.d1 = tail_load<DT>(d.box, boff + hw);
+  g.d2 = tail_load<DT>(d.box, boff + 2 * hw);
+  g.d3 = tail_load<DT>(d.box, boff + 3 * hw);
   return g;
 }
 
@@ -203,23 +213,24 @@ struct alignas(16) SelLds {
   u32 hist[kTailBins];      // score bins; after the cut: next free slot of every bin's group
   u16 gstart[kTailBins];    // first slot of a bin's group
   u64 umin[kSelUnits];      // smallest key of every unit of the level
-  u64 lb;                   // lower bound of the level's K-th key (largest minimum of its FULL unit lists)
+  u32 ufull[kSelUnits];     // ... and whether its list is full (K keys)
+  u64 lb;                   // lower bound of the level's K-th key (largest minimum of its FULL unit lists), when needed
   int cutbin;               // -1: the level offers <= K keys, every one is a winner
   u32 ln, above, nw, bcnt, generic, pad0, pad1;
   SelScratch ss;
 };
 __host__ __device__ inline size_t sel_lds_bytes(u32 K) {
-  return sizeof(SelLds) + 2 * ((((size_t)K * 8) + 15) & ~(size_t)15);  // wkeys, wl (the boundary list lives on wl until it is written)
+  return sizeof(SelLds) + 2 * ((((size_t)K * 8) + 15) & ~(size_t)15);  // wkeys, bkeys
 }
 
+template <int DT>
 __global__ __launch_bounds__(kSelThreads) void levelsel_kernel(const SelParams p) {
   constexpr int NT = kSelThreads;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   SelLds* S = reinterpret_cast<SelLds*>(smem);
   const u32 K = p.K;
   u64* wkeys = reinterpret_cast<u64*>(smem + sizeof(SelLds));  // [K] winners grouped by bin (descending), boundary winners in order
-  u64* wl = wkeys + ((K + 1u) & ~1u);                          // [K] winners in order
-  u64* bkeys = wl;                                             // [K] boundary list (dead before wl is written)
+  u64* bkeys = wkeys + ((K + 1u) & ~1u);                       // [K] boundary list
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const u32 l = blockIdx.x, b = blockIdx.y, L = (u32)p.L;
   const bool stamp = p.stamps != nullptr && l == 0 && b == 0 && tid == 0;
@@ -243,7 +254,10 @@ __global__ __launch_bounds__(kSelThreads) void levelsel_kernel(const SelParams p
     kreg[t] = i < nslots ? keys[i] : 0ull;
   }
   for (u32 i = tid; i < kTailBins; i += NT) S->hist[i] = 0;
-  if (tid < kSelUnits) S->umin[tid] = ~0ull;
+  if (tid < kSelUnits) {
+    S->umin[tid] = ~0ull;
+    S->ufull[tid] = 0;
+  }
   if (tid == 0) {
     S->lb = 0ull;
     S->cutbin = -1;
@@ -264,98 +278,134 @@ __global__ __launch_bounds__(kSelThreads) void levelsel_kernel(const SelParams p
     }
   };
   __syncthreads();
-  // A full list proves that K keys are >= its smallest one: the largest such minimum over the level's units is a lower
-  // bound of the level's K-th key.  (An all-equal image -- the reference-init network -- leaves the first K indices in
-  // EVERY unit: only the first unit's keys survive this bound and no selection is needed at all.)
-  if (nu > 1u && nu <= kSelUnits) {  // workgroup-uniform
-    const u32 mK = K <= 1u ? 0xffffffffu : (u32)((1ull << 32) / K);
-    for_each_key([&](u64 key, u32 i) {
-      if (key == 0ull) return;
-      u32 j;
-      const u32 u = tail_divmod(i, K, mK, &j);
-      atomicMin(reinterpret_cast<unsigned long long*>(&S->umin[u]), key);
-    });
-    __syncthreads();
-    if (tid < nu && keys[(size_t)tid * K + K - 1u] != 0ull)  // a full list
-      atomicMax(reinterpret_cast<unsigned long long*>(&S->lb), S->umin[tid]);
-    __syncthreads();
-  }
-  const u64 lb = S->lb;
+  u64 lb = 0ull;  // lower bound of the level's K-th key (0: none needed so far)
   if (stamp) p.stamps[1] = clock64();
 
-  // ---- B1 pass 1: histogram of the keys at or above the bound -----------------------------------------------------------
-  {
-    u32 mine = 0;
-    for_each_key([&](u64 key, u32) {
-      const bool in = key != 0ull && key >= lb;
-      if (in) atomicAdd(&S->hist[tail_bin(key, hbase, hsh)], 1u);
-      mine += in ? 1u : 0u;
-    });
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
-    if (lane == 0 && mine) atomicAdd(&S->ln, mine);
-  }
-  __syncthreads();
-  if (stamp) p.stamps[21] = clock64();
-  // wave 0: the bin in which the count from the top reaches K, and every bin's first slot (suffix sums)
-  if (wave == 0) {
-    constexpr u32 BPL = kTailBins / 64;
-    u32 c[BPL], local = 0;
-#pragma unroll
-    for (u32 j = 0; j < BPL; j += 4) {
-      const u32x4 q4 = *reinterpret_cast<const u32x4*>(&S->hist[lane * BPL + j]);
-      c[j] = q4[0];
-      c[j + 1] = q4[1];
-      c[j + 2] = q4[2];
-      c[j + 3] = q4[3];
-      local += q4[0] + q4[1] + q4[2] + q4[3];
-    }
-    u32 incl = local;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const u32 y = __shfl_down(incl, d);
-      if (lane + d < 64) incl += y;
-    }
-    const u32 excl = incl - local;  // keys in the bins above this lane's
-    const u32 nl = (u32)__builtin_amdgcn_readfirstlane((int)incl);
-    if (nl <= K) {
-      if (lane == 0) {
+  // ---- B1 pass 1: histogram of the keys, the boundary bin, the groups' first slots.  Trip 0 takes every key.  If its
+  // boundary bin holds more than K keys and the level has several units, trip 1 first derives a LOWER BOUND of the level's
+  // K-th key: a full list proves that K keys are >= its smallest one, so the largest such minimum over the level's units
+  // bounds the K-th key from below.  (An all-equal image -- the reference-init network -- leaves the first K indices in EVERY
+  // unit: only the first unit's keys survive the bound and no selection is left.)
+  for (int trip = 0; trip < 2; ++trip) {  // workgroup-uniform
+    if (trip == 1) {
+      if (!(S->generic && nu > 1u && nu <= kSelUnits)) break;
+      const u32 mK = K <= 1u ? 0xffffffffu : (u32)((1ull << 32) / K);
+      for_each_key([&](u64 key, u32 i) {
+        if (key == 0ull) return;
+        u32 j;
+        const u32 u = tail_divmod(i, K, mK, &j);
+        atomicMin(reinterpret_cast<unsigned long long*>(&S->umin[u]), key);
+        if (j == K - 1u) S->ufull[u] = 1u;  // the list's last slot is used: a full list
+      });
+      for (u32 i = tid; i < kTailBins; i += NT) S->hist[i] = 0;
+      if (tid == 0) {
         S->cutbin = -1;
-        S->above = nl;
-        S->nw = nl;
+        S->ln = 0;
+        S->above = 0;
+        S->nw = 0;
+        S->generic = 0;
       }
-    } else if (excl < K && K <= incl) {  // exactly one lane
-      u32 acc = excl;
-      for (int j = (int)BPL - 1; j >= 0; --j) {
-        if (acc + c[j] >= K) {
-          S->cutbin = (int)(lane * BPL + (u32)j);
-          S->above = acc;
-          S->nw = K;
-          S->generic = c[j] > K ? 1u : 0u;
-          break;
-        }
-        acc += c[j];
-      }
+      __syncthreads();
+      if (tid < nu && S->ufull[tid]) atomicMax(reinterpret_cast<unsigned long long*>(&S->lb), S->umin[tid]);
+      __syncthreads();
+      lb = S->lb;
     }
-    u32 run = excl;
+    {
+      u32 mine = 0;
+      for_each_key([&](u64 key, u32) {
+        const bool in = key != 0ull && key >= lb;
+        if (in) atomicAdd(&S->hist[tail_bin(key, hbase, hsh)], 1u);
+        mine += in ? 1u : 0u;
+      });
 #pragma unroll
-    for (int j = (int)BPL - 1; j >= 0; --j) {
-      S->hist[lane * BPL + j] = run;  // cursor of the counting-sort scatter (meaningful for the bins above the boundary bin)
-      S->gstart[lane * BPL + j] = (u16)(run < 0xffffu ? run : 0xffffu);
-      run += c[j];
+      for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d);
+      if (lane == 0 && mine) atomicAdd(&S->ln, mine);
     }
+    __syncthreads();
+    if (stamp && trip == 0) p.stamps[21] = clock64();
+    // wave 0: the bin in which the count from the top reaches K, and every bin's first slot (suffix sums)
+    if (wave == 0) {
+      constexpr u32 BPL = kTailBins / 64;
+      u32 c[BPL], local = 0;
+#pragma unroll
+      for (u32 j = 0; j < BPL; j += 4) {
+        const u32x4 q4 = *reinterpret_cast<const u32x4*>(&S->hist[lane * BPL + j]);
+        c[j] = q4[0];
+        c[j + 1] = q4[1];
+        c[j + 2] = q4[2];
+        c[j + 3] = q4[3];
+        local += q4[0] + q4[1] + q4[2] + q4[3];
+      }
+      u32 incl = local;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const u32 y = __shfl_down(incl, d);
+        if (lane + d < 64) incl += y;
+      }
+      const u32 excl = incl - local;  // keys in the bins above this lane's
+      const u32 nl = (u32)__builtin_amdgcn_readfirstlane((int)incl);
+      if (nl <= K) {
+        if (lane == 0) {
+          S->cutbin = -1;
+          S->above = nl;
+          S->nw = nl;
+        }
+      } else if (excl < K && K <= incl) {  // exactly one lane
+        u32 acc = excl;
+        for (int j = (int)BPL - 1; j >= 0; --j) {
+          if (acc + c[j] >= K) {
+            S->cutbin = (int)(lane * BPL + (u32)j);
+            S->above = acc;
+            S->nw = K;
+            S->generic = c[j] > K ? 1u : 0u;
+            break;
+          }
+          acc += c[j];
+        }
+      }
+      if (excl < K) {  // (only the bins at or above the boundary bin are ever scattered into)
+        u32 run = excl;
+#pragma unroll
+        for (int j = (int)BPL - 1; j >= 0; --j) {
+          S->hist[lane * BPL + j] = run;  // cursor of the counting-sort scatter
+          S->gstart[lane * BPL + j] = (u16)(run < 0xffffu ? run : 0xffffu);
+          run += c[j];
+        }
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // pass 2: scatter.  Bins above the boundary bin: next free slot of the bin's group; boundary bin: the boundary list.
+  // (the returning LDS atomics of a thread's register keys are issued together, the stores follow: one LDS round trip
+  // instead of one per key)
   {
     const int cb = S->cutbin;
     const bool generic = S->generic != 0u;
-    for_each_key([&](u64 key, u32) {
-      if (!(key != 0ull && key >= lb)) return;
+    u32 slot[kSelReg];
+#pragma unroll
+    for (u32 t = 0; t < kSelReg; ++t) {
+      slot[t] = ~0u;
+      const u64 key = kreg[t];
+      if (t * NT < nslots && key != 0ull && key >= lb) {
+        const int bin = (int)tail_bin(key, hbase, hsh);
+        if (bin > cb) slot[t] = atomicAdd(&S->hist[(u32)bin], 1u);
+        else if (bin == cb && !generic) slot[t] = 0x80000000u | atomicAdd(&S->bcnt, 1u);
+      }
+    }
+#pragma unroll
+    for (u32 t = 0; t < kSelReg; ++t)
+      if (slot[t] != ~0u) {
+        if (slot[t] & 0x80000000u) bkeys[slot[t] & 0x7fffffffu] = kreg[t];
+        else wkeys[slot[t]] = kreg[t];
+      }
+    for (u32 i0 = kSelReg * NT; i0 < nslots; i0 += NT) {
+      const u32 i = i0 + tid;
+      const u64 key = i < nslots ? keys[i] : 0ull;
+      if (!(key != 0ull && key >= lb)) continue;
       const int bin = (int)tail_bin(key, hbase, hsh);
       if (bin > cb) wkeys[atomicAdd(&S->hist[(u32)bin], 1u)] = key;
       else if (bin == cb && !generic) bkeys[atomicAdd(&S->bcnt, 1u)] = key;
-    });
+    }
   }
   __syncthreads();
   if (stamp) p.stamps[22] = clock64();
@@ -385,51 +435,43 @@ __global__ __launch_bounds__(kSelThreads) void levelsel_kernel(const SelParams p
     }
   }
   __syncthreads();
-  // groups of the bins above: one key -> it is in place; more (ties in score, coarse bins) -> rank inside the group.
-  // (wl shares its storage with the boundary list: its last reader is behind the barrier above)
-  {
-    const u32 nw = S->nw, ab = S->above;
-    for (u32 s = tid; s < K; s += NT) {
-      if (s >= nw) {  // a slot without a winner: fewer than K candidates in the level
-        wl[s] = 0ull;
-        continue;
-      }
-      const u64 key = wkeys[s];
-      u32 dst = s;
-      if (s < ab) {
-        const u32 bin = tail_bin(key, hbase, hsh);
-        const u32 g0 = S->gstart[bin], g1 = S->hist[bin];
-        if (g1 - g0 > 1u) dst = g0 + lds_count_greater(wkeys, g0, g1, key);
-      }
-      wl[dst] = key;  // (the slots s < nw are a permutation of themselves)
-    }
-  }
-  __syncthreads();
   if (stamp) p.stamps[2] = clock64();
-
-  // ---- B2: decode of the winners, into the image's [L*K] arrays ------------------------------------------------------------
+  // ---- order + B2: every winner finds its rank (a key alone in its bin's group is in place; more -- ties in score, coarse
+  // bins -- rank inside the group), is decoded and written at l*K + rank of the image's [L*K] arrays; the other slots are
+  // zeroed (box.py:430-432)
   {
     const size_t o = ((size_t)b * L + l) * K;
     float* ms = p.mid_scores + o;
     float4* mb = reinterpret_cast<float4*>(p.mid_boxes) + o;
     float* mc = p.mid_classes + o;
-    for (u32 r0 = tid; r0 < K; r0 += 2 * NT) {  // two winners per thread and trip: their 8 delta loads fly together
-      const u32 r1 = r0 + NT;
-      const u64 key0 = wl[r0], key1 = r1 < K ? wl[r1] : 0ull;
-      TailGather g0{}, g1{};
-      if (key0 != 0ull) g0 = tail_gather(lv, p.dtype, b, key_index(key0));
-      if (key1 != 0ull) g1 = tail_gather(lv, p.dtype, b, key_index(key1));
+    const u32 nw = S->nw, ab = S->above;
+    for (u32 s0 = tid; s0 < K; s0 += 2 * NT) {  // two winners per thread and trip: their 8 delta loads fly together
+      const u32 s1 = s0 + NT;
+      const u64 key0 = s0 < nw ? wkeys[s0] : 0ull, key1 = s1 < nw ? wkeys[s1] : 0ull;
+      // branch-free: an empty slot gathers the deltas of index 0 (a valid address) and throws them away -- all eight
+      // loads of the thread are issued before the first wait
+      const TailGather g0 = tail_gather<DT>(lv, b, key0 != 0ull ? key_index(key0) : 0u);
+      const TailGather g1 = tail_gather<DT>(lv, b, key1 != 0ull ? key_index(key1) : 0u);
+      if (stamp) p.stamps[13] = clock64();
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const u32 r = h ? r1 : r0;
+        const u32 sl = h ? s1 : s0;
         const u64 key = h ? key1 : key0;
-        if (r >= K) continue;
-        float s = 0.f, c = 0.f;
+        if (sl >= K) continue;
+        u32 dst = sl;
+        if (key != 0ull && sl < ab) {
+          const u32 bin = tail_bin(key, hbase, hsh);
+          const u32 q0 = S->gstart[bin], q1 = S->hist[bin];
+          if (q1 - q0 > 1u) dst = q0 + lds_count_greater(wkeys, q0, q1, key);
+        }
+        float sc_ = 0.f, c = 0.f;
         float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (key != 0ull) tail_decode(lv, h ? g1 : g0, p.rescore, key_score(key), &s, &bx, &c);
-        ms[r] = s;
-        mb[r] = bx;
-        mc[r] = c;
+        if (key != 0ull) tail_decode(lv, h ? g1 : g0, p.rescore, key_score(key), &sc_, &bx, &c);
+        // (the slots below nw are a permutation of themselves; the slots from nw on hold no winner)
+        ms[dst] = sc_;
+        mb[dst] = bx;
+        mc[dst] = c;
+        if (stamp && h == 0) p.stamps[15] = clock64();
       }
     }
   }
@@ -557,12 +599,14 @@ __global__ __launch_bounds__(kWalkThreads) void nmswalk_kernel(const WalkParams 
           }
         }
       }
-      u32 run = excl;
+      if (excl < want) {  // (only the bins of the round are ever scattered into)
+        u32 run = excl;
 #pragma unroll
-      for (int j = (int)BPL - 1; j >= 0; --j) {
-        S->chist[lane * BPL + j] = run;  // cursor of the scatter (meaningful for the bins of the round)
-        S->cstart[lane * BPL + j] = (u16)(run < 0xffffu ? run : 0xffffu);
-        run += c[j];
+        for (int j = (int)BPL - 1; j >= 0; --j) {
+          S->chist[lane * BPL + j] = run;  // cursor of the scatter
+          S->cstart[lane * BPL + j] = (u16)(run < 0xffffu ? run : 0xffffu);
+          run += c[j];
+        }
       }
     }
     if (tid == 0) S->topcnt = 0;
@@ -777,7 +821,10 @@ int launch_levelsel(const ssdk_level* lv, int L, int B, int dtype, int K, int re
   p.mid_classes = mc;
   p.stamps = stamps;
   lds_poison(stream);
-  hipLaunchKernelGGL(levelsel_kernel, dim3((unsigned)L, (unsigned)B), dim3(kSelThreads), sel_lds_bytes((u32)K), stream, p);
+  const dim3 grid((unsigned)L, (unsigned)B);
+  if (dtype == SSDK_F32) hipLaunchKernelGGL(levelsel_kernel<SSDK_F32>, grid, dim3(kSelThreads), sel_lds_bytes((u32)K), stream, p);
+  else if (dtype == SSDK_BF16) hipLaunchKernelGGL(levelsel_kernel<SSDK_BF16>, grid, dim3(kSelThreads), sel_lds_bytes((u32)K), stream, p);
+  else hipLaunchKernelGGL(levelsel_kernel<SSDK_F16>, grid, dim3(kSelThreads), sel_lds_bytes((u32)K), stream, p);
   return check_launch("levelsel_kernel");
 }
 

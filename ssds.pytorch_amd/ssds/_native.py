@@ -247,7 +247,10 @@ class Context(object):
         check(self._call(lib.ssdk_ctx_set_side_lane, -1 if on is None else int(bool(on))), "ctx_set_side_lane")
 
     def set_profiling(self, on):
-        check(self._call(lib.ssdk_ctx_set_profiling, 1 if on else 0), "ctx_set_profiling")
+        """True / 1: hipEvents around every launch of the decode stage; 2: ONE interval around the whole stage (no event
+        between its launches: an event costs ~4.6 us of GPU time on this stack and flushes caches between the kernels it
+        separates), read back as timings_ms()[0]; False: off."""
+        check(self._call(lib.ssdk_ctx_set_profiling, 2 if on == 2 else (1 if on else 0)), "ctx_set_profiling")
 
     def timings_ms(self, back=0):
         """(scan_kernel, tail_kernel | level_kernel, nms_kernel | 0) ms of the profiled decode_nms call ``back`` calls ago."""

@@ -29,12 +29,12 @@ class Decoder(object):
         if c is None:
             c = self._ctx[device.index] = N.Context(device)
             if self._prof:
-                c.set_profiling(True)
+                c.set_profiling(self._prof)
         return c
 
     def set_profiling(self, on):
         """Record hipEvents around the stage's launches (read back with ``timings_ms``; bench.py)."""
-        self._prof = bool(on)
+        self._prof = 2 if on == 2 else bool(on)
         for c in self._ctx.values():
             c.set_profiling(self._prof)
 
