@@ -953,6 +953,11 @@ extern "C" size_t ssdk_conv_workspace_bytes(int N, int Cin, int H, int W, int Co
   const int pad = k / 2;
   const long M = (long)N * ((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
   size_t need = splitk_ws_bytes(M, Cin, Cout, k, nullptr, nullptr);
+  if (k == 3 && stride == 1) {  // the halo kernel's own split-K (small maps, long K)
+    size_t hb = 0;
+    if (halo_splitk_plan(N, Cin, H, W, Cout, true, &hb) > 1 && hb > need) need = hb;
+    if (halo_splitk_plan(N, Cin, H, W, Cout, false, &hb) > 1 && hb > need) need = hb;
+  }
   int ws = 1, wk = 0, mt = 0, ntl = 0;
   if (wave_plan(M, Cin, Cout, k, &ws, &wk, &mt, &ntl) && ws > 1) {
     const size_t w = 4096 + (size_t)mt * ntl * ws * 4096;
@@ -962,6 +967,11 @@ extern "C" size_t ssdk_conv_workspace_bytes(int N, int Cin, int H, int W, int Co
 }
 
 static thread_local bool g_underfill_ok = false;  // set by ssdk_run_ops around side-lane ops
+
+static int halo_splitk_min_pixels() {  // smallest map (pixels) that goes to the halo kernel's split-K instead of conv_smallmap
+  const char* e = getenv("SSDK_HALO_SPLITK_MINP");
+  return (e && *e) ? atoi(e) : 64;
+}
 
 extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -1126,7 +1136,19 @@ extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t worksp
   p.kt_per = p.KT;
   p.slabs = nullptr;
   p.counters = nullptr;
-  if (launch_conv_smallmap(p, d->dtype, stream) == 0) return check_launch("conv_smallmap_kernel");  // maps of <= 16 pixels
+  if (d->k == 3 && d->stride == 1 && !g_underfill_ok) {  // maps of 16 .. 64 pixels with a long K: halo tiles + split-K
+    size_t hb = 0;
+    const int hs = halo_splitk_plan(d->N, d->Cin, Ho, Wo, d->Cout, d->out_layout == SSDK_LAYOUT_NCHW, &hb);
+    if (hs > 1 && Ho * Wo >= halo_splitk_min_pixels() && workspace && workspace_bytes >= hb && !((uintptr_t)workspace & 255)) {
+      ConvParams q = p;
+      q.ksplits = hs;
+      q.counters = (unsigned*)workspace;
+      q.slabs = (float*)((char*)workspace + 4096);
+      const int rc = launch_conv3x3_halo(q, d->dtype, stream, true);
+      if (rc != 1) return rc;
+    }
+  }
+  if (launch_conv_smallmap(p, d->dtype, stream) == 0) return check_launch("conv_smallmap_kernel");  // maps of <= 64 pixels
   // Side-lane ops (small heads running next to the extras chain) prefer the halo kernel however few tiles they have:
   // an underfilled grid is free there, and unlike the split-K kernels it has no agent-scope fences, which slow down
   // every kernel running concurrently (measured: split-K heads on the side lane +0.6 %, halo heads +2.7 %).

@@ -44,6 +44,10 @@ struct HaloParams {
   int vec_nchw;              // tw % 8 == 0 && Wo % 8 == 0: 16-byte NCHW stores
   unsigned x_bytes, w_bytes;  // buffer-descriptor ranges (tensors < 4 GiB)
   unsigned mg_ntiles, mg_tx, mg_ty, mg_ppi, mg_tw, mg_hw2, mg_halo;  // ceil(2^32 / d) of the divisors below
+  int ksplits, c_per;        // split-K over the 64-channel slabs: slice z owns slabs [z*c_per, min((z+1)*c_per, cchunks))
+  unsigned mg_ks;            // (grids too small to fill the chip: few pixels, long K -- the 8x8 ... 4x4 head levels)
+  float* slabs;              // [tile][slice][16 fragments][512 lanes][4] fp32 partial accumulators
+  unsigned* counters;        // [tile] arrival tickets, zero on entry, re-armed by the last arriver
   long long* dbg;             // SSDK_H3_DBG=1: cycle stamps of workgroup 0 / wave 0 (4 per k-step)
 };
 
@@ -74,8 +78,10 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
   const u32 nwg = gridDim.x, id = blockIdx.x;
   const u32 q8 = nwg >> 3, r8 = nwg & 7u, xcd = id & 7u;
   const u32 lin = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (id >> 3);
-  u32 pt = fdiv(lin, (u32)hp.n_tiles, hp.mg_ntiles);
-  const u32 nt = lin - pt * (u32)hp.n_tiles;
+  const u32 tile_id = fdiv(lin, (u32)hp.ksplits, hp.mg_ks);  // a tile's slices are neighbours: same XCD
+  const u32 kz = lin - tile_id * (u32)hp.ksplits;
+  u32 pt = fdiv(tile_id, (u32)hp.n_tiles, hp.mg_ntiles);
+  const u32 nt = tile_id - pt * (u32)hp.n_tiles;
   u32 pq = fdiv(pt, (u32)hp.tiles_x, hp.mg_tx);
   const u32 tx = pt - pq * (u32)hp.tiles_x;
   const u32 grp = fdiv(pq, (u32)hp.tiles_y, hp.mg_ty);
@@ -83,23 +89,13 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
   const int b0 = (int)grp * hp.imgs, y0 = (int)ty * hp.th, x0 = (int)tx * hp.tw;
   const u32 n0 = nt * H3_BN;
 
-  // per-column scale / bias of this lane's four accumulator columns: fetched first, used last
-  float e_sc[4], e_bi[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const u32 n = n0 + wn * 64u + j * 16 + (lane & 15u);
-    e_sc[j] = 1.f;
-    e_bi[j] = 0.f;
-    if (n < (u32)p.Cout) {
-      if (p.scale) e_sc[j] = p.scale[n];
-      e_bi[j] = p.bias[n];
-    }
-  }
 
   const int Cin = p.Cin, H = p.H, W = p.W;
   const int HW2 = hp.tw + 2, HH2 = hp.th + 2;
   const int Ktot = 9 * Cin;
   const int cchunks = (Cin + H3_BK - 1) / H3_BK;
+  const int c0 = (int)kz * hp.c_per;                                        // this slice's slabs: [c0, c1)
+  const int c1 = c0 + hp.c_per < cchunks ? c0 + hp.c_per : cchunks;
 
   // ---- loader roles ------------------------------------------------------------------------------------------
   // Loads are buffer_load_dwordx4 ... lds through raw buffer descriptors: address = base + soffset (uniform: slab /
@@ -169,26 +165,26 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto load_b = [&](int stage, int cc, int tap) {  // weights of (slab cc, tap) -> stage; past the end: a harmless re-read
-    const bool live = cc < cchunks;
+    const bool live = cc < c1;
     const u32 tm = (live && cc == cchunks - 1) ? tailmask : 0u;
     const int soff = live ? (tap * Cin + cc * H3_BK) * 2 : 0;
     lds_u8* dst = (lds_u8*)(smem + 2 * H3_A_BYTES + stage * H3_B_BYTES + wave * 1024u);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, dst, 16, b_vo[0] | tm, soff, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, dst + 8192, 16, b_vo[1] | tm, soff, 0, 0);
   };
-  auto load_a = [&](int t, int cc) {  // halo piece t of slab cc -> buffer cc & 1; past the end: re-read slab 0
-    const bool live = cc < cchunks;
+  auto load_a = [&](int t, int cc) {  // halo piece t of slab cc -> buffer (cc - c0) & 1; past the end: re-read slab 0
+    const bool live = cc < c1;
     const u32 tm = (live && cc == cchunks - 1) ? tailmask : 0u;
     const int soff = live ? cc * H3_BK * 2 : 0;
-    lds_u8* dst = (lds_u8*)(smem + (cc & 1) * H3_A_BYTES + (t * 8 + (int)wave) * 1024);
+    lds_u8* dst = (lds_u8*)(smem + ((cc - c0) & 1) * H3_A_BYTES + (t * 8 + (int)wave) * 1024);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, a_vo[t] | tm, soff, 0, 0);
   };
 
   // ---- prologue: halo of slab 0, weights of steps 0 and 1 ------------------------------------------------------
 #pragma unroll
-  for (int t = 0; t < H3_NPIECE; ++t) load_a(t, 0);
-  load_b(0, 0, 0);
-  load_b(1, 0, 1);
+  for (int t = 0; t < H3_NPIECE; ++t) load_a(t, c0);
+  load_b(0, c0, 0);
+  load_b(1, c0, 1);
   H3_MARK(1);
   H3_WAIT(2);  // everything but the weights of step 1
   __builtin_amdgcn_s_barrier();
@@ -208,11 +204,11 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
   const bool g1 = wave >= 4u;
   u32 abuf = 0;                       // byte offset of the current halo buffer
   if (g1) __builtin_amdgcn_s_barrier();
-  for (int cc = 0; cc < cchunks; ++cc) {
+  for (int cc = c0; cc < c1; ++cc) {
     const bool half = tail_half && cc == cchunks - 1;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int stamp_i = cc * 9 + tap;
+      const int stamp_i = (cc - c0) * 9 + tap;
       H3_STAMP(0);
       // R: loads two steps ahead (+ taps 0..5: one halo piece of the next slab), then this step's fragments
       if (tap + 2 < 9) load_b((tap + 2) % 3, cc, tap + 2);
@@ -261,7 +257,62 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
   __builtin_amdgcn_s_barrier();
   H3_MARK(3);
 
+  if (hp.ksplits > 1) {
+    // ---- split-K hand-off (cdna_hip_programming.md G16, counter form; same protocol as conv_gemm_kernel): slab stores ->
+    //      every wave drains vmcnt -> barrier -> one lane: agent release + drained wait -> relaxed ticket; the last arriver
+    //      acquires once, then every wave sums the slabs IN SLICE ORDER (bit-reproducible whoever arrives last)
+    float* my = hp.slabs + ((size_t)tile_id * hp.ksplits + kz) * (size_t)(16 * H3_THREADS * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(my + ((size_t)(i * 4 + j) * H3_THREADS + tid) * 4) = acc[i][j];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    u32* flag = reinterpret_cast<u32*>(smem);  // (the halo buffers are free now)
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned old = __hip_atomic_fetch_add(hp.counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned last = (old == (unsigned)hp.ksplits - 1u) ? 1u : 0u;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(hp.counters + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    const bool last = *flag != 0u;
+    __syncthreads();  // everyone has read the flag before the epilogue reuses the LDS
+    if (!last) return;
+    const float* base = hp.slabs + (size_t)tile_id * hp.ksplits * (size_t)(16 * H3_THREADS * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = *reinterpret_cast<const f32x4*>(base + ((size_t)(i * 4 + j) * H3_THREADS + tid) * 4);
+    for (int z = 1; z < hp.ksplits; ++z) {
+      const float* other = base + (size_t)z * (size_t)(16 * H3_THREADS * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(other + ((size_t)(i * 4 + j) * H3_THREADS + tid) * 4);
+    }
+  }
+
   // ---- epilogue ------------------------------------------------------------------------------------------------
+  // per-column scale / bias of this lane's four accumulator columns.  (Requested here, not at the top of the kernel: beside
+  // LDS-DMA the compiler waits for every ordinary VGPR load before the first buffer_load ... lds is issued, which put a
+  // whole memory round trip into the set-up of every workgroup.)
+  float e_sc[4], e_bi[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const u32 n = n0 + wn * 64u + j * 16 + (lane & 15u);
+    e_sc[j] = 1.f;
+    e_bi[j] = 0.f;
+    if (n < (u32)p.Cout) {
+      if (p.scale) e_sc[j] = p.scale[n];
+      e_bi[j] = p.bias[n];
+    }
+  }
   u16* sC = reinterpret_cast<u16*>(smem);
   const bool nchw = p.out_layout == LAYOUT_NCHW;
   constexpr int LDC_M = H3_BN + 8;  // NHWC image sC[m][n]
@@ -414,14 +465,44 @@ static bool plan_patch(int N, int Ho, int Wo, bool nchw, HaloParams* hp) {
   return true;
 }
 
+// Split-K for grids that cannot fill the chip (few output pixels, long K: the 8x8 and 4x4 head levels at batch 64): the
+// number of slices (1: none) and the workspace they need.  A slice owns >= 2 slabs (>= 18 k-steps: the prologue has to
+// amortise) and the grid stops growing at ~one workgroup per CU.
+int halo_splitk_plan(int N, int Cin, int Ho, int Wo, int Cout, bool nchw, size_t* ws_bytes) {
+  // OFF by default: measured on the 8x8 head level (M = 4096, K = 4608) it ties conv_smallmap (45.2 vs 45.3 us) and loses on
+  // the 4x4 level (38.9 vs 19.2 us) -- a halo workgroup costs ~23 k cycles of set-up + epilogue whatever its K, and the reducer
+  // reads 4 x 128 KB of slabs alone.  Kept (and tested) for shapes with a longer K per slice: SSDK_HALO_SPLITK=1 | slices.
+  static const int env = getenv("SSDK_HALO_SPLITK") ? atoi(getenv("SSDK_HALO_SPLITK")) : 0;
+  if (ws_bytes) *ws_bytes = 0;
+  HaloParams hp;
+  if (!env || Cout < 96 || Cin < 128 || (Cin % 8) || !plan_patch(N, Ho, Wo, nchw, &hp)) return 1;
+  const long tiles = (long)hp.groups * hp.tiles_y * hp.tiles_x * ((Cout + H3_BN - 1) / H3_BN);
+  const int cchunks = (Cin + H3_BK - 1) / H3_BK;
+  int ks = 1;
+  while (ks * 2 <= cchunks / 2 && tiles * ks * 2 <= 320 && ks < 8) ks *= 2;
+  if (env > 1 && env <= cchunks) ks = env;  // (forced, A/B runs)
+  if (ks <= 1 || tiles > 1024) return 1;
+  if (ws_bytes) *ws_bytes = 4096 + (size_t)tiles * ks * 16 * H3_THREADS * 4 * sizeof(float);
+  return ks;
+}
+
 int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool allow_underfill) {
   static const int env = getenv("SSDK_CONV3X3_HALO") ? atoi(getenv("SSDK_CONV3X3_HALO")) : 1;
-  if (!env || p.k != 3 || p.stride != 1 || p.pad != 1 || (p.Cin % 8) || p.ksplits > 1) return 1;
+  if (!env || p.k != 3 || p.stride != 1 || p.pad != 1 || (p.Cin % 8)) return 1;
   if (p.Cout < 96 || p.Cin < 32) return 1;
   HaloParams hp;
   hp.c = p;
   if (!plan_patch(p.N, p.Ho, p.Wo, p.out_layout == LAYOUT_NCHW, &hp)) return 1;
   hp.n_tiles = (p.Cout + H3_BN - 1) / H3_BN;
+  // p.ksplits > 1 here means: the caller planned THIS kernel's split (halo_splitk_plan) and provides slabs / counters
+  hp.ksplits = p.ksplits > 1 ? p.ksplits : 1;
+  {
+    const int cch = (p.Cin + H3_BK - 1) / H3_BK;
+    hp.c_per = (cch + hp.ksplits - 1) / hp.ksplits;
+    hp.ksplits = (cch + hp.c_per - 1) / hp.c_per;  // every slice owns at least one slab
+  }
+  hp.slabs = p.slabs;
+  hp.counters = p.counters;
   auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
   hp.mg_ntiles = magic(hp.n_tiles);
   hp.mg_tx = magic(hp.tiles_x);
@@ -430,11 +511,12 @@ int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool
   hp.mg_tw = magic(hp.tw);
   hp.mg_hw2 = magic(hp.tw + 2);
   hp.mg_halo = magic((hp.th + 2) * (hp.tw + 2));
+  hp.mg_ks = magic(hp.ksplits);
   const long xb = (long)p.N * p.H * p.W * p.Cin * 2, wb = (long)p.Cout * 9 * p.Cin * 2;
   if (xb >= 0xfffffff0l || wb >= 0xfffffff0l) return 1;  // 32-bit buffer offsets
   hp.x_bytes = (unsigned)xb;
   hp.w_bytes = (unsigned)wb;
-  const long tiles = (long)hp.groups * hp.tiles_y * hp.tiles_x * hp.n_tiles;
+  const long tiles = (long)hp.groups * hp.tiles_y * hp.tiles_x * hp.n_tiles * hp.ksplits;
   if (env != 2 && !allow_underfill && tiles < 96) return 1;  // too few tiles to fill the chip: the split-K path is faster
   if (tiles >= (1l << 26)) return 1;  // keeps tile-id * divisor < 2^32 for the magic divisions
   static bool attr_done[2] = {false, false};

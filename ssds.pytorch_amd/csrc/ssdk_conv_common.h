@@ -175,6 +175,8 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
 // grouped 3x3 convolution, 16 channels per group (ssdk_gconv.hip)
 int launch_gconv3x3_g16(const ssdk_conv_desc* d, int Ho, int Wo, hipStream_t stream);
 
+// halo-tile 3x3 kernel with split-K over its channel slabs: slices to use (1: no split) and the workspace they need
+int halo_splitk_plan(int N, int Cin, int Ho, int Wo, int Cout, bool nchw, size_t* ws_bytes);
 // halo-tile 3x3 kernel (ssdk_conv3x3.hip); returns SSDK_OK, or 1 when the layer does not fit it
 int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool allow_underfill);
 

@@ -34,15 +34,57 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   const int RS = Cin * 2 + 16;                           // LDS row stride (bytes); row ROWS = zeros
   const u16* x = (const u16*)p.x;
 
-  // ---- stage the maps: 64 rows x Cin, 16-byte pieces, rows of images past N are zero -------------------------------
+  // ---- the weight stream starts first: it does not depend on the maps -----------------------------------------------
+  const int co_row0 = ((int)blockIdx.y * (int)(blockDim.x >> 6) + (int)wave) * 16;  // 1, 2 or 4 waves per workgroup
+  int co_a = co_row0 + (int)fr;
+  co_a = co_a < p.Cout ? co_a : p.Cout - 1;  // rows past Cout: computed on a valid row, never stored
+  const u16* wrow = (const u16*)p.w + (size_t)co_a * 9 * Cin + fg * 8;
+  static_assert(CS % 2 == 0, "even number of slices");
+  // k-loop: 32-channel slices outside, the nine taps inside (static: the row offsets are plain registers).  Weight
+  // fragments run TWO slices = 18 k-steps ahead of the MFMAs through 18 register stages; the loop body has no branch, so
+  // the compiler counts the loads in flight (s_waitcnt vmcnt(17)) instead of draining them -- a k-step is four MFMAs
+  // (~70 cycles), an L2 round trip 2-4k cycles, and with a branch in the body every k-step waited for its own load
+  // (1.2k cycles per k-step measured).
+  u32x4 rw[2][TAPS];
+  auto issue = [&](int buf, int t, int slc) {
+    const int s2 = slc < CS ? slc : CS - 1;  // past the end: a harmless re-read
+    rw[buf][t] = *reinterpret_cast<const u32x4*>(wrow + (size_t)((t + TAP0) * CS + s2) * 32);
+  };
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) issue(0, t, 0);
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) issue(1, t, 1);
+  // the epilogue's per-channel constants too (as first written they were loaded in the epilogue: one more exposed round trip)
+  const int co0 = co_row0 + (int)fg * 4;
+  float e_sc[4], e_bi[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = co0 + r < p.Cout ? co0 + r : p.Cout - 1;
+    e_sc[r] = p.scale ? p.scale[co] : 1.f;
+    e_bi[r] = p.bias[co];
+  }
+
+  // ---- stage the maps: ROWS rows x Cin, 16-byte pieces, rows of images past N are zero, row ROWS = zeros ---------------
+  // Batches of eight independent loads per thread, then their eight LDS stores.  (As first written -- one load, one store per
+  // loop iteration -- the nine iterations of the 4x4 level each waited a full memory round trip: ~9 us of a 19 us kernel.)
   {
-    const int cpr = Cin / 8;
-    for (int q = (int)tid; q < (ROWS + 1) * cpr; q += (int)blockDim.x) {
-      const int row = q / cpr, c = q % cpr;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < ROWS && img0 + row / P < p.N) v = *reinterpret_cast<const u32x4*>(x + ((size_t)img0 * P + row) * Cin + c * 8);
-      *reinterpret_cast<u32x4*>(smem + (size_t)row * RS + c * 16) = v;
+    constexpr int CPR = CS * 4, TOTAL = ROWS * CPR, SB = 8;
+    const int nthr = (int)blockDim.x;
+    for (int q0 = (int)tid; q0 < TOTAL; q0 += nthr * SB) {
+      u32x4 v[SB];
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        const int q = q0 + j * nthr, row = q / CPR, c = q % CPR;
+        v[j] = u32x4{0u, 0u, 0u, 0u};
+        if (q < TOTAL && img0 + row / P < p.N) v[j] = *reinterpret_cast<const u32x4*>(x + ((size_t)img0 * P + row) * Cin + c * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        const int q = q0 + j * nthr, row = q / CPR, c = q % CPR;
+        if (q < TOTAL) *reinterpret_cast<u32x4*>(smem + (size_t)row * RS + c * 16) = v[j];
+      }
     }
+    if ((int)tid < CPR) *reinterpret_cast<u32x4*>(smem + (size_t)ROWS * RS + tid * 16) = u32x4{0u, 0u, 0u, 0u};
   }
   // LDS byte offset of the input pixel behind (output pixel = fragment m, lane fr; tap), the zero row outside the map
   u32 rowoff[MFR][TAPS];
@@ -58,54 +100,40 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   }
   __syncthreads();
 
-  const int co_row0 = ((int)blockIdx.y * (int)(blockDim.x >> 6) + (int)wave) * 16;  // 1, 2 or 4 waves per workgroup
-  int co_a = co_row0 + (int)fr;
-  co_a = co_a < p.Cout ? co_a : p.Cout - 1;  // rows past Cout: computed on a valid row, never stored
-  const u16* wrow = (const u16*)p.w + (size_t)co_a * 9 * Cin + fg * 8;
-  static_assert(CS % 2 == 0, "even number of slices");
   f32x4 acc[MFR];
 #pragma unroll
   for (int m = 0; m < MFR; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // k-loop: 32-channel slices outside, the nine taps inside (static: the row offsets are plain registers).  Weight
-  // fragments run TWO slices = 18 k-steps ahead of the MFMAs through 18 register stages; the loop body has no branch, so
-  // the compiler counts the loads in flight (s_waitcnt vmcnt(17)) instead of draining them -- a k-step is four MFMAs
-  // (~70 cycles), an L2 round trip 2-4k cycles, and with a branch in the body every k-step waited for its own load
-  // (1.2k cycles per k-step measured).
-  u32x4 rw[2][TAPS];
-  auto issue = [&](int buf, int t, int slc) {
-    const int s2 = slc < CS ? slc : CS - 1;  // past the end: a harmless re-read
-    rw[buf][t] = *reinterpret_cast<const u32x4*>(wrow + (size_t)((t + TAP0) * CS + s2) * 32);
+  // The pixel operands (B fragments, LDS) run TWO k-steps ahead of the MFMAs through a ring of three register sets.  (As
+  // first written every MFMA waited for a ds_read issued one or two instructions before it -- s_waitcnt lgkmcnt(1) in front
+  // of each of the four MFMAs of a k-step: ~660 cycles per k-step for 64 cycles of matrix work, the whole kernel ran at the
+  // LDS latency of one wave per SIMD.)
+  constexpr int NS = CS * TAPS;  // k-steps: 32-channel slices outside, taps inside
+  constexpr int D = 2;           // B-fragment prefetch distance
+  u32x4 bq[D + 1][MFR];
+  auto lds_issue = [&](int slot, int step) {
+    const int t = step % TAPS, sl = step / TAPS;
+#pragma unroll
+    for (int m = 0; m < MFR; ++m) bq[slot][m] = *reinterpret_cast<const u32x4*>(smem + rowoff[m][t] + sl * 64);
   };
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t) issue(0, t, 0);
+  for (int st = 0; st < D; ++st) lds_issue(st, st < NS ? st : NS - 1);
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t) issue(1, t, 1);
+  for (int st = 0; st < NS; ++st) {
+    const int t = st % TAPS, sl = st / TAPS, bsl = sl & 1;
+    if (st + D < NS) lds_issue((st + D) % (D + 1), st + D);
 #pragma unroll
-  for (int sl0 = 0; sl0 < CS; sl0 += 2) {
-#pragma unroll
-    for (int bsl = 0; bsl < 2; ++bsl) {
-      const int sl = sl0 + bsl;
-#pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-#pragma unroll
-        for (int m = 0; m < MFR; ++m) {
-          const u32x4 b = *reinterpret_cast<const u32x4*>(smem + rowoff[m][t] + sl * 64);
-          acc[m] = mfma16<DT>(rw[bsl][t], b, acc[m]);  // D[co = 4fg + r][px = fr]
-        }
-        issue(bsl, t, sl + 2);
-        __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks every load down to its use, 18 k-steps later)
-      }
-    }
+    for (int m = 0; m < MFR; ++m) acc[m] = mfma16<DT>(rw[bsl][t], bq[st % (D + 1)][m], acc[m]);  // D[co = 4fg + r][px = fr]
+    issue(bsl, t, sl + 2);
+    __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks every load down to its use, 18 k-steps later)
   }
 
   // ---- epilogue: lane = (pixel fr of fragment m, channels co0 + 4fg .. +3) -----------------------------------------
-  const int co0 = co_row0 + (int)fg * 4;
   const bool nchw = p.out_layout == LAYOUT_NCHW;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int co = co0 + r;
     if (co >= p.Cout) continue;
-    const float sc = p.scale ? p.scale[co] : 1.f, bi = p.bias[co];
+    const float sc = e_sc[r], bi = e_bi[r];
     const ActSel as = act_sel(co >= p.split ? p.act2 : p.act);
 #pragma unroll
     for (int m = 0; m < MFR; ++m) {

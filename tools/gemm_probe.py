@@ -17,6 +17,8 @@ SHAPES = {
     "head_L1": (64, 320, 16, 16, 504, 3, 1, "head"),
     "head_L2": (64, 512, 8, 8, 504, 3, 1, "head"),
     "head_L3": (64, 256, 4, 4, 504, 3, 1, "head"),
+    "head_L4": (64, 256, 2, 2, 504, 3, 1, "head"),
+    "head_L5": (64, 128, 1, 1, 504, 3, 1, "head"),
     "tower_P3": (32, 256, 80, 80, 256, 3, 1, "relu"),
     "tower_P5": (32, 256, 20, 20, 256, 3, 1, "relu"),
     "tower_cls": (32, 256, 80, 80, 720, 3, 1, "relu"),
