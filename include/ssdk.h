@@ -259,7 +259,17 @@ typedef struct ssdk_conv_desc {
   int32_t in_layout, out_layout;
   int32_t res_mode;     /* bit 0: `residual` is half resolution [N][H/2][W/2][Cout], added nearest-x2-upsampled (FPN
                            top-down path, fpn.py:80-87); bit 1: activation applied AFTER the add (ResNet blocks) */
+  const void* w_frag;   /* optional (NULL: not given): the same weights in FRAGMENT-MAJOR order, see ssdk_weight_frag_bytes.
+                           Kernels that stream weights straight into MFMA operand registers (small maps: the weights ARE the
+                           traffic) read it instead of `w`: 1 KiB contiguous per wave instruction instead of 16 rows x 64 B,
+                           measured 40-50 instead of 14 B/clk per CU (tools/micro/wstream.hip) */
 } ssdk_conv_desc;
+/* Fragment-major image of a row-major weight matrix w[rows][K] (a KRSC conv weight: rows = Cout, K = k*k*Cin), K % 32 == 0:
+ *   frag[g][ks][fg][fr][j] = w[16*g + fr][32*ks + 8*fg + j]     g < ceil(rows/16), ks < K/32, fg < 4, fr < 16, j < 8
+ * rows past `rows` are zero.  One (g, ks) block = 1 KiB = the A operand of one v_mfma_f32_16x16x32 k-step of 16 output
+ * channels, lane (16*fg + fr) owning 16 contiguous bytes.  Pure layout: the caller builds it once per model (the Python
+ * host does it in ConvPack.frag()). */
+size_t ssdk_weight_frag_bytes(int rows, int K);
 size_t ssdk_conv_workspace_bytes(int N, int Cin, int H, int W, int Cout, int k, int stride, int dtype);
 int ssdk_conv(const ssdk_conv_desc* desc, void* workspace, size_t workspace_bytes, void* stream);
 /* a whole pre-planned network: descs[0..n) launched in order on `stream` (one host call per forward) */
@@ -412,6 +422,8 @@ typedef struct ssdk_xpair_desc {
   const float* scale2;
   const float* bias2;
   int32_t N, H, W, Cin, Cmid, Cout, act1, act2, dtype, pad;
+  const void* w1_frag;  /* optional fragment-major images of w1 [Cmid][Cin] and w2 [Cout][9*Cmid] (ssdk_weight_frag_bytes); */
+  const void* w2_frag;  /* both or neither */
 } ssdk_xpair_desc;
 int ssdk_xpair(const ssdk_xpair_desc* desc, void* stream);
 

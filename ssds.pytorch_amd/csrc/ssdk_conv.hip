@@ -973,6 +973,11 @@ static int halo_splitk_min_pixels() {  // smallest map (pixels) that goes to the
   return (e && *e) ? atoi(e) : 64;
 }
 
+extern "C" size_t ssdk_weight_frag_bytes(int rows, int K) {
+  if (rows < 1 || K < 32 || (K % 32)) return 0;
+  return (size_t)((rows + 15) / 16) * 16 * (size_t)K * 2;
+}
+
 extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ssdk::lds_poison(stream);
@@ -1094,6 +1099,7 @@ extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t worksp
   ConvParams p;
   p.x = d->x;
   p.w = d->w;
+  p.w_frag = d->w_frag;
   p.scale = d->scale;
   p.bias = d->bias;
   p.res = d->residual;

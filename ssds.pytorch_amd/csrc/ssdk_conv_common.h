@@ -16,6 +16,7 @@ enum { LAYOUT_NCHW = 0, LAYOUT_NHWC = 1 };
 struct ConvParams {
   const void* x;
   const void* w;
+  const void* w_frag;  // optional fragment-major image of w (ssdk.h: ssdk_weight_frag_bytes)
   const float* scale;
   const float* bias;
   const void* res;  // residual, same layout/dtype as y (NHWC only)

@@ -22,7 +22,8 @@ constexpr int kSmThreads = 256;
 // MFR = pixel fragments per workgroup (4: 64 pixels, 8: 128 pixels -- half the weight traffic per pixel, for the level
 // whose grid still fills the chip then)
 // TAPS = 9, or 1 for 1x1 maps: only the centre tap ever sees data there (the other eight multiply the padding), so K is Cin
-template <int DT, int CS, int MFR, int TAPS>
+// PK: weights from the fragment-major image p.w_frag (ssdk.h: 1 KiB contiguous per k-step and wave) instead of the KRSC tensor
+template <int DT, int CS, int MFR, int TAPS, bool PK>
 __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvParams p) {
   constexpr int ROWS = 16 * MFR;
   constexpr int TAP0 = TAPS == 9 ? 0 : 4;  // first tap visited
@@ -38,22 +39,33 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   const int co_row0 = ((int)blockIdx.y * (int)(blockDim.x >> 6) + (int)wave) * 16;  // 1, 2 or 4 waves per workgroup
   int co_a = co_row0 + (int)fr;
   co_a = co_a < p.Cout ? co_a : p.Cout - 1;  // rows past Cout: computed on a valid row, never stored
-  const u16* wrow = (const u16*)p.w + (size_t)co_a * 9 * Cin + fg * 8;
+  const u16* wrow = PK ? (const u16*)p.w_frag + (size_t)(co_row0 < p.Cout ? co_row0 >> 4 : (p.Cout - 1) >> 4) * 9 * Cin * 16 + lane * 8
+                       : (const u16*)p.w + (size_t)co_a * 9 * Cin + fg * 8;
   static_assert(CS % 2 == 0, "even number of slices");
-  // k-loop: 32-channel slices outside, the nine taps inside (static: the row offsets are plain registers).  Weight
-  // fragments run TWO slices = 18 k-steps ahead of the MFMAs through 18 register stages; the loop body has no branch, so
+  // k-loop (static: the row offsets are plain registers).  Weight
+  // fragments run 18 k-steps ahead of the MFMAs through 18 register stages; the loop body has no branch, so
   // the compiler counts the loads in flight (s_waitcnt vmcnt(17)) instead of draining them -- a k-step is four MFMAs
   // (~70 cycles), an L2 round trip 2-4k cycles, and with a branch in the body every k-step waited for its own load
   // (1.2k cycles per k-step measured).
-  u32x4 rw[2][TAPS];
-  auto issue = [&](int buf, int t, int slc) {
-    const int s2 = slc < CS ? slc : CS - 1;  // past the end: a harmless re-read
-    rw[buf][t] = *reinterpret_cast<const u32x4*>(wrow + (size_t)((t + TAP0) * CS + s2) * 32);
+  // Order of the k-steps.  PK: taps outside, slices inside = the order of the packed image, consecutive KiB.  KRSC: slice
+  // PAIRS outside, taps inside, the two slices of a pair innermost -- the two 64-byte halves of a weight row's 128-byte line
+  // are then fetched by neighbouring loads.
+  constexpr int RING = 2 * TAPS;  // register stages = k-steps in flight
+  u32x4 rw[RING];
+  auto kmap = [](int st, int& t, int& sl) {
+    if (PK) { t = st / CS; sl = st % CS; return; }
+    if (TAPS == 1) { t = 0; sl = st; return; }
+    const int sp = st / RING, in = st % RING;
+    t = in >> 1;
+    sl = 2 * sp + (in & 1);
+  };
+  auto issue = [&](int st) {
+    int t, sl;
+    kmap(st < CS * TAPS ? st : CS * TAPS - 1, t, sl);  // past the end: a harmless re-read
+    rw[st % RING] = *reinterpret_cast<const u32x4*>(wrow + (size_t)((t + TAP0) * CS + sl) * (PK ? 512 : 32));
   };
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t) issue(0, t, 0);
-#pragma unroll
-  for (int t = 0; t < TAPS; ++t) issue(1, t, 1);
+  for (int st = 0; st < RING; ++st) issue(st);
   // the epilogue's per-channel constants too (as first written they were loaded in the epilogue: one more exposed round trip)
   const int co0 = co_row0 + (int)fg * 4;
   float e_sc[4], e_bi[4];
@@ -65,10 +77,11 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   }
 
   // ---- stage the maps: ROWS rows x Cin, 16-byte pieces, rows of images past N are zero, row ROWS = zeros ---------------
-  // Batches of eight independent loads per thread, then their eight LDS stores.  (As first written -- one load, one store per
+  // Batches of up to 17 independent loads per thread, then their LDS stores.  (As first written -- one load, one store per
   // loop iteration -- the nine iterations of the 4x4 level each waited a full memory round trip: ~9 us of a 19 us kernel.)
   {
-    constexpr int CPR = CS * 4, TOTAL = ROWS * CPR, SB = 8;
+    constexpr int CPR = CS * 4, TOTAL = ROWS * CPR;
+    constexpr int PER = (TOTAL + kSmThreads - 1) / kSmThreads, SB = PER < 17 ? PER : 17;  // one or two round trips
     const int nthr = (int)blockDim.x;
     for (int q0 = (int)tid; q0 < TOTAL; q0 += nthr * SB) {
       u32x4 v[SB];
@@ -111,7 +124,8 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   constexpr int D = 2;           // B-fragment prefetch distance
   u32x4 bq[D + 1][MFR];
   auto lds_issue = [&](int slot, int step) {
-    const int t = step % TAPS, sl = step / TAPS;
+    int t, sl;
+    kmap(step, t, sl);
 #pragma unroll
     for (int m = 0; m < MFR; ++m) bq[slot][m] = *reinterpret_cast<const u32x4*>(smem + rowoff[m][t] + sl * 64);
   };
@@ -119,11 +133,10 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   for (int st = 0; st < D; ++st) lds_issue(st, st < NS ? st : NS - 1);
 #pragma unroll
   for (int st = 0; st < NS; ++st) {
-    const int t = st % TAPS, sl = st / TAPS, bsl = sl & 1;
     if (st + D < NS) lds_issue((st + D) % (D + 1), st + D);
 #pragma unroll
-    for (int m = 0; m < MFR; ++m) acc[m] = mfma16<DT>(rw[bsl][t], bq[st % (D + 1)][m], acc[m]);  // D[co = 4fg + r][px = fr]
-    issue(bsl, t, sl + 2);
+    for (int m = 0; m < MFR; ++m) acc[m] = mfma16<DT>(rw[st % RING], bq[st % (D + 1)][m], acc[m]);  // D[co = 4fg + r][px = fr]
+    issue(st + RING);
     __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks every load down to its use, 18 k-steps later)
   }
 
@@ -172,11 +185,18 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   const dim3 grid((unsigned)groups, (unsigned)((nfr + nw - 1) / nw));
   const size_t lds = (size_t)(16 * mfr + 1) * (p.Cin * 2 + 16);
   const int cs = p.Cin / 32;
-#define SSDK_SM1(DT, CS_, MFR_, TAPS_)                                                                                     \
+  static const int env_pk = getenv("SSDK_WFRAG") ? atoi(getenv("SSDK_WFRAG")) : 1;
+  const bool packed = p.w_frag != nullptr && env_pk != 0;
+#define SSDK_SM0(DT, CS_, MFR_, TAPS_, PK_)                                                                                \
   do {                                                                                                                     \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_, MFR_, TAPS_>),                 \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_, MFR_, TAPS_, PK_>),            \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
-    hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_, MFR_, TAPS_>), grid, dim3(64 * nw), lds, stream, p);                 \
+    hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_, MFR_, TAPS_, PK_>), grid, dim3(64 * nw), lds, stream, p);            \
+  } while (0)
+#define SSDK_SM1(DT, CS_, MFR_, TAPS_)               \
+  do {                                               \
+    if (packed) SSDK_SM0(DT, CS_, MFR_, TAPS_, true); \
+    else SSDK_SM0(DT, CS_, MFR_, TAPS_, false);      \
   } while (0)
 #define SSDK_SM(DT, CS_)                       \
   do {                                         \
@@ -195,6 +215,7 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   }
 #undef SSDK_SM
 #undef SSDK_SM1
+#undef SSDK_SM0
   return 0;
 }
 

@@ -40,7 +40,8 @@ __device__ __forceinline__ float xp_act(float v, int act) {
 // NF2 = output-channel fragments of the workgroup's quarter (Cout = 64 * NF2; KSPLIT = 4 / NF2 waves share a fragment and
 // split the 32-channel slices), CS1 = Cin / 32.  Both k-loops are unrolled completely and have no branch: only then does
 // the compiler count the loads in flight (s_waitcnt vmcnt(n)) instead of draining them at every loop back edge / merge.
-template <int DT, int MF1, int NPW, int NF2, int CS1>
+// PK: both weight matrices come as fragment-major images (ssdk.h ssdk_weight_frag_bytes: 1 KiB contiguous per wave load)
+template <int DT, int MF1, int NPW, int NF2, int CS1, bool PK>
 __global__ __launch_bounds__(kXpThreads) void xpair_kernel(const XpairParams p) {
   constexpr int KSPLIT = 4 / NF2;
   constexpr int CSM = 2 * NPW;          // 32-channel slices of the intermediate map
@@ -74,11 +75,12 @@ __global__ __launch_bounds__(kXpThreads) void xpair_kernel(const XpairParams p) 
       xa[m] = p.x + ((size_t)n * P + px) * Cin + fg * 8;
     }
 #pragma unroll
-    for (int a = 0; a < NPW; ++a) wa[a] = p.w1 + (size_t)((wave + 4u * (u32)a) * 16u + fr) * Cin + fg * 8;
+    for (int a = 0; a < NPW; ++a)
+      wa[a] = PK ? p.w1 + (size_t)(wave + 4u * (u32)a) * CS1 * 512 + lane * 8 : p.w1 + (size_t)((wave + 4u * (u32)a) * 16u + fr) * Cin + fg * 8;
     u32x4 ra[PF][NPW], rb[PF][MF1];
     auto issue = [&](int slot, int ks) {
 #pragma unroll
-      for (int a = 0; a < NPW; ++a) ra[slot][a] = *reinterpret_cast<const u32x4*>(wa[a] + ks * 32);
+      for (int a = 0; a < NPW; ++a) ra[slot][a] = *reinterpret_cast<const u32x4*>(wa[a] + ks * (PK ? 512 : 32));
 #pragma unroll
       for (int m = 0; m < MF1; ++m) rb[slot][m] = *reinterpret_cast<const u32x4*>(xa[m] + ks * 32);
     };
@@ -125,24 +127,31 @@ __global__ __launch_bounds__(kXpThreads) void xpair_kernel(const XpairParams p) 
     }
   }
   f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-  const u16* w2row = p.w2 + (size_t)co_row * 9 * Cmid + fg * 8 + (size_t)sl_beg * 32;
+  const u16* w2row = PK ? p.w2 + ((size_t)(cq * NF2 + nf) * 9 * CSM + sl_beg) * 512 + lane * 8
+                        : p.w2 + (size_t)co_row * 9 * Cmid + fg * 8 + (size_t)sl_beg * 32;
   u32x4 rw[RB][9];
   auto issue2 = [&](int buf, int t, int s) {  // weights of (tap t, slice sl_beg + s)
-    rw[buf][t] = *reinterpret_cast<const u32x4*>(w2row + (size_t)t * Cmid + s * 32);
+    rw[buf][t] = *reinterpret_cast<const u32x4*>(PK ? w2row + (size_t)(t * CSM + s) * 512 : w2row + (size_t)t * Cmid + s * 32);
   };
+  // k-step order: slice pairs outside, taps inside, the two slices of a pair innermost -- neighbouring loads then fetch the
+  // two 64-byte halves of the same 128-byte weight line (as in conv_smallmap_kernel)
 #pragma unroll
-  for (int b2 = 0; b2 < RB; ++b2)
+  for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) issue2(b2, t, b2);  // in flight under the rest of phase 1 of the other waves
+    for (int b2 = 0; b2 < RB; ++b2) issue2(b2, t, b2);  // in flight under the rest of phase 1 of the other waves
   __syncthreads();  // the intermediate map is complete
 #pragma unroll
-  for (int s = 0; s < SPW; ++s) {
+  for (int sp = 0; sp < SPW; sp += RB) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const u32x4 bfrag = *reinterpret_cast<const u32x4*>(smem + rowoff[t] + (sl_beg + s) * 64);
-      acc2 = mfma16<DT>(rw[s % RB][t], bfrag, acc2);  // D[co = 4fg + r][opx = fr]
-      if (s + RB < SPW) issue2(s % RB, t, s + RB);  // (compile-time condition)
-      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int h = 0; h < RB; ++h) {
+        const int s = sp + h;
+        const u32x4 bfrag = *reinterpret_cast<const u32x4*>(smem + rowoff[t] + (sl_beg + s) * 64);
+        acc2 = mfma16<DT>(rw[h][t], bfrag, acc2);  // D[co = 4fg + r][opx = fr]
+        if (s + RB < SPW) issue2(h, t, s + RB);  // (compile-time condition)
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
   if constexpr (KSPLIT > 1) {
@@ -166,8 +175,9 @@ __global__ __launch_bounds__(kXpThreads) void xpair_kernel(const XpairParams p) 
 }
 
 template <int DT, int MF1, int NPW, int NF2, int CS1>
-static void xp_launch(const XpairParams& p, size_t lds, hipStream_t stream) {
-  hipLaunchKernelGGL((xpair_kernel<DT, MF1, NPW, NF2, CS1>), dim3((unsigned)p.N * 4u), dim3(kXpThreads), lds, stream, p);
+static void xp_launch(const XpairParams& p, bool packed, size_t lds, hipStream_t stream) {
+  if (packed) hipLaunchKernelGGL((xpair_kernel<DT, MF1, NPW, NF2, CS1, true>), dim3((unsigned)p.N * 4u), dim3(kXpThreads), lds, stream, p);
+  else hipLaunchKernelGGL((xpair_kernel<DT, MF1, NPW, NF2, CS1, false>), dim3((unsigned)p.N * 4u), dim3(kXpThreads), lds, stream, p);
 }
 
 }  // namespace ssdk
@@ -193,10 +203,12 @@ extern "C" int ssdk_xpair(const ssdk_xpair_desc* d, void* stream_) {
   XpairParams p;
   p.x = (const u16*)d->x;
   p.y = (u16*)d->y;
-  p.w1 = (const u16*)d->w1;
+  static const int env_pk = getenv("SSDK_WFRAG") ? atoi(getenv("SSDK_WFRAG")) : 1;
+  const bool packed = d->w1_frag && d->w2_frag && env_pk != 0;
+  p.w1 = (const u16*)(packed ? d->w1_frag : d->w1);
   p.s1 = d->scale1;
   p.b1 = d->bias1;
-  p.w2 = (const u16*)d->w2;
+  p.w2 = (const u16*)(packed ? d->w2_frag : d->w2);
   p.s2 = d->scale2;
   p.b2 = d->bias2;
   p.N = d->N;
@@ -214,10 +226,10 @@ extern "C" int ssdk_xpair(const ssdk_xpair_desc* d, void* stream_) {
   // the instances that exist (every one is a fully unrolled kernel): the three extras of SSD-MobileNetV2@512 and a 128-wide one
 #define SSDK_XP(DT)                                                                                     \
   do {                                                                                                  \
-    if (mf1 == 4 && npw == 2 && nf2 == 4 && cs1 == 16) xp_launch<DT, 4, 2, 4, 16>(p, lds, stream);      \
-    else if (mf1 == 1 && npw == 2 && nf2 == 4 && cs1 == 8) xp_launch<DT, 1, 2, 4, 8>(p, lds, stream);   \
-    else if (mf1 == 1 && npw == 1 && nf2 == 2 && cs1 == 8) xp_launch<DT, 1, 1, 2, 8>(p, lds, stream);   \
-    else if (mf1 == 1 && npw == 1 && nf2 == 2 && cs1 == 4) xp_launch<DT, 1, 1, 2, 4>(p, lds, stream);   \
+    if (mf1 == 4 && npw == 2 && nf2 == 4 && cs1 == 16) xp_launch<DT, 4, 2, 4, 16>(p, packed, lds, stream);      \
+    else if (mf1 == 1 && npw == 2 && nf2 == 4 && cs1 == 8) xp_launch<DT, 1, 2, 4, 8>(p, packed, lds, stream);   \
+    else if (mf1 == 1 && npw == 1 && nf2 == 2 && cs1 == 8) xp_launch<DT, 1, 1, 2, 8>(p, packed, lds, stream);   \
+    else if (mf1 == 1 && npw == 1 && nf2 == 2 && cs1 == 4) xp_launch<DT, 1, 1, 2, 4>(p, packed, lds, stream);   \
     else {                                                                                              \
       set_error("xpair: no instance for %d pixel fragments, Cin=%d, Cmid=%d, Cout=%d", mf1, d->Cin, d->Cmid, d->Cout); \
       return SSDK_E_BADARG;                                                                             \

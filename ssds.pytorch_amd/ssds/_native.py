@@ -48,7 +48,7 @@ class ConvDesc(ctypes.Structure):
         ("Cout", ctypes.c_int32), ("k", ctypes.c_int32), ("stride", ctypes.c_int32), ("groups", ctypes.c_int32),
         ("act", ctypes.c_int32), ("act2", ctypes.c_int32), ("split", ctypes.c_int32),
         ("dtype", ctypes.c_int32), ("in_layout", ctypes.c_int32), ("out_layout", ctypes.c_int32),
-        ("res_mode", ctypes.c_int32),
+        ("res_mode", ctypes.c_int32), ("w_frag", ctypes.c_void_p),
     ]
 
 
@@ -81,7 +81,8 @@ class PoolDesc(ctypes.Structure):
 
 class XpairDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ("x", "y", "w1", "scale1", "bias1", "w2", "scale2", "bias2")] + [
-        (n, ctypes.c_int32) for n in ("N", "H", "W", "Cin", "Cmid", "Cout", "act1", "act2", "dtype", "pad")]
+        (n, ctypes.c_int32) for n in ("N", "H", "W", "Cin", "Cmid", "Cout", "act1", "act2", "dtype", "pad")] + [
+        ("w1_frag", ctypes.c_void_p), ("w2_frag", ctypes.c_void_p)]
 
 
 class Op(ctypes.Structure):
@@ -177,6 +178,8 @@ def _load():
     lib.ssdk_map_match.argtypes = [vp, vp, vp, i32, i32, vp, i32, i32, f32, f32, vp, vp, vp, vp]
     lib.ssdk_map_average_precision.restype = i32
     lib.ssdk_map_average_precision.argtypes = [vp, vp, vp, i32, vp, vp]
+    lib.ssdk_weight_frag_bytes.restype = sz
+    lib.ssdk_weight_frag_bytes.argtypes = [i32, i32]
     lib.ssdk_conv_workspace_bytes.restype = sz
     lib.ssdk_conv_workspace_bytes.argtypes = [i32] * 8
     lib.ssdk_conv_bn_act.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32,
@@ -208,7 +211,7 @@ EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_p
            "ssdk_ctx_create", "ssdk_ctx_destroy", "ssdk_ctx_set_tail_stream", "ssdk_ctx_set_side_lane", "ssdk_ctx_set_profiling",
            "ssdk_ctx_get_timings", "ssdk_ctx_set_op_profiling", "ssdk_ctx_get_op_timings", "ssdk_ctx_get_tail_stamps",
            "ssdk_run_ops_ctx", "ssdk_decode_nms_ctx",
-           "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_xpair", "ssdk_fuse", "ssdk_preprocess", "ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data",
+           "ssdk_weight_frag_bytes", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_xpair", "ssdk_fuse", "ssdk_preprocess", "ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data",
            "ssdk_dwconv_bwd_weight_workspace_bytes", "ssdk_dwconv_bwd_weight", "ssdk_dwconv_plan", "ssdk_bn_workspace_bytes",
            "ssdk_bn_train_fwd", "ssdk_bn_train_bwd", "ssdk_bn_act_train_fwd", "ssdk_bn_act_train_bwd", "ssdk_conv_stem7", "ssdk_maxpool3x3s2", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 

@@ -77,12 +77,39 @@ def conv_kind(conv):
     return None
 
 
+# Fragment-major weight images for the kernels that stream weights into operand registers (ConvPack.frag); False keeps
+# those kernels on the KRSC tensor (A/B runs and the test of that path).
+USE_WFRAG = os.environ.get("SSDK_WFRAG", "1") != "0"
+
+
 class ConvPack(object):
     """Weights of one fused layer in kernel layout (built once per model/dtype)."""
 
-    __slots__ = ("kind", "w", "scale", "bias", "cin", "cout", "k", "stride", "groups", "act")
+    __slots__ = ("kind", "w", "scale", "bias", "cin", "cout", "k", "stride", "groups", "act", "_frag")
+
+    def frag(self):
+        """Fragment-major image of the dense weights (include/ssdk.h ``ssdk_weight_frag_bytes``) for the kernels that stream
+        weights straight into MFMA operand registers (conv_smallmap, xpair); None where no such kernel applies.  Built once
+        per weight tensor (pure layout: [rows][K] -> [rows/16][K/32][4][16][8], rows zero-padded to a multiple of 16)."""
+        k_elems = self.k * self.k * self.cin
+        if (not USE_WFRAG or self.kind != "dense" or self.w.dtype not in (torch.bfloat16, torch.float16) or k_elems % 32
+                or self.cin % 32):
+            return None
+        cached = getattr(self, "_frag", None)
+        if cached is not None and cached[0] == (self.w.data_ptr(), self.w._version):
+            return cached[1]
+        rows = self.cout
+        g = (rows + 15) // 16
+        w2d = self.w.reshape(rows, k_elems)
+        if g * 16 != rows:
+            w2d = torch.cat([w2d, w2d.new_zeros((g * 16 - rows, k_elems))], 0)
+        img = w2d.view(g, 16, k_elems // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+        assert img.numel() * 2 == N.lib.ssdk_weight_frag_bytes(rows, k_elems)
+        self._frag = ((self.w.data_ptr(), self.w._version), img)
+        return img
 
     def __init__(self, conv, bn, act, dtype, extra_cout=None):
+        self._frag = None
         self.kind = conv_kind(conv)
         if self.kind is None:
             raise N.SsdkError("conv {} is not covered by the HIP kernels".format(conv))
@@ -275,6 +302,8 @@ def fill_xpair_desc(d, x_ptr, y_ptr, n, h, w, p1, p2, dtype_code):
     d.x, d.y = x_ptr, y_ptr
     d.w1, d.scale1, d.bias1 = p1.w.data_ptr(), p1.scale.data_ptr(), p1.bias.data_ptr()
     d.w2, d.scale2, d.bias2 = p2.w.data_ptr(), p2.scale.data_ptr(), p2.bias.data_ptr()
+    f1, f2 = p1.frag(), p2.frag()
+    d.w1_frag, d.w2_frag = (f1.data_ptr(), f2.data_ptr()) if f1 is not None and f2 is not None else (None, None)
     d.N, d.H, d.W, d.Cin, d.Cmid, d.Cout = n, h, w, p1.cin, p1.cout, p2.cout
     d.act1, d.act2, d.dtype = N.ACT[p1.act], N.ACT[p2.act], dtype_code
     return d
@@ -352,6 +381,9 @@ def _out_hw(h, w, k, stride):
 def fill_desc(d, x_ptr, n, h, w, pack, dtype_code, act, y_ptr, in_layout=N.NHWC, out_layout=N.NHWC,
               residual_ptr=None, y2_ptr=None, split=None, act2=None):
     d.x, d.w = x_ptr, pack.w.data_ptr()
+    # small maps: the kernel streams weights into operand registers and wants them fragment-major (conv_smallmap_kernel)
+    frag = pack.frag() if (pack.kind == "dense" and pack.k == 3 and pack.stride == 1 and h * w <= 64) else None
+    d.w_frag = frag.data_ptr() if frag is not None else None
     d.scale = pack.scale.data_ptr() if pack.scale is not None else None
     d.bias = pack.bias.data_ptr()
     d.residual, d.y, d.y2 = residual_ptr, y_ptr, y2_ptr

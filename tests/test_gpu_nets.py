@@ -33,7 +33,7 @@ CAP = {"bfloat16": 0.9, "float16": 0.3}  # absolute cap on the median error (a w
 SLACK = {"bfloat16": (0.06, 0.2), "float16": (0.015, 0.05)}
 
 
-def _check_against_floor(plan_out, torch_out, want, what, dtype, tail_factor=2.0):
+def _check_against_floor(plan_out, torch_out, want, what, dtype, tail_factor=2.0, tail_up_to_floor_max=False):
     """Untrained deep networks amplify rounding noise (torch's own bf16 execution of MobileNetV2 is 0.1-0.6 RMS away
     from fp32 at the deeper levels), so the bar is relative to the noise floor of the SAME module executed by
     PyTorch-ROCm in the SAME dtype: the plan must be as close to the reference's fp32 outputs as that, up to a factor
@@ -46,7 +46,14 @@ def _check_against_floor(plan_out, torch_out, want, what, dtype, tail_factor=2.0
             sp, st = _stats(p, w), _stats(t, w)
             report.append("%s%d plan %.4f/%.4f/%.4f floor %.4f/%.4f/%.4f" % ((tag, i) + sp + st))
             m_abs, p_abs = SLACK[dtype]
-            if not (sp[0] <= 2.0 * st[0] + m_abs and sp[1] <= tail_factor * st[1] + p_abs and sp[0] <= CAP[dtype]):
+            # tail_up_to_floor_max (bench sizes only): a sigmoid output whose logit sits near 0 turns a logit error d into
+            # d/4, i.e. ~25 d in units of the RMS of an output that is ~0.01 everywhere else; on the untrained FPN-R50@640 in
+            # fp16 both executions have such elements (max 27 RMS in both), how many of them cross the 99.9th percentile
+            # varies from run to run in the torch floor itself (1.7-3.2) -- the plan's tail may reach the floor's own maximum
+            tail_bar = tail_factor * st[1] + p_abs
+            if tail_up_to_floor_max:
+                tail_bar = max(tail_bar, st[2])
+            if not (sp[0] <= 2.0 * st[0] + m_abs and sp[1] <= tail_bar and sp[0] <= CAP[dtype]):
                 bad.append(report[-1])
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
