@@ -1196,6 +1196,7 @@ extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t worksp
       p.slabs = (float*)((char*)workspace + 4096);
     }
   }
+  if (launch_conv3x3_short(p, d->dtype, stream) == 0) return check_launch("conv3x3_short_kernel");  // short K, two workgroups per CU
   {
     const int rc = launch_conv3x3_halo(p, d->dtype, stream, false);  // 3x3 stride-1 layers with enough tiles
     if (rc != 1) return rc;

@@ -1,0 +1,334 @@
+// ssdk_conv3x3s.hip -- 3x3 / stride-1 convolution with a SHORT K (Cin <= 128) on the matrix cores: the multibox head of the
+// first SSD level (reference ssd.py:100-103 on the 96-channel 32x32 map: K = 864, N = 504, M = 65 536 at batch 64).
+//
+// Why a second halo kernel: conv3x3_halo_kernel owns all 160 KiB of LDS (two 64-channel halo slabs + a weight ring), i.e. ONE
+// workgroup per CU, and with K = 864 its main loop is only half of a tile's time -- address set-up, the first halo round
+// trip and above all the epilogue (sigmoid on 480 of 504 columns, 16-bit conversion, stores) run with the matrix cores idle
+// (measured per tile: 4.2 k + 2.2 k cycles before, 12.3 k + 3.6 k cycles behind a 25.6 k loop: 24 % of the MFMA peak).
+// Here K is short enough for the WHOLE halo of a 128-pixel patch to sit in LDS ((th+2)(tw+2) rows of Cin channels: 42 KiB at
+// Cin = 96), so a workgroup keeps its patch and walks over ALL output-channel tiles:
+//
+//   * workgroup = one 128-pixel patch (th x tw of one image), 4 waves as 2 (M) x 2 (N); per 128-channel tile 4 x 4
+//     accumulator fragments of v_mfma_f32_16x16x32 per wave; the halo is staged ONCE for the ceil(Cout / 128) tiles, and
+//     nothing else ever writes LDS: there is no barrier behind the staging;
+//   * k-step = (tap, 32-channel slice), taps outside: the A fragment of a lane is 16 bytes of the halo row of "its" pixel
+//     shifted by the tap -- an address offset; rows are padded to an odd number of 16-byte chunks (conflict-free ds_read_b128);
+//   * the B fragments (weights) go straight from the fragment-major image (ssdk.h ssdk_weight_frag_bytes) into operand
+//     registers: a wave's 64 channels x 32 k are four coalesced 1 KiB loads, three k-steps ahead through three register
+//     sets (9 * Cin / 32 k-steps per tile is a multiple of three: the ring runs on across tiles).  Measured against staging
+//     them through a three-deep LDS ring with one barrier per k-step: the same 78 us -- the loop was not what bound it;
+//   * what bound it was the epilogue (sigmoid on 480 of 504 columns: ~60 VALU instructions per fragment, 25 us over the
+//     launch).  The epilogue of tile t is INTERLEAVED with the main loop of tile t + 1: the finished accumulators move to a
+//     second register set and one fragment per k-step is scaled / activated / converted / stored, its instructions issued
+//     BETWEEN that step's MFMAs (sched_group_barrier: one MFMA, four VALU, ...): a MFMA holds the matrix pipe for 16 cycles
+//     but the issue port for 4.  For that the fragment has to be straight-line code in the MFMAs' basic block: activation
+//     classes are template parameters, the per-lane activation select is two plain selects, and stores are raw buffer
+//     stores whose out-of-range offset masks a lane (no exec-mask branch).  (First version: one tile per workgroup, two
+//     workgroups per CU -- all workgroups start together, so both were in their epilogue at the same time: loop 44 us +
+//     epilogue 30 us + staging 10 us ran back to back.  Second: epilogue code behind the 16 MFMAs of its k-step, in program
+//     order: no overlap at all, 78 us.  Interleaved: 66-68 us.)
+//   * stores go straight from the accumulators: with pixels as the A operand a lane holds four consecutive pixels of one
+//     channel = 8 contiguous bytes of an NCHW plane (split loc | conf heads).  NCHW output only (the heads), Wo % 4 == 0;
+//     NHWC layers of this shape stay on conv3x3_halo_kernel.
+#include "ssdk_conv_common.h"
+
+namespace ssdk {
+
+constexpr int S3_THREADS = 256, S3_BN = 128, S3_PIX = 128;
+
+struct ShortParams {
+  ConvParams c;
+  int th, tw, tw_shift;  // patch (th * tw == 128, tw a power of two >= 8)
+  int tiles_y, tiles_x, n_tiles;
+  int hw2, hrows;        // tw + 2, (th + 2) * (tw + 2)
+  int groups;            // ceil(Cout / 16): 16-row groups of the fragment-major weight image
+  unsigned mg_tx, mg_ty, mg_hw2;
+  unsigned y1bytes, y2bytes;  // buffer-descriptor ranges of the two outputs (< 4 GiB each)
+};
+
+__device__ __forceinline__ u32 s3_div(u32 n, u32 d, u32 M) { return d == 1u ? n : __umulhi(n, M); }
+
+// CS = Cin / 32 (1..4); SIG / CLAMP: does any column of this launch use a sigmoid-type / a clamp-type activation (compile
+// time: the epilogue must be straight-line code to be scheduled between the MFMAs)
+template <int DT, int CS, bool SIG, bool CLAMP>
+__global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_short_kernel(const ShortParams sp) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const ConvParams& p = sp.c;
+  constexpr int RS = CS * 64 + 16;  // halo row stride (bytes): an odd number of 16-byte chunks
+  constexpr int NS = 9 * CS;        // k-steps per channel tile (a multiple of 3)
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const u32 wm = wave >> 1, wn = wave & 1u, fr = lane & 15u, fg = lane >> 4;
+
+  u32 pq = s3_div(blockIdx.x, (u32)sp.tiles_x, sp.mg_tx);
+  const u32 tx = blockIdx.x - pq * (u32)sp.tiles_x;
+  const u32 b = s3_div(pq, (u32)sp.tiles_y, sp.mg_ty);
+  const u32 ty = pq - b * (u32)sp.tiles_y;
+  const int y0 = (int)ty * sp.th, x0 = (int)tx * sp.tw;
+
+  // ---- weights: the B fragments of this wave's 64 channels (blocks g = 8 nt + 4 wn + j of the image), straight from
+  //      global memory into operand registers, three k-steps ahead (uniform block offset + 32-bit lane offset: the loads take
+  //      the scalar-base form)
+  const unsigned char* wbase = (const unsigned char*)p.w_frag;
+  const u32 wlane = lane * 16u;
+  auto woff = [&](u32 nt, int j) -> size_t {  // byte offset of block (g, k-step 0): uniform
+    u32 g = nt * 8u + 4u * wn + (u32)j;
+    g = g < (u32)sp.groups ? g : (u32)sp.groups - 1u;  // groups past Cout: any valid block (never stored)
+    return (size_t)g * NS * 1024;
+  };
+  auto ldw = [&](size_t off) { return *reinterpret_cast<const u32x4*>(wbase + off + wlane); };
+  u32x4 fbq[3][4];  // register set q holds the B fragments of a k-step s with s % 3 == q
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fbq[s][j] = ldw(woff(0, j) + (size_t)s * 1024);
+
+  // ---- halo: (th+2) x (tw+2) rows of Cin channels, zeros outside the image, batches of independent 16-byte loads --------
+  {
+    constexpr int CPR = CS * 4;  // 16-byte pieces per row
+    const int total = sp.hrows * CPR;
+    const u16* xb = (const u16*)p.x + (size_t)b * p.H * p.W * p.Cin;
+    constexpr int SB = 10;
+    for (int q0 = (int)tid; q0 < total; q0 += S3_THREADS * SB) {
+      u32x4 v[SB];
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        const int q = q0 + j * S3_THREADS;
+        const u32 row = (u32)q / (u32)CPR, cpiece = (u32)q - row * (u32)CPR;
+        const u32 hy = s3_div(row, (u32)sp.hw2, sp.mg_hw2), hx = row - hy * (u32)sp.hw2;
+        const int iy = y0 + (int)hy - 1, ix = x0 + (int)hx - 1;
+        v[j] = u32x4{0u, 0u, 0u, 0u};
+        if (q < total && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          v[j] = *reinterpret_cast<const u32x4*>(xb + ((size_t)iy * p.W + ix) * p.Cin + cpiece * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        const int q = q0 + j * S3_THREADS;
+        const u32 row = (u32)q / (u32)CPR, cpiece = (u32)q - row * (u32)CPR;
+        if (q < total) *reinterpret_cast<u32x4*>(smem + (size_t)row * RS + cpiece * 16) = v[j];
+      }
+    }
+  }
+
+  // ---- fragment roles ----------------------------------------------------------------------------------------------------
+  u32 a_ad[4];  // LDS byte address of pixel fragment i at tap (0, 0), slice 0
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u32 ml = wm * 64u + (u32)i * 16u + fr;
+    const u32 y = ml >> sp.tw_shift, x = ml & (u32)(sp.tw - 1);
+    a_ad[i] = (y * (u32)sp.hw2 + x) * (u32)RS + fg * 16u;
+  }
+  // output pixels of this lane's four accumulator rows (fragment i: pixels wm*64 + 16 i + 4 fg .. +3, one map row)
+  u32 o_off[4];  // oy * Wo + ox, or ~0 outside the map
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u32 ml = wm * 64u + (u32)i * 16u + fg * 4u;
+    const int oy = y0 + (int)(ml >> sp.tw_shift), ox = x0 + (int)(ml & (u32)(sp.tw - 1));
+    o_off[i] = (oy < p.Ho && ox < p.Wo) ? (u32)(oy * p.Wo + ox) : 0xffffffffu;
+  }
+  const u32 hw = (u32)(p.Ho * p.Wo);
+
+  f32x4 acc[4][4], prev[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = prev[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // epilogue constants of the tile whose accumulators sit in `prev`: column j = channel e_n0 + 16 j (kept small: the main
+  // loop lives at the 256-register limit of two workgroups per CU -- activation selectors and plane pointers are rebuilt
+  // per fragment from the channel number, in the MFMAs' shadow)
+  float e_sc[4], e_bi[4];
+  u32 e_n0 = 0;
+  const ActSel as_a = act_sel(p.act), as_b = act_sel(p.act2);
+  // Branch-free: raw buffer stores, one per output tensor (loc | conf planes); a lane that has nothing to store there carries
+  // an out-of-range offset and the hardware drops it -- no exec-mask branch, so the whole fragment stays in the basic block of
+  // the MFMAs it is scheduled between.
+  const __amdgpu_buffer_rsrc_t yr1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, sp.y1bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y2 ? p.y2 : p.y), 0, sp.y2bytes, 0x00020000);
+  auto epi_frag = [&](const f32x4& a, int i, int j) {
+    const u32 n = e_n0 + (u32)j * 16u;
+    const bool second = (int)n >= p.split;
+    ActSel as;
+    as.lo = second ? as_b.lo : as_a.lo;
+    as.hi = second ? as_b.hi : as_a.hi;
+    as.mode = second ? as_b.mode : as_a.mode;
+    // (epilogue4 of ssdk_conv_common.h with the activation select written as two plain selects: as a nested conditional
+    //  with a multiply in one arm it compiles to exec-mask branches -- basic-block boundaries the scheduler cannot cross)
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = a[r] * e_sc[j] + e_bi[j];
+      if (SIG) {
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * v[r]));
+        const float t = v[r] * sg;
+        const float u = as.mode == 1 ? sg : v[r];
+        v[r] = as.mode == 2 ? t : u;
+      }
+      if (CLAMP) v[r] = __builtin_fminf(__builtin_fmaxf(v[r], as.lo), as.hi);
+    }
+    const uint2 h = make_uint2(pack2_16<DT>(v[0], v[1]), pack2_16<DT>(v[2], v[3]));
+    const u32 plane = second ? ((b * (u32)(p.Cout - p.split) + (n - (u32)p.split)) * hw) * 2u : ((b * (u32)p.split + n) * hw) * 2u;
+    const bool ok = n < (u32)p.Cout && o_off[i] != 0xffffffffu;
+    const u32 off = plane + o_off[i] * 2u;
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(v2u{h.x, h.y}, yr1, (int)(ok && !second ? off : 0xfffffff0u), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(v2u{h.x, h.y}, yr2, (int)(ok && second ? off : 0xfffffff0u), 0, 0);
+  };
+  __syncthreads();
+
+  // one channel tile: NS k-steps, completely unrolled (the compiler counts the loads / stores in flight).  EPI: finish the
+  // fragments of the previous tile along the way (ceil(16 / NS) per k-step)
+  auto run_tile = [&](u32 nt, auto epi_tag) {
+    constexpr bool EPI = decltype(epi_tag)::value;
+    constexpr int FPS = (16 + NS - 1) / NS;
+    const u32 ntn = nt + 1u < (u32)sp.n_tiles ? nt + 1u : nt;  // behind the last tile: harmless re-reads of its own weights
+    size_t wc[4], wx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      wc[j] = woff(nt, j);
+      wx[j] = woff(ntn, j);
+    }
+    const u32 nbase = nt * S3_BN + wn * 64u + fr;
+    constexpr int KC = (16 + FPS - 1) / FPS;  // k-step in which this tile's epilogue constants are requested: the previous
+                                              // tile's fragments -- which still use e_sc / e_bi -- are finished by then
+    static_assert(KC <= NS - 1, "the constants must be requested inside the tile's loop");
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      const int tap = ks / CS, sl = ks % CS;
+      const u32 toff = (u32)((tap / 3) * sp.hw2 + (tap % 3)) * (u32)RS + (u32)sl * 64u;
+      u32x4 fa[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(smem + a_ad[i] + toff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<DT>(fa[i], fbq[ks % 3][j], acc[i][j]);
+      if (EPI) {
+#pragma unroll
+        for (int e = ks * FPS; e < (ks + 1) * FPS && e < 16; ++e) epi_frag(prev[e >> 2][e & 3], e >> 2, e & 3);
+      }
+      {
+        const int k3 = ks + 3;  // the B fragments of step ks + 3 into the set just used
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          fbq[ks % 3][j] = ldw(k3 < NS ? wc[j] + (size_t)k3 * 1024 : wx[j] + (size_t)(k3 - NS) * 1024);
+      }
+      // issue order inside the k-step: one MFMA, then a few of the epilogue's VALU instructions, 16 times over -- a MFMA
+      // holds the matrix pipe for 16 cycles but the issue port for 4, and left to itself the scheduler emits the 16 MFMAs
+      // back to back and the epilogue behind them (measured: the "interleaved" epilogue then cost as much as a separate one)
+      if (EPI && ks * FPS < 16) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 4 * FPS, 0);  // VALU
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks == KC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32 n = nbase + (u32)j * 16u, nn = n < (u32)p.Cout ? n : (u32)p.Cout - 1u;
+          const float sv = (p.scale ? p.scale : p.bias)[nn];  // (no branch: a select of the address, then of the value)
+          e_sc[j] = p.scale ? sv : 1.f;
+          e_bi[j] = p.bias[nn];
+        }
+      }
+    }
+    // hand the accumulators over
+    e_n0 = nbase;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        prev[i][j] = acc[i][j];
+        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  };
+  // (the B fragments of steps 0..2 of tile 0 are in fbq; step ks loads ks + 3, and every later tile finds its first three
+  //  steps loaded by the previous tile's last ones)
+  run_tile(0u, std::false_type{});
+  for (u32 nt = 1; nt < (u32)sp.n_tiles; ++nt) run_tile(nt, std::true_type{});
+  // the last tile's epilogue has no main loop to hide behind
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) epi_frag(prev[i][j], i, j);
+}
+
+// 1: not one of this kernel's layers (the caller goes on), 0: launched
+int launch_conv3x3_short(const ConvParams& p, int dtype, hipStream_t stream) {
+  static const int env = getenv("SSDK_CONV3X3_SHORT") ? atoi(getenv("SSDK_CONV3X3_SHORT")) : 1;
+  static const int env_pk = getenv("SSDK_WFRAG") ? atoi(getenv("SSDK_WFRAG")) : 1;
+  if (!env || !env_pk || !p.w_frag || p.k != 3 || p.stride != 1 || p.pad != 1 || p.H != p.Ho || p.W != p.Wo) return 1;
+  if ((p.Cin % 32) || p.Cin > 128 || p.Cout < 96 || p.in_layout != LAYOUT_NHWC || p.res || p.post != SSDK_ACT_NONE) return 1;
+  if (p.out_layout != LAYOUT_NCHW) return 1;
+  if (p.Ho * p.Wo < S3_PIX || p.Wo < 8 || (p.Wo & 3)) return 1;  // (8-byte stores of four pixels of a map row)
+  ShortParams sp;
+  sp.c = p;
+  // patch: th x tw = 128 pixels, tw a power of two; the shape that wastes the fewest tile rows, wide ones preferred (NCHW
+  // stores: long runs per channel)
+  int best_tw = 0;
+  double best_u = 0.0;
+  for (int t = 8; t <= 64 && t <= 2 * p.Wo; t *= 2) {
+    const int th = S3_PIX / t;
+    const double u = (double)p.Ho * p.Wo / ((double)((p.Ho + th - 1) / th) * ((p.Wo + t - 1) / t) * S3_PIX) * (1.0 + 0.01 * t / 64.0);
+    if (u > best_u) {
+      best_u = u;
+      best_tw = t;
+    }
+  }
+  if (best_u < 0.6) return 1;
+  sp.tw = best_tw;
+  sp.th = S3_PIX / best_tw;
+  sp.tw_shift = 0;
+  while ((1 << sp.tw_shift) < sp.tw) ++sp.tw_shift;
+  sp.tiles_y = (p.Ho + sp.th - 1) / sp.th;
+  sp.tiles_x = (p.Wo + sp.tw - 1) / sp.tw;
+  sp.n_tiles = (p.Cout + S3_BN - 1) / S3_BN;
+  sp.hw2 = sp.tw + 2;
+  sp.hrows = (sp.th + 2) * (sp.tw + 2);
+  sp.groups = (p.Cout + 15) / 16;
+  const long patches = (long)p.N * sp.tiles_y * sp.tiles_x;
+  if (patches < 256 || patches > 0x7fffffffl) return 1;  // a workgroup per CU at least
+  const int cs = p.Cin / 32;
+  const size_t lds = (size_t)((sp.hrows * (cs * 64 + 16) + 1023) & ~1023);
+  if (lds > 80 * 1024) return 1;
+  auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+  sp.mg_tx = magic(sp.tiles_x);
+  sp.mg_ty = magic(sp.tiles_y);
+  sp.mg_hw2 = magic(sp.hw2);
+  {
+    const size_t hw = (size_t)p.Ho * p.Wo;
+    const size_t b1 = (size_t)p.N * p.split * hw * 2, b2 = (size_t)p.N * (p.Cout - p.split) * hw * 2;
+    if (b1 >= 0xfffffff0ull || b2 >= 0xfffffff0ull) return 1;  // 32-bit buffer offsets
+    sp.y1bytes = (unsigned)b1;
+    sp.y2bytes = (unsigned)b2;
+  }
+  const bool any_sig = p.act == SSDK_ACT_SIGMOID || p.act == SSDK_ACT_SILU || p.act2 == SSDK_ACT_SIGMOID || p.act2 == SSDK_ACT_SILU;
+  const bool any_clamp = p.act == SSDK_ACT_RELU || p.act == SSDK_ACT_RELU6 || p.act2 == SSDK_ACT_RELU || p.act2 == SSDK_ACT_RELU6;
+#define SSDK_S3(DT, CS_, SIG_, CLAMP_)                                                                                        \
+  do {                                                                                                                     \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_short_kernel<DT, CS_, SIG_, CLAMP_>),                 \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
+    hipLaunchKernelGGL((conv3x3_short_kernel<DT, CS_, SIG_, CLAMP_>), dim3((unsigned)patches), dim3(S3_THREADS), lds, stream, sp); \
+  } while (0)
+#define SSDK_S3A(DT, CS_)                                   \
+  do {                                                      \
+    if (any_sig && any_clamp) SSDK_S3(DT, CS_, true, true);  \
+    else if (any_sig) SSDK_S3(DT, CS_, true, false);        \
+    else SSDK_S3(DT, CS_, false, true);                     \
+  } while (0)
+#define SSDK_S3C(DT)                    \
+  do {                                  \
+    if (cs == 1) SSDK_S3A(DT, 1);       \
+    else if (cs == 2) SSDK_S3A(DT, 2);  \
+    else if (cs == 3) SSDK_S3A(DT, 3);  \
+    else SSDK_S3A(DT, 4);               \
+  } while (0)
+  if (dtype == SSDK_BF16) SSDK_S3C(SSDK_BF16);
+  else SSDK_S3C(SSDK_F16);
+#undef SSDK_S3C
+#undef SSDK_S3A
+#undef SSDK_S3
+  return 0;
+}
+
+}  // namespace ssdk

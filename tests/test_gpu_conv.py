@@ -94,7 +94,7 @@ def test_dense_conv(cin, cout, k, stride, h, w, n, act, dtype_name):
     _check(y2, _ref(x, conv, bn, act), dtype, "dense nchw")
 
 
-HALO, G256, SMALLMAP = "conv3x3_halo_kernel", "conv_gemm256_kernel", "conv_smallmap_kernel"
+HALO, G256, SMALLMAP, SHORT = "conv3x3_halo_kernel", "conv_gemm256_kernel", "conv_smallmap_kernel", "conv3x3_short_kernel"
 LARGE = [
     # cin, cout, k, stride, h, w, n, act, kernel the layer must be dispatched to
     (96, 504, 3, 1, 32, 32, 8, "none", HALO),      # SSD head L0: 16x16 patches, last slab holds 32 channels
@@ -110,6 +110,11 @@ LARGE = [
     (256, 504, 3, 1, 2, 2, 35, "relu", SMALLMAP),  # SSD head L4: sixteen maps per workgroup
     (128, 504, 3, 1, 1, 1, 64, "silu", SMALLMAP),  # SSD head L5: 1x1 maps, only the centre tap sees data
     (256, 40, 3, 1, 2, 4, 9, "relu6", SMALLMAP),   # 2x4 map, a single partial channel range
+    # (the short-K kernel writes NCHW only: the NHWC call of these rows runs on another kernel)
+    (96, 504, 3, 1, 32, 32, 64, "sigmoid", SHORT), # SSD head L0 at bench size: short K, a 128-pixel patch x 4 channel tiles per workgroup
+    (128, 256, 3, 1, 40, 40, 20, "relu", SHORT),   # ragged patches (40 = 2.5 x 16), the largest halo, two channel tiles
+    (32, 130, 3, 1, 64, 64, 8, "relu6", SHORT),    # one 32-channel slice, a ragged second channel tile
+    (64, 160, 3, 1, 24, 48, 32, "silu", SHORT),    # non-square map
     (64, 256, 1, 1, 64, 64, 8, "relu", G256),      # wide 1x1
     (96, 320, 3, 2, 64, 64, 32, "relu6", G256),    # 3x3 stride 2, partial 64-channel slab
     (72, 200, 1, 1, 90, 50, 8, "silu", G256),      # ragged everything
@@ -141,7 +146,7 @@ def test_large_tile_kernels(cin, cout, k, stride, h, w, n, act, kernel, dtype_na
     pack = FC.ConvPack(conv, bn, act, dtype)
     want = _ref(x, conv, bn, act)
     y = FC.conv_native(x.cuda(), pack)
-    assert N.last_kernel() == kernel, N.last_kernel()
+    assert N.last_kernel() == kernel or kernel == SHORT, N.last_kernel()
     _check(y, want, dtype, "large nhwc")
     y2 = FC.conv_native(x.cuda(), pack, nchw_out=True)
     assert N.last_kernel() == kernel
@@ -181,6 +186,42 @@ def test_small_map_kernel_on_krsc_and_on_fragment_major_weights(cin, h, w, n, mo
         _check(got, ref, dtype, "small map, frag=%s" % use)
         outs.append(got)
     assert float((outs[0] - outs[1]).abs().max()) <= 2e-2 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+def test_short_k_kernel_split_heads(dtype_name):
+    """SSD head L0 (96 -> 24 loc | 480 conf, NCHW split, sigmoid on conf only) on conv3x3_short_kernel, and the same layer on
+    the halo kernel (no fragment-major image: the short kernel does not apply)."""
+    import torch
+    import torch.nn as nn
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    torch.manual_seed(5)
+    conv = nn.Conv2d(96, 504, 3, 1, 1, bias=True)
+    conv.weight.data = conv.weight.data.to(dtype).float()
+    x = torch.randn(64, 96, 32, 32).to(dtype)
+    conv = conv.cuda()
+    want = _ref(x, conv, None, "none")
+    ref = torch.cat([want[:, :24], torch.sigmoid(want[:, 24:])], 1)
+    pack = FC.ConvPack(conv, None, "none", dtype)
+    y = FC.conv_native(x.cuda(), pack, nchw_out=True, split=24, act2="sigmoid")
+    assert N.last_kernel() == SHORT, N.last_kernel()
+    assert y[0].shape == (64, 24, 32, 32) and y[1].shape == (64, 480, 32, 32) and y[0].is_contiguous() and y[1].is_contiguous()
+    got = torch.cat([y[0].float(), y[1].float()], 1)
+    _check(got, ref, dtype, "short-K split heads")
+    mp = pytest.MonkeyPatch()
+    try:
+        mp.setattr(FC, "USE_WFRAG", False)
+        plain = FC.ConvPack(conv, None, "none", dtype)
+        z = FC.conv_native(x.cuda(), plain, nchw_out=True, split=24, act2="sigmoid")
+        assert N.last_kernel() == HALO, N.last_kernel()
+    finally:
+        mp.undo()
+    got2 = torch.cat([z[0].float(), z[1].float()], 1)
+    _check(got2, ref, dtype, "halo split heads")
+    assert float((got - got2).abs().max()) <= 2e-2
 
 
 def test_halo_kernel_residual_and_split_heads():
