@@ -8,13 +8,13 @@
 // Here K is short enough for the WHOLE halo of a 128-pixel patch to sit in LDS ((th+2)(tw+2) rows of Cin channels: 42 KiB at
 // Cin = 96), so a workgroup keeps its patch and walks over ALL output-channel tiles:
 //
-//   * workgroup = one 128-pixel patch (th x tw of one image), 4 waves as 2 (M) x 2 (N); per 128-channel tile 4 x 4
+//   * workgroup = one 128-pixel patch (th x tw of one image), 4 waves as 1 (M) x 4 (N); per 128-channel tile 8 x 2
 //     accumulator fragments of v_mfma_f32_16x16x32 per wave; the halo is staged ONCE for the ceil(Cout / 128) tiles, and
 //     nothing else ever writes LDS: there is no barrier behind the staging;
 //   * k-step = (tap, 32-channel slice), taps outside: the A fragment of a lane is 16 bytes of the halo row of "its" pixel
 //     shifted by the tap -- an address offset; rows are padded to an odd number of 16-byte chunks (conflict-free ds_read_b128);
 //   * the B fragments (weights) go straight from the fragment-major image (ssdk.h ssdk_weight_frag_bytes) into operand
-//     registers: a wave's 64 channels x 32 k are four coalesced 1 KiB loads, three k-steps ahead through three register
+//     registers: a wave's 32 channels x 32 k are two coalesced 1 KiB loads, three k-steps ahead through three register
 //     sets (9 * Cin / 32 k-steps per tile is a multiple of three: the ring runs on across tiles).  Measured against staging
 //     them through a three-deep LDS ring with one barrier per k-step: the same 78 us -- the loop was not what bound it;
 //   * what bound it was the epilogue (sigmoid on 480 of 504 columns: ~60 VALU instructions per fragment, 25 us over the
@@ -57,7 +57,12 @@ __global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_short_kernel(const Shor
   constexpr int RS = CS * 64 + 16;  // halo row stride (bytes): an odd number of 16-byte chunks
   constexpr int NS = 9 * CS;        // k-steps per channel tile (a multiple of 3)
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-  const u32 wm = wave >> 1, wn = wave & 1u, fr = lane & 15u, fg = lane >> 4;
+  // wave layout 1 (M) x 4 (N): a wave owns ALL 128 pixels x 32 channels = MI x NJ = 8 x 2 fragments.  (2 x 2 waves of 4 x 4
+  // fragments need the same 16 MFMAs per k-step but 4 KiB of weights per wave and k-step, half of them a duplicate of the
+  // neighbour's: 32 KiB per CU and k-step pair against ~45 B/clk of L2 bandwidth = 711 cycles for 512 of matrix work.
+  // Here: 2 KiB of weights and 8 KiB of LDS reads per wave -- 355 / 512 / 512 cycles of L2 / LDS / MFMA.)
+  constexpr int MI = 8, NJ = 2;
+  const u32 wn = wave, fr = lane & 15u, fg = lane >> 4;
 
   u32 pq = s3_div(blockIdx.x, (u32)sp.tiles_x, sp.mg_tx);
   const u32 tx = blockIdx.x - pq * (u32)sp.tiles_x;
@@ -65,22 +70,22 @@ __global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_short_kernel(const Shor
   const u32 ty = pq - b * (u32)sp.tiles_y;
   const int y0 = (int)ty * sp.th, x0 = (int)tx * sp.tw;
 
-  // ---- weights: the B fragments of this wave's 64 channels (blocks g = 8 nt + 4 wn + j of the image), straight from
+  // ---- weights: the B fragments of this wave's 32 channels (blocks g = 8 nt + 2 wn + j of the image), straight from
   //      global memory into operand registers, three k-steps ahead (uniform block offset + 32-bit lane offset: the loads take
   //      the scalar-base form)
   const unsigned char* wbase = (const unsigned char*)p.w_frag;
   const u32 wlane = lane * 16u;
   auto woff = [&](u32 nt, int j) -> size_t {  // byte offset of block (g, k-step 0): uniform
-    u32 g = nt * 8u + 4u * wn + (u32)j;
+    u32 g = nt * 8u + (u32)NJ * wn + (u32)j;
     g = g < (u32)sp.groups ? g : (u32)sp.groups - 1u;  // groups past Cout: any valid block (never stored)
     return (size_t)g * NS * 1024;
   };
   auto ldw = [&](size_t off) { return *reinterpret_cast<const u32x4*>(wbase + off + wlane); };
-  u32x4 fbq[3][4];  // register set q holds the B fragments of a k-step s with s % 3 == q
+  u32x4 fbq[3][NJ];  // register set q holds the B fragments of a k-step s with s % 3 == q
 #pragma unroll
   for (int s = 0; s < 3; ++s)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) fbq[s][j] = ldw(woff(0, j) + (size_t)s * 1024);
+    for (int j = 0; j < NJ; ++j) fbq[s][j] = ldw(woff(0, j) + (size_t)s * 1024);
 
   // ---- halo: (th+2) x (tw+2) rows of Cin channels, zeros outside the image, batches of independent 16-byte loads --------
   {
@@ -110,32 +115,32 @@ __global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_short_kernel(const Shor
   }
 
   // ---- fragment roles ----------------------------------------------------------------------------------------------------
-  u32 a_ad[4];  // LDS byte address of pixel fragment i at tap (0, 0), slice 0
+  u32 a_ad[MI];  // LDS byte address of pixel fragment i at tap (0, 0), slice 0
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const u32 ml = wm * 64u + (u32)i * 16u + fr;
+  for (int i = 0; i < MI; ++i) {
+    const u32 ml = (u32)i * 16u + fr;
     const u32 y = ml >> sp.tw_shift, x = ml & (u32)(sp.tw - 1);
     a_ad[i] = (y * (u32)sp.hw2 + x) * (u32)RS + fg * 16u;
   }
-  // output pixels of this lane's four accumulator rows (fragment i: pixels wm*64 + 16 i + 4 fg .. +3, one map row)
-  u32 o_off[4];  // oy * Wo + ox, or ~0 outside the map
+  // output pixels of this lane's four accumulator rows (fragment i: pixels 16 i + 4 fg .. +3, one map row)
+  u32 o_off[MI];  // oy * Wo + ox, or ~0 outside the map
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const u32 ml = wm * 64u + (u32)i * 16u + fg * 4u;
+  for (int i = 0; i < MI; ++i) {
+    const u32 ml = (u32)i * 16u + fg * 4u;
     const int oy = y0 + (int)(ml >> sp.tw_shift), ox = x0 + (int)(ml & (u32)(sp.tw - 1));
     o_off[i] = (oy < p.Ho && ox < p.Wo) ? (u32)(oy * p.Wo + ox) : 0xffffffffu;
   }
   const u32 hw = (u32)(p.Ho * p.Wo);
 
-  f32x4 acc[4][4], prev[4][4];
+  f32x4 acc[MI][NJ], prev[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = prev[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = prev[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // epilogue constants of the tile whose accumulators sit in `prev`: column j = channel e_n0 + 16 j (kept small: the main
   // loop lives at the 256-register limit of two workgroups per CU -- activation selectors and plane pointers are rebuilt
   // per fragment from the channel number, in the MFMAs' shadow)
-  float e_sc[4], e_bi[4];
+  float e_sc[NJ], e_bi[NJ];
   u32 e_n0 = 0;
   const ActSel as_a = act_sel(p.act), as_b = act_sel(p.act2);
   // Branch-free: raw buffer stores, one per output tensor (loc | conf planes); a lane that has nothing to store there carries
@@ -180,13 +185,13 @@ __global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_short_kernel(const Shor
     constexpr bool EPI = decltype(epi_tag)::value;
     constexpr int FPS = (16 + NS - 1) / NS;
     const u32 ntn = nt + 1u < (u32)sp.n_tiles ? nt + 1u : nt;  // behind the last tile: harmless re-reads of its own weights
-    size_t wc[4], wx[4];
+    size_t wc[NJ], wx[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       wc[j] = woff(nt, j);
       wx[j] = woff(ntn, j);
     }
-    const u32 nbase = nt * S3_BN + wn * 64u + fr;
+    const u32 nbase = nt * S3_BN + wn * (16u * NJ) + fr;
     constexpr int KC = (16 + FPS - 1) / FPS;  // k-step in which this tile's epilogue constants are requested: the previous
                                               // tile's fragments -- which still use e_sc / e_bi -- are finished by then
     static_assert(KC <= NS - 1, "the constants must be requested inside the tile's loop");
@@ -194,21 +199,21 @@ __global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_short_kernel(const Shor
     for (int ks = 0; ks < NS; ++ks) {
       const int tap = ks / CS, sl = ks % CS;
       const u32 toff = (u32)((tap / 3) * sp.hw2 + (tap % 3)) * (u32)RS + (u32)sl * 64u;
-      u32x4 fa[4];
+      u32x4 fa[MI];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const u32x4*>(smem + a_ad[i] + toff);
+      for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const u32x4*>(smem + a_ad[i] + toff);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<DT>(fa[i], fbq[ks % 3][j], acc[i][j]);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16<DT>(fa[i], fbq[ks % 3][j], acc[i][j]);
       if (EPI) {
 #pragma unroll
-        for (int e = ks * FPS; e < (ks + 1) * FPS && e < 16; ++e) epi_frag(prev[e >> 2][e & 3], e >> 2, e & 3);
+        for (int e = ks * FPS; e < (ks + 1) * FPS && e < 16; ++e) epi_frag(prev[e / NJ][e % NJ], e / NJ, e % NJ);
       }
       {
         const int k3 = ks + 3;  // the B fragments of step ks + 3 into the set just used
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           fbq[ks % 3][j] = ldw(k3 < NS ? wc[j] + (size_t)k3 * 1024 : wx[j] + (size_t)(k3 - NS) * 1024);
       }
       // issue order inside the k-step: one MFMA, then a few of the epilogue's VALU instructions, 16 times over -- a MFMA
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_short_kernel(const Shor
       __builtin_amdgcn_sched_barrier(0);
       if (ks == KC) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           const u32 n = nbase + (u32)j * 16u, nn = n < (u32)p.Cout ? n : (u32)p.Cout - 1u;
           const float sv = (p.scale ? p.scale : p.bias)[nn];  // (no branch: a select of the address, then of the value)
           e_sc[j] = p.scale ? sv : 1.f;
@@ -235,9 +240,9 @@ __global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_short_kernel(const Shor
     // hand the accumulators over
     e_n0 = nbase;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         prev[i][j] = acc[i][j];
         acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -248,9 +253,9 @@ __global__ __launch_bounds__(S3_THREADS, 2) void conv3x3_short_kernel(const Shor
   for (u32 nt = 1; nt < (u32)sp.n_tiles; ++nt) run_tile(nt, std::true_type{});
   // the last tile's epilogue has no main loop to hide behind
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) epi_frag(prev[i][j], i, j);
+    for (int j = 0; j < NJ; ++j) epi_frag(prev[i][j], i, j);
 }
 
 // 1: not one of this kernel's layers (the caller goes on), 0: launched

@@ -23,8 +23,12 @@ constexpr int kSmThreads = 256;
 // whose grid still fills the chip then)
 // TAPS = 9, or 1 for 1x1 maps: only the centre tap ever sees data there (the other eight multiply the padding), so K is Cin
 // PK: weights from the fragment-major image p.w_frag (ssdk.h: 1 KiB contiguous per k-step and wave) instead of the KRSC tensor
-template <int DT, int CS, int MFR, int TAPS, bool PK>
+// NA: 16-channel weight fragments per wave (1 | 2).  With 2 (fragment-major weights only) a pixel fragment read from LDS
+// serves two MFMAs: the 8x8 level as 128 pixels x 16 channels per wave was bound by its LDS reads (every wave reads every
+// pixel fragment: 8 KiB per wave and k-step for 128 cycles of matrix work); 64 pixels x 32 channels per wave reads 4 KiB
+template <int DT, int CS, int MFR, int TAPS, bool PK, int NA>
 __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvParams p) {
+  static_assert(NA == 1 || PK, "two channel fragments per wave read the fragment-major image");
   constexpr int ROWS = 16 * MFR;
   constexpr int TAP0 = TAPS == 9 ? 0 : 4;  // first tap visited
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -36,7 +40,7 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   const u16* x = (const u16*)p.x;
 
   // ---- the weight stream starts first: it does not depend on the maps -----------------------------------------------
-  const int co_row0 = ((int)blockIdx.y * (int)(blockDim.x >> 6) + (int)wave) * 16;  // 1, 2 or 4 waves per workgroup
+  const int co_row0 = ((int)blockIdx.y * (int)(blockDim.x >> 6) + (int)wave) * 16 * NA;  // 1, 2 or 4 waves per workgroup
   int co_a = co_row0 + (int)fr;
   co_a = co_a < p.Cout ? co_a : p.Cout - 1;  // rows past Cout: computed on a valid row, never stored
   const u16* wrow = PK ? (const u16*)p.w_frag + (size_t)(co_row0 < p.Cout ? co_row0 >> 4 : (p.Cout - 1) >> 4) * 9 * Cin * 16 + lane * 8
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   // PAIRS outside, taps inside, the two slices of a pair innermost -- the two 64-byte halves of a weight row's 128-byte line
   // are then fetched by neighbouring loads.
   constexpr int RING = 2 * TAPS;  // register stages = k-steps in flight
-  u32x4 rw[RING];
+  u32x4 rw[RING][NA];
   auto kmap = [](int st, int& t, int& sl) {
     if (PK) { t = st / CS; sl = st % CS; return; }
     if (TAPS == 1) { t = 0; sl = st; return; }
@@ -62,19 +66,25 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   auto issue = [&](int st) {
     int t, sl;
     kmap(st < CS * TAPS ? st : CS * TAPS - 1, t, sl);  // past the end: a harmless re-read
-    rw[st % RING] = *reinterpret_cast<const u32x4*>(wrow + (size_t)((t + TAP0) * CS + sl) * (PK ? 512 : 32));
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {  // (fragment a of this wave: the next 16-row group of the image, clamped like the first)
+      const size_t ga = (a && co_row0 + 16 * a < p.Cout) ? (size_t)a * 9 * Cin * 16 : 0;
+      rw[st % RING][a] = *reinterpret_cast<const u32x4*>(wrow + ga + (size_t)((t + TAP0) * CS + sl) * (PK ? 512 : 32));
+    }
   };
 #pragma unroll
   for (int st = 0; st < RING; ++st) issue(st);
   // the epilogue's per-channel constants too (as first written they were loaded in the epilogue: one more exposed round trip)
   const int co0 = co_row0 + (int)fg * 4;
-  float e_sc[4], e_bi[4];
+  float e_sc[NA][4], e_bi[NA][4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int co = co0 + r < p.Cout ? co0 + r : p.Cout - 1;
-    e_sc[r] = p.scale ? p.scale[co] : 1.f;
-    e_bi[r] = p.bias[co];
-  }
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + 16 * a + r < p.Cout ? co0 + 16 * a + r : p.Cout - 1;
+      e_sc[a][r] = p.scale ? p.scale[co] : 1.f;
+      e_bi[a][r] = p.bias[co];
+    }
 
   // ---- stage the maps: ROWS rows x Cin, 16-byte pieces, rows of images past N are zero, row ROWS = zeros ---------------
   // Batches of up to 17 independent loads per thread, then their LDS stores.  (As first written -- one load, one store per
@@ -113,9 +123,11 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   }
   __syncthreads();
 
-  f32x4 acc[MFR];
+  f32x4 acc[NA][MFR];
 #pragma unroll
-  for (int m = 0; m < MFR; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int m = 0; m < MFR; ++m) acc[a][m] = f32x4{0.f, 0.f, 0.f, 0.f};
   // The pixel operands (B fragments, LDS) run TWO k-steps ahead of the MFMAs through a ring of three register sets.  (As
   // first written every MFMA waited for a ds_read issued one or two instructions before it -- s_waitcnt lgkmcnt(1) in front
   // of each of the four MFMAs of a k-step: ~660 cycles per k-step for 64 cycles of matrix work, the whole kernel ran at the
@@ -135,7 +147,9 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   for (int st = 0; st < NS; ++st) {
     if (st + D < NS) lds_issue((st + D) % (D + 1), st + D);
 #pragma unroll
-    for (int m = 0; m < MFR; ++m) acc[m] = mfma16<DT>(rw[st % RING], bq[st % (D + 1)][m], acc[m]);  // D[co = 4fg + r][px = fr]
+    for (int m = 0; m < MFR; ++m)
+#pragma unroll
+      for (int a = 0; a < NA; ++a) acc[a][m] = mfma16<DT>(rw[st % RING][a], bq[st % (D + 1)][m], acc[a][m]);  // D[co = 4fg + r][px = fr]
     issue(st + RING);
     __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks every load down to its use, 18 k-steps later)
   }
@@ -143,27 +157,29 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   // ---- epilogue: lane = (pixel fr of fragment m, channels co0 + 4fg .. +3) -----------------------------------------
   const bool nchw = p.out_layout == LAYOUT_NCHW;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int co = co0 + r;
-    if (co >= p.Cout) continue;
-    const float sc = e_sc[r], bi = e_bi[r];
-    const ActSel as = act_sel(co >= p.split ? p.act2 : p.act);
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
-    for (int m = 0; m < MFR; ++m) {
-      const int px = m * 16 + (int)fr, b = img0 + px / P, q = px % P;
-      if (b >= p.N) continue;
-      float v = acc[m][r] * sc + bi;
-      if (as.mode) {
-        const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * v));
-        v = as.mode == 1 ? sg : v * sg;
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + 16 * a + r;
+      if (co >= p.Cout) continue;
+      const float sc = e_sc[a][r], bi = e_bi[a][r];
+      const ActSel as = act_sel(co >= p.split ? p.act2 : p.act);
+#pragma unroll
+      for (int m = 0; m < MFR; ++m) {
+        const int px = m * 16 + (int)fr, b = img0 + px / P, q = px % P;
+        if (b >= p.N) continue;
+        float v = acc[a][m][r] * sc + bi;
+        if (as.mode) {
+          const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * v));
+          v = as.mode == 1 ? sg : v * sg;
+        }
+        v = __builtin_fminf(__builtin_fmaxf(v, as.lo), as.hi);
+        const u16 h = (u16)(pack2_16<DT>(v, 0.f) & 0xffffu);
+        if (!nchw) ((u16*)p.y)[((size_t)b * P + q) * p.Cout + co] = h;
+        else if (co < p.split) ((u16*)p.y)[((size_t)b * p.split + co) * P + q] = h;
+        else ((u16*)p.y2)[((size_t)b * (p.Cout - p.split) + (co - p.split)) * P + q] = h;
       }
-      v = __builtin_fminf(__builtin_fmaxf(v, as.lo), as.hi);
-      const u16 h = (u16)(pack2_16<DT>(v, 0.f) & 0xffffu);
-      if (!nchw) ((u16*)p.y)[((size_t)b * P + q) * p.Cout + co] = h;
-      else if (co < p.split) ((u16*)p.y)[((size_t)b * p.split + co) * P + q] = h;
-      else ((u16*)p.y2)[((size_t)b * (p.Cout - p.split) + (co - p.split)) * P + q] = h;
     }
-  }
 }
 
 // 1: not one of this kernel's layers (the caller goes on), 0: launched
@@ -174,35 +190,40 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   if (!env || p.k != 3 || p.stride != 1 || p.pad != 1 || p.H != p.Ho || p.W != p.Wo || P > env_maxp || P > 64 || (64 % P) || (p.Cin != 128 && p.Cin != 256 && p.Cin != 512) ||
       p.in_layout != LAYOUT_NHWC || p.res || p.post != SSDK_ACT_NONE || p.Cout < 16)
     return 1;
-  // 128 pixels per workgroup where the grid then still has a workgroup per CU (the 8x8 level at batch 64: 32 x 8), else 64
+  static const int env_pk = getenv("SSDK_WFRAG") ? atoi(getenv("SSDK_WFRAG")) : 1;
+  const bool packed = p.w_frag != nullptr && env_pk != 0;
+  // Where 128 pixels per workgroup still leave a workgroup per CU (the 8x8 level at batch 64): with fragment-major weights
+  // 64 pixels x 32 channels per wave (na = 2: a pixel fragment serves two MFMAs), else 128 pixels x 16 channels per wave
   const int nfr64 = (p.Cout + 63) / 64;
-  const int mfr = (2 * P <= 128 && (128 % P) == 0 && (long)((p.N + 128 / P - 1) / (128 / P)) * nfr64 >= 256) ? 8 : 4;
+  const bool big = 2 * P <= 128 && (128 % P) == 0 && (long)((p.N + 128 / P - 1) / (128 / P)) * nfr64 >= 256;
+  static const int env_na = getenv("SSDK_CONV_SMALLMAP_NA") ? atoi(getenv("SSDK_CONV_SMALLMAP_NA")) : 2;
+  const int na = (big && packed && env_na == 2) ? 2 : 1;
+  const int mfr = (big && na == 1) ? 8 : 4;
   const int G = 16 * mfr / P;
-  // waves (= 16-channel fragments) per workgroup
-  const int groups = (p.N + G - 1) / G, nfr = (p.Cout + 15) / 16;
+  // waves (= 16 na-channel fragments) per workgroup
+  const int groups = (p.N + G - 1) / G, nfr = (p.Cout + 16 * na - 1) / (16 * na);
   static const int env_nw = getenv("SSDK_CONV_SMALLMAP_NW") ? atoi(getenv("SSDK_CONV_SMALLMAP_NW")) : 4;
   const int nw = env_nw == 1 || env_nw == 2 ? env_nw : 4;  // (fewer waves per workgroup = more workgroups: measured slower on every level)
   const dim3 grid((unsigned)groups, (unsigned)((nfr + nw - 1) / nw));
   const size_t lds = (size_t)(16 * mfr + 1) * (p.Cin * 2 + 16);
   const int cs = p.Cin / 32;
-  static const int env_pk = getenv("SSDK_WFRAG") ? atoi(getenv("SSDK_WFRAG")) : 1;
-  const bool packed = p.w_frag != nullptr && env_pk != 0;
-#define SSDK_SM0(DT, CS_, MFR_, TAPS_, PK_)                                                                                \
+#define SSDK_SM0(DT, CS_, MFR_, TAPS_, PK_, NA_)                                                                           \
   do {                                                                                                                     \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_, MFR_, TAPS_, PK_>),            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_, MFR_, TAPS_, PK_, NA_>),       \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
-    hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_, MFR_, TAPS_, PK_>), grid, dim3(64 * nw), lds, stream, p);            \
+    hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_, MFR_, TAPS_, PK_, NA_>), grid, dim3(64 * nw), lds, stream, p);       \
   } while (0)
-#define SSDK_SM1(DT, CS_, MFR_, TAPS_)               \
-  do {                                               \
-    if (packed) SSDK_SM0(DT, CS_, MFR_, TAPS_, true); \
-    else SSDK_SM0(DT, CS_, MFR_, TAPS_, false);      \
+#define SSDK_SM1(DT, CS_, MFR_, TAPS_)                  \
+  do {                                                  \
+    if (packed) SSDK_SM0(DT, CS_, MFR_, TAPS_, true, 1); \
+    else SSDK_SM0(DT, CS_, MFR_, TAPS_, false, 1);      \
   } while (0)
-#define SSDK_SM(DT, CS_)                       \
-  do {                                         \
-    if (P == 1) SSDK_SM1(DT, CS_, 4, 1);       \
-    else if (mfr == 8) SSDK_SM1(DT, CS_, 8, 9); \
-    else SSDK_SM1(DT, CS_, 4, 9);              \
+#define SSDK_SM(DT, CS_)                         \
+  do {                                           \
+    if (P == 1) SSDK_SM1(DT, CS_, 4, 1);         \
+    else if (na == 2) SSDK_SM0(DT, CS_, 4, 9, true, 2); \
+    else if (mfr == 8) SSDK_SM1(DT, CS_, 8, 9);  \
+    else SSDK_SM1(DT, CS_, 4, 9);                \
   } while (0)
   if (dtype == SSDK_BF16) {
     if (cs == 4) SSDK_SM(SSDK_BF16, 4);
