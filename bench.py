@@ -350,8 +350,21 @@ def main():
                 "note": "backbone + neck (every op of the plan that is not a head): the part of the step that dominates "
                         "by time; bytes = each op's input + output + weights once"}
         if h_ms > 0:
+            # what an EMPTY event interval reads on this stack (two hipEventRecords back to back): every per-op time above
+            # contains one.  `ms` / `frac` stay raw; `ms_net` / `frac_net` subtract it once per head op.
+            nulls = []
+            for _ in range(21):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                nulls.append(e0.elapsed_time(e1))
+            null_ms = sorted(nulls)[len(nulls) // 2]
+            net_ms = max(h_ms - len(hl) * null_ms, 1e-6)
             heads = {"flops": h_flops, "ms": round(h_ms, 4), "achieved_TFLOPs": round(h_flops / (h_ms * 1e-3) / 1e12, 1),
                      "peak_TFLOPs": MFMA_PEAK_TFLOPS, "frac": round(h_flops / (h_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                     "ops": len(hl), "empty_event_interval_us": round(null_ms * 1e3, 2), "ms_net": round(net_ms, 4),
+                     "frac_net": round(h_flops / (net_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                      "note": "3x3 head convs of all levels (SSD: loc|conf as one GEMM per level; FPN / BiFPN: the 4+1 convs "
                              "of both shared towers on every level, fpn.py:10-18), summed algorithmic FLOPs / summed per-op "
                              "time, dense MFMA peak"}

@@ -26,15 +26,23 @@ constexpr int kSmThreads = 256;
 // NA: 16-channel weight fragments per wave (1 | 2).  With 2 (fragment-major weights only) a pixel fragment read from LDS
 // serves two MFMAs: the 8x8 level as 128 pixels x 16 channels per wave was bound by its LDS reads (every wave reads every
 // pixel fragment: 8 KiB per wave and k-step for 128 cycles of matrix work); 64 pixels x 32 channels per wave reads 4 KiB
-template <int DT, int CS, int MFR, int TAPS, bool PK, int NA>
+// S: stride (1 | 2).  With 2 the staged map is the INPUT map (H x W = 2 Ho x 2 Wo pixels per image) and a lane's sixteen
+// pixels sit two input columns / two input rows apart; the LDS image skews every second input row by one row slot
+// (row index iy * W + ix + (iy >> 1)) so that the sixteen 16-byte reads of a fragment still fall into sixteen different
+// bank groups (row stride = an odd number of 16-byte chunks; without the skew output rows oy and oy + 1 collide).
+template <int DT, int CS, int MFR, int TAPS, bool PK, int NA, int S>
 __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvParams p) {
   static_assert(NA == 1 || PK, "two channel fragments per wave read the fragment-major image");
+  static_assert(S == 1 || TAPS == 9, "stride 2 visits all taps");
   constexpr int ROWS = 16 * MFR;
   constexpr int TAP0 = TAPS == 9 ? 0 : 4;  // first tap visited
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const u32 fr = lane & 15u, fg = lane >> 4;
-  const int P = p.Ho * p.Wo, G = ROWS / P, Cin = p.Cin;  // pixels per image, images per workgroup
+  const int P = p.Ho * p.Wo, G = ROWS / P, Cin = p.Cin;  // output pixels per image, images per workgroup
+  const int PI = p.H * p.W;                                 // input pixels per image (== P for stride 1)
+  const int PL = S == 2 ? PI + (p.H >> 1) : PI;             // LDS row slots per image (skewed for stride 2)
+  const int ZROW = G * PL;                                  // the zero row
   const int img0 = (int)blockIdx.x * G;
   const int RS = Cin * 2 + 16;                           // LDS row stride (bytes); row ROWS = zeros
   const u16* x = (const u16*)p.x;
@@ -90,8 +98,9 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   // Batches of up to 17 independent loads per thread, then their LDS stores.  (As first written -- one load, one store per
   // loop iteration -- the nine iterations of the 4x4 level each waited a full memory round trip: ~9 us of a 19 us kernel.)
   {
-    constexpr int CPR = CS * 4, TOTAL = ROWS * CPR;
-    constexpr int PER = (TOTAL + kSmThreads - 1) / kSmThreads, SB = PER < 17 ? PER : 17;  // one or two round trips
+    constexpr int CPR = CS * 4;
+    const int TOTAL = G * PI * CPR;  // (stride 1: ROWS * CPR)
+    constexpr int PER = (ROWS * S * S * CPR + kSmThreads - 1) / kSmThreads, SB = PER < 17 ? PER : 17;  // one or two round trips
     const int nthr = (int)blockDim.x;
     for (int q0 = (int)tid; q0 < TOTAL; q0 += nthr * SB) {
       u32x4 v[SB];
@@ -99,15 +108,22 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
       for (int j = 0; j < SB; ++j) {
         const int q = q0 + j * nthr, row = q / CPR, c = q % CPR;
         v[j] = u32x4{0u, 0u, 0u, 0u};
-        if (q < TOTAL && img0 + row / P < p.N) v[j] = *reinterpret_cast<const u32x4*>(x + ((size_t)img0 * P + row) * Cin + c * 8);
+        if (q < TOTAL && img0 + row / PI < p.N) v[j] = *reinterpret_cast<const u32x4*>(x + ((size_t)img0 * PI + row) * Cin + c * 8);
       }
 #pragma unroll
       for (int j = 0; j < SB; ++j) {
         const int q = q0 + j * nthr, row = q / CPR, c = q % CPR;
-        if (q < TOTAL) *reinterpret_cast<u32x4*>(smem + (size_t)row * RS + c * 16) = v[j];
+        int lrow = row;
+        if (S == 2) {
+          const int g = row / PI, qi = row % PI;
+          lrow = g * PL + qi + ((qi / p.W) >> 1);
+        }
+        if (q < TOTAL) *reinterpret_cast<u32x4*>(smem + (size_t)lrow * RS + c * 16) = v[j];
       }
     }
-    if ((int)tid < CPR) *reinterpret_cast<u32x4*>(smem + (size_t)ROWS * RS + tid * 16) = u32x4{0u, 0u, 0u, 0u};
+    if ((int)tid < CPR) *reinterpret_cast<u32x4*>(smem + (size_t)ZROW * RS + tid * 16) = u32x4{0u, 0u, 0u, 0u};
+    if (S == 2) {  // the skew slots (one per two input rows) are never read; nothing to clear
+    }
   }
   // LDS byte offset of the input pixel behind (output pixel = fragment m, lane fr; tap), the zero row outside the map
   u32 rowoff[MFR][TAPS];
@@ -116,9 +132,9 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
     const int px = m * 16 + (int)fr, g = px / P, q = px % P, oy = q / p.Wo, ox = q % p.Wo;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
-      const int iy = oy - 1 + (t + TAP0) / 3, ix = ox - 1 + (t + TAP0) % 3;
-      const bool ok = (unsigned)iy < (unsigned)p.Ho && (unsigned)ix < (unsigned)p.Wo;
-      rowoff[m][t] = (u32)((ok ? g * P + iy * p.Wo + ix : ROWS) * RS) + fg * 16u;
+      const int iy = oy * S - 1 + (t + TAP0) / 3, ix = ox * S - 1 + (t + TAP0) % 3;
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      rowoff[m][t] = (u32)((ok ? g * PL + iy * p.W + ix + (S == 2 ? iy >> 1 : 0) : ZROW) * RS) + fg * 16u;
     }
   }
   __syncthreads();
@@ -187,17 +203,26 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   static const int env = getenv("SSDK_CONV_SMALLMAP") ? atoi(getenv("SSDK_CONV_SMALLMAP")) : 1;
   static const int env_maxp = getenv("SSDK_CONV_SMALLMAP_MAXP") ? atoi(getenv("SSDK_CONV_SMALLMAP_MAXP")) : 64;
   const int P = p.Ho * p.Wo;
-  if (!env || p.k != 3 || p.stride != 1 || p.pad != 1 || p.H != p.Ho || p.W != p.Wo || P > env_maxp || P > 64 || (64 % P) || (p.Cin != 128 && p.Cin != 256 && p.Cin != 512) ||
+  if (!env || p.k != 3 || p.pad != 1 || P > env_maxp || P > 64 || (64 % P) || (p.Cin != 128 && p.Cin != 256 && p.Cin != 512) ||
       p.in_layout != LAYOUT_NHWC || p.res || p.post != SSDK_ACT_NONE || p.Cout < 16)
     return 1;
   static const int env_pk = getenv("SSDK_WFRAG") ? atoi(getenv("SSDK_WFRAG")) : 1;
   const bool packed = p.w_frag != nullptr && env_pk != 0;
+  static const int env_s2 = getenv("SSDK_CONV_SMALLMAP_S2") ? atoi(getenv("SSDK_CONV_SMALLMAP_S2")) : 1;
+  const bool s2 = p.stride == 2;
+  if (s2) {  // the stride-2 instance: even input map, fragment-major weights, the input maps of a workgroup fit the LDS
+    if (!env_s2 || !packed || p.H != 2 * p.Ho || p.W != 2 * p.Wo || P == 1) return 1;
+    const size_t need = (size_t)((64 / P) * (p.H * p.W + p.H / 2) + 1) * (p.Cin * 2 + 16);
+    if (need > 160 * 1024) return 1;
+  } else if (p.stride != 1 || p.H != p.Ho || p.W != p.Wo) {
+    return 1;
+  }
   // Where 128 pixels per workgroup still leave a workgroup per CU (the 8x8 level at batch 64): with fragment-major weights
   // 64 pixels x 32 channels per wave (na = 2: a pixel fragment serves two MFMAs), else 128 pixels x 16 channels per wave
   const int nfr64 = (p.Cout + 63) / 64;
   const bool big = 2 * P <= 128 && (128 % P) == 0 && (long)((p.N + 128 / P - 1) / (128 / P)) * nfr64 >= 256;
   static const int env_na = getenv("SSDK_CONV_SMALLMAP_NA") ? atoi(getenv("SSDK_CONV_SMALLMAP_NA")) : 2;
-  const int na = (big && packed && env_na == 2) ? 2 : 1;
+  const int na = ((big && packed && env_na == 2) || s2) ? 2 : 1;
   const int mfr = (big && na == 1) ? 8 : 4;
   const int G = 16 * mfr / P;
   // waves (= 16 na-channel fragments) per workgroup
@@ -205,14 +230,15 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   static const int env_nw = getenv("SSDK_CONV_SMALLMAP_NW") ? atoi(getenv("SSDK_CONV_SMALLMAP_NW")) : 4;
   const int nw = env_nw == 1 || env_nw == 2 ? env_nw : 4;  // (fewer waves per workgroup = more workgroups: measured slower on every level)
   const dim3 grid((unsigned)groups, (unsigned)((nfr + nw - 1) / nw));
-  const size_t lds = (size_t)(16 * mfr + 1) * (p.Cin * 2 + 16);
+  const size_t lds = s2 ? (size_t)(G * (p.H * p.W + p.H / 2) + 1) * (p.Cin * 2 + 16) : (size_t)(16 * mfr + 1) * (p.Cin * 2 + 16);
   const int cs = p.Cin / 32;
-#define SSDK_SM0(DT, CS_, MFR_, TAPS_, PK_, NA_)                                                                           \
+#define SSDK_SMS(DT, CS_, MFR_, TAPS_, PK_, NA_, S_)                                                                       \
   do {                                                                                                                     \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_, MFR_, TAPS_, PK_, NA_>),       \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_, MFR_, TAPS_, PK_, NA_, S_>),   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
-    hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_, MFR_, TAPS_, PK_, NA_>), grid, dim3(64 * nw), lds, stream, p);       \
+    hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_, MFR_, TAPS_, PK_, NA_, S_>), grid, dim3(64 * nw), lds, stream, p);   \
   } while (0)
+#define SSDK_SM0(DT, CS_, MFR_, TAPS_, PK_, NA_) SSDK_SMS(DT, CS_, MFR_, TAPS_, PK_, NA_, 1)
 #define SSDK_SM1(DT, CS_, MFR_, TAPS_)                  \
   do {                                                  \
     if (packed) SSDK_SM0(DT, CS_, MFR_, TAPS_, true, 1); \
@@ -220,7 +246,8 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   } while (0)
 #define SSDK_SM(DT, CS_)                         \
   do {                                           \
-    if (P == 1) SSDK_SM1(DT, CS_, 4, 1);         \
+    if (s2) SSDK_SMS(DT, CS_, 4, 9, true, 2, 2); \
+    else if (P == 1) SSDK_SM1(DT, CS_, 4, 1);    \
     else if (na == 2) SSDK_SM0(DT, CS_, 4, 9, true, 2); \
     else if (mfr == 8) SSDK_SM1(DT, CS_, 8, 9);  \
     else SSDK_SM1(DT, CS_, 4, 9);                \
@@ -237,6 +264,7 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
 #undef SSDK_SM
 #undef SSDK_SM1
 #undef SSDK_SM0
+#undef SSDK_SMS
   return 0;
 }
 
