@@ -434,84 +434,9 @@ __global__ __launch_bounds__(256) void bn_apply_flat_kernel(const BnParams p, co
   }
 }
 
-// Second version of the flat apply pass (SSDK_BN_FLAT=3; not the default until it has been measured).  What the first
-// one does badly on the planes where the per-plane kernel is good: its coefficient loads are per-lane global loads issued
-// AFTER the data loads of a trip have been waited for, one dependent L2 round trip per vector.  Here a workgroup whose
-// range lies inside one plane (CHUNKED) reads its four coefficients once, uniformly (scalar registers); the others fetch
-// each vector's coefficients together with its data, before the wait.
-template <int DT, int MODE, bool CHUNKED>
-__global__ __launch_bounds__(256) void bn_apply_flat2_kernel(const BnParams p, const BnFlat f) {
-  constexpr int VN = BnVec<DT>::n;
-  const int act = p.act;
-  const long NC = (long)p.N * p.C;
-  const u32 bid = blockIdx.x;
-  const long P0 = (long)(bid / (u32)f.chunks) * f.G;
-  const int lo = (int)(bid % (u32)f.chunks) * kBnChunk;
-  const long left = NC - P0;
-  const int hi = CHUNKED ? (p.HW - lo < kBnChunk ? p.HW : lo + kBnChunk) : (int)(left < f.G ? left : f.G) * p.HW;
-  const int c0 = (int)(P0 % p.C);
-  const size_t base = (size_t)P0 * p.HW;
-  const float4* coef = reinterpret_cast<const float4*>(p.coef);
-  auto channel = [&](int le) {
-    const int cc = c0 + bn_div_small(le, f.rcpHW);
-    return cc - bn_div_small(cc, f.rcpC) * p.C;
-  };
-  auto one = [&](float x, float g, const float4 k) {  // k = (a, k0, k1, fb)
-    if (MODE == 0) {
-      float o = x * k.x + k.y;
-      if (act) o = fmaxf(o, 0.f);
-      if (act == 1) o = fminf(o, 6.f);
-      return o;
-    }
-    if (act && !bn_act_open<DT>(x * k.x + k.w, act)) g = 0.f;
-    return g * k.x + x * k.z + k.y;
-  };
-  const float4 k0 = coef[c0];  // uniform: the whole range when CHUNKED
-  const int nvec = (hi - lo) / VN;
-  for (int vb = 0; vb < nvec; vb += 256 * kBnU) {
-    u32x4 xr[kBnU], gr[kBnU];
-    float4 kv[kBnU];
-#pragma unroll
-    for (int u = 0; u < kBnU; ++u) {
-      const int v = vb + u * 256 + (int)threadIdx.x;
-      xr[u] = u32x4{0u, 0u, 0u, 0u};
-      gr[u] = u32x4{0u, 0u, 0u, 0u};
-      kv[u] = k0;
-      if (v < nvec) {
-        const size_t off = base + lo + (size_t)v * VN;
-        xr[u] = bn_load_raw<DT>(p.x, off);
-        if (MODE == 1) gr[u] = bn_load_raw<DT>(p.dy, off);
-        if (!CHUNKED) kv[u] = coef[channel(lo + v * VN)];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < kBnU; ++u) {
-      const int v = vb + u * 256 + (int)threadIdx.x;
-      if (v >= nvec) continue;
-      const int le = lo + v * VN;
-      float xv[8], gv[8], o[8];
-      bn_unpack<DT>(xr[u], xv);
-      bn_unpack<DT>(gr[u], gv);
-      bool straddle = false;
-      if (!CHUNKED) straddle = le + VN > (bn_div_small(le, f.rcpHW) + 1) * p.HW;
-      if (!straddle) {
-#pragma unroll
-        for (int e = 0; e < VN; ++e) o[e] = one(xv[e], gv[e], kv[u]);
-      } else {  // the vector straddles planes (plane sizes that are not a multiple of the vector width)
-#pragma unroll
-        for (int e = 0; e < VN; ++e) o[e] = one(xv[e], gv[e], coef[channel(le + e)]);
-      }
-      bn_store_raw<DT>(p.out, base + le, o);
-    }
-  }
-  const int rest = (hi - lo) - nvec * VN;
-  if ((int)threadIdx.x < rest) {
-    const int le = lo + nvec * VN + (int)threadIdx.x;
-    const float x = bn_ld1<DT>(p.x, base + le), g = MODE == 1 ? bn_ld1<DT>(p.dy, base + le) : 0.f;
-    bn_st1<DT>(p.out, base + le, one(x, g, CHUNKED ? k0 : coef[channel(le)]));
-  }
-}
+// (A second version of the flat apply pass -- coefficients through scalar loads where a workgroup's range lies inside one
+//  plane, fetched with the data otherwise -- was written at the end of round 2, run in round 3 (57 BatchNorm tests green) and
+//  A/B-timed on the 512 px training step: 24.66 / 24.52 ms without, 24.77 / 24.58 ms with it.  No gain: deleted.)
 
 static int bn_split(int N, int C) {
   int s = (1024 + C - 1) / C;
@@ -522,7 +447,7 @@ static int bn_split(int N, int C) {
 
 template <int MODE>
 static void bn_launch(const BnParams& p, hipStream_t st) {
-  // 0: the per-plane kernels, 1: the flat kernels, 3: the flat kernels with the second apply pass, 2 (default): the flat reduction always, the flat apply pass only where
+  // 0: the per-plane kernels, 1: the flat kernels, 2 (default): the flat reduction always, the flat apply pass only where
   // the per-plane one cannot use vectors (plane size not a multiple of the vector width, or a misaligned tensor: there it
   // works element by element).  Per launch on the 512 px step, bf16 (profiles/r02_train_kernel_split_v2.txt against a trace
   // with SSDK_BN_FLAT=1): reduction 21.2 -> 18.1 us forward, 38.8 -> 36.6 us backward; apply 26.3 -> 25.8 us forward but
@@ -533,8 +458,7 @@ static void bn_launch(const BnParams& p, hipStream_t st) {
   const bool vec_ok = (p.HW % vn) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)p.dy) | ((uintptr_t)p.out)) & 15u) == 0;
   const bool fits = (long)p.N * p.HW < (1l << 30) && p.HW < (1 << 20) && p.C < (1 << 19);
   const bool flat_r = env_flat != 0 && fits;
-  const bool flat = (env_flat == 1 || env_flat == 3 || (env_flat == 2 && !vec_ok)) && fits;
-  const bool flat2 = env_flat == 3;  // the second version of the flat apply pass, everywhere (to be measured)
+  const bool flat = (env_flat == 1 || (env_flat == 2 && !vec_ok)) && fits;
   BnFlat f;
   f.G = p.HW >= kBnChunk ? 1 : kBnChunk / p.HW;
   f.chunks = p.HW >= kBnChunk ? (p.HW + kBnChunk - 1) / kBnChunk : 1;
@@ -549,10 +473,7 @@ static void bn_launch(const BnParams& p, hipStream_t st) {
     else hipLaunchKernelGGL((bn_reduce_kernel<DT, MODE>), rgrid, dim3(256), 0, st, p);                      \
     if (MODE == 0) hipLaunchKernelGGL((bn_fwd_finalize_kernel<DT>), dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p); \
     else hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p);  \
-    if (flat && flat2 && fgrid < (1l << 31)) {                                                              \
-      if (f.chunks > 1) hipLaunchKernelGGL((bn_apply_flat2_kernel<DT, MODE, true>), dim3((unsigned)fgrid), dim3(256), 0, st, p, f); \
-      else hipLaunchKernelGGL((bn_apply_flat2_kernel<DT, MODE, false>), dim3((unsigned)fgrid), dim3(256), 0, st, p, f); \
-    } else if (flat && fgrid < (1l << 31)) hipLaunchKernelGGL((bn_apply_flat_kernel<DT, MODE>), dim3((unsigned)fgrid), dim3(256), 0, st, p, f); \
+    if (flat && fgrid < (1l << 31)) hipLaunchKernelGGL((bn_apply_flat_kernel<DT, MODE>), dim3((unsigned)fgrid), dim3(256), 0, st, p, f); \
     else hipLaunchKernelGGL((bn_apply_kernel<DT, MODE>), agrid, dim3(256), 0, st, p);                        \
   } while (0)
   if (p.dtype == SSDK_F32) SSDK_BN(SSDK_F32);
