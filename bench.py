@@ -14,10 +14,10 @@ Other BASELINE configs through the same file: `--cfg experiments/cfgs/fpn_resnet
 `--cfg experiments/cfgs/bifpn_regnetx008_896.yml --batch 16 --dtype fp16 --graph 1` (config 5).
 
 The whole step runs in line on one stream by default.  Serving-loop pipelining is an option (--tail-stream 1): the
-latency-bound end of the decode stage (tail_kernel: level merge + box decode + NMS, one workgroup per image) is then
-enqueued on its own HIP stream and runs under the NEXT step's forward pass while the HBM-bound scan_kernel stays in
-line on the main stream.  It was the default in round 1 (+3 % with the three-launch decode stage); with the fused
-tail kernel it is within noise of the in-line step (37.01 vs 37.06 k img/s on the same box), so the simpler path is
+latency-bound end of the decode stage (levelsel_kernel + nmswalk_kernel: per-level select + box decode, NMS) is then
+enqueued on its own HIP stream and runs under the NEXT step's forward pass while the HBM-bound scan16_kernel stays in
+line on the main stream.  It was the default in round 1 (+3 % with that round's decode stage); since round 2 it is
+within noise of the in-line step (round 3, same box: 45.89 / 45.90 k in line, 45.78 / 45.73 k img/s with it), so the simpler path is
 the one that is timed.  All work of the K steps completes inside the timed region (device-wide synchronize on both
 sides).  After the timed loop the last step is re-run in line (bit-equal outputs required) and, on rank 0 of an N=1 run,
 the numpy oracle decodes the GPU's own head outputs of a sample of images (must reproduce the timed detections) and the
