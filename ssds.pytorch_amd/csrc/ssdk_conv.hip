@@ -1301,6 +1301,49 @@ static int edge(hipStream_t from, hipEvent_t e, hipStream_t to) {  // work recor
   return SSDK_OK;
 }
 
+// Grouped launch of neighbouring small-map layers (launch_conv_smallmap_group): the ConvParams of a plan op that is a plain
+// dense 3x3 / stride-1 / NHWC-input convolution without residual -- anything else (and anything ssdk_conv would reject) is
+// not a member and goes through ssdk_conv, with its checks and error messages, as before.
+static bool group_member_params(const ssdk_conv_desc* d, ConvParams* p) {
+  if (!d->x || !d->w || !d->w_frag || !d->bias || !d->y || d->residual) return false;
+  if ((d->dtype != SSDK_BF16 && d->dtype != SSDK_F16) || d->k != 3 || d->stride != 1 || d->groups != 1) return false;
+  if (d->N < 1 || d->Cin < 8 || (d->Cin % 8) || d->H < 1 || d->W < 1 || d->Cout < 1 || d->in_layout != LAYOUT_NHWC) return false;
+  if (((uintptr_t)d->x | (uintptr_t)d->w | (uintptr_t)d->w_frag | (uintptr_t)d->y | (uintptr_t)d->y2) & 15) return false;
+  const int split = (d->y2 && d->split > 0 && d->split < d->Cout) ? d->split : d->Cout;
+  if (d->out_layout == LAYOUT_NHWC && split != d->Cout) return false;
+  if ((long)d->N * d->H * d->W >= (1l << 31)) return false;
+  memset(p, 0, sizeof(*p));
+  p->x = d->x;
+  p->w = d->w;
+  p->w_frag = d->w_frag;
+  p->scale = d->scale;
+  p->bias = d->bias;
+  p->y = d->y;
+  p->y2 = d->y2;
+  p->N = d->N;
+  p->Cin = d->Cin;
+  p->H = d->H;
+  p->W = d->W;
+  p->Cout = d->Cout;
+  p->k = 3;
+  p->stride = 1;
+  p->pad = 1;
+  p->Ho = d->H;
+  p->Wo = d->W;
+  p->M = d->N * d->H * d->W;
+  p->cin_chunks = (d->Cin + BK - 1) / BK;
+  p->KT = 9 * p->cin_chunks;
+  p->act = d->act;
+  p->act2 = d->act2;
+  p->split = split;
+  p->in_layout = d->in_layout;
+  p->out_layout = d->out_layout;
+  p->post = SSDK_ACT_NONE;
+  p->ksplits = 1;
+  p->kt_per = p->KT;
+  return true;
+}
+
 extern "C" int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* workspace, size_t workspace_bytes,
                                 void* stream) {
   if (int rc = ssdk::ctx_enter(ctx)) return rc;
@@ -1344,6 +1387,36 @@ extern "C" int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* 
       st = ctx->side;
       w = ws_side;
       wb = ws_side_bytes;
+    }
+    if (!rc && !side && ops[i].kind == SSDK_OP_CONV) {
+      // neighbouring small-map layers that do not read each other's outputs: one launch
+      ConvParams gp[kSmallmapGroupMax];
+      int m = 0;
+      while (m < kSmallmapGroupMax && i + m < n && ops[i + m].kind == SSDK_OP_CONV && !(use_side && ops[i + m].lane == 1) &&
+             ops[i + m].conv.dtype == ops[i].conv.dtype && group_member_params(&ops[i + m].conv, &gp[m])) {
+        bool indep = true;
+        for (int a = 0; a < m; ++a)
+          indep = indep && gp[m].x != gp[a].y && (gp[a].y2 == nullptr || gp[m].x != gp[a].y2);
+        if (!indep) break;
+        ++m;
+      }
+      if (m >= 2) {
+        ssdk::lds_poison(st);
+        if (launch_conv_smallmap_group(gp, m, ops[i].conv.dtype, st) == 0) {
+          rc = check_launch("conv_smallmap_group_kernel");
+          if (!rc) {
+            for (int a = 0; a < m; ++a) {  // (profiling: the group's time lands on its first op, the others read ~0)
+              if (prof) ctx->op_kernel[i + a] = ssdk_last_kernel();
+              if (prof && a > 0 && hipEventRecord(ctx->op_ev[i + a], main_s) != hipSuccess) {
+                set_error("run_ops: hipEventRecord failed");
+                return SSDK_E_LAUNCH;
+              }
+            }
+            i += m - 1;
+            continue;
+          }
+        }
+      }
     }
     if (!rc) {
       ssdk::lds_poison(st);

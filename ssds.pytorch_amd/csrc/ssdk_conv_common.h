@@ -180,6 +180,8 @@ int launch_gconv3x3_g16(const ssdk_conv_desc* d, int Ho, int Wo, hipStream_t str
 int halo_splitk_plan(int N, int Cin, int Ho, int Wo, int Cout, bool nchw, size_t* ws_bytes);
 // halo-tile 3x3 kernel (ssdk_conv3x3.hip); returns SSDK_OK, or 1 when the layer does not fit it
 int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool allow_underfill);
-int launch_conv3x3_short(const ConvParams& p, int dtype, hipStream_t stream);  // ssdk_conv3x3s.hip: Cin <= 128, needs p.w_frag
+int launch_conv3x3_short(const ConvParams& p, int dtype, hipStream_t stream);
+constexpr int kSmallmapGroupMax = 4;
+int launch_conv_smallmap_group(const ConvParams* ps, int n, int dtype, hipStream_t stream);  // ssdk_smallmap.hip  // ssdk_conv3x3s.hip: Cin <= 128, needs p.w_frag
 
 }  // namespace ssdk

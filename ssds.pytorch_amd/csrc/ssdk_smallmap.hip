@@ -31,7 +31,7 @@ constexpr int kSmThreads = 256;
 // (row index iy * W + ix + (iy >> 1)) so that the sixteen 16-byte reads of a fragment still fall into sixteen different
 // bank groups (row stride = an odd number of 16-byte chunks; without the skew output rows oy and oy + 1 collide).
 template <int DT, int CS, int MFR, int TAPS, bool PK, int NA, int S>
-__global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvParams p) {
+__device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx, const u32 by) {
   static_assert(NA == 1 || PK, "two channel fragments per wave read the fragment-major image");
   static_assert(S == 1 || TAPS == 9, "stride 2 visits all taps");
   constexpr int ROWS = 16 * MFR;
@@ -43,12 +43,12 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
   const int PI = p.H * p.W;                                 // input pixels per image (== P for stride 1)
   const int PL = S == 2 ? PI + (p.H >> 1) : PI;             // LDS row slots per image (skewed for stride 2)
   const int ZROW = G * PL;                                  // the zero row
-  const int img0 = (int)blockIdx.x * G;
+  const int img0 = (int)bx * G;
   const int RS = Cin * 2 + 16;                           // LDS row stride (bytes); row ROWS = zeros
   const u16* x = (const u16*)p.x;
 
   // ---- the weight stream starts first: it does not depend on the maps -----------------------------------------------
-  const int co_row0 = ((int)blockIdx.y * (int)(blockDim.x >> 6) + (int)wave) * 16 * NA;  // 1, 2 or 4 waves per workgroup
+  const int co_row0 = ((int)by * (int)(blockDim.x >> 6) + (int)wave) * 16 * NA;  // 1, 2 or 4 waves per workgroup
   int co_a = co_row0 + (int)fr;
   co_a = co_a < p.Cout ? co_a : p.Cout - 1;  // rows past Cout: computed on a valid row, never stored
   const u16* wrow = PK ? (const u16*)p.w_frag + (size_t)(co_row0 < p.Cout ? co_row0 >> 4 : (p.Cout - 1) >> 4) * 9 * Cin * 16 + lane * 8
@@ -196,6 +196,85 @@ __global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvPar
         else ((u16*)p.y2)[((size_t)b * (p.Cout - p.split) + (co - p.split)) * P + q] = h;
       }
     }
+}
+
+template <int DT, int CS, int MFR, int TAPS, bool PK, int NA, int S>
+__global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvParams p) {
+  smallmap_body<DT, CS, MFR, TAPS, PK, NA, S>(p, blockIdx.x, blockIdx.y);
+}
+
+// Several independent small-map layers in ONE launch (the multibox heads of the 4x4 / 2x2 / 1x1 levels: 128 + 32 + 8
+// workgroups whose kernels are chains of dependent latencies -- weights, map, epilogue -- of 8-12 us each with most of the
+// chip idle; run together they cost the longest one).  Members: 3x3 / stride 1, fragment-major weights, 64 pixels x 16
+// channels per wave (MFR = 4, NA = 1), 256 threads.  The executor groups neighbouring plan ops that qualify and do not
+// read each other's outputs (ssdk_run_ops).
+struct SmallmapGroup {
+  ConvParams p[kSmallmapGroupMax];
+  unsigned start[kSmallmapGroupMax + 1];  // first workgroup of member i
+  unsigned gx[kSmallmapGroupMax];         // grid.x of member i (image groups)
+  int code[kSmallmapGroupMax];            // 2 * log2(Cin / 128) + (1x1 map)
+  int n;
+};
+template <int DT>
+__global__ __launch_bounds__(kSmThreads) void conv_smallmap_group_kernel(const SmallmapGroup g) {
+  int m = 0;
+  for (int i = 1; i < g.n; ++i)
+    if (blockIdx.x >= g.start[i]) m = i;
+  const u32 local = blockIdx.x - g.start[m], bx = local % g.gx[m], by = local / g.gx[m];
+  const ConvParams& p = g.p[m];
+  switch (g.code[m]) {
+    case 0: smallmap_body<DT, 4, 4, 9, true, 1, 1>(p, bx, by); break;
+    case 1: smallmap_body<DT, 4, 4, 1, true, 1, 1>(p, bx, by); break;
+    case 2: smallmap_body<DT, 8, 4, 9, true, 1, 1>(p, bx, by); break;
+    case 3: smallmap_body<DT, 8, 4, 1, true, 1, 1>(p, bx, by); break;
+    case 4: smallmap_body<DT, 16, 4, 9, true, 1, 1>(p, bx, by); break;
+    default: smallmap_body<DT, 16, 4, 1, true, 1, 1>(p, bx, by); break;
+  }
+}
+
+// Can this layer be a member of a grouped launch?  (what launch_conv_smallmap would run as <CS, 4, TAPS, true, 1, 1>)
+static bool smallmap_group_member(const ConvParams& p) {
+  static const int env = getenv("SSDK_CONV_SMALLMAP") ? atoi(getenv("SSDK_CONV_SMALLMAP")) : 1;
+  static const int env_pk = getenv("SSDK_WFRAG") ? atoi(getenv("SSDK_WFRAG")) : 1;
+  const int P = p.Ho * p.Wo;
+  if (!env || !env_pk || !p.w_frag || p.k != 3 || p.stride != 1 || p.pad != 1 || p.H != p.Ho || p.W != p.Wo || P > 64 || (64 % P) ||
+      (p.Cin != 128 && p.Cin != 256 && p.Cin != 512) || p.in_layout != LAYOUT_NHWC || p.res || p.post != SSDK_ACT_NONE || p.Cout < 16)
+    return false;
+  const int nfr64 = (p.Cout + 63) / 64;
+  const bool big = 2 * P <= 128 && (128 % P) == 0 && (long)((p.N + 128 / P - 1) / (128 / P)) * nfr64 >= 256;
+  return !big;  // (the 8x8 level at batch 64 fills the chip on its own, with another instance)
+}
+
+// 1: not a group this kernel takes (the caller launches the layers one by one), 0: launched
+int launch_conv_smallmap_group(const ConvParams* ps, int n, int dtype, hipStream_t stream) {
+  static const int env = getenv("SSDK_CONV_SMALLMAP_GROUP") ? atoi(getenv("SSDK_CONV_SMALLMAP_GROUP")) : 1;
+  if (!env || n < 2 || n > kSmallmapGroupMax) return 1;
+  SmallmapGroup g;
+  g.n = n;
+  size_t lds = 0;
+  unsigned total = 0;
+  for (int i = 0; i < n; ++i) {
+    const ConvParams& p = ps[i];
+    if (!smallmap_group_member(p)) return 1;
+    const int P = p.Ho * p.Wo, G = 64 / P;
+    g.p[i] = p;
+    g.gx[i] = (unsigned)((p.N + G - 1) / G);
+    const unsigned gy = (unsigned)(((p.Cout + 15) / 16 + 3) / 4);
+    g.start[i] = total;
+    total += g.gx[i] * gy;
+    g.code[i] = (p.Cin == 128 ? 0 : p.Cin == 256 ? 2 : 4) + (P == 1 ? 1 : 0);
+    const size_t l = (size_t)(64 + 1) * (p.Cin * 2 + 16);
+    lds = l > lds ? l : lds;
+  }
+  g.start[n] = total;
+  if (dtype == SSDK_BF16) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_group_kernel<SSDK_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((conv_smallmap_group_kernel<SSDK_BF16>), dim3(total), dim3(kSmThreads), lds, stream, g);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_group_kernel<SSDK_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((conv_smallmap_group_kernel<SSDK_F16>), dim3(total), dim3(kSmThreads), lds, stream, g);
+  }
+  return 0;
 }
 
 // 1: not one of this kernel's layers (the caller goes on), 0: launched

@@ -132,19 +132,20 @@ def build_ssd_plan(model, x):
         feats = record_backbone(plan, plan.input_value(), model.backbone)
         for i, f in enumerate(feats):
             head(i, f)
-    # The heads of the extras' levels are a serial chain on the side lane (each waits for its feature map); the extras
-    # themselves are short, so the main lane would idle while the side lane works through four heads.  The first of
-    # them (the largest: 8x8 at 512 input) therefore runs on the MAIN lane behind the last extra layer.
+    # The heads of the extras' levels are recorded BEHIND the extras chain, next to each other (outputs keep the level order):
+    # they depend only on their feature maps, and the executor launches neighbouring small-map layers that do not read each
+    # other's outputs as ONE kernel (ssdk_run_ops -> conv_smallmap_group_kernel: the 4x4 / 2x2 / 1x1 heads are chains of
+    # dependent latencies with 128 / 32 / 8 workgroups each).  SSDK_HEAD_BALANCE=0: every head right behind its feature map.
     balance = os.environ.get("SSDK_HEAD_BALANCE", "1") != "0" and len(model.extras) > 1
-    deferred = None
+    deferred = []
     for j, extra in enumerate(model.extras):
         feats.append(record_chain(plan, feats[-1], extra, keep_input=True))
-        if balance and j == 0:
-            deferred = (len(feats) - 1, feats[-1])
+        if balance:
+            deferred.append((len(feats) - 1, feats[-1]))
         else:
             head(len(feats) - 1, feats[-1])
-    if deferred is not None:
-        head(deferred[0], deferred[1], lane=0, position=deferred[0])
+    for i, f in deferred:
+        head(i, f, lane=0, position=i)
     return plan.finalize()
 
 

@@ -368,7 +368,8 @@ def test_fusing_bn_activations_changes_nothing_on_cpu():
 def test_ssd_mobilenetv2_plan_recording_fuses_extras_and_keeps_head_order():
     """Recording only (CPU, no kernel runs): the recorded plan of SSD-MobileNetV2@512 has one fused block per
     inverted-residual block, the three small extra layers as single `xpair` ops, and its head outputs in LEVEL order
-    although the 8x8 level's head is recorded last (main lane, behind the extras)."""
+    although the heads of the extras' levels are recorded behind the extras chain, next to each other (main lane: the
+    executor launches the three small-map heads that follow the 8x8 one as one kernel)."""
     import os
     import torch
     from ssds.core import config
@@ -381,9 +382,9 @@ def test_ssd_mobilenetv2_plan_recording_fuses_extras_and_keeps_head_order():
     plan = planner.build_ssd_plan(model, torch.zeros(2, 3, 512, 512, dtype=torch.bfloat16))
     kinds = [L.get("kind") or ("head" if L.get("nchw") else "conv") for L in plan.layers]
     assert kinds.count("mb") == 17 and kinds.count("xpair") == 3 and kinds.count("head") == 6 and kinds.count("conv") == 2
-    assert kinds[-1] == "head" and plan.layers[-1]["lane"] == 0      # the deferred 8x8 head: last op, main lane
+    assert kinds[-4:] == ["head"] * 4 and all(L["lane"] == 0 for L in plan.layers[-4:])  # the extras' heads: last ops, main lane
     assert [(h[4], h[5]) for h in plan.heads] == [(32, 32), (16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
-    assert plan.heads[2][0] == len(plan.layers) - 1                  # ... and third in the output order
+    assert [h[0] for h in plan.heads[2:]] == list(range(len(plan.layers) - 4, len(plan.layers)))   # ... in level order
     xp = [L for L in plan.layers if L.get("kind") == "xpair"]
     assert [(L["h"], L["pack"].cin, L["pack"].cout, L["pack2"].cout) for L in xp] == [(8, 512, 128, 256), (4, 256, 128, 256),
                                                                                       (2, 256, 64, 128)]
