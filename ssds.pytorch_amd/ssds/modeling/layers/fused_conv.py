@@ -382,10 +382,10 @@ def fill_desc(d, x_ptr, n, h, w, pack, dtype_code, act, y_ptr, in_layout=N.NHWC,
               residual_ptr=None, y2_ptr=None, split=None, act2=None):
     d.x, d.w = x_ptr, pack.w.data_ptr()
     # small maps: the kernel streams weights into operand registers and wants them fragment-major (conv_smallmap_kernel)
-    # short K (Cin <= 128): conv3x3_short_kernel stages its weights from the same image
+    # conv3x3_short_kernel (Cin <= 128, 256) reads its weight fragments from the same image
     # stride 2 onto a small map (the first SSD extra, 16x16 -> 8x8): the stride-2 instance of conv_smallmap_kernel
     frag = pack.frag() if (pack.kind == "dense" and pack.k == 3 and (
-        (pack.stride == 1 and (h * w <= 64 or pack.cin <= 128)) or (pack.stride == 2 and h * w <= 256))) else None
+        (pack.stride == 1 and (h * w <= 64 or pack.cin <= 128 or pack.cin == 256)) or (pack.stride == 2 and h * w <= 256))) else None
     d.w_frag = frag.data_ptr() if frag is not None else None
     d.scale = pack.scale.data_ptr() if pack.scale is not None else None
     d.bias = pack.bias.data_ptr()

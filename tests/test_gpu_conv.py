@@ -110,11 +110,13 @@ LARGE = [
     (256, 504, 3, 1, 2, 2, 35, "relu", SMALLMAP),  # SSD head L4: sixteen maps per workgroup
     (128, 504, 3, 1, 1, 1, 64, "silu", SMALLMAP),  # SSD head L5: 1x1 maps, only the centre tap sees data
     (256, 40, 3, 1, 2, 4, 9, "relu6", SMALLMAP),   # 2x4 map, a single partial channel range
-    # (the short-K kernel writes NCHW only: the NHWC call of these rows runs on another kernel)
-    (96, 504, 3, 1, 32, 32, 64, "sigmoid", SHORT), # SSD head L0 at bench size: short K, a 128-pixel patch x 4 channel tiles per workgroup
-    (128, 256, 3, 1, 40, 40, 20, "relu", SHORT),   # ragged patches (40 = 2.5 x 16), the largest halo, two channel tiles
-    (32, 130, 3, 1, 64, 64, 8, "relu6", SHORT),    # one 32-channel slice, a ragged second channel tile
-    (64, 160, 3, 1, 24, 48, 32, "silu", SHORT),    # non-square map
+    # conv3x3_short_kernel: (kernel of the NHWC call, kernel of the NCHW call) -- NHWC takes none / relu / relu6, NCHW none / sigmoid / silu
+    (96, 504, 3, 1, 32, 32, 64, "sigmoid", (HALO, SHORT)), # SSD head L0 at bench size: a 128-pixel patch x 4 channel tiles per workgroup
+    (128, 256, 3, 1, 40, 40, 20, "relu", (SHORT, HALO)),   # ragged patches (40 = 2.5 x 16), two channel tiles
+    (32, 132, 3, 1, 64, 64, 8, "none", SHORT),             # one 32-channel slice, a ragged second channel tile
+    (64, 160, 3, 1, 24, 48, 32, "silu", (HALO, SHORT)),    # non-square map
+    (256, 256, 3, 1, 40, 40, 32, "relu", (SHORT, HALO)),   # FPN tower layer: one workgroup per CU, A fragments one k-step ahead
+    (256, 720, 3, 1, 24, 24, 48, "sigmoid", (HALO, SHORT)),# FPN head: six channel tiles, the last one ragged
     (256, 512, 3, 2, 16, 16, 64, "relu", SMALLMAP),   # first SSD extra: stride 2 from a 16x16 onto an 8x8 map (skewed input rows)
     (128, 256, 3, 2, 8, 8, 33, "relu6", SMALLMAP),    # stride 2 onto 4x4: four images per workgroup, a ragged last group
     (128, 100, 3, 2, 4, 4, 70, "silu", SMALLMAP),     # stride 2 onto 2x2, a partial channel range
@@ -148,11 +150,12 @@ def test_large_tile_kernels(cin, cout, k, stride, h, w, n, act, kernel, dtype_na
     conv, bn = conv.cuda(), bn.cuda()
     pack = FC.ConvPack(conv, bn, act, dtype)
     want = _ref(x, conv, bn, act)
+    k_nhwc, k_nchw = kernel if isinstance(kernel, tuple) else (kernel, kernel)
     y = FC.conv_native(x.cuda(), pack)
-    assert N.last_kernel() == kernel or kernel == SHORT, N.last_kernel()
+    assert N.last_kernel() == k_nhwc, N.last_kernel()
     _check(y, want, dtype, "large nhwc")
     y2 = FC.conv_native(x.cuda(), pack, nchw_out=True)
-    assert N.last_kernel() == kernel
+    assert N.last_kernel() == k_nchw, N.last_kernel()
     _check(y2, want, dtype, "large nchw")
 
 

@@ -20,6 +20,7 @@ SHAPES = {
     "head_L4": (64, 256, 2, 2, 504, 3, 1, "head"),
     "head_L5": (64, 128, 1, 1, 504, 3, 1, "head"),
     "tower_P3": (32, 256, 80, 80, 256, 3, 1, "relu"),
+    "tower_P4": (32, 256, 40, 40, 256, 3, 1, "relu"),
     "tower_P5": (32, 256, 20, 20, 256, 3, 1, "relu"),
     "tower_cls": (32, 256, 80, 80, 720, 3, 1, "relu"),
     "pw_320_1280": (64, 320, 16, 16, 1280, 1, 1, "relu"),
