@@ -461,3 +461,33 @@ def test_a_model_that_went_through_the_training_solver_still_records_its_eval_pl
     assert kinds.count("mb") == 17 and kinds.count("xpair") == 3 and kinds.count("head") == 6
     acts = [L["pack"].act for L in plan.layers if L.get("kind") == "xpair"]
     assert acts == ["relu"] * 3 or all(a in ("relu", "relu6") for a in acts)
+
+
+def test_fragment_major_weight_image_layout_and_size():
+    """ConvPack.frag() (pure layout, runs on CPU): block (g, ks), lane (fg, fr) holds w[16 g + fr][32 ks + 8 fg .. + 7] of the
+    KRSC matrix, rows past Cout are zero, and the byte count is what the C-ABI's ssdk_weight_frag_bytes promises
+    (include/ssdk.h); layers no kernel reads it for get none."""
+    import torch
+    import torch.nn as nn
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+
+    torch.manual_seed(3)
+    conv = nn.Conv2d(96, 504, 3, 1, 1, bias=True)
+    pack = FC.ConvPack(conv, None, "none", torch.bfloat16)
+    img = pack.frag()
+    k = 9 * 96
+    assert img.shape == (32, k // 32, 4, 16, 8) and img.dtype == torch.bfloat16 and img.is_contiguous()
+    assert img.numel() * 2 == N.lib.ssdk_weight_frag_bytes(504, k) == 32 * 16 * k * 2
+    w2d = pack.w.reshape(504, k)
+    for g, ks, fg, fr in ((0, 0, 0, 0), (7, 13, 3, 9), (31, 26, 2, 7)):
+        assert torch.equal(img[g, ks, fg, fr], w2d[16 * g + fr, 32 * ks + 8 * fg:32 * ks + 8 * fg + 8])
+    assert float(img[31, :, :, 8:].float().abs().max()) == 0.0          # rows 504 .. 511
+    assert pack.frag() is img                                          # built once per weight tensor
+    pack.w = pack.w.clone()
+    assert pack.frag() is not img                                      # ... and again for a new one
+    assert N.lib.ssdk_weight_frag_bytes(504, 100) == 0                 # K must be a multiple of 32
+    dw = FC.ConvPack(nn.Conv2d(32, 32, 3, 1, 1, groups=32, bias=False), nn.BatchNorm2d(32), "relu6", torch.bfloat16)
+    assert dw.frag() is None                                           # depthwise: no MFMA operand stream
+    odd = FC.ConvPack(nn.Conv2d(24, 64, 3, 1, 1, bias=False), nn.BatchNorm2d(64), "relu", torch.bfloat16)
+    assert odd.frag() is None                                          # Cin % 32 != 0
