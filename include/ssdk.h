@@ -109,12 +109,13 @@ ssdk_ctx* ssdk_ctx_create(void);       /* NULL + ssdk_last_error() when there is
 void ssdk_ctx_destroy(ssdk_ctx* ctx);  /* the caller has synchronised the streams that used it */
 
 /* decoder.py:25-49 Decoder.__call__: decode every level -> concat -> nms, nothing returns to the host in between.
- * Two launches: scan_kernel (one HBM pass over the conf tensors: threshold + exact top-k per scan unit, sorted) and
- * tail_kernel (per image: merge of the units by rank, delta2box + centre rescoring of the winners, sort by rescored
- * score, greedy class-aware (D)IoU NMS).  Geometries whose per-image candidate lists do not fit one CU's LDS run
- * level_kernel + nms_kernel behind the scan instead (three launches, same results; SSDK_DECODE_FUSED=0 forces it).
+ * Three launches: scan16_kernel (one HBM pass over the conf tensors: threshold + exact top-k per scan unit, unsorted;
+ * scan_kernel for fp32 heads, thresholds <= 0 and top_n > 512), levelsel_kernel (per (image, level): select the level's
+ * top_n of its units' keys, order them, delta2box + centre rescoring) and nmswalk_kernel (per image: order by rescored
+ * score in rounds, greedy class-aware (D)IoU NMS).  Geometries whose per-level lists do not fit the LDS run round 1's
+ * level_kernel + nms_kernel behind the scan instead (same results; SSDK_DECODE_FUSED=0 forces it).
  * mid_* (optional, may be NULL): the concatenated per-level decode output [B, L*top_n(,4)] that the reference
- * materialises with torch.cat (decoder.py:48); with the fused tail it only exists when asked for. */
+ * materialises with torch.cat (decoder.py:48); when NULL the library keeps them in the workspace. */
 size_t ssdk_decode_nms_workspace_bytes(const ssdk_level* levels, int L, int B, int dtype,
                                        int top_n_per_level, int ndetections);
 int ssdk_decode_nms(const ssdk_level* levels, int L, int B, int dtype, float threshold,
@@ -128,7 +129,7 @@ int ssdk_decode_nms_ctx(ssdk_ctx* ctx, const ssdk_level* levels, int L, int B, i
                         float* mid_scores, float* mid_boxes, float* mid_classes, void* workspace,
                         size_t workspace_bytes, void* stream);
 
-/* (new) Tail stream of ssdk_decode_nms[_ctx] (NULL = off, the default): when set, scan_kernel still runs on the
+/* (new) Tail stream of ssdk_decode_nms[_ctx] (NULL = off, the default): when set, the scan still runs on the
  * `stream` argument but everything behind it is enqueued on the tail stream, ordered after the scan by an event -- the
  * latency-bound end of the stage then overlaps the next batch's forward pass.  The caller owns the consequences: the
  * outputs are complete on the TAIL stream, the workspace and the box tensors must stay untouched until the tail work
@@ -146,16 +147,17 @@ int ssdk_debug_lds_probe(unsigned* count, void* stream);
 
 /* Optional per-kernel timing for roofline accounting (bench.py): when enabled, ssdk_decode_nms[_ctx] records
  * hipEvents around its launches into the context's ring of 256 slots (no synchronisation inside the timed region).
- * ssdk_[ctx_]get_timings(back, ms, 3): ms[0] = scan_kernel, ms[1] = tail_kernel (or level_kernel on the 3-launch
- * path), ms[2] = nms_kernel (0 on the fused path) of the call `back` calls before the most recent one; it
- * synchronises on that call's last event. */
+ * enable = 1: one event interval per launch -- ssdk_[ctx_]get_timings(back, ms, 3): ms[0] = scan, ms[1] = levelsel (or
+ * level_kernel on the round-1 path), ms[2] = nmswalk (nms_kernel) of the call `back` calls before the most recent one;
+ * enable = 2: ONE interval around the stage's launches (every extra event costs ~4.6 us of GPU time and separates the
+ * kernels it sits between) -- ms[0] = the whole stage, ms[1] = ms[2] = 0.  It synchronises on that call's last event. */
 int ssdk_ctx_set_profiling(ssdk_ctx* ctx, int enable);
 int ssdk_ctx_get_timings(ssdk_ctx* ctx, int back, float* ms, int n);
 int ssdk_set_profiling(int enable);
 int ssdk_get_timings(int back, float* ms, int n);
-/* (debug) SSDK_TAIL_STAMPS=1: shader-clock stamps of workgroup 0 at the phase boundaries of the most recent
- * tail_kernel (out[0..5]: start, lists staged, winners decoded, sorted, walked, end) and scan_kernel (out[8..12]: start,
- * cut found, streamed, selected, end; out[13] = fast-path flag << 32 | winners); n >= 48; synchronises the device. */
+/* (debug) SSDK_TAIL_STAMPS=1: clock stamps of the most recent decode stage -- workgroup 0's phase boundaries in
+ * levelsel_kernel / nmswalk_kernel / scan16_kernel (out[0..23]; layout: tools/scan_probe.py) and, from out[48] on, the
+ * wall-clock start / end of every scan workgroup (2 x min(workgroups, 4096) words); n >= 48; synchronises the device. */
 int ssdk_ctx_get_tail_stamps(ssdk_ctx* ctx, unsigned long long* out, int n);
 /* Per-op timing of ssdk_run_ops[_ctx]: when enabled, an event is recorded before every op (and after the last) on the
  * caller's stream.  After synchronising, ssdk_[ctx_]get_op_timings fills ms[i] / kernels[i] (kernel name, may be
