@@ -921,7 +921,12 @@ static int launch_gemm(const ConvParams& p, hipStream_t stream) {
     if (gz > 1) hipLaunchKernelGGL((conv_gemm_kernel<DT, WM, WN, FM_, FN_, true>), grid, dim3(kConvThreads), 0, stream, p); \
     else hipLaunchKernelGGL((conv_gemm_kernel<DT, WM, WN, FM_, FN_, false>), grid, dim3(kConvThreads), 0, stream, p);      \
   } while (0)
-  if (p.Cout > 64) SSDK_GEMM(2, 2, 4, 4, (p.Cout + 127) / 128);
+  // short K on a grid that gives 128-wide tiles one workgroup per CU at most (the 1x1 320 -> 256 layer of the first SSD
+  // extra: 10 k-steps, 256 tiles): 64-wide tiles = two workgroups per CU to overlap the per-k-step latency chain
+  static const int env_n64 = getenv("SSDK_GEMM_N64") ? atoi(getenv("SSDK_GEMM_N64")) : 1;
+  const bool n64 = env_n64 && gz == 1 && p.Cout > 64 && (p.Cout % 64) == 0 && p.KT <= 12 && (long)gm * ((p.Cout + 127) / 128) <= 256;
+  if (n64) SSDK_GEMM(4, 1, 2, 4, (p.Cout + 63) / 64);
+  else if (p.Cout > 64) SSDK_GEMM(2, 2, 4, 4, (p.Cout + 127) / 128);
   else if (p.Cout > 32) SSDK_GEMM(4, 1, 2, 4, (p.Cout + 63) / 64);
   else if (p.Cout > 16) SSDK_GEMM(4, 1, 2, 2, 1);
   else SSDK_GEMM(4, 1, 2, 1, 1);
