@@ -659,13 +659,18 @@ static int env_int(const char* name, int dflt) {
 // tiles, so the workgroups that carry the bulk of the bytes are balanced (a CU's share of the HBM stream is what
 // bounds the kernel), and the small levels are one small unit each.  `exact`: every level uses exactly `target`
 // tiles per unit (SSDK_TILES_PER_UNIT, tests).
-static void plan_units(DecodePlan* pl, int L, int B, int K, u32 vec, u32 tile, u32 target, bool exact) {
+// `cap`: the largest unit the scan kernel takes on its fast path (scan16_kernel buffers ~K * tiles / REG candidate keys per
+// unit: a longer unit overflows its key segments and re-runs on the exact stream).  The balanced split rounds the number of
+// units to the NEAREST, so without the cap a level of 1.4 x target tiles became ONE unit of 1.4 x target: found on the
+// BiFPN@896 heads, where one 92-tile unit (cap 81) per image took the fallback and tripled the kernel's time.
+static void plan_units(DecodePlan* pl, int L, int B, int K, u32 vec, u32 tile, u32 target, bool exact, u32 cap) {
   pl->tiles_per_unit = target;
   u32 base = 0;
   for (int l = 0; l < L; ++l) {
     const u32 tiles = (u32)(((unsigned long long)pl->n[l] + vec + tile - 1) / tile);
     u32 units = exact ? (tiles + target - 1) / target : (tiles + target / 2) / target;
     if (units < 1) units = 1;
+    if (!exact && (tiles + units - 1) / units > cap) units = (tiles + cap - 1) / cap;
     pl->tpu[l] = exact ? target : (tiles + units - 1) / units;
     pl->units[l] = (tiles + pl->tpu[l] - 1) / pl->tpu[l];
     pl->unit_base[l] = base;
@@ -725,7 +730,7 @@ int make_plan(const ssdk_level* lv, int L, int B, int dtype, int K, DecodePlan* 
   } else if (plan16 && tpu > 255) {
     tpu = 255;  // (a vector's number inside its unit is stored in 16 bits)
   }
-  plan_units(pl, L, B, K, vec, tile, (u32)tpu, forced);
+  plan_units(pl, L, B, K, vec, tile, (u32)tpu, forced, plan16 ? scan16_max_tiles_per_unit(K) : 4096u);
   if (ndet > 0 && env_int("SSDK_DECODE_FUSED", 1) != 0) pl->fused = tail_fits(K, L, ndet) != 0;
   return SSDK_OK;
 }

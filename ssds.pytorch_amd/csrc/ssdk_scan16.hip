@@ -453,6 +453,13 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
     if (ovf) sc->ovf = 1u;
   }
   __syncthreads();
+  if (wall && tid == 0 && sc->ovf) {  // (debug) what the overflowing unit looked like
+    p.stamps[24 + 2 * 3000] = ((unsigned long long)blockIdx.x << 32) | ((unsigned long long)cut16 << 16) | (unsigned long long)ntiles;
+    p.stamps[24 + 2 * 3000 + 1] = ((unsigned long long)sc->wcount[0] << 48) | ((unsigned long long)sc->wcount[1] << 32) |
+                                  ((unsigned long long)sc->wcount[2] << 16) | (unsigned long long)sc->wcount[3];
+    p.stamps[24 + 2 * 3001] = ((unsigned long long)S << 48) | ((unsigned long long)sstride << 32) | ((unsigned long long)eq << 16) | (unsigned long long)sc->above;
+    p.stamps[24 + 2 * 3001 + 1] = ((unsigned long long)sc->cb << 32) | (unsigned long long)(tie_rich ? 1u : 0u) | ((unsigned long long)thr16 << 8);
+  }
   if (stamp) p.stamps[2] = clock64();
 
   u32 cnt = 0;
@@ -534,7 +541,7 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
   }
   for (u32 i = cnt + tid; i < K; i += NT) out[i] = 0ull;
   if (tid == 0) *out_cnt = cnt;
-  if (wall) p.stamps[24 + 2 * blockIdx.x + 1] = wall_clock64();
+  if (wall) p.stamps[24 + 2 * blockIdx.x + 1] = (wall_clock64() & ~1ull) | (done ? 0ull : 1ull);  // bit 0: took the exact fallback
   if (stamp) {
     p.stamps[3] = clock64();
     p.stamps[4] = clock64();

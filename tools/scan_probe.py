@@ -14,21 +14,29 @@ import torch
 from ssds import _native as N
 from ssds.modeling.layers import box
 
-B, A, C = 64, 6, 80
-sizes = [32, 16, 8, 4, 2, 1]
-strides = [16, 32, 64, 128, 256, 512]
-anchors = OrderedDict((s, box.generate_anchors(s, [1, 2, 0.5], [2.0, 2.828])) for s in strides)
+# PROBE_SHAPE=bifpn896: config 5's heads (batch 16, 9 anchors, levels 112..7); PROBE_DTYPE=f16: fp16 heads
+DT = torch.float16 if os.environ.get("PROBE_DTYPE", "bf16") == "f16" else torch.bfloat16
+if os.environ.get("PROBE_SHAPE", "ssd512") == "bifpn896":
+    B, A, C = 16, 9, 80
+    sizes = [112, 56, 28, 14, 7]
+    strides = [8, 16, 32, 64, 128]
+    anchors = OrderedDict((s, box.generate_anchors(s, [1, 2, 0.5], [2.0, 2.52, 3.175])) for s in strides)
+else:
+    B, A, C = 64, 6, 80
+    sizes = [32, 16, 8, 4, 2, 1]
+    strides = [16, 32, 64, 128, 256, 512]
+    anchors = OrderedDict((s, box.generate_anchors(s, [1, 2, 0.5], [2.0, 2.828])) for s in strides)
 torch.manual_seed(0)
-loc = [torch.randn(B, A * 4, h, h, device="cuda").mul(0.1).to(torch.bfloat16) for h in sizes]
+loc = [torch.randn(B, A * 4, h, h, device="cuda").mul(0.1).to(DT) for h in sizes]
 nbytes = sum(B * A * C * h * h * 2 for h in sizes)
 
 
 ctx = N.Context(torch.device("cuda", 0))
-STAGE_BYTES = nbytes + sum(B * A * 4 * h * h * 2 for h in sizes) + B * (2 * 24 * 6 * 300 + 24 * 100)
+STAGE_BYTES = nbytes + sum(B * A * 4 * h * h * 2 for h in sizes) + B * (2 * 24 * len(sizes) * 300 + 24 * 100)
 
 
 def run(name, make, thr=0.01, reps=20):
-    conf = [make(B, A * C, h, h).to(torch.bfloat16) for h in sizes]
+    conf = [make(B, A * C, h, h).to(DT) for h in sizes]
     for _ in range(3):
         box.decode_nms(loc, conf, anchors, thr, 300, True, 0.6, 100, True, ctx=ctx)
     ctx.set_profiling(True)
@@ -63,10 +71,20 @@ def run(name, make, thr=0.01, reps=20):
                       "select %.1f = %.1f  fast=%d winners=%d" % (
                           e(0, 8), e(8, 9), e(9, 10), e(10, 1), e(1, 2), e(2, 11), e(11, 3), e(0, 4), sc[5] >> 32,
                           sc[5] & 0xffffffff))
-            W = 1024
+            W = 4096
             tl = ctx.tail_stamps(48 + 2 * W)[48:]
             se = [(tl[2 * i], tl[2 * i + 1]) for i in range(W) if tl[2 * i + 1]]
             if se:
+                slow = sorted(((tl[2 * i + 1] - tl[2 * i]) / 100.0, i, tl[2 * i + 1] & 1) for i in range(W) if tl[2 * i + 1])[-6:]
+                nfb = sum(1 for i in range(W) if tl[2 * i + 1] & 1)
+                extra += "\n      scan: %d workgroups took the exact fallback; slowest (us, block %% B = image, block // B = unit, fallback): %s" % (
+                    nfb, " ".join("(%.0f,%d,%d,%d)" % (d_, i % B, i // B, f) for d_, i, f in slow))
+                dbg = tl[2 * 3000:2 * 3000 + 4]
+                if dbg[0]:
+                    extra += ("\n      scan overflow debug: block %d cut16 0x%04x ntiles %d | wave key counts %d %d %d %d | S %d sstride %d eq %d above %d"
+                              " cb %d tie_rich %d thr16 0x%04x" % (dbg[0] >> 32, (dbg[0] >> 16) & 0xffff, dbg[0] & 0xffff, dbg[1] >> 48, (dbg[1] >> 32) & 0xffff,
+                                                                   (dbg[1] >> 16) & 0xffff, dbg[1] & 0xffff, dbg[2] >> 48, (dbg[2] >> 32) & 0xffff,
+                                                                   (dbg[2] >> 16) & 0xffff, dbg[2] & 0xffff, dbg[3] >> 32, dbg[3] & 1, (dbg[3] >> 8) & 0xffff))
                 t0 = min(a for a, _ in se)
                 st_ = sorted((a - t0) / 100.0 for a, _ in se)
                 en_ = sorted((b - t0) / 100.0 for _, b in se)
