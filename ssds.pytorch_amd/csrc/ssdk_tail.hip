@@ -223,9 +223,10 @@ __host__ __device__ inline size_t sel_lds_bytes(u32 K) {
   return sizeof(SelLds) + 2 * ((((size_t)K * 8) + 15) & ~(size_t)15);  // wkeys, bkeys
 }
 
-template <int DT>
-__global__ __launch_bounds__(kSelThreads) void levelsel_kernel(const SelParams p) {
-  constexpr int NT = kSelThreads;
+// NT: 256 threads, or 1024 where a level has many scan units (the 112x112 / 80x80 levels of the FPN / BiFPN heads: 55 / 28
+// units x K keys per image -- with 256 threads the two passes over the keys were 80 k of the workgroup's 94 k cycles)
+template <int DT, int NT>
+__global__ __launch_bounds__(NT) void levelsel_kernel(const SelParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   SelLds* S = reinterpret_cast<SelLds*>(smem);
   const u32 K = p.K;
@@ -822,9 +823,19 @@ int launch_levelsel(const ssdk_level* lv, int L, int B, int dtype, int K, int re
   p.stamps = stamps;
   lds_poison(stream);
   const dim3 grid((unsigned)L, (unsigned)B);
-  if (dtype == SSDK_F32) hipLaunchKernelGGL(levelsel_kernel<SSDK_F32>, grid, dim3(kSelThreads), sel_lds_bytes((u32)K), stream, p);
-  else if (dtype == SSDK_BF16) hipLaunchKernelGGL(levelsel_kernel<SSDK_BF16>, grid, dim3(kSelThreads), sel_lds_bytes((u32)K), stream, p);
-  else hipLaunchKernelGGL(levelsel_kernel<SSDK_F16>, grid, dim3(kSelThreads), sel_lds_bytes((u32)K), stream, p);
+  u32 most = 0;
+  for (int l = 0; l < L; ++l) most = units[l] > most ? units[l] : most;
+  static const int env_wide = getenv("SSDK_LEVELSEL_WIDE") ? atoi(getenv("SSDK_LEVELSEL_WIDE")) : 1;
+  const bool wide = env_wide && (size_t)most * (size_t)K > 4096;
+#define SSDK_SEL(DT)                                                                                                        \
+  do {                                                                                                                     \
+    if (wide) hipLaunchKernelGGL((levelsel_kernel<DT, 1024>), grid, dim3(1024), sel_lds_bytes((u32)K), stream, p);         \
+    else hipLaunchKernelGGL((levelsel_kernel<DT, kSelThreads>), grid, dim3(kSelThreads), sel_lds_bytes((u32)K), stream, p); \
+  } while (0)
+  if (dtype == SSDK_F32) SSDK_SEL(SSDK_F32);
+  else if (dtype == SSDK_BF16) SSDK_SEL(SSDK_BF16);
+  else SSDK_SEL(SSDK_F16);
+#undef SSDK_SEL
   return check_launch("levelsel_kernel");
 }
 

@@ -21,6 +21,11 @@ if os.environ.get("PROBE_SHAPE", "ssd512") == "bifpn896":
     sizes = [112, 56, 28, 14, 7]
     strides = [8, 16, 32, 64, 128]
     anchors = OrderedDict((s, box.generate_anchors(s, [1, 2, 0.5], [2.0, 2.52, 3.175])) for s in strides)
+elif os.environ.get("PROBE_SHAPE") == "fpn640":
+    B, A, C = 32, 9, 80
+    sizes = [80, 40, 20, 10, 5]
+    strides = [8, 16, 32, 64, 128]
+    anchors = OrderedDict((s, box.generate_anchors(s, [1, 2, 0.5], [2.0, 2.52, 3.175])) for s in strides)
 else:
     B, A, C = 64, 6, 80
     sizes = [32, 16, 8, 4, 2, 1]
