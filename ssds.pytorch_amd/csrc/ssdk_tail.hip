@@ -826,7 +826,7 @@ int launch_levelsel(const ssdk_level* lv, int L, int B, int dtype, int K, int re
   u32 most = 0;
   for (int l = 0; l < L; ++l) most = units[l] > most ? units[l] : most;
   static const int env_wide = getenv("SSDK_LEVELSEL_WIDE") ? atoi(getenv("SSDK_LEVELSEL_WIDE")) : 1;
-  const bool wide = env_wide && (size_t)most * (size_t)K > 4096;
+  const bool wide = env_wide == 2 || (env_wide && (size_t)most * (size_t)K > 4096);  // (2: always -- A/B switch)
 #define SSDK_SEL(DT)                                                                                                        \
   do {                                                                                                                     \
     if (wide) hipLaunchKernelGGL((levelsel_kernel<DT, 1024>), grid, dim3(1024), sel_lds_bytes((u32)K), stream, p);         \
