@@ -894,7 +894,11 @@ static bool use_gemm256(const ConvParams& p) {
   if (!env || p.ksplits > 1 || (p.Cin % 8)) return false;
   const long tiles = (long)((p.M + G2_BM - 1) / G2_BM) * ((p.Cout + G2_BN - 1) / G2_BN);
   if (env == 2) return true;
-  return p.Cout >= 192 && tiles >= 128;
+  // ... and a k-loop long enough to fill its two 64 KiB stages: measured per layer on FPN-ResNet50@640 (batch 32) against
+  // conv_gemm_kernel, 1x1 layers: 64 -> 256 @160x160 355 vs 262 us, 128 -> 512 @80x80 224 vs 173, 256 -> 1024 @40x40 131 vs
+  // 100, 512 -> 256 @80x80 148 vs 136, 512 -> 2048 @20x20 79 vs 77, but 1024 -> 256 @40x40 53 vs 68: with K < 1024 the
+  // 256 x 256 tile is one or two loads, one burst of MFMAs and a 128 KiB store, one workgroup per CU, nothing overlapping
+  return p.Cout >= 192 && tiles >= 128 && p.KT >= 32;
 }
 
 template <int DT>

@@ -120,9 +120,10 @@ LARGE = [
     (256, 512, 3, 2, 16, 16, 64, "relu", SMALLMAP),   # first SSD extra: stride 2 from a 16x16 onto an 8x8 map (skewed input rows)
     (128, 256, 3, 2, 8, 8, 33, "relu6", SMALLMAP),    # stride 2 onto 4x4: four images per workgroup, a ragged last group
     (128, 100, 3, 2, 4, 4, 70, "silu", SMALLMAP),     # stride 2 onto 2x2, a partial channel range
-    (64, 256, 1, 1, 64, 64, 8, "relu", G256),      # wide 1x1
-    (96, 320, 3, 2, 64, 64, 32, "relu6", G256),    # 3x3 stride 2, partial 64-channel slab
-    (72, 200, 1, 1, 90, 50, 8, "silu", G256),      # ragged everything
+    (1024, 256, 1, 1, 40, 40, 24, "relu", G256),   # wide 1x1 with a long K (the flat-K 256 x 256 kernel takes K >= 1024 only)
+    (128, 320, 3, 2, 64, 64, 32, "relu6", G256),   # 3x3 stride 2
+    (1064, 200, 1, 1, 45, 50, 16, "silu", G256),   # ragged everything
+    (64, 256, 1, 1, 64, 64, 8, "relu", "conv_gemm_kernel"),  # wide 1x1, short K: the 128-row kernel (several workgroups per CU)
 ]
 
 
