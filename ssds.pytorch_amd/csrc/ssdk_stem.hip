@@ -66,14 +66,28 @@ __global__ __launch_bounds__(256) void stem7_kernel(const StemParams p) {
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
     const u16* img = p.x + (size_t)n * 3 * p.H * p.W;
     __syncthreads();  // the previous tile's fragment reads are done
-    for (u32 i = tid; i < (u32)(ST_PR * (ST_PC - 1) * 3); i += 256) {  // (channel, row, column): columns fastest
-      const u32 c = i % (u32)(ST_PC - 1);
-      const u32 r2 = i / (u32)(ST_PC - 1);
-      const u32 r = r2 % (u32)ST_PR, ch = r2 / (u32)ST_PR;
-      const int iy = iy0 + (int)r, ix = ix0 + (int)c;
-      u16 v = 0;
-      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = img[((size_t)iy * p.W + ix) * pstride + ch * cstride];
-      patch[(r * ST_PC + c) * 4 + ch] = v;
+    {  // (channel, row, column): columns fastest.  All of a thread's loads are issued before the first LDS store: as a plain
+       // loop (one 2-byte load, one store per iteration) every iteration waited a full memory round trip -- ten per tile
+      constexpr u32 NEL = (u32)(ST_PR * (ST_PC - 1) * 3), NPT = (NEL + 255u) / 256u;
+      u16 v[NPT];
+#pragma unroll
+      for (u32 k = 0; k < NPT; ++k) {
+        const u32 i = tid + k * 256u;
+        const u32 c = i % (u32)(ST_PC - 1);
+        const u32 r2 = i / (u32)(ST_PC - 1);
+        const u32 r = r2 % (u32)ST_PR, ch = r2 / (u32)ST_PR;
+        const int iy = iy0 + (int)r, ix = ix0 + (int)c;
+        v[k] = 0;
+        if (i < NEL && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v[k] = img[((size_t)iy * p.W + ix) * pstride + ch * cstride];
+      }
+#pragma unroll
+      for (u32 k = 0; k < NPT; ++k) {
+        const u32 i = tid + k * 256u;
+        const u32 c = i % (u32)(ST_PC - 1);
+        const u32 r2 = i / (u32)(ST_PC - 1);
+        const u32 r = r2 % (u32)ST_PR, ch = r2 / (u32)ST_PR;
+        if (i < NEL) patch[(r * ST_PC + c) * 4 + ch] = v[k];
+      }
     }
     __syncthreads();
 #pragma unroll

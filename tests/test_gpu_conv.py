@@ -262,7 +262,7 @@ def test_halo_kernel_residual_and_split_heads():
 
 @pytest.mark.parametrize("cin,cout,k,h,w,n,kernel", [
     (64, 256, 1, 16, 20, 2, "conv_gemm_kernel"),       # FPN lateral + top-down add, tiled kernel
-    (128, 256, 1, 64, 64, 16, G256),                   # same on the 256x256 kernel
+    (1024, 256, 1, 64, 64, 16, G256),                  # same on the 256x256 kernel (K >= 1024)
     (64, 64, 1, 2, 2, 8, "conv_wave_kernel"),          # same on the wave kernel
 ])
 def test_conv_half_resolution_residual(cin, cout, k, h, w, n, kernel):
@@ -288,7 +288,7 @@ def test_conv_half_resolution_residual(cin, cout, k, h, w, n, kernel):
 @pytest.mark.parametrize("cin,cout,k,h,w,n,act,kernel", [
     (64, 64, 3, 14, 14, 2, "relu", "conv_gemm_kernel"),
     (128, 256, 3, 16, 16, 48, "relu", HALO),
-    (256, 512, 1, 64, 32, 16, "relu", G256),
+    (1024, 512, 1, 64, 32, 16, "relu", G256),
     (64, 64, 3, 2, 2, 8, "relu6", "conv_wave_kernel"),
 ])
 def test_conv_activation_after_residual(cin, cout, k, h, w, n, act, kernel):
