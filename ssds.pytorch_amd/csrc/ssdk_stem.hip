@@ -57,39 +57,51 @@ __global__ __launch_bounds__(256) void stem7_kernel(const StemParams p) {
   const size_t cstride = p.in_layout == LAYOUT_NCHW ? (size_t)p.H * p.W : 1;
   const size_t pstride = p.in_layout == LAYOUT_NCHW ? 1 : 3;
 
-  for (u32 t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+  // The image patch of the NEXT tile is requested (into registers) before the current tile is computed: with ~200 VGPRs
+  // only two workgroups share a CU, too few to hide a tile's staging round trip (372 us for the 640x640 stem at batch 32 when
+  // every tile waited for its own loads).
+  constexpr u32 NEL = (u32)(ST_PR * (ST_PC - 1) * 3), NPT = (NEL + 255u) / 256u;
+  u16 pv[NPT];
+  auto tile_origin = [&](u32 t, u32* n_, int* oy0_, int* ox0_) {
     const u32 tx = t % (u32)p.tiles_x;
-    u32 q = t / (u32)p.tiles_x;
-    const u32 ty = q % (u32)p.tiles_y;
-    const u32 n = q / (u32)p.tiles_y;
-    const int oy0 = (int)ty * ST_TH, ox0 = (int)tx * ST_TW;
+    const u32 q = t / (u32)p.tiles_x;
+    *n_ = q / (u32)p.tiles_y;
+    *oy0_ = (int)(q % (u32)p.tiles_y) * ST_TH;
+    *ox0_ = (int)tx * ST_TW;
+  };
+  auto fetch = [&](u32 t) {  // (channel, row, column): columns fastest; all of a thread's loads issued together
+    u32 n;
+    int oy0, ox0;
+    tile_origin(t < p.ntiles ? t : p.ntiles - 1u, &n, &oy0, &ox0);  // (past the end: a harmless re-read)
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
     const u16* img = p.x + (size_t)n * 3 * p.H * p.W;
+#pragma unroll
+    for (u32 k = 0; k < NPT; ++k) {
+      const u32 i = tid + k * 256u;
+      const u32 c = i % (u32)(ST_PC - 1);
+      const u32 r2 = i / (u32)(ST_PC - 1);
+      const u32 r = r2 % (u32)ST_PR, ch = r2 / (u32)ST_PR;
+      const int iy = iy0 + (int)r, ix = ix0 + (int)c;
+      pv[k] = 0;
+      if (i < NEL && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) pv[k] = img[((size_t)iy * p.W + ix) * pstride + ch * cstride];
+    }
+  };
+  if (blockIdx.x < p.ntiles) fetch(blockIdx.x);
+  for (u32 t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+    u32 n;
+    int oy0, ox0;
+    tile_origin(t, &n, &oy0, &ox0);
     __syncthreads();  // the previous tile's fragment reads are done
-    {  // (channel, row, column): columns fastest.  All of a thread's loads are issued before the first LDS store: as a plain
-       // loop (one 2-byte load, one store per iteration) every iteration waited a full memory round trip -- ten per tile
-      constexpr u32 NEL = (u32)(ST_PR * (ST_PC - 1) * 3), NPT = (NEL + 255u) / 256u;
-      u16 v[NPT];
 #pragma unroll
-      for (u32 k = 0; k < NPT; ++k) {
-        const u32 i = tid + k * 256u;
-        const u32 c = i % (u32)(ST_PC - 1);
-        const u32 r2 = i / (u32)(ST_PC - 1);
-        const u32 r = r2 % (u32)ST_PR, ch = r2 / (u32)ST_PR;
-        const int iy = iy0 + (int)r, ix = ix0 + (int)c;
-        v[k] = 0;
-        if (i < NEL && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v[k] = img[((size_t)iy * p.W + ix) * pstride + ch * cstride];
-      }
-#pragma unroll
-      for (u32 k = 0; k < NPT; ++k) {
-        const u32 i = tid + k * 256u;
-        const u32 c = i % (u32)(ST_PC - 1);
-        const u32 r2 = i / (u32)(ST_PC - 1);
-        const u32 r = r2 % (u32)ST_PR, ch = r2 / (u32)ST_PR;
-        if (i < NEL) patch[(r * ST_PC + c) * 4 + ch] = v[k];
-      }
+    for (u32 k = 0; k < NPT; ++k) {
+      const u32 i = tid + k * 256u;
+      const u32 c = i % (u32)(ST_PC - 1);
+      const u32 r2 = i / (u32)(ST_PC - 1);
+      const u32 r = r2 % (u32)ST_PR, ch = r2 / (u32)ST_PR;
+      if (i < NEL) patch[(r * ST_PC + c) * 4 + ch] = pv[k];
     }
     __syncthreads();
+    fetch(t + gridDim.x);  // in flight under this tile's MFMAs and stores
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       const int f = (int)wave * 2 + mi;  // output row of the tile = m-fragment
