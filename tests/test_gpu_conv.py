@@ -344,10 +344,13 @@ def test_resnet_stem_and_maxpool(layout, h, w, dtype_name):
     assert torch.equal(pooled.float().cpu(), F.max_pool2d(y.float().cpu(), 3, 2, 1)), "maxpool must be exact"
 
 
-@pytest.mark.parametrize("c,stride,h,w,n", [(64, 1, 20, 24, 2), (128, 2, 33, 31, 3), (288, 1, 7, 9, 2), (672, 2, 14, 14, 1)])
+@pytest.mark.parametrize("c,stride,h,w,n", [(64, 1, 20, 24, 2), (128, 2, 33, 31, 3), (288, 1, 7, 9, 2), (672, 2, 14, 14, 1),
+                                            (288, 1, 56, 56, 2), (208, 2, 40, 24, 3)])
 @pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
 def test_grouped_conv_16_per_group(c, stride, h, w, n, dtype_name):
-    """RegNetX bottleneck conv: 3x3, groups = C/16 (+ BN + ReLU) vs torch fp32."""
+    """RegNetX bottleneck conv: 3x3, groups = C/16 (+ BN + ReLU) vs torch fp32; stride 1 and 2, ragged maps, channel counts
+    that leave a partial block of groups (288 = 18 groups, 208 = 13).  Output maps at least 8 pixels wide run from an LDS halo
+    tile (gconv3x3_g16_tile_kernel), narrower ones straight from L2 (gconv3x3_g16_kernel)."""
     import torch
     import torch.nn as nn
     from ssds import _native as N
@@ -368,7 +371,8 @@ def test_grouped_conv_16_per_group(c, stride, h, w, n, dtype_name):
     pack = FC.ConvPack(conv, bn, "relu", dtype)
     assert pack.kind == "g16"
     y = FC.conv_native(x.cuda(), pack)
-    assert N.last_kernel() == "gconv3x3_g16_kernel"
+    wo = (w + 2 - 3) // stride + 1
+    assert N.last_kernel() == ("gconv3x3_g16_tile_kernel" if wo >= 8 else "gconv3x3_g16_kernel"), N.last_kernel()
     _check(y, want, dtype, "grouped conv")
 
 
