@@ -133,8 +133,8 @@ __device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx,
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
       const int iy = oy * S - 1 + (t + TAP0) / 3, ix = ox * S - 1 + (t + TAP0) % 3;
-      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      rowoff[m][t] = (u32)((ok ? g * PL + iy * p.W + ix + (S == 2 ? iy >> 1 : 0) : ZROW) * RS) + fg * 16u;
+      const bool ok = g < G && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;  // (g >= G: a pixel slot past the
+      rowoff[m][t] = (u32)((ok ? g * PL + iy * p.W + ix + (S == 2 ? iy >> 1 : 0) : ZROW) * RS) + fg * 16u;  // workgroup's images: 64 % P != 0)
     }
   }
   __syncthreads();
@@ -183,7 +183,7 @@ __device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx,
 #pragma unroll
       for (int m = 0; m < MFR; ++m) {
         const int px = m * 16 + (int)fr, b = img0 + px / P, q = px % P;
-        if (b >= p.N) continue;
+        if (px / P >= G || b >= p.N) continue;
         float v = acc[a][m][r] * sc + bi;
         if (as.mode) {
           const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * v));
@@ -237,7 +237,7 @@ static bool smallmap_group_member(const ConvParams& p) {
   static const int env = getenv("SSDK_CONV_SMALLMAP") ? atoi(getenv("SSDK_CONV_SMALLMAP")) : 1;
   static const int env_pk = getenv("SSDK_WFRAG") ? atoi(getenv("SSDK_WFRAG")) : 1;
   const int P = p.Ho * p.Wo;
-  if (!env || !env_pk || !p.w_frag || p.k != 3 || p.stride != 1 || p.pad != 1 || p.H != p.Ho || p.W != p.Wo || P > 64 || (64 % P) ||
+  if (!env || !env_pk || !p.w_frag || p.k != 3 || p.stride != 1 || p.pad != 1 || p.H != p.Ho || p.W != p.Wo || P > 64 ||
       (p.Cin != 128 && p.Cin != 256 && p.Cin != 512) || p.in_layout != LAYOUT_NHWC || p.res || p.post != SSDK_ACT_NONE || p.Cout < 16)
     return false;
   const int nfr64 = (p.Cout + 63) / 64;
@@ -282,7 +282,7 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   static const int env = getenv("SSDK_CONV_SMALLMAP") ? atoi(getenv("SSDK_CONV_SMALLMAP")) : 1;
   static const int env_maxp = getenv("SSDK_CONV_SMALLMAP_MAXP") ? atoi(getenv("SSDK_CONV_SMALLMAP_MAXP")) : 64;
   const int P = p.Ho * p.Wo;
-  if (!env || p.k != 3 || p.pad != 1 || P > env_maxp || P > 64 || (64 % P) || (p.Cin != 128 && p.Cin != 256 && p.Cin != 512) ||
+  if (!env || p.k != 3 || p.pad != 1 || P > env_maxp || P > 64 || (p.Cin != 128 && p.Cin != 256 && p.Cin != 512) ||
       p.in_layout != LAYOUT_NHWC || p.res || p.post != SSDK_ACT_NONE || p.Cout < 16)
     return 1;
   static const int env_pk = getenv("SSDK_WFRAG") ? atoi(getenv("SSDK_WFRAG")) : 1;

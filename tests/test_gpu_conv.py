@@ -110,6 +110,9 @@ LARGE = [
     (256, 504, 3, 1, 2, 2, 35, "relu", SMALLMAP),  # SSD head L4: sixteen maps per workgroup
     (128, 504, 3, 1, 1, 1, 64, "silu", SMALLMAP),  # SSD head L5: 1x1 maps, only the centre tap sees data
     (256, 40, 3, 1, 2, 4, 9, "relu6", SMALLMAP),   # 2x4 map, a single partial channel range
+    (256, 256, 3, 1, 5, 5, 32, "relu", SMALLMAP),  # FPN tower on the 5x5 level: 25 pixels do not divide 64 (two maps + 14 idle slots)
+    (256, 720, 3, 1, 7, 7, 16, "sigmoid", SMALLMAP),  # BiFPN head on the 7x7 level: one map per workgroup
+    (128, 504, 3, 1, 3, 5, 9, "none", SMALLMAP),   # 15 pixels: four maps per workgroup, a ragged last group
     # conv3x3_short_kernel: (kernel of the NHWC call, kernel of the NCHW call) -- NHWC takes none / relu / relu6, NCHW none / sigmoid / silu
     (96, 504, 3, 1, 32, 32, 64, "sigmoid", (HALO, SHORT)), # SSD head L0 at bench size: a 128-pixel patch x 4 channel tiles per workgroup
     (128, 256, 3, 1, 40, 40, 20, "relu", (SHORT, HALO)),   # ragged patches (40 = 2.5 x 16), two channel tiles
