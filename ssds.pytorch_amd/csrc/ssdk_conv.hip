@@ -41,7 +41,9 @@ __device__ __forceinline__ u32 swz(u32 row, u32 chunk) {
 constexpr int kConvThreads = 256;
 constexpr int BM = 128, BK = 32;
 
-template <int DT, int WAVES_M, int WAVES_N, int FM, int FN, bool SPLITK = false>
+// RES: an instance of its own for layers with a residual (NHWC, Cout % 8 == 0): the store loop requests the residual vectors
+// four at a time.  (As part of the one kernel the extra registers cost every layer a wave per SIMD: measured, reverted.)
+template <int DT, int WAVES_M, int WAVES_N, int FM, int FN, bool SPLITK = false, bool RES = false>
 __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParams p) {
   constexpr int BN = WAVES_N * FN * 16;
   static_assert(WAVES_M * FM * 16 == BM, "tile");
@@ -259,7 +261,39 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
   }
   __syncthreads();
 
-  if (!nchw) {
+  if (!nchw && RES) {
+    // ResNet / RegNet bottleneck tails: every chunk is whole (Cout % 8 == 0, checked by the host).  In the generic loop below
+    // each of a thread's eight iterations waits for its own residual load: here four are in flight at a time.
+    constexpr int CH = BN / 8, IT = (BM * CH + kConvThreads - 1) / kConvThreads, RB = 4;
+#pragma unroll
+    for (int b0 = 0; b0 < IT; b0 += RB) {
+      u32x4 rr[RB];
+#pragma unroll
+      for (int k = 0; k < RB; ++k) {
+        const u32 q = tid + (u32)(b0 + k) * kConvThreads, row = q / CH, cc = q % CH;
+        const u32 m = m0 + row, n = n0 + cc * 8;
+        rr[k] = u32x4{0u, 0u, 0u, 0u};
+        if (b0 + k < IT && q < (u32)(BM * CH) && m < (u32)p.M && n < (u32)p.Cout)
+          rr[k] = *reinterpret_cast<const u32x4*>((const u16*)p.res + res_pixel_offset(p, m) + n);
+      }
+#pragma unroll
+      for (int k = 0; k < RB; ++k) {
+        const u32 q = tid + (u32)(b0 + k) * kConvThreads, row = q / CH, cc = q % CH;
+        const u32 m = m0 + row, n = n0 + cc * 8;
+        if (b0 + k < IT && q < (u32)(BM * CH) && m < (u32)p.M && n < (u32)p.Cout) {
+          u32x4 v = *reinterpret_cast<const u32x4*>(&sC[row * LDC_M + cc * 8]);
+          const u32x4 r4 = rr[k];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float lo = post_act(bits16_to_f32<DT>(v[e] & 0xffffu) + bits16_to_f32<DT>(r4[e] & 0xffffu), post);
+            const float hi = post_act(bits16_to_f32<DT>(v[e] >> 16) + bits16_to_f32<DT>(r4[e] >> 16), post);
+            v[e] = pack2_16<DT>(lo, hi);
+          }
+          *reinterpret_cast<u32x4*>((u16*)p.y + (size_t)m * p.Cout + n) = v;
+        }
+      }
+    }
+  } else if (!nchw) {
     constexpr int CH = BN / 8;  // 16-byte chunks per tile row
     for (u32 q = tid; q < (u32)(BM * CH); q += kConvThreads) {
       const u32 row = q / CH, cc = q % CH;
@@ -945,10 +979,13 @@ static int launch_gemm(const ConvParams& p, hipStream_t stream) {
   if (use_gemm256(p)) return launch_gemm256<DT>(p, stream);
   const unsigned gm = (unsigned)((p.M + BM - 1) / BM);
   const unsigned gz = (unsigned)p.ksplits;
+  static const int env_resv = getenv("SSDK_GEMM_RESV") ? atoi(getenv("SSDK_GEMM_RESV")) : 1;
+  const bool resv = env_resv && p.res != nullptr && p.out_layout == LAYOUT_NHWC && (p.Cout & 7) == 0 && p.Cout > 32;
 #define SSDK_GEMM(WM, WN, FM_, FN_, GY)                                                                          \
   do {                                                                                                          \
     dim3 grid(gm, (unsigned)(GY), gz);                                                                          \
     if (gz > 1) hipLaunchKernelGGL((conv_gemm_kernel<DT, WM, WN, FM_, FN_, true>), grid, dim3(kConvThreads), 0, stream, p); \
+    else if (resv) hipLaunchKernelGGL((conv_gemm_kernel<DT, WM, WN, FM_, FN_, false, true>), grid, dim3(kConvThreads), 0, stream, p); \
     else hipLaunchKernelGGL((conv_gemm_kernel<DT, WM, WN, FM_, FN_, false>), grid, dim3(kConvThreads), 0, stream, p);      \
   } while (0)
   // short K on a grid that gives 128-wide tiles one workgroup per CU at most (the 1x1 320 -> 256 layer of the first SSD
