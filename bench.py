@@ -164,6 +164,100 @@ def reference_cpu_record():
     return out
 
 
+def forward_check(args, cfg, x, xs, S, tdt, dev, timed_kernels, seed=4242):
+    """The part of `verified` that checks the NETWORK kernels (rank 0, N = 1, after the timed region).  The timed model
+    carries the reference's init, on which no forward comparison discriminates (see the caller); so the same architecture
+    is built again with seeded O(1) weights (conv ~ N(0, 1.5 / fan_in), BatchNorm weight ~ U(0.5, 1.5), biases ~ N(0, 0.1),
+    class-head bias -4) and BatchNorm statistics calibrated on two random batches, and run
+      * on the device through the recorded plan at the TIMED batch shape (the planner picks kernels by shape, so these are
+        the timed run's kernels: the per-op kernel names must be identical),
+      * in fp32 on the CPU on the S sampled images (the reference),
+      * by PyTorch-ROCm / MIOpen in the model dtype on those images (the noise floor of 16-bit execution of a deep untrained
+        network: 0.02 ... 0.6 rms depending on the level).
+    Bar per head tensor, no absolute term above the signal: rms(plan - fp32) / rms(fp32) <= 2 x the same ratio of the
+    PyTorch-ROCm execution + 0.02; class heads are compared as logits (a sigmoid output near 0.01 hides its logit)."""
+    import torch
+    import torch.nn as nn
+
+    from ssds.core import config
+    from ssds.modeling import model_builder
+
+    torch.manual_seed(seed)
+    cal = model_builder.create_model(cfg.MODEL)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in cal.modules():
+            if isinstance(m, nn.Conv2d):
+                fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (1.5 / fan_in) ** 0.5)
+                if m.bias is not None:
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_mean.zero_()
+                m.running_var.fill_(1.0)
+                m.momentum = None  # cumulative average over the calibration batches
+            else:
+                for name, prm in m.named_parameters(recurse=False):
+                    if prm.dim() == 2:  # BiFPN fusion weights (bifpn.py:35-38): some negative, cut by the relu
+                        prm.copy_(torch.rand(prm.shape, generator=g) * 1.2 - 0.2)
+        finals = list(cal.conf) if isinstance(cal.conf, nn.ModuleList) else [list(cal.conf.children())[-1]]
+        for m in finals:  # an untrained-looking score distribution: logits ~ N(-4, ~1)
+            m.weight.mul_(0.6)
+            m.bias.copy_(m.bias * 3 - 4.0)
+        H, W = cfg.MODEL.IMAGE_SIZE
+        cal.train()
+        for _ in range(2):
+            cal(torch.rand((2, 3, H, W), generator=g))
+        cal.eval()
+        state = {k: v.clone() for k, v in cal.state_dict().items()}
+        cl, cc = cal(xs)  # fp32 CPU reference on the sampled images
+        dmodel = cal.to(dev, tdt)
+        if args.channels_last:
+            dmodel = dmodel.to(memory_format=torch.channels_last)
+        gl, gc = dmodel(x)  # the timed batch shape -> the timed kernels
+        plan = dmodel._plan(x) if hasattr(dmodel, "_plan") else None
+        if plan is None or isinstance(plan, str):
+            plans = [q for q in getattr(dmodel, "_neck_plans", {}).values() if not isinstance(q, str)]
+            plan = plans[0] if plans else None
+        kernels = None
+        if plan is not None:
+            plan.ctx.set_op_profiling(True)
+            dmodel(x)
+            torch.cuda.synchronize(dev)
+            kernels = [k for k, _ in plan.ctx.op_timings()]
+            plan.ctx.set_op_profiling(False)
+        os.environ["SSDK_FUSED_CONV"] = "0"  # PyTorch-ROCm / MIOpen executing the same module in the same dtype: the floor
+        try:
+            tl, tc = dmodel(x[:S])
+        finally:
+            del os.environ["SSDK_FUSED_CONV"]
+        torch.cuda.synchronize(dev)
+    del state
+
+    def logit(p):
+        p = p.float().clamp(1e-7, 1.0 - 1e-7)
+        return torch.log(p) - torch.log1p(-p)
+
+    def rel(a, ref):
+        return float((a - ref).pow(2).mean().sqrt()) / max(float(ref.pow(2).mean().sqrt()), 1e-30)
+
+    rows, worst = [], 0.0
+    for tag, gs, ts, cs, f in (("loc", gl, tl, cl, lambda t: t.float()), ("conf(logit)", gc, tc, cc, logit)):
+        for i, (gt, tt, ct) in enumerate(zip(gs, ts, cs)):
+            ref = f(ct)
+            r_plan, r_floor = rel(f(gt[:S].cpu()), ref), rel(f(tt.cpu()), ref)
+            bar = 2.0 * r_floor + 0.02
+            worst = max(worst, r_plan / bar)
+            rows.append({"tensor": "%s%d" % (tag, i), "ref_rms": float("%.3g" % float(ref.pow(2).mean().sqrt())),
+                         "plan": float("%.3g" % r_plan), "pytorch_rocm": float("%.3g" % r_floor), "bar": float("%.3g" % bar)})
+    same = (kernels == timed_kernels) if (kernels is not None and timed_kernels is not None) else None
+    return {"weights": "seeded O(1) weights + calibrated BatchNorm statistics, same architecture and batch shape as the timed run",
+            "images": S, "relative_rms_error": rows, "worst_ratio_to_bar": float("%.3g" % worst),
+            "same_kernels_as_timed": same, "ok": bool(worst <= 1.0 and same is not False)}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -319,6 +413,7 @@ def main():
 
     # ---- per-layer table (separate, untimed pass: one hipEvent per op of the recorded plan) ------------------
     layers, heads, body = None, None, None
+    timed_kernels = None  # kernel name per op of the timed plan (forward_check compares its own plan's with these)
     if (plan is None or isinstance(plan, str)) and plans:
         plan = plans[0]  # FPN / BiFPN: the recorded plan of backbone + neck + shared towers (NeckPlanMixin)
     if plan is not None and not isinstance(plan, str):
@@ -332,6 +427,7 @@ def main():
                 acc = [a + b[1] for a, b in zip(acc, t)] if acc else [b[1] for b in t]
         plan.ctx.set_op_profiling(False)
         names = [k for k, _ in t]
+        timed_kernels = list(names)
         layers = []
         for row, kern, ms5 in zip(plan.layer_table(), names, acc):
             ms = ms5 / 5.0
@@ -507,28 +603,32 @@ def main():
         if not oracle_ok:
             print("oracle check failed: sample rows equal the timed batch's %s, per-level decode vs oracle %s, oracle NMS on "
                   "the device's per-level output %s" % (same_rows, mid_ok, nms_ok), file=sys.stderr)
-        # loc deltas are compared per level as rms(gpu - cpu) against rms(cpu) with an absolute floor of 1e-3 (a delta of
-        # 1e-3 moves a box edge by 1e-3 anchor sizes): with the reference's untrained init the activations behind the
-        # first level decay below the fp16 range of the fused blocks' internal tensors (exact zeros against ~1e-9 on the
-        # CPU), which is no error
-        rel, ok_l = [], []
-        for gl, rl in zip(g_loc, cl):
-            err, ref = float((gl - rl).pow(2).mean().sqrt()), float(rl.pow(2).mean().sqrt())
-            rel.append(float("%.3g" % (err / max(ref, 1e-30))))
-            ok_l.append(err <= 0.35 * ref + 1e-3)
-        cos = ["%.1e" % float(rl.pow(2).mean().sqrt()) for rl in cl]  # rms of the CPU reference per level, for the record
-        conf_err = max(float((gc - rc).abs().max()) for gc, rc in zip(g_conf, cc))
-        heads_ok = bool(all(ok_l) and conf_err <= 2e-2)
+        # The reference-initialised network of the timed run cannot check the forward pass: its activations decay level by
+        # level (box heads of ~1e-9 behind the first level, every class output = sigmoid(bias)), so any comparison on it
+        # either has an absolute floor above the signal or compares rounding noise.  Reported for the record only:
+        ref_init = {"loc_rms_per_level": ["%.1e" % float(rl.pow(2).mean().sqrt()) for rl in cl],
+                    "loc_relative_rms_error": [float("%.3g" % (float((gl - rl).pow(2).mean().sqrt()) / max(float(rl.pow(2).mean().sqrt()), 1e-30)))
+                                               for gl, rl in zip(g_loc, cl)],
+                    "max_abs_conf_error": float("%.3g" % max(float((gc - rc).abs().max()) for gc, rc in zip(g_conf, cc))),
+                    "part_of_verified": False}
+        # The forward check that CAN fail (forward_check below): the same architecture with seeded O(1) weights and calibrated
+        # BatchNorm statistics, the SAME batch shape (hence the same kernels: asserted by name), purely relative bars.
+        fwd = forward_check(args, cfg2, x, xs, S, tdt, dev, timed_kernels)
+        heads_ok = bool(fwd["ok"])
         result["verified"] = bool(verified and oracle_ok and heads_ok)
+        result["forward_check"] = fwd
+        result["forward_check"]["reference_init_heads_vs_fp32_cpu"] = ref_init
         result["config"]["verification"] += (
             "; numpy oracle on the GPU's own head outputs of %d images: per-level decode (classes bit-exact, boxes 1e-3, "
-            "scores 1e-4), oracle NMS on the device's per-level output = the timed detections bit for bit: %s; GPU heads "
-            "vs the fp32 CPU forward of the same module on "
-            "those images: loc rms per level %s, relative rms error %s (bar: 0.35 rms + 1e-3), max |conf error| %.2e: %s"
-            % (S, oracle_ok, cos, rel, conf_err, heads_ok))
+            "scores 1e-4), oracle NMS on the device's per-level output = the timed detections bit for bit: %s; forward pass: "
+            "the same architecture with seeded, BatchNorm-calibrated weights at the timed batch shape (same kernels: %s) against "
+            "its fp32 CPU forward on those images, relative rms error per head tensor <= 2 x the error of PyTorch-ROCm "
+            "executing the module in %s + 0.02, no absolute floor (worst ratio to that bar %.2f): %s"
+            % (S, oracle_ok, fwd["same_kernels_as_timed"], args.dtype, fwd["worst_ratio_to_bar"], heads_ok))
         if not (oracle_ok and heads_ok):
             print(json.dumps(result["config"]), file=sys.stderr)
-            raise SystemExit("bench.py: the timed outputs disagree with the oracle / the fp32 CPU forward -- no number reported")
+            print(json.dumps(fwd), file=sys.stderr)
+            raise SystemExit("bench.py: the timed outputs disagree with the oracle / the forward check failed -- no number reported")
         result["cpu_baseline"] = {
             "value": round(S / cpu_s, 3),
             "unit": "images/sec",

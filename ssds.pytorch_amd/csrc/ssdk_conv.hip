@@ -1416,6 +1416,33 @@ static bool group_member_params(const ssdk_conv_desc* d, ConvParams* p) {
   return true;
 }
 
+// Byte ranges of a group member: input [x, +N*H*W*Cin), outputs y (split channels, or all) and y2 (the rest).
+struct GroupRange {
+  uintptr_t lo, hi;
+  bool overlaps(const GroupRange& o) const { return lo < o.hi && o.lo < hi; }
+};
+static inline GroupRange group_range(const void* ptr, size_t bytes) {
+  return GroupRange{(uintptr_t)ptr, (uintptr_t)ptr + (ptr ? bytes : 0)};
+}
+static bool group_members_independent(const ConvParams& a, const ConvParams& b) {
+  const size_t es = 2;  // bf16 / f16 only (group_member_params)
+  auto ranges = [&](const ConvParams& p, GroupRange (&r)[3]) {
+    const size_t px = (size_t)p.N * p.H * p.W;
+    r[0] = group_range(p.x, px * p.Cin * es);
+    r[1] = group_range(p.y, px * (size_t)(p.y2 ? p.split : p.Cout) * es);
+    r[2] = group_range(p.y2, p.y2 ? px * (size_t)(p.Cout - p.split) * es : 0);
+  };
+  GroupRange ra[3], rb[3];
+  ranges(a, ra);
+  ranges(b, rb);
+  for (int i = 0; i < 3; ++i)       // anything of b against a's outputs
+    for (int j = 1; j < 3; ++j)
+      if (rb[i].overlaps(ra[j])) return false;
+  for (int j = 1; j < 3; ++j)       // b's outputs against a's input
+    if (rb[j].overlaps(ra[0])) return false;
+  return true;
+}
+
 extern "C" int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* workspace, size_t workspace_bytes,
                                 void* stream) {
   if (int rc = ssdk::ctx_enter(ctx)) return rc;
@@ -1466,9 +1493,12 @@ extern "C" int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* 
       int m = 0;
       while (m < kSmallmapGroupMax && i + m < n && ops[i + m].kind == SSDK_OP_CONV && !(use_side && ops[i + m].lane == 1) &&
              ops[i + m].conv.dtype == ops[i].conv.dtype && group_member_params(&ops[i + m].conv, &gp[m])) {
+        // Members run as ONE kernel in no particular order: a candidate joins only if none of its byte ranges (input,
+        // outputs) overlaps an earlier member's OUTPUT ranges (read-after-write, write-after-write) and its outputs do
+        // not overlap an earlier member's INPUT range (write-after-read: the plan arena hands a buffer out again as soon
+        // as its last reader is recorded, so the op behind a tower's head may write the buffer the head still reads).
         bool indep = true;
-        for (int a = 0; a < m; ++a)
-          indep = indep && gp[m].x != gp[a].y && (gp[a].y2 == nullptr || gp[m].x != gp[a].y2);
+        for (int a = 0; a < m && indep; ++a) indep = group_members_independent(gp[a], gp[m]);
         if (!indep) break;
         ++m;
       }

@@ -19,10 +19,12 @@
 // x is read straight from global memory as the expand GEMM's B operand (16 bytes = 8 input channels of one pixel per
 // lane, one row ahead); the strips overlap by two pixels (halo), segments of rows by two rows.
 //
-// Numerics are those of ssdk_mbconv.hip: E = fp16(clamp(bn(expand), 0, 6)) (round toward zero), depthwise in packed
-// fp16 in the order (ky, kx), D = clamp(acc + bias, 0, 6), projection on the f16 MFMA with fp32 accumulation, output
-// rounded to the model dtype before the residual is added.  Stride 2: lane fr of a strip holds input column
-// 2*ox0 - 1 + fr, outputs sit in the odd lanes 1..13 (7 per strip).
+// Numerics follow ssdk_mbconv.hip: E = fp16(clamp(bn(expand), 0, 6)) (round toward zero; the BN scale is folded into the
+// expand weights -- by the host before they are rounded, else at staging time -- and the BN bias is the accumulator the
+// MFMA starts from), depthwise in packed fp16 in the order bias, (ky, kx), D = clamp(acc, 0, 6), projection on the f16 MFMA
+// with fp32 accumulation, output rounded to the model dtype before the residual is added.  Stride 2: lane fr of a strip
+// holds input column 2*ox0 - 1 + fr, outputs sit in the odd lanes 1..13 (7 per strip); with two strips per wave the
+// second strip's outputs move into the even lanes of ONE shared accumulator set (fl_merge_s2).
 #include <atomic>
 #include <type_traits>
 
@@ -90,6 +92,36 @@ template <int DT> __device__ __forceinline__ float fl_from16(u32 h) {
 __device__ __forceinline__ u32 fl_from_left(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }   // row_shr:1
 __device__ __forceinline__ u32 fl_from_right(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }  // row_shl:1
 
+// Stride 2, two strips per wave: only the ODD lanes 1..13 of a strip own an output pixel, so the taps of strip `a` stay in
+// the odd lanes and those of strip `b` move one lane to the left into the even lanes 0..12 -- one register set then holds
+// the 14 outputs of both strips and every packed FMA, the bias / ReLU6 pass, the projection MFMAs and the epilogue run once
+// for the pair instead of once per strip (half of their lanes idle).  Lane j of the merged registers:
+//   odd  j: left a[j-1], centre a[j],   right a[j+1]      (strip a, output (j-1)/2)
+//   even j: left b[j],   centre b[j+1], right b[j+2]      (strip b, output j/2)
+// A select whose one arm is a lane shift is ONE instruction (v_cndmask_b32_dpp: VCC ? src1 : dpp(src0)); the compiler
+// does not form it (it branches around a v_mov_b32_dpp instead, which reads disabled lanes), hence the asm block: VCC holds
+// the odd-lane mask, then the even-lane mask; s_nop 1 = the two wait states between a VALU write and a DPP read of it.
+__device__ __forceinline__ void fl_merge_s2(u32 a0, u32 a1, u32 b0, u32 b1, u32& l0, u32& l1, u32& c0, u32& c1, u32& r0, u32& r1) {
+  u32 t0, t1;
+  asm volatile(
+      "s_nop 1\n\t"
+      "s_mov_b32 vcc_lo, 0xaaaaaaaa\n\t"
+      "s_mov_b32 vcc_hi, 0xaaaaaaaa\n\t"
+      "v_cndmask_b32_dpp %2, %10, %8, vcc row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %3, %11, %9, vcc row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp %6, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_mov_b32_dpp %7, %9 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %4, %10, %6, vcc row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %5, %11, %7, vcc row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_mov_b32 vcc_lo, 0x55555555\n\t"
+      "s_mov_b32 vcc_hi, 0x55555555\n\t"
+      "v_cndmask_b32_dpp %0, %8, %10, vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_cndmask_b32_dpp %1, %9, %11, vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      : "=&v"(l0), "=&v"(l1), "=&v"(c0), "=&v"(c1), "=&v"(r0), "=&v"(r1), "=&v"(t0), "=&v"(t1)
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+      : "vcc");
+}
+
 constexpr int kFlowThreads = 256;
 
 // LDS image of the weights (bytes), all 16-byte aligned; NCH = hidden chunks of 16, T = projection k-steps, NFO = Cout / 16
@@ -129,6 +161,19 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
       }
     } else {
       if (hc < (u32)Chid && k0 < (u32)Cin) v = *reinterpret_cast<const u32x4*>(p.we + (size_t)hc * Cin + k0);
+    }
+    // The expand BatchNorm rides on the matrix cores: its scale is folded into the staged weights here (a scale of
+    // exactly 1 -- the host folds it before rounding the weights, fused_conv.MbPack -- leaves them bit for bit), its
+    // bias is the accumulator the MFMA starts from.  The row loop then has no BN arithmetic at all.
+    if (hc < (u32)Chid) {
+      const float sc = p.se[hc];
+      if (sc != 1.0f) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const u32 w2 = v[q];
+          v[q] = fl_to16<DT>(fl_from16<DT>(w2 & 0xffffu) * sc) | (fl_to16<DT>(fl_from16<DT>(w2 >> 16) * sc) << 16);
+        }
+      }
     }
     *reinterpret_cast<u32x4*>(smem + L::we + i * 16) = v;
   }
@@ -189,18 +234,28 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
     seg = __builtin_ctzll(m);
   }
   constexpr int OW = S == 1 ? 14 : 7;             // output pixels per strip
+  // stride 2 with two strips per wave: the outputs of both strips share ONE accumulator set (fl_merge_s2)
+  constexpr bool MERGE = S == 2 && NS == 2;
+  constexpr int NA = MERGE ? 1 : NS;              // accumulator / output sets per wave
   const int oy0 = seg * p.rs, oy1 = (oy0 + p.rs < p.Ho ? oy0 + p.rs : p.Ho) - 1;  // output rows [oy0, oy1]
-  int ix[NS], oxl[NS];
-  bool col_ok[NS], out_lane[NS];
+  int ix[NS], oxl[NA];
+  bool col_ok[NS], out_lane[NA];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int strip = grp * NS + s;
     const int ox0 = strip * OW;
     ix[s] = ox0 * S - 1 + (int)fr;                 // this lane's input column in strip s
     col_ok[s] = strip < p.strips && (unsigned)ix[s] < (unsigned)p.W;
-    // output pixel of this lane (if any): stride 1: lanes 1..14, stride 2: odd lanes 1..13
-    oxl[s] = S == 1 ? ox0 + (int)fr - 1 : ox0 + ((int)fr - 1) / 2;
-    out_lane[s] = strip < p.strips && (S == 1 ? (fr >= 1u && fr <= 14u) : ((fr & 1u) && fr <= 13u)) && oxl[s] < p.Wo;
+    if constexpr (!MERGE) {
+      // output pixel of this lane (if any): stride 1: lanes 1..14, stride 2: odd lanes 1..13
+      oxl[s] = S == 1 ? ox0 + (int)fr - 1 : ox0 + ((int)fr - 1) / 2;
+      out_lane[s] = strip < p.strips && (S == 1 ? (fr >= 1u && fr <= 14u) : ((fr & 1u) && fr <= 13u)) && oxl[s] < p.Wo;
+    }
+  }
+  if constexpr (MERGE) {  // odd lane j <= 13: output (j-1)/2 of strip 0; even lane j <= 12: output j/2 of strip 1
+    const int strip = grp * NS + ((fr & 1u) ? 0 : 1);
+    oxl[0] = strip * OW + (int)(fr >> 1);
+    out_lane[0] = strip < p.strips && fr <= 13u && oxl[0] < p.Wo;
   }
 
   const u16* ximg = STEM ? p.x + (size_t)n * p.Cimg * p.Himg * p.Wimg : p.x + (size_t)n * p.H * p.W * Cin;
@@ -211,17 +266,15 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
   // that falls left / right of the image (or a k >= 27) carries an offset far outside the buffer, and a buffer load
   // out of range returns 0 without touching memory -- the steady-state loop needs no masks and no branches.
   constexpr u32 kOOR = 0x40000000u;
-  u32 xoff[STEM ? NS : 1][STEM ? 8 : 1], xoff0[(STEM && !YE) ? NS : 1][(STEM && !YE) ? 8 : 1], kmw[STEM ? 4 : 1], kyM[STEM ? 3 : 1];
+  u32 xoff[STEM ? NS : 1][STEM ? 8 : 1], xoff0[(STEM && !YE) ? NS : 1][(STEM && !YE) ? 8 : 1], kyM[STEM ? 3 : 1];
   const int pstr = STEM ? (p.layout == 1 ? 1 : p.Cimg) : 0, cstr = STEM ? (p.layout == 1 ? p.Himg * p.Wimg : 1) : 0;
   if constexpr (STEM) {
-    u32 kvalid = 0;
     kyM[0] = kyM[1] = kyM[2] = 0u;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const u32 k = fg * 8u + (u32)j, ci = k / 9u, ky = (k % 9u) / 3u, kx = k % 3u;
       const bool kv = k < 27u && ci < (u32)p.Cimg;
       const u32 vo = (u32)(2 * (int)fr * pstr + (int)ci * cstr + ((int)ky * p.Wimg + (int)kx) * pstr) * 2u;
-      kvalid |= kv ? (1u << j) : 0u;
       kyM[0] |= (kv && ky == 0u) ? (1u << j) : 0u;
       kyM[1] |= (kv && ky == 1u) ? (1u << j) : 0u;
       kyM[2] |= (kv && ky == 2u) ? (1u << j) : 0u;
@@ -231,9 +284,7 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
         if constexpr (!YE) xoff0[s][j] = ky == 0u ? kOOR : xoff[s][j];  // stem row 0: its ky = 0 taps lie above the image
       }
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) kmw[q] = (((kvalid >> (2 * q)) & 1u) ? 0xffffu : 0u) | (((kvalid >> (2 * q + 1)) & 1u) ? 0xffff0000u : 0u);
-  }
+  }  // (a k >= 27 carries an out-of-range offset like an out-of-image value: the load returns 0, no mask needed)
   // STEM: the buffer is this image, opened `xmargin` bytes EARLY so that the (row, strip) offset in the SGPR is never
   // negative (row 0 starts one image row and three pixels before the image); nothing in front of the image is ever
   // read: the values that would lie there carry out-of-range offsets.
@@ -286,20 +337,20 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
     }
   };
 
-  fl_h2 accA[NS][NCH * 2], accB[NS][NCH * 2], accC[NS][NCH * 2];
+  fl_h2 accA[NA][NCH * 2], accB[NA][NCH * 2], accC[NA][NCH * 2];
   const fl_h2 zero2 = {(_Float16)0.f, (_Float16)0.f}, six2 = {(_Float16)6.f, (_Float16)6.f};
 
   // One input row.  FIN / MID / INI: the row is the last (ky = 2) / middle (ky = 1) / first (ky = 0) row of the output
   // row accumulated in fin / mid / ini; the FIN row is completed, projected and stored as output row `oy_fin`.
-  auto row = [&](const XRow (&xraw)[NS], int iy, auto FINc, auto MIDc, auto INIc, fl_h2 (&fin)[NS][NCH * 2],
-                 fl_h2 (&mid)[NS][NCH * 2], fl_h2 (&ini)[NS][NCH * 2], int oy_fin) {
+  auto row = [&](const XRow (&xraw)[NS], int iy, auto FINc, auto MIDc, auto INIc, fl_h2 (&fin)[NA][NCH * 2],
+                 fl_h2 (&mid)[NA][NCH * 2], fl_h2 (&ini)[NA][NCH * 2], int oy_fin) {
     constexpr bool FIN = decltype(FINc)::value, MID = decltype(MIDc)::value, INI = decltype(INIc)::value;
     u32x4 xf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       if constexpr (STEM) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xf[s][q] = (xraw[s].w[2 * q] | (xraw[s].w[2 * q + 1] << 16)) & kmw[q];
+        for (int q = 0; q < 4; ++q) xf[s][q] = xraw[s].w[2 * q] | (xraw[s].w[2 * q + 1] << 16);
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) xf[s][q] = xraw[s].w[q];
@@ -309,10 +360,10 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
 #pragma unroll
     for (int s = 0; s < NS; ++s) hi[s] = (col_ok[s] && (unsigned)iy < (unsigned)p.H) ? 6.f : 0.f;
     const bool store_row = FIN && oy_fin >= oy0 && oy_fin <= oy1;               // wave-uniform
-    uint2 resv[NS][NFO];
-    if (!STEM && FIN && store_row && p.residual) {  // issued early; consumed in the epilogue
+    uint2 resv[NA][NFO];
+    if (!STEM && !MERGE && FIN && store_row && p.residual) {  // issued early; consumed in the epilogue (stride 1 only)
 #pragma unroll
-      for (int s = 0; s < NS; ++s)
+      for (int s = 0; s < NA; ++s)
 #pragma unroll
         for (int f = 0; f < NFO; ++f) {
           const int co = f * 16 + (int)fg * 4;
@@ -327,36 +378,41 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
                                     //  not kept in hundreds of registers across the rows)
     f32x4 e_cur[NS], e_nxt[NS];
     u32x4 wa = *reinterpret_cast<const u32x4*>(smem + L::we + (int)lane * 16);
+    {  // the accumulator starts from the BN bias of the lane's four channels (the scale sits in the weights)
+      const f32x4 bv0 = *reinterpret_cast<const f32x4*>(smem + L::sb + (int)fg * 32 + 16);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) e_cur[s] = fl_mfma<DT>(wa, xf[s], f32x4{0.f, 0.f, 0.f, 0.f});  // D[hc = 16c + 4fg + r][px = fr]
+      for (int s = 0; s < NS; ++s) e_cur[s] = fl_mfma<DT>(wa, xf[s], bv0);  // D[hc = 16c + 4fg + r][px = fr]
+    }
     if (NCH > 1) wa = *reinterpret_cast<const u32x4*>(smem + L::we + (64 + (int)lane) * 16);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       asm volatile("" ::: "memory");
-      const f32x4 sv = *reinterpret_cast<const f32x4*>(smem + L::sb + (c * 4 + (int)fg) * 32);
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(smem + L::sb + (c * 4 + (int)fg) * 32 + 16);
       uint2 wt[9];
 #pragma unroll
       for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const uint2*>(smem + L::wd + ((c * 9 + t) * 4 + (int)fg) * 8);
+      // the depthwise bias is the value a fresh accumulator starts from (ky = 0 row)
+      uint2 bdi = make_uint2(0u, 0u);
+      if constexpr (INI) bdi = *reinterpret_cast<const uint2*>(smem + L::bd + (c * 4 + (int)fg) * 8);
       if (c + 1 < NCH) {
+        const f32x4 bvn = *reinterpret_cast<const f32x4*>(smem + L::sb + ((c + 1) * 4 + (int)fg) * 32 + 16);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) e_nxt[s] = fl_mfma<DT>(wa, xf[s], f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int s = 0; s < NS; ++s) e_nxt[s] = fl_mfma<DT>(wa, xf[s], bvn);
         if (c + 2 < NCH) wa = *reinterpret_cast<const u32x4*>(smem + L::we + ((c + 2) * 64 + (int)lane) * 16);
       }
       __builtin_amdgcn_sched_barrier(0);
+      u32 ew[NS][2];  // E = fp16(clamp(bn(expand), 0, 6 | 0)) of the lane's pixel: channels (0, 1) and (2, 3) of its four
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const f32x4 e = e_cur[s];
-        const u32 e0 = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(fmaf(e[0], sv[0], bv[0]), 0.f, hi[s]),
-                                                                          __builtin_amdgcn_fmed3f(fmaf(e[1], sv[1], bv[1]), 0.f, hi[s])));
-        const u32 e1 = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(fmaf(e[2], sv[2], bv[2]), 0.f, hi[s]),
-                                                                          __builtin_amdgcn_fmed3f(fmaf(e[3], sv[3], bv[3]), 0.f, hi[s])));
-        const fl_h2 c0 = fl_as_h2(e0), c1 = fl_as_h2(e1);
-        const fl_h2 l0 = fl_as_h2(fl_from_left(e0)), l1 = fl_as_h2(fl_from_left(e1));
-        const fl_h2 r0 = fl_as_h2(fl_from_right(e0)), r1 = fl_as_h2(fl_from_right(e1));
+        ew[s][0] = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(e[0], 0.f, hi[s]),
+                                                                      __builtin_amdgcn_fmed3f(e[1], 0.f, hi[s])));
+        ew[s][1] = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(e[2], 0.f, hi[s]),
+                                                                      __builtin_amdgcn_fmed3f(e[3], 0.f, hi[s])));
+      }
+      auto fold = [&](fl_h2 l0, fl_h2 l1, fl_h2 c0, fl_h2 c1, fl_h2 r0, fl_h2 r1, int a) {
         auto taps = [&](int ky, fl_h2& a0, fl_h2& a1, bool init) {
           const uint2 w0 = wt[ky * 3], w1 = wt[ky * 3 + 1], w2 = wt[ky * 3 + 2];
-          fl_h2 s0 = init ? zero2 : a0, s1 = init ? zero2 : a1;
+          fl_h2 s0 = init ? fl_as_h2(bdi.x) : a0, s1 = init ? fl_as_h2(bdi.y) : a1;
           s0 = __builtin_elementwise_fma(l0, fl_as_h2(w0.x), s0);
           s1 = __builtin_elementwise_fma(l1, fl_as_h2(w0.y), s1);
           s0 = __builtin_elementwise_fma(c0, fl_as_h2(w1.x), s0);
@@ -370,9 +426,19 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
           a0 = s0;
           a1 = s1;
         };
-        if constexpr (INI) taps(0, ini[s][2 * c], ini[s][2 * c + 1], true);
-        if constexpr (MID) taps(1, mid[s][2 * c], mid[s][2 * c + 1], false);
-        if constexpr (FIN) taps(2, fin[s][2 * c], fin[s][2 * c + 1], false);
+        if constexpr (INI) taps(0, ini[a][2 * c], ini[a][2 * c + 1], true);
+        if constexpr (MID) taps(1, mid[a][2 * c], mid[a][2 * c + 1], false);
+        if constexpr (FIN) taps(2, fin[a][2 * c], fin[a][2 * c + 1], false);
+      };
+      if constexpr (MERGE) {
+        u32 l0, l1, c0, c1, r0, r1;
+        fl_merge_s2(ew[0][0], ew[0][1], ew[1][0], ew[1][1], l0, l1, c0, c1, r0, r1);
+        fold(fl_as_h2(l0), fl_as_h2(l1), fl_as_h2(c0), fl_as_h2(c1), fl_as_h2(r0), fl_as_h2(r1), 0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          fold(fl_as_h2(fl_from_left(ew[s][0])), fl_as_h2(fl_from_left(ew[s][1])), fl_as_h2(ew[s][0]), fl_as_h2(ew[s][1]),
+               fl_as_h2(fl_from_right(ew[s][0])), fl_as_h2(fl_from_right(ew[s][1])), s);
       }
 #pragma unroll
       for (int s = 0; s < NS; ++s) e_cur[s] = e_nxt[s];
@@ -384,25 +450,24 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
       if (store_row) {
         // ---- the output row is complete: bias + ReLU6 in place, then it IS the projection's B operand --------------
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          const uint2 bdv = *reinterpret_cast<const uint2*>(smem + L::bd + (c * 4 + (int)fg) * 8);
+        for (int c = 0; c < NCH; ++c) {  // (the bias went in with the ky = 0 row)
 #pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            fin[s][2 * c] = __builtin_elementwise_min(__builtin_elementwise_max(fin[s][2 * c] + fl_as_h2(bdv.x), zero2), six2);
-            fin[s][2 * c + 1] = __builtin_elementwise_min(__builtin_elementwise_max(fin[s][2 * c + 1] + fl_as_h2(bdv.y), zero2), six2);
+          for (int s = 0; s < NA; ++s) {
+            fin[s][2 * c] = __builtin_elementwise_min(__builtin_elementwise_max(fin[s][2 * c], zero2), six2);
+            fin[s][2 * c + 1] = __builtin_elementwise_min(__builtin_elementwise_max(fin[s][2 * c + 1], zero2), six2);
           }
         }
         asm volatile("" ::: "memory");
-        f32x4 yacc[NS][NFO];
+        f32x4 yacc[NA][NFO];
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < NA; ++s)
 #pragma unroll
           for (int f = 0; f < NFO; ++f) yacc[s][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          u32x4 db[NS];
+          u32x4 db[NA];
 #pragma unroll
-          for (int s = 0; s < NS; ++s) {
+          for (int s = 0; s < NA; ++s) {
             db[s][0] = fl_as_u32(fin[s][4 * t]);
             db[s][1] = fl_as_u32(fin[s][4 * t + 1]);
             if (2 * t + 1 < NCH) {
@@ -417,11 +482,11 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
           for (int f = 0; f < NFO; ++f) {
             const u32x4 wf = *reinterpret_cast<const u32x4*>(smem + L::wp + ((f * T + t) * 64 + (int)lane) * 16);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) yacc[s][f] = fl_mfma<SSDK_F16>(wf, db[s], yacc[s][f]);  // D[co = 16f + 4fg + r][px = fr]
+            for (int s = 0; s < NA; ++s) yacc[s][f] = fl_mfma<SSDK_F16>(wf, db[s], yacc[s][f]);  // D[co = 16f + 4fg + r][px = fr]
           }
         }
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
+        for (int s = 0; s < NA; ++s) {
           if (out_lane[s]) {
             u16* yrow = p.y + (((size_t)n * p.Ho + oy_fin) * p.Wo + oxl[s]) * Cout;
 #pragma unroll
@@ -433,7 +498,7 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
                 // (hardware packed conversions: round to nearest even like the integer sequence of ssdk_mbconv.hip)
                 u32 h01 = fl_pack2<DT>(fmaf(yacc[s][f][0], spv[0], bpv[0]), fmaf(yacc[s][f][1], spv[1], bpv[1]));
                 u32 h23 = fl_pack2<DT>(fmaf(yacc[s][f][2], spv[2], bpv[2]), fmaf(yacc[s][f][3], spv[3], bpv[3]));
-                if (!STEM && p.residual) {  // the block's output is rounded to the model dtype first, then x is added (torch's tensor add)
+                if (!STEM && !MERGE && p.residual) {  // the block's output is rounded to the model dtype first, then x is added (torch's tensor add)
                   const u32 x01 = resv[s][f].x, x23 = resv[s][f].y;
                   h01 = fl_pack2<DT>(fl_from16<DT>(h01 & 0xffffu) + fl_from16<DT>(x01 & 0xffffu), fl_from16<DT>(h01 >> 16) + fl_from16<DT>(x01 >> 16));
                   h23 = fl_pack2<DT>(fl_from16<DT>(h23 & 0xffffu) + fl_from16<DT>(x23 & 0xffffu), fl_from16<DT>(h23 >> 16) + fl_from16<DT>(x23 >> 16));

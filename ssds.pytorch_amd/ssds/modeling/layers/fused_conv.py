@@ -239,7 +239,10 @@ class MbPack(object):
             wpad = torch.zeros((cs.out_channels, 3, 8, 4), device=w.device, dtype=torch.float32)
             wpad[:, :, :3, : w.shape[3]] = w
             self.e = ConvPack.__new__(ConvPack)
-            self.e.w, self.e.scale, self.e.bias = wpad.reshape(cs.out_channels, 96).to(dtype).contiguous(), scale, bias
+            # the BN scale goes into the weights BEFORE they are rounded (the block kernels then apply a scale of exactly 1:
+            # csrc/ssdk_mbflow.hip starts its expand MFMA from the BN bias and has no BN arithmetic left in the row loop)
+            wpad = wpad * scale.view(-1, 1, 1, 1)
+            self.e.w, self.e.scale, self.e.bias = wpad.reshape(cs.out_channels, 96).to(dtype).contiguous(), torch.ones_like(scale), bias
             self.d = ConvPack(cd, bd, "relu6", dtype)
             self.p = ConvPack(cp, bp, "none", dtype)
             self.cin, self.chid, self.cout = cs.in_channels, cs.out_channels, cp.out_channels
@@ -248,6 +251,9 @@ class MbPack(object):
             return
         (ce, be, _), (cd, bd, _), (cp, bp, _) = groups
         self.e = ConvPack(ce, be, "relu6", dtype)
+        # expand BN scale folded into the weights before rounding (see the stem case above); KRSC [Chid][1][1][Cin]
+        w_e = ce.weight.detach().float().permute(0, 2, 3, 1) * self.e.scale.view(-1, 1, 1, 1)
+        self.e.w, self.e.scale = w_e.contiguous().to(dtype), torch.ones_like(self.e.scale)
         self.d = ConvPack(cd, bd, "relu6", dtype)
         self.p = ConvPack(cp, bp, "none", dtype)
         self.cin, self.chid, self.cout = ce.in_channels, ce.out_channels, cp.out_channels

@@ -56,6 +56,7 @@ def _seeded_model(cfg_name, seed=321):
     ("ssd_mobilenetv2_512.yml", 64, "bfloat16", ("mbflow", "conv3x3_halo", "conv3x3_short", "conv_smallmap", "conv_smallmap_group", "xpair")),
     ("ssd_mobilenetv2_512.yml", 64, "float16", ("mbflow", "conv3x3_halo", "conv3x3_short", "conv_smallmap_group")),
     ("fpn_resnet50_640.yml", 32, "float16", ("stem7", "conv3x3_halo")),
+    ("fpn_resnet50_640.yml", 32, "bfloat16", ("stem7", "conv3x3_halo")),  # BASELINE config 3's own dtype
     ("bifpn_regnetx008_896.yml", 16, "float16", ("gconv3x3_g16", "fuse", "conv3x3_halo")),
 ])
 def test_forward_at_bench_size_against_the_fp32_module(cfg_name, batch, dtype, expect, monkeypatch):
