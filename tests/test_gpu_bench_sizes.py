@@ -100,12 +100,10 @@ def test_forward_at_bench_size_against_the_fp32_module(cfg_name, batch, dtype, e
         tl, tc = model(xd[pick])
     monkeypatch.delenv("SSDK_FUSED_CONV")
     got = {"loc": [t[pick] for t in loc], "conf": [t[pick] for t in conf]}
-    # (tail_factor 4: at these sizes the 99.9th percentile of a sigmoid output is set by a few thousand confident peaks
-    #  where d sigmoid / d logit is largest -- FPN-R50@640 fp16 level 0 measured 6.9 RMS for the plan against 2.2-3.2 for
-    #  PyTorch-ROCm (two runs) with equal medians (3e-4) and equal maxima (27.7); the median bar is the discriminating
-    #  one.  The heavier tail of the plan on that level is recorded as an open question in DESIGN.md.)
+    # (class heads as logits, see _check_against_floor; tail_factor 3: the floor here is PyTorch-ROCm on 4 images, the plan
+    #  ran the whole batch -- MIOpen picks its algorithms per batch size, which moves the floor's own tail by ~1.5x)
     _check_against_floor(got, {"loc": tl, "conf": tc}, {"loc": wl, "conf": wc}, "bench size %s B=%d" % (cfg_name, batch),
-                         dtype, tail_factor=4.0, tail_up_to_floor_max=True)
+                         dtype, tail_factor=3.0)
     del ref_state
 
 

@@ -18,41 +18,53 @@ from oracle import box_oracle as O
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-def _stats(got, want):
-    """(median, 99.9th percentile, max) of |got - want| / rms(want)."""
+def _logit(p):
+    import torch
+
+    p = p.float().clamp(1e-7, 1.0 - 1e-7)
+    return torch.log(p) - torch.log1p(-p)
+
+
+def _stats(got, want, logit=False):
+    """(median, 99.9th percentile, max) of |got - want| / rms(want); ``logit``: both mapped back through the sigmoid."""
     g = got.float().cpu()
     assert g.shape == want.shape, (g.shape, want.shape)
+    if logit:
+        g, want = _logit(g), _logit(want)
     rms = float(want.pow(2).mean().sqrt())
     e = ((g - want).abs() / max(rms, 1e-6)).flatten()
     k = max(int(e.numel() * 0.999) - 1, 0)
     return float(e.median()), float(e.kthvalue(k + 1).values), float(e.max())
 
 
-CAP = {"bfloat16": 0.9, "float16": 0.3}  # absolute cap on the median error (a wrong wire is >= 1)
+CAP = {"bfloat16": 0.7, "float16": 0.3}  # absolute cap on the median error (a wrong wire is >= 1; measured bf16: <= 0.63)
 # absolute slack on (median, p99.9): the last levels are a few dozen values, whose statistics are noise themselves
 SLACK = {"bfloat16": (0.06, 0.2), "float16": (0.015, 0.05)}
 
 
-def _check_against_floor(plan_out, torch_out, want, what, dtype, tail_factor=2.0, tail_up_to_floor_max=False):
+def _check_against_floor(plan_out, torch_out, want, what, dtype, tail_factor=2.0):
     """Untrained deep networks amplify rounding noise (torch's own bf16 execution of MobileNetV2 is 0.1-0.6 RMS away
     from fp32 at the deeper levels), so the bar is relative to the noise floor of the SAME module executed by
     PyTorch-ROCm in the SAME dtype: the plan must be as close to the reference's fp32 outputs as that, up to a factor
     2 (+ a small absolute term for the levels where both are tiny).  A wiring / folding / layout error is ~1.4 RMS
     (uncorrelated outputs) whatever the floor; the absolute cap makes the fp16 runs (8x less rounding noise than bf16)
-    the discriminating ones."""
+    the discriminating ones.
+
+    The class heads are compared as LOGITS (round 4).  A sigmoid output hides its logit: d sigmoid / d logit is 0.01 at the
+    p = 0.01 of the untrained prior and 0.25 at p = 0.5, so in probability space the 99.9th percentile of the error is set
+    by how many of the few-per-mille confident peaks happen to cross it -- on FPN-ResNet50@640 (level 0: 0.14 % of the
+    elements have p > 0.1, BOTH executions miss those by 0.1 - 0.7 in probability) that statistic jumped between 1.7 and
+    7.1 RMS from run to run and needed an escape clause; tools/plan_trace.py (profiles/r04_plan_trace_fpn_*.txt) audits all
+    112 layers of that plan one by one against fp32 on the layer's own input: every kernel sits at its rounding level.  In
+    logit space the error is homogeneous and the plain factor rule applies to every tensor."""
     report, bad = [], []
     for tag in ("loc", "conf"):
         for i, (p, t, w) in enumerate(zip(plan_out[tag], torch_out[tag], want[tag])):
-            sp, st = _stats(p, w), _stats(t, w)
-            report.append("%s%d plan %.4f/%.4f/%.4f floor %.4f/%.4f/%.4f" % ((tag, i) + sp + st))
+            lg = tag == "conf"
+            sp, st = _stats(p, w, lg), _stats(t, w, lg)
+            report.append("%s%d%s plan %.4f/%.4f/%.4f floor %.4f/%.4f/%.4f" % ((tag, i, "(logit)" if lg else "") + sp + st))
             m_abs, p_abs = SLACK[dtype]
-            # tail_up_to_floor_max (bench sizes only): a sigmoid output whose logit sits near 0 turns a logit error d into
-            # d/4, i.e. ~25 d in units of the RMS of an output that is ~0.01 everywhere else; on the untrained FPN-R50@640 in
-            # fp16 both executions have such elements (max 27 RMS in both), how many of them cross the 99.9th percentile
-            # varies from run to run in the torch floor itself (1.7-3.2) -- the plan's tail may reach the floor's own maximum
             tail_bar = tail_factor * st[1] + p_abs
-            if tail_up_to_floor_max:
-                tail_bar = max(tail_bar, st[2])
             if not (sp[0] <= 2.0 * st[0] + m_abs and sp[1] <= tail_bar and sp[0] <= CAP[dtype]):
                 bad.append(report[-1])
     out = os.path.join(ROOT, "gpurun_out")
