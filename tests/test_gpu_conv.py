@@ -736,6 +736,59 @@ def test_register_flow_block_fp16(cin, cout, stride, h, w):
     assert float((outs["flow"].float() - outs["tiled"].float()).abs().max()) <= 2e-2 * max(1.0, float(y.abs().max()))
 
 
+SPLIT = [  # cin, cout, stride, h, w, n: the block shapes ssdk_mbsplit.hip is instantiated for (hidden = 6 * cin)
+    (24, 32, 2, 70, 45, 3),    # three waves x 3 chunks, merged stride-2 strips, ragged strips / segments
+    (32, 32, 1, 31, 47, 3),    # four waves x 3 chunks, residual, two output fragments per strip
+    (32, 32, 1, 64, 64, 5),    # the bench's map: three strip pairs, full segments
+    (32, 64, 2, 36, 41, 4),    # stride 2 with four output fragments
+]
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,stride,h,w,n", SPLIT)
+def test_split_register_flow_block(cin, cout, stride, h, w, n, dtype_name):
+    """ssdk_mbsplit.hip (hidden channels of a strip pair split over the waves of a workgroup, partial projections
+    exchanged through LDS) against the torch fp32 block with 16-bit-rounded intermediates, against the LDS-tiled kernel,
+    and bit-reproducible from run to run (the exchange adds the partial sums in wave order)."""
+    import torch
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+    from ssds.modeling.layers.planner import groups_of
+    from ssds.modeling.nets.mobilenet import InvertedResidual
+
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    torch.manual_seed(cin * 11 + cout + stride + h)
+    blk = InvertedResidual(cin, cout, stride, 6).eval()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data = (m.weight.data * 2).to(dtype).float()
+    x = torch.randn(n, cin, h, w).to(dtype)
+    with torch.no_grad():
+        y = x.float()
+        mods = list(blk.conv.children())
+        y = mods[0](y).to(dtype).float()
+        y = mods[1](y).to(dtype).float()
+        y = mods[3](mods[2](y))
+        if blk.use_res_connect:
+            y = y.to(dtype).float() + x.float()
+    blk = blk.cuda()
+    pk = FC.MbPack(groups_of(blk.conv), blk.use_res_connect, dtype)
+    got = FC.mbconv_native(x.cuda(), pk, variant=2)
+    name = N.last_kernel()
+    assert "mbsplit" in name, name
+    _check(got, y, dtype, "split block %d->%d s%d" % (cin, cout, stride), floor=1.0)
+    again = FC.mbconv_native(x.cuda(), pk, variant=2)
+    assert torch.equal(got, again), "the exchange is not bit-reproducible"
+    tiled = FC.mbconv_native(x.cuda(), pk, variant=-1)
+    assert "mbsplit" not in N.last_kernel() and "mbflow" not in N.last_kernel()
+    assert float((got.float() - tiled.float()).abs().max()) <= 2e-2 * max(1.0, float(y.abs().max()))
+
+
 @pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
 def test_fused_blocks_16x16_tiles(dtype_name):
     """Stride-1 blocks on maps large enough for >= 512 tiles run on the 16x16-tile instantiations (strip-tiled
