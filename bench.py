@@ -471,13 +471,16 @@ def main():
     stage_bytes = conf_bytes + loc_bytes + B * (2 * 24 * L * K + 24 * D)  # SURVEY.md 8d (1.465 MB/img at SSD@512 bf16)
 
     def stage(s_ms, t_ms, n_ms, whole_ms=None):
-        """kernels_ms: one hipEvent interval per launch (scan16 | levelsel | nmswalk); stage_ms: ONE interval around the
-        three launches (what `stage_frac` uses when it was measured: every extra event costs ~4.6 us of GPU time on this
+        """kernels_ms: one hipEvent interval per launch (scan16 | tail2, or scan16 | levelsel | nmswalk with SSDK_TAIL2=0);
+        stage_ms: ONE interval around the launches (what `stage_frac` uses when it was measured: every extra event costs ~4.6 us of GPU time on this
         stack and flushes the caches between the kernels it separates); else the sum of the three."""
         tot = whole_ms if whole_ms else s_ms + t_ms + n_ms
-        return {"kernels_ms": {"scan": round(float(s_ms), 5), "levelsel": round(float(t_ms), 5), "nmswalk": round(float(n_ms), 5)},
+        two = float(n_ms) == 0.0  # tail2_kernel: level select + decode + NMS walk in ONE launch behind the scan
+        kern = ({"scan": round(float(s_ms), 5), "tail2 (levelsel + nmswalk in one launch)": round(float(t_ms), 5)} if two else
+                {"scan": round(float(s_ms), 5), "levelsel": round(float(t_ms), 5), "nmswalk": round(float(n_ms), 5)})
+        return {"launches": 2 if two else 3, "kernels_ms": kern,
                 "stage_ms": round(float(tot), 5),
-                "stage_ms_is": "one event interval around the stage's three launches" if whole_ms else "sum of the three intervals",
+                "stage_ms_is": ("one event interval around the stage's %d launches" % (2 if two else 3)) if whole_ms else "sum of the intervals",
                 "scan_GBps": round(conf_bytes / (s_ms * 1e-3) / 1e9, 1),
                 "scan_frac": round(conf_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "stage_GBps": round(stage_bytes / (tot * 1e-3) / 1e9, 1),

@@ -16,6 +16,7 @@
 namespace ssdk {
 
 constexpr int kSmThreads = 256;
+__host__ __device__ constexpr int sm_pad(int stride) { return stride == 1 ? 32 : 16; }  // (host side sizes every instance for 32)
 
 // CS = Cin / 32 is a template parameter: the k-loop is unrolled completely, because a loop back edge makes the compiler
 // drain the load counter at the top of every iteration (s_waitcnt vmcnt(0)) however the body is written
@@ -44,7 +45,10 @@ __device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx,
   const int PL = S == 2 ? PI + (p.H >> 1) : PI;             // LDS row slots per image (skewed for stride 2)
   const int ZROW = G * PL;                                  // the zero row
   const int img0 = (int)bx * G;
-  const int RS = Cin * 2 + 16;                           // LDS row stride (bytes); row ROWS = zeros
+  // LDS row stride (bytes); row ROWS = zeros.  Stride 1 (round 4): Cin * 2 + 32, i.e. R = stride / 16 = 2 (mod 4) -- the
+  // four 16-lane groups a ds_read_b128 is serviced in mix eight pixels of k-piece fg with eight of piece fg + 1, and only
+  // R = 2 (mod 4) keeps their sixteen 16-byte slots apart (ssdk_conv3x3s.hip; the former Cin * 2 + 16 measured 48 % conflict cycles)
+  const int RS = Cin * 2 + sm_pad(S);
   const u16* x = (const u16*)p.x;
 
   // ---- the weight stream starts first: it does not depend on the maps -----------------------------------------------
@@ -263,7 +267,7 @@ int launch_conv_smallmap_group(const ConvParams* ps, int n, int dtype, hipStream
     g.start[i] = total;
     total += g.gx[i] * gy;
     g.code[i] = (p.Cin == 128 ? 0 : p.Cin == 256 ? 2 : 4) + (P == 1 ? 1 : 0);
-    const size_t l = (size_t)(64 + 1) * (p.Cin * 2 + 16);
+    const size_t l = (size_t)(64 + 1) * (p.Cin * 2 + 32);
     lds = l > lds ? l : lds;
   }
   g.start[n] = total;
@@ -291,7 +295,7 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   const bool s2 = p.stride == 2;
   if (s2) {  // the stride-2 instance: even input map, fragment-major weights, the input maps of a workgroup fit the LDS
     if (!env_s2 || !packed || p.H != 2 * p.Ho || p.W != 2 * p.Wo || P == 1) return 1;
-    const size_t need = (size_t)((64 / P) * (p.H * p.W + p.H / 2) + 1) * (p.Cin * 2 + 16);
+    const size_t need = (size_t)((64 / P) * (p.H * p.W + p.H / 2) + 1) * (p.Cin * 2 + 32);
     if (need > 160 * 1024) return 1;
   } else if (p.stride != 1 || p.H != p.Ho || p.W != p.Wo) {
     return 1;
@@ -309,7 +313,7 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   static const int env_nw = getenv("SSDK_CONV_SMALLMAP_NW") ? atoi(getenv("SSDK_CONV_SMALLMAP_NW")) : 4;
   const int nw = env_nw == 1 || env_nw == 2 ? env_nw : 4;  // (fewer waves per workgroup = more workgroups: measured slower on every level)
   const dim3 grid((unsigned)groups, (unsigned)((nfr + nw - 1) / nw));
-  const size_t lds = s2 ? (size_t)(G * (p.H * p.W + p.H / 2) + 1) * (p.Cin * 2 + 16) : (size_t)(16 * mfr + 1) * (p.Cin * 2 + 16);
+  const size_t lds = s2 ? (size_t)(G * (p.H * p.W + p.H / 2) + 1) * (p.Cin * 2 + 32) : (size_t)(16 * mfr + 1) * (p.Cin * 2 + 32);
   const int cs = p.Cin / 32;
 #define SSDK_SMS(DT, CS_, MFR_, TAPS_, PK_, NA_, S_)                                                                       \
   do {                                                                                                                     \

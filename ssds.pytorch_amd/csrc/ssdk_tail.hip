@@ -194,6 +194,41 @@ __device__ __forceinline__ bool tail_suppressed_by(const float4 b, float ab, con
   return over;
 }
 
+// COH (tail2_kernel): the [L*K] arrays travel between workgroups of ONE launch, possibly on different XCDs (one L2 each).
+// Agent-scope relaxed atomics are the cheap way: a store goes through to memory (sc1), a load does not take a line from the
+// reader's L2 -- no cache-wide write-back / invalidate (measured: with an agent-scope release fence per workgroup, i.e. 384
+// buffer_wbl2 of L2s full of the head convolutions' dirty lines, the walk's first 1800 loads took 16 us).
+template <bool COH> __device__ __forceinline__ void tail_st(float* p, float v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool COH> __device__ __forceinline__ void tail_st4(float4* p, const float4& v) {
+  if constexpr (COH) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    const unsigned long long lo = (unsigned long long)__builtin_bit_cast(u32, v.x) | ((unsigned long long)__builtin_bit_cast(u32, v.y) << 32);
+    const unsigned long long hi = (unsigned long long)__builtin_bit_cast(u32, v.z) | ((unsigned long long)__builtin_bit_cast(u32, v.w) << 32);
+    __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *p = v;
+  }
+}
+template <bool COH> __device__ __forceinline__ float tail_ld(const float* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH> __device__ __forceinline__ float4 tail_ld4(const float4* p) {
+  if constexpr (COH) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__builtin_bit_cast(float, (u32)lo), __builtin_bit_cast(float, (u32)(lo >> 32)),
+                       __builtin_bit_cast(float, (u32)hi), __builtin_bit_cast(float, (u32)(hi >> 32)));
+  } else {
+    return *p;
+  }
+}
+
 __device__ __forceinline__ float tail_bcast(float v, u32 j) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)j));
 }
@@ -225,15 +260,14 @@ __host__ __device__ inline size_t sel_lds_bytes(u32 K) {
 
 // NT: 256 threads, or 1024 where a level has many scan units (the 112x112 / 80x80 levels of the FPN / BiFPN heads: 55 / 28
 // units x K keys per image -- with 256 threads the two passes over the keys were 80 k of the workgroup's 94 k cycles)
-template <int DT, int NT>
-__global__ __launch_bounds__(NT) void levelsel_kernel(const SelParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+template <int DT, int NT, bool COH = false>
+__device__ __forceinline__ void levelsel_body(const SelParams& p, const u32 l, const u32 b, unsigned char* smem) {
   SelLds* S = reinterpret_cast<SelLds*>(smem);
   const u32 K = p.K;
   u64* wkeys = reinterpret_cast<u64*>(smem + sizeof(SelLds));  // [K] winners grouped by bin (descending), boundary winners in order
   u64* bkeys = wkeys + ((K + 1u) & ~1u);                       // [K] boundary list
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const u32 l = blockIdx.x, b = blockIdx.y, L = (u32)p.L;
+  const u32 L = (u32)p.L;
   const bool stamp = p.stamps != nullptr && l == 0 && b == 0 && tid == 0;
   if (stamp) p.stamps[0] = clock64();
   const u32 hbase = p.hist_base, hsh = p.hist_sh;
@@ -289,7 +323,9 @@ __global__ __launch_bounds__(NT) void levelsel_kernel(const SelParams p) {
   // unit: only the first unit's keys survive the bound and no selection is left.)
   for (int trip = 0; trip < 2; ++trip) {  // workgroup-uniform
     if (trip == 1) {
-      if (!(S->generic && nu > 1u && nu <= kSelUnits)) break;
+      const bool again = S->generic && nu > 1u && nu <= kSelUnits;
+      __syncthreads();  // every thread has read the flag before thread 0 clears it below (a late wave must not see the reset)
+      if (!again) break;
       const u32 mK = K <= 1u ? 0xffffffffu : (u32)((1ull << 32) / K);
       for_each_key([&](u64 key, u32 i) {
         if (key == 0ull) return;
@@ -469,14 +505,20 @@ __global__ __launch_bounds__(NT) void levelsel_kernel(const SelParams p) {
         float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
         if (key != 0ull) tail_decode(lv, h ? g1 : g0, p.rescore, key_score(key), &sc_, &bx, &c);
         // (the slots below nw are a permutation of themselves; the slots from nw on hold no winner)
-        ms[dst] = sc_;
-        mb[dst] = bx;
-        mc[dst] = c;
+        tail_st<COH>(ms + dst, sc_);
+        tail_st4<COH>(mb + dst, bx);
+        tail_st<COH>(mc + dst, c);
         if (stamp && h == 0) p.stamps[15] = clock64();
       }
     }
   }
   if (stamp) p.stamps[16] = clock64();
+}
+
+template <int DT, int NT>
+__global__ __launch_bounds__(NT) void levelsel_kernel(const SelParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  levelsel_body<DT, NT>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -499,10 +541,10 @@ __host__ __device__ inline size_t walk_lds_bytes(u32 M, u32 ndet) {
   return sizeof(WalkLds) + (size_t)(M < 128u ? 128u : M) * 8 + (size_t)ndet * 16 + ((((size_t)ndet * 8) + 15) & ~(size_t)15) + 64;
 }
 
-__global__ __launch_bounds__(kWalkThreads) void nmswalk_kernel(const WalkParams p) {
+template <bool COH = false>
+__device__ __forceinline__ void nmswalk_body(const WalkParams& p, const u32 b, unsigned char* smem) {
   constexpr int NT = kWalkThreads;
   constexpr u32 NW = NT / 64;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   WalkLds* S = reinterpret_cast<WalkLds*>(smem);
   const u32 N = p.N, M = p.M, ndet = (u32)p.ndet;
   const u32 Mp = M < 128u ? 128u : M;
@@ -514,7 +556,6 @@ __global__ __launch_bounds__(kWalkThreads) void nmswalk_kernel(const WalkParams 
   float* karea = reinterpret_cast<float*>(q);
   float* kcls = karea + ndet;
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const u32 b = blockIdx.x;
   const bool stamp = p.stamps != nullptr && b == 0 && tid == 0;
   if (stamp) p.stamps[3] = clock64();
   const float* sc = p.scores + (size_t)b * N;
@@ -531,7 +572,7 @@ __global__ __launch_bounds__(kWalkThreads) void nmswalk_kernel(const WalkParams 
   for (u32 pos = tid; pos < Mp; pos += NT) {  // (Mp is a multiple of 64: whole waves)
     u64 nkey = 0ull;
     if (pos < N) {
-      const float s = sc[pos];
+      const float s = tail_ld<COH>(sc + pos);
       nkey = (s > 0.0f) ? make_key(s, pos) : 0ull;  // box.py:496 (NaN drops out too)
     }
     nkeys[pos] = nkey;
@@ -654,9 +695,9 @@ __global__ __launch_bounds__(kWalkThreads) void nmswalk_kernel(const WalkParams 
     // the round's boxes and classes, in walk order (one gather for the whole round)
     for (u32 i = tid; i < r; i += NT) {
       const u32 pos = key_index(S->sorted[i]);
-      const float4 bb = bx[pos];
+      const float4 bb = tail_ld4<COH>(bx + pos);
       S->rbox[i] = bb;
-      S->rcls[i] = cl[pos];
+      S->rcls[i] = tail_ld<COH>(cl + pos);
       if ((bb.x != bb.x) | (bb.y != bb.y) | (bb.z != bb.z) | (bb.w != bb.w)) S->hasnan = 1u;
     }
     __syncthreads();
@@ -763,6 +804,38 @@ __global__ __launch_bounds__(kWalkThreads) void nmswalk_kernel(const WalkParams 
   if (stamp) p.stamps[5] = clock64();
 }
 
+__global__ __launch_bounds__(kWalkThreads) void nmswalk_kernel(const WalkParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  nmswalk_body<false>(p, blockIdx.x, smem);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// tail2_kernel (round 4): levelsel + nmswalk as ONE launch -- the decode stage is then two launches (scan | tail), what SURVEY
+// a12 asks for.  Grid (levels, images), 1024 threads: every workgroup runs the level select + decode of its (image, level) like
+// levelsel_kernel<DT, 1024>; the workgroup that finishes an image's LAST level (an agent-scope release / acquire ticket per
+// image: every wave drains its stores, barrier, one lane takes the ticket, the last arriver re-arms the counter) goes on with that image's NMS walk on the [L*K] arrays the L
+// workgroups have just written (agent-scope stores and loads, see tail_st / tail_ld: no cache-wide fence).  No workgroup ever
+// waits for another one, so any launch order is safe.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(kWalkThreads) void tail2_kernel(const SelParams ps, const WalkParams pw, u32* tickets) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ u32 s_last;
+  const u32 l = blockIdx.x, b = blockIdx.y;
+  levelsel_body<DT, kWalkThreads, true>(ps, l, b, smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's (write-through) [L*K] stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(tickets + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned last = (old == (unsigned)ps.L - 1u) ? 1u : 0u;
+    if (last) __hip_atomic_store(tickets + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next call
+    s_last = last;
+  }
+  __syncthreads();  // (also: the select is done with the LDS image the walk builds over it)
+  if (s_last == 0u) return;  // workgroup-uniform
+  nmswalk_body<true>(pw, b, smem);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // host side (called from ssdk_decode_nms, ssdk_ctx.cpp)
 // ------------------------------------------------------------------------------------------------------------------
@@ -784,14 +857,9 @@ size_t tail_fits(int K, int L, int ndet) {
   return need <= kTailLdsMax ? need : 0;
 }
 
-int launch_levelsel(const ssdk_level* lv, int L, int B, int dtype, int K, int rescore, const u32* units, const u32* unit_base,
-                    u32 units_per_image, const void* cand, const void* cand_cnt, u32 hist_base, u32 hist_sh, float* ms,
-                    float* mb, float* mc, unsigned long long* stamps, hipStream_t stream) {
-  if (!ms || !mb || !mc || ((uintptr_t)mb & 15)) {
-    set_error("decode_nms: null or misaligned per-level output pointer (boxes need 16-byte alignment)");
-    return SSDK_E_BADARG;
-  }
-  SelParams p;
+static void fill_sel_params(SelParams& p, const ssdk_level* lv, int L, int dtype, int K, int rescore, const u32* units,
+                            const u32* unit_base, u32 units_per_image, const void* cand, const void* cand_cnt, u32 hist_base,
+                            u32 hist_sh, float* ms, float* mb, float* mc, unsigned long long* stamps) {
   memset(&p, 0, sizeof(p));
   for (int l = 0; l < L; ++l) {
     p.lv[l].box = lv[l].box;
@@ -821,6 +889,18 @@ int launch_levelsel(const ssdk_level* lv, int L, int B, int dtype, int K, int re
   p.mid_boxes = mb;
   p.mid_classes = mc;
   p.stamps = stamps;
+}
+
+int launch_levelsel(const ssdk_level* lv, int L, int B, int dtype, int K, int rescore, const u32* units, const u32* unit_base,
+                    u32 units_per_image, const void* cand, const void* cand_cnt, u32 hist_base, u32 hist_sh, float* ms,
+                    float* mb, float* mc, unsigned long long* stamps, hipStream_t stream) {
+  if (!ms || !mb || !mc || ((uintptr_t)mb & 15)) {
+    set_error("decode_nms: null or misaligned per-level output pointer (boxes need 16-byte alignment)");
+    return SSDK_E_BADARG;
+  }
+  SelParams p;
+  fill_sel_params(p, lv, L, dtype, K, rescore, units, unit_base, units_per_image, cand, cand_cnt, hist_base, hist_sh, ms, mb, mc,
+                  stamps);
   lds_poison(stream);
   const dim3 grid((unsigned)L, (unsigned)B);
   u32 most = 0;
@@ -837,6 +917,53 @@ int launch_levelsel(const ssdk_level* lv, int L, int B, int dtype, int K, int re
   else SSDK_SEL(SSDK_F16);
 #undef SSDK_SEL
   return check_launch("levelsel_kernel");
+}
+
+// levelsel + nmswalk as one launch (tail2_kernel); `tickets`: B zero-initialised words owned by the context
+int launch_tail2(const ssdk_level* lv, int L, int B, int dtype, int K, int rescore, const u32* units, const u32* unit_base,
+                 u32 units_per_image, const void* cand, const void* cand_cnt, u32 hist_base, u32 hist_sh, float* ms, float* mb,
+                 float* mc, float nms_thr, int ndet, int diou, float* os, float* ob, float* oc, u32* tickets,
+                 unsigned long long* stamps, hipStream_t stream) {
+  if (!ms || !mb || !mc || ((uintptr_t)mb & 15) || !os || !ob || !oc || ((uintptr_t)ob & 15) || !tickets) {
+    set_error("decode_nms: null or misaligned output pointer (boxes need 16-byte alignment)");
+    return SSDK_E_BADARG;
+  }
+  SelParams ps;
+  fill_sel_params(ps, lv, L, dtype, K, rescore, units, unit_base, units_per_image, cand, cand_cnt, hist_base, hist_sh, ms, mb, mc,
+                  stamps);
+  WalkParams pw;
+  memset(&pw, 0, sizeof(pw));
+  pw.N = (u32)(L * K);
+  pw.M = tail_pow2(pw.N);
+  pw.scores = ms;
+  pw.boxes = mb;
+  pw.classes = mc;
+  pw.thr = nms_thr;
+  pw.ndet = ndet;
+  pw.diou = diou;
+  pw.out_scores = os;
+  pw.out_boxes = ob;
+  pw.out_classes = oc;
+  pw.stamps = stamps;
+  size_t lds = walk_lds_bytes(pw.M, (u32)ndet);
+  if (sel_lds_bytes((u32)K) > lds) lds = sel_lds_bytes((u32)K);
+  lds_poison(stream);
+  const dim3 grid((unsigned)L, (unsigned)B);
+  auto go = [&](auto kern) -> int {
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)kTailLdsMax) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("decode_nms: cannot raise the dynamic LDS limit of tail2_kernel");
+      return SSDK_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(kWalkThreads), lds, stream, ps, pw, tickets);
+    return SSDK_OK;
+  };
+  int rc;
+  if (dtype == SSDK_F32) rc = go(tail2_kernel<SSDK_F32>);
+  else if (dtype == SSDK_BF16) rc = go(tail2_kernel<SSDK_BF16>);
+  else rc = go(tail2_kernel<SSDK_F16>);
+  return rc ? rc : check_launch("tail2_kernel");
 }
 
 int launch_nmswalk(const float* ms, const float* mb, const float* mc, int B, int N, float nms_thr, int ndet, int diou, float* os,
