@@ -30,6 +30,9 @@ struct FlowParams {
   // STEM: row segments that touch the top / bottom of the image run in their own launch (the YE instance masks rows per
   // value; the interior instance has a branch-free gather): bit s of seg_mask = segment s belongs to THIS launch
   unsigned long long seg_mask;
+  // SSDK_MB_DBG=1 (debug): shader-clock stamps of one wave in the middle of the grid, four per input row: row entry, x row
+  // arrived (an explicit wait), chunk loop done, projection + stores issued
+  unsigned long long* dbg;
 };
 
 template <int DT>

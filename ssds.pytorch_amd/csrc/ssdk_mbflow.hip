@@ -25,6 +25,7 @@
 // with fp32 accumulation, output rounded to the model dtype before the residual is added.  Stride 2: lane fr of a strip
 // holds input column 2*ox0 - 1 + fr, outputs sit in the odd lanes 1..13 (7 per strip); with two strips per wave the
 // second strip's outputs move into the even lanes of ONE shared accumulator set (fl_merge_s2).
+#include <stdio.h>
 #include <atomic>
 #include <type_traits>
 
@@ -248,6 +249,9 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
     }
   };
 
+  // (wave-uniform: every lane of the stamped wave writes the same word)
+  const bool dbgw = p.dbg != nullptr && blockIdx.x == gridDim.x / 2 && __builtin_amdgcn_readfirstlane((int)wave) == 0;
+  int dbg_k = 0;
   fl_h2 accA[NA][NCH * 2], accB[NA][NCH * 2], accC[NA][NCH * 2];
   const fl_h2 zero2 = {(_Float16)0.f, (_Float16)0.f}, six2 = {(_Float16)6.f, (_Float16)6.f};
 
@@ -256,6 +260,12 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
   auto row = [&](const XRow (&xraw)[NS], int iy, auto FINc, auto MIDc, auto INIc, fl_h2 (&fin)[NA][NCH * 2],
                  fl_h2 (&mid)[NA][NCH * 2], fl_h2 (&ini)[NA][NCH * 2], int oy_fin) {
     constexpr bool FIN = decltype(FINc)::value, MID = decltype(MIDc)::value, INI = decltype(INIc)::value;
+    if (dbgw && dbg_k < 250) {
+      p.dbg[dbg_k++] = __builtin_readcyclecounter();
+      if constexpr (STEM) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // (the next row's loads stay in flight)
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      p.dbg[dbg_k++] = __builtin_readcyclecounter();
+    }
     u32x4 xf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -357,6 +367,7 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
       // runs out of registers
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (dbgw && dbg_k < 250) p.dbg[dbg_k++] = __builtin_readcyclecounter();
     if constexpr (FIN) {
       if (store_row) {
         // ---- the output row is complete: bias + ReLU6 in place, then it IS the projection's B operand --------------
@@ -421,6 +432,7 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
         }
       }
     }
+    if (dbgw && dbg_k < 250) p.dbg[dbg_k++] = __builtin_readcyclecounter();
   };
 
   const auto Y = std::true_type{};
@@ -537,6 +549,25 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
   p.Wo = (p.W + 2 - 3) / d->stride + 1;
   p.residual = d->residual;
   p.seg_mask = 0;
+  p.dbg = nullptr;
+  static const int env_dbg = getenv("SSDK_MB_DBG") ? atoi(getenv("SSDK_MB_DBG")) : 0;
+  static unsigned long long* dbg_dev = nullptr;
+  if (env_dbg) {
+    if (!dbg_dev) (void)hipMalloc(&dbg_dev, 256 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dbg_dev, 0, 256 * sizeof(unsigned long long), stream);
+    p.dbg = dbg_dev;
+  }
+  auto dbg_print = [&]() {  // debug only: synchronises
+    if (!env_dbg) return;
+    unsigned long long hh[256];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(hh, dbg_dev, sizeof(hh), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[mbflow dbg] Cin=%d Chid=%d Cout=%d s=%d stem=%d rs=%d: per row (wait x | chunks | project+store | to next row):", d->Cin,
+            d->Chid, d->Cout, d->stride, (int)stem, p.rs);
+    for (int i = 0; i + 4 < 250 && hh[i + 4]; i += 4)
+      fprintf(stderr, " [%llu %llu %llu %llu]", hh[i + 1] - hh[i], hh[i + 2] - hh[i + 1], hh[i + 3] - hh[i + 2], hh[i + 4] - hh[i + 3]);
+    fprintf(stderr, "\n");
+  };
   const int ow = d->stride == 1 ? 14 : 7;
   p.strips = (p.Wo + ow - 1) / ow;
   // rows per segment: long segments amortise the two halo rows, short ones give the chip enough waves (>= ~3 per SIMD)
@@ -588,10 +619,12 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
       go(std::integral_constant<int, SSDK_F16>{}, std::false_type{}, all & ~edge);
       go(std::integral_constant<int, SSDK_F16>{}, std::true_type{}, edge);
     }
+    dbg_print();
     return 0;
   }
   if (d->dtype == SSDK_BF16) ok = d->stride == 1 ? flow_dispatch<SSDK_BF16, 1>(p, nch, nfo, grid, stream) : flow_dispatch<SSDK_BF16, 2>(p, nch, nfo, grid, stream);
   else ok = d->stride == 1 ? flow_dispatch<SSDK_F16, 1>(p, nch, nfo, grid, stream) : flow_dispatch<SSDK_F16, 2>(p, nch, nfo, grid, stream);
+  if (ok) dbg_print();
   return ok ? 0 : 1;
 }
 

@@ -447,6 +447,7 @@ int launch_mbsplit(const ssdk_mbconv_desc* d, hipStream_t stream) {
   p.Wo = (p.W + 2 - 3) / d->stride + 1;
   p.residual = d->residual;
   p.seg_mask = 0;
+  p.dbg = nullptr;
   const int ow = d->stride == 1 ? 14 : 7;
   p.strips = (p.Wo + ow - 1) / ow;
   const int groups = (p.strips + 1) / 2;
