@@ -69,6 +69,19 @@ template <int DT> __device__ __forceinline__ float fl_from16(u32 h) {
 __device__ __forceinline__ u32 fl_from_left(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }   // row_shr:1
 __device__ __forceinline__ u32 fl_from_right(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }  // row_shl:1
 
+// ReLU6 of N packed-fp16 words in place, as two passes of independent instructions.  Written with __builtin_elementwise_max /
+// min the compiler (a) canonicalises every input first (v_pk_max v, v, v: the values went through an asm pin, so it no longer
+// knows they are FMA results) and (b) emits the three dependent packed instructions of a word back to back, each pair separated
+// by the s_nop a dependent VOP3P pair needs: 5 issue slots per word, 180 per output row of the 144-channel block.  Here: 2.
+template <int N>
+__device__ __forceinline__ void fl_relu6_words(fl_h2* v) {
+  const u32 six = 0x46004600u;
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("v_pk_max_f16 %0, %0, 0" : "+v"(v[i]));
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(v[i]) : "v"(six));
+}
+
 // Stride 2, two strips per wave: only the ODD lanes 1..13 of a strip own an output pixel, so the taps of strip `a` stay in
 // the odd lanes and those of strip `b` move one lane to the left into the even lanes 0..12 -- one register set then holds
 // the 14 outputs of both strips and every packed FMA, the bias / ReLU6 pass, the projection MFMAs and the epilogue run once

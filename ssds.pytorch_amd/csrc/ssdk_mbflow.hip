@@ -253,7 +253,6 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
   const bool dbgw = p.dbg != nullptr && blockIdx.x == gridDim.x / 2 && __builtin_amdgcn_readfirstlane((int)wave) == 0;
   int dbg_k = 0;
   fl_h2 accA[NA][NCH * 2], accB[NA][NCH * 2], accC[NA][NCH * 2];
-  const fl_h2 zero2 = {(_Float16)0.f, (_Float16)0.f}, six2 = {(_Float16)6.f, (_Float16)6.f};
 
   // One input row.  FIN / MID / INI: the row is the last (ky = 2) / middle (ky = 1) / first (ky = 0) row of the output
   // row accumulated in fin / mid / ini; the FIN row is completed, projected and stored as output row `oy_fin`.
@@ -371,14 +370,7 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
     if constexpr (FIN) {
       if (store_row) {
         // ---- the output row is complete: bias + ReLU6 in place, then it IS the projection's B operand --------------
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {  // (the bias went in with the ky = 0 row)
-#pragma unroll
-          for (int s = 0; s < NA; ++s) {
-            fin[s][2 * c] = __builtin_elementwise_min(__builtin_elementwise_max(fin[s][2 * c], zero2), six2);
-            fin[s][2 * c + 1] = __builtin_elementwise_min(__builtin_elementwise_max(fin[s][2 * c + 1], zero2), six2);
-          }
-        }
+        fl_relu6_words<NA * NCH * 2>(&fin[0][0]);  // (the bias went in with the ky = 0 row)
         asm volatile("" ::: "memory");
         f32x4 yacc[NA][NFO];
 #pragma unroll
@@ -487,6 +479,13 @@ constexpr int kFlowNS = 2;  // strips per wave
 template <int DT, int S, int NCH, int NFO>
 static void flow_launch(const FlowParams& p, unsigned grid, hipStream_t stream) {
   constexpr int lds = FlowLds<NCH, NFO>::bytes;
+  if constexpr (S == 1 && NCH == 9) {
+    if (p.layout == 101) {  // one strip per wave (launch_mbflow sets the marker: half the accumulators, three waves per SIMD)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<DT, S, NCH, NFO, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL((mbflow_kernel<DT, S, NCH, NFO, 1>), dim3(grid), dim3(kFlowThreads), lds, stream, p);
+      return;
+    }
+  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<DT, S, NCH, NFO, kFlowNS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL((mbflow_kernel<DT, S, NCH, NFO, kFlowNS>), dim3(grid), dim3(kFlowThreads), lds, stream, p);
 }
@@ -572,7 +571,15 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
   p.strips = (p.Wo + ow - 1) / ow;
   // rows per segment: long segments amortise the two halo rows, short ones give the chip enough waves (>= ~3 per SIMD)
   static const int env_rs = getenv("SSDK_MB_FLOW_RS") ? atoi(getenv("SSDK_MB_FLOW_RS")) : 0;
-  const int groups = (p.strips + kFlowNS - 1) / kFlowNS;
+  // strips per wave: two share every weight read, but the 144-channel stride-1 block then holds 216 registers (3 x 2 x 18
+  // accumulators): two waves per SIMD.  With ONE strip it holds 132 -- three waves per SIMD -- and runs 125 -> 114 us (round 4,
+  // same box; forcing 128 registers for a fourth wave spills and gives the gain back: 121 us).  The stem block (NCH = 2) does not
+  // gain from one strip (137 -> 140 us).  SSDK_MB_FLOW_NS1: bit 0 the 144-channel block (default on), bit 1 the stem block.
+  static const int env_ns1 = getenv("SSDK_MB_FLOW_NS1") ? atoi(getenv("SSDK_MB_FLOW_NS1")) : 1;
+  const bool ns1 = ((env_ns1 & 1) && !stem && d->stride == 1 && nch == 9) || ((env_ns1 & 2) && stem);
+  const int flow_ns = ns1 ? 1 : kFlowNS;
+  if (ns1 && !stem) p.layout = 101;
+  const int groups = (p.strips + flow_ns - 1) / flow_ns;
   // (measured: ~5000 items of 16-32 rows beat ~2500 of 32-64 rows; below 16 rows the two halo rows of a segment cost
   //  too much, and a map that then yields fewer than 2048 items -- 64x64 at batch 64 -- stays with the LDS-tiled kernel)
   int rs = 64;
@@ -608,6 +615,12 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
       q.seg_mask = mask;
       const long it = (long)d->N * groups * __builtin_popcountll(mask);
       const unsigned g = (unsigned)((it + 3) / 4);
+      if (ns1) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<DTv, 1, 2, 1, 1, true, YEv>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((mbflow_kernel<DTv, 1, 2, 1, 1, true, YEv>), dim3(g), dim3(kFlowThreads), lds, stream, q);
+        return;
+      }
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<DTv, 1, 2, 1, kFlowNS, true, YEv>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       hipLaunchKernelGGL((mbflow_kernel<DTv, 1, 2, 1, kFlowNS, true, YEv>), dim3(g), dim3(kFlowThreads), lds, stream, q);

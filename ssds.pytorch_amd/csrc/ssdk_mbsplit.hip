@@ -156,7 +156,6 @@ __global__ __launch_bounds__(64 * NW, 2) void mbsplit_kernel(const FlowParams p)
   };
 
   fl_h2 accA[NA][NCHW * 2], accB[NA][NCHW * 2], accC[NA][NCHW * 2];
-  const fl_h2 zero2 = {(_Float16)0.f, (_Float16)0.f}, six2 = {(_Float16)6.f, (_Float16)6.f};
   int xrow = 0;  // output rows exchanged so far (exchange buffer parity)
   // TREG: a wave owns only NCHW chunks, so its depthwise taps and biases fit in registers for the whole item (NCHW * 24
   // registers) instead of being re-read from LDS for every row: 9 ds_read_b64 per chunk and row (which the compiler pairs
@@ -270,13 +269,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mbsplit_kernel(const FlowParams p)
     if constexpr (FIN) {
       if (store_row) {
         // ---- this wave's chunks of the output row: ReLU6, then they ARE the B operand of its projection k-steps --------
-#pragma unroll
-        for (int c = 0; c < NCHW; ++c)
-#pragma unroll
-          for (int a = 0; a < NA; ++a) {
-            fin[a][2 * c] = __builtin_elementwise_min(__builtin_elementwise_max(fin[a][2 * c], zero2), six2);
-            fin[a][2 * c + 1] = __builtin_elementwise_min(__builtin_elementwise_max(fin[a][2 * c + 1], zero2), six2);
-          }
+        fl_relu6_words<NA * NCHW * 2>(&fin[0][0]);
         asm volatile("" ::: "memory");
         f32x4 yacc[NA][NFO];
 #pragma unroll
