@@ -43,7 +43,13 @@ def configure_optimizer(trainable_param, cfg):
         params = [{"params": p, "lr": lr} for p, lr in zip(trainable_param, cfg.DIFFERENTIAL_LEARNING_RATE)]
     name = cfg.OPTIMIZER
     if name == "sgd":
-        return optim.SGD(params, lr=cfg.LEARNING_RATE, momentum=cfg.MOMENTUM, weight_decay=cfg.WEIGHT_DECAY)
+        # On a HIP device the update runs as ONE fused multi-tensor launch, and the fused kernels take a device-side
+        # ``found_inf`` flag: pipeline_anchor_ddp.train_step skips a step on NaN/Inf without reading the flag back
+        # (the reference syncs 4-6 times per step, pipeline_anchor_apex.py:114-126).
+        flat = params if not isinstance(params[0], dict) else [q for g in params for q in g["params"]]
+        fused = len(flat) > 0 and all(q.is_cuda and q.is_floating_point() for q in flat)
+        return optim.SGD(params, lr=cfg.LEARNING_RATE, momentum=cfg.MOMENTUM, weight_decay=cfg.WEIGHT_DECAY,
+                         **({"fused": True} if fused else {}))
     if name == "rmsprop":
         return optim.RMSprop(params, lr=cfg.LEARNING_RATE, momentum=cfg.MOMENTUM, alpha=cfg.MOMENTUM_2,
                              eps=cfg.EPS, weight_decay=cfg.WEIGHT_DECAY)

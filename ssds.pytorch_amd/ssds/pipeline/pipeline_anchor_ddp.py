@@ -82,9 +82,9 @@ class ModelWithLossBasic(torch.nn.Module):
 
 
 def train_step(model_with_loss, images, targets, anchors, optimizer, autocast_dtype=torch.bfloat16):
-    """One optimisation step.  Returns (cls_loss, loc_loss, skipped): the losses stay on the device, the only
-    host synchronisation is the collective skip flag (the reference syncs 4-6 times per step,
-    pipeline_anchor_apex.py:114-126)."""
+    """One optimisation step.  Returns (cls_loss, loc_loss, skipped): the losses stay on the device; with the fused
+    optimizer of a HIP device the skip decision does too (no host synchronisation; the reference syncs 4-6 times per step,
+    pipeline_anchor_apex.py:114-126), otherwise the collective skip flag is the one value read back."""
     dev = images.device
     optimizer.zero_grad(set_to_none=True)
     use_autocast = dev.type == "cuda" and autocast_dtype is not None
@@ -97,10 +97,65 @@ def train_step(model_with_loss, images, targets, anchors, optimizer, autocast_dt
     torch.nan_to_num(total, nan=0.0, posinf=0.0, neginf=0.0).backward()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)  # collective decision
-    skipped = bool(bad.item() > 0)  # the one host sync of the step (the reference has 4-6)
+    skipped = _step_unless(optimizer, bad)
+    return cls_loss.detach(), loc_loss.detach(), skipped
+
+
+def _device_skip(optimizer):
+    """True when every parameter group runs torch's fused multi-tensor kernels, which take the skip flag on the device."""
+    return len(optimizer.param_groups) > 0 and all(g.get("fused") for g in optimizer.param_groups)
+
+
+def _step_unless(optimizer, bad):
+    """optimizer.step() unless ``bad`` (a 0/1 float tensor) is set.  Fused optimizers (core/optimizer.py on a HIP device) read
+    the flag on the DEVICE (``found_inf``, the hook GradScaler uses): no host synchronisation in the step at all, and the step
+    can be captured in a hipGraph.  Anything else reads the flag back -- the one host sync of the step.  Returns the flag (a
+    tensor on the fused path: it is only converted where somebody prints it)."""
+    if _device_skip(optimizer):
+        optimizer.grad_scale = None
+        optimizer.found_inf = bad.reshape(1)
+        optimizer.step()
+        return bad
+    skipped = bool(bad.item() > 0)
     if not skipped:
         optimizer.step()
-    return cls_loss.detach(), loc_loss.detach(), skipped
+    return skipped
+
+
+class GraphedTrainStep(object):
+    """The whole training step (forward under autocast, fused target assignment + losses, backward, device-side skip,
+    fused optimizer update: ~600 launches) captured ONCE as a hipGraph and replayed with one launch per step
+    (reference loop pipeline_anchor_apex.py:103-130).  Single-process steps only (under DDP the bucketed all-reduce hooks
+    keep the eager path); needs the fused optimizer (no host read-back inside the step) and static shapes: ``images`` /
+    ``targets`` are copied into the captured input tensors."""
+
+    def __init__(self, model_with_loss, images, targets, anchors, optimizer, autocast_dtype=torch.bfloat16, warmup=3):
+        if not (images.is_cuda and _device_skip(optimizer)):
+            raise ValueError("GraphedTrainStep needs a HIP device and a fused optimizer")
+        self.optimizer = optimizer
+        self.images, self.targets = images.clone(), targets.clone()
+        side = torch.cuda.Stream(device=images.device)
+        side.wait_stream(torch.cuda.current_stream(images.device))
+        with torch.cuda.stream(side):  # eager warm-up on a side stream (allocator pools, MIOpen / rocBLAS plans, lazy state)
+            for _ in range(warmup):
+                train_step(model_with_loss, self.images, self.targets, anchors, optimizer, autocast_dtype)
+        torch.cuda.current_stream(images.device).wait_stream(side)
+        optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            with torch.autocast(device_type="cuda", dtype=autocast_dtype, enabled=autocast_dtype is not None):
+                cls_loss, loc_loss, _, _ = model_with_loss(self.images, self.targets, anchors)
+                total = cls_loss + loc_loss
+            self.bad = (~torch.isfinite(total.detach())).float()
+            torch.nan_to_num(total, nan=0.0, posinf=0.0, neginf=0.0).backward()
+            _step_unless(optimizer, self.bad)
+            self.cls_loss, self.loc_loss = cls_loss.detach(), loc_loss.detach()
+
+    def __call__(self, images, targets):
+        self.images.copy_(images, non_blocking=True)
+        self.targets.copy_(targets, non_blocking=True)
+        self.graph.replay()
+        return self.cls_loss, self.loc_loss, self.bad
 
 
 def train_anchor_based_epoch(model, data_loader, optimizer, anchors, epoch, device, local_rank, log_every=20):

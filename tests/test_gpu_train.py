@@ -56,6 +56,91 @@ def test_model_with_loss_matches_cpu_oracle_step():
     assert not skipped and torch.isfinite(after).all() and not torch.equal(before, after)
 
 
+def _tiny_step_setup(seed=0):
+    import torch
+    from ssds.core import criterion
+    from ssds.dataset.synthetic import SyntheticDetectionLoader
+    from ssds.modeling import nets, ssds
+    from ssds.modeling.layers import box
+    from ssds.pipeline.pipeline_anchor_ddp import ModelWithLossBasic
+
+    torch.manual_seed(seed)
+    o, e, h = ssds.SSD.add_extras([[5, 7, "Conv:S"], [96, 320, 64]], [2, 2, 2], 5)
+    model = ssds.SSD(nets.MobileNetV2(outputs=o), e, h, 5)
+    mwl = ModelWithLossBasic(model, criterion.FocalLoss(), criterion.SmoothL1Loss(), 5, [0.5, 0.4], 0).cuda()
+    anchors = OrderedDict((s, box.generate_anchors(s, [1], [2.0, 2.828])) for s in (16, 32, 64))
+    loader = SyntheticDetectionLoader(4, (128, 128), 5, steps=1, device=torch.device("cuda"), max_gt=6)
+    images, targets = loader.batch()
+    targets[..., 2:4] = targets[..., 2:4].clamp(min=24)
+    targets[targets[..., 4] < 0] = -1
+    return mwl.train(), images, targets, anchors
+
+
+def test_step_is_skipped_on_the_device_with_the_fused_optimizer():
+    """train_step with the fused SGD core/optimizer.py builds on a HIP device: a non-finite loss leaves parameters AND
+    momentum untouched without the flag ever being read back (``found_inf``), a finite one steps; same update as the plain
+    optimizer (reference skip: pipeline_anchor_apex.py:110-111, 126-127)."""
+    import copy
+    import torch
+    from ssds.pipeline.pipeline_anchor_ddp import _device_skip, train_step
+
+    mwl, images, targets, anchors = _tiny_step_setup()
+    ref = copy.deepcopy(mwl)
+    opt = torch.optim.SGD(mwl.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True)
+    opt_ref = torch.optim.SGD(ref.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    assert _device_skip(opt) and not _device_skip(opt_ref)
+    flat = lambda m: torch.cat([p.detach().flatten() for p in m.parameters()])  # noqa: E731
+    for _ in range(2):
+        c, l, skipped = train_step(mwl, images, targets, anchors, opt, autocast_dtype=None)
+        c2, l2, skipped2 = train_step(ref, images, targets, anchors, opt_ref, autocast_dtype=None)
+        assert isinstance(skipped, torch.Tensor) and float(skipped) == 0 and not skipped2
+        torch.testing.assert_close(c, c2, rtol=1e-5, atol=1e-6)
+    # (two runs of the backward pass are not bit-identical -- library weight gradients accumulate with atomics -- so the twin
+    #  is compared on average: same update rule, same learning rate, momentum and weight decay)
+    assert float((flat(mwl) - flat(ref)).abs().mean()) < 2e-5
+    before = flat(mwl).clone()
+    mom = [opt.state[p]["momentum_buffer"].clone() for p in mwl.parameters() if p in opt.state and "momentum_buffer" in opt.state[p]]
+    bad_images = images.clone()
+    bad_images[0, 0, 0, 0] = float("nan")
+    c, l, skipped = train_step(mwl, bad_images, targets, anchors, opt, autocast_dtype=None)
+    assert float(skipped) == 1.0
+    assert torch.equal(before, flat(mwl)), "a skipped step must not touch the parameters"
+    mom2 = [opt.state[p]["momentum_buffer"] for p in mwl.parameters() if p in opt.state and "momentum_buffer" in opt.state[p]]
+    assert all(torch.equal(a, b) for a, b in zip(mom, mom2)), "... nor the momentum"
+
+
+def test_graphed_train_step_equals_the_eager_step():
+    """GraphedTrainStep: forward, fused losses, backward, device-side skip and fused update captured once as a hipGraph.
+    Each replay is checked against the eager step of a TWIN taken right before it (same parameters, same momentum: one step
+    apart two copies do not drift), and a NaN image must leave the parameters untouched inside the captured step too."""
+    import copy
+    import torch
+    from ssds.pipeline.pipeline_anchor_ddp import GraphedTrainStep, train_step
+
+    mwl, images, targets, anchors = _tiny_step_setup(3)
+    opt = torch.optim.SGD(mwl.parameters(), lr=0.01, momentum=0.9, fused=True)
+    graphed = GraphedTrainStep(mwl, images, targets, anchors, opt, warmup=2)
+    flat = lambda m: torch.cat([p.detach().flatten() for p in m.parameters()])  # noqa: E731
+    for _ in range(3):
+        twin = copy.deepcopy(mwl)
+        opt_twin = torch.optim.SGD(twin.parameters(), lr=0.01, momentum=0.9, fused=True)
+        opt_twin.load_state_dict(copy.deepcopy(opt.state_dict()))
+        before = flat(mwl).clone()
+        c, l, bad = graphed(images, targets)
+        c2, l2, bad2 = train_step(twin, images, targets, anchors, opt_twin)
+        assert float(bad) == 0 and float(bad2) == 0
+        torch.testing.assert_close(c.float(), c2.float(), rtol=2e-3, atol=1e-5)
+        torch.testing.assert_close(l.float(), l2.float(), rtol=2e-3, atol=1e-5)
+        assert not torch.equal(before, flat(mwl))
+        step, step2 = flat(mwl) - before, flat(twin) - before
+        assert float((step - step2).abs().mean()) <= 0.05 * float(step2.abs().mean()) + 1e-8
+    before = flat(mwl).clone()
+    bad_images = images.clone()
+    bad_images[0, 0, 0, 0] = float("nan")
+    c, l, bad = graphed(bad_images, targets)
+    assert float(bad) == 1.0 and torch.equal(before, flat(mwl))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype_name,tol", [("float32", 1e-4), ("bfloat16", 2e-2), ("float16", 4e-3)])
 @pytest.mark.parametrize("c,stride,h,w,n", [(32, 1, 20, 24, 3), (96, 2, 33, 31, 2), (144, 2, 64, 70, 2), (8, 1, 5, 130, 1),

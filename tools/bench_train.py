@@ -27,6 +27,7 @@ ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--channels-last", type=int, default=0)
 ap.add_argument("--gpus", type=int, default=1)
+ap.add_argument("--graph", type=int, default=0, help="1: the whole step as one captured hipGraph (single GPU)")
 ap.add_argument("--size", type=int, default=0, help="square input size instead of the config's (300: planes that are not a multiple of 8)")
 ap.add_argument("--cpu", type=int, default=0,
                 help="(tests/test_ddp_cpu.py) 1: ONLY the launcher / rank / barrier / MAX-time / rank-0-print logic of this "
@@ -96,6 +97,14 @@ def sync():
         torch.cuda.synchronize()
 
 
+if args.graph and not args.cpu and world == 1:
+    from ssds.pipeline.pipeline_anchor_ddp import GraphedTrainStep
+
+    _graphed = GraphedTrainStep(mwl, images, targets, anchors, solver.optimizer)
+
+    def train_step(_m, im, tg, _a, _o):  # noqa: F811 -- one hipGraphLaunch per step
+        return _graphed(im, tg)
+
 for _ in range(args.warmup):
     train_step(mwl, images, targets, anchors, solver.optimizer)
 sync()
@@ -111,7 +120,7 @@ if world > 1:
 if rank == 0:
     print(json.dumps({"metric": "images/sec (DDP training step) SSD-MobileNetV2@%d" % cfg.MODEL.IMAGE_SIZE[0], "value": round(world * args.batch * args.steps / el, 1),
                       "n_gpus": world, "ms_per_step": round(el / args.steps * 1e3, 2), "batch_per_gpu": args.batch,
-                      "cls_loss": float(c), "loc_loss": float(l), "dtype": "bf16 autocast",
+                      "cls_loss": float(c), "loc_loss": float(l), "dtype": "bf16 autocast", "hipgraph": bool(args.graph),
                       "data": "synthetic" if not args.cpu else "stub (CPU / gloo run of the rank logic)"}))
 if world > 1:
     dist.destroy_process_group()
