@@ -181,6 +181,7 @@ int halo_splitk_plan(int N, int Cin, int Ho, int Wo, int Cout, bool nchw, size_t
 // halo-tile 3x3 kernel (ssdk_conv3x3.hip); returns SSDK_OK, or 1 when the layer does not fit it
 int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool allow_underfill);
 int launch_conv3x3_short(const ConvParams& p, int dtype, hipStream_t stream);
+int launch_conv_pwflow(const ConvParams& p, int dtype, hipStream_t stream);  // ssdk_pwflow.hip: 1x1, Cin <= 256, streaming
 constexpr int kSmallmapGroupMax = 4;
 int launch_conv_smallmap_group(const ConvParams* ps, int n, int dtype, hipStream_t stream);  // ssdk_smallmap.hip  // ssdk_conv3x3s.hip: Cin <= 128, needs p.w_frag
 

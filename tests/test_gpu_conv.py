@@ -603,6 +603,62 @@ def test_fused_inverted_residual_block(cin, cout, stride, h, w, variant):
     _check(got, y, dtype, "mbconv %d->%d s%d (%s)" % (cin, cout, stride, name), floor=1.0)
 
 
+PW = [  # cin, cout, stride, h, w, n, act, residual mode (None | "same" | "half" | "post")
+    (64, 256, 1, 64, 64, 4, "relu", None),       # ResNet-50 layer1 expansion: 16 fragments per wave, two k-steps
+    (64, 256, 1, 72, 57, 4, "none", "post"),     # block tail: relu(bn(conv) + identity); ragged last pixel group
+    (128, 512, 1, 40, 52, 8, "none", "post"),    # layer2 expansion: two slices of 256 channels, four k-steps
+    (128, 64, 1, 128, 128, 1, "relu", None),     # a reduction: one slice of four fragments
+    (128, 256, 2, 160, 160, 3, "none", None),    # stride 2: every second pixel of every second row
+    (96, 192, 1, 128, 128, 1, "relu6", "same"),  # Cin not a multiple of 64 (three of four k-steps used), plain residual
+    (128, 256, 1, 80, 96, 3, "none", "half"),    # lateral + nearest x2 top-down add
+    (64, 64, 1, 160, 160, 1, "silu", None),
+]
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,stride,h,w,n,act,rmode", PW)
+def test_pointwise_streaming_kernel(cin, cout, stride, h, w, n, act, rmode, dtype_name):
+    """ssdk_pwflow.hip: 1x1 convolutions with Cin <= 256 on large maps (B operand straight from global memory, weights
+    resident in LDS, 8 consecutive channels per lane through a row permutation of the weights) against the fp32 layer,
+    every residual mode of ssdk_conv and both strides."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    torch.manual_seed(cin + cout + h + stride)
+    conv = nn.Conv2d(cin, cout, 1, stride, 0, bias=False).cuda()
+    bn = nn.BatchNorm2d(cout).cuda()
+    bn.running_mean.normal_(0, 0.2)
+    bn.running_var.uniform_(0.5, 1.5)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_(0, 0.2)
+    conv.weight.data = conv.weight.data.to(dtype).float()
+    x = torch.randn(n, cin, h, w).to(dtype)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    pack = FC.ConvPack(conv, bn, act, dtype)
+    if rmode is None:
+        want = _ref(x, conv, bn, act)
+        y = FC.conv_native(x.cuda(), pack)
+    elif rmode == "post":
+        res = torch.randn(n, cout, ho, wo).to(dtype)
+        lin = _ref(x, conv, bn, "none").to(dtype).float() + res.float()
+        want = lin.clamp(min=0)
+        y = FC.conv_native(x.cuda(), FC.ConvPack(conv, bn, "relu", dtype), residual=res.cuda(), res_mode=2)
+    elif rmode == "same":
+        res = torch.randn(n, cout, ho, wo).to(dtype)
+        want = _ref(x, conv, bn, act, residual=res)
+        y = FC.conv_native(x.cuda(), pack, residual=res.cuda())
+    else:
+        res = torch.randn(n, cout, ho // 2, wo // 2).to(dtype)
+        want = _ref(x, conv, bn, act).to(dtype).float() + F.interpolate(res.float(), scale_factor=2, mode="nearest")
+        y = FC.conv_native(x.cuda(), pack, residual=res.cuda(), res_mode=1)
+    assert N.last_kernel() == "pwflow_kernel", N.last_kernel()
+    _check(y, want, dtype, "pwflow %d->%d s%d %s" % (cin, cout, stride, rmode), floor=1.0 if rmode else 0.125)
+
+
 @pytest.mark.parametrize("variant", ["tiled", "flow"])
 @pytest.mark.parametrize("layout", ["nchw", "nhwc"])
 @pytest.mark.parametrize("h,w", [(64, 64), (37, 45), (130, 121)])
