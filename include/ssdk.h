@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 200 /* 0.2.0: contexts, fused decode tail */
+#define SSDK_VERSION 210 /* 0.2.1: ssdk_match_multibox_loss; descriptors gained fields (zero = old behaviour, see ssdk_op_desc) */
 
 #define SSDK_MAX_LEVELS 8    /* feature-map levels per decode_nms call            */
 #define SSDK_MAX_ANCHORS 16  /* anchors per location (A)                          */
@@ -211,6 +211,19 @@ int ssdk_match_loss(const float* targets, int B, int G, const float* anchors, in
                     int stride, int by_scale, float thr_a, float thr_b, float radius, const void* conf,
                     const void* loc, int dtype, float alpha, float gamma, float beta, int loc_loss,
                     void* d_conf, void* d_loc, float* sums, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same per-level body with MultiBoxLoss as the class criterion (core/criterion.py:43-71; cfg MATCHER.NEGPOS_RATIO):
+ * sigmoid cross entropy on the positives plus the hardest negpos_ratio x #positives negatives (depth == 0) of each image
+ * of THIS level, hardness = an anchor's largest per-class term (:59-61), count clamped to A*H*W - 1 (:67).  Three launches
+ * instead of the reference's two full sorts per level: match + positives' terms + hardness keys, a per-image radix select
+ * of the num_neg-th largest key (ties between EQUAL keys are kept in index order; torch's unstable sort leaves that
+ * choice unspecified), the mined negatives' terms and gradients; then the fixed-order reduction.  sums / d_conf / d_loc /
+ * loc_loss / by_scale / thr_* / radius exactly as ssdk_match_loss; sums[0] = sum over positives and mined negatives. */
+size_t ssdk_match_multibox_loss_workspace_bytes(int B, int A, int H, int W);
+int ssdk_match_multibox_loss(const float* targets, int B, int G, const float* anchors, int A, int C, int H, int W,
+                             int stride, int by_scale, float thr_a, float thr_b, float radius, const void* conf,
+                             const void* loc, int dtype, float negpos_ratio, float beta, int loc_loss, void* d_conf,
+                             void* d_loc, float* sums, void* workspace, size_t workspace_bytes, void* stream);
 
 /* VOC-style mAP bookkeeping of the eval epoch: MeanAveragePrecision.__call__
  * (core/evaluation_metrics.py:15-61, called per batch at pipeline/pipeline_anchor_basic.py:161-176) for one batch

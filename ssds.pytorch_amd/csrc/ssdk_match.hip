@@ -34,6 +34,8 @@ struct MatchParams {
   float* partial;    // [gridDim.y * gridDim.x, 3]: cls sum, loc sum, #foreground
   float alpha, gamma, beta;
   int loc_loss;  // 0: smooth-L1(beta); 1..4: IoU / GIoU / DIoU / CIoU on the deltas (criterion.py:154-239)
+  // MultiBoxLoss mode (LOSS = 2): hardness keys of the negatives, [B, A*H*W] words
+  u32* keys;
 };
 
 struct GtRow {
@@ -145,6 +147,9 @@ __device__ __forceinline__ D4 iou_family_loss(const float (&pd)[4], const float 
 // LOSS = 0: write the three target tensors.  LOSS = 1: never materialise them -- evaluate the focal and smooth-L1
 // terms of this anchor against the logits (criterion.py:74-151, masks of pipeline_anchor_apex.py:55-66), write the
 // closed-form gradients and reduce (cls sum, loc sum, #foreground) per workgroup in a fixed order.
+// LOSS = 2: the class term is MultiBoxLoss (criterion.py:43-71): sigmoid cross entropy; the positives' terms and gradients
+// are final here, every other gradient is written as zero and each negative (depth == 0) leaves its hardness
+// (max over classes of its terms, :59-61) as an ordered key for mine_select_kernel / mine_apply_kernel.
 template <int LOSS, int DT>
 __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams p) {
   __shared__ GtRow gt[SSDK_MAX_GT];
@@ -298,6 +303,23 @@ __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams 
     // focal loss on logits (criterion.py:74-108), masked by depth >= 0 (pipeline_anchor_apex.py:55-58):
     //   t=1: L = -alpha (1-p)^g log p        dL/dz = alpha (1-p)^g (g p log p - (1-p))
     //   t=0: L = -(1-alpha) p^g log(1-p)     dL/dz = (1-alpha) p^g (p - g (1-p) log(1-p))
+    if constexpr (LOSS == 2) {
+      const bool pos = dep > 0.f;
+      float hard = 0.f;
+      for (int c = 0; c < p.C; ++c) {
+        const size_t i = cls_i + (size_t)c * HW;
+        const float z = ld_elem<DT>(p.conf, i);
+        const float e = expf(-fabsf(z));
+        const float inv = 1.0f / (1.0f + e);
+        const float pr = z >= 0.f ? inv : e * inv;                                  // sigmoid(z)
+        const float ce = tmax(z, 0.f) - (c == lab ? z : 0.f) + log1pf(e);           // BCE with logits, criterion.py:56
+        hard = tmax(hard, ce);
+        s_cls += pos ? ce : 0.f;
+        st_elem<DT>(p.d_conf, i, pos ? pr - (c == lab ? 1.0f : 0.f) : 0.f);
+      }
+      // ce >= 0, so the float bits order like the values; +1 keeps 0 for "never ranks" (positives, ignored: :61)
+      p.keys[(size_t)b * total + t] = dep == 0.f ? __float_as_uint(hard) + 1u : 0u;
+    } else {
     const bool care = dep >= 0.f;
     const bool g2 = p.gamma == 2.0f;
     for (int c = 0; c < p.C; ++c) {
@@ -321,6 +343,7 @@ __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams 
       grad = pos ? grad : -grad;
       s_cls += care ? loss : 0.f;
       st_elem<DT>(p.d_conf, i, care ? grad : 0.f);
+    }
     }
     // localisation loss masked by depth > 0 (pipeline_anchor_apex.py:62-66)
     const bool fg = dep > 0.f;
@@ -356,7 +379,7 @@ __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams 
   }
   }  // t < total
 
-  if constexpr (LOSS == 1) {  // fixed-order workgroup reduction -> one partial row per workgroup
+  if constexpr (LOSS != 0) {  // fixed-order workgroup reduction -> one partial row per workgroup
     __shared__ float red[kMatchThreads / 64][3];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -399,6 +422,141 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* partial
   }
   __syncthreads();
   if (tid < 3) sums[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+
+// ---- MultiBoxLoss hard-negative mining (criterion.py:58-71) -----------------------------------------------------------
+// The reference sorts the hardness of all A*H*W anchors of an image twice (sort, then sort of the permutation) to get every
+// anchor's rank and keeps rank < num_neg = min(negpos_ratio * #positives, A*H*W - 1).  Only the num_neg-th largest key is
+// needed: one workgroup per image finds it with a 4 x 8-bit radix select over the keys match_kernel<2> left behind, then
+// turns the keys into 0/1 flags in place (key > T, or key == T for the first `need` ties in index order; torch's sort is
+// not stable, so which of several EQUAL negatives it keeps is unspecified there too).
+constexpr int kMineThreads = 1024;
+
+__global__ __launch_bounds__(kMineThreads) void mine_select_kernel(u32* keys, int N, const float* partial, int rows_per_image,
+                                                                   float negpos_ratio) {
+  __shared__ u32 hist[256];
+  __shared__ float s_red[kMineThreads / 64];
+  __shared__ u32 s_wave[kMineThreads / 64];
+  __shared__ u32 s_pick[2];
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u32 b = blockIdx.x;
+  u32* key = keys + (size_t)b * N;
+
+  // #positives of this image = the foreground column of its partial rows (exact: counts stay far below 2^24)
+  float np = 0.f;
+  for (int r = (int)tid; r < rows_per_image; r += kMineThreads) np += partial[((size_t)b * rows_per_image + r) * 3 + 2];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) np += __shfl_xor(np, o);
+  if (lane == 0) s_red[wave] = np;
+  __syncthreads();
+  np = 0.f;
+#pragma unroll
+  for (int w = 0; w < kMineThreads / 64; ++w) np += s_red[w];
+  // ranks r = 0, 1, ... with r < min(ratio * #pos, N - 1)   (:66-68; the ratio may be fractional)
+  const float lim = tmin(negpos_ratio * np, (float)(N - 1));
+  u32 remaining = lim > 0.f ? (u32)ceilf(lim) : 0u;
+
+  u32 prefix = 0, mask = 0;
+  if (remaining != 0) {
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      for (int i = (int)tid; i < N; i += kMineThreads) {
+        const u32 k = key[i];
+        if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (wave == 0) {  // bins 255 .. 0 in four rounds of 64: the first bin where the running count reaches `remaining`
+        u32 above = 0;
+        bool done = false;
+        for (int round = 0; round < 4 && !done; ++round) {
+          const u32 bin = 255u - (u32)(round * 64) - lane;
+          const u32 c = hist[bin];
+          u32 inc = c;  // inclusive prefix over lanes (descending bins)
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const u32 v = __shfl_up(inc, o);
+            if ((int)lane >= o) inc += v;
+          }
+          const u64 hit = __ballot(above + inc >= remaining);
+          if (hit != 0) {
+            const u32 first = (u32)__ffsll((long long)hit) - 1u;
+            if (lane == first) {
+              s_pick[0] = bin;
+              s_pick[1] = remaining - (above + inc - c);
+            }
+            done = true;
+          }
+          above += __shfl(inc, 63);
+        }
+      }
+      __syncthreads();
+      prefix |= s_pick[0] << shift;
+      mask |= 255u << shift;
+      remaining = s_pick[1];
+      __syncthreads();
+    }
+  }
+  const u32 T = prefix, need = remaining;  // remaining == 0 with prefix == 0: nothing is mined
+
+  u32 running = 0;
+  for (int base = 0; base < N; base += kMineThreads) {
+    const int i = base + (int)tid;
+    const u32 k = i < N ? key[i] : 0u;
+    const bool live = k != 0u && (remaining != 0 || prefix != 0);
+    const bool tie = live && k == T;
+    const u64 m = __ballot(tie);
+    if (lane == 0) s_wave[wave] = (u32)__popcll(m);
+    __syncthreads();
+    u32 before = running, all = 0;
+#pragma unroll
+    for (int w = 0; w < kMineThreads / 64; ++w) {
+      const u32 c = s_wave[w];
+      before += w < (int)wave ? c : 0u;
+      all += c;
+    }
+    const u32 rank = before + mbcnt(m);
+    if (i < N) key[i] = (live && (k > T || (tie && rank < need))) ? 1u : 0u;
+    running += all;
+    __syncthreads();
+  }
+}
+
+// the mined negatives' terms: all-zero target (depth == 0 means background), so L = softplus(z), dL/dz = sigmoid(z)
+template <int DT>
+__global__ __launch_bounds__(kMatchThreads) void mine_apply_kernel(const MatchParams p, float* partial) {
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u32 b = blockIdx.y;
+  const u32 HW = (u32)(p.H * p.W);
+  const u32 total = (u32)p.A * HW;
+  const u32 t = blockIdx.x * kMatchThreads + tid;
+  float s_cls = 0.f;
+  if (t < total && p.keys[(size_t)b * total + t] != 0u) {
+    const u32 a = t / HW, yx = t % HW;
+    const size_t cls_i = (((size_t)b * p.A + a) * p.C) * HW + yx;
+    for (int c = 0; c < p.C; ++c) {
+      const size_t i = cls_i + (size_t)c * HW;
+      const float z = ld_elem<DT>(p.conf, i);
+      const float e = expf(-fabsf(z));
+      const float inv = 1.0f / (1.0f + e);
+      s_cls += tmax(z, 0.f) + log1pf(e);
+      st_elem<DT>(p.d_conf, i, z >= 0.f ? inv : e * inv);
+    }
+  }
+  __shared__ float red[kMatchThreads / 64];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s_cls += __shfl_xor(s_cls, o);
+  if (lane == 0) red[wave] = s_cls;
+  __syncthreads();
+  if (tid < 3) {
+    float acc = 0.f;
+    if (tid == 0) {
+#pragma unroll
+      for (int w = 0; w < kMatchThreads / 64; ++w) acc += red[w];
+    }
+    partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + tid] = acc;
+  }
 }
 
 }  // namespace ssdk
@@ -461,34 +619,39 @@ extern "C" int ssdk_match_targets_by_scale(const float* targets, int B, int G, c
 }
 
 // ---- fused target assignment + losses -----------------------------------------------------------
-extern "C" size_t ssdk_match_loss_workspace_bytes(int B, int A, int H, int W) {
-  if (B < 1 || A < 1 || H < 1 || W < 1) return 0;
-  const size_t wgs = ((size_t)A * H * W + ssdk::kMatchThreads - 1) / ssdk::kMatchThreads;
-  return wgs * (size_t)B * 3 * sizeof(float);
+namespace ssdk {
+static size_t match_rows(int B, int A, int H, int W) {
+  return (((size_t)A * H * W + kMatchThreads - 1) / kMatchThreads) * (size_t)B;
 }
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-extern "C" int ssdk_match_loss(const float* targets, int B, int G, const float* anchors, int A, int C, int H,
-                               int W, int stride, int by_scale, float thr_a, float thr_b, float radius,
-                               const void* conf, const void* loc, int dtype, float alpha, float gamma,
-                               float beta, int loc_loss, void* d_conf, void* d_loc, float* sums, void* workspace,
-                               size_t workspace_bytes, void* stream) {
-  using namespace ssdk;
+// cls_kind 0: FocalLoss(alpha, gamma); 1: MultiBoxLoss(negpos_ratio = alpha)
+static int run_match_loss(const char* what, int cls_kind, const float* targets, int B, int G, const float* anchors, int A,
+                          int C, int H, int W, int stride, int by_scale, float thr_a, float thr_b, float radius,
+                          const void* conf, const void* loc, int dtype, float alpha, float gamma, float beta, int loc_loss,
+                          void* d_conf, void* d_loc, float* sums, void* workspace, size_t workspace_bytes, void* stream) {
   if (!targets || !anchors || !conf || !loc || !d_conf || !d_loc || !sums || !workspace) {
-    set_error("match_loss: null pointer");
+    set_error("%s: null pointer", what);
     return SSDK_E_BADARG;
   }
   if (B < 1 || G < 0 || G > SSDK_MAX_GT || A < 1 || A > SSDK_MAX_ANCHORS || C < 1 || H < 1 || W < 1 ||
       stride < 1 || loc_loss < 0 || loc_loss > 4 || (loc_loss == 0 && !(beta > 0.f))) {
-    set_error("match_loss: bad dims B=%d G=%d (<=%d) A=%d (<=%d) C=%d H=%d W=%d stride=%d beta=%g loc_loss=%d", B, G,
+    set_error("%s: bad dims B=%d G=%d (<=%d) A=%d (<=%d) C=%d H=%d W=%d stride=%d beta=%g loc_loss=%d", what, B, G,
               SSDK_MAX_GT, A, SSDK_MAX_ANCHORS, C, H, W, stride, (double)beta, loc_loss);
     return SSDK_E_BADARG;
   }
-  if (dtype != SSDK_F32 && dtype != SSDK_BF16 && dtype != SSDK_F16) {
-    set_error("match_loss: dtype %d not supported", dtype);
+  if (cls_kind == 1 && !(alpha >= 0.f)) {
+    set_error("%s: negpos_ratio %g", what, (double)alpha);
     return SSDK_E_BADARG;
   }
-  if (workspace_bytes < ssdk_match_loss_workspace_bytes(B, A, H, W)) {
-    set_error("match_loss: workspace too small");
+  if (dtype != SSDK_F32 && dtype != SSDK_BF16 && dtype != SSDK_F16) {
+    set_error("%s: dtype %d not supported", what, dtype);
+    return SSDK_E_BADARG;
+  }
+  const size_t need = cls_kind == 1 ? ssdk_match_multibox_loss_workspace_bytes(B, A, H, W)
+                                    : ssdk_match_loss_workspace_bytes(B, A, H, W);
+  if (workspace_bytes < need) {
+    set_error("%s: workspace too small (%zu < %zu)", what, workspace_bytes, need);
     return SSDK_E_BADARG;
   }
   MatchParams p;
@@ -523,13 +686,66 @@ extern "C" int ssdk_match_loss(const float* targets, int B, int G, const float* 
   p.loc_loss = loc_loss;
   const unsigned total = (unsigned)A * H * W;
   dim3 grid((total + kMatchThreads - 1) / kMatchThreads, (unsigned)B);
+  const size_t rows = (size_t)grid.x * grid.y;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == SSDK_BF16) hipLaunchKernelGGL((match_kernel<1, SSDK_BF16>), grid, dim3(kMatchThreads), 0, st, p);
-  else if (dtype == SSDK_F16) hipLaunchKernelGGL((match_kernel<1, SSDK_F16>), grid, dim3(kMatchThreads), 0, st, p);
-  else hipLaunchKernelGGL((match_kernel<1, SSDK_F32>), grid, dim3(kMatchThreads), 0, st, p);
-  int rc = check_launch("match_loss_kernel");
+  if (cls_kind == 0) {
+    if (dtype == SSDK_BF16) hipLaunchKernelGGL((match_kernel<1, SSDK_BF16>), grid, dim3(kMatchThreads), 0, st, p);
+    else if (dtype == SSDK_F16) hipLaunchKernelGGL((match_kernel<1, SSDK_F16>), grid, dim3(kMatchThreads), 0, st, p);
+    else hipLaunchKernelGGL((match_kernel<1, SSDK_F32>), grid, dim3(kMatchThreads), 0, st, p);
+    int rc = check_launch("match_loss_kernel");
+    if (rc != SSDK_OK) return rc;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)p.partial, (int)rows, sums);
+    return check_launch("loss_finalize_kernel");
+  }
+  // MultiBoxLoss: rows [0, rows) of the partial table come from the match pass (positives, loc, #fg), rows [rows, 2 rows)
+  // from the mined negatives; the keys follow
+  float* partial2 = p.partial + rows * 3;
+  p.keys = (u32*)((char*)workspace + align256(2 * rows * 3 * sizeof(float)));
+  if (dtype == SSDK_BF16) hipLaunchKernelGGL((match_kernel<2, SSDK_BF16>), grid, dim3(kMatchThreads), 0, st, p);
+  else if (dtype == SSDK_F16) hipLaunchKernelGGL((match_kernel<2, SSDK_F16>), grid, dim3(kMatchThreads), 0, st, p);
+  else hipLaunchKernelGGL((match_kernel<2, SSDK_F32>), grid, dim3(kMatchThreads), 0, st, p);
+  int rc = check_launch("match_multibox_kernel");
   if (rc != SSDK_OK) return rc;
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)p.partial,
-                     (int)(grid.x * grid.y), sums);
+  hipLaunchKernelGGL(mine_select_kernel, dim3((unsigned)B), dim3(kMineThreads), 0, st, p.keys, (int)total,
+                     (const float*)p.partial, (int)grid.x, alpha);
+  rc = check_launch("mine_select_kernel");
+  if (rc != SSDK_OK) return rc;
+  if (dtype == SSDK_BF16) hipLaunchKernelGGL((mine_apply_kernel<SSDK_BF16>), grid, dim3(kMatchThreads), 0, st, p, partial2);
+  else if (dtype == SSDK_F16) hipLaunchKernelGGL((mine_apply_kernel<SSDK_F16>), grid, dim3(kMatchThreads), 0, st, p, partial2);
+  else hipLaunchKernelGGL((mine_apply_kernel<SSDK_F32>), grid, dim3(kMatchThreads), 0, st, p, partial2);
+  rc = check_launch("mine_apply_kernel");
+  if (rc != SSDK_OK) return rc;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)p.partial, (int)(2 * rows), sums);
   return check_launch("loss_finalize_kernel");
+}
+}  // namespace ssdk
+
+extern "C" size_t ssdk_match_loss_workspace_bytes(int B, int A, int H, int W) {
+  if (B < 1 || A < 1 || H < 1 || W < 1) return 0;
+  return ssdk::match_rows(B, A, H, W) * 3 * sizeof(float);
+}
+
+extern "C" size_t ssdk_match_multibox_loss_workspace_bytes(int B, int A, int H, int W) {
+  if (B < 1 || A < 1 || H < 1 || W < 1) return 0;
+  return ssdk::align256(2 * ssdk::match_rows(B, A, H, W) * 3 * sizeof(float)) + (size_t)B * A * H * W * sizeof(unsigned);
+}
+
+extern "C" int ssdk_match_loss(const float* targets, int B, int G, const float* anchors, int A, int C, int H,
+                               int W, int stride, int by_scale, float thr_a, float thr_b, float radius,
+                               const void* conf, const void* loc, int dtype, float alpha, float gamma,
+                               float beta, int loc_loss, void* d_conf, void* d_loc, float* sums, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  return ssdk::run_match_loss("match_loss", 0, targets, B, G, anchors, A, C, H, W, stride, by_scale, thr_a, thr_b, radius,
+                              conf, loc, dtype, alpha, gamma, beta, loc_loss, d_conf, d_loc, sums, workspace,
+                              workspace_bytes, stream);
+}
+
+extern "C" int ssdk_match_multibox_loss(const float* targets, int B, int G, const float* anchors, int A, int C, int H,
+                                        int W, int stride, int by_scale, float thr_a, float thr_b, float radius,
+                                        const void* conf, const void* loc, int dtype, float negpos_ratio, float beta,
+                                        int loc_loss, void* d_conf, void* d_loc, float* sums, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  return ssdk::run_match_loss("match_multibox_loss", 1, targets, B, G, anchors, A, C, H, W, stride, by_scale, thr_a, thr_b,
+                              radius, conf, loc, dtype, negpos_ratio, 0.f, beta, loc_loss, d_conf, d_loc, sums, workspace,
+                              workspace_bytes, stream);
 }

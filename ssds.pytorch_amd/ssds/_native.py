@@ -156,6 +156,11 @@ def _load():
     lib.ssdk_match_loss.restype = i32
     lib.ssdk_match_loss.argtypes = [vp, i32, i32, c.POINTER(f32), i32, i32, i32, i32, i32, i32, f32, f32, f32,
                                     vp, vp, i32, f32, f32, f32, i32, vp, vp, vp, vp, sz, vp]
+    lib.ssdk_match_multibox_loss_workspace_bytes.restype = sz
+    lib.ssdk_match_multibox_loss_workspace_bytes.argtypes = [i32] * 4
+    lib.ssdk_match_multibox_loss.restype = i32
+    lib.ssdk_match_multibox_loss.argtypes = [vp, i32, i32, c.POINTER(f32), i32, i32, i32, i32, i32, i32, f32, f32, f32,
+                                             vp, vp, i32, f32, f32, i32, vp, vp, vp, vp, sz, vp]
     lib.ssdk_debug_lds_probe.restype = i32
     lib.ssdk_debug_lds_probe.argtypes = [vp, vp]
     lib.ssdk_set_decode_tail_stream.restype = i32
@@ -207,6 +212,7 @@ EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_p
            "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
            "ssdk_match_targets_by_scale", "ssdk_match_loss_workspace_bytes", "ssdk_match_loss",
+           "ssdk_match_multibox_loss_workspace_bytes", "ssdk_match_multibox_loss",
            "ssdk_map_match", "ssdk_map_average_precision", "ssdk_set_decode_tail_stream", "ssdk_debug_lds_probe",
            "ssdk_ctx_create", "ssdk_ctx_destroy", "ssdk_ctx_set_tail_stream", "ssdk_ctx_set_side_lane", "ssdk_ctx_set_profiling",
            "ssdk_ctx_get_timings", "ssdk_ctx_set_op_profiling", "ssdk_ctx_get_op_timings", "ssdk_ctx_get_tail_stamps",

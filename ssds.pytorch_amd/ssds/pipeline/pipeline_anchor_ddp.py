@@ -35,10 +35,10 @@ class ModelWithLossBasic(torch.nn.Module):
         self.center_radius = center_sampling_radius
 
     def _fused(self, conf):
-        """The fused target-assign + loss kernel applies when the criteria are exactly the reference's FocalLoss and
-        SmoothL1Loss or IOULoss (iou / giou / diou / ciou) and the heads live on a HIP device (SSDK_FUSED_LOSS=0 keeps
-        the unfused torch ops; MultiBoxLoss always takes them)."""
-        return (conf[0].is_cuda and type(self.cls_criterion) is _crit.FocalLoss
+        """The fused target-assign + loss kernels apply when the criteria are exactly the reference's FocalLoss or
+        MultiBoxLoss and SmoothL1Loss or IOULoss (iou / giou / diou / ciou) and the heads live on a HIP device
+        (SSDK_FUSED_LOSS=0 keeps the unfused torch ops)."""
+        return (conf[0].is_cuda and type(self.cls_criterion) in (_crit.FocalLoss, _crit.MultiBoxLoss)
                 and type(self.loc_criterion) in (_crit.SmoothL1Loss, _crit.IOULoss)
                 and os.environ.get("SSDK_FUSED_LOSS", "1") != "0")
 
@@ -50,11 +50,11 @@ class ModelWithLossBasic(torch.nn.Module):
             from ssds.core.fused_loss import match_loss
         for j, (stride, anchor) in enumerate(anchors.items()):
             if fused:  # one launch: match + focal + smooth-L1 + masks + sums, gradients written in the same pass
-                lc = self.loc_criterion
+                lc, cc = self.loc_criterion, self.cls_criterion
                 cls_sum, loc_sum, fg = match_loss(
                     conf[j], loc[j], targets, anchors, self.num_classes, stride, self.match, self.center_radius,
-                    self.cls_criterion.alpha, self.cls_criterion.gamma, getattr(lc, "beta", 0.11),
-                    getattr(lc, "loss_type", "smoothl1"))
+                    getattr(cc, "alpha", 0.25), getattr(cc, "gamma", 2.0), getattr(lc, "beta", 0.11),
+                    getattr(lc, "loss_type", "smoothl1"), getattr(cc, "negpos_ratio", None))
                 fg_targets.append(fg.clamp(min=1))
                 cls_losses.append(cls_sum)
                 loc_losses.append(loc_sum)

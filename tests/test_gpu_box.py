@@ -181,6 +181,39 @@ def test_nms_kat_and_ties():
         np.testing.assert_array_equal(g_.cpu().numpy(), w_)
 
 
+@pytest.mark.parametrize("dtype_name", ["bfloat16", "float16"])
+@pytest.mark.parametrize("name", list(cases.DECODER_CASES))
+def test_every_decoder_golden_through_the_16_bit_scan(name, dtype_name):
+    """The reference fixtures are fp32 and therefore exercise scan_kernel; every BASELINE configuration runs 16-bit heads
+    through scan16_kernel (packed 16-bit compares, sampled cut, vector queues).  Each Decoder fixture's inputs, rounded to
+    bf16 / fp16, through the device stage (scan16 -> levelsel -> nmswalk) against the oracle on the SAME rounded heads:
+    per-level output and final detections, classes / order bit-exact (the rounding creates ties: the (score desc, flat
+    index asc) contract decides them on both sides)."""
+    import torch
+    from ssds.modeling.layers.box import decode_nms
+
+    d = cases.decoder_inputs(name, O.generate_anchors)
+    if not (d["thr"] > 0 and d["per_level"] <= 512):
+        pytest.skip("the 16-bit scan needs a positive threshold and K <= 512")
+    tdt = getattr(torch, dtype_name)
+    loc = [torch.from_numpy(x).to(tdt) for x in d["loc"]]
+    conf = [torch.from_numpy(x).to(tdt) for x in d["conf"]]
+    anchors = OrderedDict((k, torch.from_numpy(v)) for k, v in d["anchors"].items())
+    (s, b, c), mid = decode_nms([t.cuda() for t in loc], [t.cuda() for t in conf], anchors, d["thr"], d["per_level"], d["rescore"],
+                                d["nms"], d["top_n"], d["diou"], return_mid=True)
+    odec = O.Decoder(d["thr"], d["nms"], d["top_n"], d["per_level"], d["rescore"], d["diou"])
+    ol, oc = [t.float().numpy() for t in loc], [t.float().numpy() for t in conf]
+    wm = odec.decode_levels(ol, oc, d["anchors"])
+    np.testing.assert_array_equal(mid[2].cpu().numpy(), wm[2])
+    np.testing.assert_allclose(mid[1].cpu().numpy(), wm[1], atol=BOX_ATOL, rtol=0)
+    np.testing.assert_allclose(mid[0].cpu().numpy(), wm[0], atol=1e-4, rtol=1e-4, equal_nan=True)
+    # NMS on the device's own per-level output (bit-identical input on both sides: ulp-level differences of the rescored
+    # scores must not decide the walk order of tied candidates)
+    wn = O.nms(mid[0].cpu().numpy(), mid[1].cpu().numpy(), mid[2].cpu().numpy(), d["nms"], d["top_n"], d["diou"])
+    for g_, w_ in zip((s, b, c), wn):
+        np.testing.assert_array_equal(g_.cpu().numpy(), w_)
+
+
 @pytest.mark.parametrize("name", list(cases.DECODER_CASES))
 def test_decoder_vs_reference(name):
     import torch

@@ -126,7 +126,8 @@ LARGE = [
     (1024, 256, 1, 1, 40, 40, 24, "relu", G256),   # wide 1x1 with a long K (the flat-K 256 x 256 kernel takes K >= 1024 only)
     (128, 320, 3, 2, 64, 64, 32, "relu6", G256),   # 3x3 stride 2
     (1064, 200, 1, 1, 45, 50, 16, "silu", G256),   # ragged everything
-    (64, 256, 1, 1, 64, 64, 8, "relu", "conv_gemm_kernel"),  # wide 1x1, short K: the 128-row kernel (several workgroups per CU)
+    # wide 1x1, short K: NHWC streams through pwflow_kernel (round 4), NCHW takes the 128-row GEMM kernel (several workgroups per CU)
+    (64, 256, 1, 1, 64, 64, 8, "relu", ("pwflow_kernel", "conv_gemm_kernel")),
 ]
 
 

@@ -38,6 +38,13 @@ def _stats(got, want, logit=False):
 
 
 CAP = {"bfloat16": 0.7, "float16": 0.3}  # absolute cap on the median error (a wrong wire is >= 1; measured bf16: <= 0.63)
+# levels of fewer than SMALL values (the 1x1 / 2x2 maps at the end of the pyramid: a handful of positions whose errors are all
+# correlated through one input vector) are ONE draw of the noise, not a statistic: PyTorch-ROCm's own bf16 run lands anywhere
+# between 0.19 and 0.75 RMS on them.  Their floor is therefore the larger of their own and the median floor of the same
+# head's levels, and their bf16 cap is 1.0 (still below the 1.4 of uncorrelated outputs; the fp16 run of the same case keeps
+# its 0.3 and is the one that discriminates).
+SMALL = 4096
+CAP_SMALL = {"bfloat16": 1.0, "float16": 0.3}
 # absolute slack on (median, p99.9): the last levels are a few dozen values, whose statistics are noise themselves
 SLACK = {"bfloat16": (0.06, 0.2), "float16": (0.015, 0.05)}
 
@@ -59,13 +66,20 @@ def _check_against_floor(plan_out, torch_out, want, what, dtype, tail_factor=2.0
     logit space the error is homogeneous and the plain factor rule applies to every tensor."""
     report, bad = [], []
     for tag in ("loc", "conf"):
-        for i, (p, t, w) in enumerate(zip(plan_out[tag], torch_out[tag], want[tag])):
-            lg = tag == "conf"
-            sp, st = _stats(p, w, lg), _stats(t, w, lg)
-            report.append("%s%d%s plan %.4f/%.4f/%.4f floor %.4f/%.4f/%.4f" % ((tag, i, "(logit)" if lg else "") + sp + st))
+        lg = tag == "conf"
+        floors = [_stats(t, w, lg) for t, w in zip(torch_out[tag], want[tag])]
+        pooled = tuple(sorted(f[j] for f in floors)[len(floors) // 2] for j in range(3))
+        for i, (p, w) in enumerate(zip(plan_out[tag], want[tag])):
+            sp, st = _stats(p, w, lg), floors[i]
+            small = w.numel() < SMALL
+            report.append("%s%d%s plan %.4f/%.4f/%.4f floor %.4f/%.4f/%.4f%s" % (
+                (tag, i, "(logit)" if lg else "") + sp + st + (" (small level)" if small else "",)))
+            if small:
+                st = tuple(max(a, b) for a, b in zip(st, pooled))
             m_abs, p_abs = SLACK[dtype]
             tail_bar = tail_factor * st[1] + p_abs
-            if not (sp[0] <= 2.0 * st[0] + m_abs and sp[1] <= tail_bar and sp[0] <= CAP[dtype]):
+            cap = CAP_SMALL[dtype] if small else CAP[dtype]
+            if not (sp[0] <= 2.0 * st[0] + m_abs and sp[1] <= tail_bar and sp[0] <= cap):
                 bad.append(report[-1])
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
