@@ -69,47 +69,29 @@ template <int DT> __device__ __forceinline__ float fl_from16(u32 h) {
 __device__ __forceinline__ u32 fl_from_left(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }   // row_shr:1
 __device__ __forceinline__ u32 fl_from_right(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }  // row_shl:1
 
-// ReLU6 of N packed-fp16 words in place, as two passes of independent instructions.  Written with __builtin_elementwise_max /
-// min the compiler (a) canonicalises every input first (v_pk_max v, v, v: the values went through an asm pin, so it no longer
-// knows they are FMA results) and (b) emits the three dependent packed instructions of a word back to back, each pair separated
-// by the s_nop a dependent VOP3P pair needs: 5 issue slots per word, 180 per output row of the 144-channel block.  Here: 2.
-template <int N>
-__device__ __forceinline__ void fl_relu6_words(fl_h2* v) {
-  const u32 six = 0x46004600u;
-#pragma unroll
-  for (int i = 0; i < N; ++i) asm volatile("v_pk_max_f16 %0, %0, 0" : "+v"(v[i]));
-#pragma unroll
-  for (int i = 0; i < N; ++i) asm volatile("v_pk_min_f16 %0, %0, %1" : "+v"(v[i]) : "v"(six));
+// ---- ReLU6 in units of six (round 4) ---------------------------------------------------------------------------------
+// relu6(v) = 6 * clamp(v / 6, 0, 1), and clamping to [0, 1] is a free output modifier of the VALU.  The flow kernels keep both
+// internal tensors in units of six: E' = clamp(e / 6) comes out of ONE packed fp32 multiply per two accumulators (its factor
+// is 1/6, or 0 for a pixel outside the image: the zero padding of the expanded tensor) followed by the packed conversion,
+// instead of two v_med3_f32 per pair; the depthwise sum of E' with the bias / 6 is D / 6 and the LAST packed FMA of an output
+// row clamps it (instead of a v_pk_max + v_pk_min pass over the finished row); the factor 6 returns in the fp32 scale of the
+// projection epilogue.  Taps and weights are untouched, so the only new rounding is that of bias / 6 to fp16.
+typedef float fl_f2 __attribute__((ext_vector_type(2)));
+constexpr float kFlSixth = 1.0f / 6.0f;
+__device__ __forceinline__ u32 fl_unit_pack(float a, float b, fl_f2 k) {
+  const fl_f2 v = {a, b};
+  fl_f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(v), "v"(k));
+  return __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(r[0], r[1]));
 }
-
-// Stride 2, two strips per wave: only the ODD lanes 1..13 of a strip own an output pixel, so the taps of strip `a` stay in
-// the odd lanes and those of strip `b` move one lane to the left into the even lanes 0..12 -- one register set then holds
-// the 14 outputs of both strips and every packed FMA, the bias / ReLU6 pass, the projection MFMAs and the epilogue run once
-// for the pair instead of once per strip (half of their lanes idle).  Lane j of the merged registers:
-//   odd  j: left a[j-1], centre a[j],   right a[j+1]      (strip a, output (j-1)/2)
-//   even j: left b[j],   centre b[j+1], right b[j+2]      (strip b, output j/2)
-// A select whose one arm is a lane shift is ONE instruction (v_cndmask_b32_dpp: VCC ? src1 : dpp(src0)); the compiler
-// does not form it (it branches around a v_mov_b32_dpp instead, which reads disabled lanes), hence the asm block: VCC holds
-// the odd-lane mask, then the even-lane mask; s_nop 1 = the two wait states between a VALU write and a DPP read of it.
-__device__ __forceinline__ void fl_merge_s2(u32 a0, u32 a1, u32 b0, u32 b1, u32& l0, u32& l1, u32& c0, u32& c1, u32& r0, u32& r1) {
-  u32 t0, t1;
-  asm volatile(
-      "s_nop 1\n\t"
-      "s_mov_b32 vcc_lo, 0xaaaaaaaa\n\t"
-      "s_mov_b32 vcc_hi, 0xaaaaaaaa\n\t"
-      "v_cndmask_b32_dpp %2, %10, %8, vcc row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_cndmask_b32_dpp %3, %11, %9, vcc row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_mov_b32_dpp %6, %8 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_mov_b32_dpp %7, %9 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_cndmask_b32_dpp %4, %10, %6, vcc row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_cndmask_b32_dpp %5, %11, %7, vcc row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "s_mov_b32 vcc_lo, 0x55555555\n\t"
-      "s_mov_b32 vcc_hi, 0x55555555\n\t"
-      "v_cndmask_b32_dpp %0, %8, %10, vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_cndmask_b32_dpp %1, %9, %11, vcc row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      : "=&v"(l0), "=&v"(l1), "=&v"(c0), "=&v"(c1), "=&v"(r0), "=&v"(r1), "=&v"(t0), "=&v"(t1)
-      : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
-      : "vcc");
+__device__ __forceinline__ fl_h2 fl_fma_clamp01(fl_h2 a, fl_h2 b, fl_h2 c) {
+  fl_h2 r;
+  asm("v_pk_fma_f16 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// a packed pair of fp16 values divided by six (fp32 arithmetic, one rounding)
+__device__ __forceinline__ u32 fl_sixth_h2(u32 w) {
+  return fl_to16<SSDK_F16>(fl_from16<SSDK_F16>(w & 0xffffu) * kFlSixth) | (fl_to16<SSDK_F16>(fl_from16<SSDK_F16>(w >> 16) * kFlSixth) << 16);
 }
 
 }  // namespace ssdk

@@ -22,9 +22,15 @@
 // Numerics follow ssdk_mbconv.hip: E = fp16(clamp(bn(expand), 0, 6)) (round toward zero; the BN scale is folded into the
 // expand weights -- by the host before they are rounded, else at staging time -- and the BN bias is the accumulator the
 // MFMA starts from), depthwise in packed fp16 in the order bias, (ky, kx), D = clamp(acc, 0, 6), projection on the f16 MFMA
-// with fp32 accumulation, output rounded to the model dtype before the residual is added.  Stride 2: lane fr of a strip
-// holds input column 2*ox0 - 1 + fr, outputs sit in the odd lanes 1..13 (7 per strip); with two strips per wave the
-// second strip's outputs move into the even lanes of ONE shared accumulator set (fl_merge_s2).
+// with fp32 accumulation, output rounded to the model dtype before the residual is added.  (Round 4: both internal tensors
+// are kept in units of six, ReLU6 = the [0, 1] clamp modifier of the instruction that produces them: ssdk_flow_common.h.)
+// Stride 2 (round 4, "parity split"): which input pixel sits in which lane is the kernel's choice -- it is only the address
+// the lane loads its B operand from.  The wave's two strips are the EVEN and the ODD input columns of one range: lane j of
+// strip 0 holds column 2(ox0 + j), lane j of strip 1 column 2(ox0 + j) - 1, so output pixel ox0 + j finds its centre tap in
+// its own lane of strip 0, its left tap in its own lane of strip 1 and its right tap one lane up in strip 1: ONE lane
+// shift per packed word and 15 outputs per wave and row in one accumulator set.  (Contiguous columns -- round 2/3 -- left
+// the outputs in every second lane: 7 per strip, and merging two strips into one accumulator set cost 8 DPP selects per
+// word pair, a quarter of the row loop's VALU instructions.)
 #include <stdio.h>
 #include <atomic>
 #include <type_traits>
@@ -97,6 +103,7 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
       s = *reinterpret_cast<const f32x4*>(p.se + hc);
       b = *reinterpret_cast<const f32x4*>(p.be + hc);
       d = *reinterpret_cast<const uint2*>(p.bd + hc);
+      d = make_uint2(fl_sixth_h2(d.x), fl_sixth_h2(d.y));  // (units of six, ssdk_flow_common.h)
     }
     *reinterpret_cast<f32x4*>(smem + L::sb + i * 32) = s;
     *reinterpret_cast<f32x4*>(smem + L::sb + i * 32 + 16) = b;
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
     const u32 co = (i >> 2) * 16 + (i & 3u) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
     if (co < (u32)Cout) {
-      s = *reinterpret_cast<const f32x4*>(p.sp + co);
+      s = *reinterpret_cast<const f32x4*>(p.sp + co) * 6.0f;  // (the depthwise output arrives in units of six)
       b = *reinterpret_cast<const f32x4*>(p.bp + co);
     }
     *reinterpret_cast<f32x4*>(smem + L::spb + i * 32) = s;
@@ -145,8 +152,8 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
     for (int i = 0; i < seg; ++i) m &= m - 1;
     seg = __builtin_ctzll(m);
   }
-  constexpr int OW = S == 1 ? 14 : 7;             // output pixels per strip
-  // stride 2 with two strips per wave: the outputs of both strips share ONE accumulator set (fl_merge_s2)
+  constexpr int OW = S == 1 ? 14 : 7;             // output pixels per strip (stride 2 with two strips: 15 per PAIR, below)
+  // stride 2 with two strips per wave: even / odd input columns, ONE accumulator set (see the header)
   constexpr bool MERGE = S == 2 && NS == 2;
   constexpr int NA = MERGE ? 1 : NS;              // accumulator / output sets per wave
   const int oy0 = seg * p.rs, oy1 = (oy0 + p.rs < p.Ho ? oy0 + p.rs : p.Ho) - 1;  // output rows [oy0, oy1]
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
   for (int s = 0; s < NS; ++s) {
     const int strip = grp * NS + s;
     const int ox0 = strip * OW;
-    ix[s] = ox0 * S - 1 + (int)fr;                 // this lane's input column in strip s
+    ix[s] = MERGE ? 2 * (grp * 15 + (int)fr) - s : ox0 * S - 1 + (int)fr;  // this lane's input column in strip s
     col_ok[s] = strip < p.strips && (unsigned)ix[s] < (unsigned)p.W;
     if constexpr (!MERGE) {
       // output pixel of this lane (if any): stride 1: lanes 1..14, stride 2: odd lanes 1..13
@@ -164,10 +171,9 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
       out_lane[s] = strip < p.strips && (S == 1 ? (fr >= 1u && fr <= 14u) : ((fr & 1u) && fr <= 13u)) && oxl[s] < p.Wo;
     }
   }
-  if constexpr (MERGE) {  // odd lane j <= 13: output (j-1)/2 of strip 0; even lane j <= 12: output j/2 of strip 1
-    const int strip = grp * NS + ((fr & 1u) ? 0 : 1);
-    oxl[0] = strip * OW + (int)(fr >> 1);
-    out_lane[0] = strip < p.strips && fr <= 13u && oxl[0] < p.Wo;
+  if constexpr (MERGE) {  // lane j <= 14: output grp * 15 + j (lane 15 has no right tap)
+    oxl[0] = grp * 15 + (int)fr;
+    out_lane[0] = fr <= 14u && oxl[0] < p.Wo;
   }
 
   const u16* ximg = STEM ? p.x + (size_t)n * p.Cimg * p.Himg * p.Wimg : p.x + (size_t)n * p.H * p.W * Cin;
@@ -276,9 +282,12 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
         for (int q = 0; q < 4; ++q) xf[s][q] = xraw[s].w[q];
       }
     }
-    float hi[NS];  // zero padding of the EXPANDED tensor: pixels outside the image clamp to [0, 0]
+    fl_f2 hi[NS];  // 1/6, or 0 for a pixel outside the image (the zero padding of the EXPANDED tensor)
 #pragma unroll
-    for (int s = 0; s < NS; ++s) hi[s] = (col_ok[s] && (unsigned)iy < (unsigned)p.H) ? 6.f : 0.f;
+    for (int s = 0; s < NS; ++s) {
+      const float k = (col_ok[s] && (unsigned)iy < (unsigned)p.H) ? kFlSixth : 0.f;
+      hi[s] = fl_f2{k, k};
+    }
     const bool store_row = FIN && oy_fin >= oy0 && oy_fin <= oy1;               // wave-uniform
     uint2 resv[NA][NFO];
     if (!STEM && !MERGE && FIN && store_row && p.residual) {  // issued early; consumed in the epilogue (stride 1 only)
@@ -324,10 +333,8 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const f32x4 e = e_cur[s];
-        ew[s][0] = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(e[0], 0.f, hi[s]),
-                                                                      __builtin_amdgcn_fmed3f(e[1], 0.f, hi[s])));
-        ew[s][1] = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(e[2], 0.f, hi[s]),
-                                                                      __builtin_amdgcn_fmed3f(e[3], 0.f, hi[s])));
+        ew[s][0] = fl_unit_pack(e[0], e[1], hi[s]);
+        ew[s][1] = fl_unit_pack(e[2], e[3], hi[s]);
       }
       auto fold = [&](fl_h2 l0, fl_h2 l1, fl_h2 c0, fl_h2 c1, fl_h2 r0, fl_h2 r1, int a) {
         auto taps = [&](int ky, fl_h2& a0, fl_h2& a1, bool init) {
@@ -337,8 +344,13 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
           s1 = __builtin_elementwise_fma(l1, fl_as_h2(w0.y), s1);
           s0 = __builtin_elementwise_fma(c0, fl_as_h2(w1.x), s0);
           s1 = __builtin_elementwise_fma(c1, fl_as_h2(w1.y), s1);
-          s0 = __builtin_elementwise_fma(r0, fl_as_h2(w2.x), s0);
-          s1 = __builtin_elementwise_fma(r1, fl_as_h2(w2.y), s1);
+          if (ky == 2) {  // the output row is complete with this tap: ReLU6 = the clamp of the FMA (units of six)
+            s0 = fl_fma_clamp01(r0, fl_as_h2(w2.x), s0);
+            s1 = fl_fma_clamp01(r1, fl_as_h2(w2.y), s1);
+          } else {
+            s0 = __builtin_elementwise_fma(r0, fl_as_h2(w2.x), s0);
+            s1 = __builtin_elementwise_fma(r1, fl_as_h2(w2.y), s1);
+          }
           // pin the results here: the updates of the rows that finish LATER are only used by the next row's code, and the
           // compiler otherwise sinks them below this row's (conditional) projection -- with every chunk's E values and
           // weights kept alive until then (400 live registers)
@@ -350,10 +362,9 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
         if constexpr (MID) taps(1, mid[a][2 * c], mid[a][2 * c + 1], false);
         if constexpr (FIN) taps(2, fin[a][2 * c], fin[a][2 * c + 1], false);
       };
-      if constexpr (MERGE) {
-        u32 l0, l1, c0, c1, r0, r1;
-        fl_merge_s2(ew[0][0], ew[0][1], ew[1][0], ew[1][1], l0, l1, c0, c1, r0, r1);
-        fold(fl_as_h2(l0), fl_as_h2(l1), fl_as_h2(c0), fl_as_h2(c1), fl_as_h2(r0), fl_as_h2(r1), 0);
+      if constexpr (MERGE) {  // left tap: own lane of the odd columns, centre: own lane of the even ones, right: odd, one lane up
+        fold(fl_as_h2(ew[1][0]), fl_as_h2(ew[1][1]), fl_as_h2(ew[0][0]), fl_as_h2(ew[0][1]), fl_as_h2(fl_from_right(ew[1][0])),
+             fl_as_h2(fl_from_right(ew[1][1])), 0);
       } else {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
@@ -370,7 +381,6 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
     if constexpr (FIN) {
       if (store_row) {
         // ---- the output row is complete: bias + ReLU6 in place, then it IS the projection's B operand --------------
-        fl_relu6_words<NA * NCH * 2>(&fin[0][0]);  // (the bias went in with the ky = 0 row)
         asm volatile("" ::: "memory");
         f32x4 yacc[NA][NFO];
 #pragma unroll
@@ -569,6 +579,7 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
   };
   const int ow = d->stride == 1 ? 14 : 7;
   p.strips = (p.Wo + ow - 1) / ow;
+  if (d->stride == 2) p.strips = 2 * ((p.Wo + 14) / 15);  // parity split: a pair of strips = 15 outputs (even / odd input columns)
   // rows per segment: long segments amortise the two halo rows, short ones give the chip enough waves (>= ~3 per SIMD)
   static const int env_rs = getenv("SSDK_MB_FLOW_RS") ? atoi(getenv("SSDK_MB_FLOW_RS")) : 0;
   // strips per wave: two share every weight read, but the 144-channel stride-1 block then holds 216 registers (3 x 2 x 18

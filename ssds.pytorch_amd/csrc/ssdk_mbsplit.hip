@@ -42,7 +42,7 @@ struct SplitLds {
 template <int DT, int S, int KS, int NCHW, int NW, int NFO, int XB, bool TREG>
 __global__ __launch_bounds__(64 * NW, 2) void mbsplit_kernel(const FlowParams p) {
   constexpr int NS = 2;                          // strips per item
-  constexpr bool MERGE = S == 2;                 // stride 2: both strips' outputs in one accumulator set (fl_merge_s2)
+  constexpr bool MERGE = S == 2;                 // stride 2: even / odd input columns, one accumulator set (ssdk_mbflow.hip header)
   constexpr int NA = MERGE ? 1 : NS;
   using L = SplitLds<NCHW, NW, KS, NFO, NA, XB>;
   constexpr int NCH = L::NCH, TW = L::TW, F = L::F;
@@ -80,6 +80,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mbsplit_kernel(const FlowParams p)
     if (hc < (u32)Chid) {
       b = *reinterpret_cast<const f32x4*>(p.be + hc);
       d = *reinterpret_cast<const uint2*>(p.bd + hc);
+      d = make_uint2(fl_sixth_h2(d.x), fl_sixth_h2(d.y));  // (units of six, ssdk_flow_common.h)
     }
     *reinterpret_cast<f32x4*>(smem + L::be + i * 16) = b;
     *reinterpret_cast<uint2*>(smem + L::bd + i * 8) = d;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mbsplit_kernel(const FlowParams p)
     const u32 co = (i >> 2) * 16 + (i & 3u) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
     if (co < (u32)Cout) {
-      s = *reinterpret_cast<const f32x4*>(p.sp + co);
+      s = *reinterpret_cast<const f32x4*>(p.sp + co) * 6.0f;  // (the depthwise output arrives in units of six)
       b = *reinterpret_cast<const f32x4*>(p.bp + co);
     }
     *reinterpret_cast<f32x4*>(smem + L::spb + i * 32) = s;
@@ -126,17 +127,16 @@ __global__ __launch_bounds__(64 * NW, 2) void mbsplit_kernel(const FlowParams p)
   for (int s = 0; s < NS; ++s) {
     const int strip = grp * NS + s;
     const int ox0 = strip * OW;
-    ix[s] = ox0 * S - 1 + (int)fr;
+    ix[s] = MERGE ? 2 * (grp * 15 + (int)fr) - s : ox0 * S - 1 + (int)fr;
     col_ok[s] = strip < p.strips && (unsigned)ix[s] < (unsigned)p.W;
     if constexpr (!MERGE) {
       oxl[s] = ox0 + (int)fr - 1;
       out_lane[s] = strip < p.strips && fr >= 1u && fr <= 14u && oxl[s] < p.Wo;
     }
   }
-  if constexpr (MERGE) {  // odd lane j <= 13: output (j-1)/2 of strip 0; even lane j <= 12: output j/2 of strip 1
-    const int strip = grp * NS + ((fr & 1u) ? 0 : 1);
-    oxl[0] = strip * OW + (int)(fr >> 1);
-    out_lane[0] = strip < p.strips && fr <= 13u && oxl[0] < p.Wo;
+  if constexpr (MERGE) {  // lane j <= 14: output grp * 15 + j (lane 15 has no right tap)
+    oxl[0] = grp * 15 + (int)fr;
+    out_lane[0] = fr <= 14u && oxl[0] < p.Wo;
   }
 
   const u16* ximg = p.x + (size_t)n * p.H * p.W * Cin;
@@ -175,9 +175,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mbsplit_kernel(const FlowParams p)
   auto row = [&](const XRow (&xraw)[NS], int iy, auto FINc, auto MIDc, auto INIc, fl_h2 (&fin)[NA][NCHW * 2],
                  fl_h2 (&mid)[NA][NCHW * 2], fl_h2 (&ini)[NA][NCHW * 2], int oy_fin) {
     constexpr bool FIN = decltype(FINc)::value, MID = decltype(MIDc)::value, INI = decltype(INIc)::value;
-    float hi[NS];  // zero padding of the EXPANDED tensor: pixels outside the image clamp to [0, 0]
+    fl_f2 hi[NS];  // 1/6, or 0 for a pixel outside the image (the zero padding of the EXPANDED tensor)
 #pragma unroll
-    for (int s = 0; s < NS; ++s) hi[s] = (col_ok[s] && (unsigned)iy < (unsigned)p.H) ? 6.f : 0.f;
+    for (int s = 0; s < NS; ++s) {
+      const float k = (col_ok[s] && (unsigned)iy < (unsigned)p.H) ? kFlSixth : 0.f;
+      hi[s] = fl_f2{k, k};
+    }
     const bool store_row = FIN && oy_fin >= oy0 && oy_fin <= oy1;  // uniform over the workgroup
     // residual of the fragments this wave finalizes: issued early, consumed after the exchange (stride 1 only)
     uint2 resv[FPW];
@@ -229,10 +232,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mbsplit_kernel(const FlowParams p)
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const f32x4 e = e_cur[s];
-        ew[s][0] = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(e[0], 0.f, hi[s]),
-                                                                      __builtin_amdgcn_fmed3f(e[1], 0.f, hi[s])));
-        ew[s][1] = __builtin_bit_cast(u32, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_fmed3f(e[2], 0.f, hi[s]),
-                                                                      __builtin_amdgcn_fmed3f(e[3], 0.f, hi[s])));
+        ew[s][0] = fl_unit_pack(e[0], e[1], hi[s]);
+        ew[s][1] = fl_unit_pack(e[2], e[3], hi[s]);
       }
       auto fold = [&](fl_h2 l0, fl_h2 l1, fl_h2 c0, fl_h2 c1, fl_h2 r0, fl_h2 r1, int a) {
         auto taps = [&](int ky, fl_h2& a0, fl_h2& a1, bool init) {
@@ -242,8 +243,13 @@ __global__ __launch_bounds__(64 * NW, 2) void mbsplit_kernel(const FlowParams p)
           s1 = __builtin_elementwise_fma(l1, fl_as_h2(w0.y), s1);
           s0 = __builtin_elementwise_fma(c0, fl_as_h2(w1.x), s0);
           s1 = __builtin_elementwise_fma(c1, fl_as_h2(w1.y), s1);
-          s0 = __builtin_elementwise_fma(r0, fl_as_h2(w2.x), s0);
-          s1 = __builtin_elementwise_fma(r1, fl_as_h2(w2.y), s1);
+          if (ky == 2) {  // the output row is complete with this tap: ReLU6 = the clamp of the FMA (units of six)
+            s0 = fl_fma_clamp01(r0, fl_as_h2(w2.x), s0);
+            s1 = fl_fma_clamp01(r1, fl_as_h2(w2.y), s1);
+          } else {
+            s0 = __builtin_elementwise_fma(r0, fl_as_h2(w2.x), s0);
+            s1 = __builtin_elementwise_fma(r1, fl_as_h2(w2.y), s1);
+          }
           asm volatile("" : "+v"(s0), "+v"(s1));  // (pinned: see ssdk_mbflow.hip -- MachineSink below the projection)
           a0 = s0;
           a1 = s1;
@@ -252,10 +258,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mbsplit_kernel(const FlowParams p)
         if constexpr (MID) taps(1, mid[a][2 * c], mid[a][2 * c + 1], false);
         if constexpr (FIN) taps(2, fin[a][2 * c], fin[a][2 * c + 1], false);
       };
-      if constexpr (MERGE) {
-        u32 l0, l1, c0, c1, r0, r1;
-        fl_merge_s2(ew[0][0], ew[0][1], ew[1][0], ew[1][1], l0, l1, c0, c1, r0, r1);
-        fold(fl_as_h2(l0), fl_as_h2(l1), fl_as_h2(c0), fl_as_h2(c1), fl_as_h2(r0), fl_as_h2(r1), 0);
+      if constexpr (MERGE) {  // left tap: own lane of the odd columns, centre: own lane of the even ones, right: odd, one lane up
+        fold(fl_as_h2(ew[1][0]), fl_as_h2(ew[1][1]), fl_as_h2(ew[0][0]), fl_as_h2(ew[0][1]), fl_as_h2(fl_from_right(ew[1][0])),
+             fl_as_h2(fl_from_right(ew[1][1])), 0);
       } else {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
@@ -269,7 +274,6 @@ __global__ __launch_bounds__(64 * NW, 2) void mbsplit_kernel(const FlowParams p)
     if constexpr (FIN) {
       if (store_row) {
         // ---- this wave's chunks of the output row: ReLU6, then they ARE the B operand of its projection k-steps --------
-        fl_relu6_words<NA * NCHW * 2>(&fin[0][0]);
         asm volatile("" ::: "memory");
         f32x4 yacc[NA][NFO];
 #pragma unroll
@@ -443,6 +447,7 @@ int launch_mbsplit(const ssdk_mbconv_desc* d, hipStream_t stream) {
   p.dbg = nullptr;
   const int ow = d->stride == 1 ? 14 : 7;
   p.strips = (p.Wo + ow - 1) / ow;
+  if (d->stride == 2) p.strips = 2 * ((p.Wo + 14) / 15);  // parity split: a pair of strips = 15 outputs (ssdk_mbflow.hip header)
   const int groups = (p.strips + 1) / 2;
   // rows per segment: the longest of 32 / 16 / 8 that still gives the chip ~3 workgroups per CU
   static const int env_rs = getenv("SSDK_MB_SPLIT_RS") ? atoi(getenv("SSDK_MB_SPLIT_RS")) : 0;
