@@ -443,10 +443,15 @@ typedef struct ssdk_xpair_desc {
 int ssdk_xpair(const ssdk_xpair_desc* desc, void* stream);
 
 /* Plan executor: a recorded forward as a list of tagged ops (topological order), replayed with one host call.
- * lane 0 ops run in order on the caller's stream.  lane 1 ops (the multibox heads: leaves that depend only on
- * ops listed before them) are forked onto the context's side stream and run concurrently with the following
- * lane 0 ops; they use the upper half of the workspace, and everything is joined back onto the caller's stream
- * before the call returns.  Buffers read or written by lane 1 ops must not be reused by later ops of the list. */
+ * lane 0 ops run in order on the caller's stream.  lane 1 / lane 2 ops are forked onto the context's side stream (when
+ * the side lane is on, ssdk_ctx_set_side_lane) and run concurrently with the following lane 0 ops, in list order among
+ * themselves; a run of consecutive side ops forks ONCE, behind everything listed before its first op (at most 32 runs per
+ * call, else everything runs in line); they use the upper half of the workspace, and everything is joined back onto
+ * the caller's stream before the call returns.  lane 1: leaves (the multibox heads) -- next to the main chain an
+ * underfilled grid is free, so the kernel choice may differ from the in-line one.  lane 2 (version 210): chains (the
+ * towers + heads of the small pyramid levels next to the big levels' launches) -- exactly the kernels the op gets in line,
+ * so the outputs do not depend on whether the side lane is on.  Buffers read or written by side ops must not be reused
+ * by later ops of the list. */
 enum { SSDK_OP_CONV = 0, SSDK_OP_MBCONV = 1, SSDK_OP_FUSE = 2, SSDK_OP_STEM7 = 3, SSDK_OP_POOL = 4, SSDK_OP_XPAIR = 5 };
 typedef struct ssdk_op {
   int32_t kind, lane;

@@ -1024,7 +1024,14 @@ extern "C" size_t ssdk_conv_workspace_bytes(int N, int Cin, int H, int W, int Co
   if (Cin <= 4 || (k != 1 && k != 3) || (stride != 1 && stride != 2)) return 0;
   const int pad = k / 2;
   const long M = (long)N * ((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
-  size_t need = splitk_ws_bytes(M, Cin, Cout, k, nullptr, nullptr);
+  int gemm_splits = 1;
+  size_t need = splitk_ws_bytes(M, Cin, Cout, k, &gemm_splits, nullptr);
+  if (k == 3 && stride == 1 && gemm_splits > 1) {  // the halo kernel may take the layer WITH the GEMM's split: its slabs are larger
+    for (int nchw = 0; nchw < 2; ++nchw) {
+      const size_t hb = halo_ws_bytes(N, Cin, H, W, Cout, nchw != 0, gemm_splits);
+      if (hb > need) need = hb;
+    }
+  }
   if (k == 3 && stride == 1) {  // the halo kernel's own split-K (small maps, long K)
     size_t hb = 0;
     if (halo_splitk_plan(N, Cin, H, W, Cout, true, &hb) > 1 && hb > need) need = hb;
@@ -1271,7 +1278,20 @@ extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t worksp
   }
   if (launch_conv3x3_short(p, d->dtype, stream) == 0) return check_launch("conv3x3_short_kernel");  // short K, two workgroups per CU
   {
-    const int rc = launch_conv3x3_halo(p, d->dtype, stream, false);  // 3x3 stride-1 layers with enough tiles
+    // 3x3 stride-1 layers with enough tiles.  A split planned above for conv_gemm_kernel carries over (few output pixels, long
+    // K: the 10x10 FPN levels) only if the workspace also holds the HALO kernel's slabs; otherwise the halo kernel runs unsplit
+    // (or declines: too few tiles) and conv_gemm_kernel takes the layer with its own split.
+    ConvParams q = p;
+    if (q.ksplits > 1) {
+      const size_t hb = halo_ws_bytes(d->N, d->Cin, Ho, Wo, d->Cout, d->out_layout == SSDK_LAYOUT_NCHW, q.ksplits);
+      if (!hb || workspace_bytes < hb) {
+        q.ksplits = 1;
+        q.kt_per = q.KT;
+        q.counters = nullptr;
+        q.slabs = nullptr;
+      }
+    }
+    const int rc = launch_conv3x3_halo(q, d->dtype, stream, false);
     if (rc != 1) return rc;
   }
   return d->dtype == SSDK_BF16 ? launch_gemm<SSDK_BF16>(p, stream) : launch_gemm<SSDK_F16>(p, stream);
@@ -1454,10 +1474,15 @@ extern "C" int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* 
   hipStream_t main_s = (hipStream_t)stream;
   const bool prof = ctx->op_prof && ctx->op_ev_ready && n <= kSsdkMaxProfOps;
   if (prof) ctx->op_n = 0;
-  int n_side = 0;
-  for (int i = 0; i < n; ++i) n_side += ops[i].lane == 1 ? 1 : 0;
+  // side-lane ops fork off the main stream once per RUN of consecutive side ops (a chain of small-level tower layers is one
+  // run: one fork behind its producers, the join at the end of the plan); 32 fork events per context
+  int n_side = 0, n_runs = 0;
+  for (int i = 0; i < n; ++i) {
+    n_side += ops[i].lane != 0 ? 1 : 0;
+    n_runs += (ops[i].lane != 0 && (i == 0 || ops[i - 1].lane == 0)) ? 1 : 0;
+  }
   // concurrent lanes need disjoint split-K scratch: the side lane gets the upper half of the workspace
-  bool use_side = n_side > 0 && n_side <= 32 && !prof && side_wanted(ctx);
+  bool use_side = n_side > 0 && n_runs <= 32 && !prof && side_wanted(ctx);
   if (use_side)
     if (int rc = side_init(ctx)) return rc;
   char* ws_main = (char*)workspace;
@@ -1476,23 +1501,26 @@ extern "C" int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* 
       set_error("run_ops: hipEventRecord failed");
       return SSDK_E_LAUNCH;
     }
-    const bool side = use_side && ops[i].lane == 1;
+    const bool side = use_side && ops[i].lane != 0;
     hipStream_t st = main_s;
     void* w = ws_main;
     size_t wb = ws_main_bytes;
     int rc = SSDK_OK;
     if (side) {
-      rc = edge(main_s, ctx->fork[forks], ctx->side);  // everything recorded so far (the op's producers) precedes it
-      ++forks;
-      st = ctx->side;
+      if (i == 0 || ops[i - 1].lane == 0) {  // first op of a run: everything recorded so far (its producers) precedes it
+        rc = edge(main_s, ctx->fork[forks], ctx->side);
+        ++forks;
+      }
+      static const int env_same = getenv("SSDK_SIDE_DEBUG") ? atoi(getenv("SSDK_SIDE_DEBUG")) : 0;
+      st = env_same ? main_s : ctx->side;  // (debug: the side lane's bookkeeping without its concurrency)
       w = ws_side;
       wb = ws_side_bytes;
     }
-    if (!rc && !side && ops[i].kind == SSDK_OP_CONV) {
-      // neighbouring small-map layers that do not read each other's outputs: one launch
+    if (!rc && ops[i].kind == SSDK_OP_CONV) {
+      // neighbouring small-map layers (of the same lane) that do not read each other's outputs: one launch
       ConvParams gp[kSmallmapGroupMax];
       int m = 0;
-      while (m < kSmallmapGroupMax && i + m < n && ops[i + m].kind == SSDK_OP_CONV && !(use_side && ops[i + m].lane == 1) &&
+      while (m < kSmallmapGroupMax && i + m < n && ops[i + m].kind == SSDK_OP_CONV && (use_side && ops[i + m].lane != 0) == side &&
              ops[i + m].conv.dtype == ops[i].conv.dtype && group_member_params(&ops[i + m].conv, &gp[m])) {
         // Members run as ONE kernel in no particular order: a candidate joins only if none of its byte ranges (input,
         // outputs) overlaps an earlier member's OUTPUT ranges (read-after-write, write-after-write) and its outputs do
@@ -1524,7 +1552,9 @@ extern "C" int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* 
     if (!rc) {
       ssdk::lds_poison(st);
       if (ops[i].kind == SSDK_OP_CONV) {
-        g_underfill_ok = side;
+        // lane 1 (leaf heads): an underfilled grid is free next to the main chain, so the kernel choice may differ from
+        // the in-line one; lane 2 (chains of small-level layers): the kernels the op would get in line, bit for bit
+        g_underfill_ok = side && ops[i].lane == 1;
         rc = ssdk_conv(&ops[i].conv, w, wb, st);
         g_underfill_ok = false;
       }
@@ -1546,6 +1576,17 @@ extern "C" int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* 
       return rc;
     }
     if (prof) ctx->op_kernel[i] = ssdk_last_kernel();
+    static const int env_trace = getenv("SSDK_OPS_TRACE") ? atoi(getenv("SSDK_OPS_TRACE")) : 0;
+    if (env_trace) {  // debug: one line per op, synchronised (a faulting kernel is the line that never gets its "ok")
+      fprintf(stderr, "[run_ops] op %d/%d kind %d lane %d %s", i, n, ops[i].kind, ops[i].lane, ssdk_last_kernel());
+      if (ops[i].kind == SSDK_OP_CONV)
+        fprintf(stderr, " x=%p y=%p y2=%p N=%d %dx%d Cin=%d Cout=%d k=%d s=%d out=%d", ops[i].conv.x, ops[i].conv.y, ops[i].conv.y2,
+                ops[i].conv.N, ops[i].conv.H, ops[i].conv.W, ops[i].conv.Cin, ops[i].conv.Cout, ops[i].conv.k, ops[i].conv.stride,
+                ops[i].conv.out_layout);
+      fprintf(stderr, " ...");
+      const hipError_t e = hipStreamSynchronize(st);
+      fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+    }
   }
   if (forks)
     if (int rc = edge(ctx->side, ctx->join, main_s)) return rc;

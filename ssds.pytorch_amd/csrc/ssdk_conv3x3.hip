@@ -494,6 +494,21 @@ int halo_splitk_plan(int N, int Cin, int Ho, int Wo, int Cout, bool nchw, size_t
   return ks;
 }
 
+// Workspace of the halo kernel running with `ksplits` slices, whoever planned them (ssdk_conv hands a split planned for
+// conv_gemm_kernel on when the halo kernel takes the layer: its slabs are laid out per HALO tile, 1.3x the GEMM's bytes on
+// the 10x10 FPN levels -- round 4: until then the check was against the GEMM's need and the slabs ran past it).  0: the
+// geometry does not fit this kernel's split (no patch plan, or more tiles than the 4 KiB of arrival counters hold).
+size_t halo_ws_bytes(int N, int Cin, int Ho, int Wo, int Cout, bool nchw, int ksplits) {
+  HaloParams hp;
+  if (ksplits <= 1 || !plan_patch(N, Ho, Wo, nchw, &hp)) return 0;
+  const int cch = (Cin + H3_BK - 1) / H3_BK;
+  const int c_per = (cch + ksplits - 1) / ksplits;
+  const int ks = (cch + c_per - 1) / c_per;
+  const long tiles = (long)hp.groups * hp.tiles_y * hp.tiles_x * ((Cout + H3_BN - 1) / H3_BN);
+  if (tiles > 1024) return 0;
+  return 4096 + (size_t)tiles * ks * 16 * H3_THREADS * 4 * sizeof(float);
+}
+
 int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool allow_underfill) {
   static const int env = getenv("SSDK_CONV3X3_HALO") ? atoi(getenv("SSDK_CONV3X3_HALO")) : 1;
   if (!env || p.k != 3 || p.stride != 1 || p.pad != 1 || (p.Cin % 8)) return 1;

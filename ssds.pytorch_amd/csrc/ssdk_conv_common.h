@@ -179,6 +179,7 @@ int launch_gconv3x3_g16(const ssdk_conv_desc* d, int Ho, int Wo, hipStream_t str
 // halo-tile 3x3 kernel with split-K over its channel slabs: slices to use (1: no split) and the workspace they need
 int halo_splitk_plan(int N, int Cin, int Ho, int Wo, int Cout, bool nchw, size_t* ws_bytes);
 // halo-tile 3x3 kernel (ssdk_conv3x3.hip); returns SSDK_OK, or 1 when the layer does not fit it
+size_t halo_ws_bytes(int N, int Cin, int Ho, int Wo, int Cout, bool nchw, int ksplits);
 int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool allow_underfill);
 int launch_conv3x3_short(const ConvParams& p, int dtype, hipStream_t stream);
 int launch_conv_pwflow(const ConvParams& p, int dtype, hipStream_t stream);  // ssdk_pwflow.hip: 1x1, Cin <= 256, streaming

@@ -517,6 +517,8 @@ class ConvPlan(object):
         self.report = []
         self.in_shape = tuple(in_shape) if in_shape is not None else None
         self._ctx = None  # this plan's side stream / events / op-profiling ring (include/ssdk.h "Contexts"): lazy
+        self.side_chain = False  # tower chains recorded for the side stream: the plan turns its context's side lane on
+        self.head_order = []     # per head: the level it belongs to (None: recording order)
         if in_shape is not None:
             self.add_input(in_shape)
 
@@ -538,17 +540,25 @@ class ConvPlan(object):
         n, c, h, w = e.shape
         return (e, n, c, h, w)
 
-    def conv(self, val, pack, act=None, residual=None, res_mode=0, role=None):
+    def conv(self, val, pack, act=None, residual=None, res_mode=0, role=None, lane=0):
         """res_mode bit 0: the residual value is half resolution (nearest x2 upsample, FPN top-down);
         bit 1: the activation follows the add (ResNet blocks).  ``role='tower'`` marks the 3x3 convs of the shared
-        head towers (fpn.py:10-18) for the per-layer table: they are head convolutions, not neck."""
+        head towers (fpn.py:10-18) for the per-layer table: they are head convolutions, not neck.
+        ``lane=2`` records the op for the executor's side stream (a chain of small-level tower layers next to the big
+        levels, planner._record_extras_and_towers; include/ssdk.h: lane 2 = the in-line kernel choice): its input and
+        output buffers are pinned like a side-lane head's."""
         buf, n, c, h, w = val
         assert c == pack.cin, (c, pack.cin)
         ho, wo = _out_hw(h, w, pack.k, pack.stride)
         out = self.arena.get(n * pack.cout * ho * wo * self.es)
+        if lane:
+            self.side_chain = True
+            self.pinned.add(out)
+            if not isinstance(buf, ExtBuf):
+                self.pinned.add(buf)
         self.layers.append(dict(x=buf, n=n, h=h, w=w, pack=pack, act=pack.act if act is None else act, y=out,
                                 res=residual[0] if residual is not None else None, res_mode=res_mode, nchw=False,
-                                role=role))
+                                role=role, lane=lane))
         self.keep.append(pack)
         return (out, n, pack.cout, ho, wo)
 
@@ -594,9 +604,10 @@ class ConvPlan(object):
                                 mode_c=mode_c, n=n, h=h, w_=w, ch=ch, y=out))
         return (out, n, ch, h, w)
 
-    def head(self, val, pack, split=None, act="none", act2=None, tag="both", lane=None, position=None):
+    def head(self, val, pack, split=None, act="none", act2=None, tag="both", lane=None, position=None, level=None):
         """An NCHW output of the plan: loc|conf of one SSD level as one split GEMM (``tag='both'``) or the last
-        conv of one shared tower (``tag='loc' | 'conf'``)."""
+        conv of one shared tower (``tag='loc' | 'conf'``).  ``level``: the pyramid level of the output when the heads are
+        recorded out of level order (small levels first, on the side stream); the outputs are returned in level order."""
         buf, n, c, h, w = val
         ho, wo = _out_hw(h, w, pack.k, pack.stride)
         # small heads are leaves of latency-bound work: they run on the executor's side stream next to the main
@@ -613,8 +624,10 @@ class ConvPlan(object):
         entry = (len(self.layers) - 1, n, split, pack.cout, ho, wo, tag)
         if position is None:
             self.heads.append(entry)
+            self.head_order.append(level)
         else:  # recorded out of level order (lane balancing): the outputs keep the level order
             self.heads.insert(position, entry)
+            self.head_order.insert(position, level)
         self.keep.append(pack)
 
     def release(self, val):
@@ -630,6 +643,11 @@ class ConvPlan(object):
         return self.arena.ptr(buf)
 
     def finalize(self):
+        if any(o is not None for o in self.head_order):  # heads recorded out of level order: back into level order
+            assert all(o is not None for o in self.head_order)
+            order = sorted(range(len(self.heads)), key=lambda i: self.head_order[i])
+            self.heads = [self.heads[i] for i in order]
+            self.head_order = [self.head_order[i] for i in order]
         need = 0
         for L in self.layers:
             if L.get("kind") is None:
@@ -811,6 +829,10 @@ class ConvPlan(object):
                 t = torch.empty((n, cout, ho, wo), device=self.device, dtype=self.dtype)
                 self.ops[li].conv.y = t.data_ptr()
                 (loc if tag == "loc" else conf).append(t)
+        if os.environ.get("SSDK_OPS_TRACE"):
+            import sys
+            for (li, n, split, cout, ho, wo, tag), t in zip(self.heads, [None] * len(self.heads)):
+                sys.stderr.write("[plan] head op %d %s n=%d cout=%d %dx%d y=%#x\n" % (li, tag, n, cout, ho, wo, self.ops[li].conv.y or 0))
         self._held = held  # converted inputs stay alive until the next prepare()
         return tuple(loc), tuple(conf)
 
@@ -821,6 +843,9 @@ class ConvPlan(object):
             return
         ops = self.ops if lo == 0 else (N.Op * (hi - lo)).from_address(ctypes.addressof(self.ops) + lo * ctypes.sizeof(N.Op))
         sp = N.stream_ptr(self.device) if stream is None else ctypes.c_void_p(stream.cuda_stream)
+        if self.side_chain and not getattr(self, "_side_set", False):
+            self.ctx.set_side_lane(True)  # (SSDK_LEVEL_LANES=0 records no chains: planner._record_extras_and_towers)
+            self._side_set = True
         with torch.cuda.device(self.device):
             if self.ws is not None:
                 wptr = (self.ws.data_ptr() + 255) & ~255

@@ -273,29 +273,57 @@ def _tower_packs(tower, dtype):
     return body, ConvPack(last, None, "none", dtype)
 
 
-def _record_towers(plan, xx, loc_packs, conf_packs):
+def _record_towers(plan, xx, loc_packs, conf_packs, lane=None, level=None):
     for (body, final), act, tag in ((loc_packs, "none", "loc"), (conf_packs, "sigmoid", "conf")):
         cur = xx
         for pk in body:
-            nxt = plan.conv(cur, pk, role="tower")
+            nxt = plan.conv(cur, pk, role="tower", lane=lane or 0)
             if cur is not xx:
                 plan.release(cur)
             cur = nxt
-        plan.head(cur, final, act=act, tag=tag)
+        plan.head(cur, final, act=act, tag=tag, lane=lane, level=level)
         if cur is not xx:
             plan.release(cur)
 
 
+# pixels (batch x H x W) up to which a pyramid level counts as small: its tower layers are a few dozen workgroups each,
+# a chain of latency-bound launches (FPN-ResNet50@640, batch 32: the 20x20, 10x10 and 5x5 levels are 30 launches, 0.85 ms
+# one after the other, next to 3.3 ms of chip-filling launches on the two big levels)
+SMALL_LEVEL_PIXELS = 16384
+
+
 def _record_extras_and_towers(plan, model, pyramid, raw_last):
     """reference fpn.py:89-97 / bifpn.py:131-138: extras[i] on pyramid level i, extras[n] on the RAW last
-    backbone map, later extras on the previous extra; both towers on every result."""
+    backbone map, later extras on the previous extra; both towers on every result.
+
+    Order of the recording (round 4): all extras first, then the towers + heads of the SMALL levels as one contiguous
+    block for the executor's side stream (one fork behind the extras, one join at the end of the plan), then the big
+    levels on the main stream -- the small levels' launch chain runs next to the big levels instead of behind them.
+    ``SSDK_LEVEL_LANES=0`` keeps everything in level order on one stream."""
+    import os
+
     n = len(pyramid)
     loc_packs, conf_packs = _tower_packs(model.loc, plan.dtype), _tower_packs(model.conf, plan.dtype)
+    levels = []
     xx = None
     for i, v in enumerate(model.extras):
         src = pyramid[i] if i < n else (raw_last if i == n else xx)
         xx = record_chain(plan, src, v, keep_input=True)
-        _record_towers(plan, xx, loc_packs, conf_packs)
+        levels.append(xx)
+    small = [xx[1] * xx[3] * xx[4] <= SMALL_LEVEL_PIXELS for xx in levels]
+    lanes = os.environ.get("SSDK_LEVEL_LANES", "1") != "0" and any(small) and not all(small)
+    if lanes and sum(10 for sm in small if sm) > 320:
+        lanes = False
+    if not lanes:
+        for i, xx in enumerate(levels):
+            _record_towers(plan, xx, loc_packs, conf_packs, level=i)
+        return
+    for i, xx in enumerate(levels):
+        if small[i]:
+            _record_towers(plan, xx, loc_packs, conf_packs, lane=2, level=i)
+    for i, xx in enumerate(levels):
+        if not small[i]:
+            _record_towers(plan, xx, loc_packs, conf_packs, lane=0, level=i)
 
 
 def _neck_inputs(model, features, image):

@@ -122,6 +122,40 @@ def test_plan_matches_reference_module(name, dtype, monkeypatch):
     print(name, dtype, "; ".join(report))
 
 
+@pytest.mark.parametrize("name,small_pixels", [("fpn_r18", 200), ("fpn_stub", 200), ("bifpn_stub", 100)])
+def test_small_levels_on_the_side_stream_change_nothing(name, small_pixels, monkeypatch):
+    """planner._record_extras_and_towers records the towers + heads of the small pyramid levels as one block for the
+    executor's side stream (next to the big levels' launches, one fork / one join).  Same kernels on the same inputs:
+    the outputs must equal those of the plan recorded in level order on one stream bit for bit, in level order."""
+    import torch
+    from ssds.modeling.layers import fused_conv as FC
+    from ssds.modeling.layers import planner
+
+    # (the golden cases are small images: lower the bar so that their levels split into big and small ones)
+    monkeypatch.setattr(planner, "SMALL_LEVEL_PIXELS", small_pixels)
+    outs, chains = {}, {}
+    for lanes in ("0", "1"):
+        monkeypatch.setenv("SSDK_LEVEL_LANES", lanes)
+        model, x, fx = nethelp.build(name)
+        model = model.cuda().to(torch.float16)
+        with torch.no_grad():
+            loc, conf = model(x.cuda().half())
+            loc2, conf2 = model(x.cuda().half())
+        plans = [p for p in model.__dict__["_neck_plans"].values() if isinstance(p, FC.ConvPlan)]
+        assert len(plans) == 1
+        chains[lanes] = plans[0].side_chain
+        n_side = sum(1 for L in plans[0].layers if L.get("lane") == 2)
+        assert (n_side >= 10) == (lanes == "1"), n_side
+        for a, b in zip(loc + conf, loc2 + conf2):
+            assert torch.equal(a, b), "replay with the side stream is not deterministic"
+        outs[lanes] = [t.clone() for t in loc + conf]
+        torch.cuda.synchronize()
+    assert chains == {"0": False, "1": True}
+    assert len(outs["0"]) == len(outs["1"])
+    for a, b in zip(outs["0"], outs["1"]):
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
 def _seeded_detector(cfg_name, dtype):
     """SSDDetector on the cfg with seeded, BatchNorm-calibrated weights (the reference's init puts every score at the
     threshold, which decides nothing)."""
