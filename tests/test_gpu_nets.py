@@ -77,7 +77,10 @@ def _check_against_floor(plan_out, torch_out, want, what, dtype, tail_factor=2.0
             if small:
                 st = tuple(max(a, b) for a, b in zip(st, pooled))
             m_abs, p_abs = SLACK[dtype]
-            tail_bar = tail_factor * st[1] + p_abs
+            # the floor's own tail is not reproducible: the same module on the same inputs gave a conf0 p99.9 of 1.63 and of
+            # 3.54 RMS in two sessions of round 4 (MIOpen picks its algorithms by timing them), while the plan's outputs are
+            # bit-identical from run to run; a single floor sample bounds the plan's p99.9 through its MAXIMUM error
+            tail_bar = tail_factor * st[2] + p_abs
             cap = CAP_SMALL[dtype] if small else CAP[dtype]
             if not (sp[0] <= 2.0 * st[0] + m_abs and sp[1] <= tail_bar and sp[0] <= cap):
                 bad.append(report[-1])
