@@ -137,7 +137,9 @@ def test_graphed_train_step_equals_the_eager_step():
         torch.testing.assert_close(l.float(), l2.float(), rtol=2e-2, atol=1e-5)
         assert not torch.equal(before, flat(mwl))
         step, step2 = flat(mwl) - before, flat(twin) - before
-        assert float((step - step2).abs().mean()) <= 0.05 * float(step2.abs().mean()) + 1e-8
+        # (the two backward passes are not bit-reproducible either: atomics in the libraries' weight-gradient kernels; the
+        #  updates agree to a few per cent of their size on average -- measured 2 % to 8 % -- a wrong or doubled step is 100 %)
+        assert float((step - step2).abs().mean()) <= 0.2 * float(step2.abs().mean()) + 1e-8
     before = flat(mwl).clone()
     bad_images = images.clone()
     bad_images[0, 0, 0, 0] = float("nan")
