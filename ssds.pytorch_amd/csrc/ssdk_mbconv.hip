@@ -371,6 +371,29 @@ __global__ __launch_bounds__(kMbThreads, LEAN4 ? 4 : 2) void mbconv_kernel(const
     for (int j = 0; j < NFH; ++j) yacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
+  // The expand GEMM's B operand (this wave's pixel fragments of the input tile) does not change from chunk to chunk: it is
+  // read from LDS ONCE per tile into registers (round 4).  The chunk loop's P1 was LDS-bandwidth bound -- per 32-channel
+  // chunk of a 16x16 tile it re-read the 42 KB of x fragments next to 32 KB of weight fragments and 21 KB of E writes.
+  // (only where the registers are there: the 16x16 instances up to Cin = 64 / Cout = 96, the long-K 8x8 instances that run
+  //  one workgroup per CU anyway; the others spill or lose their second workgroup per CU)
+  constexpr bool XREG = !STEM && !LEAN4 && MFW * KSMAX <= 10 && NFO <= 10 &&
+                        ((TS == 16 && NFO * KSMAX < 18) || (TS == 8 && TSW == 8 && KSMAX >= 3 && !(S == 2 && NFO >= 10 && HC == 64)));
+  u32x4 xreg[XREG ? MFW : 1][XREG ? KSMAX : 1];
+  if constexpr (XREG) {
+#pragma unroll
+    for (int i = 0; i < MFW; ++i) {
+      int spix = ((int)wave + kMbWaves * i) * 16 + (int)fr;
+      if (spix >= P) spix = 0;  // also covers mf >= MF: the result is not stored
+      const unsigned char* xrow = sX + (size_t)spix * XS;
+#pragma unroll
+      for (int ks = 0; ks < KSMAX; ++ks) {
+        const int k = ks * 32 + (int)fg * 8;
+        xreg[i][ks] = u32x4{0u, 0u, 0u, 0u};
+        if (ks < KS && k < Cin) xreg[i][ks] = *reinterpret_cast<const u32x4*>(xrow + k * 2);
+      }
+    }
+  }
+
   MB_STAMP();
   for (int c = 0; c < nchunks; ++c) {
     const unsigned char* wcur = sW + (size_t)(RESIDENT ? c : (c & 1)) * p.wbuf;
@@ -411,6 +434,7 @@ __global__ __launch_bounds__(kMbThreads, LEAN4 ? 4 : 2) void mbconv_kernel(const
             xf[i][ks] = u32x4{0u, 0u, 0u, 0u};
             if (ks < KS) {
               if constexpr (STEM) xf[i][ks] = *reinterpret_cast<const u32x4*>(prow + (size_t)ks * PC * 8);
+              else if constexpr (XREG) xf[i][ks] = xreg[i][ks];
               else if (k < Cin) xf[i][ks] = *reinterpret_cast<const u32x4*>(xrow + k * 2);
             }
           }
@@ -463,7 +487,8 @@ __global__ __launch_bounds__(kMbThreads, LEAN4 ? 4 : 2) void mbconv_kernel(const
               for (int jf = 0; jf < NJ; ++jf) wv[jf] = u32x4{0u, 0u, 0u, 0u};
               if constexpr (STEM) xf = *reinterpret_cast<const u32x4*>(prow + (size_t)ks * PC * 8);
               if (k < Cin) {
-                if constexpr (!STEM) xf = *reinterpret_cast<const u32x4*>(xrow + k * 2);
+                if constexpr (XREG) xf = xreg[i][ks];
+                else if constexpr (!STEM) xf = *reinterpret_cast<const u32x4*>(xrow + k * 2);
 #pragma unroll
                 for (int jf = 0; jf < NJ; ++jf) wv[jf] = *reinterpret_cast<const u32x4*>(wcur + (size_t)(jf * 16 + fr) * WES + k * 2);
               }
