@@ -19,9 +19,13 @@ enqueued on its own HIP stream and runs under the NEXT step's forward pass while
 line on the main stream.  It was the default in round 1 (+3 % with that round's decode stage); since round 2 it is
 within noise of the in-line step (round 3, same box: 45.89 / 45.90 k in line, 45.78 / 45.73 k img/s with it), so the simpler path is
 the one that is timed.  All work of the K steps completes inside the timed region (device-wide synchronize on both
-sides).  After the timed loop the last step is re-run in line (bit-equal outputs required) and, on rank 0 of an N=1 run,
-the numpy oracle decodes the GPU's own head outputs of a sample of images (must reproduce the timed detections) and the
-fp32 CPU forward of the same module is compared with the GPU's heads: all three together are `verified`.
+sides).  After the timed loop the last step is re-run in line (bit-equal outputs required: side-stream plans and the tail
+stream must not change a bit) and, on rank 0 of an N=1 run, the numpy oracle decodes the GPU's own head outputs of a sample
+of images (must reproduce the timed detections) and `forward_check` runs the timed plan's kernels on the same architecture
+with seeded O(1) weights against its fp32 CPU forward (bar: twice PyTorch-ROCm's own 16-bit error + 0.02; the per-op
+kernel names must equal the timed plan's): all three together are `verified`, and a failure of any is a SystemExit instead
+of a number.  (On the reference's init, which the timed model carries, a forward comparison decides nothing -- the box
+heads of levels 1-5 are ~1e-9 -- so those numbers are reported as `part_of_verified: false`.)
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract fields it carries
   roofline      HBM roofline of the dominant hand-written kernel of the decode stage (scan_kernel: the one pass over

@@ -22,6 +22,10 @@
  *   - tie order (unspecified in the reference's topk/sort): score descending, flat index ascending.
  *   - all box arithmetic is IEEE fp32 in the reference's operation order without FMA contraction,
  *     inputs of any dtype are upcast to fp32 first; outputs are always fp32 (box.py:430-432).
+ *   - descriptor structs (ssdk_conv_desc, ssdk_mbconv_desc, ssdk_xpair_desc, ssdk_op, ...) are ZERO-INITIALISED by the
+ *     caller before it sets the fields it knows.  New fields are only ever appended to a struct and 0 / NULL selects
+ *     the behaviour from before the field existed; entry points never change their signature (new ones are added and
+ *     SSDK_VERSION is raised).  Bind against the header the library was built with and check ssdk_version().
  */
 #ifndef SSDK_H_
 #define SSDK_H_
@@ -33,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 210 /* 0.2.1: ssdk_match_multibox_loss; descriptors gained fields (zero = old behaviour, see ssdk_op_desc) */
+#define SSDK_VERSION 210 /* 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
 
 #define SSDK_MAX_LEVELS 8    /* feature-map levels per decode_nms call            */
 #define SSDK_MAX_ANCHORS 16  /* anchors per location (A)                          */
