@@ -142,13 +142,16 @@ def relaunch_under_torchrun(args):
     os.execv(sys.executable, cmd)
 
 
-def scan_traffic_bytes():
+def scan_traffic_bytes(cfg_stem=None):
     """(HBM read bytes per scan_kernel launch, source file) from the newest committed separate `rocprofv3 --pmc
     FETCH_SIZE` pass of this command (raw KB x 1024 x 2, the gfx950 correction of MI355X_MICROARCH.md), or (None, None).
-    PMC collection cannot run inside the timed region, so this is a REPLAYED measurement: `traffic_source` names it."""
+    PMC collection cannot run inside the timed region, so this is a REPLAYED measurement: `traffic_source` names it.
+    The headline command's passes are `profiles/r*_pmc_fetch_size_v*.csv`, another configuration's carry its cfg's name
+    (`r*_pmc_fetch_size_<cfg>_v*.csv`, tools/run/profile_r04.sh)."""
     import csv
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size_*.csv")))
+    pat = "r*_pmc_fetch_size_v*.csv" if cfg_stem is None else "r*_pmc_fetch_size_%s_v*.csv" % cfg_stem
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
     for f in reversed(files):
         for row in csv.DictReader(open(f)):
             if "scan16_kernel" in row["kernel"] or "scan_kernel" in row["kernel"]:
@@ -491,8 +494,8 @@ def main():
                 "stage_frac": round(stage_bytes / (tot * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     scan_gbs = conf_bytes / (scan_ms * 1e-3) / 1e9
-    traffic, traffic_src = scan_traffic_bytes()
     is_headline = os.path.basename(args.cfg) == "ssd_mobilenetv2_512.yml" and B == 64 and args.dtype == "bf16"
+    traffic, traffic_src = scan_traffic_bytes(None if is_headline else os.path.splitext(os.path.basename(args.cfg))[0])
     roofline = {
         "kernel": "ssdk::scan16_kernel<%s> (threshold + exact top-k over the conf tensors, one pass)" % args.dtype,
         "bound": "hbm",
@@ -500,9 +503,9 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": round(scan_gbs / HBM_PEAK_GBS, 4),
-        "traffic": traffic if is_headline else None,
-        "traffic_source": (traffic_src + " (separate rocprofv3 --pmc FETCH_SIZE pass of the headline command, x2 gfx950 "
-                           "correction; not a measurement of this run)") if (traffic and is_headline) else None,
+        "traffic": traffic,
+        "traffic_source": (traffic_src + " (separate rocprofv3 --pmc FETCH_SIZE pass of this configuration's command, x2 gfx950 "
+                           "correction; not a measurement of this run)") if traffic else None,
         "algorithmic_bytes_per_launch": int(conf_bytes),
         "avg_launch_ms": round(float(scan_ms), 5),
         "timing": "hipEvents on the launch stream inside the timed region (each event pair costs ~4.6 us of GPU time "

@@ -6,9 +6,10 @@
 cd $GRAFT_REPO_ROOT
 TAG=${1:-p}; shift
 ARGS="$@"
+ARGS_ABS=$(echo "$@" | sed "s#experiments/#$GRAFT_REPO_ROOT/experiments/#g")  # (the profiler passes run from /tmp)
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-BENCH="python $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 $ARGS"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 $ARGS_ABS"
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 pass() {  # name counters...
@@ -26,6 +27,7 @@ python tools/pmc_to_csv.py $OUT/pmc_write_size.csv $OUT/write/*/*counter_collect
 python tools/pmc_to_csv.py $OUT/pmc_sq.csv $OUT/sq1/*/*counter_collection.csv $OUT/sq2/*/*counter_collection.csv
 rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/sq1 $OUT/sq2
 head -8 $OUT/kernel_stats.csv | cut -c1-150
+[ -n "$PROFILE_ONLY" ] && exit 0
 if [ -z "$ARGS" ]; then CPU=""; else CPU="--cpu-sample 4"; fi
 timeout 600 python bench.py $ARGS $CPU > $OUT/bench.json 2> $OUT/bench.err
 timeout 300 python bench.py --cpu-sample 0 --layers 1 $ARGS > $OUT/bench_layers.json 2>> $OUT/bench.err
