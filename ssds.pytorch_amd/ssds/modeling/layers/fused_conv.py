@@ -384,14 +384,27 @@ def _out_hw(h, w, k, stride):
     return (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
 
 
+def wants_frag(pack, h, w, has_residual, in_layout=N.NHWC):
+    """Whether one of the kernels that read the fragment-major weight image can take this layer -- the host-side mirror of the
+    C dispatch (csrc/ssdk_smallmap.hip launch_conv_smallmap: 3x3 on maps of <= 64 output pixels, stride 1 | 2;
+    csrc/ssdk_conv3x3s.hip launch_conv3x3_short: 3x3 / stride 1, NHWC input, Cin a multiple of 32 up to 128 -- or 256 on maps
+    of <= 2500 pixels --, Cout >= 96, no residual, a map of >= 128 pixels and >= 8 columns).  Everything else (the ResNet /
+    RegNet backbone 3x3s, the 80x80 tower layers) stays on kernels that read the KRSC tensor and carries no second copy."""
+    if pack.kind != "dense" or pack.k != 3:
+        return False
+    ho, wo = _out_hw(h, w, pack.k, pack.stride)
+    if ho * wo <= 64:  # conv_smallmap_kernel (stride 2: the first SSD extra, 16x16 -> 8x8)
+        return True
+    if pack.stride != 1 or has_residual or in_layout != N.NHWC:
+        return False
+    short_k = pack.cin % 32 == 0 and (pack.cin <= 128 or (pack.cin == 256 and h * w <= 2500))
+    return short_k and pack.cout >= 96 and h * w >= 128 and w >= 8
+
+
 def fill_desc(d, x_ptr, n, h, w, pack, dtype_code, act, y_ptr, in_layout=N.NHWC, out_layout=N.NHWC,
               residual_ptr=None, y2_ptr=None, split=None, act2=None):
     d.x, d.w = x_ptr, pack.w.data_ptr()
-    # small maps: the kernel streams weights into operand registers and wants them fragment-major (conv_smallmap_kernel)
-    # conv3x3_short_kernel (Cin <= 128, 256) reads its weight fragments from the same image
-    # stride 2 onto a small map (the first SSD extra, 16x16 -> 8x8): the stride-2 instance of conv_smallmap_kernel
-    frag = pack.frag() if (pack.kind == "dense" and pack.k == 3 and (
-        (pack.stride == 1 and (h * w <= 64 or pack.cin <= 128 or pack.cin == 256)) or (pack.stride == 2 and h * w <= 256))) else None
+    frag = pack.frag() if wants_frag(pack, h, w, residual_ptr is not None, in_layout) else None
     d.w_frag = frag.data_ptr() if frag is not None else None
     d.scale = pack.scale.data_ptr() if pack.scale is not None else None
     d.bias = pack.bias.data_ptr()

@@ -1010,3 +1010,59 @@ def test_soak_three_queues_against_in_line_with_poisoned_lds():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     rec = json.loads(r.stdout.strip().splitlines()[-1])
     assert rec["batches"] >= 5000 and rec["mismatching_batches"] == 0 and rec["lds_poison"] == "1", rec
+
+
+def test_grouped_small_map_launch_respects_buffer_reuse():
+    """The executor puts neighbouring small-map layers that are independent into ONE launch.  On an FPN level of 8x8 at
+    batch 96 (6144 output pixels: the heads stay on lane 0) the loc head reads the last tower buffer, that buffer is released
+    and the next op -- the conf tower's first layer, which reads the level input -- may be given it as its OUTPUT: head and
+    layer are not independent (write-after-read), whichever buffer the arena picks.  The plan's outputs must equal the same
+    layers launched one by one, and the plan must have grouped something."""
+    import torch
+    import torch.nn as nn
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+    from ssds.modeling.layers import planner
+
+    torch.manual_seed(5)
+    dtype = torch.float16
+
+    def pack(cout, act, bn=True):
+        conv = nn.Conv2d(256, cout, 3, 1, 1, bias=not bn)
+        conv.weight.data.mul_(0.5)
+        b = nn.BatchNorm2d(cout) if bn else None
+        if bn:
+            b.running_mean.normal_(0, 0.1)
+            b.running_var.uniform_(0.5, 1.5)
+            b.eval()
+        return FC.ConvPack(conv.cuda(), b.cuda() if bn else None, act, dtype)
+
+    loc = ([pack(256, "relu") for _ in range(4)], pack(36, "none", bn=False))
+    conf = ([pack(256, "relu") for _ in range(4)], pack(180, "none", bn=False))
+    x = torch.randn(96, 256, 8, 8).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    plan = FC.ConvPlan(x.device, dtype)
+    xx = plan.add_input(x.shape)
+    planner._record_towers(plan, xx, loc, conf)
+    plan.finalize()
+    assert all(not L.get("lane") for L in plan.layers), "the heads of this level are expected in line"
+    (l_plan,), (c_plan,) = plan.run(x)
+    (l_again,), (c_again,) = plan.run(x)
+    plan.ctx.set_op_profiling(True)
+    plan.run(x)
+    torch.cuda.synchronize()
+    kernels = [k for k, _ in plan.ctx.op_timings()]
+    plan.ctx.set_op_profiling(False)
+    assert any("group" in k for k in kernels), kernels
+
+    def chain(body_final, act):
+        body, final = body_final
+        cur = x
+        for pk in body:
+            cur = FC.conv_native(cur, pk)
+            assert N.last_kernel() == "conv_smallmap_kernel", N.last_kernel()
+        return FC.conv_native(cur, final, act=act, nchw_out=True)
+
+    l_ref, c_ref = chain(loc, "none"), chain(conf, "sigmoid")
+    assert torch.equal(l_plan, l_ref) and torch.equal(c_plan, c_ref)
+    assert torch.equal(l_again, l_ref) and torch.equal(c_again, c_ref)
+
