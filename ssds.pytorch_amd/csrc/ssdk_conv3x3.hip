@@ -48,7 +48,8 @@ struct HaloParams {
   unsigned mg_ks;            // (grids too small to fill the chip: few pixels, long K -- the 8x8 ... 4x4 head levels)
   float* slabs;              // [tile][slice][16 fragments][512 lanes][4] fp32 partial accumulators
   unsigned* counters;        // [tile] arrival tickets, zero on entry, re-armed by the last arriver
-  long long* dbg;             // SSDK_H3_DBG=1: cycle stamps of workgroup 0 / wave 0 (4 per k-step)
+  long long* dbg;             // SSDK_H3_DBG=1: cycle stamps of one workgroup / wave 0 (4 per k-step)
+  unsigned dbg_wg;            // which workgroup is stamped (SSDK_H3_DBG_WG: 0 = the first, cold one; -1 = the last to start)
   int swz;                    // LDS bank swizzle: 1 = (chunk + row) & 7 (round 4), 0 = chunk ^ (row >> 1) (A/B runs)
 };
 
@@ -58,7 +59,7 @@ __device__ __forceinline__ u32 fdiv(u32 n, u32 d, u32 M) { return d == 1u ? n : 
 #define H3_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define H3_STAMP(slot)                                                                      \
   do {                                                                                      \
-    if (hp.dbg && blockIdx.x == 0 && tid == 0 && stamp_i < 60)                              \
+    if (hp.dbg && blockIdx.x == hp.dbg_wg && tid == 0 && stamp_i < 60)                              \
       hp.dbg[stamp_i * 4 + (slot)] = (long long)__builtin_readcyclecounter();               \
   } while (0)
 
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
   const u32 tid = threadIdx.x, lane = tid & 63u;
 #define H3_MARK(slot)                                                                                   \
   do {                                                                                                  \
-    if (hp.dbg && blockIdx.x == 0 && tid == 0) hp.dbg[240 + (slot)] = (long long)__builtin_readcyclecounter(); \
+    if (hp.dbg && blockIdx.x == hp.dbg_wg && tid == 0) hp.dbg[240 + (slot)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
   H3_MARK(0);
   const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -558,9 +559,12 @@ int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool
   }
   static const int dbg = getenv("SSDK_H3_DBG") ? atoi(getenv("SSDK_H3_DBG")) : 0;
   hp.dbg = nullptr;
+  hp.dbg_wg = 0;
   static const int env_swz = getenv("SSDK_H3_SWZ") ? atoi(getenv("SSDK_H3_SWZ")) : 1;
   hp.swz = env_swz ? 1 : 0;
   if (dbg) {
+    static const int dbg_wg = getenv("SSDK_H3_DBG_WG") ? atoi(getenv("SSDK_H3_DBG_WG")) : 0;
+    hp.dbg_wg = dbg_wg < 0 ? (unsigned)(tiles - 1) : (unsigned)dbg_wg;
     (void)hipMalloc((void**)&hp.dbg, 64 * 4 * sizeof(long long));
     (void)hipMemsetAsync(hp.dbg, 0, 64 * 4 * sizeof(long long), stream);
   }
