@@ -453,9 +453,9 @@ int ssdk_xpair(const ssdk_xpair_desc* desc, void* stream);
  * call, else everything runs in line); they use the upper half of the workspace, and everything is joined back onto
  * the caller's stream before the call returns.  lane 1: leaves (the multibox heads) -- next to the main chain an
  * underfilled grid is free, so the kernel choice may differ from the in-line one.  lane 2 (version 210): chains (the
- * towers + heads of the small pyramid levels next to the big levels' launches) -- exactly the kernels the op gets in line,
- * so the outputs do not depend on whether the side lane is on.  Buffers read or written by side ops must not be reused
- * by later ops of the list. */
+ * towers + heads of the small pyramid levels next to the big levels' launches) -- the kernel choice for an op that may
+ * underfill the chip (no split-K), made from the tag alone, so the outputs do not depend on whether the side lane is on.
+ * Buffers read or written by side ops must not be reused by later ops of the list. */
 enum { SSDK_OP_CONV = 0, SSDK_OP_MBCONV = 1, SSDK_OP_FUSE = 2, SSDK_OP_STEM7 = 3, SSDK_OP_POOL = 4, SSDK_OP_XPAIR = 5 };
 typedef struct ssdk_op {
   int32_t kind, lane;

@@ -1552,9 +1552,13 @@ extern "C" int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* 
     if (!rc) {
       ssdk::lds_poison(st);
       if (ops[i].kind == SSDK_OP_CONV) {
-        // lane 1 (leaf heads): an underfilled grid is free next to the main chain, so the kernel choice may differ from
-        // the in-line one; lane 2 (chains of small-level layers): the kernels the op would get in line, bit for bit
-        g_underfill_ok = side && ops[i].lane == 1;
+        // lane 1 (leaf heads): next to the main chain an underfilled grid is free, so on the side stream the kernel choice differs
+        // from the in-line one.  lane 2 (chains of small-level layers): ALWAYS the choice for an op that may underfill the chip
+        // (an unsplit halo launch of 32 workgroups instead of 128 split-K ones that each take a whole CU's LDS and exchange
+        // 640 KB of slabs per tile: FPN-ResNet50@640 3 225 -> 3 281 img/s) -- tied to the op's tag, not to whether the side
+        // stream is in use, so the outputs are the same bits either way (SSDK_LANE2_UNDERFILL=0: the in-line choice).
+        static const int env_l2 = getenv("SSDK_LANE2_UNDERFILL") ? atoi(getenv("SSDK_LANE2_UNDERFILL")) : 1;
+        g_underfill_ok = (side && ops[i].lane == 1) || (env_l2 && ops[i].lane == 2);
         rc = ssdk_conv(&ops[i].conv, w, wb, st);
         g_underfill_ok = false;
       }
