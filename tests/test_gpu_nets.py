@@ -128,15 +128,18 @@ def test_plan_matches_reference_module(name, dtype, monkeypatch):
 @pytest.mark.parametrize("name,small_pixels", [("fpn_r18", 200), ("fpn_stub", 200), ("bifpn_stub", 100)])
 def test_small_levels_on_the_side_stream_change_nothing(name, small_pixels, monkeypatch):
     """planner._record_extras_and_towers records the towers + heads of the small pyramid levels as one block for the
-    executor's side stream (next to the big levels' launches, one fork / one join).  Same kernels on the same inputs:
-    the outputs must equal those of the plan recorded in level order on one stream bit for bit, in level order."""
+    executor's side stream (next to the big levels' launches, one fork / one join).  (1) The same recording with the side lane
+    switched off must give the same BITS (lane-2 ops pick their kernels by their tag, not by the stream they run on: this is
+    what bench.py's in-line re-run relies on), in level order, replay after replay.  (2) Against the plan recorded in level
+    order on one stream -- where the small levels may get other kernels (split-K instead of an underfilled grid) -- the
+    outputs agree to rounding."""
     import torch
     from ssds.modeling.layers import fused_conv as FC
     from ssds.modeling.layers import planner
 
     # (the golden cases are small images: lower the bar so that their levels split into big and small ones)
     monkeypatch.setattr(planner, "SMALL_LEVEL_PIXELS", small_pixels)
-    outs, chains = {}, {}
+    outs = {}
     for lanes in ("0", "1"):
         monkeypatch.setenv("SSDK_LEVEL_LANES", lanes)
         model, x, fx = nethelp.build(name)
@@ -146,17 +149,25 @@ def test_small_levels_on_the_side_stream_change_nothing(name, small_pixels, monk
             loc2, conf2 = model(x.cuda().half())
         plans = [p for p in model.__dict__["_neck_plans"].values() if isinstance(p, FC.ConvPlan)]
         assert len(plans) == 1
-        chains[lanes] = plans[0].side_chain
+        assert plans[0].side_chain == (lanes == "1")
         n_side = sum(1 for L in plans[0].layers if L.get("lane") == 2)
         assert (n_side >= 10) == (lanes == "1"), n_side
         for a, b in zip(loc + conf, loc2 + conf2):
-            assert torch.equal(a, b), "replay with the side stream is not deterministic"
+            assert torch.equal(a, b), "replay is not deterministic"
         outs[lanes] = [t.clone() for t in loc + conf]
+        if lanes == "1":  # the same plan, everything in line on the caller's stream
+            plans[0].ctx.set_side_lane(False)
+            with torch.no_grad():
+                loc3, conf3 = model(x.cuda().half())
+            for a, b in zip(loc + conf, loc3 + conf3):
+                assert a.shape == b.shape and torch.equal(a, b), "the side stream changed the result"
+            plans[0].ctx.set_side_lane(True)
         torch.cuda.synchronize()
-    assert chains == {"0": False, "1": True}
     assert len(outs["0"]) == len(outs["1"])
     for a, b in zip(outs["0"], outs["1"]):
-        assert a.shape == b.shape and torch.equal(a, b)
+        assert a.shape == b.shape
+        err = float((a.float() - b.float()).abs().max())
+        assert err <= 4e-3 * max(1.0, float(b.float().abs().max())), err
 
 
 def _seeded_detector(cfg_name, dtype):

@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for v in "SSDK_LANE2_UNDERFILL=1" "SSDK_LANE2_UNDERFILL=0" "SSDK_LANE2_UNDERFILL=1" "SSDK_LANE2_UNDERFILL=0"; do
-for c in "--cfg experiments/cfgs/fpn_resnet50_640.yml --batch 32" "--cfg experiments/cfgs/bifpn_regnetx008_896.yml --batch 16 --dtype fp16"; do
-  echo -n "$v $c: "; env $v timeout 300 python bench.py --cpu-sample 0 $c 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['verified'])"
-done; done
+timeout 900 python -m pytest tests/test_gpu_nets.py tests/test_gpu_conv.py tests/test_gpu_bench_sizes.py -x -q -m gpu 2>&1 | tail -8
