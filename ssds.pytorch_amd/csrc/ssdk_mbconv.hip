@@ -374,10 +374,11 @@ __global__ __launch_bounds__(kMbThreads, LEAN4 ? 4 : 2) void mbconv_kernel(const
   // The expand GEMM's B operand (this wave's pixel fragments of the input tile) does not change from chunk to chunk: it is
   // read from LDS ONCE per tile into registers (round 4).  The chunk loop's P1 was LDS-bandwidth bound -- per 32-channel
   // chunk of a 16x16 tile it re-read the 42 KB of x fragments next to 32 KB of weight fragments and 21 KB of E writes.
-  // (only where the registers are there: the 16x16 instances up to Cin = 64 / Cout = 96, the long-K 8x8 instances that run
-  //  one workgroup per CU anyway; the others spill or lose their second workgroup per CU)
+  // (only where the registers are there: the 16x16 instances up to Cin = 96 / Cout = 96 -- the 96-channel one holds 256 VGPRs and
+  //  48 B of scratch with it and is still 1-3 us faster --, the long-K 8x8 instances that run one workgroup per CU anyway; the
+  //  others spill more or lose their second workgroup per CU)
   constexpr bool XREG = !STEM && !LEAN4 && MFW * KSMAX <= 10 && NFO <= 10 &&
-                        ((TS == 16 && NFO * KSMAX < 18) || (TS == 8 && TSW == 8 && KSMAX >= 3 && !(S == 2 && NFO >= 10 && HC == 64)));
+                        ((TS == 16 && NFO * KSMAX <= 18) || (TS == 8 && TSW == 8 && KSMAX >= 3 && !(S == 2 && NFO >= 10 && HC == 64)));
   u32x4 xreg[XREG ? MFW : 1][XREG ? KSMAX : 1];
   if constexpr (XREG) {
 #pragma unroll
