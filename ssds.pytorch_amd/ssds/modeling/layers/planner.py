@@ -286,10 +286,12 @@ def _record_towers(plan, xx, loc_packs, conf_packs, lane=None, level=None):
             plan.release(cur)
 
 
-# pixels (batch x H x W) up to which a pyramid level counts as small: its tower layers are a few dozen workgroups each,
-# a chain of latency-bound launches (FPN-ResNet50@640, batch 32: the 20x20, 10x10 and 5x5 levels are 30 launches, 0.85 ms
-# one after the other, next to 3.3 ms of chip-filling launches on the two big levels)
-SMALL_LEVEL_PIXELS = 16384
+# pixels (batch x H x W) up to which a pyramid level goes to the side stream.  The 20x20, 10x10 and 5x5 levels of
+# FPN-ResNet50@640 at batch 32 are 30 launches of a few dozen workgroups each, 0.85 ms one after the other, next to 3.3 ms of
+# chip-filling launches on the two big levels (16384: +4 %); with the 40x40 level (51 200 pixels) on the side stream as well
+# only the largest level stays in line and the two streams' launches fill each other's tails: another +1.9 % there, +2.3 % on
+# BiFPN-RegNetX008@896 (measured, same box; SSDK_SMALL_LEVEL_PIXELS overrides).
+SMALL_LEVEL_PIXELS = 65536
 
 
 def _record_extras_and_towers(plan, model, pyramid, raw_last):
@@ -310,7 +312,8 @@ def _record_extras_and_towers(plan, model, pyramid, raw_last):
         src = pyramid[i] if i < n else (raw_last if i == n else xx)
         xx = record_chain(plan, src, v, keep_input=True)
         levels.append(xx)
-    small = [xx[1] * xx[3] * xx[4] <= SMALL_LEVEL_PIXELS for xx in levels]
+    limit = int(os.environ.get("SSDK_SMALL_LEVEL_PIXELS", SMALL_LEVEL_PIXELS))
+    small = [xx[1] * xx[3] * xx[4] <= limit for xx in levels]
     lanes = os.environ.get("SSDK_LEVEL_LANES", "1") != "0" and any(small) and not all(small)
     if lanes and sum(10 for sm in small if sm) > 320:
         lanes = False
