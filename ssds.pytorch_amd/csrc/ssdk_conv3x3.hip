@@ -197,8 +197,25 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
   for (int t = 0; t < H3_NPIECE; ++t) load_a(t, c0);
   load_b(0, c0, 0);
   load_b(1, c0, 1);
+  // per-column scale / bias of this lane's four accumulator columns (epilogue).  Requested HERE, behind the prologue's LDS-DMA
+  // loads: at the top of the kernel the compiler waits for every ordinary VGPR load before the first buffer_load ... lds is
+  // issued (a whole memory round trip in the set-up of every workgroup), in the epilogue -- rounds 1-3 -- the round trip was
+  // exposed there (~2 k of its 7.5 k cycles); here it rides under the wait for the first tile.
+  // (eight unconditional loads from clamped indices, issued back to back; the selects happen in the epilogue -- written with
+  //  the loads inside `if (n < Cout)` the compiler put an s_waitcnt vmcnt(0) behind every pair: four round trips in a row)
+  float ld_sc[4], ld_bi[4];
+  {
+    const float* scp = p.scale ? p.scale : p.bias;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u32 n = n0 + wn * 64u + j * 16 + (lane & 15u);
+      n = n < (u32)p.Cout ? n : (u32)p.Cout - 1u;
+      ld_sc[j] = scp[n];
+      ld_bi[j] = p.bias[n];
+    }
+  }
   H3_MARK(1);
-  H3_WAIT(2);  // everything but the weights of step 1
+  H3_WAIT(10);  // everything but the weights of step 1 and the eight scale / bias loads behind them
   __builtin_amdgcn_s_barrier();
   H3_MARK(2);
 
@@ -311,19 +328,12 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
-  // per-column scale / bias of this lane's four accumulator columns.  (Requested here, not at the top of the kernel: beside
-  // LDS-DMA the compiler waits for every ordinary VGPR load before the first buffer_load ... lds is issued, which put a
-  // whole memory round trip into the set-up of every workgroup.)
   float e_sc[4], e_bi[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const u32 n = n0 + wn * 64u + j * 16 + (lane & 15u);
-    e_sc[j] = 1.f;
-    e_bi[j] = 0.f;
-    if (n < (u32)p.Cout) {
-      if (p.scale) e_sc[j] = p.scale[n];
-      e_bi[j] = p.bias[n];
-    }
+    e_sc[j] = (n < (u32)p.Cout && p.scale) ? ld_sc[j] : 1.f;
+    e_bi[j] = n < (u32)p.Cout ? ld_bi[j] : 0.f;
   }
   u16* sC = reinterpret_cast<u16*>(smem);
   const bool nchw = p.out_layout == LAYOUT_NCHW;
