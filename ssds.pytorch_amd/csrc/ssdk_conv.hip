@@ -147,6 +147,20 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const u32 fr = lane & 15u, fg = lane >> 4;
+  // per-column scale / bias of the epilogue: requested FIRST, unconditionally, from clamped indices (selects in the epilogue).
+  // Loaded inside the epilogue's column loop under `if (n < Cout)` they were FN dependent memory round trips at the end of every
+  // tile (the compiler drains vmcnt behind each conditional pair) -- a third of a short-K tile's time (round 4).
+  float ld_sc[FN], ld_bi[FN];
+  {
+    const float* scp = p.scale ? p.scale : p.bias;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      u32 n = n0 + wn * (FN * 16) + j * 16 + fr;
+      n = n < (u32)p.Cout ? n : (u32)p.Cout - 1u;
+      ld_sc[j] = scp[n];
+      ld_bi[j] = p.bias[n];
+    }
+  }
   load_tile();
   store_tile(0);
   __syncthreads();
@@ -237,13 +251,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_gemm_kernel(const ConvParam
   for (int j = 0; j < FN; ++j) {
     const u32 nl = wn * (FN * 16) + j * 16 + fr;
     const u32 n = n0 + nl;
-    float sc = 1.f, bi = 0.f;
-    int act = p.act;
-    if (n < (u32)p.Cout) {
-      if (p.scale) sc = p.scale[n];
-      bi = p.bias[n];
-      if ((int)n >= p.split) act = p.act2;
-    }
+    const bool col = n < (u32)p.Cout;
+    const float sc = (col && p.scale) ? ld_sc[j] : 1.f, bi = col ? ld_bi[j] : 0.f;
+    const int act = (col && (int)n >= p.split) ? p.act2 : p.act;
     const ActSel as = act_sel(act);
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
