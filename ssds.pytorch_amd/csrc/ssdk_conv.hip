@@ -675,6 +675,19 @@ __global__ __launch_bounds__(G2_THREADS) void conv_gemm256_kernel(const ConvPara
   constexpr int LDC_M = 128 + 8;      // NHWC image sC[m][n-local]
   constexpr int LDC_N = G2_BM + 8;    // NCHW image sC[n-local][m]
   const u32 hw = (u32)(p.Ho * p.Wo);
+  // this wave's eight per-column constants in ONE round trip (unconditional loads from clamped indices; inside the column loop
+  // under `if (n < Cout)` they were four dependent round trips per wave)
+  float ld_sc[4], ld_bi[4];
+  {
+    const float* scp = p.scale ? p.scale : p.bias;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u32 n = n0 + (wn >> 1) * 128u + (wn & 1u) * 64u + j * 16 + fr;
+      n = n < (u32)p.Cout ? n : (u32)p.Cout - 1u;
+      ld_sc[j] = scp[n];
+      ld_bi[j] = p.bias[n];
+    }
+  }
   for (u32 half = 0; half < 2; ++half) {
     if (n0 + half * 128u >= (u32)p.Cout) break;  // workgroup-uniform
     if ((wn >> 1) == half) {
@@ -684,13 +697,9 @@ __global__ __launch_bounds__(G2_THREADS) void conv_gemm256_kernel(const ConvPara
       for (int j = 0; j < 4; ++j) {
         const u32 nl = (wn & 1u) * 64u + j * 16 + fr;
         const u32 n = n0 + half * 128u + nl;
-        float sc = 1.f, bi = 0.f;
-        int act = p.act;
-        if (n < (u32)p.Cout) {
-          if (p.scale) sc = p.scale[n];
-          bi = p.bias[n];
-          if ((int)n >= p.split) act = p.act2;
-        }
+        const bool col = n < (u32)p.Cout;
+        const float sc = (col && p.scale) ? ld_sc[j] : 1.f, bi = col ? ld_bi[j] : 0.f;
+        const int act = (col && (int)n >= p.split) ? p.act2 : p.act;
         const ActSel as = act_sel(act);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
