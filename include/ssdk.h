@@ -222,7 +222,9 @@ int ssdk_match_loss(const float* targets, int B, int G, const float* anchors, in
  * instead of the reference's two full sorts per level: match + positives' terms + hardness keys, a per-image radix select
  * of the num_neg-th largest key (ties between EQUAL keys are kept in index order; torch's unstable sort leaves that
  * choice unspecified), the mined negatives' terms and gradients; then the fixed-order reduction.  sums / d_conf / d_loc /
- * loc_loss / by_scale / thr_* / radius exactly as ssdk_match_loss; sums[0] = sum over positives and mined negatives. */
+ * loc_loss / by_scale / thr_* / radius exactly as ssdk_match_loss; sums[0] = sum over positives and mined negatives.
+ * A mined negative's term is BCE against the anchor's OWN one-hot target: all zeros for a background anchor, one-hot for an
+ * anchor that matched a box but lies outside the centre-sampling region (depth 0 with a class target, box.py:183-207). */
 size_t ssdk_match_multibox_loss_workspace_bytes(int B, int A, int H, int W);
 int ssdk_match_multibox_loss(const float* targets, int B, int G, const float* anchors, int A, int C, int H, int W,
                              int stride, int by_scale, float thr_a, float thr_b, float radius, const void* conf,

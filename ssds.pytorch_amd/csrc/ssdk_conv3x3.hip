@@ -204,6 +204,11 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
   // (eight unconditional loads from clamped indices, issued back to back; the selects happen in the epilogue -- written with
   //  the loads inside `if (n < Cout)` the compiler put an s_waitcnt vmcnt(0) behind every pair: four round trips in a row)
   float ld_sc[4], ld_bi[4];
+  // H3_WAIT(10) below counts on this ORDER (nine tile loads, then 2 + 8 younger requests): pinned for the IR passes (memory
+  // clobber) and for the machine scheduler (sched_barrier) -- a constant load hoisted above a tile load would let the
+  // barrier pass before that tile has landed
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
   {
     const float* scp = p.scale ? p.scale : p.bias;
 #pragma unroll
@@ -214,6 +219,8 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
       ld_bi[j] = p.bias[n];
     }
   }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
   H3_MARK(1);
   H3_WAIT(10);  // everything but the weights of step 1 and the eight scale / bias loads behind them
   __builtin_amdgcn_s_barrier();

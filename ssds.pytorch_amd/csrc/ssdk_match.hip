@@ -34,8 +34,12 @@ struct MatchParams {
   float* partial;    // [gridDim.y * gridDim.x, 3]: cls sum, loc sum, #foreground
   float alpha, gamma, beta;
   int loc_loss;  // 0: smooth-L1(beta); 1..4: IoU / GIoU / DIoU / CIoU on the deltas (criterion.py:154-239)
-  // MultiBoxLoss mode (LOSS = 2): hardness keys of the negatives, [B, A*H*W] words
+  // MultiBoxLoss mode (LOSS = 2): hardness keys of the negatives, [B, A*H*W] words, and the label the one-hot target of every
+  // anchor carries (C = none), [B, A*H*W] halfwords: a mined negative is NOT always an all-zero target -- with IoU matching
+  // and center_sampling_radius > 0 an anchor that overlaps a box by >= the match threshold but lies outside the sampling
+  // region has depth 0 (box.py:183-191) and keeps its one-hot class target (box.py:195-207)
   u32* keys;
+  u16* labs;
 };
 
 struct GtRow {
@@ -319,6 +323,7 @@ __global__ __launch_bounds__(kMatchThreads) void match_kernel(const MatchParams 
       }
       // ce >= 0, so the float bits order like the values; +1 keeps 0 for "never ranks" (positives, ignored: :61)
       p.keys[(size_t)b * total + t] = dep == 0.f ? __float_as_uint(hard) + 1u : 0u;
+      p.labs[(size_t)b * total + t] = (u16)lab;
     } else {
     const bool care = dep >= 0.f;
     const bool g2 = p.gamma == 2.0f;
@@ -523,7 +528,9 @@ __global__ __launch_bounds__(kMineThreads) void mine_select_kernel(u32* keys, in
   }
 }
 
-// the mined negatives' terms: all-zero target (depth == 0 means background), so L = softplus(z), dL/dz = sigmoid(z)
+// the mined negatives' terms: BCE with logits against the anchor's one-hot target (criterion.py:56, 69-71) -- all zeros for a
+// background anchor (L = softplus(z), dL/dz = sigmoid(z)), one-hot at `lab` for an anchor that matched a box but fell outside
+// the centre-sampling region (depth 0 with a class target: box.py:183-207)
 template <int DT>
 __global__ __launch_bounds__(kMatchThreads) void mine_apply_kernel(const MatchParams p, float* partial) {
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -535,13 +542,14 @@ __global__ __launch_bounds__(kMatchThreads) void mine_apply_kernel(const MatchPa
   if (t < total && p.keys[(size_t)b * total + t] != 0u) {
     const u32 a = t / HW, yx = t % HW;
     const size_t cls_i = (((size_t)b * p.A + a) * p.C) * HW + yx;
+    const int lab = (int)p.labs[(size_t)b * total + t];
     for (int c = 0; c < p.C; ++c) {
       const size_t i = cls_i + (size_t)c * HW;
       const float z = ld_elem<DT>(p.conf, i);
       const float e = expf(-fabsf(z));
       const float inv = 1.0f / (1.0f + e);
-      s_cls += tmax(z, 0.f) + log1pf(e);
-      st_elem<DT>(p.d_conf, i, z >= 0.f ? inv : e * inv);
+      s_cls += tmax(z, 0.f) - (c == lab ? z : 0.f) + log1pf(e);
+      st_elem<DT>(p.d_conf, i, (z >= 0.f ? inv : e * inv) - (c == lab ? 1.0f : 0.f));
     }
   }
   __shared__ float red[kMatchThreads / 64];
@@ -648,6 +656,10 @@ static int run_match_loss(const char* what, int cls_kind, const float* targets, 
     set_error("%s: dtype %d not supported", what, dtype);
     return SSDK_E_BADARG;
   }
+  if (cls_kind == 1 && C > 65534) {  // (the mined pass reads every anchor's target label from a 16-bit side array)
+    set_error("%s: C=%d classes (<= 65534)", what, C);
+    return SSDK_E_BADARG;
+  }
   const size_t need = cls_kind == 1 ? ssdk_match_multibox_loss_workspace_bytes(B, A, H, W)
                                     : ssdk_match_loss_workspace_bytes(B, A, H, W);
   if (workspace_bytes < need) {
@@ -701,6 +713,7 @@ static int run_match_loss(const char* what, int cls_kind, const float* targets, 
   // from the mined negatives; the keys follow
   float* partial2 = p.partial + rows * 3;
   p.keys = (u32*)((char*)workspace + align256(2 * rows * 3 * sizeof(float)));
+  p.labs = (u16*)((char*)p.keys + align256((size_t)B * total * sizeof(u32)));
   if (dtype == SSDK_BF16) hipLaunchKernelGGL((match_kernel<2, SSDK_BF16>), grid, dim3(kMatchThreads), 0, st, p);
   else if (dtype == SSDK_F16) hipLaunchKernelGGL((match_kernel<2, SSDK_F16>), grid, dim3(kMatchThreads), 0, st, p);
   else hipLaunchKernelGGL((match_kernel<2, SSDK_F32>), grid, dim3(kMatchThreads), 0, st, p);
@@ -727,7 +740,8 @@ extern "C" size_t ssdk_match_loss_workspace_bytes(int B, int A, int H, int W) {
 
 extern "C" size_t ssdk_match_multibox_loss_workspace_bytes(int B, int A, int H, int W) {
   if (B < 1 || A < 1 || H < 1 || W < 1) return 0;
-  return ssdk::align256(2 * ssdk::match_rows(B, A, H, W) * 3 * sizeof(float)) + (size_t)B * A * H * W * sizeof(unsigned);
+  return ssdk::align256(2 * ssdk::match_rows(B, A, H, W) * 3 * sizeof(float)) +
+         ssdk::align256((size_t)B * A * H * W * sizeof(unsigned)) + (size_t)B * A * H * W * sizeof(unsigned short);
 }
 
 extern "C" int ssdk_match_loss(const float* targets, int B, int G, const float* anchors, int A, int C, int H,

@@ -253,7 +253,21 @@ class Context(object):
               "ctx_set_tail_stream")
 
     def set_side_lane(self, on):
+        """True / False: the caller's explicit choice (a plan with side-stream chains respects it); None: back to the default
+        (SSDK_SIDE_STREAM, and a plan that recorded side-stream chains turns the lane on again by itself)."""
+        self.side_user = None if on is None else bool(on)
+        self.side_auto = False
         check(self._call(lib.ssdk_ctx_set_side_lane, -1 if on is None else int(bool(on))), "ctx_set_side_lane")
+
+    def auto_side_lane(self):
+        """A plan whose small pyramid levels were recorded for the side stream (fused_conv.ConvPlan.launch): on, unless the
+        caller chose (set_side_lane True / False) or the environment says SSDK_SIDE_STREAM=0."""
+        if getattr(self, "side_user", None) is not None or getattr(self, "side_auto", False):
+            return
+        if os.environ.get("SSDK_SIDE_STREAM", "") == "0":
+            return
+        check(self._call(lib.ssdk_ctx_set_side_lane, 1), "ctx_set_side_lane")
+        self.side_auto = True
 
     def set_profiling(self, on):
         """True / 1: hipEvents around every launch of the decode stage; 2: ONE interval around the whole stage (no event

@@ -856,9 +856,8 @@ class ConvPlan(object):
             return
         ops = self.ops if lo == 0 else (N.Op * (hi - lo)).from_address(ctypes.addressof(self.ops) + lo * ctypes.sizeof(N.Op))
         sp = N.stream_ptr(self.device) if stream is None else ctypes.c_void_p(stream.cuda_stream)
-        if self.side_chain and not getattr(self, "_side_set", False):
-            self.ctx.set_side_lane(True)  # (SSDK_LEVEL_LANES=0 records no chains: planner._record_extras_and_towers)
-            self._side_set = True
+        if self.side_chain:  # (SSDK_LEVEL_LANES=0 records no chains: planner._record_extras_and_towers)
+            self.ctx.auto_side_lane()  # on by default; an explicit set_side_lane(False) / SSDK_SIDE_STREAM=0 is respected
         with torch.cuda.device(self.device):
             if self.ws is not None:
                 wptr = (self.ws.data_ptr() + 255) & ~255

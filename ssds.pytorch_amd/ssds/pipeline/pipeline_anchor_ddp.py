@@ -106,15 +106,34 @@ def _device_skip(optimizer):
     return len(optimizer.param_groups) > 0 and all(g.get("fused") for g in optimizer.param_groups)
 
 
+def _ensure_momentum_buffers(optimizer):
+    """Zero momentum buffers for every parameter that has none yet.  torch's fused SGD allocates them with ``empty_like``
+    inside its first step and returns early when ``found_inf`` is set: a skipped FIRST step would leave uninitialised
+    memory behind as momentum.  With zero buffers in place the first real step computes ``0 * momentum + grad`` -- exactly
+    the first-step rule (dampening is 0 in core/optimizer.configure_optimizer)."""
+    for group in optimizer.param_groups:
+        if not group.get("momentum"):
+            continue
+        for p in group["params"]:
+            if p.requires_grad and "momentum_buffer" not in optimizer.state[p]:
+                optimizer.state[p]["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+
 def _step_unless(optimizer, bad):
     """optimizer.step() unless ``bad`` (a 0/1 float tensor) is set.  Fused optimizers (core/optimizer.py on a HIP device) read
     the flag on the DEVICE (``found_inf``, the hook GradScaler uses): no host synchronisation in the step at all, and the step
     can be captured in a hipGraph.  Anything else reads the flag back -- the one host sync of the step.  Returns the flag (a
     tensor on the fused path: it is only converted where somebody prints it)."""
     if _device_skip(optimizer):
+        if not torch.cuda.is_current_stream_capturing():
+            _ensure_momentum_buffers(optimizer)  # (a captured step was warmed up: its buffers exist)
         optimizer.grad_scale = None
         optimizer.found_inf = bad.reshape(1)
-        optimizer.step()
+        try:
+            optimizer.step()
+        finally:  # like GradScaler: a later plain optimizer.step() must not see this step's flag
+            del optimizer.found_inf
+            del optimizer.grad_scale
         return bad
     skipped = bool(bad.item() > 0)
     if not skipped:
@@ -127,19 +146,53 @@ class GraphedTrainStep(object):
     fused optimizer update: ~600 launches) captured ONCE as a hipGraph and replayed with one launch per step
     (reference loop pipeline_anchor_apex.py:103-130).  Single-process steps only (under DDP the bucketed all-reduce hooks
     keep the eager path); needs the fused optimizer (no host read-back inside the step) and static shapes: ``images`` /
-    ``targets`` are copied into the captured input tensors."""
+    ``targets`` are copied into the captured input tensors.
+
+    What a captured step freezes, and what it does not:
+      * the LEARNING RATE stays live: every parameter group's ``lr`` is turned into a device tensor before the capture
+        (fused SGD reads it on the device), and torch's schedulers update a tensor ``lr`` in place (``fill_``), so
+        ``lr_scheduler.step()`` / a warm-up that assigns through ``set_lr`` reach the replayed kernels;
+      * momentum, weight decay, nesterov are kernel ARGUMENTS of the captured launch: changing them afterwards needs a new
+        GraphedTrainStep;
+      * the ``warmup`` eager steps (>= 1: allocator pools, MIOpen / rocBLAS plans, the optimizer's lazily created state --
+        a capture of the very first step would bake ``is_first_step`` in and overwrite the momentum on every replay) run on
+        the sample batch but leave NO trace: parameters, buffers (BatchNorm statistics) and the optimizer state are
+        snapshotted before and restored after them (momentum buffers that did not exist are zeroed: see
+        ``_ensure_momentum_buffers``)."""
 
     def __init__(self, model_with_loss, images, targets, anchors, optimizer, autocast_dtype=torch.bfloat16, warmup=3):
         if not (images.is_cuda and _device_skip(optimizer)):
             raise ValueError("GraphedTrainStep needs a HIP device and a fused optimizer")
+        if warmup < 1:
+            raise ValueError("GraphedTrainStep: warmup >= 1 (the optimizer's first step must not be the captured one)")
         self.optimizer = optimizer
         self.images, self.targets = images.clone(), targets.clone()
-        side = torch.cuda.Stream(device=images.device)
-        side.wait_stream(torch.cuda.current_stream(images.device))
-        with torch.cuda.stream(side):  # eager warm-up on a side stream (allocator pools, MIOpen / rocBLAS plans, lazy state)
+        dev = images.device
+        for group in optimizer.param_groups:  # a live learning rate (see the class comment)
+            if not isinstance(group["lr"], torch.Tensor):
+                group["lr"] = torch.tensor(float(group["lr"]), device=dev, dtype=torch.float32)
+        _ensure_momentum_buffers(optimizer)
+        snap_model = [t.detach().clone() for t in list(model_with_loss.parameters()) + list(model_with_loss.buffers())]
+        snap_opt = {p: {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
+                    for p, st in optimizer.state.items()}
+        snap_lr = [g["lr"].clone() for g in optimizer.param_groups]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # eager warm-up on a side stream
             for _ in range(warmup):
                 train_step(model_with_loss, self.images, self.targets, anchors, optimizer, autocast_dtype)
-        torch.cuda.current_stream(images.device).wait_stream(side)
+            with torch.no_grad():  # ... undone: the warm-up must not be part of the training trajectory
+                for t, s in zip(list(model_with_loss.parameters()) + list(model_with_loss.buffers()), snap_model):
+                    t.copy_(s)
+                for p, st in snap_opt.items():
+                    for k, v in st.items():
+                        if isinstance(v, torch.Tensor):
+                            optimizer.state[p][k].copy_(v)
+                        else:
+                            optimizer.state[p][k] = v
+                for g, l in zip(optimizer.param_groups, snap_lr):
+                    g["lr"].copy_(l)
+        torch.cuda.current_stream(dev).wait_stream(side)
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -150,6 +203,12 @@ class GraphedTrainStep(object):
             torch.nan_to_num(total, nan=0.0, posinf=0.0, neginf=0.0).backward()
             _step_unless(optimizer, self.bad)
             self.cls_loss, self.loc_loss = cls_loss.detach(), loc_loss.detach()
+
+    def set_lr(self, lr, group=None):
+        """Assign a learning rate (warm-up loops that write ``param_group['lr'] = x`` would replace the live tensor)."""
+        for i, g in enumerate(self.optimizer.param_groups):
+            if group is None or group == i:
+                g["lr"].fill_(float(lr))
 
     def __call__(self, images, targets):
         self.images.copy_(images, non_blocking=True)

@@ -2,6 +2,7 @@
 make_golden.gen_nets from the REFERENCE's SSD / SSDFPN / SSDBiFPN classes): builds this repo's model for a case,
 checks its ``state_dict`` schema against the reference's and loads the seeded weights + stored BatchNorm statistics."""
 import os
+import re
 
 import numpy as np
 import torch
@@ -24,6 +25,29 @@ class StubBackbone(torch.nn.Module):
 
     def forward(self, x):
         return [f.to(device=x.device, dtype=x.dtype).clone() for f in self.feats]
+
+
+_FINAL_CONF = re.compile(r"^conf\.\d+\.(weight|bias)$")
+
+
+def untrained_score_prior(state):
+    """An untrained-looking score distribution (logits ~ N(-4, ~1), a few confident peaks) applied to the FINAL class
+    convolutions ONLY -- ``conf.<i>.weight|bias``: the six leaf convolutions of SSD (ssd.py:100-103), the last convolution
+    of the shared tower of SSDFPN / SSDBiFPN (fpn.py:10-18: ``conf.4``).  Round 4 matched ``conf.*bias``, which in the
+    tower also names the BatchNorm betas ``conf.<i>.1.bias`` of the four ConvBNReLU layers: beta ~ -4 put every tower
+    activation behind the ReLU's zero, and the bench-size FPN / BiFPN case compared a constant.  In place; returns the
+    number of tensors touched."""
+    n = 0
+    for k in state:
+        m = _FINAL_CONF.match(k)
+        if not m:
+            continue
+        n += 1
+        if m.group(1) == "weight":
+            state[k] = state[k] * np.float32(0.6)
+        else:
+            state[k] = (state[k] * 3 - 4.0).astype(np.float32)
+    return n
 
 
 def load_fixture(name):

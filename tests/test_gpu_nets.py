@@ -26,15 +26,22 @@ def _logit(p):
 
 
 def _stats(got, want, logit=False):
-    """(median, 99.9th percentile, max) of |got - want| / rms(want); ``logit``: both mapped back through the sigmoid."""
+    """(median, 99.9th percentile, max) of |got - want| / std(want), and the correlation of got with want; ``logit``: both
+    mapped back through the sigmoid.  The unit is the CENTRED rms (round 5): a class head's logits are -4 +- 0.6, and in
+    units of their plain rms (4.05) every error looked six times smaller than it is."""
     g = got.float().cpu()
     assert g.shape == want.shape, (g.shape, want.shape)
     if logit:
         g, want = _logit(g), _logit(want)
-    rms = float(want.pow(2).mean().sqrt())
-    e = ((g - want).abs() / max(rms, 1e-6)).flatten()
+    want = want.float()
+    wc = want - want.mean()
+    std = max(float(wc.pow(2).mean().sqrt()), 1e-6)
+    e = ((g - want).abs() / std).flatten()
     k = max(int(e.numel() * 0.999) - 1, 0)
-    return float(e.median()), float(e.kthvalue(k + 1).values), float(e.max())
+    gc = g - g.mean()
+    gs = float(gc.pow(2).mean().sqrt())
+    corr = float((gc * wc).mean()) / (gs * std) if gs > 0 else 0.0  # (a constant output correlates with nothing)
+    return float(e.median()), float(e.kthvalue(k + 1).values), float(e.max()), corr
 
 
 CAP = {"bfloat16": 0.7, "float16": 0.3}  # absolute cap on the median error (a wrong wire is >= 1; measured bf16: <= 0.63)
@@ -47,47 +54,67 @@ SMALL = 4096
 CAP_SMALL = {"bfloat16": 1.0, "float16": 0.3}
 # absolute slack on (median, p99.9): the last levels are a few dozen values, whose statistics are noise themselves
 SLACK = {"bfloat16": (0.06, 0.2), "float16": (0.015, 0.05)}
+CORR_SLACK = 0.05  # the plan may correlate with the fp32 reference this much less than PyTorch-ROCm's 16-bit execution does
+
+
+def floor_runs(model, x, runs=3):
+    """PyTorch-ROCm / MIOpen executing the module in its own dtype, ``runs`` times (MIOpen picks algorithms by timing them:
+    the floor's tail statistic moved 2x between sessions of round 4) -> list of {"loc": ..., "conf": ...}."""
+    import torch
+
+    out = []
+    os.environ["SSDK_FUSED_CONV"] = "0"
+    try:
+        with torch.no_grad():
+            for _ in range(runs):
+                tl, tc = model(x)
+                out.append({"loc": tl, "conf": tc})
+    finally:
+        del os.environ["SSDK_FUSED_CONV"]
+    return out
 
 
 def _check_against_floor(plan_out, torch_out, want, what, dtype, tail_factor=2.0):
     """Untrained deep networks amplify rounding noise (torch's own bf16 execution of MobileNetV2 is 0.1-0.6 RMS away
     from fp32 at the deeper levels), so the bar is relative to the noise floor of the SAME module executed by
     PyTorch-ROCm in the SAME dtype: the plan must be as close to the reference's fp32 outputs as that, up to a factor
-    2 (+ a small absolute term for the levels where both are tiny).  A wiring / folding / layout error is ~1.4 RMS
-    (uncorrelated outputs) whatever the floor; the absolute cap makes the fp16 runs (8x less rounding noise than bf16)
-    the discriminating ones.
+    2 (+ a small absolute term for the levels where both are tiny).  ``torch_out``: one floor execution or a list of them
+    (floor_runs); the floor's median / p99.9 / correlation are the most favourable over the runs FOR THE PLAN'S BAR only
+    in the sense of "what PyTorch-ROCm itself can show": median and p99.9 take their maximum, the correlation its minimum.
 
-    The class heads are compared as LOGITS (round 4).  A sigmoid output hides its logit: d sigmoid / d logit is 0.01 at the
-    p = 0.01 of the untrained prior and 0.25 at p = 0.5, so in probability space the 99.9th percentile of the error is set
-    by how many of the few-per-mille confident peaks happen to cross it -- on FPN-ResNet50@640 (level 0: 0.14 % of the
-    elements have p > 0.1, BOTH executions miss those by 0.1 - 0.7 in probability) that statistic jumped between 1.7 and
-    7.1 RMS from run to run and needed an escape clause; tools/plan_trace.py (profiles/r04_plan_trace_fpn_*.txt) audits all
-    112 layers of that plan one by one against fp32 on the layer's own input: every kernel sits at its rounding level.  In
-    logit space the error is homogeneous and the plain factor rule applies to every tensor."""
+    Three rules per tensor (round 5; VERDICT round 4 Weak 1-3):
+      * median error <= 2 x the floor's + slack, and <= an absolute cap;
+      * 99.9th percentile <= tail_factor x the floor's 99.9th PERCENTILE (round 4 compared it with the floor's maximum);
+      * correlation with the fp32 reference >= the floor's - 0.05.  This is the rule an all-zero, constant or shuffled
+        output cannot pass in any dtype: its correlation is 0 while the floor's is 0.7 - 0.99 (a zero output has a median
+        error of 0.67 sigma, below the bf16 cap: test_a_zero_or_shuffled_head_fails_the_floor_check).
+    Errors are in units of the CENTRED rms of the reference tensor; the class heads are compared as LOGITS (a sigmoid output
+    hides its logit: d sigmoid / d logit is 0.01 at the p = 0.01 of the untrained prior)."""
+    runs = torch_out if isinstance(torch_out, (list, tuple)) else [torch_out]
     report, bad = [], []
     for tag in ("loc", "conf"):
         lg = tag == "conf"
-        floors = [_stats(t, w, lg) for t, w in zip(torch_out[tag], want[tag])]
-        pooled = tuple(sorted(f[j] for f in floors)[len(floors) // 2] for j in range(3))
+        per_run = [[_stats(t, w, lg) for t, w in zip(r[tag], want[tag])] for r in runs]
+        floors = [(max(pr[i][0] for pr in per_run), max(pr[i][1] for pr in per_run), max(pr[i][2] for pr in per_run),
+                   min(pr[i][3] for pr in per_run)) for i in range(len(want[tag]))]
+        pooled = tuple(sorted(f[j] for f in floors)[len(floors) // 2] for j in range(4))
         for i, (p, w) in enumerate(zip(plan_out[tag], want[tag])):
             sp, st = _stats(p, w, lg), floors[i]
             small = w.numel() < SMALL
-            report.append("%s%d%s plan %.4f/%.4f/%.4f floor %.4f/%.4f/%.4f%s" % (
+            report.append("%s%d%s plan %.4f/%.4f/%.4f r=%.4f floor %.4f/%.4f/%.4f r=%.4f%s" % (
                 (tag, i, "(logit)" if lg else "") + sp + st + (" (small level)" if small else "",)))
             if small:
-                st = tuple(max(a, b) for a, b in zip(st, pooled))
+                st = tuple(max(a, b) for a, b in zip(st[:3], pooled[:3])) + (min(st[3], pooled[3]),)
             m_abs, p_abs = SLACK[dtype]
-            # the floor's own tail is not reproducible: the same module on the same inputs gave a conf0 p99.9 of 1.63 and of
-            # 3.54 RMS in two sessions of round 4 (MIOpen picks its algorithms by timing them), while the plan's outputs are
-            # bit-identical from run to run; a single floor sample bounds the plan's p99.9 through its MAXIMUM error
-            tail_bar = tail_factor * st[2] + p_abs
             cap = CAP_SMALL[dtype] if small else CAP[dtype]
-            if not (sp[0] <= 2.0 * st[0] + m_abs and sp[1] <= tail_bar and sp[0] <= cap):
+            ok = (sp[0] <= 2.0 * st[0] + m_abs and sp[0] <= cap and sp[1] <= tail_factor * st[1] + p_abs
+                  and sp[3] >= st[3] - CORR_SLACK)
+            if not ok:
                 bad.append(report[-1])
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "net_report.txt"), "a") as f:
-            f.write("%s %s (median/p99.9/max in RMS units)\n  %s\n" % (what, dtype, "\n  ".join(report)))
+            f.write("%s %s (median/p99.9/max in centred RMS units, r = correlation with fp32)\n  %s\n" % (what, dtype, "\n  ".join(report)))
     assert not bad, (what, dtype, bad)
     return report
 
@@ -114,14 +141,10 @@ def test_plan_matches_reference_module(name, dtype, monkeypatch):
         assert loc[i].is_contiguous() and conf[i].is_contiguous() and loc[i].dtype == tdt
         assert torch.equal(loc[i], loc2[i]) and torch.equal(conf[i], conf2[i]), "replay is not deterministic"
     # noise floor: the same module, same dtype, on PyTorch-ROCm / MIOpen
-    monkeypatch.setenv("SSDK_FUSED_CONV", "0")
     n0 = FC.STATS["native_layers"]
-    with torch.no_grad():
-        tl, tc = model(xd)
+    floor = floor_runs(model, xd)
     assert FC.STATS["native_layers"] == n0
-    monkeypatch.delenv("SSDK_FUSED_CONV")
-    report = _check_against_floor({"loc": loc, "conf": conf}, {"loc": tl, "conf": tc}, {"loc": wl, "conf": wc},
-                                  name, dtype)
+    report = _check_against_floor({"loc": loc, "conf": conf}, floor, {"loc": wl, "conf": wc}, name, dtype)
     print(name, dtype, "; ".join(report))
 
 
@@ -180,11 +203,7 @@ def _seeded_detector(cfg_name, dtype):
     model = det.model.float().cpu()
     spec = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
     state = cases.seeded_state(spec, 123)
-    for k in state:  # an untrained-looking score distribution: logits ~ N(-4, ~1), a few confident peaks
-        if k.startswith("conf.") and k.endswith("weight"):
-            state[k] = state[k] * np.float32(0.6)
-        if k.startswith("conf.") and k.endswith("bias"):
-            state[k] = (state[k] * 3 - 4.0).astype(np.float32)
+    nethelp.untrained_score_prior(state)  # logits ~ N(-4, ~1), a few confident peaks (final class convolutions only)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     for m in model.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
@@ -252,14 +271,8 @@ def test_ssd_detector_call_end_to_end(layout, dtype):
     cpu.eval()
     with torch.no_grad():
         cl, cc = cpu(torch.from_numpy(O.preprocess(img, det.mean, det.std)))
-    os.environ["SSDK_FUSED_CONV"] = "0"  # noise floor: the same module in bf16 on PyTorch-ROCm
-    try:
-        with torch.no_grad():
-            tl, tc = det.model(x)
-    finally:
-        del os.environ["SSDK_FUSED_CONV"]
-    _check_against_floor({"loc": loc, "conf": conf}, {"loc": tl, "conf": tc}, {"loc": cl, "conf": cc}, "detector " + layout,
-                         dtype)
+    floor = floor_runs(det.model, x)  # noise floor: the same module in the same dtype on PyTorch-ROCm
+    _check_against_floor({"loc": loc, "conf": conf}, floor, {"loc": cl, "conf": cc}, "detector " + layout, dtype)
     fs, fb, fc = odec([t.numpy() for t in cl], [t.numpy() for t in cc], oanch)
     drift = np.abs(np.sort(scores, 1) - np.sort(fs, 1))  # (the single top score is itself an extreme-value statistic)
     assert drift.mean() < (0.04 if dtype == "bfloat16" else 0.01) and drift.max() < 0.25, "score order statistics drifted"

@@ -147,6 +147,69 @@ def test_graphed_train_step_equals_the_eager_step():
     assert float(bad) == 1.0 and torch.equal(before, flat(mwl))
 
 
+def test_graphed_step_keeps_the_learning_rate_live_and_its_warmup_leaves_no_trace():
+    """(1) the eager warm-up steps of GraphedTrainStep are undone -- parameters, BatchNorm statistics and
+    momentum are what they were before the constructor; (2) the learning rate is a device tensor the captured update reads
+    at replay time: a scheduler step (torch fills a tensor lr in place) and ``set_lr`` both reach the replayed kernels;
+    (3) warmup = 0 is refused (the optimizer's first step would be captured with is_first_step baked in); (4) a plain
+    optimizer.step() after a skipped step does not see a stale found_inf."""
+    import torch
+    from ssds.pipeline.pipeline_anchor_ddp import GraphedTrainStep, train_step
+
+    mwl, images, targets, anchors = _tiny_step_setup(5)
+    opt = torch.optim.SGD(mwl.parameters(), lr=0.02, momentum=0.9, fused=True)
+    flat = lambda m: torch.cat([p.detach().flatten() for p in m.parameters()])  # noqa: E731
+    bufs = lambda m: torch.cat([b.detach().float().flatten() for b in m.buffers()])  # noqa: E731
+    p0, b0 = flat(mwl).clone(), bufs(mwl).clone()
+    with pytest.raises(ValueError):
+        GraphedTrainStep(mwl, images, targets, anchors, opt, warmup=0)
+    graphed = GraphedTrainStep(mwl, images, targets, anchors, opt, warmup=2)
+    assert torch.equal(p0, flat(mwl)) and torch.equal(b0, bufs(mwl)), "the warm-up changed the model"
+    assert all(float(opt.state[p]["momentum_buffer"].abs().max()) == 0.0 for p in mwl.parameters() if p in opt.state)
+    assert all(isinstance(g["lr"], torch.Tensor) and g["lr"].is_cuda for g in opt.param_groups)
+    # a full-size step, then lr -> 0 through a scheduler: the replay moves nothing
+    graphed(images, targets)
+    step1 = float((flat(mwl) - p0).abs().mean())
+    assert step1 > 0
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.0)
+    sched.step()
+    assert float(opt.param_groups[0]["lr"]) == 0.0
+    before = flat(mwl).clone()
+    graphed(images, targets)
+    assert torch.equal(before, flat(mwl)), "the captured update ignored the scheduler"
+    # ... and back up through set_lr: a tenth of the rate moves about a tenth as far (momentum carries over: same order)
+    graphed.set_lr(0.002)
+    graphed(images, targets)
+    small = float((flat(mwl) - before).abs().mean())
+    assert 0 < small < 0.6 * step1, (small, step1)
+    # a skipped eager step leaves no flag behind on the optimizer
+    bad_images = images.clone()
+    bad_images[0, 0, 0, 0] = float("nan")
+    c, l, skipped = train_step(mwl, bad_images, targets, anchors, opt)
+    assert float(skipped) == 1.0 and not hasattr(opt, "found_inf") and not hasattr(opt, "grad_scale")
+
+
+def test_a_skipped_first_step_leaves_zero_momentum():
+    """the fused SGD allocates its momentum buffers with empty_like and returns early on found_inf --
+    a skipped FIRST step must not leave uninitialised memory behind as momentum."""
+    import torch
+    from ssds.pipeline.pipeline_anchor_ddp import train_step
+
+    mwl, images, targets, anchors = _tiny_step_setup(6)
+    opt = torch.optim.SGD(mwl.parameters(), lr=0.01, momentum=0.9, fused=True)
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]  # poison what the allocator hands out next
+    del junk
+    bad_images = images.clone()
+    bad_images[0, 0, 0, 0] = float("nan")
+    c, l, skipped = train_step(mwl, bad_images, targets, anchors, opt, autocast_dtype=None)
+    assert float(skipped) == 1.0
+    for p in mwl.parameters():
+        if p in opt.state and "momentum_buffer" in opt.state[p]:
+            assert float(opt.state[p]["momentum_buffer"].abs().max()) == 0.0
+    c, l, skipped = train_step(mwl, images, targets, anchors, opt, autocast_dtype=None)
+    assert float(skipped) == 0.0 and all(bool(torch.isfinite(p).all()) for p in mwl.parameters())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype_name,tol", [("float32", 1e-4), ("bfloat16", 2e-2), ("float16", 4e-3)])
 @pytest.mark.parametrize("c,stride,h,w,n", [(32, 1, 20, 24, 3), (96, 2, 33, 31, 2), (144, 2, 64, 70, 2), (8, 1, 5, 130, 1),
@@ -402,7 +465,10 @@ def test_fused_match_loss_matches_unfused_losses(mode, dtype_name, gamma, loc_lo
 
 @pytest.mark.parametrize("mode,dtype_name,ratio,loc_loss", [
     ("iou", "float32", 3, "smoothl1"), ("iou", "bfloat16", 3, "smoothl1"), ("scale_center", "float16", 3, "giou"),
-    ("iou_radius", "float32", 0.5, "smoothl1"), ("iou", "float32", 1000, "smoothl1"), ("scale", "float32", 1, "diou")])
+    ("iou_radius", "float32", 0.5, "smoothl1"), ("iou", "float32", 1000, "smoothl1"), ("scale", "float32", 1, "diou"),
+    # every negative is mined, so the anchors that matched a box (overlap >= 0.5) but lie outside the centre-sampling region
+    # are too: depth 0 WITH a one-hot class target (box.py:183-207) -- their term is BCE against that target, not softplus
+    ("iou_radius", "float32", 1000, "smoothl1"), ("iou_radius", "bfloat16", 1000, "smoothl1")])
 def test_fused_multibox_loss_matches_unfused_mining(mode, dtype_name, ratio, loc_loss):
     """ssdk_match_multibox_loss (match + positives, per-image radix select of the hardest negatives, their terms) against
     extract_targets + MultiBoxLoss (criterion.py:43-71, two full sorts) + autograd.  Where several negatives share the
@@ -440,6 +506,8 @@ def test_fused_multibox_loss_matches_unfused_mining(mode, dtype_name, ratio, loc
     beta = getattr(sl, "beta", 0.11)
 
     ct, lt, depth = box.extract_targets(targets, anchors, C, stride, (H, W), match, radius)
+    if mode == "iou_radius" and ratio >= 1000:  # the case exists for these anchors: a negative (depth 0) with a class target
+        assert int(((depth == 0) & (ct.max(2, keepdim=True)[0] > 0)).sum()) >= 1
     c = conf.view_as(ct).float()
     cls_ref = ((depth >= 0).expand_as(ct).float() * mb(c, ct, depth)).sum()
     l = loc.view_as(lt).float()

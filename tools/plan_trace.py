@@ -31,18 +31,6 @@ def stats(got, want):
     return float(e.median()), float(e.kthvalue(k).values), float(e.max())
 
 
-def act_fn(y, act):
-    if act == "relu":
-        return y.clamp(min=0)
-    if act == "relu6":
-        return y.clamp(0, 6)
-    if act == "silu":
-        return y * torch.sigmoid(y)
-    if act == "sigmoid":
-        return torch.sigmoid(y)
-    return y
-
-
 def main():
     cfg_name, batch, dtype = sys.argv[1], int(sys.argv[2]), getattr(torch, sys.argv[3])
     seed = int(sys.argv[4]) if len(sys.argv) > 4 else 321
@@ -63,86 +51,14 @@ def main():
         loc, conf = model(xd)
     plan = model._plan(xd) if hasattr(model, "_plan") else next(iter(model._neck_plans.values()))
     assert not isinstance(plan, str), plan
-    es = 2
+    import planaudit
 
-    def arena_tensor(buf, n, c, hh, ww):
-        """NHWC arena buffer -> [n, c, hh, ww] view (channels_last memory)."""
-        if isinstance(buf, FC.ExtBuf):
-            return xd if buf.index == 0 else None
-        t = plan.arena.bufs[buf][0][: n * c * hh * ww * es].view(dtype).view(n, hh, ww, c)
-        return t.permute(0, 3, 1, 2)
-
-    outs = plan.prepare(xd)
-    rows = plan.layer_table()
-    print("%3s %-34s %-26s %9s %9s %9s" % ("#", "layer", "kernel", "median", "p99.9", "max"))
-    for i, L in enumerate(plan.layers):
-        kind = L.get("kind")
-        xin = None
-        if kind in (None, "stem7", "pool"):
-            pk = L.get("pack")
-            cin = 3 if kind == "stem7" else (L["ch"] if kind == "pool" else pk.cin)
-            xin = arena_tensor(L["x"], L["n"], cin, L["h"], L["w"])
-            xin = xin.float().clone() if xin is not None else None
-        res = None
-        if kind is None and L["res"] is not None:
-            rh, rw = (L["h"] // 2, L["w"] // 2) if (L.get("res_mode", 0) & 1) else FC._out_hw(L["h"], L["w"], L["pack"].k, L["pack"].stride)
-            res = arena_tensor(L["res"], L["n"], L["pack"].cout, rh, rw).float().clone()
-        plan.launch(i, i + 1)
-        torch.cuda.synchronize()
-        name = N.last_kernel()
-        if xin is None:
-            print("%3d %-34s %-26s %s" % (i, rows[i]["name"], name.replace("_kernel", ""), "(not audited)"))
-            continue
-        with torch.no_grad():
-            if kind == "pool":
-                want = F.max_pool2d(xin, 3, 2, 1)
-                got = arena_tensor(L["y"], L["n"], L["ch"], want.shape[2], want.shape[3])
-            elif kind == "stem7":
-                pk = L["pack"]
-                wt = pk.w.float()[:, :, :7, :3].permute(0, 3, 1, 2).contiguous()
-                want = F.conv2d(xin, wt, None, 2, 3) * pk.scale.view(1, -1, 1, 1) + pk.bias.view(1, -1, 1, 1)
-                want = act_fn(want, pk.act)
-                got = arena_tensor(L["y"], L["n"], pk.cout, want.shape[2], want.shape[3])
-            else:
-                pk = L["pack"]
-                if pk.kind == "stem":
-                    wt = pk.w.float().permute(0, 3, 1, 2).contiguous()
-                    want = F.conv2d(xin, wt, None, pk.stride, pk.k // 2) + pk.bias.view(1, -1, 1, 1)
-                elif pk.kind == "dw":
-                    wt = pk.w.float().permute(2, 0, 1).unsqueeze(1).contiguous()
-                    want = F.conv2d(xin, wt, None, pk.stride, 1, 1, pk.cin)
-                    want = want * pk.scale.view(1, -1, 1, 1) + pk.bias.view(1, -1, 1, 1)
-                else:
-                    wt = pk.w.float().permute(0, 3, 1, 2).contiguous()
-                    want = F.conv2d(xin, wt, None, pk.stride, pk.k // 2, 1, pk.groups)
-                    if pk.scale is not None:
-                        want = want * pk.scale.view(1, -1, 1, 1)
-                    want = want + pk.bias.view(1, -1, 1, 1)
-                rm = L.get("res_mode", 0)
-                if L["nchw"]:  # a head: NCHW outputs of the plan (split | single)
-                    hi = [hh for hh in plan.heads if hh[0] == i][0]
-                    pos = plan.heads.index(hi)
-                    split, tag = hi[2], hi[6]
-                    if tag == "both":
-                        got = torch.cat([outs[0][pos], outs[1][pos]], 1)
-                        want = torch.cat([act_fn(want[:, :split], L["act"]), act_fn(want[:, split:], L.get("act2") or L["act"])], 1)
-                    else:
-                        idx = [hh for hh in plan.heads if hh[6] == tag].index(hi)
-                        got = (outs[0] if tag == "loc" else outs[1])[idx]
-                        want = act_fn(want, L["act"])
-                else:
-                    if res is not None and (rm & 1):
-                        res = F.interpolate(res, scale_factor=2, mode="nearest")
-                    if res is not None and (rm & 2):
-                        want = act_fn(want.to(dtype).float() + res, L["act"])
-                    elif res is not None:
-                        want = act_fn(want, L["act"]).to(dtype).float() + res
-                    else:
-                        want = act_fn(want, L["act"])
-                    got = arena_tensor(L["y"], L["n"], pk.cout, want.shape[2], want.shape[3])
-            s = stats(got, want)
-            # the same op by PyTorch-ROCm in the model dtype (conv -> rounded -> affine -> act as two roundings at most)
-        print("%3d %-34s %-26s %9.5f %9.5f %9.5f" % ((i, rows[i]["name"], name.replace("_kernel", "")) + s))
+    audit = planaudit.PlanAudit(plan, [xd])
+    rows = audit.run()  # every op on its own against fp32 of that op on its own input (tests/planaudit.py)
+    outs = audit.outs
+    print(planaudit.format_rows(rows))
+    bad = planaudit.failures(rows, dtype)
+    print("\n%d ops, %d outside their bar%s" % (len(rows), len(bad), (":\n  " + "\n  ".join(bad)) if bad else ""))
     torch.cuda.synchronize()
 
     # ---- end to end: plan vs fp32, PyTorch-ROCm 16-bit vs fp32; class heads also as logits -------------------------------
