@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 210 /* 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
+#define SSDK_VERSION 220 /* 0.2.2: ssdk_mbconv_desc.image_nw / w_image / w_image_bytes (ssdk_mbk.hip), larger ssdk_match_multibox_loss workspace; 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
 
 #define SSDK_MAX_LEVELS 8    /* feature-map levels per decode_nms call            */
 #define SSDK_MAX_ANCHORS 16  /* anchors per location (A)                          */
@@ -325,9 +325,26 @@ typedef struct ssdk_mbconv_desc {
                       blocks (Cin <= 32, hidden in {96, 144, 192}, Cout <= 64, or the stem block), a register-flow one
                       (ssdk_mbflow.hip).  0: automatic (register-flow where the map is large enough to pay), 1: register-flow
                       wherever it exists, -1: LDS-tiled only (tests, A/B runs).  Part of the descriptor: the library keeps
-                      no process-wide switch.  ssdk_last_kernel() names the kernel that ran. */
+                      no process-wide switch.  ssdk_last_kernel() names the kernel that ran.
+                      2: ssdk_mbsplit.hip wherever it exists, 3: ssdk_mbk.hip wherever it exists (tests). */
+  /* appended in 0.2.2 (zero = absent).  OPTIONAL fragment-major image of the block's 1x1 weights for ssdk_mbk.hip (16-pixel-
+   * wide maps, Cin a multiple of 32, Chid of 16, Cout of 160: the 160 -> 960 -> 160 | 320 blocks of MobileNetV2 on 16x16 maps,
+   * mobilenet.py:56, 84-89), built once per model by the host; without it those blocks run on the LDS-tiled kernel.
+   *   image_nw  slices of the hidden channels = waves per workgroup the image is built for (4 | 6 | 3)
+   *   layout    [Cout / 160 halves][image_nw slices][NP = ceil(NCHW / 2) chunk pairs][2 KS + 10 fragments of 1 KiB],
+   *             NCHW = ceil(Chid / 16 / image_nw), KS = Cin / 32.  Fragment = 64 lanes x 8 elements, lane l:
+   *             expand (chunk cc of the pair, k-step ks): w_expand[16 c + (l & 15)][32 ks + 8 (l >> 4) + 0..7], c = slice *
+   *               NCHW + 2 pair + cc, in the activation dtype (BN scale folded in, like w_expand);
+   *             project (column fragment f of half h): element j = w_project[160 h + 16 f + (l & 15)][16 (slice * NCHW +
+   *               2 pair + j / 4) + 4 (l >> 4) + j % 4], fp16;
+   *             zeros where the chunk lies beyond the slice (an odd NCHW) or beyond Chid.
+   *   w_image_bytes >= ssdk_mbk_image_bytes(Cin, Chid, Cout, image_nw) (0: no instance of the kernel takes the block). */
+  int32_t image_nw;
+  const void* w_image;
+  size_t w_image_bytes;
 } ssdk_mbconv_desc;
 int ssdk_mbconv(const ssdk_mbconv_desc* desc, void* stream);
+size_t ssdk_mbk_image_bytes(int Cin, int Chid, int Cout, int image_nw);
 
 /* Weighted feature fusion of the BiFPN (bifpn.py:41-62), NHWC, one launch:
  *   y = w0 * a + w1 * R_b(b) [+ w2 * R_c(c)]      a, y: [N][H][W][C]

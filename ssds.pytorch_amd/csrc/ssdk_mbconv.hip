@@ -762,6 +762,7 @@ static int launch_mb(const MbParams& p, int ks, int nfo, size_t lds, unsigned gr
 namespace ssdk {
 int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream);  // ssdk_mbflow.hip: 0 = launched, 1 = not one of its blocks
 int launch_mbsplit(const ssdk_mbconv_desc* d, hipStream_t stream);  // ssdk_mbsplit.hip: same contract
+int launch_mbk(const ssdk_mbconv_desc* d, hipStream_t stream);      // ssdk_mbk.hip: same contract
 }
 using namespace ssdk;
 
@@ -791,6 +792,7 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   }
   if (launch_mbflow(d, stream) == 0) return check_launch(stem ? "mbflow_kernel(stem)" : "mbflow_kernel");  // high-resolution blocks: ssdk_mbflow.hip
   if (launch_mbsplit(d, stream) == 0) return check_launch("mbsplit_kernel");  // mid-resolution blocks: hidden channels split over the waves
+  if (launch_mbk(d, stream) == 0) return check_launch("mbk_kernel");  // 16-pixel-wide maps: row pairs, weights from L2 into MFMA operands
   MbParams p;
   p.x = (const u16*)d->x;
   p.y = (u16*)d->y;

@@ -56,7 +56,8 @@ class MbConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in (
         "x", "y", "w_expand", "scale_expand", "bias_expand", "w_dw", "bias_dw", "w_project",
         "scale_project", "bias_project")] + [(n, ctypes.c_int32) for n in (
-            "N", "H", "W", "Cin", "Chid", "Cout", "stride", "residual", "dtype", "stem", "variant")]
+            "N", "H", "W", "Cin", "Chid", "Cout", "stride", "residual", "dtype", "stem", "variant",
+            "image_nw")] + [("w_image", ctypes.c_void_p), ("w_image_bytes", ctypes.c_size_t)]
 
 
 class FuseDesc(ctypes.Structure):
@@ -107,6 +108,8 @@ def _load():
     lib.ssdk_version.restype = i32
     lib.ssdk_last_error.restype = c.c_char_p
     lib.ssdk_last_kernel.restype = c.c_char_p
+    lib.ssdk_mbk_image_bytes.argtypes = [i32] * 4
+    lib.ssdk_mbk_image_bytes.restype = sz
     lib.ssdk_fuse.argtypes = [c.POINTER(FuseDesc), vp]
     lib.ssdk_fuse.restype = i32
     lib.ssdk_dwconv_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
@@ -217,7 +220,7 @@ EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_p
            "ssdk_ctx_create", "ssdk_ctx_destroy", "ssdk_ctx_set_tail_stream", "ssdk_ctx_set_side_lane", "ssdk_ctx_set_profiling",
            "ssdk_ctx_get_timings", "ssdk_ctx_set_op_profiling", "ssdk_ctx_get_op_timings", "ssdk_ctx_get_tail_stamps",
            "ssdk_run_ops_ctx", "ssdk_decode_nms_ctx",
-           "ssdk_weight_frag_bytes", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_xpair", "ssdk_fuse", "ssdk_preprocess", "ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data",
+           "ssdk_weight_frag_bytes", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_mbk_image_bytes", "ssdk_xpair", "ssdk_fuse", "ssdk_preprocess", "ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data",
            "ssdk_dwconv_bwd_weight_workspace_bytes", "ssdk_dwconv_bwd_weight", "ssdk_dwconv_plan", "ssdk_bn_workspace_bytes",
            "ssdk_bn_train_fwd", "ssdk_bn_train_bwd", "ssdk_bn_act_train_fwd", "ssdk_bn_act_train_bwd", "ssdk_conv_stem7", "ssdk_maxpool3x3s2", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 

@@ -200,7 +200,7 @@ class MbPack(object):
     fused block kernel (csrc/ssdk_mbconv.hip).  ``groups`` = [(conv, bn, act)] x 3 as produced by
     ``sequential_groups`` on the flattened block."""
 
-    __slots__ = ("e", "d", "p", "we", "wd", "bd", "wp", "cin", "chid", "cout", "stride", "residual", "stem")
+    __slots__ = ("e", "d", "p", "we", "wd", "bd", "wp", "cin", "chid", "cout", "stride", "residual", "stem", "_image")
 
     @staticmethod
     def supported(groups, residual):
@@ -229,6 +229,7 @@ class MbPack(object):
 
     def __init__(self, groups, residual, dtype, stem_group=None):
         self.stem = 0
+        self._image = None
         if stem_group is not None:  # the stem conv plays the role of the expand conv
             cs, bs, _ = stem_group
             (cd, bd, _), (cp, bp, _) = groups
@@ -269,6 +270,56 @@ class MbPack(object):
         self.wp = cp.weight.detach().float().permute(0, 2, 3, 1).contiguous().to(torch.float16)
 
 
+    def image(self, nw=None):
+        """(nw, tensor) -- the fragment-major image of the two 1x1 weight matrices for csrc/ssdk_mbk.hip (layout: include/ssdk.h
+        ``ssdk_mbconv_desc.w_image``), or None where no instance of that kernel takes the block (16-pixel-wide maps are the
+        caller's condition: the image depends on the channel counts only).  Built once per pack: a pure permutation of
+        ``e.w`` (activation dtype, BN scale folded in) and ``wp`` (fp16), both carried as 16-bit words.  ``nw``: slices of the
+        hidden channels = waves per workgroup (SSDK_MBK_NW, default 4)."""
+        if self.stem or self.stride != 1:
+            return None
+        nw = int(os.environ.get("SSDK_MBK_NW", "4")) if nw is None else int(nw)
+        if self._image is not None and self._image[0] == nw:
+            return self._image
+        need = int(N.lib.ssdk_mbk_image_bytes(self.cin, self.chid, self.cout, nw))
+        if need == 0:
+            return None
+        ks, nch, nfo = self.cin // 32, self.chid // 16, 10
+        nchw = (nch + nw - 1) // nw
+        npair = (nchw + 1) // 2
+        halves = self.cout // (16 * nfo)
+        dev = self.wp.device
+        we = self.e.w.reshape(self.chid, self.cin).view(torch.int16)
+        wp = self.wp.reshape(self.cout, self.chid).view(torch.int16)
+        we = torch.cat([we, we.new_zeros((1, self.cin))], 0)      # row chid = the zero row of a chunk beyond the slice / Chid
+        wp = torch.cat([wp, wp.new_zeros((self.cout, 1))], 1)     # column chid likewise
+        ar = lambda n: torch.arange(n, device=dev)  # noqa: E731
+        lane = ar(64)
+        fr, fg = lane & 15, lane >> 4
+        # expand fragments [slice w][pair t][chunk cc][k-step][lane][8]
+        w_, t_, cc_, ks_, j_ = ar(nw).view(-1, 1, 1, 1, 1, 1), ar(npair).view(1, -1, 1, 1, 1, 1), ar(2).view(1, 1, -1, 1, 1, 1), \
+            ar(ks).view(1, 1, 1, -1, 1, 1), ar(8).view(1, 1, 1, 1, 1, -1)
+        loc = 2 * t_ + cc_
+        chunk = w_ * nchw + loc
+        ok = (loc < nchw) & (chunk < nch)
+        row = torch.where(ok, chunk * 16 + fr.view(1, 1, 1, 1, -1, 1), torch.full_like(chunk, self.chid))
+        col = (32 * ks_ + 8 * fg.view(1, 1, 1, 1, -1, 1) + j_).expand(nw, npair, 2, ks, 64, 8)
+        exp = we[row.expand(nw, npair, 2, ks, 64, 8), col]                                  # [nw, np, 2, ks, 64, 8]
+        # projection fragments [half h][slice w][pair t][fragment f][lane][8]
+        h_, w2, t2, f_, j2 = ar(halves).view(-1, 1, 1, 1, 1, 1), ar(nw).view(1, -1, 1, 1, 1, 1), ar(npair).view(1, 1, -1, 1, 1, 1), \
+            ar(nfo).view(1, 1, 1, -1, 1, 1), ar(8).view(1, 1, 1, 1, 1, -1)
+        loc2 = 2 * t2 + j2 // 4
+        chunk2 = w2 * nchw + loc2
+        ok2 = (loc2 < nchw) & (chunk2 < nch)
+        hid = torch.where(ok2, chunk2 * 16 + 4 * fg.view(1, 1, 1, 1, -1, 1) + j2 % 4, torch.full_like(chunk2 + fg.view(1, 1, 1, 1, -1, 1), self.chid))
+        co = (h_ * (16 * nfo) + 16 * f_ + fr.view(1, 1, 1, 1, -1, 1)).expand(halves, nw, npair, nfo, 64, 8)
+        prj = wp[co, hid.expand(halves, nw, npair, nfo, 64, 8)]                               # [halves, nw, np, nfo, 64, 8]
+        img = torch.cat([exp.reshape(1, nw, npair, 2 * ks * 512).expand(halves, -1, -1, -1),
+                         prj.reshape(halves, nw, npair, nfo * 512)], 3).contiguous()
+        assert img.numel() * 2 == need, (img.numel() * 2, need)
+        self._image = (nw, img)
+        return self._image
+
     def fp16_safe(self):
         """The block kernel keeps the expanded tensor, the depthwise weights / bias / output and the projection weights
         in fp16 (11-bit mantissa: more precise than bf16 inside its range, but the range is 65504).  Everything the
@@ -288,6 +339,11 @@ def fill_mb_desc(d, x_ptr, y_ptr, n, h, w, pk, dtype_code):
     d.w_project, d.scale_project, d.bias_project = pk.wp.data_ptr(), pk.p.scale.data_ptr(), pk.p.bias.data_ptr()
     d.N, d.H, d.W, d.Cin, d.Chid, d.Cout = n, h, w, pk.cin, pk.chid, pk.cout
     d.stride, d.residual, d.dtype, d.stem = pk.stride, int(pk.residual), dtype_code, pk.stem
+    d.image_nw, d.w_image, d.w_image_bytes = 0, None, 0
+    if w == 16 and not pk.stem and pk.stride == 1:  # ssdk_mbk.hip: the wide blocks on 16-pixel-wide maps
+        im = pk.image()
+        if im is not None:
+            d.image_nw, d.w_image, d.w_image_bytes = im[0], im[1].data_ptr(), im[1].numel() * 2
     return d
 
 

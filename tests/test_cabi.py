@@ -21,7 +21,7 @@ def test_header_symbols_exported():
     assert declared == set(N.EXPORTS), declared ^ set(N.EXPORTS)
     for name in declared:
         assert hasattr(N.lib, name), name
-    assert N.lib.ssdk_version() == 210
+    assert N.lib.ssdk_version() == 220
 
 
 def test_library_is_in_tree_and_has_gfx950_code():

@@ -847,6 +847,61 @@ def test_split_register_flow_block(cin, cout, stride, h, w, n, dtype_name):
 
 
 @pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+@pytest.mark.parametrize("nw", [4, 6, 3])
+@pytest.mark.parametrize("cin,cout,h,n", [(160, 160, 16, 3), (160, 320, 16, 2), (160, 160, 5, 2), (160, 320, 1, 3)])
+def test_row_pair_block_kernel_on_16_wide_maps(cin, cout, h, n, nw, dtype_name, monkeypatch):
+    """ssdk_mbk.hip (16-pixel-wide maps: a work item is a pair of output rows, the hidden channels are split over the waves,
+    every wave streams its own weights from the fragment-major image into MFMA operands; mobilenet.py:56, 84-89) against the
+    torch fp32 block with 16-bit-rounded intermediates, against the LDS-tiled kernel, and bit-reproducible from run to run.
+    160 -> 960 -> 160 (residual) and 160 -> 960 -> 320 (two column halves) -- blocks 15-17 of SSD-MobileNetV2@512 -- on full
+    16x16 maps, on an odd number of rows (a pair with one output row) and on a single row; all three slice counts."""
+    import torch
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+    from ssds.modeling.layers.planner import groups_of
+    from ssds.modeling.nets.mobilenet import InvertedResidual
+
+    monkeypatch.setenv("SSDK_MBK_NW", str(nw))
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    torch.manual_seed(cin * 7 + cout + h + nw)
+    blk = InvertedResidual(cin, cout, 1, 6).eval()
+    for m in blk.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.data = (m.weight.data * 2).to(dtype).float()
+    x = torch.randn(n, cin, h, 16).to(dtype)
+    with torch.no_grad():
+        y = x.float()
+        mods = list(blk.conv.children())
+        y = mods[0](y).to(dtype).float()
+        y = mods[1](y).to(dtype).float()
+        y = mods[3](mods[2](y))
+        if blk.use_res_connect:
+            y = y.to(dtype).float() + x.float()
+    blk = blk.cuda()
+    pk = FC.MbPack(groups_of(blk.conv), blk.use_res_connect, dtype)
+    im = pk.image()
+    assert im is not None and im[0] == nw and im[1].numel() * 2 == N.lib.ssdk_mbk_image_bytes(cin, 6 * cin, cout, nw)
+    got = FC.mbconv_native(x.cuda(), pk, variant=3)
+    name = N.last_kernel()
+    assert "mbk" in name, name
+    _check(got, y, dtype, "row-pair block %d->%d h=%d nw=%d" % (cin, cout, h, nw), floor=1.0)
+    again = FC.mbconv_native(x.cuda(), pk, variant=3)
+    assert torch.equal(got, again), "the exchange is not bit-reproducible"
+    tiled = FC.mbconv_native(x.cuda(), pk, variant=-1)
+    assert "mbk" not in N.last_kernel()
+    assert float((got.float() - tiled.float()).abs().max()) <= 2e-2 * max(1.0, float(y.abs().max()))
+    # a map that is not 16 pixels wide, or a block without an image, never reaches the kernel
+    x8 = torch.randn(n, cin, 8, 8).to(dtype).cuda()
+    FC.mbconv_native(x8, pk, variant=0)
+    assert "mbk" not in N.last_kernel()
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
 def test_fused_blocks_16x16_tiles(dtype_name):
     """Stride-1 blocks on maps large enough for >= 512 tiles run on the 16x16-tile instantiations (strip-tiled
     depthwise, batched expand fragments): a residual block and the stem block, ragged sizes included."""
