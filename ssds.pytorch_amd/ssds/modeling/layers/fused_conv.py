@@ -314,8 +314,28 @@ class MbPack(object):
         hid = torch.where(ok2, chunk2 * 16 + 4 * fg.view(1, 1, 1, 1, -1, 1) + j2 % 4, torch.full_like(chunk2 + fg.view(1, 1, 1, 1, -1, 1), self.chid))
         co = (h_ * (16 * nfo) + 16 * f_ + fr.view(1, 1, 1, 1, -1, 1)).expand(halves, nw, npair, nfo, 64, 8)
         prj = wp[co, hid.expand(halves, nw, npair, nfo, 64, 8)]                               # [halves, nw, np, nfo, 64, 8]
-        img = torch.cat([exp.reshape(1, nw, npair, 2 * ks * 512).expand(halves, -1, -1, -1),
-                         prj.reshape(halves, nw, npair, nfo * 512)], 3).contiguous()
+        wts = torch.cat([exp.reshape(1, nw, npair, 2 * ks * 512).expand(halves, -1, -1, -1),
+                         prj.reshape(halves, nw, npair, nfo * 512)], 3).reshape(-1)
+        # per-slice constants, laid out as the kernel reads them: bias_expand fp32 | taps fp16 | bias_dw / 6 fp16
+        c_, g_, q_ = ar(nchw).view(1, -1, 1, 1), ar(4).view(1, 1, -1, 1), ar(4).view(1, 1, 1, -1)
+        gc = ar(nw).view(-1, 1, 1, 1) * nchw + c_
+        ch = torch.where(gc < nch, gc * 16 + 4 * g_ + q_, torch.full_like(gc + g_ + q_, self.chid))   # [nw, nchw, 4, 4]
+        zf = lambda t: torch.cat([t, t.new_zeros((1,) + tuple(t.shape[1:]))], 0)  # noqa: E731 -- index chid = zeros
+        be = zf(self.e.bias.float())[ch]                                                           # fp32 [nw, nchw, 4, 4]
+        wd = zf(self.wd.reshape(9, self.chid).t().contiguous())[ch]                                # fp16 [nw, nchw, 4, 4, 9]
+        wd = wd.permute(0, 1, 4, 2, 3).contiguous()                                                # [nw, nchw, 9, 4, 4]
+        bd6 = zf((self.bd.float() * torch.tensor(1.0 / 6.0, dtype=torch.float32, device=dev)).to(torch.float16))[ch]
+        misc_kb = (nchw * 384 + 1023) // 1024
+        misc = torch.cat([be.contiguous().view(torch.int16).reshape(nw, -1), wd.view(torch.int16).reshape(nw, -1),
+                          bd6.contiguous().view(torch.int16).reshape(nw, -1)], 1)
+        misc = torch.cat([misc, misc.new_zeros((nw, misc_kb * 512 - misc.shape[1]))], 1).reshape(-1)
+        # projection BN per half: [nfo][4 g][scale * 6 (4 q) | bias (4 q)] fp32
+        cof = (ar(halves).view(-1, 1, 1, 1) * (16 * nfo) + 16 * ar(nfo).view(1, -1, 1, 1) + 4 * ar(4).view(1, 1, -1, 1)
+               + ar(4).view(1, 1, 1, -1))
+        spb = torch.cat([(self.p.scale.float() * 6.0)[cof], self.p.bias.float()[cof]], 3).contiguous()  # [halves, nfo, 4, 8]
+        spb = spb.view(torch.int16).reshape(halves, -1)
+        spb = torch.cat([spb, spb.new_zeros((halves, 1024 - spb.shape[1]))], 1).reshape(-1)
+        img = torch.cat([wts, misc, spb]).contiguous()
         assert img.numel() * 2 == need, (img.numel() * 2, need)
         self._image = (nw, img)
         return self._image

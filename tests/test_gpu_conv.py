@@ -847,14 +847,15 @@ def test_split_register_flow_block(cin, cout, stride, h, w, n, dtype_name):
 
 
 @pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
-@pytest.mark.parametrize("nw", [4, 6, 3])
+@pytest.mark.parametrize("nw,items", [(4, 2), (4, 1), (6, 1), (3, 2)])
 @pytest.mark.parametrize("cin,cout,h,n", [(160, 160, 16, 3), (160, 320, 16, 2), (160, 160, 5, 2), (160, 320, 1, 3)])
-def test_row_pair_block_kernel_on_16_wide_maps(cin, cout, h, n, nw, dtype_name, monkeypatch):
+def test_row_pair_block_kernel_on_16_wide_maps(cin, cout, h, n, nw, items, dtype_name, monkeypatch):
     """ssdk_mbk.hip (16-pixel-wide maps: a work item is a pair of output rows, the hidden channels are split over the waves,
     every wave streams its own weights from the fragment-major image into MFMA operands; mobilenet.py:56, 84-89) against the
     torch fp32 block with 16-bit-rounded intermediates, against the LDS-tiled kernel, and bit-reproducible from run to run.
     160 -> 960 -> 160 (residual) and 160 -> 960 -> 320 (two column halves) -- blocks 15-17 of SSD-MobileNetV2@512 -- on full
-    16x16 maps, on an odd number of rows (a pair with one output row) and on a single row; all three slice counts."""
+    16x16 maps, on an odd number of rows (a pair with one output row) and on a single row; all three slice counts, one and
+    two items per workgroup (an odd number of items falls back to one)."""
     import torch
     from ssds import _native as N
     from ssds.modeling.layers import fused_conv as FC
@@ -862,6 +863,7 @@ def test_row_pair_block_kernel_on_16_wide_maps(cin, cout, h, n, nw, dtype_name, 
     from ssds.modeling.nets.mobilenet import InvertedResidual
 
     monkeypatch.setenv("SSDK_MBK_NW", str(nw))
+    monkeypatch.setenv("SSDK_MBK_ITEMS", str(items))
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
     torch.manual_seed(cin * 7 + cout + h + nw)
     blk = InvertedResidual(cin, cout, 1, 6).eval()
