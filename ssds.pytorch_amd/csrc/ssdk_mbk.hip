@@ -227,22 +227,27 @@ __global__ __launch_bounds__(64 * NW * ITEMS, 2) void mbk_kernel(const MbkParams
     }
   };
 
-  // ---- main loop over this wave's chunk pairs: no barrier, no other wave's data ------------------------------------------
+  // ---- main loop over this wave's chunk pairs: no barrier, no other wave's data.  Every weight fragment is requested about
+  // one chunk phase (~1.5 k cycles) before the MFMA that reads it: the pair's ten projection fragments at its top, the next
+  // pair's first chunk behind this pair's first, the next pair's second chunk behind this pair's second.  (The first version
+  // requested half of the projection fragments and the next chunk right in front of the projection MFMAs: two exposed L2
+  // round trips per pair, 4.1 k cycles per pair for 1.9 k of MFMA time per SIMD.) -------------------------------------------
+  u32x4 wb[KS];  // expand A fragments of the pair's second chunk (an ODD slice's missing chunk: zeros, never used)
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) wb[ks] = wimg[(size_t)(KS + ks) * 64];
   for (int t = 0; t < NP; ++t) {
     const u32x4* wp = wimg + (size_t)t * (PAIR_KB * 64);
     const bool last = t == NP - 1;
+    const u32x4* wn = wimg + (size_t)(last ? t : t + 1) * (PAIR_KB * 64);  // (past the end: the last pair again, harmless)
     u32 d0[2][2], d1[2][2];
-    // chunk 2t: its fragments were requested one chunk ago; request chunk 2t+1's behind its MFMAs
-    u32x4 wb[KS];
+    u32x4 wf[NFO];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wb[ks] = wp[(size_t)(KS + ks) * 64];  // (an ODD slice's missing chunk: zeros, never used)
+    for (int f = 0; f < NFO; ++f) wf[f] = wp[(size_t)(2 * KS + f) * 64];
     chunk(2 * t, wa, d0);
     __builtin_amdgcn_sched_barrier(0);
-    // the projection's first fragments travel while chunk 2t+1 is expanded and filtered
-    constexpr int FH = NFO / 2;
-    u32x4 wf0[FH];
+    u32x4 na[KS];
 #pragma unroll
-    for (int f = 0; f < FH; ++f) wf0[f] = wp[(size_t)(2 * KS + f) * 64];
+    for (int ks = 0; ks < KS; ++ks) na[ks] = wn[(size_t)ks * 64];
     if (!(ODD && last)) {
       chunk(2 * t + 1, wb, d1);
     } else {
@@ -250,15 +255,9 @@ __global__ __launch_bounds__(64 * NW * ITEMS, 2) void mbk_kernel(const MbkParams
       for (int o = 0; o < 2; ++o) d1[o][0] = d1[o][1] = 0u;
     }
     __builtin_amdgcn_sched_barrier(0);
-    // next pair's first chunk (past the end: the last pair again, harmless) and the second half of the projection fragments
-    {
-      const u32x4* wn = wimg + (size_t)(last ? t : t + 1) * (PAIR_KB * 64);
+    u32x4 nb[KS];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) wa[ks] = wn[(size_t)ks * 64];
-    }
-    u32x4 wf1[NFO - FH];
-#pragma unroll
-    for (int f = FH; f < NFO; ++f) wf1[f - FH] = wp[(size_t)(2 * KS + f) * 64];
+    for (int ks = 0; ks < KS; ++ks) nb[ks] = wn[(size_t)(KS + ks) * 64];
     // projection k-step t: the pair's 32 hidden channels ARE the B operand (k-step element j <-> chunk 2t + j/4, channel
     // 4fg + j%4: the permutation the image applies to the projection weights)
     u32x4 db[2];
@@ -272,14 +271,15 @@ __global__ __launch_bounds__(64 * NW * ITEMS, 2) void mbk_kernel(const MbkParams
     }
     mbk_valu_guard();  // db comes out of inline asm (the clamping FMA)
 #pragma unroll
-    for (int f = 0; f < FH; ++f)
+    for (int f = 0; f < NFO; ++f)
 #pragma unroll
-      for (int o = 0; o < 2; ++o) yacc[o][f] = fl_mfma<SSDK_F16>(wf0[f], db[o], yacc[o][f]);  // D[co = 16f + 4fg + q][px = fr]
-#pragma unroll
-    for (int f = FH; f < NFO; ++f)
-#pragma unroll
-      for (int o = 0; o < 2; ++o) yacc[o][f] = fl_mfma<SSDK_F16>(wf1[f - FH], db[o], yacc[o][f]);
+      for (int o = 0; o < 2; ++o) yacc[o][f] = fl_mfma<SSDK_F16>(wf[f], db[o], yacc[o][f]);  // D[co = 16f + 4fg + q][px = fr]
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      wa[ks] = na[ks];
+      wb[ks] = nb[ks];
+    }
   }
   if (stamp) p.dbg[2] = __builtin_readcyclecounter();
 
@@ -287,6 +287,19 @@ __global__ __launch_bounds__(64 * NW * ITEMS, 2) void mbk_kernel(const MbkParams
   // them in wave order 0 .. NW-1, applies the projection BN (+ residual) and stores; one more barrier frees the buffer ----
   unsigned char* xb = smem + L::xch + it * (NW * XF * 1024);
   const unsigned char* spb = smem + L::spb + it * (G::SPB_KB * 1024);
+  // the residual values of the fragments this wave will finalize, requested before the first round (they were one exposed
+  // memory round trip per round)
+  constexpr int GPW = (XF + NW - 1) / NW;  // fragments a wave finalizes per round
+  uint2 resv[ROUNDS][GPW];
+#pragma unroll
+  for (int R = 0; R < ROUNDS; ++R)
+#pragma unroll
+    for (int gg = 0; gg < GPW; ++gg) {
+      const int g = wv + gg * NW, q = R * XF + g, o = q / NFO, f = q % NFO;
+      const int oy = oy0 + o, co = co_base + f * 16 + (int)fg * 4;
+      resv[R][gg] = make_uint2(0u, 0u);
+      if (p.residual && g < XF && oy < H && co < Cout) resv[R][gg] = *reinterpret_cast<const uint2*>(ximg + ((size_t)oy * W + fr) * Cin + co);
+    }
 #pragma unroll
   for (int R = 0; R < ROUNDS; ++R) {
 #pragma unroll
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(64 * NW * ITEMS, 2) void mbk_kernel(const MbkParams
     }
     __syncthreads();
 #pragma unroll
-    for (int gg = 0; gg < (XF + NW - 1) / NW; ++gg) {
+    for (int gg = 0; gg < GPW; ++gg) {
       const int g = wv + gg * NW;  // wave-uniform
       if (g < XF) {
         const int q = R * XF + g, o = q / NFO, f = q % NFO;
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(64 * NW * ITEMS, 2) void mbk_kernel(const MbkParams
           u32 h01 = fl_pack2<DT>(fmaf(y[0], spv[0], bpv[0]), fmaf(y[1], spv[1], bpv[1]));
           u32 h23 = fl_pack2<DT>(fmaf(y[2], spv[2], bpv[2]), fmaf(y[3], spv[3], bpv[3]));
           if (p.residual) {  // rounded to the model dtype first, then x is added (torch's tensor add)
-            const uint2 xr = *reinterpret_cast<const uint2*>(ximg + ((size_t)oy * W + fr) * Cin + co);
+            const uint2 xr = resv[R][gg];
             h01 = fl_pack2<DT>(fl_from16<DT>(h01 & 0xffffu) + fl_from16<DT>(xr.x & 0xffffu), fl_from16<DT>(h01 >> 16) + fl_from16<DT>(xr.x >> 16));
             h23 = fl_pack2<DT>(fl_from16<DT>(h23 & 0xffffu) + fl_from16<DT>(xr.y & 0xffffu), fl_from16<DT>(h23 >> 16) + fl_from16<DT>(xr.y >> 16));
           }
