@@ -328,30 +328,32 @@ typedef struct ssdk_mbconv_desc {
                       no process-wide switch.  ssdk_last_kernel() names the kernel that ran.
                       2: ssdk_mbsplit.hip wherever it exists, 3: ssdk_mbk.hip wherever it exists (tests). */
   /* appended in 0.2.2 (zero = absent).  OPTIONAL image of the block's 1x1 weights and per-channel constants for ssdk_mbk.hip
-   * (16-pixel-wide maps, Cin a multiple of 32, Chid of 16, Cout of 160: the 160 -> 960 -> 160 | 320 blocks of MobileNetV2 on
-   * 16x16 maps, mobilenet.py:56, 84-89), built once per model by the host (ssds/modeling/layers/fused_conv.py MbPack.image);
-   * without it those blocks run on the LDS-tiled kernel.
-   *   image_nw  slices of the hidden channels = waves per work item the image is built for (4 | 6 | 3);
-   *             NCHW = ceil(Chid / 16 / image_nw) chunks of 16 per slice, NP = ceil(NCHW / 2) chunk pairs, KS = Cin / 32
-   *   layout    1. weights [Cout / 160 halves][image_nw slices][NP pairs][2 KS + 10 fragments of 1 KiB]; a fragment = 64 lanes
-   *                x 8 16-bit elements, lane l:
+   * (the blocks of MobileNetV2 on 16- and 32-pixel-wide maps, mobilenet.py:56, 84-89: 64 -> 384 -> 64 | 96 and 96 -> 576 -> 96
+   * @32x32, 96 -> 576 -> 160 / stride 2 @32x32, 160 -> 960 -> 160 | 320 @16x16), built once per model by the host
+   * (ssds/modeling/layers/fused_conv.py MbPack.image); without it those blocks run on the LDS-tiled kernel.
+   *   image_nw  slices of the hidden channels = waves per work item the image is built for (4);
+   *             NCHW = ceil(Chid / 16 / image_nw) chunks of 16 per slice, NP = ceil(NCHW / 2) chunk pairs, KS = Cin / 32,
+   *             NFO = column fragments per half (ssdk_mbk_image_bytes reports it), halves = Cout / (16 NFO)
+   *   layout    1. weights [halves][image_nw slices][NP pairs][2 KS + NFO fragments of 1 KiB]; a fragment = 64 lanes x 8
+   *                16-bit elements, lane l:
    *                  expand (chunk cc of the pair, k-step ks): w_expand[16 c + (l & 15)][32 ks + 8 (l >> 4) + 0..7], c = slice *
    *                    NCHW + 2 pair + cc, in the activation dtype (BN scale folded in, like w_expand);
-   *                  project (column fragment f of half h): element j = w_project[160 h + 16 f + (l & 15)][16 (slice * NCHW +
-   *                    2 pair + j / 4) + 4 (l >> 4) + j % 4], fp16;
+   *                  project (column fragment f of half h): element j = w_project[16 NFO h + 16 f + (l & 15)][16 (slice * NCHW
+   *                    + 2 pair + j / 4) + 4 (l >> 4) + j % 4], fp16;
    *                  zeros where the chunk lies beyond the slice (an odd NCHW) or beyond Chid;
    *             2. constants [image_nw slices][ceil(NCHW * 384 / 1024) KiB]: per slice, for its chunks c (channel = 16 (slice *
    *                NCHW + c) + 4 g + q): bias_expand [NCHW][4 g][4 q] fp32 | w_dw [NCHW][9 taps][4 g][4 q] fp16 |
    *                bias_dw / 6 [NCHW][4 g][4 q] fp16 (fp32 multiply by 1/6, rounded to fp16), zero-padded to the KiB;
-   *             3. projection BN [halves][2 KiB]: [10 f][4 g][scale_project * 6 (4 q fp32) | bias_project (4 q fp32)], channel
-   *                160 h + 16 f + 4 g + q, zero-padded.
-   *   w_image_bytes >= ssdk_mbk_image_bytes(Cin, Chid, Cout, image_nw) (0: no instance of the kernel takes the block). */
+   *             3. projection BN [halves][2 KiB]: [NFO f][4 g][scale_project * 6 (4 q fp32) | bias_project (4 q fp32)], channel
+   *                16 NFO h + 16 f + 4 g + q, zero-padded.
+   *   w_image_bytes >= ssdk_mbk_image_bytes(Cin, Chid, Cout, stride, output width, image_nw, &NFO) (0: no instance of the
+   *   kernel takes the block at that width). */
   int32_t image_nw;
   const void* w_image;
   size_t w_image_bytes;
 } ssdk_mbconv_desc;
 int ssdk_mbconv(const ssdk_mbconv_desc* desc, void* stream);
-size_t ssdk_mbk_image_bytes(int Cin, int Chid, int Cout, int image_nw);
+size_t ssdk_mbk_image_bytes(int Cin, int Chid, int Cout, int stride, int out_width, int image_nw, int* nfo);
 
 /* Weighted feature fusion of the BiFPN (bifpn.py:41-62), NHWC, one launch:
  *   y = w0 * a + w1 * R_b(b) [+ w2 * R_c(c)]      a, y: [N][H][W][C]

@@ -108,7 +108,7 @@ def _load():
     lib.ssdk_version.restype = i32
     lib.ssdk_last_error.restype = c.c_char_p
     lib.ssdk_last_kernel.restype = c.c_char_p
-    lib.ssdk_mbk_image_bytes.argtypes = [i32] * 4
+    lib.ssdk_mbk_image_bytes.argtypes = [i32] * 6 + [c.POINTER(i32)]
     lib.ssdk_mbk_image_bytes.restype = sz
     lib.ssdk_fuse.argtypes = [c.POINTER(FuseDesc), vp]
     lib.ssdk_fuse.restype = i32

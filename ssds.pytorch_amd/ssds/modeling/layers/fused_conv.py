@@ -270,21 +270,27 @@ class MbPack(object):
         self.wp = cp.weight.detach().float().permute(0, 2, 3, 1).contiguous().to(torch.float16)
 
 
-    def image(self, nw=None):
-        """(nw, tensor) -- the fragment-major image of the two 1x1 weight matrices for csrc/ssdk_mbk.hip (layout: include/ssdk.h
-        ``ssdk_mbconv_desc.w_image``), or None where no instance of that kernel takes the block (16-pixel-wide maps are the
-        caller's condition: the image depends on the channel counts only).  Built once per pack: a pure permutation of
-        ``e.w`` (activation dtype, BN scale folded in) and ``wp`` (fp16), both carried as 16-bit words.  ``nw``: slices of the
-        hidden channels = waves per workgroup (SSDK_MBK_NW, default 4)."""
-        if self.stem or self.stride != 1:
+    def image(self, w_in, nw=None):
+        """(nw, tensor) -- the image of the two 1x1 weight matrices and the per-channel constants for csrc/ssdk_mbk.hip
+        (layout: include/ssdk.h ``ssdk_mbconv_desc.w_image``) on a map ``w_in`` pixels wide, or None where no instance of that
+        kernel takes the block.  Built once per pack and output width: pure permutations of ``e.w`` (activation dtype, BN
+        scale folded in), ``wp`` / ``wd`` (fp16) and the folded biases, carried as 16-bit words.  ``nw``: slices of the hidden
+        channels = waves per work item (4)."""
+        if self.stem or self.stride not in (1, 2):
             return None
-        nw = int(os.environ.get("SSDK_MBK_NW", "4")) if nw is None else int(nw)
-        if self._image is not None and self._image[0] == nw:
-            return self._image
-        need = int(N.lib.ssdk_mbk_image_bytes(self.cin, self.chid, self.cout, nw))
+        nw = 4 if nw is None else int(nw)
+        wo = (w_in + 2 - 3) // self.stride + 1
+        if w_in != wo * self.stride:
+            return None
+        key = (nw, wo)
+        if self._image is not None and self._image[0] == key:
+            return self._image[1]
+        nfo_c = ctypes.c_int(0)
+        need = int(N.lib.ssdk_mbk_image_bytes(self.cin, self.chid, self.cout, self.stride, wo, nw, ctypes.byref(nfo_c)))
         if need == 0:
+            self._image = (key, None)
             return None
-        ks, nch, nfo = self.cin // 32, self.chid // 16, 10
+        ks, nch, nfo = self.cin // 32, self.chid // 16, int(nfo_c.value)
         nchw = (nch + nw - 1) // nw
         npair = (nchw + 1) // 2
         halves = self.cout // (16 * nfo)
@@ -337,8 +343,8 @@ class MbPack(object):
         spb = torch.cat([spb, spb.new_zeros((halves, 1024 - spb.shape[1]))], 1).reshape(-1)
         img = torch.cat([wts, misc, spb]).contiguous()
         assert img.numel() * 2 == need, (img.numel() * 2, need)
-        self._image = (nw, img)
-        return self._image
+        self._image = (key, (nw, img))
+        return self._image[1]
 
     def fp16_safe(self):
         """The block kernel keeps the expanded tensor, the depthwise weights / bias / output and the projection weights
@@ -360,8 +366,8 @@ def fill_mb_desc(d, x_ptr, y_ptr, n, h, w, pk, dtype_code):
     d.N, d.H, d.W, d.Cin, d.Chid, d.Cout = n, h, w, pk.cin, pk.chid, pk.cout
     d.stride, d.residual, d.dtype, d.stem = pk.stride, int(pk.residual), dtype_code, pk.stem
     d.image_nw, d.w_image, d.w_image_bytes = 0, None, 0
-    if w == 16 and not pk.stem and pk.stride == 1:  # ssdk_mbk.hip: the wide blocks on 16-pixel-wide maps
-        im = pk.image()
+    if w in (16, 32) and not pk.stem:  # ssdk_mbk.hip: the blocks on 16- and 32-pixel-wide maps
+        im = pk.image(w)
         if im is not None:
             d.image_nw, d.w_image, d.w_image_bytes = im[0], im[1].data_ptr(), im[1].numel() * 2
     return d

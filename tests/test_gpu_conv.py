@@ -846,27 +846,32 @@ def test_split_register_flow_block(cin, cout, stride, h, w, n, dtype_name):
     assert float((got.float() - tiled.float()).abs().max()) <= 2e-2 * max(1.0, float(y.abs().max()))
 
 
+MBK = [
+    # cin, cout, stride, h, w, n -- the blocks of MobileNetV2 from the 32x32 maps down (SSD-MobileNetV2@512, blocks 8-17)
+    (160, 160, 1, 16, 16, 3), (160, 320, 1, 16, 16, 2),   # 16x16 maps: one strip; 320 columns = two halves
+    (160, 160, 1, 5, 16, 2), (160, 320, 1, 1, 16, 3),     # an odd number of rows (a pair with one output row), a single row
+    (96, 160, 2, 32, 32, 2), (96, 160, 2, 10, 32, 3),     # stride 2, 32 -> 16 columns (even / odd column fragments); Ho = 5
+    (64, 64, 1, 32, 32, 2), (64, 96, 1, 6, 32, 3),        # 32-wide maps: two strips per row, cross-strip taps
+    (96, 96, 1, 32, 32, 2), (96, 96, 1, 3, 32, 2),
+]
+
+
 @pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
-@pytest.mark.parametrize("nw,items", [(4, 2), (4, 1), (6, 1), (3, 2)])
-@pytest.mark.parametrize("cin,cout,h,n", [(160, 160, 16, 3), (160, 320, 16, 2), (160, 160, 5, 2), (160, 320, 1, 3)])
-def test_row_pair_block_kernel_on_16_wide_maps(cin, cout, h, n, nw, items, dtype_name, monkeypatch):
-    """ssdk_mbk.hip (16-pixel-wide maps: a work item is a pair of output rows, the hidden channels are split over the waves,
-    every wave streams its own weights from the fragment-major image into MFMA operands; mobilenet.py:56, 84-89) against the
-    torch fp32 block with 16-bit-rounded intermediates, against the LDS-tiled kernel, and bit-reproducible from run to run.
-    160 -> 960 -> 160 (residual) and 160 -> 960 -> 320 (two column halves) -- blocks 15-17 of SSD-MobileNetV2@512 -- on full
-    16x16 maps, on an odd number of rows (a pair with one output row) and on a single row; all three slice counts, one and
-    two items per workgroup (an odd number of items falls back to one)."""
+@pytest.mark.parametrize("cin,cout,stride,h,w,n", MBK)
+def test_row_pair_block_kernel(cin, cout, stride, h, w, n, dtype_name):
+    """ssdk_mbk.hip (16- and 32-pixel-wide maps: a work item is a pair of output rows, the hidden channels are split over the
+    waves, every wave streams its own weights from the fragment-major image into MFMA operands; mobilenet.py:56, 84-89)
+    against the torch fp32 block with 16-bit-rounded intermediates, against the LDS-tiled kernel, and bit-reproducible from
+    run to run."""
     import torch
     from ssds import _native as N
     from ssds.modeling.layers import fused_conv as FC
     from ssds.modeling.layers.planner import groups_of
     from ssds.modeling.nets.mobilenet import InvertedResidual
 
-    monkeypatch.setenv("SSDK_MBK_NW", str(nw))
-    monkeypatch.setenv("SSDK_MBK_ITEMS", str(items))
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
-    torch.manual_seed(cin * 7 + cout + h + nw)
-    blk = InvertedResidual(cin, cout, 1, 6).eval()
+    torch.manual_seed(cin * 7 + cout + h + stride)
+    blk = InvertedResidual(cin, cout, stride, 6).eval()
     for m in blk.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
             m.running_mean.normal_(0, 0.2)
@@ -875,7 +880,7 @@ def test_row_pair_block_kernel_on_16_wide_maps(cin, cout, h, n, nw, items, dtype
             m.bias.data.normal_(0, 0.2)
         if isinstance(m, torch.nn.Conv2d):
             m.weight.data = (m.weight.data * 2).to(dtype).float()
-    x = torch.randn(n, cin, h, 16).to(dtype)
+    x = torch.randn(n, cin, h, w).to(dtype)
     with torch.no_grad():
         y = x.float()
         mods = list(blk.conv.children())
@@ -886,18 +891,18 @@ def test_row_pair_block_kernel_on_16_wide_maps(cin, cout, h, n, nw, items, dtype
             y = y.to(dtype).float() + x.float()
     blk = blk.cuda()
     pk = FC.MbPack(groups_of(blk.conv), blk.use_res_connect, dtype)
-    im = pk.image()
-    assert im is not None and im[0] == nw and im[1].numel() * 2 == N.lib.ssdk_mbk_image_bytes(cin, 6 * cin, cout, nw)
+    im = pk.image(w)
+    assert im is not None and im[0] == 4
     got = FC.mbconv_native(x.cuda(), pk, variant=3)
     name = N.last_kernel()
     assert "mbk" in name, name
-    _check(got, y, dtype, "row-pair block %d->%d h=%d nw=%d" % (cin, cout, h, nw), floor=1.0)
+    _check(got, y, dtype, "row-pair block %d->%d s%d %dx%d" % (cin, cout, stride, h, w), floor=1.0)
     again = FC.mbconv_native(x.cuda(), pk, variant=3)
     assert torch.equal(got, again), "the exchange is not bit-reproducible"
     tiled = FC.mbconv_native(x.cuda(), pk, variant=-1)
     assert "mbk" not in N.last_kernel()
     assert float((got.float() - tiled.float()).abs().max()) <= 2e-2 * max(1.0, float(y.abs().max()))
-    # a map that is not 16 pixels wide, or a block without an image, never reaches the kernel
+    # a map of another width never reaches the kernel
     x8 = torch.randn(n, cin, 8, 8).to(dtype).cuda()
     FC.mbconv_native(x8, pk, variant=0)
     assert "mbk" not in N.last_kernel()

@@ -17,7 +17,6 @@ from ssds.modeling.nets.mobilenet import InvertedResidual
 dtype = torch.bfloat16
 torch.manual_seed(5)
 cin, cout, h, n, nw = 160, 160, 16, 2, 4
-os.environ["SSDK_MBK_NW"] = str(nw)
 blk = InvertedResidual(cin, cout, 1, 6).eval()
 for m in blk.modules():
     if isinstance(m, torch.nn.BatchNorm2d):
