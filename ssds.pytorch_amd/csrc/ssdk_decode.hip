@@ -594,7 +594,7 @@ __global__ __launch_bounds__(kLevelThreads) void level_kernel(const LevelParams 
   const u64* src = p.cand + ((size_t)b * p.units_per_image + d.unit_base) * K;
   u32 n;
   if (d.units == 1) {  // the scan kernel already produced the exact top-K of this (image, level)
-    n = p.cand_cnt[(size_t)b * p.units_per_image + d.unit_base];
+    n = p.cand_cnt[(size_t)b * p.units_per_image + d.unit_base] & 0x7fffffffu;  // (bit 31: scan16_kernel's "ordered ties" flag)
     for (u32 i = tid; i < n; i += NT) buf[i] = src[i];
     __syncthreads();
   } else {

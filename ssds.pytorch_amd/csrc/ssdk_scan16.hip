@@ -464,6 +464,7 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
 
   u32 cnt = 0;
   bool done = false;
+  bool ordered = false;  // the unit's list is its ties alone, in index order (the flag in cand_cnt: see the end of the kernel)
   if ((sc->ovf | sc->nan) == 0u) {
     if (stamp) p.stamps[11] = clock64();
     // ---- select: exact top-K of the extracted keys (+ the tie keys), unordered, straight to the workspace ----------
@@ -478,6 +479,7 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
       for (u32 i = lane; i < kc; i += 64) out[before + i] = seg[i];
       for (u32 i = tid; i < ntie; i += NT) out[nk - ntie + i] = tiebuf[i];
       cnt = nk;
+      ordered = ntie != 0u && nk == ntie;  // nothing beat the cut: the list IS the tie prefix (workgroup-uniform)
     } else {
       if (tid == 0) sc->cutbin = ~0u;
       __syncthreads();
@@ -540,7 +542,10 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
     for (u32 i = tid; i < cnt; i += NT) out[i] = buf[i];
   }
   for (u32 i = cnt + tid; i < K; i += NT) out[i] = 0ull;
-  if (tid == 0) *out_cnt = cnt;
+  // bit 31: every key of the list carries the SAME score and the list is in descending key (= ascending index) order -- what a
+  // unit of an all-equal image leaves (the reference-init network: every score of a level is one bf16 value).  levelsel_kernel
+  // then takes a full first unit as the level's answer without selecting anything (ssdk_tail.hip).
+  if (tid == 0) *out_cnt = cnt | (ordered ? 0x80000000u : 0u);
   if (wall) p.stamps[24 + 2 * blockIdx.x + 1] = (wall_clock64() & ~1ull) | (done ? 0ull : 1ull);  // bit 0: took the exact fallback
   if (stamp) {
     p.stamps[3] = clock64();

@@ -251,7 +251,7 @@ struct alignas(16) SelLds {
   u32 ufull[kSelUnits];     // ... and whether its list is full (K keys)
   u64 lb;                   // lower bound of the level's K-th key (largest minimum of its FULL unit lists), when needed
   int cutbin;               // -1: the level offers <= K keys, every one is a winner
-  u32 ln, above, nw, bcnt, generic, pad0, pad1;
+  u32 ln, above, nw, bcnt, generic, smax, pad1;  // smax: largest score (ordered bits) of the level's keys (ties fast path)
   SelScratch ss;
 };
 __host__ __device__ inline size_t sel_lds_bytes(u32 K) {
@@ -301,6 +301,7 @@ __device__ __forceinline__ void levelsel_body(const SelParams& p, const u32 l, c
     S->nw = 0;
     S->bcnt = 0;
     S->generic = 0;
+    S->smax = 0;
   }
   // f(key, i) for every non-zero key slot of the level (all lanes of a wave run the same trips)
   auto for_each_key = [&](auto f) {
@@ -315,6 +316,41 @@ __device__ __forceinline__ void levelsel_body(const SelParams& p, const u32 l, c
   __syncthreads();
   u64 lb = 0ull;  // lower bound of the level's K-th key (0: none needed so far)
   if (stamp) p.stamps[1] = clock64();
+
+  // ---- ties fast path (round 5).  scan16_kernel flags a unit whose list is nothing but its FIRST K ties, in index order (bit
+  // 31 of its count): every key of it carries one score s.  If that is the level's first unit, its list is full and no key of
+  // the level has a larger score, the list IS the level's top K under the (score desc, index asc) contract -- every other key
+  // with score s has a larger index -- already in final order: no histogram, no scatter, no rank.  This is the reference-init
+  // network (box.py:446 on an all-equal level), where the generic route cost two histogram passes with every key on ONE LDS
+  // counter, a 64-bit atomicMin pass and K^2 rank compares (26.7 vs 12.9 us for the launch).
+  bool fast = false;
+  {
+    const u32 c0 = p.cand_cnt[(size_t)b * p.units_per_image + p.lv[l].unit_base];  // workgroup-uniform
+    if ((c0 & 0x80000000u) && (c0 & 0x7fffffffu) == K) {
+      u32 mx = 0;
+      for_each_key([&](u64 key, u32) { mx = (u32)(key >> 32) > mx ? (u32)(key >> 32) : mx; });
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        const u32 y = (u32)__shfl_xor((int)mx, d);
+        mx = y > mx ? y : mx;
+      }
+      if (lane == 0) atomicMax(&S->smax, mx);
+      __syncthreads();
+      fast = S->smax == (u32)(keys[0] >> 32);  // (slot 0 = the flagged unit's first key; a uniform load)
+      if (fast) {
+#pragma unroll
+        for (u32 t = 0; t < kSelReg; ++t) {
+          const u32 i = tid + t * NT;
+          if (i < K) wkeys[i] = kreg[t];  // (K <= 512 <= kSelReg * NT: the first unit's list sits in the register keys)
+        }
+        if (tid == 0) {
+          S->nw = K;
+          S->above = 0;  // every winner is "boundary": its slot is its rank
+        }
+      }
+    }
+  }
+  if (!fast) {
 
   // ---- B1 pass 1: histogram of the keys, the boundary bin, the groups' first slots.  Trip 0 takes every key.  If its
   // boundary bin holds more than K keys and the level has several units, trip 1 first derives a LOWER BOUND of the level's
@@ -471,6 +507,7 @@ __device__ __forceinline__ void levelsel_body(const SelParams& p, const u32 l, c
       if (ab + r < nw) wkeys[ab + r] = me;
     }
   }
+  }  // !fast
   __syncthreads();
   if (stamp) p.stamps[2] = clock64();
   // ---- order + B2: every winner finds its rank (a key alone in its bin's group is in place; more -- ties in score, coarse
@@ -537,8 +574,10 @@ struct alignas(16) WalkLds {
   float rcls[kRoundMax];
   SelScratch ss;
 };
+// [WalkLds][nkeys: Mp x 8][kbox: ndet x 16][karea | kcls: ndet x 8][abox: Mp x 16][acls: Mp x 4]
 __host__ __device__ inline size_t walk_lds_bytes(u32 M, u32 ndet) {
-  return sizeof(WalkLds) + (size_t)(M < 128u ? 128u : M) * 8 + (size_t)ndet * 16 + ((((size_t)ndet * 8) + 15) & ~(size_t)15) + 64;
+  const size_t Mp = M < 128u ? 128u : M;
+  return sizeof(WalkLds) + Mp * 8 + (size_t)ndet * 16 + ((((size_t)ndet * 8) + 15) & ~(size_t)15) + Mp * 16 + Mp * 4 + 64;
 }
 
 template <bool COH = false>
@@ -555,6 +594,12 @@ __device__ __forceinline__ void nmswalk_body(const WalkParams& p, const u32 b, u
   q += (size_t)ndet * 16;
   float* karea = reinterpret_cast<float*>(q);
   float* kcls = karea + ndet;
+  q += (((size_t)ndet * 8) + 15) & ~(size_t)15;
+  // every candidate's box and class, fetched together with its score (round 5: the round's gather was a second, dependent
+  // memory round trip per round; 20 bytes x L*K = 36 KB of LDS on a kernel that owns its CU anyway)
+  float4* abox = reinterpret_cast<float4*>(q);
+  q += (size_t)Mp * 16;
+  float* acls = reinterpret_cast<float*>(q);
   const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const bool stamp = p.stamps != nullptr && b == 0 && tid == 0;
   if (stamp) p.stamps[3] = clock64();
@@ -573,6 +618,8 @@ __device__ __forceinline__ void nmswalk_body(const WalkParams& p, const u32 b, u
     u64 nkey = 0ull;
     if (pos < N) {
       const float s = tail_ld<COH>(sc + pos);
+      abox[pos] = tail_ld4<COH>(bx + pos);
+      acls[pos] = tail_ld<COH>(cl + pos);
       nkey = (s > 0.0f) ? make_key(s, pos) : 0ull;  // box.py:496 (NaN drops out too)
     }
     nkeys[pos] = nkey;
@@ -657,6 +704,71 @@ __device__ __forceinline__ void nmswalk_body(const WalkParams& p, const u32 b, u
     u32 r = S->chead;
     if (r > kRoundMax || (S->ccut == 0u && r > want)) {
       r = want;
+      // Ties fast path (round 5): the round's boundary bin holds too many keys.  If every key of that bin carries the SAME
+      // score (the reference-init network: all rescored scores of an image are one value), the keys order by position, and
+      // nkeys[] is indexed by position: the round = every key of the bins above + the first `need` keys of the boundary bin
+      // in array order -- one min / max pass and one prefix count instead of the adaptive radix select (31.5 vs 14.9 us for
+      // the launch on the bench's own input).
+      const u32 cc = S->ccut;
+      u32 lo = 0xffffffffu, hi2 = 0u, inb = 0u;
+      for (u32 i = tid; i < Mp; i += NT) {
+        const u64 k = nkeys[i];
+        if (k != 0ull && cbin_of(k) == cc) {
+          const u32 sbits = (u32)(k >> 32);
+          lo = sbits < lo ? sbits : lo;
+          hi2 = sbits > hi2 ? sbits : hi2;
+          ++inb;
+        }
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        const u32 a = (u32)__shfl_xor((int)lo, d), b2 = (u32)__shfl_xor((int)hi2, d);
+        lo = a < lo ? a : lo;
+        hi2 = b2 > hi2 ? b2 : hi2;
+        inb += (u32)__shfl_xor((int)inb, d);
+      }
+      if (tid == 0) {
+        S->ss.bin = 0xffffffffu;  // min
+        S->ss.above = 0u;         // max
+        S->ss.cb = 0u;            // keys in the boundary bin
+      }
+      __syncthreads();
+      if (lane == 0 && inb) {
+        atomicMin(&S->ss.bin, lo);
+        atomicMax(&S->ss.above, hi2);
+        atomicAdd(&S->ss.cb, inb);
+      }
+      __syncthreads();
+      const bool uniform = S->ss.bin == S->ss.above && S->ss.cb >= 1u;
+      const u32 higher = S->chead - S->ss.cb;  // keys in the bins above the boundary bin (all of them belong to the round)
+      if (uniform && higher < want) {  // workgroup-uniform
+        const u32 need = want - higher;
+        u32 run = 0;  // boundary-bin keys in front of this trip's positions
+        for (u32 i0 = 0; i0 < Mp; i0 += NT) {  // uniform trip count (Mp is a multiple of 64; whole waves)
+          const u32 i = i0 + tid;
+          const u64 k = i < Mp ? nkeys[i] : 0ull;
+          const bool have = k != 0ull;
+          const u32 bin = have ? cbin_of(k) : 0u;
+          const bool edge = have && bin == cc, up = have && bin > cc;
+          const u64 me = __ballot(edge);
+          if (lane == 0) S->ss.wsum[wave] = (u32)__popcll(me);
+          __syncthreads();
+          u32 before = run, all = 0;
+#pragma unroll
+          for (u32 w = 0; w < NW; ++w) {
+            const u32 cw = S->ss.wsum[w];
+            before += w < wave ? cw : 0u;
+            all += cw;
+          }
+          const bool take = up || (edge && before + mbcnt(me) < need);
+          if (take) {
+            S->top_u[atomicAdd(&S->topcnt, 1u)] = k;
+            nkeys[i] = 0ull;
+          }
+          run += all;
+          __syncthreads();
+        }
+      } else {
       u64 T = 1ull;  // every remaining (non-zero) key
       if (left > r) T = wg_select_kth<NT>(nkeys, Mp, r, &S->ss);  // r-th largest of the remaining keys (box.py:505)
       for (u32 i = tid; i < Mp; i += NT) {
@@ -665,6 +777,7 @@ __device__ __forceinline__ void nmswalk_body(const WalkParams& p, const u32 b, u
           S->top_u[atomicAdd(&S->topcnt, 1u)] = k;
           nkeys[i] = 0ull;
         }
+      }
       }
       __syncthreads();
       for (u32 i = tid; i < r; i += NT) {
@@ -695,9 +808,9 @@ __device__ __forceinline__ void nmswalk_body(const WalkParams& p, const u32 b, u
     // the round's boxes and classes, in walk order (one gather for the whole round)
     for (u32 i = tid; i < r; i += NT) {
       const u32 pos = key_index(S->sorted[i]);
-      const float4 bb = tail_ld4<COH>(bx + pos);
+      const float4 bb = abox[pos];
       S->rbox[i] = bb;
-      S->rcls[i] = tail_ld<COH>(cl + pos);
+      S->rcls[i] = acls[pos];
       if ((bb.x != bb.x) | (bb.y != bb.y) | (bb.z != bb.z) | (bb.w != bb.w)) S->hasnan = 1u;
     }
     __syncthreads();
