@@ -405,11 +405,13 @@ static void mbk_launch(const MbkParams& p, hipStream_t stream) {
 // The instantiations: (S, NS, KS, NCHW, NFO), all with NW = 4 slices -- the blocks of MobileNetV2 from the 32x32 maps down:
 //   1 1 5 15 10   160 -> 960 -> 160 | 320 @16x16        1 2 2  6 4    64 -> 384 -> 64 @32x32      1 2 3 9 6   96 -> 576 -> 96 @32x32
 //   2 1 3  9 10    96 -> 576 -> 160 @32x32 -> 16x16     1 2 2  6 6    64 -> 384 -> 96 @32x32
+//   2 2 1  3  4    32 -> 192 -> 64 @64x64 -> 32x32      1 4 1  3 2    32 -> 192 -> 32 @64x64
 constexpr int kMbkNW = 4;
 struct MbkInst {
   int s, ns, ks, nchw, nfo;
 };
-static const MbkInst kMbkInst[] = {{1, 1, 5, 15, 10}, {2, 1, 3, 9, 10}, {1, 2, 2, 6, 4}, {1, 2, 2, 6, 6}, {1, 2, 3, 9, 6}};
+static const MbkInst kMbkInst[] = {{1, 1, 5, 15, 10}, {2, 1, 3, 9, 10}, {1, 2, 2, 6, 4}, {1, 2, 2, 6, 6}, {1, 2, 3, 9, 6},
+                                   {2, 2, 1, 3, 4}, {1, 4, 1, 3, 2}};
 
 // -> index into kMbkInst, or -1.  Wo: output width.
 static int mbk_find(int stride, int Wo, int Cin, int Chid, int Cout, int nw, int* halves) {
@@ -432,6 +434,8 @@ static size_t mbk_bytes(int inst, int halves) {
     case 2: return MbkGeo<2, kMbkNW, 6, 4>::bytes(halves);
     case 3: return MbkGeo<2, kMbkNW, 6, 6>::bytes(halves);
     case 4: return MbkGeo<3, kMbkNW, 9, 6>::bytes(halves);
+    case 5: return MbkGeo<1, kMbkNW, 3, 4>::bytes(halves);
+    case 6: return MbkGeo<1, kMbkNW, 3, 2>::bytes(halves);
   }
   return 0;
 }
@@ -445,6 +449,8 @@ static void mbk_dispatch(const MbkParams& p, int inst, hipStream_t stream) {
     case 2: mbk_launch<DT, 1, 2, 2, kMbkNW, 6, 4>(p, stream); break;
     case 3: mbk_launch<DT, 1, 2, 2, kMbkNW, 6, 6>(p, stream); break;
     case 4: mbk_launch<DT, 1, 2, 3, kMbkNW, 9, 6>(p, stream); break;
+    case 5: mbk_launch<DT, 2, 2, 1, kMbkNW, 3, 4>(p, stream); break;
+    case 6: mbk_launch<DT, 1, 4, 1, kMbkNW, 3, 2>(p, stream); break;
   }
 }
 

@@ -366,7 +366,7 @@ def fill_mb_desc(d, x_ptr, y_ptr, n, h, w, pk, dtype_code):
     d.N, d.H, d.W, d.Cin, d.Chid, d.Cout = n, h, w, pk.cin, pk.chid, pk.cout
     d.stride, d.residual, d.dtype, d.stem = pk.stride, int(pk.residual), dtype_code, pk.stem
     d.image_nw, d.w_image, d.w_image_bytes = 0, None, 0
-    if w in (16, 32) and not pk.stem:  # ssdk_mbk.hip: the blocks on 16- and 32-pixel-wide maps
+    if w in (16, 32, 64) and not pk.stem:  # ssdk_mbk.hip: the blocks on 16- to 64-pixel-wide maps
         im = pk.image(w)
         if im is not None:
             d.image_nw, d.w_image, d.w_image_bytes = im[0], im[1].data_ptr(), im[1].numel() * 2

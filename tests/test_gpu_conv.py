@@ -853,6 +853,8 @@ MBK = [
     (96, 160, 2, 32, 32, 2), (96, 160, 2, 10, 32, 3),     # stride 2, 32 -> 16 columns (even / odd column fragments); Ho = 5
     (64, 64, 1, 32, 32, 2), (64, 96, 1, 6, 32, 3),        # 32-wide maps: two strips per row, cross-strip taps
     (96, 96, 1, 32, 32, 2), (96, 96, 1, 3, 32, 2),
+    (32, 64, 2, 64, 64, 2), (32, 64, 2, 6, 64, 3),        # stride 2 with two output strips (four input fragments per row)
+    (32, 32, 1, 64, 64, 2), (32, 32, 1, 5, 64, 2),        # 64-wide maps: four strips per row
 ]
 
 
