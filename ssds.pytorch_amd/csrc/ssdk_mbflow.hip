@@ -519,7 +519,7 @@ static bool flow_dispatch(const FlowParams& p, int nch, int nfo, unsigned grid, 
 int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
   static const int env = getenv("SSDK_MB_FLOW") ? atoi(getenv("SSDK_MB_FLOW")) : 1;
   const int variant = d->variant;  // 0 auto, 1 register-flow wherever it exists, -1 never (ssdk_mbconv_desc)
-  if ((!env && variant <= 0) || variant < 0 || variant == 2) return 1;  // (2 = the split kernel of ssdk_mbsplit.hip)
+  if ((!env && variant <= 0) || variant < 0 || variant == 2 || variant == 3) return 1;  // (2 / 3 = ssdk_mbsplit.hip / ssdk_mbk.hip)
   const bool stem = d->stem != 0;
   if (stem) {  // network stem + expand-free first block: 3x3/s2 conv (<= 3 channels -> 32) as the "expand" GEMM, dw stride 1, 32 -> 16
     if (d->Cin > 3 || d->Chid != 32 || d->Cout != 16 || d->stride != 1 || d->residual) return 1;

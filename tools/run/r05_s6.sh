@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/s6; mkdir -p $OUT
 ( timeout 600 python -m pytest tests/test_gpu_conv.py -q -k "row_pair" 2>&1 | tail -25 ) > $OUT/t_mbk.log 2>&1; tail -6 $OUT/t_mbk.log
 # instance bits: 2 = 16x16 s1, 4 = 32->16 s2, 8 / 16 = 64->384->64 | 96, 32 = 96->576->96, 64 = block 7 (64->32 s2), 128 = blocks 5-6 (64x64)
-for v in "SSDK_MBK=62" "SSDK_MBK=126" "SSDK_MBK=190" "SSDK_MBK=1"; do
+for v in "SSDK_MBK=1" "SSDK_MBK=1 SSDK_MBK_FIRST=1"; do
   tag=$(echo $v | tr '= ' '__')
   env $v timeout 300 python bench.py --steps 20 --warmup 5 --layers 1 --cpu-sample 0 > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err
   python - <<PY
