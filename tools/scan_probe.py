@@ -109,6 +109,9 @@ def run(name, make, thr=0.01, reps=20):
 
 run("SURVEY 8d heads sigmoid(N(-4.6,1.5))", lambda *s: torch.sigmoid(torch.randn(*s, device="cuda") * 1.5 - 4.6))
 run("all equal (focal prior)", lambda *s: torch.full(s, 0.01, device="cuda"))
+# the reference-init network behind a SHARED tower (FPN / BiFPN bench input): logits -log(99) +- a little, i.e. a handful of
+# adjacent 16-bit values around the threshold, each occurring millions of times
+run("near ties: sigmoid(N(-4.595, 0.02))", lambda *s: torch.sigmoid(torch.randn(*s, device="cuda") * 0.02 - 4.595))
 run("uniform, half above thr", lambda *s: torch.rand(*s, device="cuda") * 0.02)
 run("sparse, 0.1% above thr", lambda *s: torch.rand(*s, device="cuda") * 0.01001)
 run("nothing above thr", lambda *s: torch.rand(*s, device="cuda") * 0.009)
