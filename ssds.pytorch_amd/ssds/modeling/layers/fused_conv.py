@@ -667,12 +667,17 @@ class ConvPlan(object):
         self.keep.append(pk)
         return (out, n, pk.cout, ho, wo)
 
-    def xpair(self, val, p1, p2):
+    def xpair(self, val, p1, p2, lane=0):
         buf, n, c, h, w = val
         assert c == p1.cin, (c, p1.cin)
         ho, wo = _out_hw(h, w, 3, 2)
         out = self.arena.get(n * p2.cout * ho * wo * self.es)
-        self.layers.append(dict(kind="xpair", x=buf, n=n, h=h, w=w, pack=p1, pack2=p2, y=out))
+        if lane:  # a side-stream chain op: its buffers are never handed out again (see conv())
+            self.side_chain = True
+            self.pinned.add(out)
+            if not isinstance(buf, ExtBuf):
+                self.pinned.add(buf)
+        self.layers.append(dict(kind="xpair", x=buf, n=n, h=h, w=w, pack=p1, pack2=p2, y=out, lane=lane))
         self.keep.extend([p1, p2])
         return (out, n, p2.cout, ho, wo)
 
@@ -765,6 +770,7 @@ class ConvPlan(object):
                 continue
             if kind == "xpair":
                 op.kind = N.OP_XPAIR
+                op.lane = L.get("lane", 0)
                 fill_xpair_desc(op.xpair, self._ptr(L["x"], self.patches, i, "xpair.x"), self.arena.ptr(L["y"]), L["n"], L["h"],
                                 L["w"], L["pack"], L["pack2"], self.dtype_code)
                 continue

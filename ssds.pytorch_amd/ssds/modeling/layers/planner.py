@@ -40,7 +40,7 @@ def groups_of(module):
     return groups
 
 
-def record_chain(plan, val, module, residual=None, keep_input=False):
+def record_chain(plan, val, module, residual=None, keep_input=False, lane=0):
     """Record the Conv-BN-act chain of ``module`` starting from value ``val``; the residual (if any, always
     the chain input) is added in the epilogue of the LAST conv.  Intermediate buffers are released as soon
     as they have been read; the chain input is released at the end unless ``keep_input``."""
@@ -48,7 +48,7 @@ def record_chain(plan, val, module, residual=None, keep_input=False):
     if residual is None and len(groups) == 2:  # an SSD extra layer on a small map: one launch (csrc/ssdk_xpair.hip)
         p1, p2 = (ConvPack(conv, bn, act, plan.dtype) for conv, bn, act in groups)
         if xpair_supported(p1, p2, val[3], val[4]):
-            out = plan.xpair(val, p1, p2)
+            out = plan.xpair(val, p1, p2, lane=lane)
             if not keep_input:
                 plan.release(val)
             return out
@@ -56,7 +56,7 @@ def record_chain(plan, val, module, residual=None, keep_input=False):
     for i, (conv, bn, act) in enumerate(groups):
         pack = ConvPack(conv, bn, act, plan.dtype)
         last = i == len(groups) - 1
-        nxt = plan.conv(cur, pack, residual=residual if last else None)
+        nxt = plan.conv(cur, pack, residual=residual if last else None, lane=lane)
         if cur is not val:
             plan.release(cur)
         cur = nxt
@@ -126,8 +126,14 @@ def build_ssd_plan(model, x):
 
     from ssds.modeling.nets.mobilenet import MobileNetEx
 
+    # SSDK_SSD_TAIL_SIDE=1 (round-5 experiment): the extras chain and the heads of its levels -- a dozen latency-bound launches
+    # that underfill the chip -- as ONE side-stream run behind the backbone, next to the two chip-filling backbone-level heads
+    # on the main stream (recorded last: their feature maps stay alive until then).
+    tail_side = os.environ.get("SSDK_SSD_TAIL_SIDE", "0") == "1" and isinstance(model.backbone, MobileNetEx) and len(model.extras) > 1
+    late = []
     if isinstance(model.backbone, MobileNetEx):
-        feats = record_mobilenet(plan, plan.input_value(), model.backbone, on_output=head)
+        feats = record_mobilenet(plan, plan.input_value(), model.backbone,
+                                 on_output=(lambda i, f: late.append((i, f))) if tail_side else head)
     else:
         feats = record_backbone(plan, plan.input_value(), model.backbone)
         for i, f in enumerate(feats):
@@ -139,12 +145,14 @@ def build_ssd_plan(model, x):
     balance = os.environ.get("SSDK_HEAD_BALANCE", "1") != "0" and len(model.extras) > 1
     deferred = []
     for j, extra in enumerate(model.extras):
-        feats.append(record_chain(plan, feats[-1], extra, keep_input=True))
+        feats.append(record_chain(plan, feats[-1], extra, keep_input=True, lane=2 if tail_side else 0))
         if balance:
             deferred.append((len(feats) - 1, feats[-1]))
         else:
             head(len(feats) - 1, feats[-1])
     for i, f in deferred:
+        head(i, f, lane=2 if tail_side else 0, position=i)
+    for i, f in late:  # (tail_side) the backbone levels' heads, on the main stream, while the side run is in flight
         head(i, f, lane=0, position=i)
     return plan.finalize()
 
