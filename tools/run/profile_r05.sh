@@ -1,5 +1,5 @@
-# Round-4 profiles of ONE bench configuration on one MI355X box (run through gpurun):
-#   bash tools/run/profile_r04.sh <tag> [bench.py arguments of the configuration ...]
+# Round-5 profiles of ONE bench configuration on one MI355X box (run through gpurun):
+#   bash tools/run/profile_r05.sh <tag> [bench.py arguments of the configuration ...]
 # kernel stats, the FETCH_SIZE pass, the WRITE_SIZE pass and two SQ passes, each in its own rocprofv3 run with --kernel-trace
 # only; then the bench lines themselves (with the CPU leg / oracle check: --cpu-sample 4 for the neck configurations) and the
 # per-layer table.  Summaries land in gpurun_out/<tag>/ ready to be copied into profiles/.
