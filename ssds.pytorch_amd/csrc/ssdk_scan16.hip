@@ -30,14 +30,17 @@ namespace ssdk {
 
 constexpr u32 kVq = 128;   // slots of a wave's circular queue of candidate vectors (a round of 64 is extracted as soon as it is full)
 constexpr u32 kSeg = 512;  // keys per wave segment of the key buffer
+constexpr u32 kNearTie = 64;   // occurrences of the cut value among the 1024 sample maxima that make a unit count its sample exactly
+constexpr u32 kNearCap = 1536; // predicted keys of a unit above which a segment (4 x kSeg, uneven over the waves) is expected to overflow
 // REG (template parameter of the kernel, SSDK_SCAN_REG = 8 | 16 | 32): tiles of a unit whose vectors are the SAMPLE and stay
 // in registers (4 VGPRs each); the rest of the unit streams through the LDS ring behind the cut
 
 struct S16Ctl {  // LDS
   u32 wcount[kScanThreads / 64];
-  u32 cutbin, above, cb, pad0;
+  u32 cutbin, above, cb, ngt;    // ngt / neq: exact counts over the sample registers (near-tie units)
   u32 cut16, eq, nan, ovf;
-  u32 kcnt, ocnt, scnt, pad1;
+  u32 kcnt, ocnt, scnt, neq;
+  u32 cutbin_k, pad0, pad1, pad2;  // bin of the K-th sample maximum (the PROVEN cut) when cutbin is that of a smaller rank
   u32 sub[32];
 };
 
@@ -154,6 +157,42 @@ __device__ __forceinline__ void hist_kth_bin(SelScratch* ss, S16Ctl* sc, u32 K) 
   __syncthreads();
 }
 
+// The same for two ranks R <= K in one pass: sc->cutbin / above / cb describe rank R, sc->cutbin_k is the bin of rank K (~0
+// when fewer values were counted).  Ends with a barrier.
+__device__ __forceinline__ void hist_two_ranks(SelScratch* ss, S16Ctl* sc, u32 R, u32 K) {
+  constexpr int NT = kScanThreads, BPT = kHistBins / NT;
+  const u32 tid = threadIdx.x;
+  u32 local = 0;
+#pragma unroll
+  for (int j = 0; j < BPT; ++j) local += ss->hist[tid * BPT + j];
+  const u32 incl = wg_incl_suffix_sum<NT>(local, ss->wsum);
+  const u32 excl = incl - local;
+  if (excl < R && R <= incl) {  // at most one thread
+    u32 acc = excl;
+    for (int j = BPT - 1; j >= 0; --j) {
+      const u32 h = ss->hist[tid * BPT + j];
+      if (acc + h >= R) {
+        sc->cutbin = tid * BPT + j;
+        sc->above = acc;
+        sc->cb = h;
+        break;
+      }
+      acc += h;
+    }
+  }
+  if (excl < K && K <= incl) {  // at most one thread
+    u32 acc = excl;
+    for (int j = BPT - 1; j >= 0; --j) {
+      acc += ss->hist[tid * BPT + j];
+      if (acc >= K) {
+        sc->cutbin_k = tid * BPT + j;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 template <int DT, int PF, int REG>
 __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParams p) {
   constexpr int NT = kScanThreads;
@@ -162,7 +201,7 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
   constexpr u32 ULP_SH = DT == SSDK_BF16 ? 16u : 13u;  // ordered-fp32 bits below one ulp of the head's dtype
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* buf = reinterpret_cast<u64*>(smem);  // the fallback's key buffer; the fast path's vector buffers live on it
-  u64* kbuf = reinterpret_cast<u64*>(smem);                                 // [NW][kSeg] extracted keys, one segment per wave
+  u64* kbuf = reinterpret_cast<u64*>(smem);                                 // [NW * kSeg] extracted keys (one cursor: sc->kcnt)
   u64* tiebuf = kbuf + (size_t)NW * kSeg;                                   // [512] the unit's tie keys (tie-rich units)
   u32x4* vqb = reinterpret_cast<u32x4*>(tiebuf + 512);                      // [NW][kVq] candidate vectors waiting for extraction
   u16* iqb = reinterpret_cast<u16*>(smem + ((size_t)NW * kSeg + 512) * 8 + (size_t)NW * kVq * 16);  // [NW][kVq] their numbers
@@ -228,6 +267,7 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
   for (u32 i = tid; i < kHistBins; i += NT) ss->hist[i] = 0;
   if (tid == 0) {
     sc->cutbin = ~0u;
+    sc->cutbin_k = ~0u;
     sc->above = 0;
     sc->cb = 0;
     sc->eq = 0;
@@ -273,7 +313,18 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
   for (int j = 0; j < 4; ++j) hist_add(ss->hist, sv4[j] >= thr16, hist_bin(ord_of16<DT>(sv4[j]), p.hist_base, p.hist_sh));
   __syncthreads();
   if (stamp) p.stamps[9] = clock64();
-  hist_kth_bin(ss, sc, K);  // (ends with a barrier)
+  // Which sample maximum gives the cut.  The K-th largest is a PROVEN lower bound of the unit's K-th score (the K-th largest
+  // of a subset is <= that of the whole) and predicts ~K ntiles / S candidates -- 1 500 of the buffer's 2 048 in an 81-tile
+  // unit: a head with channel structure (the sample tiles miss the channels that score high) exceeds that by a third and the
+  // unit overflows.  Round 5: the cut comes from the rank that predicts sqrt(K x capacity) candidates (the same factor of
+  // safety against a short list as against an overflow: 2.6 for K = 300); a list that comes back short reruns the unit
+  // from the proven cut, so the result is exact either way.
+  u32 R = K;
+  if (ntiles > S) {
+    const u32 r = (u32)(sqrtf((float)K * (float)(NW * kSeg)) * (float)S / (float)ntiles);
+    R = r < 1u ? 1u : (r < K ? r : K);
+  }
+  hist_two_ranks(ss, sc, R, K);  // (ends with a barrier)
   u32 cut16 = thr16, eq = 0;
   {
     const u32 cutbin = sc->cutbin;
@@ -295,7 +346,7 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
           }
         __syncthreads();
         if (tid == 0) {
-          const u32 need = K - sc->above;
+          const u32 need = R - sc->above;
           u32 acc = 0, add = 0, e = 0;
           for (int j = (int)(span < 32u ? span : 32u) - 1; j >= 0; --j) {
             const u32 h = sc->sub[j];
@@ -317,7 +368,85 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
   }
   cut16 = (u32)__builtin_amdgcn_readfirstlane((int)cut16);
   eq = (u32)__builtin_amdgcn_readfirstlane((int)eq);
-  const bool tie_rich = eq >= K && cut16 < inf16;  // the cut value itself fills K of the 1024 sample slots
+  bool tie_rich = eq >= K && cut16 < inf16;  // the cut value itself fills K of the 1024 sample slots
+  // ---- near ties (round 5).  Heads whose scores sit on a few hundred neighbouring 16-bit values (calibrated random weights,
+  // the reference-init FPN / BiFPN towers) have thousands of elements per value: the K-th largest of the 1024 sample maxima
+  // is then a value whose occurrences alone overflow the key segments (the exact fallback re-reads the unit).  When the cut
+  // value is suspiciously frequent among the maxima, COUNT: the S sample tiles are in registers, and the exact numbers G / E
+  // of their elements above / at the cut predict what the stream will find (x ntiles / S).
+  //   G >= K          K elements of the sample alone lie above the cut: cut + 1 is a PROVEN lower bound of the K-th score;
+  //   G predicts >= 2K in the unit: raise SPECULATIVELY -- the stream collects everything above the cut, and if fewer than K
+  //                   keys come back the unit runs the exact fallback from the last proven cut (the result stays exact);
+  //   else            stop: if G + E fits, collect everything at or above the cut as usual; if not, the cut value itself is
+  //                   needed -- settle it as a tie if it is dense enough for a short prefix walk.
+  u32 cutv = thr16;  // the last PROVEN lower bound (what the fallback may start from): the lowest value of the K-th maximum's bin
+  {
+    const u32 cbk = sc->cutbin_k;
+    if (cbk != ~0u) {
+      const u32 c0 = ceil16_of_ord<DT>(p.hist_base + (cbk << p.hist_sh));
+      cutv = c0 > thr16 ? c0 : thr16;
+    }
+    // the cut IS proven when it comes from rank K itself, or when its value fills K of the sample maxima
+    cutv = (R == K || tie_rich || cutv > cut16) ? cut16 : cutv;
+    cutv = (u32)__builtin_amdgcn_readfirstlane((int)cutv);
+  }
+  bool spec = cut16 > cutv;  // cut16 is a prediction
+  bool counted = false;
+  if (!tie_rich && eq >= kNearTie && cut16 < inf16) {  // workgroup-uniform
+    const u32 per = ntiles / S;  // (>= 1) unit tiles per sample tile
+    u32 G = 0, E = 0;
+    bool fits = false;
+    counted = true;
+    for (int it = 0; it < 8; ++it) {
+      if (tid == 0) {
+        sc->ngt = 0;
+        sc->neq = 0;
+      }
+      __syncthreads();
+      u32 g = 0, e = 0;
+#pragma unroll
+      for (u32 i = 0; i < kReg; ++i)
+        if (i < S) {  // wave-uniform (vectors outside the image were zeroed by mask_outside)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const u32 x = sv[i][d], lo = x & 0xffffu, hi = x >> 16;
+            g += ((int)(short)(u16)lo > (int)cut16 ? 1u : 0u) + ((int)(short)(u16)hi > (int)cut16 ? 1u : 0u);
+            e += (lo == cut16 ? 1u : 0u) + (hi == cut16 ? 1u : 0u);
+          }
+        }
+      u32 ge = (g << 16) | e;  // (<= 128 each per lane)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ge += (u32)__shfl_xor((int)ge, o, 64);  // <= 8192 per field per wave
+      if (lane == 0) {
+        atomicAdd(&sc->ngt, ge >> 16);
+        atomicAdd(&sc->neq, ge & 0xffffu);
+      }
+      __syncthreads();
+      G = sc->ngt;
+      E = sc->neq;
+      __syncthreads();  // every thread has its copy before thread 0 clears the counters again: the decisions below must be uniform
+      const bool room = it < 7 && cut16 + 1u < inf16;
+      if (G >= K && room) {  // "above the cut" IS "at or above the next pattern"
+        cut16 += 1u;
+        cutv = cut16;
+        spec = false;
+        continue;
+      }
+      // (not "the first cut that fits": the sample of a channel-structured head under-predicts by a third and more, so the
+      //  cut goes up as long as the prediction stays at 2 K -- the SMALLEST list the sample still vouches for)
+      if (G * per >= 2u * K && room) {
+        cut16 += 1u;
+        spec = true;
+        continue;
+      }
+      fits = (G + E) * per <= kNearCap;
+      break;
+    }
+    cut16 = (u32)__builtin_amdgcn_readfirstlane((int)cut16);
+    cutv = (u32)__builtin_amdgcn_readfirstlane((int)cutv);
+    // a tie walk visits ~K S / E tiles, one dependent load each: worth it up to about four samples' worth of tiles
+    if (!fits && !spec && G * per <= kNearCap && E * 4u >= K) tie_rich = true;
+  }
   if (stamp) p.stamps[10] = clock64();
 
   // ---- tie prefix (tie-rich units only): the first K scores EQUAL to the cut, in index order ------------------------------
@@ -373,7 +502,6 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
   for (u32 i = tid; i < kHistBins; i += NT) ss->hist[i] = 0;  // (phase H is done with it; the barrier is below)
   u32x4* vq = vqb + (size_t)wave * kVq;
   u16* iq = iqb + (size_t)wave * kVq;
-  u64* seg = kbuf + (size_t)wave * kSeg;
   u32 wcnt = 0, xdone = 0, kc = 0;  // vectors queued / extracted, keys in the segment (wave-uniform)
   bool ovf = false;
   auto extract = [&](u32 nround) {  // the next min(64, nround) queued vectors
@@ -410,18 +538,23 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
         tot += (u32)__popcll(mb) << bit;
       }
     }
-    if (kc + tot > kSeg) {  // wave-uniform: more candidates than the segment holds (a misleading sample)
+    // one key buffer for the workgroup, one LDS cursor (round 5: with a segment per wave, a unit whose candidates cluster in
+    // two of the four lane quarters overflowed at 1 660 of its 2 048 slots -- channel-structured heads do that)
+    u32 base = 0;
+    if (lane == 0) base = atomicAdd(&sc->kcnt, tot);
+    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+    if (base + tot > NW * kSeg) {  // wave-uniform: more candidates than the buffer holds (a misleading sample)
       ovf = true;
       return;
     }
-    u32 at = kc + excl, left = pm;
+    u32 at = base + excl, left = pm;
     while (left) {
       const u32 e = (u32)__ffs((int)left) - 1u;
       left &= left - 1u;
       const u32 w16 = e < 2u ? v[0] : (e < 4u ? v[1] : (e < 6u ? v[2] : v[3]));
       const u32 h = (e & 1u) ? (w16 >> 16) : (w16 & 0xffffu);
       const u32 o = ord_of16<DT>(h);
-      seg[at++] = ((u64)o << 32) | (u64)(~(idx0 + e));
+      kbuf[at++] = ((u64)o << 32) | (u64)(~(idx0 + e));
       atomicAdd(&ss->hist[hist_bin(o, p.hist_base, p.hist_sh)], 1u);
     }
     kc += tot;
@@ -468,15 +601,12 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
   if ((sc->ovf | sc->nan) == 0u) {
     if (stamp) p.stamps[11] = clock64();
     // ---- select: exact top-K of the extracted keys (+ the tie keys), unordered, straight to the workspace ----------
-    u32 nk = ntie, before = 0;
-#pragma unroll
-    for (u32 w = 0; w < NW; ++w) {
-      const u32 cw = sc->wcount[w];
-      before += w < wave ? cw : 0u;
-      nk += cw;
-    }
-    if (nk <= K) {
-      for (u32 i = lane; i < kc; i += 64) out[before + i] = seg[i];
+    const u32 nkeys = sc->kcnt;  // (<= NW * kSeg: an overflowing round returns before it writes, and sets ovf)
+    const u32 nk = ntie + nkeys;
+    if (spec && nk < K) {
+      // the prediction failed (fewer than K scores above the raised cut): the exact stream from the proven cut below
+    } else if (nk <= K) {
+      for (u32 i = tid; i < nkeys; i += NT) out[i] = kbuf[i];
       for (u32 i = tid; i < ntie; i += NT) out[nk - ntie + i] = tiebuf[i];
       cnt = nk;
       ordered = ntie != 0u && nk == ntie;  // nothing beat the cut: the list IS the tie prefix (workgroup-uniform)
@@ -486,20 +616,14 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
       hist_kth_bin(ss, sc, K);
       const u32 cbin = sc->cutbin, above = sc->above, cb = sc->cb, need = K - above;
       if (cb > 512u) {  // heavy ties inside one bin: the generic exact select over one contiguous array (rare)
-        // segments compacted in place, wave by wave (registers in between), the tie keys behind them
-        u32 off = sc->wcount[0];
-        for (u32 w = 1; w <= NW; ++w) {
-          const u32 cw = w < NW ? sc->wcount[w] : ntie;
-          const u64* src = w < NW ? kbuf + (size_t)w * kSeg : tiebuf;
-          u64 t0 = 0, t1 = 0;
-          if (tid < cw) t0 = src[tid];
-          if (tid + NT < cw) t1 = src[tid + NT];
-          __syncthreads();
-          if (tid < cw) kbuf[off + tid] = t0;
-          if (tid + NT < cw) kbuf[off + tid + NT] = t1;
-          __syncthreads();
-          off += cw;
-        }
+        // the tie keys behind the extracted ones (tiebuf follows kbuf: the ranges may overlap -- through registers)
+        u64 t0 = 0, t1 = 0;
+        if (tid < ntie) t0 = tiebuf[tid];
+        if (tid + NT < ntie) t1 = tiebuf[tid + NT];
+        __syncthreads();
+        if (tid < ntie) kbuf[nkeys + tid] = t0;
+        if (tid + NT < ntie) kbuf[nkeys + tid + NT] = t1;
+        __syncthreads();
         const u64 T = wg_select_kth<NT>(kbuf, nk, K, ss);
         for (u32 i = tid; i < nk; i += NT) {
           const u64 k = kbuf[i];
@@ -521,7 +645,7 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
           if (win) out[bw + mbcnt(mw)] = k;
           if (edge) small[be + mbcnt(me)] = k;
         };
-        for (u32 i0 = 0; i0 < kc; i0 += 64) classify(i0 + lane < kc ? seg[i0 + lane] : 0ull, i0 + lane < kc);
+        for (u32 i0 = 0; i0 < nkeys; i0 += NT) classify(i0 + tid < nkeys ? kbuf[i0 + tid] : 0ull, i0 + tid < nkeys);
         for (u32 i0 = 0; i0 < ntie; i0 += NT) classify(i0 + tid < ntie ? tiebuf[i0 + tid] : 0ull, i0 + tid < ntie);
         __syncthreads();
         for (u32 t = tid; t < cb; t += NT) {
@@ -532,11 +656,11 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
       }
       cnt = K;
     }
-    done = true;
+    done = !(spec && nk < K);
   }
   if (!done) {
     // ---- the exact TopK stream over the whole unit (a misleading sample, NaNs, adversarial inputs) ----------------------
-    const float c16 = f32_of16<DT>(cut16 <= inf16 ? cut16 : inf16);
+    const float c16 = f32_of16<DT>(cutv <= inf16 ? cutv : inf16);  // (the PROVEN cut: cut16 may be a failed prediction)
     const float cut0 = (sc->nan == 0u && c16 > p.thr) ? c16 : p.thr;  // the sample's cut stays a valid lower bound
     cnt = unit_topk_stream<DT, PF>(U, cut0, K, buf, ss, ctl, stage);
     for (u32 i = tid; i < cnt; i += NT) out[i] = buf[i];
@@ -546,7 +670,10 @@ __global__ __launch_bounds__(kScanThreads, 3) void scan16_kernel(const ScanParam
   // unit of an all-equal image leaves (the reference-init network: every score of a level is one bf16 value).  levelsel_kernel
   // then takes a full first unit as the level's answer without selecting anything (ssdk_tail.hip).
   if (tid == 0) *out_cnt = cnt | (ordered ? 0x80000000u : 0u);
-  if (wall) p.stamps[24 + 2 * blockIdx.x + 1] = (wall_clock64() & ~1ull) | (done ? 0ull : 1ull);  // bit 0: took the exact fallback
+  // bit 0: took the exact fallback; bits 1-3 (near-tie rule): counted its sample | ended on a predicted cut | settled a tie; bit 4: a key segment overflowed
+  if (wall)
+    p.stamps[24 + 2 * blockIdx.x + 1] = (wall_clock64() & ~31ull) | (done ? 0ull : 1ull) | (counted ? 2ull : 0ull) | (spec ? 4ull : 0ull) |
+                                        ((counted && tie_rich) ? 8ull : 0ull) | (sc->ovf ? 16ull : 0ull);
   if (stamp) {
     p.stamps[3] = clock64();
     p.stamps[4] = clock64();

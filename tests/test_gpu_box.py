@@ -678,7 +678,8 @@ def _decoder_vs_oracle(loc, conf, anchors, args, what, check_mid=True):
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
-@pytest.mark.parametrize("kind", ["nan_inf_negative", "misleading_sample", "all_equal", "two_values", "dense_above"])
+@pytest.mark.parametrize("kind", ["nan_inf_negative", "misleading_sample", "all_equal", "two_values", "dense_above", "near_ties",
+                                  "few_values", "stairs"])
 @pytest.mark.parametrize("tpu", ["0", "3", "40"])
 def test_scan16_special_values_ties_and_fallback(kind, dtype, tpu, monkeypatch):
     """The 16-bit scan (ssdk_scan16.hip) compares bit patterns as signed 16-bit integers and trusts a sample of the unit
@@ -689,7 +690,13 @@ def test_scan16_special_values_ties_and_fallback(kind, dtype, tpu, monkeypatch):
       all_equal          one value everywhere (f16: in the middle of a histogram bin -> the in-bin refinement);
       two_values         60 % of the scores at one value, the rest at a second, larger one in the LAST part of the map
                          (ties at the cut in some units, nothing but ties above the cut in others);
-      dense_above        every score above the threshold and distinct per position (more candidates than any buffer)."""
+      dense_above        every score above the threshold and distinct per position (more candidates than any buffer);
+      near_ties          sigmoid(N(-4.595, 0.02)): every score on a handful of neighbouring 16-bit values -- the value at the
+                         cut occurs thousands of times per unit without filling the sample's maxima (round 5: the unit
+                         counts its sample registers, raises the cut or settles the cut value as a tie);
+      few_values         uniform over [0.01, 0.02): ~128 bf16 values of equal frequency (several raises of the cut);
+      stairs             five values, the larger the rarer (1, 4, 16, 64 per mille): the cut lands on each of them for
+                         some K."""
     import torch
 
     tdt = getattr(torch, dtype)
@@ -716,6 +723,15 @@ def test_scan16_special_values_ties_and_fallback(kind, dtype, tpu, monkeypatch):
             stride = max(ntiles // 8, 1)
             dense = (t % stride != 0) | (t >= 8 * stride)  # (exact for a single unit; harmless otherwise)
             c[:, dense] = (0.02 + 0.9 * rs.random_sample((B, int(dense.sum())))).astype(F32)
+        elif kind == "near_ties":
+            c = cases.sigmoid(rs.standard_normal((B, n)).astype(F32) * F32(0.02) - F32(4.595))
+        elif kind == "few_values":
+            c = (0.01 + 0.01 * rs.random_sample((B, n))).astype(F32)
+        elif kind == "stairs":
+            u = rs.random_sample((B, n))
+            c = np.full((B, n), 0.125, F32)
+            for v, f in ((0.25, 0.064), (0.375, 0.016), (0.5, 0.004), (0.75, 0.001)):
+                c[u < f] = v
         elif kind == "all_equal":
             c = np.full((B, n), 0.3337, F32)
         elif kind == "two_values":
@@ -728,6 +744,39 @@ def test_scan16_special_values_ties_and_fallback(kind, dtype, tpu, monkeypatch):
     anchors = OrderedDict((s, torch.from_numpy(O.generate_anchors(s, [1, 2, 0.5], [2.0]))) for s in strides)
     for args in ((0.01, 300, True, 0.6, 100, True), (0.05, 37, False, 0.5, 20, False), (0.2, 512, True, 0.6, 100, True)):
         _decoder_vs_oracle(loc, conf, anchors, args, "%s %s tpu=%s K=%d" % (kind, dtype, tpu, args[1]))
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_scan16_failed_prediction_falls_back_to_the_proven_cut(dtype, monkeypatch):
+    """The near-tie rule of ssdk_scan16.hip may raise its cut on a PREDICTION (the sample tiles hold 240 scores above the cut
+    value, x 5 tiles per sample tile = 1 200 expected in the unit, >= 2 K): here the larger value lives in the sample tiles
+    ONLY (every fifth tile of an 80-tile unit), so fewer than K keys come back and the unit must rerun exactly from the last
+    proven cut.  Layout: 0.125 everywhere (above the threshold, below the cut), ~16 scores of 0.25 in every tile (the cut
+    value: frequent in the unit, 230 of the 1 024 sample maxima), 15 scores of 0.5 in the sample tiles."""
+    import torch
+
+    tdt = getattr(torch, dtype)
+    monkeypatch.setenv("SSDK_TILES_PER_UNIT", "80")
+    rs = np.random.RandomState(11)
+    A, C, B = 3, 40, 2
+    maps, strides = [(40, 48), (20, 24)], [8, 16]
+    conf, loc = [], []
+    tile = 256 * 8
+    for h, w in maps:
+        n = A * C * h * w
+        c = np.full((B, n), 0.125, F32)
+        for bi in range(B):
+            for t in range((n + tile - 1) // tile):
+                lo, hi = t * tile, min((t + 1) * tile, n)
+                pos = rs.choice(hi - lo, size=min(31, hi - lo), replace=False) + lo
+                c[bi, pos[:16]] = 0.25
+                if t % 5 == 0 and t < 80:
+                    c[bi, pos[16:31]] = 0.5
+        conf.append(torch.from_numpy(c.reshape(B, A * C, h, w)).to(tdt).cuda())
+        loc.append(torch.from_numpy((rs.standard_normal((B, A * 4, h, w)) * 0.5).astype(F32)).to(tdt).cuda())
+    anchors = OrderedDict((s, torch.from_numpy(O.generate_anchors(s, [1, 2, 0.5], [2.0]))) for s in strides)
+    for args in ((0.01, 300, True, 0.6, 100, True), (0.01, 260, False, 0.5, 50, True)):
+        _decoder_vs_oracle(loc, conf, anchors, args, "failed prediction %s K=%d" % (dtype, args[1]))
 
 
 @pytest.mark.parametrize("tpu", ["1", "0"])

@@ -82,6 +82,10 @@ def run(name, make, thr=0.01, reps=20):
             if se:
                 slow = sorted(((tl[2 * i + 1] - tl[2 * i]) / 100.0, i, tl[2 * i + 1] & 1) for i in range(W) if tl[2 * i + 1])[-6:]
                 nfb = sum(1 for i in range(W) if tl[2 * i + 1] & 1)
+                flags = [sum(1 for i in range(W) if tl[2 * i + 1] & b) for b in (2, 4, 8, 16)]
+                flags.append(sum(1 for i in range(W) if (tl[2 * i + 1] & 21) == 5))
+                extra += ("\n      scan: near-tie rule: %d units counted their sample, %d ended on a predicted cut, %d settled a tie; %d units "
+                          "overflowed a key segment, %d predictions came back short" % tuple(flags))
                 extra += "\n      scan: %d workgroups took the exact fallback; slowest (us, block %% B = image, block // B = unit, fallback): %s" % (
                     nfb, " ".join("(%.0f,%d,%d,%d)" % (d_, i % B, i // B, f) for d_, i, f in slow))
                 dbg = tl[2 * 3000:2 * 3000 + 4]
@@ -107,6 +111,19 @@ def run(name, make, thr=0.01, reps=20):
         flush=True)
 
 
+if os.environ.get("PROBE_CFG"):  # the bench's own input: reference-init network of that configuration on torch.rand images
+    from ssds.core import config as _C
+    from ssds.modeling import model_builder as _mb
+
+    _cfg = _C.cfg_from_file(os.environ["PROBE_CFG"])
+    torch.manual_seed(1234)
+    _model = _mb.create_model(_cfg.MODEL).eval().cuda().to(DT)
+    _S = int(_cfg.MODEL.IMAGE_SIZE[0])
+    with torch.no_grad():
+        _loc, _conf = _model(torch.rand(B, 3, _S, _S, device="cuda").to(DT))
+    _by_h = {int(c.shape[-1]): c.float() for c in _conf}
+    assert sorted(_by_h) == sorted(sizes), (sorted(_by_h), sizes)
+    run("bench input of " + os.path.basename(os.environ["PROBE_CFG"]), lambda b, ac, h, w: _by_h[h])
 run("SURVEY 8d heads sigmoid(N(-4.6,1.5))", lambda *s: torch.sigmoid(torch.randn(*s, device="cuda") * 1.5 - 4.6))
 run("all equal (focal prior)", lambda *s: torch.full(s, 0.01, device="cuda"))
 # the reference-init network behind a SHARED tower (FPN / BiFPN bench input): logits -log(99) +- a little, i.e. a handful of
