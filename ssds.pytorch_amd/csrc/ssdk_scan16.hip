@@ -24,6 +24,12 @@
 // the scores EQUAL to the cut only the first K in index order can be winners; they are collected by a short prefix walk
 // and the stream then looks for cut + 1.  A unit whose sample misleads (buffers overflow) or holds a NaN among its
 // largest patterns runs the exact TopK stream instead (unit_topk_stream, ssdk_scan.h).
+//
+// Round 5 (what a sample cannot promise): the extracted keys share ONE buffer behind an LDS cursor (a segment per
+// wave overflowed when the candidates clustered in two lane quarters); the cut comes from the sample rank that predicts
+// sqrt(K x capacity) candidates, with the PROVEN cut (rank K) kept for the rerun when the list comes back short; a unit
+// whose cut value is suspiciously frequent among the maxima counts its sample registers exactly and raises the cut (proven
+// while K sample elements lie above it, predicted while they promise 2 K in the unit) or settles the cut value as a tie.
 #include "ssdk_scan.h"
 
 namespace ssdk {
