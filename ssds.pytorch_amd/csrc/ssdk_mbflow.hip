@@ -55,8 +55,9 @@ struct FlowLds {
   static constexpr int bytes = spb + NFO * 4 * 32;
 };
 
-template <int DT, int S, int NCH, int NFO, int NS, bool STEM = false, bool YE = false>
-__global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_kernel(const FlowParams p) {
+template <int DT, int S, int NCH, int NFO, int NS, bool STEM = false, bool YE = false, bool PAIR = false>
+__global__ __launch_bounds__(kFlowThreads, ((STEM && !YE) || PAIR) ? 3 : 2) void mbflow_kernel(const FlowParams p) {
+  static_assert(!PAIR || (S == 1 && !STEM), "row pairs: stride-1 blocks");
   using L = FlowLds<NCH, NFO>;
   constexpr int T = L::T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
   const bool dbgw = p.dbg != nullptr && blockIdx.x == gridDim.x / 2 && __builtin_amdgcn_readfirstlane((int)wave) == 0;
   int dbg_k = 0;
   fl_h2 accA[NA][NCH * 2], accB[NA][NCH * 2], accC[NA][NCH * 2];
+  fl_h2 accD[PAIR ? NA : 1][PAIR ? NCH * 2 : 1];  // row pairs keep four output rows open
 
   // One input row.  FIN / MID / INI: the row is the last (ky = 2) / middle (ky = 1) / first (ky = 0) row of the output
   // row accumulated in fin / mid / ini; the FIN row is completed, projected and stored as output row `oy_fin`.
@@ -437,6 +439,182 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
     if (dbgw && dbg_k < 250) p.dbg[dbg_k++] = __builtin_readcyclecounter();
   };
 
+
+  // TWO input rows per visit of the chunks (PAIR; round 5): every weight read of the row loop -- expand fragment, bias, nine
+  // taps, projection fragments -- then serves two rows.  (SQ counters of the 24 -> 144 -> 24 block at 128 x 128: LDS pipe 72 %
+  // busy, 31 % of the wave cycles waiting for it -- twelve broadcast reads per chunk and row of one strip.)  Input rows iy,
+  // iy + 1: row iy is the last row of output iy - 1 (a0), the middle of iy (a1), the first of iy + 1 (a2); row iy + 1 the
+  // last of iy (a1), the middle of iy + 1 (a2), the first of iy + 2 (a3).  Stride 1, every row has all three roles.
+  auto row2 = [&](const XRow (&x0)[NS], const XRow (&x1)[NS], int iy, fl_h2 (&a0)[NA][NCH * 2], fl_h2 (&a1)[NA][NCH * 2],
+                  fl_h2 (&a2)[NA][NCH * 2], fl_h2 (&a3)[NA][NCH * 2]) {
+    if (dbgw && dbg_k < 250) {
+      p.dbg[dbg_k++] = __builtin_readcyclecounter();
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (the next pair's loads stay in flight)
+      p.dbg[dbg_k++] = __builtin_readcyclecounter();
+    }
+    u32x4 xf[2][NS];
+    fl_f2 hi[2][NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        xf[0][s][q] = x0[s].w[q];
+        xf[1][s][q] = x1[s].w[q];
+      }
+      const float k0 = (col_ok[s] && (unsigned)iy < (unsigned)p.H) ? kFlSixth : 0.f;
+      const float k1 = (col_ok[s] && (unsigned)(iy + 1) < (unsigned)p.H) ? kFlSixth : 0.f;
+      hi[0][s] = fl_f2{k0, k0};
+      hi[1][s] = fl_f2{k1, k1};
+    }
+    const bool st[2] = {iy - 1 >= oy0 && iy - 1 <= oy1, iy >= oy0 && iy <= oy1};  // wave-uniform: output rows iy - 1, iy
+    uint2 resv[2][NA][NFO];
+    if (p.residual) {
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int s = 0; s < NA; ++s)
+#pragma unroll
+          for (int f = 0; f < NFO; ++f) {
+            const int co = f * 16 + (int)fg * 4;
+            uint2 r = make_uint2(0u, 0u);
+            if (st[o] && out_lane[s] && co < Cout) r = *reinterpret_cast<const uint2*>(ximg + ((size_t)(iy - 1 + o) * p.W + oxl[s]) * Cin + co);
+            resv[o][s][f] = r;
+          }
+    }
+    asm volatile("" ::: "memory");
+    f32x4 e_cur[2][NS], e_nxt[2][NS];
+    u32x4 wa = *reinterpret_cast<const u32x4*>(smem + L::we + (int)lane * 16);
+    {
+      const f32x4 bv0 = *reinterpret_cast<const f32x4*>(smem + L::sb + (int)fg * 32 + 16);
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) e_cur[o][s] = fl_mfma<DT>(wa, xf[o][s], bv0);
+    }
+    if (NCH > 1) wa = *reinterpret_cast<const u32x4*>(smem + L::we + (64 + (int)lane) * 16);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      asm volatile("" ::: "memory");
+      uint2 wt[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const uint2*>(smem + L::wd + ((c * 9 + t) * 4 + (int)fg) * 8);
+      const uint2 bdi = *reinterpret_cast<const uint2*>(smem + L::bd + (c * 4 + (int)fg) * 8);
+      if (c + 1 < NCH) {
+        const f32x4 bvn = *reinterpret_cast<const f32x4*>(smem + L::sb + ((c + 1) * 4 + (int)fg) * 32 + 16);
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int s = 0; s < NS; ++s) e_nxt[o][s] = fl_mfma<DT>(wa, xf[o][s], bvn);
+        if (c + 2 < NCH) wa = *reinterpret_cast<const u32x4*>(smem + L::we + ((c + 2) * 64 + (int)lane) * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      auto taps = [&](int ky, fl_h2 l0, fl_h2 l1, fl_h2 c0, fl_h2 c1, fl_h2 r0, fl_h2 r1, fl_h2& q0, fl_h2& q1) {
+        const uint2 w0 = wt[ky * 3], w1 = wt[ky * 3 + 1], w2 = wt[ky * 3 + 2];
+        fl_h2 s0 = ky == 0 ? fl_as_h2(bdi.x) : q0, s1 = ky == 0 ? fl_as_h2(bdi.y) : q1;
+        s0 = __builtin_elementwise_fma(l0, fl_as_h2(w0.x), s0);
+        s1 = __builtin_elementwise_fma(l1, fl_as_h2(w0.y), s1);
+        s0 = __builtin_elementwise_fma(c0, fl_as_h2(w1.x), s0);
+        s1 = __builtin_elementwise_fma(c1, fl_as_h2(w1.y), s1);
+        if (ky == 2) {
+          s0 = fl_fma_clamp01(r0, fl_as_h2(w2.x), s0);
+          s1 = fl_fma_clamp01(r1, fl_as_h2(w2.y), s1);
+        } else {
+          s0 = __builtin_elementwise_fma(r0, fl_as_h2(w2.x), s0);
+          s1 = __builtin_elementwise_fma(r1, fl_as_h2(w2.y), s1);
+        }
+        asm volatile("" : "+v"(s0), "+v"(s1));
+        q0 = s0;
+        q1 = s1;
+      };
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const f32x4 e = e_cur[o][s];
+          const u32 w0 = fl_unit_pack(e[0], e[1], hi[o][s]), w1 = fl_unit_pack(e[2], e[3], hi[o][s]);
+          const fl_h2 l0 = fl_as_h2(fl_from_left(w0)), l1 = fl_as_h2(fl_from_left(w1)), c0 = fl_as_h2(w0), c1 = fl_as_h2(w1);
+          const fl_h2 r0 = fl_as_h2(fl_from_right(w0)), r1 = fl_as_h2(fl_from_right(w1));
+          if (o == 0) {
+            taps(0, l0, l1, c0, c1, r0, r1, a2[s][2 * c], a2[s][2 * c + 1]);
+            taps(1, l0, l1, c0, c1, r0, r1, a1[s][2 * c], a1[s][2 * c + 1]);
+            taps(2, l0, l1, c0, c1, r0, r1, a0[s][2 * c], a0[s][2 * c + 1]);
+          } else {
+            taps(0, l0, l1, c0, c1, r0, r1, a3[s][2 * c], a3[s][2 * c + 1]);
+            taps(1, l0, l1, c0, c1, r0, r1, a2[s][2 * c], a2[s][2 * c + 1]);
+            taps(2, l0, l1, c0, c1, r0, r1, a1[s][2 * c], a1[s][2 * c + 1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) e_cur[o][s] = e_nxt[o][s];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (dbgw && dbg_k < 250) p.dbg[dbg_k++] = __builtin_readcyclecounter();
+    if (st[0] || st[1]) {  // (wave-uniform) both finished rows are projected with one read of every weight fragment
+      asm volatile("" ::: "memory");
+      f32x4 yacc[2][NA][NFO];
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int s = 0; s < NA; ++s)
+#pragma unroll
+          for (int f = 0; f < NFO; ++f) yacc[o][s][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        u32x4 db[2][NA];
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+          for (int s = 0; s < NA; ++s) {
+            const fl_h2* fin = o == 0 ? a0[s] : a1[s];
+            db[o][s][0] = fl_as_u32(fin[4 * t]);
+            db[o][s][1] = fl_as_u32(fin[4 * t + 1]);
+            if (2 * t + 1 < NCH) {
+              db[o][s][2] = fl_as_u32(fin[(4 * t + 2 < NCH * 2) ? 4 * t + 2 : 0]);
+              db[o][s][3] = fl_as_u32(fin[(4 * t + 3 < NCH * 2) ? 4 * t + 3 : 0]);
+            } else {
+              db[o][s][2] = 0u;
+              db[o][s][3] = 0u;
+            }
+          }
+#pragma unroll
+        for (int f = 0; f < NFO; ++f) {
+          const u32x4 wf = *reinterpret_cast<const u32x4*>(smem + L::wp + ((f * T + t) * 64 + (int)lane) * 16);
+#pragma unroll
+          for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int s = 0; s < NA; ++s) yacc[o][s][f] = fl_mfma<SSDK_F16>(wf, db[o][s], yacc[o][s][f]);
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < NFO; ++f) {
+        const int co = f * 16 + (int)fg * 4;
+        if (co < Cout) {
+          const f32x4 spv = *reinterpret_cast<const f32x4*>(smem + L::spb + (f * 4 + (int)fg) * 32);
+          const f32x4 bpv = *reinterpret_cast<const f32x4*>(smem + L::spb + (f * 4 + (int)fg) * 32 + 16);
+#pragma unroll
+          for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int s = 0; s < NA; ++s) {
+              if (!(st[o] && out_lane[s])) continue;
+              u16* yrow = p.y + (((size_t)n * p.Ho + (iy - 1 + o)) * p.Wo + oxl[s]) * Cout;
+              u32 h01 = fl_pack2<DT>(fmaf(yacc[o][s][f][0], spv[0], bpv[0]), fmaf(yacc[o][s][f][1], spv[1], bpv[1]));
+              u32 h23 = fl_pack2<DT>(fmaf(yacc[o][s][f][2], spv[2], bpv[2]), fmaf(yacc[o][s][f][3], spv[3], bpv[3]));
+              if (p.residual) {
+                const u32 x01 = resv[o][s][f].x, x23 = resv[o][s][f].y;
+                h01 = fl_pack2<DT>(fl_from16<DT>(h01 & 0xffffu) + fl_from16<DT>(x01 & 0xffffu), fl_from16<DT>(h01 >> 16) + fl_from16<DT>(x01 >> 16));
+                h23 = fl_pack2<DT>(fl_from16<DT>(h23 & 0xffffu) + fl_from16<DT>(x23 & 0xffffu), fl_from16<DT>(h23 >> 16) + fl_from16<DT>(x23 >> 16));
+              }
+              *reinterpret_cast<uint2*>(yrow + co) = make_uint2(h01, h23);
+            }
+        }
+      }
+    }
+    if (dbgw && dbg_k < 250) p.dbg[dbg_k++] = __builtin_readcyclecounter();
+  };
+
   const auto Y = std::true_type{};
   const auto No = std::false_type{};
   auto load_row = [&](XRow (&dst)[NS], int iy) {
@@ -448,7 +626,21 @@ __global__ __launch_bounds__(kFlowThreads, (STEM && !YE) ? 3 : 2) void mbflow_ke
   // into accumulators nobody stores (their output rows lie past oy1).  x is fetched one row ahead.
   XRow xa[NS], xb[NS];
   {
-    if constexpr (S == 1) {
+    if constexpr (PAIR) {
+      // pairs of input rows (r, r + 1), fetched one pair ahead; the four accumulator sets rotate by two per pair
+      const int rend = oy1 + 1;
+      XRow xc[NS], xd[NS];
+      load_row(xa, oy0 - 1);
+      load_row(xb, oy0);
+      for (int r = oy0 - 1; r <= rend; r += 4) {
+        load_row(xc, r + 2);
+        load_row(xd, r + 3);
+        row2(xa, xb, r, accA, accB, accC, accD);
+        load_row(xa, r + 4);
+        load_row(xb, r + 5);
+        row2(xc, xd, r + 2, accC, accD, accA, accB);
+      }
+    } else if constexpr (S == 1) {
       // input rows oy0-1 .. oy1+1; input row r is the first row of output r+1, the middle of r, the last of r-1
       const int rend = oy1 + 1;
       load_row(xa, oy0 - 1);
@@ -491,6 +683,12 @@ static void flow_launch(const FlowParams& p, unsigned grid, hipStream_t stream) 
   constexpr int lds = FlowLds<NCH, NFO>::bytes;
   if constexpr (S == 1 && NCH == 9) {
     if (p.layout == 101) {  // one strip per wave (launch_mbflow sets the marker: half the accumulators, three waves per SIMD)
+      static const int pair = getenv("SSDK_FLOW_PAIR") ? atoi(getenv("SSDK_FLOW_PAIR")) : 1;
+      if (pair) {  // two input rows per visit of the chunks: every weight read serves two rows
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<DT, S, NCH, NFO, 1, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((mbflow_kernel<DT, S, NCH, NFO, 1, false, false, true>), dim3(grid), dim3(kFlowThreads), lds, stream, p);
+        return;
+      }
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<DT, S, NCH, NFO, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       hipLaunchKernelGGL((mbflow_kernel<DT, S, NCH, NFO, 1>), dim3(grid), dim3(kFlowThreads), lds, stream, p);
       return;
