@@ -1,10 +1,13 @@
 """Numerics of the fused conv kernels (MFMA implicit GEMM, depthwise, stem) against a plain PyTorch fp32
 reference of the same op on the same (bf16/f16-rounded) operands.  Tolerance: the kernels accumulate in
 fp32 and round once to the 16-bit output type, so |err| <= ~2^-8 relative to the output magnitude (bf16)."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _ref(x, conv, bn, act, residual=None):
@@ -844,6 +847,46 @@ def test_split_register_flow_block(cin, cout, stride, h, w, n, dtype_name):
     tiled = FC.mbconv_native(x.cuda(), pk, variant=-1)
     assert "mbsplit" not in N.last_kernel() and "mbflow" not in N.last_kernel()
     assert float((got.float() - tiled.float()).abs().max()) <= 2e-2 * max(1.0, float(y.abs().max()))
+
+
+def test_flow_row_pairs_equal_single_rows_bit_for_bit(tmp_path):
+    """mbflow_kernel<..., PAIR> (two input rows per visit of the chunks: every weight read serves two rows) performs the same
+    operations per element in the same order as the single-row instance: the outputs must be EQUAL.  The instance is chosen
+    from the environment once per process, so the two run in subprocesses (odd height: the last pair is half empty; several
+    segments; residual)."""
+    import subprocess
+    import sys
+
+    script = r"""
+import os, sys, torch
+sys.path[:0] = [%r, %r]
+from ssds import _native as N
+from ssds.modeling.layers import fused_conv as FC
+from ssds.modeling.layers.planner import groups_of
+from ssds.modeling.nets.mobilenet import InvertedResidual
+torch.manual_seed(7)
+blk = InvertedResidual(24, 24, 1, 6).eval()
+for m in blk.modules():
+    if isinstance(m, torch.nn.BatchNorm2d):
+        m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+x = torch.randn(3, 24, 45, 37).to(torch.bfloat16).cuda()
+pk = FC.MbPack(groups_of(blk.cuda().conv), blk.use_res_connect, torch.bfloat16)
+y = FC.mbconv_native(x, pk, variant=1)
+assert "mbflow" in N.last_kernel(), N.last_kernel()
+torch.save(y.float().cpu(), sys.argv[1])
+""" % (ROOT, os.path.join(ROOT, "ssds.pytorch_amd"))
+    outs = []
+    for v in ("0", "1"):
+        f = str(tmp_path / ("y%s.pt" % v))
+        env = dict(os.environ, SSDK_FLOW_PAIR=v)
+        r = subprocess.run([sys.executable, "-c", script, f], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(f)
+    import torch
+
+    a, b = torch.load(outs[0]), torch.load(outs[1])
+    assert a.abs().max() > 0.1
+    assert torch.equal(a, b)
 
 
 MBK = [
