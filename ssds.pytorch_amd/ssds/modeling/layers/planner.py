@@ -129,7 +129,12 @@ def build_ssd_plan(model, x):
     # SSDK_SSD_TAIL_SIDE=1 (round-5 experiment): the extras chain and the heads of its levels -- a dozen latency-bound launches
     # that underfill the chip -- as ONE side-stream run behind the backbone, next to the two chip-filling backbone-level heads
     # on the main stream (recorded last: their feature maps stay alive until then).
-    tail_side = os.environ.get("SSDK_SSD_TAIL_SIDE", "0") == "1" and isinstance(model.backbone, MobileNetEx) and len(model.extras) > 1
+    # SSDK_SSD_TAIL_SIDE=2: only the SMALL extras (the fused pairs behind the first one) and the heads of their levels as the
+    # side run, next to the 8x8 level's head on the main stream (recorded behind the run): two branches that both hang on the
+    # first extra's output, neither of which fills the chip or its LDS.
+    ts_mode = os.environ.get("SSDK_SSD_TAIL_SIDE", "0")
+    tail_side = ts_mode == "1" and isinstance(model.backbone, MobileNetEx) and len(model.extras) > 1
+    tail_small = ts_mode == "2" and isinstance(model.backbone, MobileNetEx) and len(model.extras) > 2
     late = []
     if isinstance(model.backbone, MobileNetEx):
         feats = record_mobilenet(plan, plan.input_value(), model.backbone,
@@ -144,12 +149,23 @@ def build_ssd_plan(model, x):
     # dependent latencies with 128 / 32 / 8 workgroups each).  SSDK_HEAD_BALANCE=0: every head right behind its feature map.
     balance = os.environ.get("SSDK_HEAD_BALANCE", "1") != "0" and len(model.extras) > 1
     deferred = []
+    first_extra_level = None
     for j, extra in enumerate(model.extras):
-        feats.append(record_chain(plan, feats[-1], extra, keep_input=True, lane=2 if tail_side else 0))
+        feats.append(record_chain(plan, feats[-1], extra, keep_input=True, lane=2 if (tail_side or (tail_small and j > 0)) else 0))
+        if j == 0:
+            first_extra_level = len(feats) - 1
         if balance:
             deferred.append((len(feats) - 1, feats[-1]))
         else:
             head(len(feats) - 1, feats[-1])
+    if tail_small and balance:
+        for i, f in deferred:
+            if i != first_extra_level:
+                head(i, f, lane=2, position=i)
+        for i, f in deferred:
+            if i == first_extra_level:
+                head(i, f, lane=0, position=i)
+        deferred = []
     for i, f in deferred:
         head(i, f, lane=2 if tail_side else 0, position=i)
     for i, f in late:  # (tail_side) the backbone levels' heads, on the main stream, while the side run is in flight
