@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 220 /* 0.2.2: ssdk_mbconv_desc.image_nw / w_image / w_image_bytes (ssdk_mbk.hip), larger ssdk_match_multibox_loss workspace; 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
+#define SSDK_VERSION 230 /* 0.2.3: ssdk_struct_size; 0.2.2: ssdk_mbconv_desc.image_nw / w_image / w_image_bytes (ssdk_mbk.hip), larger ssdk_match_multibox_loss workspace; 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
 
 #define SSDK_MAX_LEVELS 8    /* feature-map levels per decode_nms call            */
 #define SSDK_MAX_ANCHORS 16  /* anchors per location (A)                          */
@@ -73,6 +73,18 @@ typedef struct ssdk_level {
 } ssdk_level;
 
 int ssdk_version(void);
+/* sizeof() of a descriptor struct AS THE LIBRARY WAS BUILT (version 230): a binding checks its own layout against it at
+ * load time instead of trusting the version number alone -- a caller compiled against an older header passes a shorter
+ * struct, and the library would read past its end.  which: */
+#define SSDK_SIZEOF_LEVEL 0
+#define SSDK_SIZEOF_CONV_DESC 1
+#define SSDK_SIZEOF_MBCONV_DESC 2
+#define SSDK_SIZEOF_FUSE_DESC 3
+#define SSDK_SIZEOF_STEM_DESC 4
+#define SSDK_SIZEOF_POOL_DESC 5
+#define SSDK_SIZEOF_XPAIR_DESC 6
+#define SSDK_SIZEOF_OP 7
+size_t ssdk_struct_size(int which); /* 0 for an unknown `which` */
 const char* ssdk_last_error(void);
 /* name of the kernel the calling thread launched last (which variant a layer was dispatched to; tests, tools) */
 const char* ssdk_last_kernel(void);

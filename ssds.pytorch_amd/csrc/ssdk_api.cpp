@@ -33,6 +33,19 @@ int check_launch(const char* what) {
 }  // namespace ssdk
 
 extern "C" int ssdk_version(void) { return SSDK_VERSION; }
+extern "C" size_t ssdk_struct_size(int which) {
+  switch (which) {
+    case SSDK_SIZEOF_LEVEL: return sizeof(ssdk_level);
+    case SSDK_SIZEOF_CONV_DESC: return sizeof(ssdk_conv_desc);
+    case SSDK_SIZEOF_MBCONV_DESC: return sizeof(ssdk_mbconv_desc);
+    case SSDK_SIZEOF_FUSE_DESC: return sizeof(ssdk_fuse_desc);
+    case SSDK_SIZEOF_STEM_DESC: return sizeof(ssdk_stem_desc);
+    case SSDK_SIZEOF_POOL_DESC: return sizeof(ssdk_pool_desc);
+    case SSDK_SIZEOF_XPAIR_DESC: return sizeof(ssdk_xpair_desc);
+    case SSDK_SIZEOF_OP: return sizeof(ssdk_op);
+    default: return 0;
+  }
+}
 extern "C" const char* ssdk_last_error(void) { return ssdk::g_err; }
 extern "C" const char* ssdk_last_kernel(void) { return ssdk::g_last_kernel; }
 

@@ -106,6 +106,14 @@ def _load():
     c = ctypes
     vp, i32, f32, sz = c.c_void_p, c.c_int, c.c_float, c.c_size_t
     lib.ssdk_version.restype = i32
+    lib.ssdk_struct_size.argtypes = [i32]
+    lib.ssdk_struct_size.restype = sz
+    # the ctypes mirrors below must have the layout the library was BUILT with: a shorter struct would be read past its end
+    for which, cls in enumerate((Level, ConvDesc, MbConvDesc, FuseDesc, StemDesc, PoolDesc, XpairDesc, Op)):
+        want = lib.ssdk_struct_size(which)
+        if want != ctypes.sizeof(cls):
+            raise ImportError("libssdk.so at {} was built against another include/ssdk.h: sizeof({}) is {} there, {} in ssds/_native.py"
+                              .format(LIB_PATH, cls.__name__, want, ctypes.sizeof(cls)))
     lib.ssdk_last_error.restype = c.c_char_p
     lib.ssdk_last_kernel.restype = c.c_char_p
     lib.ssdk_mbk_image_bytes.argtypes = [i32] * 6 + [c.POINTER(i32)]
@@ -211,7 +219,7 @@ def _load():
 
 
 lib = _load()
-EXPORTS = ("ssdk_version", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_profiling", "ssdk_get_op_timings", "ssdk_device_info", "ssdk_generate_anchors",
+EXPORTS = ("ssdk_version", "ssdk_struct_size", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_profiling", "ssdk_get_op_timings", "ssdk_device_info", "ssdk_generate_anchors",
            "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
            "ssdk_match_targets_by_scale", "ssdk_match_loss_workspace_bytes", "ssdk_match_loss",

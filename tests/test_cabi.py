@@ -21,7 +21,29 @@ def test_header_symbols_exported():
     assert declared == set(N.EXPORTS), declared ^ set(N.EXPORTS)
     for name in declared:
         assert hasattr(N.lib, name), name
-    assert N.lib.ssdk_version() == 220
+    assert N.lib.ssdk_version() == 230
+
+
+def test_descriptor_layouts_are_the_ones_the_library_was_built_with():
+    """ssdk_struct_size (version 230): the ctypes mirrors of every descriptor struct have the size the library reports (the
+    loader refuses to import otherwise), an unknown index reports 0, and the C compiler agrees with both about the header."""
+    import subprocess
+    import tempfile
+
+    from ssds import _native as N
+
+    classes = (N.Level, N.ConvDesc, N.MbConvDesc, N.FuseDesc, N.StemDesc, N.PoolDesc, N.XpairDesc, N.Op)
+    sizes = [int(N.lib.ssdk_struct_size(i)) for i in range(len(classes))]
+    assert sizes == [ctypes.sizeof(c) for c in classes] and all(sizes)
+    assert N.lib.ssdk_struct_size(len(classes)) == 0 and N.lib.ssdk_struct_size(-1) == 0
+    src = ('#include <stdio.h>\n#include "ssdk.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ssdk_level), '
+           "sizeof(ssdk_conv_desc), sizeof(ssdk_mbconv_desc), sizeof(ssdk_fuse_desc), sizeof(ssdk_stem_desc), sizeof(ssdk_pool_desc), "
+           "sizeof(ssdk_xpair_desc), sizeof(ssdk_op)); return 0;}\n")
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")], check=True)
+        out = subprocess.run([os.path.join(d, "s")], check=True, capture_output=True, text=True).stdout.split()
+    assert [int(v) for v in out] == sizes
 
 
 def test_library_is_in_tree_and_has_gfx950_code():
