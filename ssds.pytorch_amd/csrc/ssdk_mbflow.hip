@@ -55,9 +55,10 @@ struct FlowLds {
   static constexpr int bytes = spb + NFO * 4 * 32;
 };
 
-template <int DT, int S, int NCH, int NFO, int NS, bool STEM = false, bool YE = false, bool PAIR = false>
+template <int DT, int S, int NCH, int NFO, int NS, bool STEM = false, bool YE = false, bool PAIR = false, bool XD = false>
 __global__ __launch_bounds__(kFlowThreads, ((STEM && !YE) || PAIR) ? 3 : 2) void mbflow_kernel(const FlowParams p) {
   static_assert(!PAIR || (S == 1 && !STEM), "row pairs: stride-1 blocks");
+  static_assert(!XD || (STEM && !YE), "dword image loads: the stem's interior instance");
   using L = FlowLds<NCH, NFO>;
   constexpr int T = L::T;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -73,8 +74,35 @@ __global__ __launch_bounds__(kFlowThreads, ((STEM && !YE) || PAIR) ? 3 : 2) void
       if (hc < (u32)Chid) {
 #pragma unroll
         for (u32 j = 0; j < 8; ++j) {
-          const u32 k = k0 + j, ci = k / 9u, ky = (k % 9u) / 3u, kx = k % 3u;
-          const u32 h = (k < 27u && ci < (u32)p.Cimg) ? (u32)p.we[(size_t)hc * 96 + (ky * 8 + kx) * 4 + ci] : 0u;
+          u32 ci, ky, kx;
+          bool kv;
+          if constexpr (XD) {  // the slot order of the dword image loads (load_x below): lane group g holds the triples 2g, 2g + 1 (+ 8)
+            const u32 g = k0 >> 3;
+            u32 t;
+            if (j < 3u) {  // (kx 1, kx 2) = the pixel's own aligned dword, kx 0 = the high half of its left neighbour's
+              t = 2u * g;
+              kx = j == 2u ? 0u : j + 1u;
+              kv = true;
+            } else if (j < 6u) {
+              t = 2u * g + 1u;
+              kx = j == 3u ? 0u : j - 3u;
+              kv = true;
+            } else {  // triple 8: its dword in group 0, its kx = 0 tap in the high half of group 1's last dword
+              t = 8u;
+              kx = g == 0u ? j - 5u : 0u;
+              kv = g == 0u || (g == 1u && j == 7u);
+            }
+            ci = t / 3u;
+            ky = t % 3u;
+            kv = kv && ci < (u32)p.Cimg;
+          } else {
+            const u32 k = k0 + j;
+            ci = k / 9u;
+            ky = (k % 9u) / 3u;
+            kx = k % 3u;
+            kv = k < 27u && ci < (u32)p.Cimg;
+          }
+          const u32 h = kv ? (u32)p.we[(size_t)hc * 96 + (ky * 8 + kx) * 4 + ci] : 0u;
           v[j >> 1] |= h << ((j & 1u) * 16u);
         }
       }
@@ -207,6 +235,37 @@ __global__ __launch_bounds__(kFlowThreads, ((STEM && !YE) || PAIR) ? 3 : 2) void
   // STEM: the buffer is this image, opened `xmargin` bytes EARLY so that the (row, strip) offset in the SGPR is never
   // negative (row 0 starts one image row and three pixels before the image); nothing in front of the image is ever
   // read: the values that would lie there carry out-of-range offsets.
+  // XD (round 5): the image rows are read as ALIGNED DWORDS (NCHW image, even width).  Of a 3x3 / stride-2 patch the taps
+  // kx = 1, 2 of a (channel, kernel row) are one aligned dword (columns 2 ix, 2 ix + 1) and kx = 0 (column 2 ix - 1) is the
+  // high half of the LEFT NEIGHBOUR pixel's dword -- one lane down (DPP).  Nine (ci, ky) triples in 32 k-slots: lane group
+  // g holds triples 2g and 2g + 1 as dwords [pair A | (A.kx0, B.kx0) | pair B | x], x = the pair of triple 8 in group 0 and
+  // triple 8's kx = 0 (the high half of the left neighbour's dword, loaded directly) in group 1: THREE dword loads per lane,
+  // row and strip (+ two for the left edge lane of the wave's first strip) instead of eight 2-byte loads -- the kernel's
+  // time follows the number of load instructions (measured with timing-only builds: 137 / 115 / 104 us for 8 / 5 / 3).
+  // Byte offsets: soff = (row 2 iy - 1, column of the strip's lane 0) + xmargin - 4, per lane (2 fr + ci plane + ky row) * 2
+  // + 4 for its own pixel, + 0 for its left neighbour (so that nothing is ever negative); invalid values carry kOOR.
+  u32 xd_off[XD ? NS : 1][3], xd_off0[XD ? NS : 1][2], xd_edge[2], xd_edge0[2];
+  if constexpr (XD) {
+    const u32 tA = 2u * fg, tB = 2u * fg + 1u;
+    auto voff = [&](u32 t, int shift, int s_) -> u32 {  // triple t of pixel ix[s_] - shift
+      const u32 ci = t / 3u, ky = t % 3u;
+      const int px = ix[s_] - shift;
+      const bool ok = ci < (u32)p.Cimg && grp * NS + s_ < p.strips && (unsigned)px < (unsigned)p.W;
+      return ok ? (u32)((2 * (int)fr + (int)ci * p.Himg * p.Wimg + (int)ky * p.Wimg) * 2 + 4 * (1 - shift)) : kOOR;
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      xd_off[s][0] = voff(tA, 0, s);
+      xd_off[s][1] = voff(tB, 0, s);
+      xd_off[s][2] = fg == 0u ? voff(8u, 0, s) : (fg == 1u ? voff(8u, 1, s) : kOOR);
+      xd_off0[s][0] = tA % 3u == 0u ? kOOR : xd_off[s][0];  // stem row 0: the ky = 0 taps lie above the image
+      xd_off0[s][1] = tB % 3u == 0u ? kOOR : xd_off[s][1];
+    }
+    xd_edge[0] = fr == 0u ? voff(tA, 1, 0) : kOOR;  // the wave's first strip: its lane 0 has no lane to its left
+    xd_edge[1] = fr == 0u ? voff(tB, 1, 0) : kOOR;
+    xd_edge0[0] = tA % 3u == 0u ? kOOR : xd_edge[0];
+    xd_edge0[1] = tB % 3u == 0u ? kOOR : xd_edge[1];
+  }
   const int xmargin = STEM ? (p.Wimg + 8) * pstr * 2 : 0;
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<const unsigned char*>(ximg) - xmargin), 0, STEM ? p.Cimg * p.Himg * p.Wimg * 2 + xmargin : 0, 0x00020000);
@@ -224,7 +283,18 @@ __global__ __launch_bounds__(kFlowThreads, ((STEM && !YE) || PAIR) ? 3 : 2) void
       const int strip = grp * NS + s;
       // element offset of (image row 2iy-1, image column 2*ix-1 of the strip's lane 0, channel 0)
       const int base = ((2 * iy - 1) * p.Wimg + (2 * (strip * 14 - 1) - 1)) * pstr;
-      if constexpr (YE) {  // items that touch the top / bottom of the image: rows outside it are masked per value
+      if constexpr (XD) {
+        const bool row_in = (unsigned)iy < (unsigned)p.H, top = iy == 0;  // wave-uniform
+        const int soff = row_in ? (base + 1) * 2 + xmargin - 4 : (int)kOOR;  // (column 2 ix of the strip's lane 0; pstr == 1)
+        out.w[0] = (u32)__builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)(top ? xd_off0[s][0] : xd_off[s][0]), soff, 0);
+        out.w[1] = (u32)__builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)(top ? xd_off0[s][1] : xd_off[s][1]), soff, 0);
+        out.w[2] = (u32)__builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)xd_off[s][2], soff, 0);
+        if (s == 0) {
+          out.w[3] = (u32)__builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)(top ? xd_edge0[0] : xd_edge[0]), soff, 0);
+          out.w[4] = (u32)__builtin_amdgcn_raw_buffer_load_b32(xrsrc, (int)(top ? xd_edge0[1] : xd_edge[1]), soff, 0);
+        }
+        return out;
+      } else if constexpr (YE) {  // items that touch the top / bottom of the image: rows outside it are masked per value
         u32 rowmask = 0;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -276,7 +346,24 @@ __global__ __launch_bounds__(kFlowThreads, ((STEM && !YE) || PAIR) ? 3 : 2) void
     u32x4 xf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      if constexpr (STEM) {
+      if constexpr (XD) {
+        // the left neighbour pixel's dwords: one lane down; lane 0 takes the edge load (first strip) or lane 13 of the strip to
+        // the left (strips are 14 pixels apart: its lane 14 is this strip's lane 0)
+        int oa, ob;
+        if (s == 0) {
+          oa = (int)xraw[0].w[3];
+          ob = (int)xraw[0].w[4];
+        } else {
+          oa = __builtin_amdgcn_update_dpp(0, (int)xraw[s - 1].w[0], 0x123, 0xf, 0xf, true);  // row_ror:3: lane 0 <- lane 13
+          ob = __builtin_amdgcn_update_dpp(0, (int)xraw[s - 1].w[1], 0x123, 0xf, 0xf, true);
+        }
+        const u32 an = (u32)__builtin_amdgcn_update_dpp(oa, (int)xraw[s].w[0], 0x111, 0xf, 0xf, false);  // row_shr:1, lane 0 keeps `old`
+        const u32 bn = (u32)__builtin_amdgcn_update_dpp(ob, (int)xraw[s].w[1], 0x111, 0xf, 0xf, false);
+        xf[s][0] = xraw[s].w[0];
+        xf[s][1] = __builtin_amdgcn_perm(bn, an, 0x07060302u);  // (A.kx0 = high half of an, B.kx0 = high half of bn)
+        xf[s][2] = xraw[s].w[1];
+        xf[s][3] = fg == 1u ? (xraw[s].w[2] & 0xffff0000u) : xraw[s].w[2];
+      } else if constexpr (STEM) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) xf[s][q] = xraw[s].w[2 * q] | (xraw[s].w[2 * q + 1] << 16);
       } else {
@@ -829,6 +916,17 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((mbflow_kernel<DTv, 1, 2, 1, 1, true, YEv>), dim3(g), dim3(kFlowThreads), lds, stream, q);
         return;
+      }
+      if constexpr (!YEv) {
+        // NCHW image of even width, 4-byte aligned: the interior instance reads it as aligned dwords (three loads per lane,
+        // row and strip instead of eight; SSDK_STEM_DWORD=0: the 2-byte gather)
+        static const int env_xd = getenv("SSDK_STEM_DWORD") ? atoi(getenv("SSDK_STEM_DWORD")) : 1;
+        if (env_xd && q.layout == 1 && (q.Wimg & 1) == 0 && (reinterpret_cast<uintptr_t>(q.x) & 3u) == 0) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<DTv, 1, 2, 1, kFlowNS, true, false, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+          hipLaunchKernelGGL((mbflow_kernel<DTv, 1, 2, 1, kFlowNS, true, false, false, true>), dim3(g), dim3(kFlowThreads), lds, stream, q);
+          return;
+        }
       }
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mbflow_kernel<DTv, 1, 2, 1, kFlowNS, true, YEv>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -665,9 +665,12 @@ def test_pointwise_streaming_kernel(cin, cout, stride, h, w, n, act, rmode, dtyp
 
 @pytest.mark.parametrize("variant", ["tiled", "flow"])
 @pytest.mark.parametrize("layout", ["nchw", "nhwc"])
-@pytest.mark.parametrize("h,w", [(64, 64), (37, 45), (130, 121)])
+@pytest.mark.parametrize("h,w", [(64, 64), (37, 45), (130, 121), (70, 90), (129, 122), (66, 60)])
 def test_fused_stem_block(layout, h, w, variant):
-    """Stem (3x3/s2, BN, ReLU6) + expand-free first block (dw 3x3, pw 32->16) as ONE launch from the image."""
+    """Stem (3x3/s2, BN, ReLU6) + expand-free first block (dw 3x3, pw 32->16) as ONE launch from the image.  NCHW images of
+    even width take the register-flow kernel's dword loads (three per lane, row and strip; the left tap comes from the
+    neighbour lane): widths that end inside a strip / on a strip boundary, odd heights (the masking instance runs the bottom
+    segment on the 2-byte gather), several strips per wave and an odd number of strips."""
     import torch
     from ssds.modeling.layers import fused_conv as FC
     from ssds.modeling.layers.planner import groups_of
