@@ -25,7 +25,13 @@
  *   - descriptor structs (ssdk_conv_desc, ssdk_mbconv_desc, ssdk_xpair_desc, ssdk_op, ...) are ZERO-INITIALISED by the
  *     caller before it sets the fields it knows.  New fields are only ever appended to a struct and 0 / NULL selects
  *     the behaviour from before the field existed; entry points never change their signature (new ones are added and
- *     SSDK_VERSION is raised).  Bind against the header the library was built with and check ssdk_version().
+ *     SSDK_VERSION is raised).
+ *   - ABI: a descriptor that GROWS changes sizeof(ssdk_op), which is the array stride of ssdk_run_ops -- so every
+ *     SSDK_VERSION step that appends a descriptor field (210, 220) is ABI-BREAKING for callers of the descriptor entry points:
+ *     a caller must be compiled against the header of the library it loads.  The library cannot see the caller's layout
+ *     through a pointer, so the caller proves it once: ssdk_abi_check(SSDK_VERSION, sizeof(ssdk_op)) right after loading
+ *     (0 = the caller's header and the library's agree; the Python host does this in ssds/_native.py and refuses to run
+ *     otherwise), or per struct with ssdk_struct_size().  The box entry points (plain pointers and scalars) are unaffected.
  */
 #ifndef SSDK_H_
 #define SSDK_H_
@@ -37,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 230 /* 0.2.3: ssdk_struct_size; 0.2.2: ssdk_mbconv_desc.image_nw / w_image / w_image_bytes (ssdk_mbk.hip), larger ssdk_match_multibox_loss workspace; 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
+#define SSDK_VERSION 240 /* 0.2.4: ssdk_abi_check, ssdk_pw_* (1x1 convolutions of the training step: forward / input gradient / weight gradient on NCHW tensors); 0.2.3: ssdk_struct_size; 0.2.2: ssdk_mbconv_desc.image_nw / w_image / w_image_bytes (ssdk_mbk.hip), larger ssdk_match_multibox_loss workspace; 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
 
 #define SSDK_MAX_LEVELS 8    /* feature-map levels per decode_nms call            */
 #define SSDK_MAX_ANCHORS 16  /* anchors per location (A)                          */
@@ -85,6 +91,10 @@ int ssdk_version(void);
 #define SSDK_SIZEOF_XPAIR_DESC 6
 #define SSDK_SIZEOF_OP 7
 size_t ssdk_struct_size(int which); /* 0 for an unknown `which` */
+/* The caller's view of the ABI against the library's: header_version = the SSDK_VERSION the caller was compiled with,
+ * sizeof_op = its sizeof(ssdk_op).  0 if header_version / 10 == the library's version / 10 (the last digit counts additions
+ * that leave every layout alone) and the sizes agree; SSDK_E_BADARG (text in ssdk_last_error) otherwise.  (version 240) */
+int ssdk_abi_check(int header_version, size_t sizeof_op);
 const char* ssdk_last_error(void);
 /* name of the kernel the calling thread launched last (which variant a layer was dispatched to; tests, tools) */
 const char* ssdk_last_kernel(void);

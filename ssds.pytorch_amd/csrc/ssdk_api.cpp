@@ -46,6 +46,14 @@ extern "C" size_t ssdk_struct_size(int which) {
     default: return 0;
   }
 }
+extern "C" int ssdk_abi_check(int header_version, size_t sizeof_op) {
+  if (header_version / 10 != SSDK_VERSION / 10 || sizeof_op != sizeof(ssdk_op)) {
+    ssdk::set_error("ssdk_abi_check: caller was compiled for ABI %d with sizeof(ssdk_op) = %zu, this library is ABI %d with %zu",
+                    header_version, sizeof_op, SSDK_VERSION, sizeof(ssdk_op));
+    return SSDK_E_BADARG;
+  }
+  return SSDK_OK;
+}
 extern "C" const char* ssdk_last_error(void) { return ssdk::g_err; }
 extern "C" const char* ssdk_last_kernel(void) { return ssdk::g_last_kernel; }
 

@@ -96,6 +96,9 @@ FUSE_SAME, FUSE_UP2, FUSE_POOL2 = 0, 1, 2
 NCHW, NHWC = 0, 1
 
 
+ABI_VERSION = 240  # include/ssdk.h SSDK_VERSION this module's ctypes mirrors and prototypes are written for
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -106,6 +109,15 @@ def _load():
     c = ctypes
     vp, i32, f32, sz = c.c_void_p, c.c_int, c.c_float, c.c_size_t
     lib.ssdk_version.restype = i32
+    # version FIRST: a library older than ABI 230 has no ssdk_struct_size, and a bare AttributeError from
+    # the symbol lookup below would hide what is wrong
+    try:
+        have = int(lib.ssdk_version())
+    except AttributeError:
+        have = 0
+    if have < ABI_VERSION:
+        raise ImportError("libssdk.so at {} is ABI {} but ssds/_native.py is written for ABI {}: rebuild it "
+                          "(`make -C ssds.pytorch_amd/csrc`)".format(LIB_PATH, have, ABI_VERSION))
     lib.ssdk_struct_size.argtypes = [i32]
     lib.ssdk_struct_size.restype = sz
     # the ctypes mirrors below must have the layout the library was BUILT with: a shorter struct would be read past its end
@@ -115,6 +127,10 @@ def _load():
             raise ImportError("libssdk.so at {} was built against another include/ssdk.h: sizeof({}) is {} there, {} in ssds/_native.py"
                               .format(LIB_PATH, cls.__name__, want, ctypes.sizeof(cls)))
     lib.ssdk_last_error.restype = c.c_char_p
+    lib.ssdk_abi_check.argtypes = [i32, sz]
+    lib.ssdk_abi_check.restype = i32
+    if lib.ssdk_abi_check(ABI_VERSION, ctypes.sizeof(Op)) != 0:
+        raise ImportError("libssdk.so at {}: {}".format(LIB_PATH, lib.ssdk_last_error().decode()))
     lib.ssdk_last_kernel.restype = c.c_char_p
     lib.ssdk_mbk_image_bytes.argtypes = [i32] * 6 + [c.POINTER(i32)]
     lib.ssdk_mbk_image_bytes.restype = sz
@@ -219,7 +235,7 @@ def _load():
 
 
 lib = _load()
-EXPORTS = ("ssdk_version", "ssdk_struct_size", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_profiling", "ssdk_get_op_timings", "ssdk_device_info", "ssdk_generate_anchors",
+EXPORTS = ("ssdk_version", "ssdk_struct_size", "ssdk_abi_check", "ssdk_last_error", "ssdk_last_kernel", "ssdk_set_op_profiling", "ssdk_get_op_timings", "ssdk_device_info", "ssdk_generate_anchors",
            "ssdk_decode_workspace_bytes", "ssdk_decode", "ssdk_nms_workspace_bytes", "ssdk_nms",
            "ssdk_decode_nms_workspace_bytes", "ssdk_decode_nms", "ssdk_match_targets",
            "ssdk_match_targets_by_scale", "ssdk_match_loss_workspace_bytes", "ssdk_match_loss",

@@ -21,7 +21,7 @@ def test_header_symbols_exported():
     assert declared == set(N.EXPORTS), declared ^ set(N.EXPORTS)
     for name in declared:
         assert hasattr(N.lib, name), name
-    assert N.lib.ssdk_version() == 230
+    assert N.lib.ssdk_version() == 240 == N.ABI_VERSION
 
 
 def test_descriptor_layouts_are_the_ones_the_library_was_built_with():
@@ -44,6 +44,18 @@ def test_descriptor_layouts_are_the_ones_the_library_was_built_with():
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")], check=True)
         out = subprocess.run([os.path.join(d, "s")], check=True, capture_output=True, text=True).stdout.split()
     assert [int(v) for v in out] == sizes
+
+
+def test_abi_check_rejects_another_header():
+    """ssdk_abi_check (version 240): the library accepts the header it was built with (any last digit of the version) and
+    rejects a caller compiled for another minor version or with another sizeof(ssdk_op) -- with a message, not a crash."""
+    from ssds import _native as N
+
+    sz = ctypes.sizeof(N.Op)
+    assert N.lib.ssdk_abi_check(N.ABI_VERSION, sz) == 0
+    assert N.lib.ssdk_abi_check(N.ABI_VERSION // 10 * 10 + 9, sz) == 0
+    assert N.lib.ssdk_abi_check(N.ABI_VERSION - 10, sz) == -1 and b"ABI" in N.lib.ssdk_last_error()
+    assert N.lib.ssdk_abi_check(N.ABI_VERSION, sz - 8) == -1 and b"sizeof" in N.lib.ssdk_last_error()
 
 
 def test_library_is_in_tree_and_has_gfx950_code():

@@ -64,6 +64,34 @@ CORR_FACTOR_SMALL = 0.5
 MEDIAN_FACTOR_SMALL = 3.0
 
 
+def pooled_small_level_stats(plans, floors, wants, small=SMALL):
+    """``plans`` / ``floors`` / ``wants``: one {"loc": [...], "conf": [...]} per INPUT DRAW (seed).  For every level of fewer
+    than ``small`` values per draw -> dict with the per-draw correlations (mean / min over the draws) and the POOLED statistics
+    (all draws' values concatenated: a 1x1 level of 24 box values per image becomes a sample of draws x batch x 24), of the
+    plan and of the floor, each against the fp32 reference.  Class heads as logits."""
+    import torch
+
+    rows = []
+    for tag in ("loc", "conf"):
+        lg = tag == "conf"
+        for i in range(len(wants[0][tag])):
+            if wants[0][tag][i].numel() >= small:
+                continue
+            per = {"plan": [], "floor": []}
+            for src, outs in (("plan", plans), ("floor", floors)):
+                for o, w in zip(outs, wants):
+                    per[src].append(_stats(o[tag][i], w[tag][i], lg)[3])
+            cat = lambda seq: torch.cat([d[tag][i].float().cpu().flatten() for d in seq])
+            wp = cat(wants)
+            sp, sf = _stats(cat(plans), wp, lg), _stats(cat(floors), wp, lg)
+            rows.append({"tensor": "%s%d" % (tag, i), "values": int(wp.numel()),
+                         "plan_r_mean": sum(per["plan"]) / len(per["plan"]), "plan_r_min": min(per["plan"]),
+                         "floor_r_mean": sum(per["floor"]) / len(per["floor"]), "floor_r_min": min(per["floor"]),
+                         "plan_r_pooled": sp[3], "floor_r_pooled": sf[3],
+                         "plan_median_pooled": sp[0], "floor_median_pooled": sf[0]})
+    return rows
+
+
 def floor_runs(model, x, runs=3):
     """PyTorch-ROCm / MIOpen executing the module in its own dtype, ``runs`` times (MIOpen picks algorithms by timing them:
     the floor's tail statistic moved 2x between sessions of round 4) -> list of {"loc": ..., "conf": ...}."""

@@ -639,3 +639,238 @@ def test_eval_epoch_on_device_matches_oracle_metric():
     assert sum(len(x) for x in orc.score) > 0
     np.testing.assert_allclose(np.array(ap), np.array(oap), rtol=1e-12, atol=1e-15, equal_nan=True)
     assert (np.isnan(mAP) and np.isnan(omAP)) or abs(mAP - omAP) < 1e-12
+
+
+# ---- the COMPOSITION: every parameter's gradient of the whole step at config-4 geometry ----------------------------------------
+def _rel_and_corr(got, want):
+    """(rms(got - want) / rms(want), Pearson r) of two flat fp32 tensors."""
+    import torch
+
+    g, w = got.double().flatten(), want.double().flatten()
+    rw = float(w.pow(2).mean().sqrt())
+    rel = float((g - w).pow(2).mean().sqrt()) / max(rw, 1e-30)
+    gc, wc = g - g.mean(), w - w.mean()
+    den = float(gc.pow(2).mean().sqrt()) * float(wc.pow(2).mean().sqrt())
+    r = float((gc * wc).mean()) / den if den > 0 else 0.0
+    return rel, r
+
+
+def _whole_step_case(size, batch, seed=11):
+    """SSD-MobileNetV2 of experiments/cfgs/ssd_mobilenetv2_512.yml (C = 80, six levels, A = 6) at ``size`` px with seeded O(1)
+    weights -> (fp32 CPU module in train mode, anchors, images, targets, cfg), everything on the CPU."""
+    import torch
+    from ssds.core import config
+    from ssds.dataset.synthetic import SyntheticDetectionLoader
+    from ssds.modeling import model_builder
+    import cases
+    import nethelp
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config.reset_cfg()
+    cfg = config.cfg_from_file(os.path.join(root, "experiments", "cfgs", "ssd_mobilenetv2_512.yml"))
+    cfg.MODEL.IMAGE_SIZE = [size, size]
+    torch.manual_seed(seed)
+    model = model_builder.create_model(cfg.MODEL)
+    spec = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    state = cases.seeded_state(spec, seed)
+    nethelp.untrained_score_prior(state)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    anchors = model_builder.create_anchors(cfg.MODEL, model, cfg.MODEL.IMAGE_SIZE)
+    assert len(anchors) == 6, "two levels share a stride at this size (model_builder.py:41 keys the anchors by stride)"
+    loader = SyntheticDetectionLoader(batch, (size, size), cfg.MODEL.NUM_CLASSES, 1, torch.device("cpu"), seed=seed)
+    images, targets = loader.batch()
+    # The loader's boxes (2 - 40 % of the image) never reach the anchors of the last levels (stride 256 / 512: 512 - 1448 px).
+    # So that EVERY level's box head has foreground anchors, rows 0..5 of every image are one anchor box of each level
+    # (random cell, random anchor, shrunk by 4 %: IoU 0.92) -- for the last level that box extends beyond the image, which
+    # extract_targets (box.py:362-405) neither checks nor needs.
+    g = torch.Generator().manual_seed(seed + 1)
+    m = size // 16
+    for j, (stride, anc) in enumerate(anchors.items()):
+        for b in range(batch):
+            a = int(torch.randint(0, anc.shape[0], (1,), generator=g))
+            ix, iy = (int(v) for v in torch.randint(0, m, (2,), generator=g))
+            x1, y1, x2, y2 = (float(v) for v in anc[a] + torch.tensor([ix, iy, ix, iy], dtype=torch.float32) * stride)
+            w, h = (x2 - x1 + 1) * 0.96, (y2 - y1 + 1) * 0.96
+            targets[b, j] = torch.tensor([x1 + 0.02 * w, y1 + 0.02 * h, w, h, float((7 * b + 13 * j) % cfg.MODEL.NUM_CLASSES)])
+        m = (m + 1) // 2 if j >= 1 else m // 2
+    return model.train(), anchors, images, targets, cfg
+
+
+def _cpu_reference_step(model, anchors, images, targets, num_classes, match):
+    """The reference's step body (pipeline_anchor_apex.py:37-72) in fp32 on the CPU with the ORACLE's target assignment
+    (box.py:362-405 restated in oracle/box_oracle.py) and the reference-pinned criteria -> (cls_loss, loc_loss, {name: grad})."""
+    import torch
+    from oracle import box_oracle as O
+    from ssds.core import criterion
+
+    cls_c, loc_c = criterion.FocalLoss(), criterion.SmoothL1Loss()
+    model.zero_grad(set_to_none=True)
+    loc, conf = model(images)
+    oanch = OrderedDict((k, v.numpy()) for k, v in anchors.items())
+    c_sum, l_sum, fg = 0.0, 0.0, 0.0
+    for j, (stride, _) in enumerate(anchors.items()):
+        size = tuple(conf[j].shape[-2:])
+        ct, bt, dp = (torch.from_numpy(x) for x in O.extract_targets(targets.numpy(), oanch, num_classes, stride, size, tuple(match)))
+        fg = fg + (dp > 0).sum().float().clamp(min=1)
+        c = conf[j].view_as(ct).float()
+        c_sum = c_sum + ((dp >= 0).expand_as(ct).float() * cls_c(c, ct, dp)).sum()
+        l = loc[j].view_as(bt).float()
+        ll = loc_c(l, bt)
+        l_sum = l_sum + ((dp > 0).expand_as(ll).float() * ll).sum()
+    cls_loss, loc_loss = c_sum / fg, l_sum / fg
+    (cls_loss + loc_loss).backward()
+    return float(cls_loss.detach()), float(loc_loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+
+def _device_step(model, anchors, images, targets, cfg, autocast, ssdk=True, ddp=False):
+    """The step of this repository on the HIP device, set up like ssds.utils.train_ddp.Solver does (kernel-backed BatchNorm
+    with the folded activations, GEMM-backed 1x1 convolutions, kernel-backed depthwise convolutions, fused target assignment +
+    loss).  ``ssdk=False``: the SAME module as plain PyTorch-ROCm modules with the unfused torch losses (the noise floor of
+    the dtype).  ``ddp``: wrapped in torch DDP (world size 1 over RCCL, gradient_as_bucket_view: the gradients live in the
+    bucket views the all-reduce works on).  -> (cls_loss, loc_loss, {name: grad})."""
+    import copy
+    import torch
+    import torch.nn as nn
+    from ssds.core import criterion
+    from ssds.modeling.layers.dwconv import DepthwiseConv2d
+    from ssds.pipeline.pipeline_anchor_ddp import ModelWithLossBasic
+
+    m = copy.deepcopy(model)
+    if ssdk:
+        from ssds.modeling.layers.batchnorm import fuse_bn_activations, use_fast_batchnorm
+        from ssds.modeling.layers.pointwise import use_pointwise_gemm
+
+        use_fast_batchnorm(m)
+        assert fuse_bn_activations(m) > 30
+        use_pointwise_gemm(m)
+    else:
+        for mod in m.modules():
+            if type(mod) is DepthwiseConv2d:
+                mod.__class__ = nn.Conv2d
+    mwl = ModelWithLossBasic(m, criterion.FocalLoss(), criterion.SmoothL1Loss(), cfg.MODEL.NUM_CLASSES,
+                             cfg.MATCHER.MATCH_THRESHOLD, cfg.MATCHER.CENTER_SAMPLING_RADIUS).cuda().train()
+    inner = mwl
+    if ddp:
+        import torch.distributed as dist
+        from torch.nn.parallel import DistributedDataParallel as DDP
+
+        assert dist.is_initialized()
+        mwl = DDP(mwl, device_ids=[0], bucket_cap_mb=16, gradient_as_bucket_view=True)
+    old = os.environ.get("SSDK_FUSED_LOSS")
+    if not ssdk:
+        os.environ["SSDK_FUSED_LOSS"] = "0"
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            cls_loss, loc_loss, _, _ = mwl(images.cuda(), targets.cuda(), anchors)
+            total = cls_loss + loc_loss
+        total.backward()
+        torch.cuda.synchronize()
+    finally:
+        if not ssdk:
+            if old is None:
+                del os.environ["SSDK_FUSED_LOSS"]
+            else:
+                os.environ["SSDK_FUSED_LOSS"] = old
+    grads = {}
+    for k, p in inner.model.named_parameters():
+        assert p.grad is not None, "no gradient reached %s" % k
+        grads[k] = p.grad.detach().float().cpu()
+    return float(cls_loss), float(loc_loss), grads
+
+
+# fp32 on the device against fp32 on the CPU: the two differ by summation order only (hipBLASLt / MIOpen / the ssdk reductions vs
+# MKL).  Bars: every parameter's gradient within FP32_WORST relative rms, the median parameter within FP32_MEDIAN.
+FP32_WORST, FP32_MEDIAN = 1e-3, 1e-4
+POOL_BELOW = 512  # parameters with fewer elements (BatchNorm vectors of the narrow layers) are judged as ONE pooled vector
+
+
+def _judge_16bit(got, floor, ref, what):
+    """bf16-autocast gradients of the ssdk step against the fp32 CPU gradients, relative to PyTorch-ROCm's own bf16-autocast
+    execution of the same module (the floor): per parameter of >= POOL_BELOW elements
+        rel(plan) <= 2 x rel(floor) + 0.02   and   r(plan) >= r(floor) - 0.05      (the correlation rule of test_gpu_nets.py),
+    and the same for all smaller parameters pooled (each scaled by the rms of its fp32 gradient)."""
+    import torch
+
+    bad, rows, pool = [], [], {"got": [], "floor": [], "ref": []}
+    for k, w in ref.items():
+        rw = float(w.double().pow(2).mean().sqrt())
+        if rw == 0.0:
+            assert float(got[k].abs().max()) == 0.0, "%s: fp32 gradient is zero, the device's is not" % k
+            continue
+        if w.numel() < POOL_BELOW:
+            for tag, src in (("got", got), ("floor", floor), ("ref", ref)):
+                pool[tag].append(src[k].flatten().double() / rw)
+            continue
+        (rp, cp), (rf, cf) = _rel_and_corr(got[k], w), _rel_and_corr(floor[k], w)
+        rows.append((k, w.numel(), rp, cp, rf, cf))
+        if not (rp <= 2.0 * rf + 0.02 and cp >= cf - 0.05):
+            bad.append("%s (%d): plan rel %.4f r %.4f | floor rel %.4f r %.4f" % (k, w.numel(), rp, cp, rf, cf))
+    if pool["ref"]:
+        w = torch.cat(pool["ref"])
+        (rp, cp), (rf, cf) = _rel_and_corr(torch.cat(pool["got"]), w), _rel_and_corr(torch.cat(pool["floor"]), w)
+        rows.append(("<pooled small parameters>", int(w.numel()), rp, cp, rf, cf))
+        if not (rp <= 2.0 * rf + 0.02 and cp >= cf - 0.05):
+            bad.append("pooled small parameters: plan rel %.4f r %.4f | floor rel %.4f r %.4f" % (rp, cp, rf, cf))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "whole_step_gradients.txt"), "a") as f:
+            f.write("%s: bf16 autocast, per parameter: elements | plan rel, r | floor rel, r\n" % what)
+            for row in rows:
+                f.write("  %-44s %8d | %.4f %.4f | %.4f %.4f\n" % row)
+    assert not bad, "%s\n%s" % (what, "\n".join(bad))
+    return rows
+
+
+@pytest.mark.parametrize("size,batch,ddp", [(320, 4, False), (512, 8, False), (320, 4, True)])
+def test_whole_step_gradients_match_the_fp32_cpu_module(size, batch, ddp):
+    """The COMPOSITION of the training step (reference pipeline_anchor_apex.py:37-72, 103-130) at BASELINE config 4's geometry:
+    SSD-MobileNetV2, 80 classes, six levels, six anchors per cell, 512 px (and 320 px: the same six levels in a quarter of the
+    time; 128 / 256 px would give two levels the same stride, which model_builder.py:41 cannot key).  EVERY parameter's
+    gradient of (cls_loss + loc_loss) after one forward + backward -- the kernel-backed depthwise convolutions and BatchNorm
+    (+ folded ReLU6 / ReLU), the 1x1 convolutions, the 3x3 stem / extras / head convolutions, the fused target assignment +
+    focal + smooth-L1 kernel -- against the same step in fp32 on the CPU with the numpy oracle's target assignment:
+      * fp32 on the device: relative rms <= FP32_WORST for every parameter, <= FP32_MEDIAN for the median one, losses to 1e-5;
+      * bf16 autocast (the configuration the step runs in): against the PyTorch-ROCm floor with the correlation rule.
+    ``ddp``: the module wrapped in torch DDP over RCCL (world size 1) with gradient_as_bucket_view, i.e. the gradients are
+    written into the bucket views the all-reduce works on.  A dropped branch, a BatchNorm backward with the wrong mask or a
+    weight gradient summed over the wrong axis on ONE layer moves that layer's row to rel ~ 1 / r ~ 0."""
+    import torch
+
+    model, anchors, images, targets, cfg = _whole_step_case(size, batch)
+    rc, rl, ref = _cpu_reference_step(model, anchors, images, targets, cfg.MODEL.NUM_CLASSES, cfg.MATCHER.MATCH_THRESHOLD)
+    assert rl > 0 and all(float(g.abs().max()) > 0 for k, g in ref.items() if k.endswith("weight")), "a dead reference step"
+    if ddp:
+        import socket
+        import torch.distributed as dist
+
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0,
+                                device_id=torch.device("cuda", 0))
+    try:
+        # fp32 on the device
+        dc, dl, got = _device_step(model, anchors, images, targets, cfg, autocast=False, ddp=ddp)
+        np.testing.assert_allclose([dc, dl], [rc, rl], rtol=1e-5)
+        assert set(got) == set(ref)
+        rels = {k: _rel_and_corr(got[k], ref[k])[0] for k in ref if float(ref[k].abs().max()) > 0}
+        worst = max(rels, key=rels.get)
+        med = sorted(rels.values())[len(rels) // 2]
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        if os.path.isdir(out):
+            with open(os.path.join(out, "whole_step_gradients.txt"), "a") as f:
+                f.write("%d px B=%d ddp=%s fp32: %d parameters, median rel %.3g, worst %.3g (%s); losses %.6f %.6f vs %.6f %.6f\n"
+                        % (size, batch, ddp, len(rels), med, rels[worst], worst, dc, dl, rc, rl))
+        assert rels[worst] <= FP32_WORST and med <= FP32_MEDIAN, (worst, rels[worst], med)
+        # bf16 autocast: the ssdk step and the PyTorch-ROCm floor, both against fp32
+        ac, al, got16 = _device_step(model, anchors, images, targets, cfg, autocast=True, ddp=ddp)
+        np.testing.assert_allclose([ac, al], [rc, rl], rtol=2e-2)
+        _, _, floor16 = _device_step(model, anchors, images, targets, cfg, autocast=True, ssdk=False)
+        _judge_16bit(got16, floor16, ref, "%d px B=%d ddp=%s" % (size, batch, ddp))
+    finally:
+        if ddp:
+            import torch.distributed as dist
+
+            dist.destroy_process_group()
