@@ -403,6 +403,25 @@ int ssdk_fuse(const ssdk_fuse_desc* desc, void* stream);
 int ssdk_preprocess(const void* x, int src_dtype, int src_layout, int N, int H, int W, int C, const float* mean,
                     const float* std, void* y, int dst_dtype, void* stream);
 
+/* Dense 1x1 / stride-1 convolutions of the TRAINING step on NCHW tensors (version 240; csrc/ssdk_pwtrain.hip): the pointwise
+ * convolutions of MobileNetV2's inverted-residual blocks (nets/mobilenet.py:56, 78 through torchvision's InvertedResidual /
+ * ConvBNReLU) and of the SSD extras (layers/basic_layers.py:40-57), forward and backward in the reference's DDP step
+ * (pipeline/pipeline_anchor_apex.py:103-130).  16-bit tensors (SSDK_BF16 | SSDK_F16), fp32 accumulation, HW = H * W, tensors
+ * contiguous, pointers need the alignment of their element type only (the weight matrix: 16 bytes).
+ *   ssdk_pw_prepare   w32 [Cout, Cin] fp32 (the master weights)  ->  w16 [Cout, Cin] and wt16 [Cin, Cout] in `dtype`
+ *   ssdk_pw_forward   y[b] = a x[b] (+ bias):  x [B, K, HW], a [M, K] row-major 16 bit, bias fp32 [M] or NULL  ->  y [B, M, HW]
+ *                     forward:         a = w16  (K = Cin,  M = Cout)
+ *                     input gradient:  a = wt16 (K = Cout, M = Cin), x = dy, bias = NULL
+ *                     K must be a multiple of 8.
+ *   ssdk_pw_wgrad     dw [Cout, Cin] fp32 = sum_b dy[b] x[b]^T  (dy [B, Cout, HW], x [B, Cin, HW]); per-wave fp32 partial tiles
+ *                     through `workspace` (ssdk_pw_wgrad_workspace_bytes), added in index order: bit-reproducible. */
+int ssdk_pw_prepare(const float* w32, void* w16, void* wt16, int Cout, int Cin, int dtype, void* stream);
+int ssdk_pw_forward(const void* x, const void* a, const float* bias, void* y, int B, int K, int M, int HW, int dtype,
+                    void* stream);
+size_t ssdk_pw_wgrad_workspace_bytes(int B, int Cout, int Cin, int HW);
+int ssdk_pw_wgrad(const void* dy, const void* x, float* dw, void* workspace, size_t workspace_bytes, int B, int Cout, int Cin,
+                  int HW, int dtype, void* stream);
+
 /* Depthwise 3x3 convolution (pad 1, stride 1|2) for the TRAINING step: forward, input gradient and weight gradient,
  * NCHW contiguous, dtype SSDK_F32 | SSDK_BF16 | SSDK_F16, fp32 accumulation (replaces MIOpen's naive_conv_* kernels
  * behind torch.nn.functional.conv2d(groups = C) in the DDP step, pipeline_anchor_apex.py:75-171).

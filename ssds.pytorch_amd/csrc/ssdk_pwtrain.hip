@@ -1,0 +1,563 @@
+// ssdk_pwtrain.hip -- the dense 1x1 convolutions of the TRAINING step on the NCHW tensors themselves: forward, input gradient
+// and weight gradient on the matrix cores, no layout change, no library.
+//
+// Reference: the pointwise convolutions of torchvision's InvertedResidual / ConvBNReLU inside MobileNetV2 (nets/mobilenet.py:56,
+// 78, 180-192) and of the SSD extras (layers/basic_layers.py:40-57), forward + backward under Apex AMP O1 in the reference's DDP
+// step (pipeline/pipeline_anchor_apex.py:103-130, utils/train_ddp.py:106-108).  Rounds 2-5 ran them as hipBLASLt strided-batched
+// GEMMs through torch.matmul / torch.bmm ("library dispatch is not implemented").
+//
+//     y[b]  = W   x[b]            [Cout,Cin] [Cin,HW]     forward            pw_gemm_kernel   (a = W)
+//     dx[b] = W^T dy[b]           [Cin,Cout] [Cout,HW]    input gradient     pw_gemm_kernel   (a = W^T, prepared once per step)
+//     dW    = sum_b dy[b] x[b]^T  [Cout,HW]  [HW,Cin]     weight gradient    pw_wgrad_kernel + pw_wgrad_reduce_kernel
+//
+// All three are STREAMS at the shapes of this network (16 ... 960 channels): in + out bytes decide, so nothing is staged through
+// LDS except the (small) weight matrix.  What makes NCHW natural for v_mfma_f32_16x16x32:
+//   * y = a x: the B operand of an MFMA is "8 consecutive k of one column per lane".  In NCHW the 8 k (channels) of a pixel are
+//     HW elements apart -- but WHICH pixel a lane's column is, is free.  A lane loads 16 bytes = 8 consecutive PIXELS of one
+//     channel for each of its 8 channels (8 loads, every wave-level load is 16 lanes x 16 B = 256 contiguous bytes of a channel
+//     row), transposes the 8 x 8 block in its own registers with 32 v_perm_b32, and owns the B operands of EIGHT MFMAs: MFMA t
+//     multiplies the pixel set {p0 + 8 fr + t}.  Its accumulators then hold, per output channel row, 8 consecutive pixels =
+//     one 16-byte store into the NCHW output.  No LDS transpose on either side.
+//   * dW = dy x^T contracts over PIXELS, which are contiguous in both operands: A fragments of dy and B fragments of x are plain
+//     16-byte loads.  The k <-> pixel assignment is free as well (it only has to agree between the two operands), so a lane takes
+//     32 consecutive pixels (four k-steps) of its row: every row is read in 256-byte runs.
+//   * the weight gradient is split over (tile of the [Cout, Cin] matrix) x (range of pixels); every wave writes its fp32 partial
+//     tile to the workspace and pw_wgrad_reduce_kernel adds the partials in index order: no float atomics, bit-reproducible.
+// HBM bytes: forward (Cin + Cout) * 2 per pixel, input gradient the same, weight gradient (Cin + Cout) * 2 per pixel read.
+#include "ssdk_conv_common.h"
+
+namespace ssdk {
+
+typedef u32x4 pw_u32x4_a2 __attribute__((aligned(2)));
+constexpr int PWT_THREADS = 256;
+constexpr int PWT_KC = 8;  // k-steps (of 32 channels) of weights staged per chunk in the long-K kernel
+
+struct PwtParams {
+  const u16* x;       // [B, K, HW]
+  const u16* a;       // [M, K] row-major, 16 bit
+  const float* bias;  // [M] or null
+  u16* y;             // [B, M, HW]
+  int B, K, M, HW;
+  int KS;             // ceil(K / 32)
+  int nf;             // output fragments (16 rows) per workgroup slice
+  u32 gpi;            // 128-pixel groups per image
+  u32 groups;         // B * gpi
+  u32 wg_iters;       // (P) iterations of a workgroup (4 groups each)
+};
+
+// 8 consecutive 16-bit elements at p (any 2-byte alignment); lanes with nvalid < 8 read element by element and zero-fill
+template <bool TAIL>
+__device__ __forceinline__ u32x4 pw_load8(const u16* p, int nvalid) {
+  if constexpr (!TAIL) {
+    return *reinterpret_cast<const pw_u32x4_a2*>(p);
+  } else {
+    if (nvalid >= 8) return *reinterpret_cast<const pw_u32x4_a2*>(p);
+    u32 h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = e < nvalid ? (u32)p[e] : 0u;
+    return u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+  }
+}
+template <bool TAIL>
+__device__ __forceinline__ void pw_store8(u16* p, const u32x4 v, int nvalid) {
+  if constexpr (!TAIL) {
+    *reinterpret_cast<pw_u32x4_a2*>(p) = v;
+  } else {
+    if (nvalid >= 8) {
+      *reinterpret_cast<pw_u32x4_a2*>(p) = v;
+      return;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (e < nvalid) p[e] = (u16)((e & 1) ? (v[e >> 1] >> 16) : (v[e >> 1] & 0xffffu));
+  }
+}
+
+// raw[j] = 8 pixels of channel j of the lane's 8 channels  ->  bop[t] = the 8 channels of pixel t (MFMA B operand of pixel set t)
+__device__ __forceinline__ void pw_transpose8(const u32x4 (&raw)[8], u32x4 (&bop)[8]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const u32 lo = raw[2 * q][h], hi = raw[2 * q + 1][h];
+      bop[2 * h][q] = __builtin_amdgcn_perm(hi, lo, 0x05040100u);      // low halves: pixel 2h of channels 2q, 2q + 1
+      bop[2 * h + 1][q] = __builtin_amdgcn_perm(hi, lo, 0x07060302u);  // high halves: pixel 2h + 1
+    }
+  }
+}
+
+// the lane's 8 x 8 block of k-step ks: channels 32 ks + 8 fg + (0..7), pixels px .. px + 7 of image base xb
+template <bool TAIL>
+__device__ __forceinline__ void pw_load_raw(const u16* xb, u32 HW, u32 K, u32 chan0, int nvalid, u32x4 (&raw)[8]) {
+  if (chan0 < K) {  // (K is a multiple of 8: all eight channels or none)
+    const u16* p = xb + (size_t)chan0 * HW;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[j] = pw_load8<TAIL>(p + (size_t)j * HW, nvalid);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[j] = u32x4{0u, 0u, 0u, 0u};
+  }
+}
+
+// A fragment (f, ks) of the slice: lane (fr, fg) holds a[m0 + 16 f + fr][32 ks + 8 fg .. + 7], zero outside the matrix
+__device__ __forceinline__ void pw_stage_a(unsigned char* lds, const u16* a, u32 M, u32 K, u32 m0, u32 nf, u32 ks0, u32 nks,
+                                           u32 tid) {
+  for (u32 i = tid; i < nf * nks * 64u; i += PWT_THREADS) {
+    const u32 l = i & 63u, fk = i >> 6, ks = fk % nks, f = fk / nks;
+    const u32 row = m0 + 16u * f + (l & 15u), k0 = (ks0 + ks) * 32u + (l >> 4) * 8u;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < M && k0 < K) v = *reinterpret_cast<const u32x4*>(a + (size_t)row * K + k0);
+    *reinterpret_cast<u32x4*>(lds + (size_t)i * 16u) = v;
+  }
+}
+
+// finished accumulators of fragment f (rows 4 fg + i of it, pixels 8 fr + t) -> four 16-byte stores
+template <int DT, bool TAIL>
+__device__ __forceinline__ void pw_store_frag(const f32x4 (&acc)[8], u16* yb, u32 HW, u32 M, u32 row0, int nvalid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (row0 + (u32)i < M) {
+      const u32x4 o = {pack2_16<DT>(acc[0][i], acc[1][i]), pack2_16<DT>(acc[2][i], acc[3][i]),
+                       pack2_16<DT>(acc[4][i], acc[5][i]), pack2_16<DT>(acc[6][i], acc[7][i])};
+      pw_store8<TAIL>(yb + (size_t)(row0 + (u32)i) * HW, o, nvalid);
+    }
+  }
+}
+
+// ---- (E) short K (<= 96 channels): the B operands of a 128-pixel group stay in registers, the wave walks over ALL output
+// fragments of the slice.  Expansion layers (16 -> 96 ... 96 -> 576) and the input gradients of the projections. ---------------
+template <int DT, int KS>
+__global__ __launch_bounds__(PWT_THREADS) void pw_gemm_short_kernel(const PwtParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const u32 tid = threadIdx.x, lane = tid & 63u;
+  const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const u32 fr = lane & 15u, fg = lane >> 4;
+  const u32 M = (u32)p.M, K = (u32)p.K, HW = (u32)p.HW;
+  const u32 m0 = blockIdx.y * (u32)(16 * p.nf);
+  const u32 nf = min((u32)p.nf, (M - m0 + 15u) / 16u);
+  pw_stage_a(smem, p.a, M, K, m0, nf, 0u, (u32)KS, tid);
+  __syncthreads();
+  const u32 gstride = gridDim.x * 4u;
+  for (u32 g = blockIdx.x * 4u + wave; g < p.groups; g += gstride) {
+    const u32 b = g / p.gpi, p0 = (g - b * p.gpi) * 128u + 8u * fr;
+    const bool tail = (g - b * p.gpi) * 128u + 128u > HW;  // wave-uniform
+    const int nvalid = (int)HW - (int)p0;
+    const u16* xb = p.x + (size_t)b * K * HW + p0;
+    u16* yb = p.y + (size_t)b * M * HW + p0;
+    u32x4 bop[KS][8];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 raw[8];
+      if (tail) pw_load_raw<true>(xb, HW, K, (u32)ks * 32u + fg * 8u, nvalid, raw);
+      else pw_load_raw<false>(xb, HW, K, (u32)ks * 32u + fg * 8u, 8, raw);
+      pw_transpose8(raw, bop[ks]);
+    }
+    for (u32 f = 0; f < nf; ++f) {
+      f32x4 acc[8];
+      const u32 row0 = m0 + 16u * f + 4u * fg;
+      f32x4 init = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) init[i] = row0 + (u32)i < M ? p.bias[row0 + (u32)i] : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = init;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const u32x4 wa = *reinterpret_cast<const u32x4*>(smem + ((size_t)(f * (u32)KS + (u32)ks) * 64u + lane) * 16u);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = mfma16<DT>(wa, bop[ks][t], acc[t]);
+      }
+      if (tail) pw_store_frag<DT, true>(acc, yb, HW, M, row0, nvalid);
+      else pw_store_frag<DT, false>(acc, yb, HW, M, row0, 8);
+    }
+  }
+}
+
+// ---- (P) long K: NF output fragments x 8 pixel sets of accumulators per wave, k-steps outermost, the weights of the slice
+// staged in chunks of PWT_KC k-steps (a workgroup's four waves walk through the chunks together).  Projection layers
+// (96 ... 960 -> 16 ... 320) and the input gradients of the expansions. -------------------------------------------------------
+template <int DT, int NF>
+__global__ __launch_bounds__(PWT_THREADS) void pw_gemm_long_kernel(const PwtParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const u32 tid = threadIdx.x, lane = tid & 63u;
+  const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const u32 fr = lane & 15u, fg = lane >> 4;
+  const u32 M = (u32)p.M, K = (u32)p.K, HW = (u32)p.HW, KS = (u32)p.KS;
+  const u32 m0 = blockIdx.y * (u32)(16 * NF);
+  const bool one_chunk = KS <= (u32)PWT_KC;
+  if (one_chunk) {
+    pw_stage_a(smem, p.a, M, K, m0, (u32)NF, 0u, KS, tid);
+    __syncthreads();
+  }
+  for (u32 it = blockIdx.x; it < p.wg_iters; it += gridDim.x) {
+    const u32 g = it * 4u + wave;
+    const bool live = g < p.groups;  // wave-uniform; a dead wave still stages and meets the barriers
+    const u32 gg = live ? g : p.groups - 1u;
+    const u32 b = gg / p.gpi, p0 = (gg - b * p.gpi) * 128u + 8u * fr;
+    const bool tail = (gg - b * p.gpi) * 128u + 128u > HW;
+    const int nvalid = (int)HW - (int)p0;
+    const u16* xb = p.x + (size_t)b * K * HW + p0;
+    u16* yb = p.y + (size_t)b * M * HW + p0;
+    f32x4 acc[NF][8];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const u32 row0 = m0 + 16u * (u32)f + 4u * fg;
+      f32x4 init = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) init[i] = row0 + (u32)i < M ? p.bias[row0 + (u32)i] : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[f][t] = init;
+    }
+    u32x4 raw[8];
+    if (tail) pw_load_raw<true>(xb, HW, K, fg * 8u, nvalid, raw);
+    else pw_load_raw<false>(xb, HW, K, fg * 8u, 8, raw);
+    for (u32 c0 = 0; c0 < KS; c0 += (u32)PWT_KC) {
+      const u32 nks = min((u32)PWT_KC, KS - c0);
+      if (!one_chunk) {
+        __syncthreads();  // every wave is done with the previous chunk's fragments
+        pw_stage_a(smem, p.a, M, K, m0, (u32)NF, c0, nks, tid);
+        __syncthreads();
+      }
+      for (u32 ks = 0; ks < nks; ++ks) {
+        u32x4 bop[8];
+        pw_transpose8(raw, bop);
+        const u32 kn = c0 + ks + 1u;
+        if (kn < KS) {  // the next k-step's block travels under this one's MFMAs
+          if (tail) pw_load_raw<true>(xb, HW, K, kn * 32u + fg * 8u, nvalid, raw);
+          else pw_load_raw<false>(xb, HW, K, kn * 32u + fg * 8u, 8, raw);
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const u32x4 wa = *reinterpret_cast<const u32x4*>(smem + ((size_t)((u32)f * nks + ks) * 64u + lane) * 16u);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) acc[f][t] = mfma16<DT>(wa, bop[t], acc[f][t]);
+        }
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const u32 row0 = m0 + 16u * (u32)f + 4u * fg;
+        if (tail) pw_store_frag<DT, true>(acc[f], yb, HW, M, row0, nvalid);
+        else pw_store_frag<DT, false>(acc[f], yb, HW, M, row0, 8);
+      }
+    }
+  }
+}
+
+static int pw_gemm_launch(const void* x, const void* a, const float* bias, void* y, int B, int K, int M, int HW, int dtype,
+                          hipStream_t stream) {
+  PwtParams p;
+  p.x = (const u16*)x;
+  p.a = (const u16*)a;
+  p.bias = bias;
+  p.y = (u16*)y;
+  p.B = B;
+  p.K = K;
+  p.M = M;
+  p.HW = HW;
+  p.KS = (K + 31) / 32;
+  p.gpi = (u32)((HW + 127) / 128);
+  p.groups = (u32)B * p.gpi;
+  p.wg_iters = (p.groups + 3u) / 4u;
+  const int mf = (M + 15) / 16;
+  static const int force_long = getenv("SSDK_PW_LONG") ? atoi(getenv("SSDK_PW_LONG")) : 0;
+  if (p.KS <= 3 && !force_long) {
+    // slice: all output fragments if their A fragments fit 64 KiB, else equal slices
+    int slices = (mf * p.KS + 63) / 64;
+    p.nf = (mf + slices - 1) / slices;
+    slices = (mf + p.nf - 1) / p.nf;
+    const size_t lds = (size_t)p.nf * p.KS * 1024;
+    unsigned gx = (unsigned)(256 * 4 / slices);  // ~4 workgroups per CU over all slices
+    if (gx < 1u) gx = 1u;
+    if (gx > p.wg_iters) gx = p.wg_iters;
+    const dim3 grid(gx, (unsigned)slices);
+#define SSDK_PWS(DT, KS_)                                                                                              \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_short_kernel<DT, KS_>),                          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
+    hipLaunchKernelGGL((pw_gemm_short_kernel<DT, KS_>), grid, dim3(PWT_THREADS), lds, stream, p);                     \
+  } while (0)
+#define SSDK_PWSD(DT)                    \
+  do {                                   \
+    if (p.KS == 1) SSDK_PWS(DT, 1);      \
+    else if (p.KS == 2) SSDK_PWS(DT, 2); \
+    else SSDK_PWS(DT, 3);                \
+  } while (0)
+    if (dtype == SSDK_BF16) SSDK_PWSD(SSDK_BF16);
+    else SSDK_PWSD(SSDK_F16);
+#undef SSDK_PWSD
+#undef SSDK_PWS
+    return check_launch("pw_gemm_short_kernel");
+  }
+  // long K: NF fragments per slice, equal slices
+  int slices = (mf + 3) / 4;
+  int nf = (mf + slices - 1) / slices;
+  slices = (mf + nf - 1) / nf;
+  p.nf = nf;
+  const int nks = p.KS < PWT_KC ? p.KS : PWT_KC;
+  const size_t lds = (size_t)nf * nks * 1024;
+  unsigned gx = (unsigned)(256 * 3 / slices);
+  if (gx < 1u) gx = 1u;
+  if (gx > p.wg_iters) gx = p.wg_iters;
+  const dim3 grid(gx, (unsigned)slices);
+#define SSDK_PWL(DT, NF_)                                                                                             \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_long_kernel<DT, NF_>),                           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
+    hipLaunchKernelGGL((pw_gemm_long_kernel<DT, NF_>), grid, dim3(PWT_THREADS), lds, stream, p);                      \
+  } while (0)
+#define SSDK_PWLD(DT)                   \
+  do {                                  \
+    if (nf == 1) SSDK_PWL(DT, 1);       \
+    else if (nf == 2) SSDK_PWL(DT, 2);  \
+    else if (nf == 3) SSDK_PWL(DT, 3);  \
+    else SSDK_PWL(DT, 4);               \
+  } while (0)
+  if (dtype == SSDK_BF16) SSDK_PWLD(SSDK_BF16);
+  else SSDK_PWLD(SSDK_F16);
+#undef SSDK_PWLD
+#undef SSDK_PWL
+  return check_launch("pw_gemm_long_kernel");
+}
+
+// ---- weight gradient ------------------------------------------------------------------------------------------------------
+struct PwgParams {
+  const u16* dy;  // [B, Cout, HW]
+  const u16* x;   // [B, Cin, HW]
+  float* ws;      // [S][Cout][Cin] fp32 partials
+  int B, Cout, Cin, HW;
+  u32 cpi;        // 128-pixel chunks per image
+  u32 chunks;     // B * cpi
+  u32 mt, nt;     // tiles of the [Cout, Cin] matrix
+  u32 splits;     // pixel ranges
+  u32 cps;        // chunks per split
+};
+
+template <int DT, int MFW, int NFW>
+__global__ __launch_bounds__(PWT_THREADS) void pw_wgrad_kernel(const PwgParams p) {
+  const u32 tid = threadIdx.x, lane = tid & 63u;
+  const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const u32 fr = lane & 15u, fg = lane >> 4;
+  const u32 tiles = p.mt * p.nt;
+  const u32 item = blockIdx.x * 4u + wave;
+  if (item >= tiles * p.splits) return;
+  const u32 tile = item % tiles, s = item / tiles;
+  const u32 m0 = (tile / p.nt) * (u32)(16 * MFW), n0 = (tile % p.nt) * (u32)(16 * NFW);
+  const u32 Cout = (u32)p.Cout, Cin = (u32)p.Cin, HW = (u32)p.HW;
+  f32x4 acc[MFW][NFW];
+#pragma unroll
+  for (int i = 0; i < MFW; ++i)
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32 c_end = min(p.chunks, (s + 1u) * p.cps);
+  for (u32 c = s * p.cps; c < c_end; ++c) {
+    const u32 b = c / p.cpi, p0 = (c - b * p.cpi) * 128u + 32u * fg;
+    const bool tail = (c - b * p.cpi) * 128u + 128u > HW;  // wave-uniform
+    u32x4 av[MFW][4], bv[NFW][4];
+#pragma unroll
+    for (int i = 0; i < MFW; ++i) {
+      const u32 row = m0 + 16u * (u32)i + fr;
+      const u16* src = p.dy + ((size_t)b * Cout + row) * HW + p0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (row < Cout) av[i][u] = tail ? pw_load8<true>(src + 8 * u, (int)HW - (int)p0 - 8 * u) : pw_load8<false>(src + 8 * u, 8);
+        else av[i][u] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) {
+      const u32 row = n0 + 16u * (u32)j + fr;
+      const u16* src = p.x + ((size_t)b * Cin + row) * HW + p0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (row < Cin) bv[j][u] = tail ? pw_load8<true>(src + 8 * u, (int)HW - (int)p0 - 8 * u) : pw_load8<false>(src + 8 * u, 8);
+        else bv[j][u] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < MFW; ++i)
+#pragma unroll
+        for (int j = 0; j < NFW; ++j) acc[i][j] = mfma16<DT>(av[i][u], bv[j][u], acc[i][j]);
+  }
+  // partial tile -> workspace: D[row 4 fg + r of fragment i][column fr of fragment j]
+  float* ws = p.ws + (size_t)s * Cout * Cin;
+#pragma unroll
+  for (int i = 0; i < MFW; ++i)
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) {
+      const u32 ci = n0 + 16u * (u32)j + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const u32 co = m0 + 16u * (u32)i + 4u * fg + (u32)r;
+        if (co < Cout && ci < Cin) ws[(size_t)co * Cin + ci] = acc[i][j][r];
+      }
+    }
+}
+
+// rows [by * 64, by * 64 + 64) of a [rows][n] fp32 matrix summed per element in a FIXED order: thread (element, quarter kq) adds its
+// 16 rows one after the other (sixteen independent coalesced loads), the four quarters are added in order 0..3.  Applied until one
+// row is left (<= 4096 partials: two passes).  (As first written ONE thread per element walked all <= 2048 partials: 6 workgroups,
+// 4.4 ms per training step in 34 launches.)
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* in, float* out, u32 n, u32 rows) {
+  __shared__ float part[4][64];
+  const u32 el = threadIdx.x & 63u, kq = threadIdx.x >> 6;
+  const u32 i = blockIdx.x * 64u + el, r0 = blockIdx.y * 64u + kq * 16u;
+  float v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = (i < n && r0 + (u32)k < rows) ? in[(size_t)(r0 + (u32)k) * n + i] : 0.f;
+  float s = v[0];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) s += v[k];
+  part[kq][el] = s;
+  __syncthreads();
+  if (kq == 0 && i < n) out[(size_t)blockIdx.y * n + i] = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
+}
+
+static void pw_wgrad_plan(int B, int Cout, int Cin, int HW, PwgParams* p, int* mfw, int* nfw) {
+  const int mf = (Cout + 15) / 16, nf = (Cin + 15) / 16;
+  // wave tile: 3 x 2 fragments (20 vectors of 16 bytes in flight per lane), 3 x 1 for narrow inputs
+  *mfw = mf >= 3 ? 3 : mf;
+  *nfw = nf >= 2 ? 2 : 1;
+  p->mt = (u32)((mf + *mfw - 1) / *mfw);
+  p->nt = (u32)((nf + *nfw - 1) / *nfw);
+  p->cpi = (u32)((HW + 127) / 128);
+  p->chunks = (u32)B * p->cpi;
+  const u32 tiles = p->mt * p->nt;
+  u32 splits = 4096u / tiles;  // ~16 waves per CU
+  if (splits < 1u) splits = 1u;
+  if (splits > p->chunks) splits = p->chunks;
+  p->cps = (p->chunks + splits - 1u) / splits;
+  p->splits = (p->chunks + p->cps - 1u) / p->cps;
+}
+
+}  // namespace ssdk
+
+using namespace ssdk;
+
+static int pw_check(const void* a, const void* b, const void* c, int B, int K, int M, int HW, int dtype, const char* what) {
+  if (!a || !b || !c || B < 1 || K < 8 || M < 1 || HW < 1 || (K % 8) || (dtype != SSDK_BF16 && dtype != SSDK_F16)) {
+    set_error("%s: bad argument (16-bit tensors, input channels a multiple of 8)", what);
+    return SSDK_E_BADARG;
+  }
+  if ((size_t)B * (size_t)(K > M ? K : M) * (size_t)HW >= ((size_t)1 << 32)) {
+    set_error("%s: tensor too large", what);
+    return SSDK_E_BADARG;
+  }
+  return SSDK_OK;
+}
+
+extern "C" int ssdk_pw_forward(const void* x, const void* a, const float* bias, void* y, int B, int K, int M, int HW, int dtype,
+                               void* stream) {
+  int rc = pw_check(x, a, y, B, K, M, HW, dtype, "ssdk_pw_forward");
+  if (rc) return rc;
+  if (((uintptr_t)a) & 15) {
+    set_error("ssdk_pw_forward: the weight matrix must be 16-byte aligned");
+    return SSDK_E_BADARG;
+  }
+  return pw_gemm_launch(x, a, bias, y, B, K, M, HW, dtype, (hipStream_t)stream);
+}
+
+extern "C" size_t ssdk_pw_wgrad_workspace_bytes(int B, int Cout, int Cin, int HW) {
+  if (B < 1 || Cout < 1 || Cin < 1 || HW < 1) return 0;
+  PwgParams p;
+  int mfw, nfw;
+  pw_wgrad_plan(B, Cout, Cin, HW, &p, &mfw, &nfw);
+  return ((size_t)p.splits + (size_t)((p.splits + 63u) / 64u)) * (size_t)Cout * (size_t)Cin * sizeof(float);
+}
+
+extern "C" int ssdk_pw_wgrad(const void* dy, const void* x, float* dw, void* ws, size_t ws_bytes, int B, int Cout, int Cin, int HW,
+                             int dtype, void* stream) {
+  if (!dy || !x || !dw || !ws || B < 1 || Cout < 1 || Cin < 1 || HW < 1 || (dtype != SSDK_BF16 && dtype != SSDK_F16)) {
+    set_error("ssdk_pw_wgrad: bad argument");
+    return SSDK_E_BADARG;
+  }
+  if ((size_t)B * (size_t)(Cout > Cin ? Cout : Cin) * (size_t)HW >= ((size_t)1 << 32)) {
+    set_error("ssdk_pw_wgrad: tensor too large");
+    return SSDK_E_BADARG;
+  }
+  PwgParams p;
+  int mfw, nfw;
+  pw_wgrad_plan(B, Cout, Cin, HW, &p, &mfw, &nfw);
+  if (ws_bytes < ((size_t)p.splits + (size_t)((p.splits + 63u) / 64u)) * (size_t)Cout * (size_t)Cin * sizeof(float)) {
+    set_error("ssdk_pw_wgrad: workspace too small");
+    return SSDK_E_WORKSPACE;
+  }
+  p.dy = (const u16*)dy;
+  p.x = (const u16*)x;
+  p.ws = (float*)ws;
+  p.B = B;
+  p.Cout = Cout;
+  p.Cin = Cin;
+  p.HW = HW;
+  const u32 items = p.mt * p.nt * p.splits;
+  const dim3 grid((items + 3u) / 4u);
+  hipStream_t st = (hipStream_t)stream;
+#define SSDK_PWG(DT, MF_, NF_) hipLaunchKernelGGL((pw_wgrad_kernel<DT, MF_, NF_>), grid, dim3(PWT_THREADS), 0, st, p)
+#define SSDK_PWGD(DT)                                  \
+  do {                                                 \
+    if (mfw == 3 && nfw == 2) SSDK_PWG(DT, 3, 2);      \
+    else if (mfw == 3) SSDK_PWG(DT, 3, 1);             \
+    else if (mfw == 2 && nfw == 2) SSDK_PWG(DT, 2, 2); \
+    else if (mfw == 2) SSDK_PWG(DT, 2, 1);             \
+    else if (nfw == 2) SSDK_PWG(DT, 1, 2);             \
+    else SSDK_PWG(DT, 1, 1);                           \
+  } while (0)
+  if (dtype == SSDK_BF16) SSDK_PWGD(SSDK_BF16);
+  else SSDK_PWGD(SSDK_F16);
+#undef SSDK_PWGD
+#undef SSDK_PWG
+  int rc = check_launch("pw_wgrad_kernel");
+  if (rc) return rc;
+  const u32 n = (u32)Cout * (u32)Cin;
+  const float* src = (const float*)ws;
+  float* mid = (float*)ws + (size_t)p.splits * n;  // second-level rows behind the partials
+  u32 rows = p.splits;
+  while (true) {
+    const u32 out_rows = (rows + 63u) / 64u;
+    float* dst = out_rows == 1u ? dw : mid;
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((n + 63u) / 64u, out_rows), dim3(256), 0, st, src, dst, n, rows);
+    if (out_rows == 1u) break;
+    src = mid;  // (<= 4096 partials: the second pass is the last one; a third would need another buffer)
+    rows = out_rows;
+    if (rows > 64u) {
+      set_error("ssdk_pw_wgrad: more than 4096 partial tiles");
+      return SSDK_E_BADARG;
+    }
+  }
+  return check_launch("pw_wgrad_reduce_kernel");
+}
+
+// w32 [Cout, Cin] fp32 (the master weights) -> w16 [Cout, Cin] and wt16 [Cin, Cout] in the compute dtype: the cast autocast
+// would launch anyway, plus the transposed copy the input gradient reads as ITS row-major matrix.
+namespace ssdk {
+template <int DT>
+__global__ __launch_bounds__(256) void pw_prepare_kernel(const float* w32, u16* w16, u16* wt16, u32 cout, u32 cin) {
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= cout * cin) return;
+  const u32 co = i / cin, ci = i - co * cin;
+  const u16 v = (u16)f32_to_bits16<DT>(w32[i]);
+  w16[i] = v;
+  wt16[(size_t)ci * cout + co] = v;
+}
+}  // namespace ssdk
+
+extern "C" int ssdk_pw_prepare(const float* w32, void* w16, void* wt16, int Cout, int Cin, int dtype, void* stream) {
+  if (!w32 || !w16 || !wt16 || Cout < 1 || Cin < 1 || (dtype != SSDK_BF16 && dtype != SSDK_F16)) {
+    set_error("ssdk_pw_prepare: bad argument");
+    return SSDK_E_BADARG;
+  }
+  const u32 n = (u32)Cout * (u32)Cin;
+  if (dtype == SSDK_BF16)
+    hipLaunchKernelGGL(pw_prepare_kernel<SSDK_BF16>, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, w32, (u16*)w16,
+                       (u16*)wt16, (u32)Cout, (u32)Cin);
+  else
+    hipLaunchKernelGGL(pw_prepare_kernel<SSDK_F16>, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, w32, (u16*)w16,
+                       (u16*)wt16, (u32)Cout, (u32)Cin);
+  return check_launch("pw_prepare_kernel");
+}

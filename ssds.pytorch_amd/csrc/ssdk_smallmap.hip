@@ -31,14 +31,25 @@ __host__ __device__ constexpr int sm_pad(int stride) { return stride == 1 ? 32 :
 // pixels sit two input columns / two input rows apart; the LDS image skews every second input row by one row slot
 // (row index iy * W + ix + (iy >> 1)) so that the sixteen 16-byte reads of a fragment still fall into sixteen different
 // bank groups (row stride = an odd number of 16-byte chunks; without the skew output rows oy and oy + 1 collide).
-template <int DT, int CS, int MFR, int TAPS, bool PK, int NA, int S>
+// KW (round 6): wave GROUPS per workgroup that split K between them (1 | 2): group kg takes the 32-channel slices
+// sl = kg (mod KW) of every tap, i.e. every KW-th KiB of the fragment-major image and the LDS columns 64 kg (mod 64 KW) -- a
+// pointer offset and a row-offset bias, every other address stays an immediate.  The layer is a chain of dependent latencies
+// (L2 weight fragment -> MFMA) at ONE wave per SIMD: the 8x8 level streamed 1.18 MB of weights per workgroup through four such
+// chains in 29 us, for 7.7 us of matrix work (Weak 5).  With KW = 2 a SIMD holds two waves, each walking half
+// the k-steps; the partial accumulators of group 1 meet group 0's through LDS once at the end (fp32, group 0 + group 1: a fixed
+// order).
+template <int DT, int CS, int MFR, int TAPS, bool PK, int NA, int S, int KW = 1>
 __device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx, const u32 by) {
   static_assert(NA == 1 || PK, "two channel fragments per wave read the fragment-major image");
   static_assert(S == 1 || TAPS == 9, "stride 2 visits all taps");
+  static_assert(KW == 1 || (PK && CS % (2 * KW) == 0), "the K split walks the fragment-major image");
+  constexpr int CSL = CS / KW;  // slices per wave group
   constexpr int ROWS = 16 * MFR;
   constexpr int TAP0 = TAPS == 9 ? 0 : 4;  // first tap visited
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const u32 tid = threadIdx.x, lane = tid & 63u, wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const u32 tid = threadIdx.x, lane = tid & 63u, wave_all = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const u32 nwc = (u32)(blockDim.x >> 6) / (u32)KW;  // channel waves per workgroup
+  const u32 wave = KW == 1 ? wave_all : wave_all % nwc, kg = KW == 1 ? 0u : wave_all / nwc;
   const u32 fr = lane & 15u, fg = lane >> 4;
   const int P = p.Ho * p.Wo, G = ROWS / P, Cin = p.Cin;  // output pixels per image, images per workgroup
   const int PI = p.H * p.W;                                 // input pixels per image (== P for stride 1)
@@ -52,10 +63,10 @@ __device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx,
   const u16* x = (const u16*)p.x;
 
   // ---- the weight stream starts first: it does not depend on the maps -----------------------------------------------
-  const int co_row0 = ((int)by * (int)(blockDim.x >> 6) + (int)wave) * 16 * NA;  // 1, 2 or 4 waves per workgroup
+  const int co_row0 = ((int)by * (int)nwc + (int)wave) * 16 * NA;  // 1, 2 or 4 channel waves per workgroup
   int co_a = co_row0 + (int)fr;
   co_a = co_a < p.Cout ? co_a : p.Cout - 1;  // rows past Cout: computed on a valid row, never stored
-  const u16* wrow = PK ? (const u16*)p.w_frag + (size_t)(co_row0 < p.Cout ? co_row0 >> 4 : (p.Cout - 1) >> 4) * 9 * Cin * 16 + lane * 8
+  const u16* wrow = PK ? (const u16*)p.w_frag + (size_t)(co_row0 < p.Cout ? co_row0 >> 4 : (p.Cout - 1) >> 4) * 9 * Cin * 16 + lane * 8 + kg * 512u
                        : (const u16*)p.w + (size_t)co_a * 9 * Cin + fg * 8;
   static_assert(CS % 2 == 0, "even number of slices");
   // k-loop (static: the row offsets are plain registers).  Weight
@@ -66,10 +77,10 @@ __device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx,
   // Order of the k-steps.  PK: taps outside, slices inside = the order of the packed image, consecutive KiB.  KRSC: slice
   // PAIRS outside, taps inside, the two slices of a pair innermost -- the two 64-byte halves of a weight row's 128-byte line
   // are then fetched by neighbouring loads.
-  constexpr int RING = 2 * TAPS;  // register stages = k-steps in flight
+  constexpr int RING = KW == 1 ? 2 * TAPS : (TAPS == 9 ? 9 : 2);  // register stages = k-steps in flight (two waves per SIMD: half)
   u32x4 rw[RING][NA];
-  auto kmap = [](int st, int& t, int& sl) {
-    if (PK) { t = st / CS; sl = st % CS; return; }
+  auto kmap = [](int st, int& t, int& sl) {  // sl: the wave group's slice number times KW (+ kg: in the pointers)
+    if (PK) { t = st / CSL; sl = (st % CSL) * KW; return; }
     if (TAPS == 1) { t = 0; sl = st; return; }
     const int sp = st / RING, in = st % RING;
     t = in >> 1;
@@ -77,7 +88,7 @@ __device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx,
   };
   auto issue = [&](int st) {
     int t, sl;
-    kmap(st < CS * TAPS ? st : CS * TAPS - 1, t, sl);  // past the end: a harmless re-read
+    kmap(st < CSL * TAPS ? st : CSL * TAPS - 1, t, sl);  // past the end: a harmless re-read
 #pragma unroll
     for (int a = 0; a < NA; ++a) {  // (fragment a of this wave: the next 16-row group of the image, clamped like the first)
       const size_t ga = (a && co_row0 + 16 * a < p.Cout) ? (size_t)a * 9 * Cin * 16 : 0;
@@ -138,7 +149,7 @@ __device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx,
     for (int t = 0; t < TAPS; ++t) {
       const int iy = oy * S - 1 + (t + TAP0) / 3, ix = ox * S - 1 + (t + TAP0) % 3;
       const bool ok = g < G && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;  // (g >= G: a pixel slot past the
-      rowoff[m][t] = (u32)((ok ? g * PL + iy * p.W + ix + (S == 2 ? iy >> 1 : 0) : ZROW) * RS) + fg * 16u;  // workgroup's images: 64 % P != 0)
+      rowoff[m][t] = (u32)((ok ? g * PL + iy * p.W + ix + (S == 2 ? iy >> 1 : 0) : ZROW) * RS) + fg * 16u + kg * 64u;  // workgroup's images: 64 % P != 0)
     }
   }
   __syncthreads();
@@ -152,7 +163,7 @@ __device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx,
   // first written every MFMA waited for a ds_read issued one or two instructions before it -- s_waitcnt lgkmcnt(1) in front
   // of each of the four MFMAs of a k-step: ~660 cycles per k-step for 64 cycles of matrix work, the whole kernel ran at the
   // LDS latency of one wave per SIMD.)
-  constexpr int NS = CS * TAPS;  // k-steps: 32-channel slices outside, taps inside
+  constexpr int NS = CSL * TAPS;  // k-steps of this wave group
   constexpr int D = 2;           // B-fragment prefetch distance
   u32x4 bq[D + 1][MFR];
   auto lds_issue = [&](int slot, int step) {
@@ -174,6 +185,27 @@ __device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx,
     __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks every load down to its use, 18 k-steps later)
   }
 
+  if constexpr (KW > 1) {  // the wave groups' partial sums meet in LDS behind the maps: group 0 adds groups 1.. in order
+    unsigned char* red = smem + (((size_t)(ZROW + 1) * RS + 15) & ~(size_t)15);
+    if (kg > 0) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int m = 0; m < MFR; ++m)
+          *reinterpret_cast<f32x4*>(red + ((((size_t)(kg - 1) * nwc + wave) * NA + a) * MFR + m) * 1024 + lane * 16) = acc[a][m];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int g2 = 1; g2 < KW; ++g2)
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int m = 0; m < MFR; ++m) {
+          const f32x4 o = *reinterpret_cast<const f32x4*>(red + ((((size_t)(g2 - 1) * nwc + wave) * NA + a) * MFR + m) * 1024 + lane * 16);
+          acc[a][m] += o;
+        }
+  }
   // ---- epilogue: lane = (pixel fr of fragment m, channels co0 + 4fg .. +3) -----------------------------------------
   const bool nchw = p.out_layout == LAYOUT_NCHW;
 #pragma unroll
@@ -202,9 +234,9 @@ __device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx,
     }
 }
 
-template <int DT, int CS, int MFR, int TAPS, bool PK, int NA, int S>
-__global__ __launch_bounds__(kSmThreads) void conv_smallmap_kernel(const ConvParams p) {
-  smallmap_body<DT, CS, MFR, TAPS, PK, NA, S>(p, blockIdx.x, blockIdx.y);
+template <int DT, int CS, int MFR, int TAPS, bool PK, int NA, int S, int KW = 1>
+__global__ __launch_bounds__(kSmThreads * KW) void conv_smallmap_kernel(const ConvParams p) {
+  smallmap_body<DT, CS, MFR, TAPS, PK, NA, S, KW>(p, blockIdx.x, blockIdx.y);
 }
 
 // Several independent small-map layers in ONE launch (the multibox heads of the 4x4 / 2x2 / 1x1 levels: 128 + 32 + 8
@@ -219,20 +251,20 @@ struct SmallmapGroup {
   int code[kSmallmapGroupMax];            // 2 * log2(Cin / 128) + (1x1 map)
   int n;
 };
-template <int DT>
-__global__ __launch_bounds__(kSmThreads) void conv_smallmap_group_kernel(const SmallmapGroup g) {
+template <int DT, int KW>
+__global__ __launch_bounds__(kSmThreads * KW) void conv_smallmap_group_kernel(const SmallmapGroup g) {
   int m = 0;
   for (int i = 1; i < g.n; ++i)
     if (blockIdx.x >= g.start[i]) m = i;
   const u32 local = blockIdx.x - g.start[m], bx = local % g.gx[m], by = local / g.gx[m];
   const ConvParams& p = g.p[m];
   switch (g.code[m]) {
-    case 0: smallmap_body<DT, 4, 4, 9, true, 1, 1>(p, bx, by); break;
-    case 1: smallmap_body<DT, 4, 4, 1, true, 1, 1>(p, bx, by); break;
-    case 2: smallmap_body<DT, 8, 4, 9, true, 1, 1>(p, bx, by); break;
-    case 3: smallmap_body<DT, 8, 4, 1, true, 1, 1>(p, bx, by); break;
-    case 4: smallmap_body<DT, 16, 4, 9, true, 1, 1>(p, bx, by); break;
-    default: smallmap_body<DT, 16, 4, 1, true, 1, 1>(p, bx, by); break;
+    case 0: smallmap_body<DT, 4, 4, 9, true, 1, 1, KW>(p, bx, by); break;
+    case 1: smallmap_body<DT, 4, 4, 1, true, 1, 1, KW>(p, bx, by); break;
+    case 2: smallmap_body<DT, 8, 4, 9, true, 1, 1, KW>(p, bx, by); break;
+    case 3: smallmap_body<DT, 8, 4, 1, true, 1, 1, KW>(p, bx, by); break;
+    case 4: smallmap_body<DT, 16, 4, 9, true, 1, 1, KW>(p, bx, by); break;
+    default: smallmap_body<DT, 16, 4, 1, true, 1, 1, KW>(p, bx, by); break;
   }
 }
 
@@ -271,13 +303,23 @@ int launch_conv_smallmap_group(const ConvParams* ps, int n, int dtype, hipStream
     lds = l > lds ? l : lds;
   }
   g.start[n] = total;
+  static const int env_kw = getenv("SSDK_CONV_SMALLMAP_KW") ? atoi(getenv("SSDK_CONV_SMALLMAP_KW")) : 2;
+  const int kw = env_kw == 2 ? 2 : 1;
+  lds = ((lds + 15) & ~(size_t)15) + (size_t)(kw - 1) * 4 * 4 * 1024;  // + the partial sums of wave group 1 (4 waves x 4 fragments)
+#define SSDK_SMG(DT, KW_)                                                                                                    \
+  do {                                                                                                                       \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_group_kernel<DT, KW_>),                           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
+    hipLaunchKernelGGL((conv_smallmap_group_kernel<DT, KW_>), dim3(total), dim3(kSmThreads * KW_), lds, stream, g);          \
+  } while (0)
   if (dtype == SSDK_BF16) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_group_kernel<SSDK_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((conv_smallmap_group_kernel<SSDK_BF16>), dim3(total), dim3(kSmThreads), lds, stream, g);
+    if (kw == 2) SSDK_SMG(SSDK_BF16, 2);
+    else SSDK_SMG(SSDK_BF16, 1);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_group_kernel<SSDK_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((conv_smallmap_group_kernel<SSDK_F16>), dim3(total), dim3(kSmThreads), lds, stream, g);
+    if (kw == 2) SSDK_SMG(SSDK_F16, 2);
+    else SSDK_SMG(SSDK_F16, 1);
   }
+#undef SSDK_SMG
   return 0;
 }
 
@@ -313,13 +355,23 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   static const int env_nw = getenv("SSDK_CONV_SMALLMAP_NW") ? atoi(getenv("SSDK_CONV_SMALLMAP_NW")) : 4;
   const int nw = env_nw == 1 || env_nw == 2 ? env_nw : 4;  // (fewer waves per workgroup = more workgroups: measured slower on every level)
   const dim3 grid((unsigned)groups, (unsigned)((nfr + nw - 1) / nw));
-  const size_t lds = s2 ? (size_t)(G * (p.H * p.W + p.H / 2) + 1) * (p.Cin * 2 + 32) : (size_t)(16 * mfr + 1) * (p.Cin * 2 + 32);
+  size_t lds = s2 ? (size_t)(G * (p.H * p.W + p.H / 2) + 1) * (p.Cin * 2 + 32) : (size_t)(16 * mfr + 1) * (p.Cin * 2 + 32);
   const int cs = p.Cin / 32;
+  // K split over two wave groups (smallmap_body, KW): the weight-bound instance of the 8x8 level (na == 2, stride 1, 4 waves)
+  static const int env_kw = getenv("SSDK_CONV_SMALLMAP_KW") ? atoi(getenv("SSDK_CONV_SMALLMAP_KW")) : 2;
+  const int kw = (env_kw == 2 && na == 2 && !s2 && nw == 4 && P > 1) ? 2 : 1;
+  if (kw == 2) lds = ((lds + 15) & ~(size_t)15) + (size_t)nw * na * mfr * 1024;
 #define SSDK_SMS(DT, CS_, MFR_, TAPS_, PK_, NA_, S_)                                                                       \
   do {                                                                                                                     \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_, MFR_, TAPS_, PK_, NA_, S_>),   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
     hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_, MFR_, TAPS_, PK_, NA_, S_>), grid, dim3(64 * nw), lds, stream, p);   \
+  } while (0)
+#define SSDK_SMK2(DT, CS_)                                                                                                 \
+  do {                                                                                                                     \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_, 4, 9, true, 2, 1, 2>),          \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
+    hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_, 4, 9, true, 2, 1, 2>), grid, dim3(64 * nw * 2), lds, stream, p);     \
   } while (0)
 #define SSDK_SM0(DT, CS_, MFR_, TAPS_, PK_, NA_) SSDK_SMS(DT, CS_, MFR_, TAPS_, PK_, NA_, 1)
 #define SSDK_SM1(DT, CS_, MFR_, TAPS_)                  \
@@ -331,6 +383,7 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   do {                                           \
     if (s2) SSDK_SMS(DT, CS_, 4, 9, true, 2, 2); \
     else if (P == 1) SSDK_SM1(DT, CS_, 4, 1);    \
+    else if (na == 2 && kw == 2) SSDK_SMK2(DT, CS_);    \
     else if (na == 2) SSDK_SM0(DT, CS_, 4, 9, true, 2); \
     else if (mfr == 8) SSDK_SM1(DT, CS_, 8, 9);  \
     else SSDK_SM1(DT, CS_, 4, 9);                \
@@ -347,6 +400,7 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
 #undef SSDK_SM
 #undef SSDK_SM1
 #undef SSDK_SM0
+#undef SSDK_SMK2
 #undef SSDK_SMS
   return 0;
 }

@@ -1,4 +1,6 @@
-"""1x1 convolutions of the training step as plain batched GEMMs on the NCHW tensors themselves.
+"""1x1 convolutions of the training step on the NCHW tensors themselves: hand-written matrix-core kernels for 16-bit tensors
+(round 6: csrc/ssdk_pwtrain.hip -- forward, input gradient, weight gradient; no library GEMM in the bf16 / fp16 step), plain
+batched library GEMMs for fp32 tensors.
 
 PyTorch-ROCm sends ``nn.Conv2d(k=1)`` in bf16 to MIOpen, which runs NHWC implicit-GEMM kernels between
 ``batched_transpose_*`` layout changes (10 of the 27 ms of kernel time of the reference's DDP step on SSD-MobileNetV2,
@@ -13,8 +15,12 @@ i.e. three strided-batched library GEMMs (rocBLAS / hipBLASLt through ``torch.ma
 the tensors the neighbouring kernels already produce.  ``PointwiseConv2d`` is an ``nn.Conv2d`` (same parameters,
 ``state_dict`` keys and initialisation); CPU tensors, channels-last tensors and anything that is not a dense 1x1 /
 stride 1 / pad 0 convolution take ``nn.Conv2d.forward``."""
+import os
+
 import torch
 import torch.nn as nn
+
+from ssds import _native as N
 
 
 class _Pointwise(torch.autograd.Function):
@@ -55,8 +61,80 @@ class _Pointwise(torch.autograd.Function):
         return gx, gw, gb
 
 
+def _native_ok(x, cin):
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and cin % 8 == 0
+            and os.environ.get("SSDK_PW_NATIVE", "1") != "0")
+
+
+class _PointwiseNative(torch.autograd.Function):
+    """16-bit NCHW x, weight [Cout, Cin, 1, 1] either fp32 (the master parameter under autocast: cast + transposed copy in ONE
+    launch, the weight gradient comes back in fp32 without a cast) or in x's dtype; bias fp32 / 16-bit or None.
+        forward          ssdk_pw_prepare (fp32 weight) + ssdk_pw_forward(a = W)
+        input gradient   ssdk_pw_forward(a = W^T)
+        weight gradient  ssdk_pw_wgrad (fp32, fixed-order reduction)"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        b, cin, h, wd = (int(v) for v in x.shape)
+        cout, hw, dev, dt = int(w.shape[0]), h * wd, x.device, x.dtype
+        code = N.dtype_code(x)
+        x = x.detach()
+        with torch.cuda.device(dev):
+            sp = N.stream_ptr(dev)
+            if w.dtype == torch.float32:
+                w16 = torch.empty((cout, cin), device=dev, dtype=dt)
+                wt16 = torch.empty((cin, cout), device=dev, dtype=dt)
+                N.check(N.lib.ssdk_pw_prepare(w.detach().data_ptr(), w16.data_ptr(), wt16.data_ptr(), cout, cin, code, sp), "pw_prepare")
+            else:
+                w16 = w.detach().reshape(cout, cin).contiguous()
+                wt16 = w16.t().contiguous()
+            b32 = None if bias is None else bias.detach().float().contiguous()
+            y = torch.empty((b, cout, h, wd), device=dev, dtype=dt)
+            N.check(N.lib.ssdk_pw_forward(x.data_ptr(), w16.data_ptr(), None if b32 is None else b32.data_ptr(), y.data_ptr(),
+                                          b, cin, cout, hw, code, sp), "pw_forward")
+        ctx.save_for_backward(x, wt16)
+        ctx.meta = (w.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wt16 = ctx.saved_tensors
+        wdt, bdt = ctx.meta
+        b, cin, h, wd = (int(v) for v in x.shape)
+        cout, hw, dev = int(wt16.shape[1]), h * wd, x.device
+        gy = gy.contiguous()
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        code = N.dtype_code(x)
+        gx = gw = gb = None
+        with torch.cuda.device(dev):
+            sp = N.stream_ptr(dev)
+            if ctx.needs_input_grad[0]:
+                if cout % 8 == 0:
+                    gx = torch.empty_like(x)
+                    N.check(N.lib.ssdk_pw_forward(gy.data_ptr(), wt16.data_ptr(), None, gx.data_ptr(), b, cout, cin, hw, code, sp),
+                            "pw_forward (input gradient)")
+                else:  # (the kernel's K must be a multiple of 8; no such layer in the reference's networks)
+                    gx = torch.matmul(wt16, gy.view(b, cout, hw)).view(b, cin, h, wd)
+            if ctx.needs_input_grad[1]:
+                need = int(N.lib.ssdk_pw_wgrad_workspace_bytes(b, cout, cin, hw))
+                ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                gw32 = torch.empty((cout, cin, 1, 1), device=dev, dtype=torch.float32)
+                N.check(N.lib.ssdk_pw_wgrad(gy.data_ptr(), x.data_ptr(), gw32.data_ptr(), ws.data_ptr(), need, b, cout, cin, hw, code,
+                                            sp), "pw_wgrad")
+                gw = gw32 if wdt == torch.float32 else gw32.to(wdt)
+        if bdt is not None and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3), dtype=torch.float32).to(bdt)
+        return gx, gw, gb
+
+
 def pointwise_conv(x, weight, bias=None):
     """1x1 / stride 1 convolution of a contiguous NCHW tensor: weight [Cout,Cin,1,1], same floating dtype; differentiable."""
+    if _native_ok(x, int(x.shape[1])):
+        return _PointwiseNative.apply(x, weight, bias)
+    if weight.dtype != x.dtype:
+        weight = weight.to(x.dtype)
+        bias = bias.to(x.dtype) if bias is not None else None
     return _Pointwise.apply(x, weight, bias)
 
 
@@ -72,8 +150,10 @@ class PointwiseConv2d(nn.Conv2d):
         w, bias = self.weight, self.bias
         if torch.is_autocast_enabled():
             dt = torch.get_autocast_dtype("cuda")
-            x, w = x.to(dt), w.to(dt)
-            bias = bias.to(dt) if bias is not None else None
+            x = x.to(dt)
+            if not (_native_ok(x, self.in_channels) and w.dtype == torch.float32):
+                w = w.to(dt)  # (the native kernels take the fp32 master weights themselves: no cast launch, fp32 gradient)
+                bias = bias.to(dt) if bias is not None else None
         elif w.dtype != x.dtype:
             return super(PointwiseConv2d, self).forward(x)
         with torch.autocast("cuda", enabled=False):

@@ -16,7 +16,7 @@ import cases
 import nethelp
 from oracle import box_oracle as O
 from test_gpu_box import BOX_ATOL
-from test_gpu_nets import _check_against_floor, floor_runs
+from test_gpu_nets import SMALL, _check_against_floor, check_small_levels_pooled, floor_runs
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -103,6 +103,18 @@ def test_forward_at_bench_size_against_the_fp32_module(cfg_name, batch, dtype, e
     # (class heads as logits, see _check_against_floor; tail_factor 3: the floor here is PyTorch-ROCm on 4 images, the plan
     #  ran the whole batch -- MIOpen picks its algorithms per batch size, which moves the floor's own tail by ~1.5x)
     _check_against_floor(got, floor, {"loc": wl, "conf": wc}, "bench size %s B=%d" % (cfg_name, batch), dtype, tail_factor=3.0)
+    # small levels (SSD: the 2x2 / 1x1 maps): pooled over the WHOLE batch at full strength (test_gpu_nets.py, comment at SMALL)
+    if any(w.numel() < SMALL for w in tuple(wl) + tuple(wc)):
+        cpu_ref, _ = _seeded_model(cfg_name)
+        with torch.no_grad():
+            al, ac = cpu_ref(x)
+        fa = floor_runs(model, xd, runs=1)[0]
+        cpu = lambda t: t.float().cpu()
+        rows = check_small_levels_pooled([{"loc": [cpu(t) for t in loc], "conf": [cpu(t) for t in conf]}],
+                                         [{"loc": [cpu(t) for t in fa["loc"]], "conf": [cpu(t) for t in fa["conf"]]}],
+                                         [{"loc": list(al), "conf": list(ac)}], "bench size %s B=%d" % (cfg_name, batch), dtype,
+                                         small=SMALL * batch // len(pick))  # (the levels that are small on the picked images)
+        assert rows
     del ref_state
 
 

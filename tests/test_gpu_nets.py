@@ -46,22 +46,19 @@ def _stats(got, want, logit=False):
 
 CAP = {"bfloat16": 0.7, "float16": 0.3}  # absolute cap on the median error (a wrong wire is >= 1; measured bf16: <= 0.63)
 # levels of fewer than SMALL values (the 1x1 / 2x2 maps at the end of the pyramid: a handful of positions whose errors are all
-# correlated through one input vector) are ONE draw of the noise, not a statistic: PyTorch-ROCm's own bf16 run lands anywhere
-# between 0.19 and 0.75 RMS on them.  Their floor is therefore the larger of their own and the median floor of the same
-# head's levels, and their bf16 cap is 1.0 (still below the 1.4 of uncorrelated outputs; the fp16 run of the same case keeps
-# its 0.3 and is the one that discriminates).
+# correlated through one input vector) are ONE draw of the noise, not a statistic.  Round 5 gave them a weaker rule on that
+# single draw (half the floor's correlation, 3x its median).  Round 6 measured the DISTRIBUTION instead
+# (tools/small_level_probe.py, profiles/r06_small_level_probe_*.txt: SSD-MobileNetV2@512, 6 input draws x 8 images): the plan
+# is not further from fp32 than PyTorch-ROCm on any level -- pooled r 0.747 vs 0.702 on the 1x1 box level in bf16, 0.954 vs
+# 0.951 in fp16, per-draw minimum 0.68 vs 0.51 -- i.e. round 5's "plan 0.34 / floor 0.64" was one unlucky draw of two images.
+# So the small levels are now judged POOLED over many inputs, at FULL strength (check_small_levels_pooled: r >= floor - 0.05,
+# median <= 2 x floor + slack, both dtypes), and on the single fixture draw only by the absolute cap on the median.
 SMALL = 4096
 CAP_SMALL = {"bfloat16": 1.0, "float16": 0.3}
 # absolute slack on (median, p99.9): the last levels are a few dozen values, whose statistics are noise themselves
 SLACK = {"bfloat16": (0.06, 0.2), "float16": (0.015, 0.05)}
 CORR_SLACK = 0.05  # the plan may correlate with the fp32 reference this much less than PyTorch-ROCm's 16-bit execution does
-# ... on a SMALL level: at least HALF the floor's correlation (- 0.05), and a median of up to 3x the floor's.  A 1x1 / 2x2 map's
-# few hundred values are one correlated draw of the rounding noise for the plan and another one for the floor (measured in
-# round 5, bf16: SSD-MobileNetV2@512 level 5 -- 96 box values from ONE 128-channel vector per image -- plan r = 0.34 / floor
-# 0.64, FPN-ResNet50 level 4 at 160 px plan 0.67 / floor 0.91, while every level of >= 4096 values agrees to 0.001 in r and
-# the fp16 runs of the same cases sit at r >= 0.96 on every level).  A zero, constant or shuffled head has r = 0 +- 0.1 there.
-CORR_FACTOR_SMALL = 0.5
-MEDIAN_FACTOR_SMALL = 3.0
+POOL_DRAWS = 24    # extra input draws (x the fixture's batch of 2 - 3 images) behind the pooled small-level rule
 
 
 def pooled_small_level_stats(plans, floors, wants, small=SMALL):
@@ -89,6 +86,29 @@ def pooled_small_level_stats(plans, floors, wants, small=SMALL):
                          "floor_r_mean": sum(per["floor"]) / len(per["floor"]), "floor_r_min": min(per["floor"]),
                          "plan_r_pooled": sp[3], "floor_r_pooled": sf[3],
                          "plan_median_pooled": sp[0], "floor_median_pooled": sf[0]})
+    return rows
+
+
+def check_small_levels_pooled(plans, floors, wants, what, dtype, small=SMALL):
+    """The small-level rule at full strength on the pooled sample (see the comment at SMALL): per small level
+        r(plan, fp32) >= r(floor, fp32) - CORR_SLACK   and   median error(plan) <= 2 x median error(floor) + slack.
+    -> the rows (for the report); fails with the offending rows."""
+    rows = pooled_small_level_stats(plans, floors, wants, small=small)
+    bad = []
+    for r in rows:
+        ok = (r["plan_r_pooled"] >= r["floor_r_pooled"] - CORR_SLACK
+              and r["plan_median_pooled"] <= 2.0 * r["floor_median_pooled"] + SLACK[dtype][0])
+        if not ok:
+            bad.append(r)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out) and rows:
+        with open(os.path.join(out, "net_report.txt"), "a") as f:
+            f.write("%s %s small levels pooled over %d draws:\n" % (what, dtype, len(wants)))
+            for r in rows:
+                f.write("  %s (%d values) plan r %.4f median %.4f | floor r %.4f median %.4f\n" % (
+                    r["tensor"], r["values"], r["plan_r_pooled"], r["plan_median_pooled"], r["floor_r_pooled"],
+                    r["floor_median_pooled"]))
+    assert not bad, (what, dtype, bad)
     return rows
 
 
@@ -137,20 +157,17 @@ def _check_against_floor(plan_out, torch_out, want, what, dtype, tail_factor=3.0
         per_run = [[_stats(t, w, lg) for t, w in zip(r[tag], want[tag])] for r in runs]
         floors = [(max(pr[i][0] for pr in per_run), max(pr[i][1] for pr in per_run), max(pr[i][2] for pr in per_run),
                    min(pr[i][3] for pr in per_run)) for i in range(len(want[tag]))]
-        pooled = tuple(sorted(f[j] for f in floors)[len(floors) // 2] for j in range(4))
         for i, (p, w) in enumerate(zip(plan_out[tag], want[tag])):
             sp, st = _stats(p, w, lg), floors[i]
             small = w.numel() < SMALL
             report.append("%s%d%s plan %.4f/%.4f/%.4f r=%.4f floor %.4f/%.4f/%.4f r=%.4f%s" % (
                 (tag, i, "(logit)" if lg else "") + sp + st + (" (small level)" if small else "",)))
-            if small:
-                st = tuple(max(a, b) for a, b in zip(st[:3], pooled[:3])) + (min(st[3], pooled[3]),)
             m_abs, p_abs = SLACK[dtype]
-            cap = CAP_SMALL[dtype] if small else CAP[dtype]
-            mf = MEDIAN_FACTOR_SMALL if small else 2.0
-            r_min = (CORR_FACTOR_SMALL * st[3] if small else st[3]) - CORR_SLACK
-            ok = (sp[0] <= mf * st[0] + m_abs and sp[0] <= cap and sp[1] <= max(tail_factor, mf) * st[1] + p_abs
-                  and sp[3] >= r_min)
+            if small:  # one draw of a handful of values: only the cap here, the rules proper in check_small_levels_pooled
+                ok = sp[0] <= CAP_SMALL[dtype]
+            else:
+                ok = (sp[0] <= 2.0 * st[0] + m_abs and sp[0] <= CAP[dtype] and sp[1] <= max(tail_factor, 2.0) * st[1] + p_abs
+                      and sp[3] >= st[3] - CORR_SLACK)
             if not ok:
                 bad.append(report[-1])
     out = os.path.join(ROOT, "gpurun_out")
@@ -188,6 +205,30 @@ def test_plan_matches_reference_module(name, dtype, monkeypatch):
     assert FC.STATS["native_layers"] == n0
     report = _check_against_floor({"loc": loc, "conf": conf}, floor, {"loc": wl, "conf": wc}, name, dtype)
     print(name, dtype, "; ".join(report))
+    # small levels: pooled over POOL_DRAWS more inputs of the fixture's shape.  Their fp32 reference is THIS repository's module
+    # on the CPU, which test_nets_golden.py pins to the reference's own classes to ~1e-6 on the fixture input.
+    if any(w.numel() < SMALL for w in wl + wc):
+        cpu_model, _, _ = nethelp.build(name)
+        cpu = lambda t: t.float().cpu()
+        plans, floors, wants = [{"loc": [cpu(t) for t in loc], "conf": [cpu(t) for t in conf]}], [
+            {"loc": [cpu(t) for t in floor[0]["loc"]], "conf": [cpu(t) for t in floor[0]["conf"]]}], [{"loc": wl, "conf": wc}]
+        g = torch.Generator().manual_seed(4711)
+        stub = isinstance(cpu_model.backbone, nethelp.StubBackbone)
+        for _ in range(POOL_DRAWS):
+            xi = torch.rand(x.shape, generator=g)
+            if stub:  # (a stub backbone ignores the image: draw its feature maps instead)
+                feats = [torch.randn(f.shape, generator=g) * 0.7 for f in cpu_model.backbone.feats]
+                cpu_model.backbone.feats = feats
+                model.backbone.feats = feats
+            with torch.no_grad():
+                cl, cc = cpu_model(xi)
+                pl, pc = model(xi.cuda().to(tdt))
+            fl = floor_runs(model, xi.cuda().to(tdt), runs=1)[0]
+            wants.append({"loc": list(cl), "conf": list(cc)})
+            plans.append({"loc": [cpu(t) for t in pl], "conf": [cpu(t) for t in pc]})
+            floors.append({"loc": [cpu(t) for t in fl["loc"]], "conf": [cpu(t) for t in fl["conf"]]})
+        rows = check_small_levels_pooled(plans, floors, wants, name, dtype)
+        assert rows, "a level of < %d values exists but nothing was pooled" % SMALL
 
 
 @pytest.mark.parametrize("name,small_pixels", [("fpn_r18", 200), ("fpn_stub", 200), ("bifpn_stub", 100)])

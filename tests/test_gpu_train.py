@@ -344,10 +344,18 @@ def test_batchnorm_with_folded_activation_is_bit_identical_to_the_two_step_path(
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype_name,tol", [("float32", 2e-4), ("bfloat16", 2e-2), ("float16", 4e-3)])
-@pytest.mark.parametrize("n,cin,cout,h,w,bias", [(4, 16, 96, 16, 24, False), (3, 24, 144, 9, 7, True), (64, 160, 960, 16, 16, False),
-                                                 (2, 320, 256, 5, 5, True)])
+@pytest.mark.parametrize("n,cin,cout,h,w,bias", [
+    (4, 16, 96, 16, 24, False), (3, 24, 144, 9, 7, True), (64, 160, 960, 16, 16, False), (2, 320, 256, 5, 5, True),
+    # round 6 (csrc/ssdk_pwtrain.hip): every path of the native kernels -- short K with 1 / 2 / 3 k-steps and sliced outputs,
+    # long K in one chunk and in several (8 + 8 + 2 k-steps; 30), 1 - 4 output fragments per slice, output channels that do not
+    # fill a fragment (24), planes that end inside a 128-pixel group / inside a lane's 8 pixels / at 1 pixel, odd plane sizes
+    # (rows at 2-byte alignment), one image
+    (2, 32, 16, 64, 64, False), (2, 64, 384, 19, 19, False), (2, 96, 576, 10, 10, True), (1, 144, 24, 40, 32, False),
+    (3, 576, 96, 5, 5, False), (2, 960, 320, 4, 4, False), (2, 384, 64, 32, 32, False), (2, 192, 32, 33, 31, True),
+    (1, 256, 64, 1, 1, True), (2, 512, 128, 3, 3, False), (5, 160, 960, 2, 2, False)])
 def test_pointwise_gemm_conv_matches_torch(n, cin, cout, h, w, bias, dtype_name, tol):
-    """forward and all three gradients of the GEMM-backed 1x1 convolution vs nn.Conv2d in fp32 (operands rounded alike)."""
+    """forward and all three gradients of the 1x1 convolution (16 bit: the ssdk_pw_* kernels; fp32: library GEMMs) vs nn.Conv2d
+    in fp32 (operands rounded alike)."""
     import torch
     import torch.nn as nn
     from ssds.modeling.layers.pointwise import PointwiseConv2d
@@ -376,6 +384,23 @@ def test_pointwise_gemm_conv_matches_torch(n, cin, cout, h, w, bias, dtype_name,
     close(pw.weight.grad, ref.weight.grad, "dweight")
     if bias:
         close(pw.bias.grad, ref.bias.grad, "dbias")
+    if dtype_name != "float32":
+        from ssds import _native as N
+
+        assert N.last_kernel().startswith("pw_"), N.last_kernel()  # the hand-written kernels ran, not a library GEMM
+        # per ELEMENT against fp32 on the same 16-bit operands: the kernels accumulate in fp32, so what is left is the output
+        # rounding (2^-9 bf16, 2^-11 fp16) -- a wrong k <-> pixel pairing or a dropped tail pixel is O(1)
+        eps = 2.0 ** -8 if dtype_name == "bfloat16" else 2.0 ** -10
+        for got, want, what in ((yp, yr, "output"), (xp.grad, xr.grad, "dx")):
+            err = (got.float() - want).abs()
+            bar = eps * want.abs() + 4 * eps * float(want.pow(2).mean().sqrt())
+            assert bool((err <= bar).all()), "%s: %d elements outside the rounding bar, worst %.3g" % (
+                what, int((err > bar).sum()), float((err - bar).max()))
+        # the weight gradient is reduced in a fixed order: bit-reproducible
+        g1 = pw.weight.grad.clone()
+        pw.weight.grad = None
+        pw(xp.detach().clone().requires_grad_(True)).backward(g)
+        assert torch.equal(g1, pw.weight.grad)
     # under autocast the module computes in the autocast dtype from fp32 parameters, like nn.Conv2d
     pw32 = PointwiseConv2d(cin, cout, 1, bias=bias).cuda()
     with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -712,14 +737,16 @@ def _cpu_reference_step(model, anchors, images, targets, num_classes, match):
         size = tuple(conf[j].shape[-2:])
         ct, bt, dp = (torch.from_numpy(x) for x in O.extract_targets(targets.numpy(), oanch, num_classes, stride, size, tuple(match)))
         fg = fg + (dp > 0).sum().float().clamp(min=1)
-        c = conf[j].view_as(ct).float()
-        c_sum = c_sum + ((dp >= 0).expand_as(ct).float() * cls_c(c, ct, dp)).sum()
-        l = loc[j].view_as(bt).float()
-        ll = loc_c(l, bt)
-        l_sum = l_sum + ((dp > 0).expand_as(ll).float() * ll).sum()
+        dt = conf[j].dtype  # fp32, or fp64 for the truth
+        c = conf[j].view_as(ct)
+        c_sum = c_sum + ((dp >= 0).expand_as(ct).to(dt) * cls_c(c, ct.to(dt), dp)).sum()
+        l = loc[j].view_as(bt)
+        ll = loc_c(l, bt.to(dt))
+        l_sum = l_sum + ((dp > 0).expand_as(ll).to(dt) * ll).sum()
     cls_loss, loc_loss = c_sum / fg, l_sum / fg
     (cls_loss + loc_loss).backward()
-    return float(cls_loss.detach()), float(loc_loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    return (float(cls_loss.detach()), float(loc_loss.detach()),
+            {k: p.grad.detach().double().clone() for k, p in model.named_parameters()})
 
 
 def _device_step(model, anchors, images, targets, cfg, autocast, ssdk=True, ddp=False):
@@ -775,70 +802,95 @@ def _device_step(model, anchors, images, targets, cfg, autocast, ssdk=True, ddp=
     for k, p in inner.model.named_parameters():
         assert p.grad is not None, "no gradient reached %s" % k
         grads[k] = p.grad.detach().float().cpu()
-    return float(cls_loss), float(loc_loss), grads
+    return float(cls_loss.detach()), float(loc_loss.detach()), grads
 
 
-# fp32 on the device against fp32 on the CPU: the two differ by summation order only (hipBLASLt / MIOpen / the ssdk reductions vs
-# MKL).  Bars: every parameter's gradient within FP32_WORST relative rms, the median parameter within FP32_MEDIAN.
-FP32_WORST, FP32_MEDIAN = 1e-3, 1e-4
+# What the comparison can resolve.  The TRUTH is the step in fp64 on the CPU.  This network (train-mode BatchNorm, seeded O(1)
+# weights) amplifies rounding: the SAME step in fp32 on the CPU is already 0.3 - 1.5 % (relative rms, median over the parameters)
+# away from fp64 -- measured here with and without oneDNN, with 1 and 8 threads, with the reference's own initialisation
+# (0.8 %) and with BatchNorm weights of 1 (0.3 %) -- uniformly over the backbone, 1e-5 on the head biases.  So fp32 has a noise
+# floor too, and every bar below is relative to a floor execution judged against the same fp64 truth:
+#   fp32 on the device  vs  fp32 on the CPU (floor);      bf16 autocast on the ssdk kernels  vs  bf16 autocast on PyTorch-ROCm.
+# A dropped branch, a wrong BatchNorm mask or a weight gradient summed over the wrong axis on ONE layer moves that parameter to
+# rel ~ 1 / r ~ 0 (tests/test_train_judge_cpu.py feeds the judge exactly those).
 POOL_BELOW = 512  # parameters with fewer elements (BatchNorm vectors of the narrow layers) are judged as ONE pooled vector
+ZERO_BELOW = 1e-7  # x the median gradient rms: a STRUCTURALLY zero gradient (the bias of a BatchNorm whose only consumer is a 1x1
+#                    convolution + train-mode BatchNorm: fp64 says 1e-17) -- only its magnitude is judged
 
 
-def _judge_16bit(got, floor, ref, what):
-    """bf16-autocast gradients of the ssdk step against the fp32 CPU gradients, relative to PyTorch-ROCm's own bf16-autocast
-    execution of the same module (the floor): per parameter of >= POOL_BELOW elements
-        rel(plan) <= 2 x rel(floor) + 0.02   and   r(plan) >= r(floor) - 0.05      (the correlation rule of test_gpu_nets.py),
-    and the same for all smaller parameters pooled (each scaled by the rms of its fp32 gradient)."""
+def _judge_gradients(got, floor, ref, what, factor=2.0, slack=0.02, r_slack=0.05):
+    """``got`` / ``floor`` / ``ref``: {name: gradient}; ``ref`` is the fp64 truth.  Per parameter of >= POOL_BELOW elements
+        rel(got) <= factor x rel(floor) + slack   and   r(got) >= r(floor) - r_slack     (the correlation rule of test_gpu_nets.py)
+    and the same for all smaller parameters pooled (each scaled by the rms of its true gradient); structurally zero gradients
+    must stay within 10 x the floor's magnitude.  -> rows (name, elements, rel, r, floor rel, floor r)."""
     import torch
 
-    bad, rows, pool = [], [], {"got": [], "floor": [], "ref": []}
+    floors = floor if isinstance(floor, (list, tuple)) else [floor]  # several floor executions: the worst of them per parameter
+    rms = lambda t: float(t.double().pow(2).mean().sqrt())
+    scale = sorted(rms(w) for w in ref.values())[len(ref) // 2]
+    bad, rows, pool = [], [], {"got": [], "ref": [], "floor": [[] for _ in floors]}
+
+    def worst(stats):
+        return max(s[0] for s in stats), min(s[1] for s in stats)
+
     for k, w in ref.items():
-        rw = float(w.double().pow(2).mean().sqrt())
-        if rw == 0.0:
-            assert float(got[k].abs().max()) == 0.0, "%s: fp32 gradient is zero, the device's is not" % k
+        rw = rms(w)
+        if rw < ZERO_BELOW * scale:
+            fz = max(rms(f[k]) for f in floors)
+            if not rms(got[k]) <= 10.0 * fz + 1e-6 * scale:
+                bad.append("%s: structurally zero gradient, plan rms %.3g, floor rms %.3g" % (k, rms(got[k]), fz))
             continue
         if w.numel() < POOL_BELOW:
-            for tag, src in (("got", got), ("floor", floor), ("ref", ref)):
-                pool[tag].append(src[k].flatten().double() / rw)
+            pool["got"].append(got[k].flatten().double() / rw)
+            pool["ref"].append(w.flatten().double() / rw)
+            for lst, f in zip(pool["floor"], floors):
+                lst.append(f[k].flatten().double() / rw)
             continue
-        (rp, cp), (rf, cf) = _rel_and_corr(got[k], w), _rel_and_corr(floor[k], w)
+        (rp, cp), (rf, cf) = _rel_and_corr(got[k], w), worst([_rel_and_corr(f[k], w) for f in floors])
         rows.append((k, w.numel(), rp, cp, rf, cf))
-        if not (rp <= 2.0 * rf + 0.02 and cp >= cf - 0.05):
+        if not (rp <= factor * rf + slack and cp >= cf - r_slack):
             bad.append("%s (%d): plan rel %.4f r %.4f | floor rel %.4f r %.4f" % (k, w.numel(), rp, cp, rf, cf))
     if pool["ref"]:
         w = torch.cat(pool["ref"])
-        (rp, cp), (rf, cf) = _rel_and_corr(torch.cat(pool["got"]), w), _rel_and_corr(torch.cat(pool["floor"]), w)
+        (rp, cp), (rf, cf) = _rel_and_corr(torch.cat(pool["got"]), w), worst([_rel_and_corr(torch.cat(l), w) for l in pool["floor"]])
         rows.append(("<pooled small parameters>", int(w.numel()), rp, cp, rf, cf))
-        if not (rp <= 2.0 * rf + 0.02 and cp >= cf - 0.05):
+        if not (rp <= factor * rf + slack and cp >= cf - r_slack):
             bad.append("pooled small parameters: plan rel %.4f r %.4f | floor rel %.4f r %.4f" % (rp, cp, rf, cf))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
+        med = lambda col: sorted(r[col] for r in rows)[len(rows) // 2]
         with open(os.path.join(out, "whole_step_gradients.txt"), "a") as f:
-            f.write("%s: bf16 autocast, per parameter: elements | plan rel, r | floor rel, r\n" % what)
+            f.write("%s: %d rows, median rel plan %.4g floor %.4g, min r plan %.4f floor %.4f\n"
+                    % (what, len(rows), med(2), med(4), min(r[3] for r in rows), min(r[5] for r in rows)))
             for row in rows:
-                f.write("  %-44s %8d | %.4f %.4f | %.4f %.4f\n" % row)
+                f.write("  %-44s %8d | %.5f %.4f | %.5f %.4f\n" % row)
     assert not bad, "%s\n%s" % (what, "\n".join(bad))
     return rows
 
 
 @pytest.mark.parametrize("size,batch,ddp", [(320, 4, False), (512, 8, False), (320, 4, True)])
-def test_whole_step_gradients_match_the_fp32_cpu_module(size, batch, ddp):
+def test_whole_step_gradients_match_the_fp64_cpu_module(size, batch, ddp):
     """The COMPOSITION of the training step (reference pipeline_anchor_apex.py:37-72, 103-130) at BASELINE config 4's geometry:
     SSD-MobileNetV2, 80 classes, six levels, six anchors per cell, 512 px (and 320 px: the same six levels in a quarter of the
     time; 128 / 256 px would give two levels the same stride, which model_builder.py:41 cannot key).  EVERY parameter's
     gradient of (cls_loss + loc_loss) after one forward + backward -- the kernel-backed depthwise convolutions and BatchNorm
     (+ folded ReLU6 / ReLU), the 1x1 convolutions, the 3x3 stem / extras / head convolutions, the fused target assignment +
-    focal + smooth-L1 kernel -- against the same step in fp32 on the CPU with the numpy oracle's target assignment:
-      * fp32 on the device: relative rms <= FP32_WORST for every parameter, <= FP32_MEDIAN for the median one, losses to 1e-5;
-      * bf16 autocast (the configuration the step runs in): against the PyTorch-ROCm floor with the correlation rule.
+    focal + smooth-L1 kernel -- against the same step in fp64 on the CPU with the numpy oracle's target assignment:
+      * fp32 on the device: losses to 1e-5; gradients within 3 x the error of the fp32 floors (the CPU step, PyTorch-ROCm's
+        device step: the worse of the two per parameter) + 1e-3, correlation >= theirs - 0.02 (fp32 itself sits 0.3 - 1.5 %
+        from fp64 on this network: see the comment above the judge);
+      * bf16 autocast (the configuration the step runs in): within 2 x the error of PyTorch-ROCm's own bf16-autocast
+        execution of the same module + 0.02, correlation >= its - 0.05.
     ``ddp``: the module wrapped in torch DDP over RCCL (world size 1) with gradient_as_bucket_view, i.e. the gradients are
-    written into the bucket views the all-reduce works on.  A dropped branch, a BatchNorm backward with the wrong mask or a
-    weight gradient summed over the wrong axis on ONE layer moves that layer's row to rel ~ 1 / r ~ 0."""
+    written into the bucket views the all-reduce works on."""
+    import copy
     import torch
 
     model, anchors, images, targets, cfg = _whole_step_case(size, batch)
-    rc, rl, ref = _cpu_reference_step(model, anchors, images, targets, cfg.MODEL.NUM_CLASSES, cfg.MATCHER.MATCH_THRESHOLD)
-    assert rl > 0 and all(float(g.abs().max()) > 0 for k, g in ref.items() if k.endswith("weight")), "a dead reference step"
+    nc, match = cfg.MODEL.NUM_CLASSES, cfg.MATCHER.MATCH_THRESHOLD
+    tc, tl, truth = _cpu_reference_step(copy.deepcopy(model).double(), anchors, images.double(), targets, nc, match)
+    rc, rl, cpu32 = _cpu_reference_step(model, anchors, images, targets, nc, match)
+    assert tl > 0 and all(float(g.abs().max()) > 0 for k, g in truth.items() if k.endswith("weight")), "a dead reference step"
     if ddp:
         import socket
         import torch.distributed as dist
@@ -851,24 +903,20 @@ def test_whole_step_gradients_match_the_fp32_cpu_module(size, batch, ddp):
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0,
                                 device_id=torch.device("cuda", 0))
     try:
-        # fp32 on the device
+        tag = "%d px B=%d ddp=%s" % (size, batch, ddp)
+        # fp32 on the device, judged against fp32 on the CPU and fp32 on PyTorch-ROCm (MIOpen's fp32 3x3 convolutions are
+        # themselves 0.4 % from fp64 on the extras, 20 x the CPU's error there: measured in round 6, session 2)
         dc, dl, got = _device_step(model, anchors, images, targets, cfg, autocast=False, ddp=ddp)
-        np.testing.assert_allclose([dc, dl], [rc, rl], rtol=1e-5)
-        assert set(got) == set(ref)
-        rels = {k: _rel_and_corr(got[k], ref[k])[0] for k in ref if float(ref[k].abs().max()) > 0}
-        worst = max(rels, key=rels.get)
-        med = sorted(rels.values())[len(rels) // 2]
-        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-        if os.path.isdir(out):
-            with open(os.path.join(out, "whole_step_gradients.txt"), "a") as f:
-                f.write("%d px B=%d ddp=%s fp32: %d parameters, median rel %.3g, worst %.3g (%s); losses %.6f %.6f vs %.6f %.6f\n"
-                        % (size, batch, ddp, len(rels), med, rels[worst], worst, dc, dl, rc, rl))
-        assert rels[worst] <= FP32_WORST and med <= FP32_MEDIAN, (worst, rels[worst], med)
-        # bf16 autocast: the ssdk step and the PyTorch-ROCm floor, both against fp32
+        np.testing.assert_allclose([dc, dl], [tc, tl], rtol=1e-5)
+        assert set(got) == set(truth)
+        _, _, dev32 = _device_step(model, anchors, images, targets, cfg, autocast=False, ssdk=False)
+        _judge_gradients(got, [cpu32, dev32], truth, tag + " fp32 (floors: fp32 on the CPU, fp32 on PyTorch-ROCm)",
+                         factor=3.0, slack=1e-3, r_slack=0.02)
+        # bf16 autocast: the ssdk step and the PyTorch-ROCm floor, both against fp64
         ac, al, got16 = _device_step(model, anchors, images, targets, cfg, autocast=True, ddp=ddp)
-        np.testing.assert_allclose([ac, al], [rc, rl], rtol=2e-2)
+        np.testing.assert_allclose([ac, al], [tc, tl], rtol=2e-2)
         _, _, floor16 = _device_step(model, anchors, images, targets, cfg, autocast=True, ssdk=False)
-        _judge_16bit(got16, floor16, ref, "%d px B=%d ddp=%s" % (size, batch, ddp))
+        _judge_gradients(got16, floor16, truth, tag + " bf16 autocast (floor: PyTorch-ROCm bf16 autocast)")
     finally:
         if ddp:
             import torch.distributed as dist
