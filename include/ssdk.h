@@ -422,6 +422,26 @@ size_t ssdk_pw_wgrad_workspace_bytes(int B, int Cout, int Cin, int HW);
 int ssdk_pw_wgrad(const void* dy, const void* x, float* dw, void* workspace, size_t workspace_bytes, int B, int Cout, int Cin,
                   int HW, int dtype, void* stream);
 
+/* Dense 3x3 / pad 1 / stride 1 | 2 convolutions of the TRAINING step (stem mobilenet.py:78, extras basic_layers.py:40-57, heads
+ * ssd.py:100-103; version 240): y[b] = W2 col[b] with W2 = weight.view(Cout, Cin * 9) (k = ci * 9 + ky * 3 + kx) padded to
+ * Kp = Cin * 9 rounded up to 8 columns, so forward / input gradient / weight gradient are ssdk_pw_forward(col, W2),
+ * ssdk_pw_forward(dy, W2^T) + ssdk_col2im3x3, ssdk_pw_wgrad(dy, col).  16-bit NCHW tensors, Ho = (H - 1) / stride + 1.
+ *   ssdk_im2col3x3   x [B, C, H, W] -> col [B, Kp, Ho * Wo]   (zero outside the plane and in the rows C * 9 .. Kp)
+ *   ssdk_col2im3x3   dcol [B, Kp, Ho * Wo] -> dx [B, C, H, W]  (per input pixel a gather of <= 9 terms, fp32 sum in tap order) */
+int ssdk_im2col3x3(const void* x, void* col, int B, int C, int H, int W, int stride, int dtype, void* stream);
+int ssdk_col2im3x3(const void* dcol, void* dx, int B, int C, int H, int W, int stride, int dtype, void* stream);
+
+/* SGD with momentum / weight decay / Nesterov over ALL parameter tensors of a model (version 240; csrc/ssdk_sgd.hip): the
+ * optimizer.step() of the reference's loop (pipeline_anchor_apex.py:128-130 on core/optimizer.py:73-134's torch.optim.SGD) with
+ * the reference's NaN/Inf skip (:110-111, 126-127) taken on the device.  fp32 tensors.  params / grads / momentum_bufs / numel
+ * are HOST arrays of n entries (device pointers, element counts); momentum_bufs may be NULL when momentum == 0.
+ *   g = grad + weight_decay p;  buf = momentum buf + g;  p -= lr (nesterov ? g + momentum buf : buf)
+ * lr_dev (device float, may be NULL -> lr) is read by the kernel: a captured hipGraph sees later changes.  found_inf (device
+ * float, may be NULL): non-zero = no tensor is touched. */
+int ssdk_sgd_step(int n, void* const* params, const void* const* grads, void* const* momentum_bufs, const int64_t* numel,
+                  const float* lr_dev, float lr, float momentum, float weight_decay, int nesterov, const float* found_inf,
+                  void* stream);
+
 /* Depthwise 3x3 convolution (pad 1, stride 1|2) for the TRAINING step: forward, input gradient and weight gradient,
  * NCHW contiguous, dtype SSDK_F32 | SSDK_BF16 | SSDK_F16, fp32 accumulation (replaces MIOpen's naive_conv_* kernels
  * behind torch.nn.functional.conv2d(groups = C) in the DDP step, pipeline_anchor_apex.py:75-171).

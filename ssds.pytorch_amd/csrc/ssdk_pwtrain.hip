@@ -19,8 +19,8 @@
 //     multiplies the pixel set {p0 + 8 fr + t}.  Its accumulators then hold, per output channel row, 8 consecutive pixels =
 //     one 16-byte store into the NCHW output.  No LDS transpose on either side.
 //   * dW = dy x^T contracts over PIXELS, which are contiguous in both operands: A fragments of dy and B fragments of x are plain
-//     16-byte loads.  The k <-> pixel assignment is free as well (it only has to agree between the two operands), so a lane takes
-//     32 consecutive pixels (four k-steps) of its row: every row is read in 256-byte runs.
+//     16-byte loads: a k-step is 32 consecutive pixels, each load instruction reads 64 contiguous bytes of each of its 16 rows,
+//     four k-steps (128 pixels) are in flight per chunk.
 //   * the weight gradient is split over (tile of the [Cout, Cin] matrix) x (range of pixels); every wave writes its fp32 partial
 //     tile to the workspace and pw_wgrad_reduce_kernel adds the partials in index order: no float atomics, bit-reproducible.
 // HBM bytes: forward (Cin + Cout) * 2 per pixel, input gradient the same, weight gradient (Cin + Cout) * 2 per pixel read.
@@ -293,8 +293,12 @@ static int pw_gemm_launch(const void* x, const void* a, const float* bias, void*
 #undef SSDK_PWS
     return check_launch("pw_gemm_short_kernel");
   }
-  // long K: NF fragments per slice, equal slices
+  // long K: NF <= 4 fragments per slice, equal slices -- and MORE slices (each re-reads x, from L2) when the pixels alone give the
+  // chip too few workgroups: 960 -> 160 on 16 x 16 maps at batch 64 is 32 workgroup iterations; as 3 slices of 4 fragments it
+  // ran on 96 workgroups in 33 us (library GEMM: 22), as 5 slices of 2 on 160
   int slices = (mf + 3) / 4;
+  const int wanted = (int)((256u + p.wg_iters - 1u) / p.wg_iters);
+  if (slices < wanted) slices = wanted < mf ? wanted : mf;
   int nf = (mf + slices - 1) / slices;
   slices = (mf + nf - 1) / nf;
   p.nf = nf;
@@ -355,7 +359,10 @@ __global__ __launch_bounds__(PWT_THREADS) void pw_wgrad_kernel(const PwgParams p
     for (int j = 0; j < NFW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const u32 c_end = min(p.chunks, (s + 1u) * p.cps);
   for (u32 c = s * p.cps; c < c_end; ++c) {
-    const u32 b = c / p.cpi, p0 = (c - b * p.cpi) * 128u + 32u * fg;
+    // k-step u of the chunk = its pixels 32 u .. 32 u + 31, lane group fg the 8 pixels 32 u + 8 fg ..: ONE load instruction
+    // reads 64 contiguous bytes of each of its 16 rows.  (As first written a lane took 32 CONSECUTIVE pixels over its four loads,
+    // i.e. every instruction touched sixteen 16-byte pieces 64 bytes apart per row: the 32 x 32 layers ran at 0.19 of the roof.)
+    const u32 b = c / p.cpi, p0 = (c - b * p.cpi) * 128u + 8u * fg;
     const bool tail = (c - b * p.cpi) * 128u + 128u > HW;  // wave-uniform
     u32x4 av[MFW][4], bv[NFW][4];
 #pragma unroll
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(PWT_THREADS) void pw_wgrad_kernel(const PwgParams p
       const u16* src = p.dy + ((size_t)b * Cout + row) * HW + p0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (row < Cout) av[i][u] = tail ? pw_load8<true>(src + 8 * u, (int)HW - (int)p0 - 8 * u) : pw_load8<false>(src + 8 * u, 8);
+        if (row < Cout) av[i][u] = tail ? pw_load8<true>(src + 32 * u, (int)HW - (int)p0 - 32 * u) : pw_load8<false>(src + 32 * u, 8);
         else av[i][u] = u32x4{0u, 0u, 0u, 0u};
       }
     }
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(PWT_THREADS) void pw_wgrad_kernel(const PwgParams p
       const u16* src = p.x + ((size_t)b * Cin + row) * HW + p0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        if (row < Cin) bv[j][u] = tail ? pw_load8<true>(src + 8 * u, (int)HW - (int)p0 - 8 * u) : pw_load8<false>(src + 8 * u, 8);
+        if (row < Cin) bv[j][u] = tail ? pw_load8<true>(src + 32 * u, (int)HW - (int)p0 - 32 * u) : pw_load8<false>(src + 32 * u, 8);
         else bv[j][u] = u32x4{0u, 0u, 0u, 0u};
       }
     }
@@ -560,4 +567,155 @@ extern "C" int ssdk_pw_prepare(const float* w32, void* w16, void* wt16, int Cout
     hipLaunchKernelGGL(pw_prepare_kernel<SSDK_F16>, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, w32, (u16*)w16,
                        (u16*)wt16, (u32)Cout, (u32)Cin);
   return check_launch("pw_prepare_kernel");
+}
+
+// ---- 3x3 convolutions of the training step (stem, extras, multibox heads) on the same kernels -----------------------------------
+// A dense 3x3 / pad 1 / stride 1 | 2 convolution in NCHW is y[b] = W2 col[b] with W2 = weight.view(Cout, Cin * 9) -- torch's own
+// flattening, k = ci * 9 + ky * 3 + kx -- and col[b][k][p] = x[b][ci][s oy - 1 + ky][s ox - 1 + kx] (zero outside the plane).  On a
+// chip with 8 TB/s the nine-fold copy is cheap next to what it buys: forward, input gradient and weight gradient of every 3x3
+// layer ARE the 1x1 kernels above (ssdk_pw_forward with a = W2 / W2^T, ssdk_pw_wgrad against col), the weight gradient comes out
+// in the parameter's own layout, and the only new code is two index kernels:
+//   im2col3x3_kernel   x [B, C, H, W] -> col [B, Kp, Ho Wo], Kp = C * 9 rounded up to 8 (zero rows; the 3-channel stem: 27 -> 32)
+//   col2im3x3_kernel   dcol [B, Kp, Ho Wo] -> dx [B, C, H, W]: every input pixel GATHERS its <= 9 contributions (fp32 sum in tap
+//                      order, one rounding): no atomics, bit-reproducible
+// Reference: the 3x3 convolutions of ssd.py:77-104 (extras through basic_layers.py:40-57, heads ssd.py:100-103) and the stem of
+// mobilenet.py:78 in the step of pipeline_anchor_apex.py:103-130, which PyTorch-ROCm sends to MIOpen's igemm_{fwd,bwd,wrw}_gtcx35
+// kernels between batched_transpose launches.
+namespace ssdk {
+
+struct ColParams {
+  const u16* x;
+  u16* col;
+  int B, C, H, W, Ho, Wo, stride, Kp;
+};
+
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const ColParams p) {
+  const u32 HWo = (u32)(p.Ho * p.Wo), vpr = (HWo + 7u) / 8u;  // 8-pixel vectors per col row
+  const size_t total = (size_t)p.B * p.Kp * vpr;
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < total; i += (size_t)gridDim.x * 256u) {
+    const u32 v = (u32)(i % vpr), k = (u32)((i / vpr) % (u32)p.Kp), b = (u32)(i / ((size_t)vpr * p.Kp));
+    const u32 p0 = v * 8u;
+    const int nvalid = (int)HWo - (int)p0;
+    u16* dst = p.col + ((size_t)b * p.Kp + k) * HWo + p0;
+    u32 h[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (k < (u32)(p.C * 9)) {
+      const u32 c = k / 9u, t = k - c * 9u, ky = t / 3u, kx = t - ky * 3u;
+      const u16* plane = p.x + ((size_t)b * p.C + c) * p.H * p.W;
+      const u32 oy0 = p0 / (u32)p.Wo, ox0 = p0 - oy0 * (u32)p.Wo;
+      const int iy0 = (int)oy0 * p.stride - 1 + (int)ky, ix0 = (int)ox0 * p.stride - 1 + (int)kx;
+      if (p.stride == 1 && ox0 + 7u < (u32)p.Wo && nvalid >= 8 && ix0 >= 0 && ix0 + 7 < p.W) {  // one output row, interior columns
+        if ((unsigned)iy0 < (unsigned)p.H) {
+          *reinterpret_cast<pw_u32x4_a2*>(dst) = *reinterpret_cast<const pw_u32x4_a2*>(plane + (size_t)iy0 * p.W + ix0);
+          continue;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const u32 op = p0 + (u32)e, oy = op / (u32)p.Wo, ox = op - oy * (u32)p.Wo;
+          const int iy = (int)oy * p.stride - 1 + (int)ky, ix = (int)ox * p.stride - 1 + (int)kx;
+          if (e < nvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) h[e] = (u32)plane[(size_t)iy * p.W + ix];
+        }
+      }
+    }
+    pw_store8<true>(dst, u32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)}, nvalid);
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const ColParams p) {  // p.col = dcol (read), p.x = dx (written)
+  const u32 HW = (u32)(p.H * p.W), HWo = (u32)(p.Ho * p.Wo), vpr = (HW + 7u) / 8u;
+  const size_t total = (size_t)p.B * p.C * vpr;
+  u16* dx = const_cast<u16*>(p.x);
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < total; i += (size_t)gridDim.x * 256u) {
+    const u32 v = (u32)(i % vpr), c = (u32)((i / vpr) % (u32)p.C), b = (u32)(i / ((size_t)vpr * p.C));
+    const u32 p0 = v * 8u;
+    const int nvalid = (int)HW - (int)p0;
+    const u16* rows = p.col + ((size_t)b * p.Kp + (size_t)c * 9u) * HWo;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const u32 iy0 = p0 / (u32)p.W, ix0 = p0 - iy0 * (u32)p.W;
+    const bool one_row = p.stride == 1 && ix0 + 7u < (u32)p.W && nvalid >= 8;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ky = t / 3, kx = t % 3;
+      const u16* row = rows + (size_t)t * HWo;
+      if (one_row) {  // stride 1: the 8 input pixels of a row meet 8 consecutive output pixels of row iy + 1 - ky
+        const int oy = (int)iy0 + 1 - ky, ox = (int)ix0 + 1 - kx;
+        if ((unsigned)oy >= (unsigned)p.Ho) continue;
+        if (ox >= 0 && ox + 7 < p.Wo) {
+          const u32x4 d = *reinterpret_cast<const pw_u32x4_a2*>(row + (size_t)oy * p.Wo + ox);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += bits16_to_f32<DT>((e & 1) ? (d[e >> 1] >> 16) : (d[e >> 1] & 0xffffu));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if ((unsigned)(ox + e) < (unsigned)p.Wo) acc[e] += bits16_to_f32<DT>((u32)row[(size_t)oy * p.Wo + ox + e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const u32 ip = p0 + (u32)e, iy = ip / (u32)p.W, ix = ip - iy * (u32)p.W;
+          const int ny = (int)iy + 1 - ky, nx = (int)ix + 1 - kx;  // = stride * (oy, ox)
+          if (e >= nvalid || ny < 0 || nx < 0) continue;
+          if (p.stride == 2 && ((ny | nx) & 1)) continue;
+          const int oy = ny / p.stride, ox = nx / p.stride;
+          if (oy < p.Ho && ox < p.Wo) acc[e] += bits16_to_f32<DT>((u32)row[(size_t)oy * p.Wo + ox]);
+        }
+      }
+    }
+    const u32x4 o = {pack2_16<DT>(acc[0], acc[1]), pack2_16<DT>(acc[2], acc[3]), pack2_16<DT>(acc[4], acc[5]), pack2_16<DT>(acc[6], acc[7])};
+    pw_store8<true>(dx + ((size_t)b * p.C + c) * HW + p0, o, nvalid);
+  }
+}
+
+}  // namespace ssdk
+
+static int col_check(const void* a, const void* b, int B, int C, int H, int W, int stride, int dtype, const char* what) {
+  if (!a || !b || B < 1 || C < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2) || (dtype != SSDK_BF16 && dtype != SSDK_F16)) {
+    set_error("%s: bad argument (16-bit NCHW tensors, stride 1 | 2)", what);
+    return SSDK_E_BADARG;
+  }
+  const size_t kp = ((size_t)C * 9 + 7) / 8 * 8;
+  if ((size_t)B * kp * (size_t)H * (size_t)W >= ((size_t)1 << 32)) {
+    set_error("%s: tensor too large", what);
+    return SSDK_E_BADARG;
+  }
+  return SSDK_OK;
+}
+
+static ColParams col_params(const void* x, void* col, int B, int C, int H, int W, int stride) {
+  ColParams p;
+  p.x = (const u16*)x;
+  p.col = (u16*)col;
+  p.B = B;
+  p.C = C;
+  p.H = H;
+  p.W = W;
+  p.stride = stride;
+  p.Ho = (H + 2 - 3) / stride + 1;
+  p.Wo = (W + 2 - 3) / stride + 1;
+  p.Kp = (C * 9 + 7) / 8 * 8;
+  return p;
+}
+
+extern "C" int ssdk_im2col3x3(const void* x, void* col, int B, int C, int H, int W, int stride, int dtype, void* stream) {
+  int rc = col_check(x, col, B, C, H, W, stride, dtype, "ssdk_im2col3x3");
+  if (rc) return rc;
+  const ColParams p = col_params(x, col, B, C, H, W, stride);
+  const size_t total = (size_t)B * p.Kp * (((size_t)p.Ho * p.Wo + 7) / 8);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("im2col3x3_kernel");
+}
+
+extern "C" int ssdk_col2im3x3(const void* dcol, void* dx, int B, int C, int H, int W, int stride, int dtype, void* stream) {
+  int rc = col_check(dcol, dx, B, C, H, W, stride, dtype, "ssdk_col2im3x3");
+  if (rc) return rc;
+  ColParams p = col_params(dx, const_cast<void*>(dcol), B, C, H, W, stride);
+  const size_t total = (size_t)B * C * (((size_t)H * W + 7) / 8);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  if (dtype == SSDK_BF16) hipLaunchKernelGGL(col2im3x3_kernel<SSDK_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(col2im3x3_kernel<SSDK_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("col2im3x3_kernel");
 }

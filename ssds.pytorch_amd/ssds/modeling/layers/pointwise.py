@@ -168,3 +168,123 @@ def use_pointwise_gemm(model):
                 and m.groups == 1 and m.dilation == (1, 1)):
             m.__class__ = PointwiseConv2d
     return model
+
+
+# ---- dense 3x3 convolutions of the training step on the same kernels (csrc/ssdk_pwtrain.hip, second half) -----------------------
+_COL_CACHE = {"x": None, "stride": 0, "col": None, "ver": -1}  # the loc and conf heads of a level read the SAME feature map (ssd.py:100-103)
+
+
+def _im2col(x, stride):
+    c = _COL_CACHE
+    if c["x"] is x and c["stride"] == stride and c["ver"] == x._version:
+        return c["col"]
+    b, cin, h, w = (int(v) for v in x.shape)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    kp = (cin * 9 + 7) // 8 * 8
+    col = torch.empty((b, kp, ho * wo), device=x.device, dtype=x.dtype)
+    N.check(N.lib.ssdk_im2col3x3(x.data_ptr(), col.data_ptr(), b, cin, h, w, stride, N.dtype_code(x), N.stream_ptr(x.device)), "im2col3x3")
+    c.update(x=x, stride=stride, col=col, ver=x._version)
+    return col
+
+
+def release_col_cache():
+    """Drop the one cached im2col tensor (it is kept alive until the next 3x3 layer runs otherwise)."""
+    _COL_CACHE.update(x=None, col=None, stride=0, ver=-1)
+
+
+class _Conv3x3Native(torch.autograd.Function):
+    """3x3 / pad 1 / stride 1 | 2 on a 16-bit NCHW tensor: im2col + the 1x1 kernels (see csrc/ssdk_pwtrain.hip).  weight
+    [Cout, Cin, 3, 3] fp32 (master parameter under autocast) or 16-bit; bias or None."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride):
+        b, cin, h, wd = (int(v) for v in x.shape)
+        cout, dev, dt = int(w.shape[0]), x.device, x.dtype
+        ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
+        code = N.dtype_code(x)
+        x = x.detach()
+        with torch.cuda.device(dev):
+            sp = N.stream_ptr(dev)
+            col = _im2col(x, stride)
+            kp = int(col.shape[1])
+            w2 = w.detach().reshape(cout, cin * 9)
+            if kp != cin * 9:
+                w2 = torch.nn.functional.pad(w2, (0, kp - cin * 9))
+            if w2.dtype == torch.float32:
+                w16 = torch.empty((cout, kp), device=dev, dtype=dt)
+                wt16 = torch.empty((kp, cout), device=dev, dtype=dt)
+                N.check(N.lib.ssdk_pw_prepare(w2.contiguous().data_ptr(), w16.data_ptr(), wt16.data_ptr(), cout, kp, code, sp), "pw_prepare")
+            else:
+                w16 = w2.contiguous()
+                wt16 = w16.t().contiguous()
+            b32 = None if bias is None else bias.detach().float().contiguous()
+            y = torch.empty((b, cout, ho, wo), device=dev, dtype=dt)
+            N.check(N.lib.ssdk_pw_forward(col.data_ptr(), w16.data_ptr(), None if b32 is None else b32.data_ptr(), y.data_ptr(),
+                                          b, kp, cout, ho * wo, code, sp), "pw_forward (3x3)")
+        ctx.save_for_backward(col, wt16)
+        ctx.meta = (w.dtype, None if bias is None else bias.dtype, (b, cin, h, wd), stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        col, wt16 = ctx.saved_tensors
+        wdt, bdt, (b, cin, h, wd), stride = ctx.meta
+        kp, cout = (int(v) for v in wt16.shape)
+        hwo, dev, dt = int(col.shape[2]), col.device, col.dtype
+        gy = gy.contiguous()
+        if gy.dtype != dt:
+            gy = gy.to(dt)
+        code = N.dtype_code(col)
+        gx = gw = gb = None
+        with torch.cuda.device(dev):
+            sp = N.stream_ptr(dev)
+            if ctx.needs_input_grad[0]:
+                if cout % 8 == 0:
+                    dcol = torch.empty_like(col)
+                    N.check(N.lib.ssdk_pw_forward(gy.data_ptr(), wt16.data_ptr(), None, dcol.data_ptr(), b, cout, kp, hwo, code, sp),
+                            "pw_forward (3x3 input gradient)")
+                else:
+                    dcol = torch.matmul(wt16, gy.view(b, cout, hwo)).contiguous()
+                gx = torch.empty((b, cin, h, wd), device=dev, dtype=dt)
+                N.check(N.lib.ssdk_col2im3x3(dcol.data_ptr(), gx.data_ptr(), b, cin, h, wd, stride, code, sp), "col2im3x3")
+            if ctx.needs_input_grad[1]:
+                need = int(N.lib.ssdk_pw_wgrad_workspace_bytes(b, cout, kp, hwo))
+                ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                gw32 = torch.empty((cout, kp), device=dev, dtype=torch.float32)
+                N.check(N.lib.ssdk_pw_wgrad(gy.data_ptr(), col.data_ptr(), gw32.data_ptr(), ws.data_ptr(), need, b, cout, kp, hwo, code, sp),
+                        "pw_wgrad (3x3)")
+                gw = gw32[:, : cin * 9].reshape(cout, cin, 3, 3)
+                gw = gw if wdt == torch.float32 else gw.to(wdt)
+        if bdt is not None and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3), dtype=torch.float32).to(bdt)
+        return gx, gw, gb, None
+
+
+class NativeConv3x3(nn.Conv2d):
+    """``nn.Conv2d(k = 3, pad = 1, stride 1 | 2)`` whose 16-bit HIP-device forward / backward run on the ssdk kernels (same
+    parameters, ``state_dict`` keys and initialisation); everything else is ``nn.Conv2d.forward``."""
+
+    def _native(self, x):
+        return (x.is_cuda and x.dim() == 4 and self.kernel_size == (3, 3) and self.padding == (1, 1) and self.dilation == (1, 1)
+                and self.stride in ((1, 1), (2, 2)) and self.groups == 1 and self.padding_mode == "zeros" and x.is_contiguous()
+                and os.environ.get("SSDK_CONV3_NATIVE", "1") != "0")
+
+    def forward(self, x):
+        if not self._native(x):
+            return super(NativeConv3x3, self).forward(x)
+        w, bias = self.weight, self.bias
+        if torch.is_autocast_enabled():
+            x = x.to(torch.get_autocast_dtype("cuda"))
+        if x.dtype not in (torch.bfloat16, torch.float16) or (w.dtype != torch.float32 and w.dtype != x.dtype):
+            return super(NativeConv3x3, self).forward(x)
+        with torch.autocast("cuda", enabled=False):
+            return _Conv3x3Native.apply(x, w, bias, self.stride[0])
+
+
+def use_native_conv3x3(model):
+    """Switch every dense 3x3 / pad 1 / stride 1 | 2 ``nn.Conv2d`` of ``model`` to the kernel-backed subclass (in place)."""
+    for m in model.modules():
+        if (type(m) is nn.Conv2d and m.kernel_size == (3, 3) and m.padding == (1, 1) and m.stride in ((1, 1), (2, 2))
+                and m.groups == 1 and m.dilation == (1, 1) and m.padding_mode == "zeros"):
+            m.__class__ = NativeConv3x3
+    return model

@@ -111,11 +111,15 @@ def _ensure_momentum_buffers(optimizer):
     inside its first step and returns early when ``found_inf`` is set: a skipped FIRST step would leave uninitialised
     memory behind as momentum.  With zero buffers in place the first real step computes ``0 * momentum + grad`` -- exactly
     the first-step rule (dampening is 0 in core/optimizer.configure_optimizer)."""
+    from ssds.core.optimizer import SsdkSGD
+
+    if isinstance(optimizer, SsdkSGD):
+        return  # (csrc/ssdk_sgd.hip's host side creates missing buffers as zeros itself, skipped step or not)
     for group in optimizer.param_groups:
         if not group.get("momentum"):
             continue
-        for p in group["params"]:
-            if p.requires_grad and "momentum_buffer" not in optimizer.state[p]:
+        for p in group["params"]:  # only parameters that take part in this step (ADVICE round 5: not every requires_grad one)
+            if p.grad is not None and "momentum_buffer" not in optimizer.state[p]:
                 optimizer.state[p]["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
 
 
@@ -141,6 +145,16 @@ def _step_unless(optimizer, bad):
     return skipped
 
 
+def float_lr_state_dict(optimizer):
+    """``optimizer.state_dict()`` with every tensor-valued ``lr`` (GraphedTrainStep makes them device tensors) as a float: the
+    form core/checkpoint.py and the reference's checkpoints store."""
+    sd = optimizer.state_dict()
+    for g in sd["param_groups"]:
+        if isinstance(g.get("lr"), torch.Tensor):
+            g["lr"] = float(g["lr"])
+    return sd
+
+
 class GraphedTrainStep(object):
     """The whole training step (forward under autocast, fused target assignment + losses, backward, device-side skip,
     fused optimizer update: ~600 launches) captured ONCE as a hipGraph and replayed with one launch per step
@@ -151,7 +165,10 @@ class GraphedTrainStep(object):
     What a captured step freezes, and what it does not:
       * the LEARNING RATE stays live: every parameter group's ``lr`` is turned into a device tensor before the capture
         (fused SGD reads it on the device), and torch's schedulers update a tensor ``lr`` in place (``fill_``), so
-        ``lr_scheduler.step()`` / a warm-up that assigns through ``set_lr`` reach the replayed kernels;
+        ``lr_scheduler.step()`` / a warm-up that assigns through ``set_lr`` reach the replayed kernels.  SIDE EFFECT: the
+        caller's ``param_group["lr"]`` stays a device tensor afterwards -- printing it synchronises, and
+        ``optimizer.state_dict()`` would serialise tensors; ``float_lr_state_dict(optimizer)`` returns the state dict with
+        plain floats for checkpoints;
       * momentum, weight decay, nesterov are kernel ARGUMENTS of the captured launch: changing them afterwards needs a new
         GraphedTrainStep;
       * the ``warmup`` eager steps (>= 1: allocator pools, MIOpen / rocBLAS plans, the optimizer's lazily created state --

@@ -47,7 +47,14 @@ class Solver(object):
         if os.environ.get("SSDK_PW_GEMM", "1") != "0":
             from ssds.modeling.layers.pointwise import use_pointwise_gemm
 
-            use_pointwise_gemm(self.model)  # 1x1 convolutions as batched GEMMs on the NCHW tensors (no layout changes)
+            use_pointwise_gemm(self.model)  # 1x1 convolutions on the NCHW tensors (16 bit: csrc/ssdk_pwtrain.hip; fp32: library GEMMs)
+        if os.environ.get("SSDK_CONV3_NATIVE", "0") == "1":
+            # stem / extras / head 3x3 convolutions as im2col + the same kernels.  Correct (tests/test_gpu_train.py) and OFF by
+            # default: measured 23.2 vs 20.8 ms per step against MIOpen's implicit-GEMM kernels (round 6, session 4: the streaming
+            # 1x1 kernels are the wrong shape for K = 864 ... 4608 at 480 output channels)
+            from ssds.modeling.layers.pointwise import use_native_conv3x3
+
+            use_native_conv3x3(self.model)
         self.model.to(self.device)
         if render and local_rank == 0:
             print("Model architectures:\n{}\n".format(self.model))
