@@ -61,8 +61,13 @@ constexpr int s3_wpc(int cs) { return cs <= 4 ? 2 : 1; }  // workgroups per CU t
 // CS = Cin / 32.  NCHW: split-plane output with none | sigmoid | silu per column (the heads); else NHWC output with
 // none | relu | relu6 (tower / body layers).  The activation class is fixed at compile time: the epilogue must be
 // straight-line code to be scheduled between the MFMAs.
-template <int DT, int CS, bool NCHW>
+// WIDE (round 6, NCHW only): the two channel fragments (j = 0, 1) of a pixel fragment are finished TOGETHER and trade halves with
+// v_permlane16_swap_b32 -- lane rows 0 / 2 end with 8 consecutive pixels of channel j = 0, rows 1 / 3 with 8 of channel j = 1 -- so
+// the 68.8 MB of the first head level leave in 16-byte stores instead of 8-byte ones.  Needs the
+// lane's 8 pixels in one map row: Wo % 8 == 0.
+template <int DT, int CS, bool NCHW, bool WIDE = false>
 __global__ __launch_bounds__(S3_THREADS, s3_wpc(CS)) void conv3x3_short_kernel(const ShortParams sp) {
+  static_assert(!WIDE || NCHW, "the paired epilogue is the NCHW one");
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const ConvParams& p = sp.c;
   // halo row stride (bytes): an odd number of 16-byte chunks.  (Measured against 256-byte rows with the 16-byte slot XOR-ed by
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(S3_THREADS, s3_wpc(CS)) void conv3x3_short_kernel(c
   u32 o_off[MI];  // oy * Wo + ox, or ~0 outside the map
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const u32 ml = (u32)i * 16u + (NCHW ? fg * 4u : fr);
+    const u32 ml = (u32)i * 16u + (NCHW ? (WIDE ? (fg >> 1) * 8u : fg * 4u) : fr);
     const int oy = y0 + (int)(ml >> sp.tw_shift), ox = x0 + (int)(ml & (u32)(sp.tw - 1));
     o_off[i] = (oy < p.Ho && ox < p.Wo) ? (u32)(oy * p.Wo + ox) : 0xffffffffu;
   }
@@ -208,6 +213,38 @@ __global__ __launch_bounds__(S3_THREADS, s3_wpc(CS)) void conv3x3_short_kernel(c
       __builtin_amdgcn_raw_buffer_store_b64(v2u{h.x, h.y}, yr1, (int)(ok ? off : 0xfffffff0u), 0, 0);
     }
   };
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  auto epi_pair = [&](const f32x4& a0, const f32x4& a1, int i) {  // WIDE: fragments (i, 0) and (i, 1) of the finished tile
+    uint2 h[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const u32 n = e_n0 + (u32)j * 16u;
+      const int mode = (int)n >= p.split ? as_b.mode : as_a.mode;
+      const f32x4& a = j ? a1 : a0;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = a[r] * e_sc[j][0] + e_bi[j][0];
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * v[r]));
+        const float t = v[r] * sg;
+        const float u = mode == 1 ? sg : v[r];
+        v[r] = mode == 2 ? t : u;
+      }
+      h[j] = make_uint2(pack2_16<DT>(v[0], v[1]), pack2_16<DT>(v[2], v[3]));
+    }
+    // rows (fg) 1 / 3 of the j = 0 words trade places with rows 0 / 2 of the j = 1 words: the first result of a lane in row 0 | 1 |
+    // 2 | 3 is (j 0, fg 0) | (j 1, fg 0) | (j 0, fg 2) | (j 1, fg 2), the second (j 0, fg 1) | (j 1, fg 1) | (j 0, fg 3) | (j 1, fg 3)
+    const v2u sx = __builtin_amdgcn_permlane16_swap(h[0].x, h[1].x, false, false);
+    const v2u sy = __builtin_amdgcn_permlane16_swap(h[0].y, h[1].y, false, false);
+    const u32 n = e_n0 + (fg & 1u) * 16u;  // the channel this lane now holds 8 pixels of
+    const bool second = (int)n >= p.split;
+    const u32 plane = second ? ((b * (u32)(p.Cout - p.split) + (n - (u32)p.split)) * hw) * 2u : ((b * (u32)p.split + n) * hw) * 2u;
+    const bool ok = n < (u32)p.Cout && o_off[i] != 0xffffffffu;
+    const u32 off = plane + o_off[i] * 2u;
+    const v4u o = {sx.x, sy.x, sx.y, sy.y};
+    __builtin_amdgcn_raw_buffer_store_b128(o, yr1, (int)(ok && !second ? off : 0xfffffff0u), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(o, yr2, (int)(ok && second ? off : 0xfffffff0u), 0, 0);
+  };
   __syncthreads();
 
   u32x4 fa[PREF ? 2 : 1][MI];
@@ -251,8 +288,14 @@ __global__ __launch_bounds__(S3_THREADS, s3_wpc(CS)) void conv3x3_short_kernel(c
           acc[i][j] = NCHW ? mfma16<DT>(fa[PREF ? ks & 1 : 0][i], fbq[ks % 3][j], acc[i][j])
                            : mfma16<DT>(fbq[ks % 3][j], fa[PREF ? ks & 1 : 0][i], acc[i][j]);
       if (EPI) {
+        if constexpr (WIDE) {  // pairs: fragments 2 q, 2 q + 1 in the k-step that used to finish fragment 2 q
 #pragma unroll
-        for (int e = ks * FPS; e < (ks + 1) * FPS && e < 16; ++e) epi_frag(prev[e / NJ][e % NJ], e / NJ, e % NJ);
+          for (int e = ks * FPS; e < (ks + 1) * FPS && e < 16; ++e)
+            if ((e & 1) == 0) epi_pair(prev[e / NJ][0], prev[e / NJ][1], e / NJ);
+        } else {
+#pragma unroll
+          for (int e = ks * FPS; e < (ks + 1) * FPS && e < 16; ++e) epi_frag(prev[e / NJ][e % NJ], e / NJ, e % NJ);
+        }
       }
       {
         const int k3 = ks + 3;  // the B fragments of step ks + 3 into the set just used
@@ -267,7 +310,7 @@ __global__ __launch_bounds__(S3_THREADS, s3_wpc(CS)) void conv3x3_short_kernel(c
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 4 * FPS, 0);  // VALU
+          __builtin_amdgcn_sched_group_barrier(0x002, (WIDE ? 8 : 4) * FPS, 0);  // VALU
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -299,9 +342,14 @@ __global__ __launch_bounds__(S3_THREADS, s3_wpc(CS)) void conv3x3_short_kernel(c
   for (u32 nt = t0 + 1u; nt < t1; ++nt) run_tile(nt, std::true_type{});
   // the last tile's epilogue has no main loop to hide behind
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < MI; ++i) {
+    if constexpr (WIDE) {
+      epi_pair(prev[i][0], prev[i][1], i);
+    } else {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) epi_frag(prev[i][j], i, j);
+      for (int j = 0; j < NJ; ++j) epi_frag(prev[i][j], i, j);
+    }
+  }
 }
 
 // 1: not one of this kernel's layers (the caller goes on), 0: launched
@@ -374,16 +422,25 @@ int launch_conv3x3_short(const ConvParams& p, int dtype, hipStream_t stream) {
     sp.y2bytes = (unsigned)b2;
   }
   const unsigned grid = (unsigned)(patches * nsplit);
+  static const int env_wide = getenv("SSDK_S3_WIDE") ? atoi(getenv("SSDK_S3_WIDE")) : 1;
+  const bool wide = env_wide && nchw && (p.Wo & 7) == 0 && sp.tw >= 8;
 #define SSDK_S3(DT, CS_, NCHW_)                                                                                              \
   do {                                                                                                                     \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_short_kernel<DT, CS_, NCHW_>),                        \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
     hipLaunchKernelGGL((conv3x3_short_kernel<DT, CS_, NCHW_>), dim3(grid), dim3(S3_THREADS), lds, stream, sp);             \
   } while (0)
-#define SSDK_S3A(DT, CS_)              \
-  do {                                 \
-    if (nchw) SSDK_S3(DT, CS_, true);  \
-    else SSDK_S3(DT, CS_, false);      \
+#define SSDK_S3W(DT, CS_)                                                                                                   \
+  do {                                                                                                                     \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_short_kernel<DT, CS_, true, true>),                   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
+    hipLaunchKernelGGL((conv3x3_short_kernel<DT, CS_, true, true>), dim3(grid), dim3(S3_THREADS), lds, stream, sp);        \
+  } while (0)
+#define SSDK_S3A(DT, CS_)                      \
+  do {                                         \
+    if (nchw && wide) SSDK_S3W(DT, CS_);       \
+    else if (nchw) SSDK_S3(DT, CS_, true);     \
+    else SSDK_S3(DT, CS_, false);              \
   } while (0)
 #define SSDK_S3C(DT)                     \
   do {                                   \
@@ -397,6 +454,7 @@ int launch_conv3x3_short(const ConvParams& p, int dtype, hipStream_t stream) {
   else SSDK_S3C(SSDK_F16);
 #undef SSDK_S3C
 #undef SSDK_S3A
+#undef SSDK_S3W
 #undef SSDK_S3
   return 0;
 }

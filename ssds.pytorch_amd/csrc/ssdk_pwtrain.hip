@@ -407,6 +407,83 @@ __global__ __launch_bounds__(PWT_THREADS) void pw_wgrad_kernel(const PwgParams p
     }
 }
 
+// ---- weight gradient of the layers whose [Cout, Cin] matrix is large on BOTH sides (the 32 x 32 / 16 x 16 blocks: 64 ... 960
+// channels either side).  The streaming kernel above re-reads dy once per column tile and x once per row tile -- 4.3 x the bytes
+// on 96 -> 576 -- in 16-row x 64-byte pieces: 0.2 of the roof there.  Here a workgroup owns a 128 x 128 tile of dW and walks
+// over pixels in chunks of 128: both operand tiles are staged in LDS with full-row 256-byte global reads (12 independent
+// 16-byte loads per thread per chunk, the next chunk's requested before this chunk's MFMAs), a wave reads its 4 + 4 fragments
+// per k-step from LDS (row stride 288 bytes = 18 x 16: conflict-free for the lane groups of ds_read_b128).
+constexpr u32 PWG_RS = 288;
+constexpr size_t PWG_LDS = 2 * 128 * PWG_RS;
+
+template <int DT>
+__global__ __launch_bounds__(PWT_THREADS) void pw_wgrad_tiled_kernel(const PwgParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* la = smem;
+  unsigned char* lb = smem + 128 * PWG_RS;
+  const u32 tid = threadIdx.x, lane = tid & 63u;
+  const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const u32 fr = lane & 15u, fg = lane >> 4, wm = wave >> 1, wn = wave & 1u;
+  const u32 tiles = p.mt * p.nt;
+  const u32 tile = blockIdx.x % tiles, s = blockIdx.x / tiles;
+  const u32 m0 = (tile / p.nt) * 128u, n0 = (tile % p.nt) * 128u;
+  const u32 Cout = (u32)p.Cout, Cin = (u32)p.Cin, HW = (u32)p.HW;
+  const u32 r16 = tid >> 4, c16 = tid & 15u;  // staging role: row r16 (+ 16 per pass), 16-byte column c16 of the 256-byte row
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const u32 c_begin = s * p.cps, c_end = min(p.chunks, (s + 1u) * p.cps);
+  u32x4 va[8], vb[8];
+  auto fetch = [&](u32 c) {
+    const u32 b = c / p.cpi, p0 = (c - b * p.cpi) * 128u + 8u * c16;
+    const int nvalid = (int)HW - (int)p0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const u32 ra = m0 + (u32)q * 16u + r16, rb = n0 + (u32)q * 16u + r16;
+      va[q] = ra < Cout ? pw_load8<true>(p.dy + ((size_t)b * Cout + ra) * HW + p0, nvalid) : u32x4{0u, 0u, 0u, 0u};
+      vb[q] = rb < Cin ? pw_load8<true>(p.x + ((size_t)b * Cin + rb) * HW + p0, nvalid) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  if (c_begin < c_end) fetch(c_begin);
+  for (u32 c = c_begin; c < c_end; ++c) {
+    __syncthreads();  // every wave is done with the previous chunk's fragments
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      *reinterpret_cast<u32x4*>(la + ((u32)q * 16u + r16) * PWG_RS + c16 * 16u) = va[q];
+      *reinterpret_cast<u32x4*>(lb + ((u32)q * 16u + r16) * PWG_RS + c16 * 16u) = vb[q];
+    }
+    __syncthreads();
+    if (c + 1u < c_end) fetch(c + 1u);  // travels under this chunk's MFMAs
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      u32x4 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *reinterpret_cast<const u32x4*>(la + (64u * wm + 16u * (u32)i + fr) * PWG_RS + (u32)u * 64u + fg * 16u);
+        bf[i] = *reinterpret_cast<const u32x4*>(lb + (64u * wn + 16u * (u32)i + fr) * PWG_RS + (u32)u * 64u + fg * 16u);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<DT>(af[i], bf[j], acc[i][j]);
+    }
+  }
+  float* ws = p.ws + (size_t)s * Cout * Cin;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 ci = n0 + 64u * wn + 16u * (u32)j + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const u32 co = m0 + 64u * wm + 16u * (u32)i + 4u * fg + (u32)r;
+        if (co < Cout && ci < Cin) ws[(size_t)co * Cin + ci] = acc[i][j][r];
+      }
+    }
+}
+
 // rows [by * 64, by * 64 + 64) of a [rows][n] fp32 matrix summed per element in a FIXED order: thread (element, quarter kq) adds its
 // 16 rows one after the other (sixteen independent coalesced loads), the four quarters are added in order 0..3.  Applied until one
 // row is left (<= 4096 partials: two passes).  (As first written ONE thread per element walked all <= 2048 partials: 6 workgroups,
@@ -426,21 +503,35 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float* in, f
   if (kq == 0 && i < n) out[(size_t)blockIdx.y * n + i] = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
 }
 
-static void pw_wgrad_plan(int B, int Cout, int Cin, int HW, PwgParams* p, int* mfw, int* nfw) {
+// -> true: the LDS-tiled kernel (128 x 128 tiles of dW), false: the streaming kernel (wave tiles of mfw x nfw fragments)
+static bool pw_wgrad_plan(int B, int Cout, int Cin, int HW, PwgParams* p, int* mfw, int* nfw) {
   const int mf = (Cout + 15) / 16, nf = (Cin + 15) / 16;
-  // wave tile: 3 x 2 fragments (20 vectors of 16 bytes in flight per lane), 3 x 1 for narrow inputs
-  *mfw = mf >= 3 ? 3 : mf;
-  *nfw = nf >= 2 ? 2 : 1;
-  p->mt = (u32)((mf + *mfw - 1) / *mfw);
-  p->nt = (u32)((nf + *nfw - 1) / *nfw);
   p->cpi = (u32)((HW + 127) / 128);
   p->chunks = (u32)B * p->cpi;
-  const u32 tiles = p->mt * p->nt;
-  u32 splits = 4096u / tiles;  // ~16 waves per CU
+  static const int env_tiled = getenv("SSDK_PW_WGRAD_TILED") ? atoi(getenv("SSDK_PW_WGRAD_TILED")) : 1;
+  const bool tiled = env_tiled && mf >= 4 && nf >= 4;
+  u32 tiles, target;
+  if (tiled) {
+    *mfw = *nfw = 8;
+    p->mt = (u32)((Cout + 127) / 128);
+    p->nt = (u32)((Cin + 127) / 128);
+    tiles = p->mt * p->nt;
+    target = 512u;  // workgroups: two per CU
+  } else {
+    // wave tile: 3 x 2 fragments (20 vectors of 16 bytes in flight per lane), 3 x 1 for narrow inputs
+    *mfw = mf >= 3 ? 3 : mf;
+    *nfw = nf >= 2 ? 2 : 1;
+    p->mt = (u32)((mf + *mfw - 1) / *mfw);
+    p->nt = (u32)((nf + *nfw - 1) / *nfw);
+    tiles = p->mt * p->nt;
+    target = 4096u;  // waves: ~16 per CU
+  }
+  u32 splits = target / tiles;
   if (splits < 1u) splits = 1u;
   if (splits > p->chunks) splits = p->chunks;
   p->cps = (p->chunks + splits - 1u) / splits;
   p->splits = (p->chunks + p->cps - 1u) / p->cps;
+  return tiled;
 }
 
 }  // namespace ssdk
@@ -490,7 +581,7 @@ extern "C" int ssdk_pw_wgrad(const void* dy, const void* x, float* dw, void* ws,
   }
   PwgParams p;
   int mfw, nfw;
-  pw_wgrad_plan(B, Cout, Cin, HW, &p, &mfw, &nfw);
+  const bool tiled = pw_wgrad_plan(B, Cout, Cin, HW, &p, &mfw, &nfw);
   if (ws_bytes < ((size_t)p.splits + (size_t)((p.splits + 63u) / 64u)) * (size_t)Cout * (size_t)Cin * sizeof(float)) {
     set_error("ssdk_pw_wgrad: workspace too small");
     return SSDK_E_WORKSPACE;
@@ -503,8 +594,17 @@ extern "C" int ssdk_pw_wgrad(const void* dy, const void* x, float* dw, void* ws,
   p.Cin = Cin;
   p.HW = HW;
   const u32 items = p.mt * p.nt * p.splits;
-  const dim3 grid((items + 3u) / 4u);
+  const dim3 grid(tiled ? items : (items + 3u) / 4u);
   hipStream_t st = (hipStream_t)stream;
+  if (tiled) {
+    if (dtype == SSDK_BF16) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_tiled_kernel<SSDK_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PWG_LDS);
+      hipLaunchKernelGGL((pw_wgrad_tiled_kernel<SSDK_BF16>), grid, dim3(PWT_THREADS), PWG_LDS, st, p);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_tiled_kernel<SSDK_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PWG_LDS);
+      hipLaunchKernelGGL((pw_wgrad_tiled_kernel<SSDK_F16>), grid, dim3(PWT_THREADS), PWG_LDS, st, p);
+    }
+  } else {
 #define SSDK_PWG(DT, MF_, NF_) hipLaunchKernelGGL((pw_wgrad_kernel<DT, MF_, NF_>), grid, dim3(PWT_THREADS), 0, st, p)
 #define SSDK_PWGD(DT)                                  \
   do {                                                 \
@@ -519,7 +619,8 @@ extern "C" int ssdk_pw_wgrad(const void* dy, const void* x, float* dw, void* ws,
   else SSDK_PWGD(SSDK_F16);
 #undef SSDK_PWGD
 #undef SSDK_PWG
-  int rc = check_launch("pw_wgrad_kernel");
+  }
+  int rc = check_launch(tiled ? "pw_wgrad_tiled_kernel" : "pw_wgrad_kernel");
   if (rc) return rc;
   const u32 n = (u32)Cout * (u32)Cin;
   const float* src = (const float*)ws;

@@ -67,12 +67,14 @@ class _BatchNormTrain(torch.autograd.Function):
 
 class FastBatchNorm2d(nn.BatchNorm2d):
     _ssdk_act = 0  # 1 ReLU6 | 2 ReLU folded into the kernels (set per instance by fuse_bn_activations)
+    _ssdk_counter_external = False  # True: somebody bumps num_batches_tracked for ALL layers in one launch (bump_counters)
 
     def forward(self, x):
         if not (self.training and x.is_cuda and x.dim() == 4 and self.affine and self.track_running_stats
                 and x.dtype in (torch.float32, torch.bfloat16, torch.float16) and self.weight.dtype == torch.float32):
             return super(FastBatchNorm2d, self).forward(x)
-        self.num_batches_tracked.add_(1)  # nn.BatchNorm2d bookkeeping (batchnorm.py of torch)
+        if not self._ssdk_counter_external:
+            self.num_batches_tracked.add_(1)  # nn.BatchNorm2d bookkeeping (batchnorm.py of torch)
         momentum = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
         with torch.autocast("cuda", enabled=False):
             y = _BatchNormTrain.apply(x, self.weight, self.bias, self.running_mean, self.running_var, momentum, self.eps,
@@ -80,6 +82,29 @@ class FastBatchNorm2d(nn.BatchNorm2d):
         if self._ssdk_act:
             y._ssdk_act_applied = self._ssdk_act  # read by the activation module that follows (and by nothing else)
         return y
+
+
+def bump_counters(model):
+    """``num_batches_tracked += 1`` for every kernel-backed BatchNorm of ``model`` in ONE multi-tensor launch, instead of one
+    4.5 us launch per layer inside each forward (59 layers in SSD-MobileNetV2: 0.27 ms of a 20 ms step).  The caller owns the
+    bookkeeping for THIS forward: call it right before a training forward and ``release_counters`` behind it
+    (pipeline_anchor_ddp.ModelWithLossBasic does).  -> the layers that were bumped."""
+    cache = model.__dict__.get("_ssdk_bn_counters")
+    if cache is None:
+        cache = [m for m in model.modules() if type(m) is FastBatchNorm2d and m.track_running_stats]
+        model.__dict__["_ssdk_bn_counters"] = cache
+    live = [m for m in cache if m.training]
+    for m in live:
+        m._ssdk_counter_external = True
+    if live:
+        torch._foreach_add_([m.num_batches_tracked for m in live], 1)
+    return live
+
+
+def release_counters(live):
+    """The layers bump their own counter again (a forward outside the training module: BatchNorm calibration, tests)."""
+    for m in live:
+        m._ssdk_counter_external = False
 
 
 def use_fast_batchnorm(model):

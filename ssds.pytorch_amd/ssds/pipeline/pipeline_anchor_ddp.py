@@ -43,7 +43,16 @@ class ModelWithLossBasic(torch.nn.Module):
                 and os.environ.get("SSDK_FUSED_LOSS", "1") != "0")
 
     def forward(self, images, targets, anchors):
-        loc, conf = self.model(images)
+        if self.training and getattr(images, "is_cuda", False):
+            from ssds.modeling.layers.batchnorm import bump_counters, release_counters
+
+            live = bump_counters(self.model)  # num_batches_tracked of every kernel-backed BatchNorm: one launch, not one per layer
+            try:
+                loc, conf = self.model(images)
+            finally:
+                release_counters(live)
+        else:
+            loc, conf = self.model(images)
         cls_losses, loc_losses, fg_targets = [], [], []
         fused = self._fused(conf)
         if fused:
@@ -106,20 +115,22 @@ def _device_skip(optimizer):
     return len(optimizer.param_groups) > 0 and all(g.get("fused") for g in optimizer.param_groups)
 
 
-def _ensure_momentum_buffers(optimizer):
+def _ensure_momentum_buffers(optimizer, every=False):
     """Zero momentum buffers for every parameter that has none yet.  torch's fused SGD allocates them with ``empty_like``
     inside its first step and returns early when ``found_inf`` is set: a skipped FIRST step would leave uninitialised
     memory behind as momentum.  With zero buffers in place the first real step computes ``0 * momentum + grad`` -- exactly
     the first-step rule (dampening is 0 in core/optimizer.configure_optimizer)."""
     from ssds.core.optimizer import SsdkSGD
 
-    if isinstance(optimizer, SsdkSGD):
+    if isinstance(optimizer, SsdkSGD) and not every:
         return  # (csrc/ssdk_sgd.hip's host side creates missing buffers as zeros itself, skipped step or not)
     for group in optimizer.param_groups:
         if not group.get("momentum"):
             continue
-        for p in group["params"]:  # only parameters that take part in this step (ADVICE round 5: not every requires_grad one)
-            if p.grad is not None and "momentum_buffer" not in optimizer.state[p]:
+        # per step: only parameters that take part in it (ADVICE round 5: not every requires_grad one); ``every``: all trainable
+        # parameters (GraphedTrainStep: the state must exist BEFORE the warm-up so that the snapshot can restore zeros)
+        for p in group["params"]:
+            if (p.requires_grad if every else p.grad is not None) and "momentum_buffer" not in optimizer.state[p]:
                 optimizer.state[p]["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
 
 
@@ -188,7 +199,7 @@ class GraphedTrainStep(object):
         for group in optimizer.param_groups:  # a live learning rate (see the class comment)
             if not isinstance(group["lr"], torch.Tensor):
                 group["lr"] = torch.tensor(float(group["lr"]), device=dev, dtype=torch.float32)
-        _ensure_momentum_buffers(optimizer)
+        _ensure_momentum_buffers(optimizer, every=True)
         snap_model = [t.detach().clone() for t in list(model_with_loss.parameters()) + list(model_with_loss.buffers())]
         snap_opt = {p: {k: (v.detach().clone() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
                     for p, st in optimizer.state.items()}

@@ -58,6 +58,18 @@ def test_model_with_loss_matches_cpu_oracle_step():
     assert not skipped and torch.isfinite(after).all() and not torch.equal(before, after)
 
 
+def _sgd(kind, params, **kw):
+    """The two optimizers the step runs on: torch's fused multi-tensor SGD ("torch": rounds 4-5) and core/optimizer.SsdkSGD on
+    csrc/ssdk_sgd.hip ("ssdk": what core/optimizer.configure_optimizer builds on a HIP device since round 6)."""
+    import torch
+    from ssds.core.optimizer import SsdkSGD
+
+    return SsdkSGD(params, **kw) if kind == "ssdk" else torch.optim.SGD(params, fused=True, **kw)
+
+
+OPT_KINDS = pytest.mark.parametrize("opt_kind", ["ssdk", "torch"])
+
+
 def _tiny_step_setup(seed=0):
     import torch
     from ssds.core import criterion
@@ -78,7 +90,8 @@ def _tiny_step_setup(seed=0):
     return mwl.train(), images, targets, anchors
 
 
-def test_step_is_skipped_on_the_device_with_the_fused_optimizer():
+@OPT_KINDS
+def test_step_is_skipped_on_the_device_with_the_fused_optimizer(opt_kind):
     """train_step with the fused SGD core/optimizer.py builds on a HIP device: a non-finite loss leaves parameters AND
     momentum untouched without the flag ever being read back (``found_inf``), a finite one steps; same update as the plain
     optimizer (reference skip: pipeline_anchor_apex.py:110-111, 126-127)."""
@@ -88,7 +101,7 @@ def test_step_is_skipped_on_the_device_with_the_fused_optimizer():
 
     mwl, images, targets, anchors = _tiny_step_setup()
     ref = copy.deepcopy(mwl)
-    opt = torch.optim.SGD(mwl.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4, fused=True)
+    opt = _sgd(opt_kind, mwl.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     opt_ref = torch.optim.SGD(ref.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
     assert _device_skip(opt) and not _device_skip(opt_ref)
     flat = lambda m: torch.cat([p.detach().flatten() for p in m.parameters()])  # noqa: E731
@@ -111,7 +124,8 @@ def test_step_is_skipped_on_the_device_with_the_fused_optimizer():
     assert all(torch.equal(a, b) for a, b in zip(mom, mom2)), "... nor the momentum"
 
 
-def test_graphed_train_step_equals_the_eager_step():
+@OPT_KINDS
+def test_graphed_train_step_equals_the_eager_step(opt_kind):
     """GraphedTrainStep: forward, fused losses, backward, device-side skip and fused update captured once as a hipGraph.
     Each replay is checked against the eager step of a TWIN taken right before it (same parameters, same momentum: one step
     apart two copies do not drift), and a NaN image must leave the parameters untouched inside the captured step too."""
@@ -120,12 +134,12 @@ def test_graphed_train_step_equals_the_eager_step():
     from ssds.pipeline.pipeline_anchor_ddp import GraphedTrainStep, train_step
 
     mwl, images, targets, anchors = _tiny_step_setup(3)
-    opt = torch.optim.SGD(mwl.parameters(), lr=0.01, momentum=0.9, fused=True)
+    opt = _sgd(opt_kind, mwl.parameters(), lr=0.01, momentum=0.9)
     graphed = GraphedTrainStep(mwl, images, targets, anchors, opt, warmup=2)
     flat = lambda m: torch.cat([p.detach().flatten() for p in m.parameters()])  # noqa: E731
     for _ in range(3):
         twin = copy.deepcopy(mwl)
-        opt_twin = torch.optim.SGD(twin.parameters(), lr=0.01, momentum=0.9, fused=True)
+        opt_twin = _sgd(opt_kind, twin.parameters(), lr=0.01, momentum=0.9)
         opt_twin.load_state_dict(copy.deepcopy(opt.state_dict()))
         before = flat(mwl).clone()
         c, l, bad = graphed(images, targets)
@@ -147,7 +161,8 @@ def test_graphed_train_step_equals_the_eager_step():
     assert float(bad) == 1.0 and torch.equal(before, flat(mwl))
 
 
-def test_graphed_step_keeps_the_learning_rate_live_and_its_warmup_leaves_no_trace():
+@OPT_KINDS
+def test_graphed_step_keeps_the_learning_rate_live_and_its_warmup_leaves_no_trace(opt_kind):
     """(1) the eager warm-up steps of GraphedTrainStep are undone -- parameters, BatchNorm statistics and
     momentum are what they were before the constructor; (2) the learning rate is a device tensor the captured update reads
     at replay time: a scheduler step (torch fills a tensor lr in place) and ``set_lr`` both reach the replayed kernels;
@@ -157,7 +172,7 @@ def test_graphed_step_keeps_the_learning_rate_live_and_its_warmup_leaves_no_trac
     from ssds.pipeline.pipeline_anchor_ddp import GraphedTrainStep, train_step
 
     mwl, images, targets, anchors = _tiny_step_setup(5)
-    opt = torch.optim.SGD(mwl.parameters(), lr=0.02, momentum=0.9, fused=True)
+    opt = _sgd(opt_kind, mwl.parameters(), lr=0.02, momentum=0.9)
     flat = lambda m: torch.cat([p.detach().flatten() for p in m.parameters()])  # noqa: E731
     bufs = lambda m: torch.cat([b.detach().float().flatten() for b in m.buffers()])  # noqa: E731
     p0, b0 = flat(mwl).clone(), bufs(mwl).clone()
@@ -187,6 +202,29 @@ def test_graphed_step_keeps_the_learning_rate_live_and_its_warmup_leaves_no_trac
     bad_images[0, 0, 0, 0] = float("nan")
     c, l, skipped = train_step(mwl, bad_images, targets, anchors, opt)
     assert float(skipped) == 1.0 and not hasattr(opt, "found_inf") and not hasattr(opt, "grad_scale")
+
+
+def test_batchnorm_counters_are_bumped_once_per_training_forward():
+    """ModelWithLossBasic bumps num_batches_tracked of all kernel-backed BatchNorm layers in one launch per forward
+    (batchnorm.bump_counters) and hands the bookkeeping back afterwards: counters equal the number of training forwards, whether
+    the forward went through the training module or through the bare model; eval forwards do not count."""
+    import torch
+    from ssds.modeling.layers.batchnorm import FastBatchNorm2d, use_fast_batchnorm
+
+    mwl, images, targets, anchors = _tiny_step_setup(2)
+    use_fast_batchnorm(mwl.model)
+    bns = [m for m in mwl.model.modules() if type(m) is FastBatchNorm2d]
+    assert len(bns) > 30
+    for _ in range(2):
+        mwl(images, targets, anchors)
+    assert all(int(m.num_batches_tracked) == 2 for m in bns)
+    assert not any(m._ssdk_counter_external for m in bns)
+    mwl.model(images)  # the bare model in training mode: every layer bumps its own counter
+    assert all(int(m.num_batches_tracked) == 3 for m in bns)
+    mwl.eval()
+    with torch.no_grad():
+        mwl.model(images)
+    assert all(int(m.num_batches_tracked) == 3 for m in bns)
 
 
 @pytest.mark.parametrize("nesterov", [False, True])
@@ -232,14 +270,15 @@ def test_native_sgd_equals_torch_sgd(nesterov):
     o_ref.load_state_dict(sd)  # same keys as torch.optim.SGD
 
 
-def test_a_skipped_first_step_leaves_zero_momentum():
+@OPT_KINDS
+def test_a_skipped_first_step_leaves_zero_momentum(opt_kind):
     """the fused SGD allocates its momentum buffers with empty_like and returns early on found_inf --
     a skipped FIRST step must not leave uninitialised memory behind as momentum."""
     import torch
     from ssds.pipeline.pipeline_anchor_ddp import train_step
 
     mwl, images, targets, anchors = _tiny_step_setup(6)
-    opt = torch.optim.SGD(mwl.parameters(), lr=0.01, momentum=0.9, fused=True)
+    opt = _sgd(opt_kind, mwl.parameters(), lr=0.01, momentum=0.9)
     junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]  # poison what the allocator hands out next
     del junk
     bad_images = images.clone()
