@@ -159,6 +159,21 @@ def scan_traffic_bytes(cfg_stem=None):
     return None, None
 
 
+def scan_rocprof_avg_ns(cfg_stem=None):
+    """(average launch duration of scan16_kernel in ns, calls, source file) from the newest committed `rocprofv3 --kernel-trace
+    --stats` summary of this command (`profiles/r*_bench_kernel_stats_v*.csv`; another configuration's carries its cfg's name), or
+    (None, None, None).  The kernel trace times a launch by its own begin / end timestamps: no hipEvent interval (4.6 us on this
+    stack) inside the figure.  A REPLAYED measurement, like `traffic`: `frac_source` names the file."""
+    import csv
+
+    pat = "r*_bench_kernel_stats_v*.csv" if cfg_stem is None else "r*_bench_%s_kernel_stats_v*.csv" % cfg_stem
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))):
+        for row in csv.DictReader(open(f)):
+            if "scan16_kernel" in row["Name"] or "scan_kernel" in row["Name"]:
+                return float(row["AverageNs"]), int(row["Calls"]), os.path.relpath(f, ROOT)
+    return None, None, None
+
+
 def reference_cpu_record():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_reference.json")))
     if not files:
@@ -512,16 +527,14 @@ def main():
     stage_bytes = conf_bytes + loc_bytes + B * (2 * 24 * L * K + 24 * D)  # SURVEY.md 8d (1.465 MB/img at SSD@512 bf16)
 
     def stage(s_ms, t_ms, n_ms, whole_ms=None):
-        """kernels_ms: one hipEvent interval per launch (scan16 | tail2, or scan16 | levelsel | nmswalk with SSDK_TAIL2=0);
+        """kernels_ms: one hipEvent interval per launch (scan16 | levelsel | nmswalk);
         stage_ms: ONE interval around the launches (what `stage_frac` uses when it was measured: every extra event costs ~4.6 us of GPU time on this
         stack and flushes the caches between the kernels it separates); else the sum of the three."""
         tot = whole_ms if whole_ms else s_ms + t_ms + n_ms
-        two = float(n_ms) == 0.0  # tail2_kernel: level select + decode + NMS walk in ONE launch behind the scan
-        kern = ({"scan": round(float(s_ms), 5), "tail2 (levelsel + nmswalk in one launch)": round(float(t_ms), 5)} if two else
-                {"scan": round(float(s_ms), 5), "levelsel": round(float(t_ms), 5), "nmswalk": round(float(n_ms), 5)})
-        return {"launches": 2 if two else 3, "kernels_ms": kern,
+        kern = {"scan": round(float(s_ms), 5), "levelsel": round(float(t_ms), 5), "nmswalk": round(float(n_ms), 5)}
+        return {"launches": 3, "kernels_ms": kern,
                 "stage_ms": round(float(tot), 5),
-                "stage_ms_is": ("one event interval around the stage's %d launches" % (2 if two else 3)) if whole_ms else "sum of the intervals",
+                "stage_ms_is": "one event interval around the stage's 3 launches" if whole_ms else "sum of the intervals",
                 "scan_GBps": round(conf_bytes / (s_ms * 1e-3) / 1e9, 1),
                 "scan_frac": round(conf_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "stage_GBps": round(stage_bytes / (tot * 1e-3) / 1e9, 1),
@@ -530,13 +543,23 @@ def main():
     scan_gbs = conf_bytes / (scan_ms * 1e-3) / 1e9
     is_headline = os.path.basename(args.cfg) == "ssd_mobilenetv2_512.yml" and B == 64 and args.dtype == "bf16"
     traffic, traffic_src = scan_traffic_bytes(None if is_headline else os.path.splitext(os.path.basename(args.cfg))[0])
+    # `frac` (hygiene item 9): the figure that can be reproduced from profiles/ -- algorithmic bytes over the
+    # kernel's average duration in the committed rocprofv3 kernel trace of this command (all its launches: the timed loop's
+    # all-ties input and the realistic heads of the stage measurement).  The live in-loop figure (a hipEvent pair around the
+    # launch inside the timed region: + ~4.6 us of event interval, the forward's tail still draining) stays as `in_loop`.
+    rp_ns, rp_calls, rp_src = scan_rocprof_avg_ns(None if is_headline else os.path.splitext(os.path.basename(args.cfg))[0])
+    rp_gbs = conf_bytes / (rp_ns * 1e-9) / 1e9 if rp_ns else None
     roofline = {
         "kernel": "ssdk::scan16_kernel<%s> (threshold + exact top-k over the conf tensors, one pass)" % args.dtype,
         "bound": "hbm",
-        "achieved": round(scan_gbs, 1),
+        "achieved": round(rp_gbs if rp_gbs else scan_gbs, 1),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
-        "frac": round(scan_gbs / HBM_PEAK_GBS, 4),
+        "frac": round((rp_gbs if rp_gbs else scan_gbs) / HBM_PEAK_GBS, 4),
+        "frac_source": ("%s: AverageNs %.0f over %d launches of this command's rocprofv3 --kernel-trace --stats run (replayed, not "
+                        "a measurement of this run)" % (rp_src, rp_ns, rp_calls)) if rp_ns else "in_loop (no committed kernel trace of this configuration)",
+        "in_loop": {"achieved": round(scan_gbs, 1), "frac": round(scan_gbs / HBM_PEAK_GBS, 4), "avg_launch_ms": round(float(scan_ms), 5),
+                    "what": "hipEvents on the launch stream inside the timed region of THIS run, all-ties bench input"},
         "traffic": traffic,
         "traffic_source": (traffic_src + " (separate rocprofv3 --pmc FETCH_SIZE pass of this configuration's command, x2 gfx950 "
                            "correction; not a measurement of this run)") if traffic else None,

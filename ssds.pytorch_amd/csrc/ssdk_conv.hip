@@ -955,8 +955,8 @@ static int gemm_bn(int cout) { return cout > 64 ? 128 : cout > 32 ? 64 : cout > 
 // the slab round trip; aims at ~2 workgroups per CU.
 static int plan_splits(int M, int Cout, int KT) {
   static const int env = getenv("SSDK_SPLITK") ? atoi(getenv("SSDK_SPLITK")) : 1;
-  static const int target = getenv("SSDK_SPLITK_WGS") ? atoi(getenv("SSDK_SPLITK_WGS")) : 512;
-  static const int min_kt = getenv("SSDK_SPLITK_MINKT") ? atoi(getenv("SSDK_SPLITK_MINKT")) : 8;
+  constexpr int target = 512;  // (round 6: the SSDK_SPLITK_WGS switch is gone, its A/B is settled)
+  constexpr int min_kt = 8;  // (round 6: the SSDK_SPLITK_MINKT switch is gone, its A/B is settled)
   if (!env) return 1;
   const int bn = gemm_bn(Cout);
   const long tiles = (long)((M + BM - 1) / BM) * ((Cout + bn - 1) / bn);
@@ -998,7 +998,7 @@ static int launch_gemm(const ConvParams& p, hipStream_t stream) {
   if (use_gemm256(p)) return launch_gemm256<DT>(p, stream);
   const unsigned gm = (unsigned)((p.M + BM - 1) / BM);
   const unsigned gz = (unsigned)p.ksplits;
-  static const int env_resv = getenv("SSDK_GEMM_RESV") ? atoi(getenv("SSDK_GEMM_RESV")) : 1;
+  constexpr int env_resv = 1;  // (round 6: the SSDK_GEMM_RESV switch is gone, its A/B is settled)
   const bool resv = env_resv && p.res != nullptr && p.out_layout == LAYOUT_NHWC && (p.Cout & 7) == 0 && p.Cout > 32;
 #define SSDK_GEMM(WM, WN, FM_, FN_, GY)                                                                          \
   do {                                                                                                          \
@@ -1009,7 +1009,7 @@ static int launch_gemm(const ConvParams& p, hipStream_t stream) {
   } while (0)
   // short K on a grid that gives 128-wide tiles one workgroup per CU at most (the 1x1 320 -> 256 layer of the first SSD
   // extra: 10 k-steps, 256 tiles): 64-wide tiles = two workgroups per CU to overlap the per-k-step latency chain
-  static const int env_n64 = getenv("SSDK_GEMM_N64") ? atoi(getenv("SSDK_GEMM_N64")) : 1;
+  constexpr int env_n64 = 1;  // (round 6: the SSDK_GEMM_N64 switch is gone, its A/B is settled)
   const bool n64 = env_n64 && gz == 1 && p.Cout > 64 && (p.Cout % 64) == 0 && p.KT <= 12 && (long)gm * ((p.Cout + 127) / 128) <= 256;
   if (n64) SSDK_GEMM(4, 1, 2, 4, (p.Cout + 63) / 64);
   else if (p.Cout > 64) SSDK_GEMM(2, 2, 4, 4, (p.Cout + 127) / 128);
@@ -1067,8 +1067,7 @@ extern "C" size_t ssdk_conv_workspace_bytes(int N, int Cin, int H, int W, int Co
 static thread_local bool g_underfill_ok = false;  // set by ssdk_run_ops around side-lane ops
 
 static int halo_splitk_min_pixels() {  // smallest map (pixels) that goes to the halo kernel's split-K instead of conv_smallmap
-  const char* e = getenv("SSDK_HALO_SPLITK_MINP");
-  return (e && *e) ? atoi(e) : 64;
+  return 64;  // (round 6: the SSDK_HALO_SPLITK_MINP switch is gone)
 }
 
 extern "C" size_t ssdk_weight_frag_bytes(int rows, int K) {
@@ -1530,7 +1529,7 @@ extern "C" int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* 
         rc = edge(main_s, ctx->fork[forks], ctx->side);
         ++forks;
       }
-      static const int env_same = getenv("SSDK_SIDE_DEBUG") ? atoi(getenv("SSDK_SIDE_DEBUG")) : 0;
+      constexpr int env_same = 0;  // (round 6: the SSDK_SIDE_DEBUG switch is gone, its A/B is settled)
       st = env_same ? main_s : ctx->side;  // (debug: the side lane's bookkeeping without its concurrency)
       w = ws_side;
       wb = ws_side_bytes;
@@ -1576,7 +1575,7 @@ extern "C" int ssdk_run_ops_ctx(ssdk_ctx* ctx, const ssdk_op* ops, int n, void* 
         // (an unsplit halo launch of 32 workgroups instead of 128 split-K ones that each take a whole CU's LDS and exchange
         // 640 KB of slabs per tile: FPN-ResNet50@640 3 225 -> 3 281 img/s) -- tied to the op's tag, not to whether the side
         // stream is in use, so the outputs are the same bits either way (SSDK_LANE2_UNDERFILL=0: the in-line choice).
-        static const int env_l2 = getenv("SSDK_LANE2_UNDERFILL") ? atoi(getenv("SSDK_LANE2_UNDERFILL")) : 1;
+        constexpr int env_l2 = 1;  // (round 6: the SSDK_LANE2_UNDERFILL switch is gone, its A/B is settled)
         g_underfill_ok = (side && ops[i].lane == 1) || (env_l2 && ops[i].lane == 2);
         rc = ssdk_conv(&ops[i].conv, w, wb, st);
         g_underfill_ok = false;

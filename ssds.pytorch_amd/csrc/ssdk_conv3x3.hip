@@ -535,7 +535,7 @@ int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool
   if (!env || p.k != 3 || p.stride != 1 || p.pad != 1 || (p.Cin % 8)) return 1;
   // narrow outputs (the 256 -> 36 box heads of the FPN / BiFPN levels): a quarter-full 128-channel tile still beats the
   // 128 x 64 flat-K tiles of conv_gemm_kernel when K is long (SSDK_HALO_MIN_COUT, A/B)
-  static const int env_minco = getenv("SSDK_HALO_MIN_COUT") ? atoi(getenv("SSDK_HALO_MIN_COUT")) : 32;
+  constexpr int env_minco = 32;  // (round 6: the SSDK_HALO_MIN_COUT switch is gone, its A/B is settled)
   if (p.Cout < (p.Cin >= 128 ? env_minco : 96) || p.Cin < 32) return 1;
   HaloParams hp;
   hp.c = p;

@@ -405,7 +405,7 @@ int launch_conv3x3_short(const ConvParams& p, int dtype, hipStream_t stream) {
   sp.nsplit = nsplit;
   sp.tpw = (sp.n_tiles + nsplit - 1) / nsplit;
   if (sp.tpw < 2) return 1;  // one tile per workgroup: no next tile to hide the epilogue behind -- the halo kernel's case
-  static const int env_pad = getenv("SSDK_S3_PAD") ? atoi(getenv("SSDK_S3_PAD")) : 32;  // (16: the round-3 stride, A/B runs)
+  constexpr int env_pad = 32;  // (round 6: the SSDK_S3_PAD switch is gone, its A/B is settled)  // (16: the round-3 stride, A/B runs)
   sp.rs = cs * 64 + (env_pad == 16 ? 16 : 32);
   const size_t lds = (size_t)((sp.hrows * sp.rs + 1023) & ~1023);
   if (lds > (size_t)(s3_wpc(cs) == 2 ? 80 : 160) * 1024) return 1;

@@ -39,7 +39,6 @@ static void ctx_free(ssdk_ctx* c) {
   if (c->op_ev_ready)
     for (auto& e : c->op_ev) (void)hipEventDestroy(e);
   if (c->stamps) (void)hipFree(c->stamps);
-  if (c->tickets) (void)hipFree(c->tickets);
   free(c);
 }
 
@@ -162,11 +161,6 @@ extern "C" int ssdk_ctx_get_timings(ssdk_ctx* ctx, int back, float* ms, int n) {
     ms[1] = ms[2] = 0.0f;
     return hipEventElapsedTime(&ms[0], ev[0], ev[3]) == hipSuccess ? SSDK_OK : SSDK_E_LAUNCH;
   }
-  if (ctx->prof_tail2[slot]) {  // two launches: ms[0] = scan, ms[1] = tail2_kernel (levelsel + nmswalk), ms[2] = 0
-    ms[2] = 0.0f;
-    return (hipEventElapsedTime(&ms[0], ev[0], ev[1]) == hipSuccess && hipEventElapsedTime(&ms[1], ev[1], ev[3]) == hipSuccess)
-               ? SSDK_OK : SSDK_E_LAUNCH;
-  }
   for (int i = 0; i < 3; ++i)
     if (hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) != hipSuccess) return SSDK_E_LAUNCH;
   return SSDK_OK;
@@ -257,47 +251,7 @@ extern "C" int ssdk_decode_nms_ctx(ssdk_ctx* ctx, const ssdk_level* levels, int 
   float* mb = mid_boxes ? mid_boxes : (float*)w;
   w += align256(n * 16);
   float* mc = mid_classes ? mid_classes : (float*)w;
-  bool tail2 = false;
-  int env_tail2 = 0;
-  if (pl.fused) {
-    // ONE launch for the rest of the stage (tail2_kernel) when the context has its ticket words: they are allocated (and
-    // zeroed) on the first call that needs them -- never while the stream is being captured, where the two-launch form runs.
-    // Measured (round 4, profiles/r04_tail2_ab.txt): the one-launch tail is SLOWER than levelsel + nmswalk as two launches --
-    // realistic heads 33-36 vs 30 us, stage 56-57 vs 51 us on the same box: an image's six levels run on different XCDs, so the
-    // [L*K] arrays must travel through memory (write-through stores, L2-bypassing loads: ~2 us per dependent round trip, three
-    // of them) where a launch boundary costs ~4 us once.  It stays available (SSDK_TAIL2=1, tested) and off by default.
-    const char* e2 = getenv("SSDK_TAIL2");  // (read on every call: tests switch paths inside one process)
-    env_tail2 = (e2 && *e2) ? atoi(e2) : 0;
-    if (env_tail2 && ctx->tickets_cap < B) {
-      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(main_s, &cs) != hipSuccess) (void)hipGetLastError();
-      if (cs == hipStreamCaptureStatusNone) {
-        const int cap = B < 256 ? 256 : B;
-        unsigned* t = nullptr;
-        if (hipMalloc((void**)&t, (size_t)cap * sizeof(unsigned)) == hipSuccess && hipMemset(t, 0, (size_t)cap * sizeof(unsigned)) == hipSuccess) {
-          if (ctx->tickets) {  // (growing: nothing may still be counting on the old words)
-            (void)hipDeviceSynchronize();
-            (void)hipFree(ctx->tickets);
-          }
-          ctx->tickets = t;
-          ctx->tickets_cap = cap;
-        } else {
-          (void)hipGetLastError();
-          if (t) (void)hipFree(t);
-        }
-      }
-    }
-    tail2 = env_tail2 && ctx->tickets_cap >= B;
-  }
-  if (tail2) {  // tail2_kernel: level select + decode of (image, level); an image's last workgroup walks its NMS
-    u32 hbase, hsh;
-    hist_window(threshold, &hbase, &hsh);
-    rc = launch_tail2(levels, L, B, dtype, K, rescore, pl.units, pl.unit_base, pl.units_per_image, workspace,
-                      (const char*)workspace + pl.cand_bytes, hbase, hsh, ms, mb, mc, nms_threshold, ndetections, using_diou,
-                      out_scores, out_boxes, out_classes, ctx->tickets, ctx->stamps, st2);
-    if (rc) return rc;
-    if (prof && (rc = record(ev[3], st2))) return rc;
-  } else if (pl.fused) {  // levelsel_kernel (B x L workgroups: select + order + decode per level) + nmswalk_kernel (per image)
+  if (pl.fused) {  // levelsel_kernel (B x L workgroups: select + order + decode per level) + nmswalk_kernel (per image)
     u32 hbase, hsh;
     hist_window(threshold, &hbase, &hsh);
     rc = launch_levelsel(levels, L, B, dtype, K, rescore, pl.units, pl.unit_base, pl.units_per_image, workspace,
@@ -320,7 +274,6 @@ extern "C" int ssdk_decode_nms_ctx(ssdk_ctx* ctx, const ssdk_level* levels, int 
   if (prof_any && !prof && (rc = record(ev[3], st2))) return rc;
   if (prof_any) {
     ctx->prof_fused[ctx->prof_calls % kSsdkProfSlots] = !prof;
-    ctx->prof_tail2[ctx->prof_calls % kSsdkProfSlots] = prof && tail2;
     ++ctx->prof_calls;
   }
   return SSDK_OK;

@@ -26,9 +26,6 @@ struct ssdk_ctx {
   bool prof_fused[kSsdkProfSlots];  // the slot was recorded in stage mode (prof_on == 2): events 0 and 3 only
   long long prof_calls;
   unsigned long long* stamps;   // device, kSsdkStampWords words (SSDK_TAIL_STAMPS=1 only)
-  unsigned* tickets;            // device, tickets_cap zero-initialised words: per-image arrival counters of tail2_kernel
-  int tickets_cap;              // (re-armed by the kernel itself; allocated on the first call that needs them)
-  bool prof_tail2[kSsdkProfSlots];  // the slot's tail ran as ONE launch (levelsel + nmswalk): events 0, 1, 3 only
   // ---- plan executor (ssdk_run_ops_ctx) ----
   int side_lane;                // -1: environment default (SSDK_SIDE_STREAM, on), 0 off, 1 on
   hipStream_t side;

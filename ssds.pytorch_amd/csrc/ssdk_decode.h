@@ -30,10 +30,6 @@ size_t tail_fits(int K, int L, int ndet);
 int launch_levelsel(const ssdk_level* lv, int L, int B, int dtype, int K, int rescore, const u32* units, const u32* unit_base,
                     u32 units_per_image, const void* cand, const void* cand_cnt, u32 hist_base, u32 hist_sh, float* ms,
                     float* mb, float* mc, unsigned long long* stamps, hipStream_t stream);
-int launch_tail2(const ssdk_level* lv, int L, int B, int dtype, int K, int rescore, const u32* units, const u32* unit_base,
-                 u32 units_per_image, const void* cand, const void* cand_cnt, u32 hist_base, u32 hist_sh, float* ms, float* mb,
-                 float* mc, float nms_thr, int ndet, int diou, float* os, float* ob, float* oc, u32* tickets,
-                 unsigned long long* stamps, hipStream_t stream);
 int launch_nmswalk(const float* ms, const float* mb, const float* mc, int B, int N, float nms_thr, int ndet, int diou, float* os,
                    float* ob, float* oc, unsigned long long* stamps, hipStream_t stream);
 int launch_nms(const float* scores, const float* boxes, const float* classes, int B, int N, float thr, int ndet,

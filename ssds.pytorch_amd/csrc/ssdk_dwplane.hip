@@ -522,7 +522,7 @@ static DwpPlan dwp_plan(int kind, int N, int C, int H, int W, int stride, bool h
   const int rows_lds = lds_elems / p.LD;  // staged rows that fit
   // rows of the thread space whose staged rows fit / whose units fit
   const int tr_lds = dgrad2 ? 2 * (rows_lds - 2) : (rows_lds - 3) / S + 1;
-  static const int env_units = getenv("SSDK_DW_UNITS") ? atoi(getenv("SSDK_DW_UNITS")) : 0;  // (tuning: units per workgroup)
+  constexpr int env_units = 0;  // (round 6: the SSDK_DW_UNITS switch is gone, its A/B is settled)  // (tuning: units per workgroup)
   const int units = env_units >= 64 && env_units <= kDwpUnits ? env_units : kDwpUnits;
   int tr = units / p.seg;
   if (tr > tr_lds) tr = tr_lds;

@@ -792,7 +792,7 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   }
   if (launch_mbflow(d, stream) == 0) return check_launch(stem ? "mbflow_kernel(stem)" : "mbflow_kernel");  // high-resolution blocks: ssdk_mbflow.hip
   // the row-pair kernel first: it also takes the 32 -> 192 -> 32 @64x64 blocks ssdk_mbsplit.hip has an instance for (SSDK_MBK_FIRST=0: A/B)
-  static const int env_mbk_first = getenv("SSDK_MBK_FIRST") ? atoi(getenv("SSDK_MBK_FIRST")) : 1;  // (measured: 52 -> 39 us per block)
+  constexpr int env_mbk_first = 1;  // (round 6: the SSDK_MBK_FIRST switch is gone, its A/B is settled)  // (measured: 52 -> 39 us per block)
   if (env_mbk_first && launch_mbk(d, stream) == 0) return check_launch("mbk_kernel");
   if (launch_mbsplit(d, stream) == 0) return check_launch("mbsplit_kernel");  // mid-resolution blocks: hidden channels split over the waves
   if (launch_mbk(d, stream) == 0) return check_launch("mbk_kernel");  // 16- to 64-pixel-wide maps: row pairs, weights from L2 into MFMA operands
@@ -826,22 +826,22 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   p.Wo = (p.W + 2 - 3) / d->stride + 1;
   p.residual = d->residual;
   // 16x16 output tiles for stride-1 blocks with few channels on maps large enough to still fill the chip
-  static const int env_ts = getenv("SSDK_MB_TS") ? atoi(getenv("SSDK_MB_TS")) : 0;
+  constexpr int env_ts = 0;  // (round 6: the SSDK_MB_TS switch is gone, its A/B is settled)
   {
     const int nfo16 = (d->Cout + 15) / 16, ks16 = ((stem ? 96 : d->Cin) + 31) / 32;
     const long tiles16 = (long)d->N * ((p.Wo + 15) / 16) * ((p.Ho + 15) / 16);
     // measured on SSD-MobileNetV2@512 batch 64: the 16x16 tile wins down to ONE workgroup per CU (256 tiles: the
     // 64-channel blocks at 32x32 go 55 -> 35 us), i.e. work per phase matters more than co-resident workgroups
-    static const int env_min = getenv("SSDK_MB_TS16_MIN") ? atoi(getenv("SSDK_MB_TS16_MIN")) : 256;
-    static const int env_ks = getenv("SSDK_MB_TS16_KS") ? atoi(getenv("SSDK_MB_TS16_KS")) : 3;
-    static const int env_nfo = getenv("SSDK_MB_TS16_NFO") ? atoi(getenv("SSDK_MB_TS16_NFO")) : 6;
+    constexpr int env_min = 256;  // (round 6: the SSDK_MB_TS16_MIN switch is gone, its A/B is settled)
+    constexpr int env_ks = 3;  // (round 6: the SSDK_MB_TS16_KS switch is gone, its A/B is settled)
+    constexpr int env_nfo = 6;  // (round 6: the SSDK_MB_TS16_NFO switch is gone, its A/B is settled)
     const bool can16 = d->stride == 1 && nfo16 <= env_nfo && (stem || ks16 <= env_ks);
     p.ts = (can16 && env_ts != 8 && (tiles16 >= env_min || env_ts == 16)) ? 16 : 8;
   }
   p.tsw = p.ts;
   {  // 8x16 tiles for stride-2 blocks with <= 32 input channels and a long chunk loop (>= 6 chunks): twice the work per
      // phase of 8x8 but one workgroup per CU instead of two -- measured 47 -> 41 us at 192 hidden channels, a LOSS at 96 / 144
-    static const int env_816 = getenv("SSDK_MB_8X16") ? atoi(getenv("SSDK_MB_8X16")) : 1;
+    constexpr int env_816 = 1;  // (round 6: the SSDK_MB_8X16 switch is gone, its A/B is settled)
     const long tiles816 = (long)d->N * ((p.Wo + 15) / 16) * ((p.Ho + 7) / 8);
     if (env_816 && p.ts == 8 && env_ts == 0 && d->stride == 2 && !stem && d->Cin <= 32 && (d->Cout + 15) / 16 <= 4 &&
         ((tiles816 >= 256 && d->Chid >= 192) || env_816 == 2))
@@ -858,8 +858,8 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
   const int nfo_inst = nfo_t <= 2 ? 2 : nfo_t <= 4 ? 4 : nfo_t <= 6 ? 6 : nfo_t <= 10 ? 10 : 20;
   p.wes = p.xs;
   const int ks_t = (p.Cin + 31) / 32;
-  static const int env_res = getenv("SSDK_MB_RESIDENT") ? atoi(getenv("SSDK_MB_RESIDENT")) : 1;
-  static const int env_hc = getenv("SSDK_MB_HC") ? atoi(getenv("SSDK_MB_HC")) : 0;
+  constexpr int env_res = 1;  // (round 6: the SSDK_MB_RESIDENT switch is gone, its A/B is settled)
+  constexpr int env_hc = 0;  // (round 6: the SSDK_MB_HC switch is gone, its A/B is settled)
   const long tiles_total = (long)d->N * p.tiles_x * p.tiles_y;
   bool resident = false;
   auto layout = [&](int hc) -> size_t {  // fills the staged-buffer offsets for `hc`, returns the LDS bytes
@@ -899,7 +899,7 @@ extern "C" int ssdk_mbconv(const ssdk_mbconv_desc* d, void* stream_) {
     return SSDK_E_BADARG;
   }
   {  // two workgroups per CU need both halves of the CU: LDS here, registers through the LEAN4 instance
-    static const int env_lean = getenv("SSDK_MB_LEAN") ? atoi(getenv("SSDK_MB_LEAN")) : 1;
+    constexpr int env_lean = 1;  // (round 6: the SSDK_MB_LEAN switch is gone, its A/B is settled)
     const long tiles = (long)d->N * p.tiles_x * p.tiles_y;
     p.lean = (env_lean && p.ts == 16 && p.tsw == 16 && lds <= 80 * 1024 && tiles >= 512) ? 1 : 0;
   }

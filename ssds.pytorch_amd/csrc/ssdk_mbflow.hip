@@ -866,12 +866,12 @@ int launch_mbflow(const ssdk_mbconv_desc* d, hipStream_t stream) {
   p.strips = (p.Wo + ow - 1) / ow;
   if (d->stride == 2) p.strips = 2 * ((p.Wo + 14) / 15);  // parity split: a pair of strips = 15 outputs (even / odd input columns)
   // rows per segment: long segments amortise the two halo rows, short ones give the chip enough waves (>= ~3 per SIMD)
-  static const int env_rs = getenv("SSDK_MB_FLOW_RS") ? atoi(getenv("SSDK_MB_FLOW_RS")) : 0;
+  constexpr int env_rs = 0;  // (round 6: the SSDK_MB_FLOW_RS switch is gone, its A/B is settled)
   // strips per wave: two share every weight read, but the 144-channel stride-1 block then holds 216 registers (3 x 2 x 18
   // accumulators): two waves per SIMD.  With ONE strip it holds 132 -- three waves per SIMD -- and runs 125 -> 114 us (round 4,
   // same box; forcing 128 registers for a fourth wave spills and gives the gain back: 121 us).  The stem block (NCH = 2) does not
   // gain from one strip (137 -> 140 us).  SSDK_MB_FLOW_NS1: bit 0 the 144-channel block (default on), bit 1 the stem block.
-  static const int env_ns1 = getenv("SSDK_MB_FLOW_NS1") ? atoi(getenv("SSDK_MB_FLOW_NS1")) : 1;
+  constexpr int env_ns1 = 1;  // (round 6: the SSDK_MB_FLOW_NS1 switch is gone, its A/B is settled)
   const bool ns1 = ((env_ns1 & 1) && !stem && d->stride == 1 && nch == 9) || ((env_ns1 & 2) && stem);
   const int flow_ns = ns1 ? 1 : kFlowNS;
   if (ns1 && !stem) p.layout = 101;

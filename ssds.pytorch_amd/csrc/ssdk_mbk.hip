@@ -468,7 +468,7 @@ int launch_mbk(const ssdk_mbconv_desc* d, hipStream_t stream) {
   if (env != 1 && variant != 3 && !((env >> (inst + 1)) & 1)) return 1;  // (A/B: SSDK_MBK = 2 << instance, or-ed)
   const int pairs = (Ho + 1) / 2;
   const long items = (long)halves * d->N * pairs;
-  static const int env_min = getenv("SSDK_MBK_MIN") ? atoi(getenv("SSDK_MBK_MIN")) : 256;
+  constexpr int env_min = 256;  // (round 6: the SSDK_MBK_MIN switch is gone, its A/B is settled)
   if (items < env_min && variant != 3) return 1;  // a handful of items cannot fill the chip: the tiled kernel's 8x8 tiles can
   MbkParams p;
   p.x = (const u16*)d->x;

@@ -450,15 +450,15 @@ int launch_mbsplit(const ssdk_mbconv_desc* d, hipStream_t stream) {
   if (d->stride == 2) p.strips = 2 * ((p.Wo + 14) / 15);  // parity split: a pair of strips = 15 outputs (ssdk_mbflow.hip header)
   const int groups = (p.strips + 1) / 2;
   // rows per segment: the longest of 32 / 16 / 8 that still gives the chip ~3 workgroups per CU
-  static const int env_rs = getenv("SSDK_MB_SPLIT_RS") ? atoi(getenv("SSDK_MB_SPLIT_RS")) : 0;
-  static const int env_xb = getenv("SSDK_MB_SPLIT_XB") ? atoi(getenv("SSDK_MB_SPLIT_XB")) : 1;  // 1 | 2 exchange buffers, 3: one buffer + taps in registers
+  constexpr int env_rs = 0;  // (round 6: the SSDK_MB_SPLIT_RS switch is gone, its A/B is settled)
+  constexpr int env_xb = 1;  // (round 6: the SSDK_MB_SPLIT_XB switch is gone, its A/B is settled)  // 1 | 2 exchange buffers, 3: one buffer + taps in registers
   // Measured on SSD-MobileNetV2@512, batch 64 (profiles/r04_split_ab.txt): 16-row segments beat 8 (two halo rows per
   // segment: 71 vs 64 us on the 128^2 block) and 32 (too few workgroups: 82 us); three workgroups per CU (one exchange
   // buffer, two barriers per row) beat two (double-buffered exchange: 74 us) and beat two with the taps in registers (72 us)
   // -- resident waves matter more than LDS reads here; and a map that yields fewer than ~700 workgroups of 16 rows (the
   // 64^2 -> 32^2 stride-2 block: 384) stays on the tiled kernel (38 vs 47-52 us).
   int rs = 16;
-  static const int env_min = getenv("SSDK_MB_SPLIT_MIN") ? atoi(getenv("SSDK_MB_SPLIT_MIN")) : 700;
+  constexpr int env_min = 700;  // (round 6: the SSDK_MB_SPLIT_MIN switch is gone, its A/B is settled)
   if (variant == 2)  // forced (tests): short segments so that small maps still exercise several segments
     while (rs > 4 && (long)d->N * groups * ((p.Ho + rs - 1) / rs) < 64) rs >>= 1;
   if (env_rs > 0) rs = env_rs;

@@ -16,7 +16,7 @@
 //     a lane stay in registers, give the cut (top-2 per 16-bit half-lane by packed min / max, a 1024-bin histogram of those
 //     1024 values, the bin in which their count from the top reaches K) and are filtered from the registers.  Every byte of
 //     the conf tensor is fetched once.
-//   * the unit's winners leave unordered: the consumer (tail2_kernel) selects per LEVEL with a histogram anyway and no
+//   * the unit's winners leave unordered: the consumer (levelsel_kernel) selects per LEVEL with a histogram anyway and no
 //     longer merges sorted runs, so the per-unit sort (9 k cycles of 83 k) is gone and the per-unit select is one
 //     histogram pass over the extracted keys.
 //

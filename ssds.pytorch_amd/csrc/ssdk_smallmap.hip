@@ -306,7 +306,7 @@ int launch_conv_smallmap_group(const ConvParams* ps, int n, int dtype, hipStream
   // K split over two wave groups: measured on the 4x4 / 2x2 / 1x1 heads of SSD-MobileNetV2@512 (26.3 vs 26.5 us for the group:
   // nothing) and it changes the summation order against the members' single launches, which the executor's tests compare bit
   // for bit -- off unless SSDK_CONV_SMALLMAP_GROUP_KW=2
-  static const int env_kw = getenv("SSDK_CONV_SMALLMAP_GROUP_KW") ? atoi(getenv("SSDK_CONV_SMALLMAP_GROUP_KW")) : 1;
+  constexpr int env_kw = 1;  // (round 6: the SSDK_CONV_SMALLMAP_GROUP_KW switch is gone, its A/B is settled)
   const int kw = env_kw == 2 ? 2 : 1;
   lds = ((lds + 15) & ~(size_t)15) + (size_t)(kw - 1) * 4 * 4 * 1024;  // + the partial sums of wave group 1 (4 waves x 4 fragments)
 #define SSDK_SMG(DT, KW_)                                                                                                    \
@@ -329,14 +329,14 @@ int launch_conv_smallmap_group(const ConvParams* ps, int n, int dtype, hipStream
 // 1: not one of this kernel's layers (the caller goes on), 0: launched
 int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   static const int env = getenv("SSDK_CONV_SMALLMAP") ? atoi(getenv("SSDK_CONV_SMALLMAP")) : 1;
-  static const int env_maxp = getenv("SSDK_CONV_SMALLMAP_MAXP") ? atoi(getenv("SSDK_CONV_SMALLMAP_MAXP")) : 64;
+  constexpr int env_maxp = 64;  // (round 6: the SSDK_CONV_SMALLMAP_MAXP switch is gone, its A/B is settled)
   const int P = p.Ho * p.Wo;
   if (!env || p.k != 3 || p.pad != 1 || P > env_maxp || P > 64 || (p.Cin != 128 && p.Cin != 256 && p.Cin != 512) ||
       p.in_layout != LAYOUT_NHWC || p.res || p.post != SSDK_ACT_NONE || p.Cout < 16)
     return 1;
   static const int env_pk = getenv("SSDK_WFRAG") ? atoi(getenv("SSDK_WFRAG")) : 1;
   const bool packed = p.w_frag != nullptr && env_pk != 0;
-  static const int env_s2 = getenv("SSDK_CONV_SMALLMAP_S2") ? atoi(getenv("SSDK_CONV_SMALLMAP_S2")) : 1;
+  constexpr int env_s2 = 1;  // (round 6: the SSDK_CONV_SMALLMAP_S2 switch is gone, its A/B is settled)
   const bool s2 = p.stride == 2;
   if (s2) {  // the stride-2 instance: even input map, fragment-major weights, the input maps of a workgroup fit the LDS
     if (!env_s2 || !packed || p.H != 2 * p.Ho || p.W != 2 * p.Wo || P == 1) return 1;
@@ -349,13 +349,13 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   // 64 pixels x 32 channels per wave (na = 2: a pixel fragment serves two MFMAs), else 128 pixels x 16 channels per wave
   const int nfr64 = (p.Cout + 63) / 64;
   const bool big = 2 * P <= 128 && (128 % P) == 0 && (long)((p.N + 128 / P - 1) / (128 / P)) * nfr64 >= 256;
-  static const int env_na = getenv("SSDK_CONV_SMALLMAP_NA") ? atoi(getenv("SSDK_CONV_SMALLMAP_NA")) : 2;
+  constexpr int env_na = 2;  // (round 6: the SSDK_CONV_SMALLMAP_NA switch is gone, its A/B is settled)
   const int na = ((big && packed && env_na == 2) || s2) ? 2 : 1;
   const int mfr = (big && na == 1) ? 8 : 4;
   const int G = 16 * mfr / P;
   // waves (= 16 na-channel fragments) per workgroup
   const int groups = (p.N + G - 1) / G, nfr = (p.Cout + 16 * na - 1) / (16 * na);
-  static const int env_nw = getenv("SSDK_CONV_SMALLMAP_NW") ? atoi(getenv("SSDK_CONV_SMALLMAP_NW")) : 4;
+  constexpr int env_nw = 4;  // (round 6: the SSDK_CONV_SMALLMAP_NW switch is gone, its A/B is settled)
   const int nw = env_nw == 1 || env_nw == 2 ? env_nw : 4;  // (fewer waves per workgroup = more workgroups: measured slower on every level)
   const dim3 grid((unsigned)groups, (unsigned)((nfr + nw - 1) / nw));
   size_t lds = s2 ? (size_t)(G * (p.H * p.W + p.H / 2) + 1) * (p.Cin * 2 + 32) : (size_t)(16 * mfr + 1) * (p.Cin * 2 + 32);

@@ -922,33 +922,11 @@ __global__ __launch_bounds__(kWalkThreads) void nmswalk_kernel(const WalkParams 
   nmswalk_body<false>(p, blockIdx.x, smem);
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// tail2_kernel (round 4): levelsel + nmswalk as ONE launch -- the decode stage is then two launches (scan | tail), what SURVEY
-// a12 asks for.  Grid (levels, images), 1024 threads: every workgroup runs the level select + decode of its (image, level) like
-// levelsel_kernel<DT, 1024>; the workgroup that finishes an image's LAST level (an agent-scope release / acquire ticket per
-// image: every wave drains its stores, barrier, one lane takes the ticket, the last arriver re-arms the counter) goes on with that image's NMS walk on the [L*K] arrays the L
-// workgroups have just written (agent-scope stores and loads, see tail_st / tail_ld: no cache-wide fence).  No workgroup ever
-// waits for another one, so any launch order is safe.
-// ------------------------------------------------------------------------------------------------------------------------
-template <int DT>
-__global__ __launch_bounds__(kWalkThreads) void tail2_kernel(const SelParams ps, const WalkParams pw, u32* tickets) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ u32 s_last;
-  const u32 l = blockIdx.x, b = blockIdx.y;
-  levelsel_body<DT, kWalkThreads, true>(ps, l, b, smem);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's (write-through) [L*K] stores have been acknowledged
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned old = __hip_atomic_fetch_add(tickets + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned last = (old == (unsigned)ps.L - 1u) ? 1u : 0u;
-    if (last) __hip_atomic_store(tickets + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next call
-    s_last = last;
-  }
-  __syncthreads();  // (also: the select is done with the LDS image the walk builds over it)
-  if (s_last == 0u) return;  // workgroup-uniform
-  nmswalk_body<true>(pw, b, smem);
-}
-
+// (Round 4 built levelsel + nmswalk as ONE launch -- tail2_kernel: the last workgroup of an image to arrive on a per-image ticket
+//  walked its NMS -- and measured it SLOWER than the two launches (55.8 / 57.5 vs 50.9 us for the stage, profiles/r04_tail2_ab.txt:
+//  the walk's 1 800 score loads per image had to come through the coherent L2 path).  It rode along behind SSDK_TAIL2 for two
+//  rounds; round 6 removed the kernel, its launcher and the switch.  The COH template parameter of the two bodies is what is
+//  left of it: always false.)
 // ------------------------------------------------------------------------------------------------------------------
 // host side (called from ssdk_decode_nms, ssdk_ctx.cpp)
 // ------------------------------------------------------------------------------------------------------------------
@@ -1018,7 +996,7 @@ int launch_levelsel(const ssdk_level* lv, int L, int B, int dtype, int K, int re
   const dim3 grid((unsigned)L, (unsigned)B);
   u32 most = 0;
   for (int l = 0; l < L; ++l) most = units[l] > most ? units[l] : most;
-  static const int env_wide = getenv("SSDK_LEVELSEL_WIDE") ? atoi(getenv("SSDK_LEVELSEL_WIDE")) : 1;
+  constexpr int env_wide = 1;  // (round 6: the SSDK_LEVELSEL_WIDE switch is gone, its A/B is settled)
   const bool wide = env_wide == 2 || (env_wide && (size_t)most * (size_t)K > 4096);  // (2: always -- A/B switch)
 #define SSDK_SEL(DT)                                                                                                        \
   do {                                                                                                                     \
@@ -1030,53 +1008,6 @@ int launch_levelsel(const ssdk_level* lv, int L, int B, int dtype, int K, int re
   else SSDK_SEL(SSDK_F16);
 #undef SSDK_SEL
   return check_launch("levelsel_kernel");
-}
-
-// levelsel + nmswalk as one launch (tail2_kernel); `tickets`: B zero-initialised words owned by the context
-int launch_tail2(const ssdk_level* lv, int L, int B, int dtype, int K, int rescore, const u32* units, const u32* unit_base,
-                 u32 units_per_image, const void* cand, const void* cand_cnt, u32 hist_base, u32 hist_sh, float* ms, float* mb,
-                 float* mc, float nms_thr, int ndet, int diou, float* os, float* ob, float* oc, u32* tickets,
-                 unsigned long long* stamps, hipStream_t stream) {
-  if (!ms || !mb || !mc || ((uintptr_t)mb & 15) || !os || !ob || !oc || ((uintptr_t)ob & 15) || !tickets) {
-    set_error("decode_nms: null or misaligned output pointer (boxes need 16-byte alignment)");
-    return SSDK_E_BADARG;
-  }
-  SelParams ps;
-  fill_sel_params(ps, lv, L, dtype, K, rescore, units, unit_base, units_per_image, cand, cand_cnt, hist_base, hist_sh, ms, mb, mc,
-                  stamps);
-  WalkParams pw;
-  memset(&pw, 0, sizeof(pw));
-  pw.N = (u32)(L * K);
-  pw.M = tail_pow2(pw.N);
-  pw.scores = ms;
-  pw.boxes = mb;
-  pw.classes = mc;
-  pw.thr = nms_thr;
-  pw.ndet = ndet;
-  pw.diou = diou;
-  pw.out_scores = os;
-  pw.out_boxes = ob;
-  pw.out_classes = oc;
-  pw.stamps = stamps;
-  size_t lds = walk_lds_bytes(pw.M, (u32)ndet);
-  if (sel_lds_bytes((u32)K) > lds) lds = sel_lds_bytes((u32)K);
-  lds_poison(stream);
-  const dim3 grid((unsigned)L, (unsigned)B);
-  auto go = [&](auto kern) -> int {
-    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)kTailLdsMax) != hipSuccess) {
-      (void)hipGetLastError();
-      set_error("decode_nms: cannot raise the dynamic LDS limit of tail2_kernel");
-      return SSDK_E_LAUNCH;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(kWalkThreads), lds, stream, ps, pw, tickets);
-    return SSDK_OK;
-  };
-  int rc;
-  if (dtype == SSDK_F32) rc = go(tail2_kernel<SSDK_F32>);
-  else if (dtype == SSDK_BF16) rc = go(tail2_kernel<SSDK_BF16>);
-  else rc = go(tail2_kernel<SSDK_F16>);
-  return rc ? rc : check_launch("tail2_kernel");
 }
 
 int launch_nmswalk(const float* ms, const float* mb, const float* mc, int B, int N, float nms_thr, int ndet, int diou, float* os,

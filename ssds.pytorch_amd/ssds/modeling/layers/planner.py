@@ -126,19 +126,11 @@ def build_ssd_plan(model, x):
 
     from ssds.modeling.nets.mobilenet import MobileNetEx
 
-    # SSDK_SSD_TAIL_SIDE=1 (round-5 experiment): the extras chain and the heads of its levels -- a dozen latency-bound launches
-    # that underfill the chip -- as ONE side-stream run behind the backbone, next to the two chip-filling backbone-level heads
-    # on the main stream (recorded last: their feature maps stay alive until then).
-    # SSDK_SSD_TAIL_SIDE=2: only the SMALL extras (the fused pairs behind the first one) and the heads of their levels as the
-    # side run, next to the 8x8 level's head on the main stream (recorded behind the run): two branches that both hang on the
-    # first extra's output, neither of which fills the chip or its LDS.
-    ts_mode = os.environ.get("SSDK_SSD_TAIL_SIDE", "0")
-    tail_side = ts_mode == "1" and isinstance(model.backbone, MobileNetEx) and len(model.extras) > 1
-    tail_small = ts_mode == "2" and isinstance(model.backbone, MobileNetEx) and len(model.extras) > 2
-    late = []
+    # (Round 5 measured the mirror-image ordering -- extras chain + small heads as a side-stream run next to the two backbone-level
+    #  heads -- at 60.9 / 62.4 k against 61.9 / 62.9 k img/s in line; the SSDK_SSD_TAIL_SIDE switch and its two recordings are
+    #  gone in round 6: docs/HISTORY.md.)
     if isinstance(model.backbone, MobileNetEx):
-        feats = record_mobilenet(plan, plan.input_value(), model.backbone,
-                                 on_output=(lambda i, f: late.append((i, f))) if tail_side else head)
+        feats = record_mobilenet(plan, plan.input_value(), model.backbone, on_output=head)
     else:
         feats = record_backbone(plan, plan.input_value(), model.backbone)
         for i, f in enumerate(feats):
@@ -149,26 +141,13 @@ def build_ssd_plan(model, x):
     # dependent latencies with 128 / 32 / 8 workgroups each).  SSDK_HEAD_BALANCE=0: every head right behind its feature map.
     balance = os.environ.get("SSDK_HEAD_BALANCE", "1") != "0" and len(model.extras) > 1
     deferred = []
-    first_extra_level = None
     for j, extra in enumerate(model.extras):
-        feats.append(record_chain(plan, feats[-1], extra, keep_input=True, lane=2 if (tail_side or (tail_small and j > 0)) else 0))
-        if j == 0:
-            first_extra_level = len(feats) - 1
+        feats.append(record_chain(plan, feats[-1], extra, keep_input=True))
         if balance:
             deferred.append((len(feats) - 1, feats[-1]))
         else:
             head(len(feats) - 1, feats[-1])
-    if tail_small and balance:
-        for i, f in deferred:
-            if i != first_extra_level:
-                head(i, f, lane=2, position=i)
-        for i, f in deferred:
-            if i == first_extra_level:
-                head(i, f, lane=0, position=i)
-        deferred = []
     for i, f in deferred:
-        head(i, f, lane=2 if tail_side else 0, position=i)
-    for i, f in late:  # (tail_side) the backbone levels' heads, on the main stream, while the side run is in flight
         head(i, f, lane=0, position=i)
     return plan.finalize()
 
@@ -336,7 +315,7 @@ def _record_extras_and_towers(plan, model, pyramid, raw_last):
         src = pyramid[i] if i < n else (raw_last if i == n else xx)
         xx = record_chain(plan, src, v, keep_input=True)
         levels.append(xx)
-    limit = int(os.environ.get("SSDK_SMALL_LEVEL_PIXELS", SMALL_LEVEL_PIXELS))
+    limit = SMALL_LEVEL_PIXELS  # (a module attribute: tests monkeypatch it)
     small = [xx[1] * xx[3] * xx[4] <= limit for xx in levels]
     lanes = os.environ.get("SSDK_LEVEL_LANES", "1") != "0" and any(small) and not all(small)
     if lanes and sum(10 for sm in small if sm) > 320:

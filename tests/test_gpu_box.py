@@ -569,8 +569,8 @@ def test_full_size_fpn_bifpn_shapes_properties_and_sampled_oracle(shape, dtype):
 @pytest.mark.parametrize("kind", ["constant", "ramp_up", "quantized", "sparse", "logit"])
 @pytest.mark.parametrize("tpu", ["1", "4", "0"])
 def test_decoder_every_path_agrees_with_the_oracle(kind, tpu, monkeypatch):
-    """Decoder.__call__ through each way the stage can run -- levelsel_kernel + nmswalk_kernel (default) vs tail2_kernel (both in
-    one launch, SSDK_TAIL2=1) vs level_kernel + nms_kernel (SSDK_DECODE_FUSED=0), seeded barrier-free scan (default) vs the TopK stream only (SSDK_SCAN_FAST=0) -- on inputs
+    """Decoder.__call__ through each way the stage can run -- levelsel_kernel + nmswalk_kernel (default) vs level_kernel +
+    nms_kernel (SSDK_DECODE_FUSED=0), seeded barrier-free scan (default) vs the TopK stream only (SSDK_SCAN_FAST=0) -- on inputs
     full of ties, with many scan units per level (SSDK_TILES_PER_UNIT=1/4: the tail merges up to 32 sorted lists):
     every path equals the oracle (final and per-level outputs), hence each other, bit for bit in classes / order."""
     import torch
@@ -597,9 +597,8 @@ def test_decoder_every_path_agrees_with_the_oracle(kind, tpu, monkeypatch):
     want = odec(ol, oc, oanch)
     monkeypatch.setenv("SSDK_TILES_PER_UNIT", tpu)
     dl, dc = [t.cuda() for t in loc], [t.cuda() for t in conf]
-    for env in ({}, {"SSDK_TAIL2": "1"}, {"SSDK_DECODE_FUSED": "0"}, {"SSDK_SCAN_FAST": "0"}, {"SSDK_TAIL2": "1", "SSDK_SCAN_FAST": "0"},
-                {"SSDK_DECODE_FUSED": "0", "SSDK_SCAN_FAST": "0"}):
-        for k in ("SSDK_DECODE_FUSED", "SSDK_SCAN_FAST", "SSDK_TAIL2"):
+    for env in ({}, {"SSDK_DECODE_FUSED": "0"}, {"SSDK_SCAN_FAST": "0"}, {"SSDK_DECODE_FUSED": "0", "SSDK_SCAN_FAST": "0"}):
+        for k in ("SSDK_DECODE_FUSED", "SSDK_SCAN_FAST"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

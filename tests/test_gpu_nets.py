@@ -166,7 +166,11 @@ def _check_against_floor(plan_out, torch_out, want, what, dtype, tail_factor=3.0
             if small:  # one draw of a handful of values: only the cap here, the rules proper in check_small_levels_pooled
                 ok = sp[0] <= CAP_SMALL[dtype]
             else:
-                ok = (sp[0] <= 2.0 * st[0] + m_abs and sp[0] <= CAP[dtype] and sp[1] <= max(tail_factor, 2.0) * st[1] + p_abs
+                # the tail statistic: the 99.9th percentile where it rests on >= 100 elements (>= 100 000 values), else the MAXIMUM --
+                # on a 5 184-value level "p99.9" is the fifth-largest error, a coin toss (round 6: bifpn_regx002_x2 conf0 in bf16,
+                # plan 4.82 / floor 1.13 at p99.9 with maxima of 5.46 / 5.34: the same handful of saturated logits in both)
+                tail = 1 if w.numel() >= 100000 else 2
+                ok = (sp[0] <= 2.0 * st[0] + m_abs and sp[0] <= CAP[dtype] and sp[tail] <= max(tail_factor, 2.0) * st[tail] + p_abs
                       and sp[3] >= st[3] - CORR_SLACK)
             if not ok:
                 bad.append(report[-1])

@@ -964,7 +964,8 @@ ZERO_BELOW = 1e-7  # x the median gradient rms: a STRUCTURALLY zero gradient (th
 
 def _judge_gradients(got, floor, ref, what, factor=2.0, slack=0.02, r_slack=0.05):
     """``got`` / ``floor`` / ``ref``: {name: gradient}; ``ref`` is the fp64 truth.  Per parameter of >= POOL_BELOW elements
-        rel(got) <= factor x rel(floor) + slack   and   r(got) >= r(floor) - r_slack     (the correlation rule of test_gpu_nets.py)
+        rel(got) <= factor x rel(floor) + slack   and   r(got) >= r(floor) - r_slack - 3 sqrt(2 / n)   (the correlation rule of
+        test_gpu_nets.py with the sampling scatter of an n-element correlation)
     and the same for all smaller parameters pooled (each scaled by the rms of its true gradient); structurally zero gradients
     must stay within 10 x the floor's magnitude.  -> rows (name, elements, rel, r, floor rel, floor r)."""
     import torch
@@ -992,7 +993,9 @@ def _judge_gradients(got, floor, ref, what, factor=2.0, slack=0.02, r_slack=0.05
             continue
         (rp, cp), (rf, cf) = _rel_and_corr(got[k], w), worst([_rel_and_corr(f[k], w) for f in floors])
         rows.append((k, w.numel(), rp, cp, rf, cf))
-        if not (rp <= factor * rf + slack and cp >= cf - r_slack):
+        # (two executions whose gradients correlate with the truth at r ~ 0.3 -- bf16 through 50 train-mode BatchNorm layers --
+        #  are two DRAWS: the sample correlation of n elements scatters by (1 - r^2) / sqrt(n), their difference by sqrt(2) x that)
+        if not (rp <= factor * rf + slack and cp >= cf - r_slack - 3.0 * (2.0 / w.numel()) ** 0.5):
             bad.append("%s (%d): plan rel %.4f r %.4f | floor rel %.4f r %.4f" % (k, w.numel(), rp, cp, rf, cf))
     if pool["ref"]:
         w = torch.cat(pool["ref"])
