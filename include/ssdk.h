@@ -414,8 +414,15 @@ int ssdk_preprocess(const void* x, int src_dtype, int src_layout, int N, int H, 
  *                     input gradient:  a = wt16 (K = Cout, M = Cin), x = dy, bias = NULL
  *                     K must be a multiple of 8.
  *   ssdk_pw_wgrad     dw [Cout, Cin] fp32 = sum_b dy[b] x[b]^T  (dy [B, Cout, HW], x [B, Cin, HW]); per-wave fp32 partial tiles
- *                     through `workspace` (ssdk_pw_wgrad_workspace_bytes), added in index order: bit-reproducible. */
+ *                     through `workspace` (ssdk_pw_wgrad_workspace_bytes), added in index order: bit-reproducible.
+ *   ssdk_pw_forward_stats   ssdk_pw_forward + sums [M][2] = per output channel (sum y, sum y^2) over B * HW of its outputs (fp32
+ *                     accumulators, before the store's rounding): the statistics of the BatchNorm that follows the convolution (ssdk_bn_act_train_fwd_sums), without a
+ *                     pass over y.  Per-wave partials through `workspace` (ssdk_pw_stats_workspace_bytes, 16-byte aligned), added
+ *                     in index order: bit-reproducible. */
 int ssdk_pw_prepare(const float* w32, void* w16, void* wt16, int Cout, int Cin, int dtype, void* stream);
+size_t ssdk_pw_stats_workspace_bytes(int B, int K, int M, int HW);
+int ssdk_pw_forward_stats(const void* x, const void* a, const float* bias, void* y, float* sums, void* workspace,
+                          size_t workspace_bytes, int B, int K, int M, int HW, int dtype, void* stream);
 int ssdk_pw_forward(const void* x, const void* a, const float* bias, void* y, int B, int K, int M, int HW, int dtype,
                     void* stream);
 size_t ssdk_pw_wgrad_workspace_bytes(int B, int Cout, int Cin, int HW);
@@ -488,6 +495,12 @@ int ssdk_bn_train_bwd(const void* x, const void* dy, const float* weight, const 
 int ssdk_bn_act_train_fwd(const void* x, const float* weight, const float* bias, float* running_mean, float* running_var,
                           void* y, float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, int N,
                           int C, int HW, float momentum, float eps, int act, int dtype, void* stream);
+/* ... forward with the batch statistics PROVIDED: sums [C][2] = (sum x, sum x^2) over N * HW, computed by the kernel that produced
+ * x (ssdk_pw_forward_stats).  No reduction pass: finalize + apply only.  (version 240) */
+int ssdk_bn_act_train_fwd_sums(const void* x, const float* sums, const float* weight, const float* bias, float* running_mean,
+                               float* running_var, void* y, float* save_mean, float* save_invstd, void* workspace,
+                               size_t workspace_bytes, int N, int C, int HW, float momentum, float eps, int act, int dtype,
+                               void* stream);
 int ssdk_bn_act_train_bwd(const void* x, const void* dy, const float* weight, const float* bias, const float* save_mean,
                           const float* save_invstd, void* dx, float* dweight, float* dbias, void* workspace,
                           size_t workspace_bytes, int N, int C, int HW, int act, int dtype, void* stream);

@@ -32,6 +32,8 @@ struct BnParams {
   float* save_invstd;
   float* dweight;
   float* dbias;
+  const float* sums;       // optional: [C][2] = (sum x, sum x^2) over N * HW computed by the PRODUCER of x (ssdk_pw_forward_stats):
+                           // the forward pass then has no reduction of its own
   float* partial;          // [C][SPLIT][2]
   float* coef;             // [C][4] per-channel scalars of the apply pass
   int N, C, HW, split, dtype;
@@ -148,12 +150,17 @@ __global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const BnParams p) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= p.C) return;
   float s1 = 0.f, s2 = 0.f;
-  for (int s = 0; s < p.split; ++s) {
-    s1 += p.partial[((size_t)c * p.split + s) * 2 + 0];
-    s2 += p.partial[((size_t)c * p.split + s) * 2 + 1];
+  if (p.sums) {  // raw sums from the producing convolution: pivot 0
+    s1 = p.sums[2 * c + 0];
+    s2 = p.sums[2 * c + 1];
+  } else {
+    for (int s = 0; s < p.split; ++s) {
+      s1 += p.partial[((size_t)c * p.split + s) * 2 + 0];
+      s2 += p.partial[((size_t)c * p.split + s) * 2 + 1];
+    }
   }
   const float M = (float)p.N * (float)p.HW;
-  const float pivot = bn_ld1<DT>(p.x, (size_t)c * p.HW);
+  const float pivot = p.sums ? 0.f : bn_ld1<DT>(p.x, (size_t)c * p.HW);
   const float m1 = s1 / M;
   const float mean = pivot + m1;
   float var = s2 / M - m1 * m1;  // biased
@@ -469,7 +476,8 @@ static void bn_launch(const BnParams& p, hipStream_t st) {
   const dim3 agrid((unsigned)((p.HW + 256 * vn - 1) / (256 * vn)), (unsigned)NC);
 #define SSDK_BN(DT)                                                                                         \
   do {                                                                                                      \
-    if (flat_r) hipLaunchKernelGGL((bn_reduce_flat_kernel<DT, MODE>), rgrid, dim3(256), 0, st, p);          \
+    if (MODE == 0 && p.sums) {                                                                              \
+    } else if (flat_r) hipLaunchKernelGGL((bn_reduce_flat_kernel<DT, MODE>), rgrid, dim3(256), 0, st, p);   \
     else hipLaunchKernelGGL((bn_reduce_kernel<DT, MODE>), rgrid, dim3(256), 0, st, p);                      \
     if (MODE == 0) hipLaunchKernelGGL((bn_fwd_finalize_kernel<DT>), dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p); \
     else hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p);  \
@@ -540,6 +548,39 @@ extern "C" int ssdk_bn_act_train_fwd(const void* x, const float* weight, const f
   p.act = act;
   bn_launch<0>(p, (hipStream_t)stream);
   return check_launch("bn_train_fwd");
+}
+
+extern "C" int ssdk_bn_act_train_fwd_sums(const void* x, const float* sums, const float* weight, const float* bias,
+                                          float* running_mean, float* running_var, void* y, float* save_mean, float* save_invstd,
+                                          void* workspace, size_t workspace_bytes, int N, int C, int HW, float momentum, float eps,
+                                          int act, int dtype, void* stream) {
+  if (act < 0 || act > 2 || !sums) {
+    set_error("bn_train_fwd_sums: act must be 0 (none), 1 (ReLU6) or 2 (ReLU); sums must not be null");
+    return SSDK_E_BADARG;
+  }
+  if (!x || !y || !save_mean || !save_invstd || (!running_mean) != (!running_var)) {
+    set_error("bn_train_fwd_sums: null pointer");
+    return SSDK_E_BADARG;
+  }
+  BnParams p;
+  memset(&p, 0, sizeof(p));
+  const int rc = bn_common(p, "bn_train_fwd_sums", N, C, HW, dtype, workspace, workspace_bytes);
+  if (rc) return rc;
+  p.x = x;
+  p.dy = x;
+  p.out = y;
+  p.sums = sums;
+  p.weight = weight;
+  p.bias = bias;
+  p.running_mean = running_mean;
+  p.running_var = running_var;
+  p.save_mean = save_mean;
+  p.save_invstd = save_invstd;
+  p.momentum = momentum;
+  p.eps = eps;
+  p.act = act;
+  bn_launch<0>(p, (hipStream_t)stream);
+  return check_launch("bn_train_fwd_sums");
 }
 
 extern "C" int ssdk_bn_train_fwd(const void* x, const float* weight, const float* bias, float* running_mean,

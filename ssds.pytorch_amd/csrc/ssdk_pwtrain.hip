@@ -43,6 +43,7 @@ struct PwtParams {
   u32 gpi;            // 128-pixel groups per image
   u32 groups;         // B * gpi
   u32 wg_iters;       // (P) iterations of a workgroup (4 groups each)
+  float* stats;       // optional [gridDim.x * 4 waves][M][2]: per wave (sum y, sum y^2) of its outputs (fp32, before the store's rounding)
 };
 
 // 8 consecutive 16-bit elements at p (any 2-byte alignment); lanes with nvalid < 8 read element by element and zero-fill
@@ -111,22 +112,44 @@ __device__ __forceinline__ void pw_stage_a(unsigned char* lds, const u16* a, u32
   }
 }
 
+// (sum, sum of squares) of row i of the fragment over the lane's 8 pixels that lie inside the plane -- of the fp32 accumulators,
+// BEFORE the rounding of the store: the statistics of a BatchNorm over 10^5 ... 10^6 elements do not see 2^-9 of zero-mean
+// rounding per element, and unpacking the stored words cost as much as the reduction pass it was meant to save (round 6, first
+// version: forward + statistics 1 517 vs 1 088 us per step)
+__device__ __forceinline__ void pw_row_moments(const f32x4 (&acc)[8], int i, int nvalid, float& s1, float& s2) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float v = t < nvalid ? acc[t][i] : 0.f;
+    s1 += v;
+    s2 += v * v;
+  }
+}
+// sum over the 16 lanes fr of a lane group (all four groups at once)
+__device__ __forceinline__ float pw_sum16(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 // finished accumulators of fragment f (rows 4 fg + i of it, pixels 8 fr + t) -> four 16-byte stores
-template <int DT, bool TAIL>
-__device__ __forceinline__ void pw_store_frag(const f32x4 (&acc)[8], u16* yb, u32 HW, u32 M, u32 row0, int nvalid) {
+// STATS: m1[i] / m2[i] += the lane's share of (sum, sum of squares) of row i, over the pixels inside the plane
+template <int DT, bool TAIL, bool STATS = false>
+__device__ __forceinline__ void pw_store_frag(const f32x4 (&acc)[8], u16* yb, u32 HW, u32 M, u32 row0, int nvalid, float* m1 = nullptr,
+                                              float* m2 = nullptr) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (row0 + (u32)i < M) {
       const u32x4 o = {pack2_16<DT>(acc[0][i], acc[1][i]), pack2_16<DT>(acc[2][i], acc[3][i]),
                        pack2_16<DT>(acc[4][i], acc[5][i]), pack2_16<DT>(acc[6][i], acc[7][i])};
       pw_store8<TAIL>(yb + (size_t)(row0 + (u32)i) * HW, o, nvalid);
+      if constexpr (STATS) pw_row_moments(acc, i, TAIL ? nvalid : 8, m1[i], m2[i]);
     }
   }
 }
 
 // ---- (E) short K (<= 96 channels): the B operands of a 128-pixel group stay in registers, the wave walks over ALL output
 // fragments of the slice.  Expansion layers (16 -> 96 ... 96 -> 576) and the input gradients of the projections. ---------------
-template <int DT, int KS>
+template <int DT, int KS, bool STATS = false>
 __global__ __launch_bounds__(PWT_THREADS) void pw_gemm_short_kernel(const PwtParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const u32 tid = threadIdx.x, lane = tid & 63u;
@@ -136,6 +159,11 @@ __global__ __launch_bounds__(PWT_THREADS) void pw_gemm_short_kernel(const PwtPar
   const u32 m0 = blockIdx.y * (u32)(16 * p.nf);
   const u32 nf = min((u32)p.nf, (M - m0 + 15u) / 16u);
   pw_stage_a(smem, p.a, M, K, m0, nf, 0u, (u32)KS, tid);
+  // STATS: this wave's (sum, sum of squares) per output row of the slice, behind the A fragments: [nf * 16 rows][2]
+  float* wst = reinterpret_cast<float*>(smem + (size_t)p.nf * KS * 1024) + (size_t)wave * (u32)p.nf * 32u;
+  if constexpr (STATS) {
+    for (u32 i = lane; i < (u32)p.nf * 32u; i += 64u) wst[i] = 0.f;
+  }
   __syncthreads();
   const u32 gstride = gridDim.x * 4u;
   for (u32 g = blockIdx.x * 4u + wave; g < p.groups; g += gstride) {
@@ -168,16 +196,36 @@ __global__ __launch_bounds__(PWT_THREADS) void pw_gemm_short_kernel(const PwtPar
 #pragma unroll
         for (int t = 0; t < 8; ++t) acc[t] = mfma16<DT>(wa, bop[ks][t], acc[t]);
       }
-      if (tail) pw_store_frag<DT, true>(acc, yb, HW, M, row0, nvalid);
-      else pw_store_frag<DT, false>(acc, yb, HW, M, row0, 8);
+      if constexpr (STATS) {
+        float m1[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tail) pw_store_frag<DT, true, true>(acc, yb, HW, M, row0, nvalid, m1, m2);
+        else pw_store_frag<DT, false, true>(acc, yb, HW, M, row0, 8, m1, m2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float a1 = pw_sum16(m1[i]), a2 = pw_sum16(m2[i]);
+          if (fr == 0u) {  // (the wave's own words: no atomics)
+            wst[(16u * f + 4u * fg + (u32)i) * 2u + 0u] += a1;
+            wst[(16u * f + 4u * fg + (u32)i) * 2u + 1u] += a2;
+          }
+        }
+      } else {
+        if (tail) pw_store_frag<DT, true>(acc, yb, HW, M, row0, nvalid);
+        else pw_store_frag<DT, false>(acc, yb, HW, M, row0, 8);
+      }
     }
+  }
+  if constexpr (STATS) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float* dst = p.stats + ((size_t)(blockIdx.x * 4u + wave) * M + m0) * 2u;
+    for (u32 i = lane; i < nf * 32u; i += 64u)
+      if (m0 + (i >> 1) < M) dst[i] = wst[i];
   }
 }
 
 // ---- (P) long K: NF output fragments x 8 pixel sets of accumulators per wave, k-steps outermost, the weights of the slice
 // staged in chunks of PWT_KC k-steps (a workgroup's four waves walk through the chunks together).  Projection layers
 // (96 ... 960 -> 16 ... 320) and the input gradients of the expansions. -------------------------------------------------------
-template <int DT, int NF>
+template <int DT, int NF, bool STATS = false>
 __global__ __launch_bounds__(PWT_THREADS) void pw_gemm_long_kernel(const PwtParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const u32 tid = threadIdx.x, lane = tid & 63u;
@@ -190,6 +238,11 @@ __global__ __launch_bounds__(PWT_THREADS) void pw_gemm_long_kernel(const PwtPara
     pw_stage_a(smem, p.a, M, K, m0, (u32)NF, 0u, KS, tid);
     __syncthreads();
   }
+  float sm1[STATS ? NF : 1][4], sm2[STATS ? NF : 1][4];  // STATS: the lane's share of (sum, sum of squares) per output row
+#pragma unroll
+  for (int f = 0; f < (STATS ? NF : 1); ++f)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sm1[f][i] = sm2[f][i] = 0.f;
   for (u32 it = blockIdx.x; it < p.wg_iters; it += gridDim.x) {
     const u32 g = it * 4u + wave;
     const bool live = g < p.groups;  // wave-uniform; a dead wave still stages and meets the barriers
@@ -241,20 +294,41 @@ __global__ __launch_bounds__(PWT_THREADS) void pw_gemm_long_kernel(const PwtPara
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         const u32 row0 = m0 + 16u * (u32)f + 4u * fg;
-        if (tail) pw_store_frag<DT, true>(acc[f], yb, HW, M, row0, nvalid);
-        else pw_store_frag<DT, false>(acc[f], yb, HW, M, row0, 8);
+        if constexpr (STATS) {
+          if (tail) pw_store_frag<DT, true, true>(acc[f], yb, HW, M, row0, nvalid, sm1[f], sm2[f]);
+          else pw_store_frag<DT, false, true>(acc[f], yb, HW, M, row0, 8, sm1[f], sm2[f]);
+        } else {
+          if (tail) pw_store_frag<DT, true>(acc[f], yb, HW, M, row0, nvalid);
+          else pw_store_frag<DT, false>(acc[f], yb, HW, M, row0, 8);
+        }
       }
     }
   }
+  if constexpr (STATS) {
+    float* dst = p.stats + (size_t)(blockIdx.x * 4u + wave) * M * 2u;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a1 = pw_sum16(sm1[f][i]), a2 = pw_sum16(sm2[f][i]);
+        const u32 row = m0 + 16u * (u32)f + 4u * fg + (u32)i;
+        if (fr == 0u && row < M) {
+          dst[row * 2u + 0u] = a1;
+          dst[row * 2u + 1u] = a2;
+        }
+      }
+  }
 }
 
-static int pw_gemm_launch(const void* x, const void* a, const float* bias, void* y, int B, int K, int M, int HW, int dtype,
-                          hipStream_t stream) {
-  PwtParams p;
-  p.x = (const u16*)x;
-  p.a = (const u16*)a;
-  p.bias = bias;
-  p.y = (u16*)y;
+struct PwtPlan {
+  bool is_short;
+  int slices, nf;
+  unsigned gx;
+  size_t lds;
+};
+
+// geometry of a y = a x launch (shared by the launch and by the statistics workspace query)
+static PwtPlan pw_gemm_plan(PwtParams& p, int B, int K, int M, int HW, bool stats) {
   p.B = B;
   p.K = K;
   p.M = M;
@@ -265,65 +339,97 @@ static int pw_gemm_launch(const void* x, const void* a, const float* bias, void*
   p.wg_iters = (p.groups + 3u) / 4u;
   const int mf = (M + 15) / 16;
   static const int force_long = getenv("SSDK_PW_LONG") ? atoi(getenv("SSDK_PW_LONG")) : 0;
-  if (p.KS <= 3 && !force_long) {
+  PwtPlan pl;
+  pl.is_short = p.KS <= 3 && !force_long;
+  if (pl.is_short) {
     // slice: all output fragments if their A fragments fit 64 KiB, else equal slices
     int slices = (mf * p.KS + 63) / 64;
     p.nf = (mf + slices - 1) / slices;
-    slices = (mf + p.nf - 1) / p.nf;
-    const size_t lds = (size_t)p.nf * p.KS * 1024;
-    unsigned gx = (unsigned)(256 * 4 / slices);  // ~4 workgroups per CU over all slices
-    if (gx < 1u) gx = 1u;
-    if (gx > p.wg_iters) gx = p.wg_iters;
-    const dim3 grid(gx, (unsigned)slices);
-#define SSDK_PWS(DT, KS_)                                                                                              \
+    pl.slices = (mf + p.nf - 1) / p.nf;
+    pl.nf = p.nf;
+    pl.lds = (size_t)p.nf * p.KS * 1024 + (stats ? (size_t)4 * p.nf * 32 * sizeof(float) : 0);
+    pl.gx = (unsigned)(256 * 4 / pl.slices);  // ~4 workgroups per CU over all slices
+  } else {
+    // long K: NF <= 4 fragments per slice, equal slices -- and MORE slices (each re-reads x, from L2) when the pixels alone give the
+    // chip too few workgroups: 960 -> 160 on 16 x 16 maps at batch 64 is 32 workgroup iterations; as 3 slices of 4 fragments it
+    // ran on 96 workgroups in 33 us (library GEMM: 22), as 5 slices of 2 on 160
+    int slices = (mf + 3) / 4;
+    const int wanted = (int)((256u + p.wg_iters - 1u) / p.wg_iters);
+    if (slices < wanted) slices = wanted < mf ? wanted : mf;
+    const int nf = (mf + slices - 1) / slices;
+    pl.slices = (mf + nf - 1) / nf;
+    pl.nf = p.nf = nf;
+    const int nks = p.KS < PWT_KC ? p.KS : PWT_KC;
+    pl.lds = (size_t)nf * nks * 1024;
+    pl.gx = (unsigned)(256 * 3 / pl.slices);
+  }
+  if (pl.gx < 1u) pl.gx = 1u;
+  if (pl.gx > p.wg_iters) pl.gx = p.wg_iters;
+  return pl;
+}
+
+// stats_ws (optional): [gx * 4 waves][M][2] fp32 per-wave moments of the stored outputs (the caller reduces them)
+static int pw_gemm_launch(const void* x, const void* a, const float* bias, void* y, int B, int K, int M, int HW, int dtype,
+                          hipStream_t stream, float* stats_ws = nullptr, unsigned* rows_out = nullptr) {
+  PwtParams p;
+  p.x = (const u16*)x;
+  p.a = (const u16*)a;
+  p.bias = bias;
+  p.y = (u16*)y;
+  p.stats = stats_ws;
+  const bool st = stats_ws != nullptr;
+  const PwtPlan pl = pw_gemm_plan(p, B, K, M, HW, st);
+  if (rows_out) *rows_out = pl.gx * 4u;
+  const dim3 grid(pl.gx, (unsigned)pl.slices);
+  const size_t lds = pl.lds;
+  const int nf = pl.nf;
+  if (pl.is_short) {
+#define SSDK_PWS(DT, KS_, ST_)                                                                                         \
   do {                                                                                                                \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_short_kernel<DT, KS_>),                          \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_short_kernel<DT, KS_, ST_>),                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
-    hipLaunchKernelGGL((pw_gemm_short_kernel<DT, KS_>), grid, dim3(PWT_THREADS), lds, stream, p);                     \
+    hipLaunchKernelGGL((pw_gemm_short_kernel<DT, KS_, ST_>), grid, dim3(PWT_THREADS), lds, stream, p);                \
   } while (0)
-#define SSDK_PWSD(DT)                    \
-  do {                                   \
-    if (p.KS == 1) SSDK_PWS(DT, 1);      \
-    else if (p.KS == 2) SSDK_PWS(DT, 2); \
-    else SSDK_PWS(DT, 3);                \
+#define SSDK_PWSK(DT, KS_)             \
+  do {                                 \
+    if (st) SSDK_PWS(DT, KS_, true);   \
+    else SSDK_PWS(DT, KS_, false);     \
+  } while (0)
+#define SSDK_PWSD(DT)                     \
+  do {                                    \
+    if (p.KS == 1) SSDK_PWSK(DT, 1);      \
+    else if (p.KS == 2) SSDK_PWSK(DT, 2); \
+    else SSDK_PWSK(DT, 3);                \
   } while (0)
     if (dtype == SSDK_BF16) SSDK_PWSD(SSDK_BF16);
     else SSDK_PWSD(SSDK_F16);
 #undef SSDK_PWSD
+#undef SSDK_PWSK
 #undef SSDK_PWS
     return check_launch("pw_gemm_short_kernel");
   }
-  // long K: NF <= 4 fragments per slice, equal slices -- and MORE slices (each re-reads x, from L2) when the pixels alone give the
-  // chip too few workgroups: 960 -> 160 on 16 x 16 maps at batch 64 is 32 workgroup iterations; as 3 slices of 4 fragments it
-  // ran on 96 workgroups in 33 us (library GEMM: 22), as 5 slices of 2 on 160
-  int slices = (mf + 3) / 4;
-  const int wanted = (int)((256u + p.wg_iters - 1u) / p.wg_iters);
-  if (slices < wanted) slices = wanted < mf ? wanted : mf;
-  int nf = (mf + slices - 1) / slices;
-  slices = (mf + nf - 1) / nf;
-  p.nf = nf;
-  const int nks = p.KS < PWT_KC ? p.KS : PWT_KC;
-  const size_t lds = (size_t)nf * nks * 1024;
-  unsigned gx = (unsigned)(256 * 3 / slices);
-  if (gx < 1u) gx = 1u;
-  if (gx > p.wg_iters) gx = p.wg_iters;
-  const dim3 grid(gx, (unsigned)slices);
-#define SSDK_PWL(DT, NF_)                                                                                             \
+#define SSDK_PWL(DT, NF_, ST_)                                                                                        \
   do {                                                                                                                \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_long_kernel<DT, NF_>),                           \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_long_kernel<DT, NF_, ST_>),                      \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
-    hipLaunchKernelGGL((pw_gemm_long_kernel<DT, NF_>), grid, dim3(PWT_THREADS), lds, stream, p);                      \
+    hipLaunchKernelGGL((pw_gemm_long_kernel<DT, NF_, ST_>), grid, dim3(PWT_THREADS), lds, stream, p);                 \
   } while (0)
-#define SSDK_PWLD(DT)                   \
-  do {                                  \
-    if (nf == 1) SSDK_PWL(DT, 1);       \
-    else if (nf == 2) SSDK_PWL(DT, 2);  \
-    else if (nf == 3) SSDK_PWL(DT, 3);  \
-    else SSDK_PWL(DT, 4);               \
+#define SSDK_PWLN(DT, NF_)            \
+  do {                                \
+    if (st) SSDK_PWL(DT, NF_, true);  \
+    else SSDK_PWL(DT, NF_, false);    \
+  } while (0)
+#define SSDK_PWLD(DT)                    \
+  do {                                   \
+    if (nf == 1) SSDK_PWLN(DT, 1);       \
+    else if (nf == 2) SSDK_PWLN(DT, 2);  \
+    else if (nf == 3) SSDK_PWLN(DT, 3);  \
+    else SSDK_PWLN(DT, 4);               \
   } while (0)
   if (dtype == SSDK_BF16) SSDK_PWLD(SSDK_BF16);
   else SSDK_PWLD(SSDK_F16);
 #undef SSDK_PWLD
+#undef SSDK_PWLN
 #undef SSDK_PWL
   return check_launch("pw_gemm_long_kernel");
 }
@@ -550,6 +656,23 @@ static int pw_check(const void* a, const void* b, const void* c, int B, int K, i
   return SSDK_OK;
 }
 
+// sum of `rows` rows of n floats in a fixed order -> dst (<= 4096 rows: two passes through `mid`)
+static int pw_reduce_rows(const float* src, float* mid, float* dst, u32 n, u32 rows, hipStream_t st) {
+  while (true) {
+    const u32 out_rows = (rows + 63u) / 64u;
+    float* out = out_rows == 1u ? dst : mid;
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((n + 63u) / 64u, out_rows), dim3(256), 0, st, src, out, n, rows);
+    if (out_rows == 1u) break;
+    src = mid;  // (<= 4096 rows: the second pass is the last one; a third would need another buffer)
+    rows = out_rows;
+    if (rows > 64u) {
+      set_error("ssdk_pw: more than 4096 partial rows");
+      return SSDK_E_BADARG;
+    }
+  }
+  return check_launch("pw_wgrad_reduce_kernel");
+}
+
 extern "C" int ssdk_pw_forward(const void* x, const void* a, const float* bias, void* y, int B, int K, int M, int HW, int dtype,
                                void* stream) {
   int rc = pw_check(x, a, y, B, K, M, HW, dtype, "ssdk_pw_forward");
@@ -559,6 +682,36 @@ extern "C" int ssdk_pw_forward(const void* x, const void* a, const float* bias, 
     return SSDK_E_BADARG;
   }
   return pw_gemm_launch(x, a, bias, y, B, K, M, HW, dtype, (hipStream_t)stream);
+}
+
+// forward + the per-channel (sum y, sum y^2) of the stored outputs: what the BatchNorm behind the convolution needs
+extern "C" size_t ssdk_pw_stats_workspace_bytes(int B, int K, int M, int HW) {
+  if (B < 1 || K < 1 || M < 1 || HW < 1) return 0;
+  PwtParams p;
+  const PwtPlan pl = pw_gemm_plan(p, B, K, M, HW, true);
+  const size_t rows = (size_t)pl.gx * 4;
+  return (rows + (rows + 63) / 64) * (size_t)M * 2 * sizeof(float);
+}
+
+static int pw_reduce_rows(const float* src, float* mid, float* dst, u32 n, u32 rows, hipStream_t st);
+
+extern "C" int ssdk_pw_forward_stats(const void* x, const void* a, const float* bias, void* y, float* sums, void* workspace,
+                                     size_t workspace_bytes, int B, int K, int M, int HW, int dtype, void* stream) {
+  int rc = pw_check(x, a, y, B, K, M, HW, dtype, "ssdk_pw_forward_stats");
+  if (rc) return rc;
+  if (!sums || !workspace || (((uintptr_t)a) & 15) || (((uintptr_t)workspace) & 15)) {
+    set_error("ssdk_pw_forward_stats: null / misaligned pointer");
+    return SSDK_E_BADARG;
+  }
+  if (workspace_bytes < ssdk_pw_stats_workspace_bytes(B, K, M, HW)) {
+    set_error("ssdk_pw_forward_stats: workspace too small");
+    return SSDK_E_WORKSPACE;
+  }
+  unsigned rows = 0;
+  rc = pw_gemm_launch(x, a, bias, y, B, K, M, HW, dtype, (hipStream_t)stream, (float*)workspace, &rows);
+  if (rc) return rc;
+  const u32 n = (u32)M * 2u;
+  return pw_reduce_rows((const float*)workspace, (float*)workspace + (size_t)rows * n, sums, n, rows, (hipStream_t)stream);
 }
 
 extern "C" size_t ssdk_pw_wgrad_workspace_bytes(int B, int Cout, int Cin, int HW) {
@@ -623,22 +776,7 @@ extern "C" int ssdk_pw_wgrad(const void* dy, const void* x, float* dw, void* ws,
   int rc = check_launch(tiled ? "pw_wgrad_tiled_kernel" : "pw_wgrad_kernel");
   if (rc) return rc;
   const u32 n = (u32)Cout * (u32)Cin;
-  const float* src = (const float*)ws;
-  float* mid = (float*)ws + (size_t)p.splits * n;  // second-level rows behind the partials
-  u32 rows = p.splits;
-  while (true) {
-    const u32 out_rows = (rows + 63u) / 64u;
-    float* dst = out_rows == 1u ? dw : mid;
-    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((n + 63u) / 64u, out_rows), dim3(256), 0, st, src, dst, n, rows);
-    if (out_rows == 1u) break;
-    src = mid;  // (<= 4096 partials: the second pass is the last one; a third would need another buffer)
-    rows = out_rows;
-    if (rows > 64u) {
-      set_error("ssdk_pw_wgrad: more than 4096 partial tiles");
-      return SSDK_E_BADARG;
-    }
-  }
-  return check_launch("pw_wgrad_reduce_kernel");
+  return pw_reduce_rows((const float*)ws, (float*)ws + (size_t)p.splits * n, dw, n, p.splits, st);
 }
 
 // w32 [Cout, Cin] fp32 (the master weights) -> w16 [Cout, Cin] and wt16 [Cin, Cout] in the compute dtype: the cast autocast

@@ -23,7 +23,9 @@ def _ws(dev, n, c):
 
 class _BatchNormTrain(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act=0):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act=0, sums=None):
+        """``sums``: [C, 2] fp32 (sum x, sum x^2) over N * H * W from the kernel that produced x (pointwise.pointwise_conv with
+        want_sums): the forward pass then has no reduction of its own (ssdk_bn_act_train_fwd_sums)."""
         x = x.contiguous()
         n, c = int(x.shape[0]), int(x.shape[1])
         hw = int(x.shape[2]) * int(x.shape[3])
@@ -34,10 +36,17 @@ class _BatchNormTrain(torch.autograd.Function):
         ws, need = _ws(dev, n, c)
         wp = (ws.data_ptr() + 15) & ~15
         with torch.cuda.device(dev):
-            N.check(N.lib.ssdk_bn_act_train_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(),
-                                                running_var.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), wp,
-                                                need, n, c, hw, float(momentum), float(eps), int(act), N.dtype_code(x),
-                                                N.stream_ptr(dev)), "bn_train_fwd")
+            if sums is not None:
+                N.check(N.lib.ssdk_bn_act_train_fwd_sums(x.data_ptr(), sums.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                                         running_mean.data_ptr(), running_var.data_ptr(), y.data_ptr(),
+                                                         mean.data_ptr(), invstd.data_ptr(), wp, need, n, c, hw, float(momentum),
+                                                         float(eps), int(act), N.dtype_code(x), N.stream_ptr(dev)),
+                        "bn_train_fwd_sums")
+            else:
+                N.check(N.lib.ssdk_bn_act_train_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(),
+                                                    running_var.data_ptr(), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), wp,
+                                                    need, n, c, hw, float(momentum), float(eps), int(act), N.dtype_code(x),
+                                                    N.stream_ptr(dev)), "bn_train_fwd")
         ctx.save_for_backward(x, weight, bias, mean, invstd)
         ctx.act = int(act)
         ctx.mark_non_differentiable(running_mean, running_var)
@@ -62,7 +71,7 @@ class _BatchNormTrain(torch.autograd.Function):
                                                 mean.data_ptr(), invstd.data_ptr(), gx.data_ptr(), gw.data_ptr(),
                                                 gb.data_ptr(), wp, need, n, c, hw, ctx.act, N.dtype_code(x),
                                                 N.stream_ptr(dev)), "bn_train_bwd")
-        return gx, gw.to(weight.dtype), gb.to(weight.dtype), None, None, None, None, None
+        return gx, gw.to(weight.dtype), gb.to(weight.dtype), None, None, None, None, None, None
 
 
 class FastBatchNorm2d(nn.BatchNorm2d):
@@ -76,9 +85,12 @@ class FastBatchNorm2d(nn.BatchNorm2d):
         if not self._ssdk_counter_external:
             self.num_batches_tracked.add_(1)  # nn.BatchNorm2d bookkeeping (batchnorm.py of torch)
         momentum = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+        sums = x.__dict__.pop("_ssdk_bn_sums", None) if hasattr(x, "__dict__") else None  # (from the producing 1x1 convolution)
+        if sums is not None and (tuple(sums.shape) != (x.shape[1], 2) or not x.is_contiguous()):
+            sums = None
         with torch.autocast("cuda", enabled=False):
             y = _BatchNormTrain.apply(x, self.weight, self.bias, self.running_mean, self.running_var, momentum, self.eps,
-                                      self._ssdk_act)
+                                      self._ssdk_act, sums)
         if self._ssdk_act:
             y._ssdk_act_applied = self._ssdk_act  # read by the activation module that follows (and by nothing else)
         return y

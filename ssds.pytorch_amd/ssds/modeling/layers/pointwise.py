@@ -74,7 +74,9 @@ class _PointwiseNative(torch.autograd.Function):
         weight gradient  ssdk_pw_wgrad (fp32, fixed-order reduction)"""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, want_sums=False):
+        """``want_sums``: also return sums [Cout, 2] = per-channel (sum y, sum y^2) of the stored outputs -- the batch
+        statistics of the BatchNorm that follows (ssdk_pw_forward_stats: no pass over y); non-differentiable."""
         b, cin, h, wd = (int(v) for v in x.shape)
         cout, hw, dev, dt = int(w.shape[0]), h * wd, x.device, x.dtype
         code = N.dtype_code(x)
@@ -90,14 +92,26 @@ class _PointwiseNative(torch.autograd.Function):
                 wt16 = w16.t().contiguous()
             b32 = None if bias is None else bias.detach().float().contiguous()
             y = torch.empty((b, cout, h, wd), device=dev, dtype=dt)
-            N.check(N.lib.ssdk_pw_forward(x.data_ptr(), w16.data_ptr(), None if b32 is None else b32.data_ptr(), y.data_ptr(),
-                                          b, cin, cout, hw, code, sp), "pw_forward")
+            sums = None
+            if want_sums:
+                need = int(N.lib.ssdk_pw_stats_workspace_bytes(b, cin, cout, hw))
+                ws = torch.empty(need + 16, dtype=torch.uint8, device=dev)
+                sums = torch.empty((cout, 2), device=dev, dtype=torch.float32)
+                N.check(N.lib.ssdk_pw_forward_stats(x.data_ptr(), w16.data_ptr(), None if b32 is None else b32.data_ptr(), y.data_ptr(),
+                                                    sums.data_ptr(), (ws.data_ptr() + 15) & ~15, need, b, cin, cout, hw, code, sp),
+                        "pw_forward_stats")
+            else:
+                N.check(N.lib.ssdk_pw_forward(x.data_ptr(), w16.data_ptr(), None if b32 is None else b32.data_ptr(), y.data_ptr(),
+                                              b, cin, cout, hw, code, sp), "pw_forward")
         ctx.save_for_backward(x, wt16)
         ctx.meta = (w.dtype, None if bias is None else bias.dtype)
+        if want_sums:
+            ctx.mark_non_differentiable(sums)
+            return y, sums
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gsums=None):
         x, wt16 = ctx.saved_tensors
         wdt, bdt = ctx.meta
         b, cin, h, wd = (int(v) for v in x.shape)
@@ -125,12 +139,18 @@ class _PointwiseNative(torch.autograd.Function):
                 gw = gw32 if wdt == torch.float32 else gw32.to(wdt)
         if bdt is not None and ctx.needs_input_grad[2]:
             gb = gy.sum((0, 2, 3), dtype=torch.float32).to(bdt)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
-def pointwise_conv(x, weight, bias=None):
-    """1x1 / stride 1 convolution of a contiguous NCHW tensor: weight [Cout,Cin,1,1], same floating dtype; differentiable."""
+def pointwise_conv(x, weight, bias=None, want_sums=False):
+    """1x1 / stride 1 convolution of a contiguous NCHW tensor: weight [Cout,Cin,1,1], same floating dtype; differentiable.
+    ``want_sums`` (16-bit HIP tensors only): the output carries ``_ssdk_bn_sums`` = [Cout, 2] (sum y, sum y^2) for the
+    kernel-backed BatchNorm that follows (batchnorm.FastBatchNorm2d reads and consumes the attribute)."""
     if _native_ok(x, int(x.shape[1])):
+        if want_sums:
+            y, sums = _PointwiseNative.apply(x, weight, bias, True)
+            y._ssdk_bn_sums = sums
+            return y
         return _PointwiseNative.apply(x, weight, bias)
     if weight.dtype != x.dtype:
         weight = weight.to(x.dtype)
@@ -138,7 +158,12 @@ def pointwise_conv(x, weight, bias=None):
     return _Pointwise.apply(x, weight, bias)
 
 
+BN_STATS_MIN_BYTES = 64 << 20  # output tensors from 64 MiB on hand their BatchNorm the statistics
+
+
 class PointwiseConv2d(nn.Conv2d):
+    _ssdk_bn_follows = False  # set by fuse_conv_bn_statistics: the next module is a kernel-backed BatchNorm in training mode
+
     def _native(self, x):
         return (x.is_cuda and x.dim() == 4 and self.kernel_size == (1, 1) and self.stride == (1, 1)
                 and self.padding == (0, 0) and self.dilation == (1, 1) and self.groups == 1
@@ -156,8 +181,33 @@ class PointwiseConv2d(nn.Conv2d):
                 bias = bias.to(dt) if bias is not None else None
         elif w.dtype != x.dtype:
             return super(PointwiseConv2d, self).forward(x)
+        # the statistics ride on the convolution only where the BatchNorm's own pass over y costs more than they do: measured
+        # (tools/pw_probe.py, round 6) + 7 ... 39 us on the kernel + two small reduce launches against y bytes / ~5 TB/s
+        want = (self._ssdk_bn_follows and self.training
+                and x.shape[0] * self.out_channels * x.shape[2] * x.shape[3] * 2 >= BN_STATS_MIN_BYTES)
         with torch.autocast("cuda", enabled=False):
-            return pointwise_conv(x, w, bias)
+            return pointwise_conv(x, w, bias, want_sums=want)
+
+
+def fuse_conv_bn_statistics(model):
+    """For every ``nn.Sequential`` of ``model`` in which a PointwiseConv2d is directly followed by a kernel-backed BatchNorm
+    (batchnorm.FastBatchNorm2d): the convolution's forward kernel also produces the per-channel (sum, sum of squares) of its
+    output and the BatchNorm starts from them -- one full pass over the activation less per Conv-BN pair (call after
+    use_pointwise_gemm and use_fast_batchnorm; SSDK_BN_STATS_FUSED=0 keeps the BatchNorm's own reduction).  -> pairs found."""
+    from ssds.modeling.layers.batchnorm import FastBatchNorm2d
+
+    n = 0
+    if os.environ.get("SSDK_BN_STATS_FUSED", "1") == "0":
+        return n
+    for seq in model.modules():
+        if not isinstance(seq, nn.Sequential):
+            continue
+        mods = list(seq.children())
+        for conv, bn in zip(mods, mods[1:]):
+            if type(conv) is PointwiseConv2d and type(bn) is FastBatchNorm2d:
+                conv._ssdk_bn_follows = True
+                n += 1
+    return n
 
 
 def use_pointwise_gemm(model):

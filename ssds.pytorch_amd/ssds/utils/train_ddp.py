@@ -48,6 +48,10 @@ class Solver(object):
             from ssds.modeling.layers.pointwise import use_pointwise_gemm
 
             use_pointwise_gemm(self.model)  # 1x1 convolutions on the NCHW tensors (16 bit: csrc/ssdk_pwtrain.hip; fp32: library GEMMs)
+            if os.environ.get("SSDK_FAST_BN", "1") != "0" and not sync_bn:
+                from ssds.modeling.layers.pointwise import fuse_conv_bn_statistics
+
+                fuse_conv_bn_statistics(self.model)  # the 1x1 kernels hand their BatchNorm the batch statistics
         if os.environ.get("SSDK_CONV3_NATIVE", "0") == "1":
             # stem / extras / head 3x3 convolutions as im2col + the same kernels.  Correct (tests/test_gpu_train.py) and OFF by
             # default: measured 23.2 vs 20.8 ms per step against MIOpen's implicit-GEMM kernels (round 6, session 4: the streaming

@@ -51,6 +51,11 @@ for cin, cout, side, cnt in SHAPES:
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
     gw = torch.empty(cout, cin, device="cuda")
     x3, gy3 = x.view(B, cin, -1), gy.view(B, cout, -1)
+    sneed = int(N.lib.ssdk_pw_stats_workspace_bytes(B, cin, cout, hw))
+    sws = torch.empty(sneed + 16, dtype=torch.uint8, device="cuda")
+    sums = torch.empty(cout, 2, device="cuda")
+    t_stats = t(lambda: N.check(N.lib.ssdk_pw_forward_stats(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), sums.data_ptr(),
+                                                            (sws.data_ptr() + 15) & ~15, sneed, B, cin, cout, hw, 1, sp), "fs"))
     r = [t(lambda: N.check(N.lib.ssdk_pw_forward(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, cin, cout, hw, 1, sp), "f")),
          t(lambda: N.check(N.lib.ssdk_pw_forward(gy.data_ptr(), wt.data_ptr(), None, gx.data_ptr(), B, cout, cin, hw, 1, sp), "d")),
          t(lambda: N.check(N.lib.ssdk_pw_wgrad(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), ws.data_ptr(), need, B, cout, cin, hw, 1, sp), "w")),
@@ -61,6 +66,9 @@ for cin, cout, side, cnt in SHAPES:
     fr = [byt / (v * 1e-6) / PEAK for v in r[:3]]
     tot = [a + b * cnt for a, b in zip(tot, r)]
     ideal += cnt * byt / PEAK * 1e6
-    print("%4d>%-4d @%-3d   %2d | %8.1f %8.1f %8.1f | %8.1f %8.1f %8.1f | %5.2f %5.2f %5.2f" % ((cin, cout, side, cnt) + tuple(r) + tuple(fr)), flush=True)
+    tot_stats = globals().get("tot_stats", 0.0) + t_stats * cnt
+    print("%4d>%-4d @%-3d   %2d | %8.1f %8.1f %8.1f | %8.1f %8.1f %8.1f | %5.2f %5.2f %5.2f | fwd + BN statistics %8.1f" % (
+        (cin, cout, side, cnt) + tuple(r) + tuple(fr) + (t_stats,)), flush=True)
+print("forward with the BatchNorm statistics (ssdk_pw_forward_stats), layers counted: %.1f us" % tot_stats)
 print("%-19s | %8.1f %8.1f %8.1f | %8.1f %8.1f %8.1f |  (us per step, layers counted; HBM time of one pass at 8 TB/s: %.1f us)"
       % (("total",) + tuple(tot) + (ideal,)))
