@@ -458,6 +458,13 @@ int ssdk_sgd_step(int n, void* const* params, const void* const* grads, void* co
  * Any plane size; pointers need only the alignment of their element type (rows are read and written as unaligned
  * 16-byte runs). */
 int ssdk_dwconv_fwd(const void* x, const void* w, void* y, int N, int C, int H, int W, int stride, int dtype, void* stream);
+/* (version 240) forward + sums [C][2] = per channel (sum y, sum y^2) over N * Ho * Wo of its outputs (fp32 accumulators, before the
+ * store's rounding): the batch statistics of the BatchNorm behind the convolution (ssdk_bn_act_train_fwd_sums), without a pass over
+ * y.  Per-workgroup partials through `workspace` (16-byte aligned), added in index order.  ssdk_dwconv_fwd_stats_workspace_bytes
+ * returns 0 where the geometry runs on the tiled fallback kernels (rows too wide): call ssdk_dwconv_fwd there. */
+size_t ssdk_dwconv_fwd_stats_workspace_bytes(int N, int C, int H, int W, int stride, int dtype);
+int ssdk_dwconv_fwd_stats(const void* x, const void* w, void* y, float* sums, void* workspace, size_t workspace_bytes, int N, int C,
+                          int H, int W, int stride, int dtype, void* stream);
 int ssdk_dwconv_bwd_data(const void* dy, const void* w, void* dx, int N, int C, int H, int W, int stride, int dtype,
                          void* stream);
 size_t ssdk_dwconv_bwd_weight_workspace_bytes(int N, int C, int H, int W, int stride);

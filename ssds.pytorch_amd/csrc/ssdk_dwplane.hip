@@ -32,6 +32,7 @@ struct DwpParams {
   const void* a;   // staged tensor: x (forward, weight gradient) | dy (input gradient)
   const void* b;   // w [C][9] in the activation dtype (forward, input gradient) | dy (weight gradient)
   void* out;       // y | dx | partial sums [groups][C][9] fp32
+  float* stats;    // forward only, optional: [groups][C][2] per-workgroup (sum y, sum y^2) of its outputs (fp32, before the store)
   int N, C;
   int Hs, Ws;      // plane of the staged tensor
   int Ht, Wt;      // plane of the thread space: y (forward), dx (input gradient), dy (weight gradient)
@@ -263,11 +264,15 @@ __device__ __forceinline__ bool dwp_unit(const DwpParams& p, const DwpWhere& w, 
 
 // forward (FLIP = false) and the stride-1 input gradient (FLIP = true: the same window with the taps reversed, staged
 // tensor = dy):  out[r][8g + e] = sum w[ky][kx] * a[S r + ky - 1][S (8g + e) + kx - 1]
-template <int DT, int S, bool FLIP>
+// STATS (round 6, forward only): the workgroup owns ONE channel -- it also leaves (sum y, sum y^2) of its outputs for the
+// BatchNorm behind the convolution (ssdk_bn_act_train_fwd_sums): per thread in registers, then a fixed-order block sum.
+template <int DT, int S, bool FLIP, bool STATS = false>
 __global__ __launch_bounds__(kDwpThreads) void dwp_fwd_kernel(const DwpParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float sred[2][kDwpThreads / 64];
   const DwpWhere wh = dwp_where(p);
   if (!wh.live) return;
+  float st1 = 0.f, st2 = 0.f;
   float w[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) w[t] = dwp_ld<DT>(p.b, (size_t)wh.c * 9 + (FLIP ? 8 - t : t));
@@ -303,6 +308,35 @@ __global__ __launch_bounds__(kDwpThreads) void dwp_fwd_kernel(const DwpParams p)
     }
     const int oy = wh.r0 + q.r, ox = q.g * 8;
     dwp_store8<DT>(p.out, ((size_t)(wh.n0 + q.i) * p.C + wh.c) * p.Ht * p.Wt + (size_t)oy * p.Wt + ox, acc, p.Wt - ox);
+    if constexpr (STATS) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = e < p.Wt - ox ? acc[e] : 0.f;
+        st1 += v;
+        st2 += v * v;
+      }
+    }
+  }
+  if constexpr (STATS) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      st1 += __shfl_xor(st1, o, 64);
+      st2 += __shfl_xor(st2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      sred[0][threadIdx.x >> 6] = st1;
+      sred[1][threadIdx.x >> 6] = st2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float a = 0.f, b = 0.f;
+      for (int w = 0; w < kDwpThreads / 64; ++w) {  // wave order: bit-reproducible
+        a += sred[0][w];
+        b += sred[1][w];
+      }
+      p.stats[((size_t)wh.grp * p.C + wh.c) * 2 + 0] = a;
+      p.stats[((size_t)wh.grp * p.C + wh.c) * 2 + 1] = b;
+    }
   }
 }
 
@@ -581,22 +615,35 @@ static bool dwp_enabled() {
   } while (0)
 
 // 0: launched; 1: not taken (the caller uses the tiled kernels of ssdk_dwtrain.hip)
-int launch_dwp_fwd(const void* x, const void* w, void* y, int N, int C, int H, int W, int stride, int dtype, hipStream_t stream) {
+int launch_dwp_fwd(const void* x, const void* w, void* y, int N, int C, int H, int W, int stride, int dtype, hipStream_t stream,
+                   float* stats, int* groups_out) {
   if (!dwp_enabled()) return 1;
   DwpPlan pl = dwp_plan(DWP_FWD, N, C, H, W, stride, dtype != SSDK_F32);
   if (!pl.ok) return 1;
   pl.p.a = x;
   pl.p.b = w;
   pl.p.out = y;
+  pl.p.stats = stats;
+  if (groups_out) *groups_out = pl.groups;
   const dim3 grid((unsigned)(pl.p.nwg8 * 8));
 #define SSDK_DWP_FWD(DT)                                                                                                 \
   do {                                                                                                                   \
-    if (stride == 1) hipLaunchKernelGGL((dwp_fwd_kernel<DT, 1, false>), grid, dim3(kDwpThreads), pl.lds, stream, pl.p);   \
+    if (stats) {                                                                                                         \
+      if (stride == 1) hipLaunchKernelGGL((dwp_fwd_kernel<DT, 1, false, true>), grid, dim3(kDwpThreads), pl.lds, stream, pl.p); \
+      else hipLaunchKernelGGL((dwp_fwd_kernel<DT, 2, false, true>), grid, dim3(kDwpThreads), pl.lds, stream, pl.p);       \
+    } else if (stride == 1) hipLaunchKernelGGL((dwp_fwd_kernel<DT, 1, false>), grid, dim3(kDwpThreads), pl.lds, stream, pl.p); \
     else hipLaunchKernelGGL((dwp_fwd_kernel<DT, 2, false>), grid, dim3(kDwpThreads), pl.lds, stream, pl.p);               \
   } while (0)
   SSDK_DWP_BY_DTYPE(SSDK_DWP_FWD);
 #undef SSDK_DWP_FWD
   return 0;
+}
+
+// partial-sum groups of the forward statistics (0: the whole-row kernels do not take the pass)
+int dwp_fwd_groups(int N, int C, int H, int W, int stride, int dtype) {
+  if (!dwp_enabled()) return 0;
+  const DwpPlan pl = dwp_plan(DWP_FWD, N, C, H, W, stride, dtype != SSDK_F32);
+  return pl.ok ? pl.groups : 0;
 }
 
 int launch_dwp_dgrad(const void* dy, const void* w, void* dx, int N, int C, int H, int W, int stride, int dtype, hipStream_t stream) {

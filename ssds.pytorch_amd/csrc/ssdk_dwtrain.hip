@@ -319,7 +319,10 @@ static constexpr size_t dwt_lds_dy(int s) {  // tile of dy behind a DT_TH x DT_T
 }
 
 // ssdk_dwplane.hip: the whole-row kernels (0: launched, 1: not taken)
-int launch_dwp_fwd(const void* x, const void* w, void* y, int N, int C, int H, int W, int stride, int dtype, hipStream_t stream);
+int launch_dwp_fwd(const void* x, const void* w, void* y, int N, int C, int H, int W, int stride, int dtype, hipStream_t stream,
+                   float* stats = nullptr, int* groups_out = nullptr);
+int dwp_fwd_groups(int N, int C, int H, int W, int stride, int dtype);
+int reduce_rows_fixed_order(const float* src, float* mid, float* dst, unsigned n, unsigned rows, hipStream_t st);  // ssdk_pwtrain.hip
 int launch_dwp_dgrad(const void* dy, const void* w, void* dx, int N, int C, int H, int W, int stride, int dtype, hipStream_t stream);
 size_t dwp_wgrad_workspace_bytes(int N, int C, int H, int W, int stride);
 int launch_dwp_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int C, int H, int W,
@@ -338,6 +341,35 @@ extern "C" int ssdk_dwconv_fwd(const void* x, const void* w, void* y, int N, int
   const dim3 grid((unsigned)(p.tiles_x * p.tiles_y), (unsigned)(N * C));
   SSDK_DWT_LAUNCH(dw_fwd_kernel, grid, dwt_lds_in(1), dwt_lds_in(2));
   return check_launch("dw_fwd_kernel");
+}
+
+// forward + sums [C][2] = per channel (sum y, sum y^2) over N * Ho * Wo of the outputs (fp32, before the store's rounding): the batch
+// statistics of the BatchNorm behind the convolution (ssdk_bn_act_train_fwd_sums).  workspace: ssdk_dwconv_fwd_stats_workspace_bytes
+// (0: this geometry runs on the tiled kernels, which do not produce statistics -- call ssdk_dwconv_fwd).
+extern "C" size_t ssdk_dwconv_fwd_stats_workspace_bytes(int N, int C, int H, int W, int stride, int dtype) {
+  if (N < 1 || C < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2)) return 0;
+  const int g = dwp_fwd_groups(N, C, H, W, stride, dtype);
+  if (g <= 0 || g > 4096) return 0;
+  return ((size_t)g + (size_t)((g + 63) / 64)) * (size_t)C * 2 * sizeof(float);
+}
+
+extern "C" int ssdk_dwconv_fwd_stats(const void* x, const void* w, void* y, float* sums, void* workspace, size_t workspace_bytes,
+                                     int N, int C, int H, int W, int stride, int dtype, void* stream) {
+  const int rc = dwt_check("dwconv_fwd_stats", x, w, y, N, C, H, W, stride, dtype);
+  if (rc) return rc;
+  const size_t need = ssdk_dwconv_fwd_stats_workspace_bytes(N, C, H, W, stride, dtype);
+  if (!sums || !workspace || need == 0 || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
+    set_error("dwconv_fwd_stats: no workspace / this geometry does not run on the whole-row kernels");
+    return SSDK_E_WORKSPACE;
+  }
+  int groups = 0;
+  if (launch_dwp_fwd(x, w, y, N, C, H, W, stride, dtype, (hipStream_t)stream, (float*)workspace, &groups) != 0) {
+    set_error("dwconv_fwd_stats: the whole-row kernels declined");
+    return SSDK_E_BADARG;
+  }
+  const unsigned n = (unsigned)C * 2u;
+  return reduce_rows_fixed_order((const float*)workspace, (float*)workspace + (size_t)groups * n, sums, n, (unsigned)groups,
+                                 (hipStream_t)stream);
 }
 
 extern "C" int ssdk_dwconv_bwd_data(const void* dy, const void* w, void* dx, int N, int C, int H, int W, int stride,

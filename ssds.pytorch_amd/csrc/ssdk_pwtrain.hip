@@ -673,6 +673,12 @@ static int pw_reduce_rows(const float* src, float* mid, float* dst, u32 n, u32 r
   return check_launch("pw_wgrad_reduce_kernel");
 }
 
+namespace ssdk {
+int reduce_rows_fixed_order(const float* src, float* mid, float* dst, unsigned n, unsigned rows, hipStream_t st) {
+  return pw_reduce_rows(src, mid, dst, n, rows, st);
+}
+}  // namespace ssdk
+
 extern "C" int ssdk_pw_forward(const void* x, const void* a, const float* bias, void* y, int B, int K, int M, int HW, int dtype,
                                void* stream) {
   int rc = pw_check(x, a, y, B, K, M, HW, dtype, "ssdk_pw_forward");

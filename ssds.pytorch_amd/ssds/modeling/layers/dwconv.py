@@ -19,21 +19,37 @@ def _launch(fn, *args):
 
 class _DwConv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, stride):
+    def forward(ctx, x, w, stride, want_sums=False):
+        """``want_sums``: also return sums [C, 2] = per-channel (sum y, sum y^2) of the outputs -- the batch statistics of the
+        BatchNorm that follows (ssdk_dwconv_fwd_stats: no pass over y); non-differentiable; None where the geometry runs on the
+        tiled fallback kernels."""
         x = x.contiguous()
         w = w.contiguous()
         n, c, h, wd = (int(v) for v in x.shape)
         ho, wo = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
         y = torch.empty((n, c, ho, wo), device=x.device, dtype=x.dtype)
+        sums = None
         with torch.cuda.device(x.device):
-            _launch(N.lib.ssdk_dwconv_fwd, x.data_ptr(), w.data_ptr(), y.data_ptr(), n, c, h, wd, stride, N.dtype_code(x),
-                    N.stream_ptr(x.device))
+            need = int(N.lib.ssdk_dwconv_fwd_stats_workspace_bytes(n, c, h, wd, stride, N.dtype_code(x))) if want_sums else 0
+            if need:
+                ws = torch.empty(need + 16, dtype=torch.uint8, device=x.device)
+                sums = torch.empty((c, 2), device=x.device, dtype=torch.float32)
+                N.check(N.lib.ssdk_dwconv_fwd_stats(x.data_ptr(), w.data_ptr(), y.data_ptr(), sums.data_ptr(), (ws.data_ptr() + 15) & ~15,
+                                                    need, n, c, h, wd, stride, N.dtype_code(x), N.stream_ptr(x.device)), "dwconv_fwd_stats")
+            else:
+                _launch(N.lib.ssdk_dwconv_fwd, x.data_ptr(), w.data_ptr(), y.data_ptr(), n, c, h, wd, stride, N.dtype_code(x),
+                        N.stream_ptr(x.device))
         ctx.save_for_backward(x, w)
         ctx.stride = stride
+        if want_sums:
+            if sums is None:
+                sums = torch.empty(0, device=x.device)
+            ctx.mark_non_differentiable(sums)
+            return y, sums
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gsums=None):
         x, w = ctx.saved_tensors
         stride = ctx.stride
         gy = gy.contiguous()
@@ -54,17 +70,24 @@ class _DwConv3x3(torch.autograd.Function):
                 _launch(N.lib.ssdk_dwconv_bwd_weight, x.data_ptr(), gy.data_ptr(), gw32.data_ptr(), ws.data_ptr(), need,
                         n, c, h, wd, stride, N.dtype_code(x), N.stream_ptr(dev))
                 gw = gw32.to(w.dtype)
-        return gx, gw, None
+        return gx, gw, None, None
 
 
-def dwconv3x3(x, weight, stride):
-    """Depthwise 3x3, pad 1, no bias: x [N,C,H,W], weight [C,1,3,3] (same floating dtype), differentiable."""
+def dwconv3x3(x, weight, stride, want_sums=False):
+    """Depthwise 3x3, pad 1, no bias: x [N,C,H,W], weight [C,1,3,3] (same floating dtype), differentiable.  ``want_sums``: the
+    output carries ``_ssdk_bn_sums`` = [C, 2] for the kernel-backed BatchNorm behind it (see pointwise.pointwise_conv)."""
+    if want_sums:
+        y, sums = _DwConv3x3.apply(x, weight, stride, True)
+        if sums.numel():
+            y._ssdk_bn_sums = sums
+        return y
     return _DwConv3x3.apply(x, weight, stride)
 
 
 class DepthwiseConv2d(nn.Conv2d):
     """``nn.Conv2d(C, C, 3, stride, 1, groups=C, bias=False)`` whose HIP-device forward/backward run on the
     ssdk kernels; anything else falls through to ``nn.Conv2d.forward``."""
+    _ssdk_bn_follows = False  # set by pointwise.fuse_conv_bn_statistics: the next module is a kernel-backed BatchNorm
 
     def _native(self, x):
         return (x.is_cuda and x.dim() == 4 and self.kernel_size == (3, 3) and self.padding == (1, 1)
@@ -83,8 +106,13 @@ class DepthwiseConv2d(nn.Conv2d):
             w = w.to(x.dtype)
         if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
             return super(DepthwiseConv2d, self).forward(x)
+        from ssds.modeling.layers import pointwise as _pw
+
+        ho, wo = (x.shape[2] - 1) // self.stride[0] + 1, (x.shape[3] - 1) // self.stride[0] + 1
+        want = (self._ssdk_bn_follows and self.training and x.dtype != torch.float32
+                and x.shape[0] * x.shape[1] * ho * wo * 2 >= _pw.BN_STATS_MIN_BYTES)
         with torch.autocast("cuda", enabled=False):
-            return dwconv3x3(x, w, self.stride[0])
+            return dwconv3x3(x, w, self.stride[0], want_sums=want)
 
 
 def make_conv2d(in_planes, out_planes, kernel_size, stride=1, padding=0, groups=1, bias=True):

@@ -190,11 +190,12 @@ class PointwiseConv2d(nn.Conv2d):
 
 
 def fuse_conv_bn_statistics(model):
-    """For every ``nn.Sequential`` of ``model`` in which a PointwiseConv2d is directly followed by a kernel-backed BatchNorm
+    """For every ``nn.Sequential`` of ``model`` in which a PointwiseConv2d or a DepthwiseConv2d is directly followed by a kernel-backed BatchNorm
     (batchnorm.FastBatchNorm2d): the convolution's forward kernel also produces the per-channel (sum, sum of squares) of its
     output and the BatchNorm starts from them -- one full pass over the activation less per Conv-BN pair (call after
     use_pointwise_gemm and use_fast_batchnorm; SSDK_BN_STATS_FUSED=0 keeps the BatchNorm's own reduction).  -> pairs found."""
     from ssds.modeling.layers.batchnorm import FastBatchNorm2d
+    from ssds.modeling.layers.dwconv import DepthwiseConv2d
 
     n = 0
     if os.environ.get("SSDK_BN_STATS_FUSED", "1") == "0":
@@ -204,7 +205,7 @@ def fuse_conv_bn_statistics(model):
             continue
         mods = list(seq.children())
         for conv, bn in zip(mods, mods[1:]):
-            if type(conv) is PointwiseConv2d and type(bn) is FastBatchNorm2d:
+            if type(conv) in (PointwiseConv2d, DepthwiseConv2d) and type(bn) is FastBatchNorm2d:
                 conv._ssdk_bn_follows = True
                 n += 1
     return n

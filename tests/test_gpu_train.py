@@ -563,6 +563,61 @@ def test_pointwise_conv_hands_its_batchnorm_the_statistics(n, cin, cout, h, w, d
             assert float(rel.max()) <= 8 * eps, "%s: %.3g" % (what, float(rel.max()))
 
 
+@pytest.mark.parametrize("dtype_name", ["bfloat16", "float16"])
+@pytest.mark.parametrize("n,c,h,w,stride", [(4, 32, 64, 64, 1), (3, 96, 33, 31, 2), (2, 144, 16, 16, 2), (7, 8, 19, 19, 1), (2, 16, 5, 130, 1)])
+def test_depthwise_conv_hands_its_batchnorm_the_statistics(n, c, h, w, stride, dtype_name, monkeypatch):
+    """ssdk_dwconv_fwd_stats (round 6): the whole-row depthwise forward kernel also leaves (sum y, sum y^2) per channel; they
+    equal those of the tensor it stored to its rounding, the outputs are the plain forward's bit for bit, everything is
+    bit-reproducible, and dw-Conv-BN-ReLU6 with the statistics handed over matches the BatchNorm's own reduction pass."""
+    import copy
+    import torch
+    import torch.nn as nn
+    from ssds.modeling.layers import pointwise as PW
+    from ssds.modeling.layers.batchnorm import fuse_bn_activations, use_fast_batchnorm
+    from ssds.modeling.layers.dwconv import DepthwiseConv2d, dwconv3x3
+
+    dtype = getattr(torch, dtype_name)
+    torch.manual_seed(n + c + h)
+    x = (torch.randn(n, c, h, w, device="cuda") + 0.2).to(dtype)
+    wgt = (torch.randn(c, 1, 3, 3, device="cuda") * 0.4).to(dtype)
+    y = dwconv3x3(x, wgt, stride, want_sums=True)
+    sums = y._ssdk_bn_sums
+    want = torch.stack([y.double().sum((0, 2, 3)), y.double().pow(2).sum((0, 2, 3))], 1)
+    cnt = y.numel() // c
+    tol = 6e-3 if dtype_name == "bfloat16" else 1e-3
+    assert float(((sums.double() - want).abs()[:, 0] / (want[:, 1].sqrt() * cnt ** 0.5).clamp(min=1e-6)).max()) < tol
+    assert float(((sums.double() - want).abs()[:, 1] / want[:, 1].clamp(min=1e-6)).max()) < tol
+    y2 = dwconv3x3(x, wgt, stride, want_sums=True)
+    assert torch.equal(y, y2) and torch.equal(sums, y2._ssdk_bn_sums) and torch.equal(y, dwconv3x3(x, wgt, stride))
+
+    monkeypatch.setattr(PW, "BN_STATS_MIN_BYTES", 0)
+    seq = nn.Sequential(DepthwiseConv2d(c, c, 3, stride, 1, groups=c, bias=False), nn.BatchNorm2d(c), nn.ReLU6()).cuda()
+    with torch.no_grad():
+        seq[0].weight.copy_(wgt.float())
+        seq[1].weight.uniform_(0.5, 1.5)
+        seq[1].bias.normal_(0, 0.3)
+    use_fast_batchnorm(seq)
+    fuse_bn_activations(seq)
+    plain = copy.deepcopy(seq)
+    assert PW.fuse_conv_bn_statistics(seq) == 1 and not plain[0]._ssdk_bn_follows
+    outs = []
+    g = torch.randn(n, c, (h - 1) // stride + 1, (w - 1) // stride + 1, device="cuda").to(dtype)
+    for net in (seq, plain):
+        net.train()
+        xi = x.detach().clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=dtype):
+            o = net(xi)
+        o.backward(g)
+        outs.append((o.detach().float(), xi.grad.float(), net[0].weight.grad, net[1].running_mean.clone(), net[1].running_var.clone()))
+    eps = 2.0 ** -7 if dtype_name == "bfloat16" else 2.0 ** -10
+    for a, b, what in zip(outs[0], outs[1], ("output", "dx", "dweight", "running_mean", "running_var")):
+        rel = (a - b).abs() / max(float(b.abs().max()), 1e-6)
+        if what in ("output", "dx"):
+            assert float((rel > 4 * eps).float().mean()) <= 5e-3, what
+        else:
+            assert float(rel.max()) <= 8 * eps, "%s: %.3g" % (what, float(rel.max()))
+
+
 @pytest.mark.parametrize("dtype_name,tol", [("bfloat16", 2e-2), ("float16", 4e-3)])
 @pytest.mark.parametrize("n,cin,cout,h,w,stride,bias", [
     (2, 96, 24, 32, 32, 1, True), (2, 96, 480, 32, 32, 1, True),    # the heads of level 0 (ssd.py:100-103)
