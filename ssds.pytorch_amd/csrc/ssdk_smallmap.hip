@@ -38,10 +38,7 @@ __host__ __device__ constexpr int sm_pad(int stride) { return stride == 1 ? 32 :
 // chains in 29 us, for 7.7 us of matrix work (Weak 5).  With KW = 2 a SIMD holds two waves, each walking half
 // the k-steps; the partial accumulators of group 1 meet group 0's through LDS once at the end (fp32, group 0 + group 1: a fixed
 // order).
-// RM (round 6): multiplier of the weight ring's depth (1 | 2).  The 4x4 / 2x2 level heads are 128 / 32 workgroups of four waves, each
-// wave a chain of 72 dependent k-steps (one 1 KiB weight fragment from L2 -> four MFMAs): with 18 fragments in flight a wave
-// moves 18 KB per L2 round trip; 36 need 72 more registers, which one workgroup per CU has.
-template <int DT, int CS, int MFR, int TAPS, bool PK, int NA, int S, int KW = 1, int RM = 1>
+template <int DT, int CS, int MFR, int TAPS, bool PK, int NA, int S, int KW = 1>
 __device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx, const u32 by) {
   static_assert(NA == 1 || PK, "two channel fragments per wave read the fragment-major image");
   static_assert(S == 1 || TAPS == 9, "stride 2 visits all taps");
@@ -80,13 +77,12 @@ __device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx,
   // Order of the k-steps.  PK: taps outside, slices inside = the order of the packed image, consecutive KiB.  KRSC: slice
   // PAIRS outside, taps inside, the two slices of a pair innermost -- the two 64-byte halves of a weight row's 128-byte line
   // are then fetched by neighbouring loads.
-  constexpr int RING0 = KW == 1 ? 2 * TAPS * RM : (TAPS == 9 ? 9 : 2);  // register stages = k-steps in flight (two waves per SIMD: half)
-  constexpr int RING = RING0 < CSL * TAPS ? RING0 : CSL * TAPS;       // (never deeper than the k-loop)
+  constexpr int RING = KW == 1 ? 2 * TAPS : (TAPS == 9 ? 9 : 2);  // register stages = k-steps in flight (two waves per SIMD: half)
   u32x4 rw[RING][NA];
   auto kmap = [](int st, int& t, int& sl) {  // sl: the wave group's slice number times KW (+ kg: in the pointers)
     if (PK) { t = st / CSL; sl = (st % CSL) * KW; return; }
     if (TAPS == 1) { t = 0; sl = st; return; }
-    const int sp = st / (2 * TAPS), in = st % (2 * TAPS);
+    const int sp = st / RING, in = st % RING;
     t = in >> 1;
     sl = 2 * sp + (in & 1);
   };
@@ -238,9 +234,9 @@ __device__ __forceinline__ void smallmap_body(const ConvParams& p, const u32 bx,
     }
 }
 
-template <int DT, int CS, int MFR, int TAPS, bool PK, int NA, int S, int KW = 1, int RM = 1>
+template <int DT, int CS, int MFR, int TAPS, bool PK, int NA, int S, int KW = 1>
 __global__ __launch_bounds__(kSmThreads * KW) void conv_smallmap_kernel(const ConvParams p) {
-  smallmap_body<DT, CS, MFR, TAPS, PK, NA, S, KW, RM>(p, blockIdx.x, blockIdx.y);
+  smallmap_body<DT, CS, MFR, TAPS, PK, NA, S, KW>(p, blockIdx.x, blockIdx.y);
 }
 
 // Several independent small-map layers in ONE launch (the multibox heads of the 4x4 / 2x2 / 1x1 levels: 128 + 32 + 8
@@ -255,7 +251,7 @@ struct SmallmapGroup {
   int code[kSmallmapGroupMax];            // 2 * log2(Cin / 128) + (1x1 map)
   int n;
 };
-template <int DT, int KW, int RM = 1>
+template <int DT, int KW>
 __global__ __launch_bounds__(kSmThreads * KW) void conv_smallmap_group_kernel(const SmallmapGroup g) {
   int m = 0;
   for (int i = 1; i < g.n; ++i)
@@ -263,12 +259,12 @@ __global__ __launch_bounds__(kSmThreads * KW) void conv_smallmap_group_kernel(co
   const u32 local = blockIdx.x - g.start[m], bx = local % g.gx[m], by = local / g.gx[m];
   const ConvParams& p = g.p[m];
   switch (g.code[m]) {
-    case 0: smallmap_body<DT, 4, 4, 9, true, 1, 1, KW, RM>(p, bx, by); break;
-    case 1: smallmap_body<DT, 4, 4, 1, true, 1, 1, KW, RM>(p, bx, by); break;
-    case 2: smallmap_body<DT, 8, 4, 9, true, 1, 1, KW, RM>(p, bx, by); break;
-    case 3: smallmap_body<DT, 8, 4, 1, true, 1, 1, KW, RM>(p, bx, by); break;
-    case 4: smallmap_body<DT, 16, 4, 9, true, 1, 1, KW, RM>(p, bx, by); break;
-    default: smallmap_body<DT, 16, 4, 1, true, 1, 1, KW, RM>(p, bx, by); break;
+    case 0: smallmap_body<DT, 4, 4, 9, true, 1, 1, KW>(p, bx, by); break;
+    case 1: smallmap_body<DT, 4, 4, 1, true, 1, 1, KW>(p, bx, by); break;
+    case 2: smallmap_body<DT, 8, 4, 9, true, 1, 1, KW>(p, bx, by); break;
+    case 3: smallmap_body<DT, 8, 4, 1, true, 1, 1, KW>(p, bx, by); break;
+    case 4: smallmap_body<DT, 16, 4, 9, true, 1, 1, KW>(p, bx, by); break;
+    default: smallmap_body<DT, 16, 4, 1, true, 1, 1, KW>(p, bx, by); break;
   }
 }
 
@@ -313,21 +309,18 @@ int launch_conv_smallmap_group(const ConvParams* ps, int n, int dtype, hipStream
   constexpr int env_kw = 1;  // (round 6: the SSDK_CONV_SMALLMAP_GROUP_KW switch is gone, its A/B is settled)
   const int kw = env_kw == 2 ? 2 : 1;
   lds = ((lds + 15) & ~(size_t)15) + (size_t)(kw - 1) * 4 * 4 * 1024;  // + the partial sums of wave group 1 (4 waves x 4 fragments)
-#define SSDK_SMG(DT, KW_, RM_)                                                                                               \
+#define SSDK_SMG(DT, KW_)                                                                                                    \
   do {                                                                                                                       \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_group_kernel<DT, KW_, RM_>),                      \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_group_kernel<DT, KW_>),                           \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
-    hipLaunchKernelGGL((conv_smallmap_group_kernel<DT, KW_, RM_>), dim3(total), dim3(kSmThreads * KW_), lds, stream, g);     \
+    hipLaunchKernelGGL((conv_smallmap_group_kernel<DT, KW_>), dim3(total), dim3(kSmThreads * KW_), lds, stream, g);          \
   } while (0)
-  static const int env_ring = getenv("SSDK_CONV_SMALLMAP_RING") ? atoi(getenv("SSDK_CONV_SMALLMAP_RING")) : 1;
   if (dtype == SSDK_BF16) {
-    if (kw == 2) SSDK_SMG(SSDK_BF16, 2, 1);
-    else if (env_ring == 2) SSDK_SMG(SSDK_BF16, 1, 2);
-    else SSDK_SMG(SSDK_BF16, 1, 1);
+    if (kw == 2) SSDK_SMG(SSDK_BF16, 2);
+    else SSDK_SMG(SSDK_BF16, 1);
   } else {
-    if (kw == 2) SSDK_SMG(SSDK_F16, 2, 1);
-    else if (env_ring == 2) SSDK_SMG(SSDK_F16, 1, 2);
-    else SSDK_SMG(SSDK_F16, 1, 1);
+    if (kw == 2) SSDK_SMG(SSDK_F16, 2);
+    else SSDK_SMG(SSDK_F16, 1);
   }
 #undef SSDK_SMG
   return 0;
@@ -369,23 +362,18 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   const int cs = p.Cin / 32;
   // K split over two wave groups (smallmap_body, KW): the weight-bound instance of the 8x8 level (na == 2, stride 1, 4 waves).
   // Measured (SSD-MobileNetV2@512 head of the 8x8 level, batch 64, per-op events, one box): 32.6 -> 30.3 us.  Two waves per SIMD
-  // were NOT what held this kernel at 0.26 of the MFMA peak; the weight stream is (1.18 MB per workgroup from L2).
+  // were NOT what held this kernel at 0.26 of the MFMA peak; the weight stream is (1.18 MB per workgroup from L2).  Also measured
+  // and dropped (round 6, session 13): a 36-deep instead of an 18-deep weight ring -- one wave per SIMD, 462 registers: 52 us on
+  // this level, 17.6 vs 16.9 us on the grouped 4x4 / 2x2 / 1x1 heads: more fragments in flight per wave buy nothing, the stream
+  // is throughput-bound, not latency-bound.
   static const int env_kw = getenv("SSDK_CONV_SMALLMAP_KW") ? atoi(getenv("SSDK_CONV_SMALLMAP_KW")) : 2;
-  static const int env_ring1 = getenv("SSDK_CONV_SMALLMAP_RING") ? atoi(getenv("SSDK_CONV_SMALLMAP_RING")) : 1;
-  const bool ring2 = env_ring1 == 2 && na == 2 && !s2 && nw == 4 && P > 1;  // (A/B: one wave per SIMD with a 36-deep weight ring)
-  const int kw = (env_kw == 2 && na == 2 && !s2 && nw == 4 && P > 1 && !ring2) ? 2 : 1;
+  const int kw = (env_kw == 2 && na == 2 && !s2 && nw == 4 && P > 1) ? 2 : 1;
   if (kw == 2) lds = ((lds + 15) & ~(size_t)15) + (size_t)nw * na * mfr * 1024;
 #define SSDK_SMS(DT, CS_, MFR_, TAPS_, PK_, NA_, S_)                                                                       \
   do {                                                                                                                     \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_, MFR_, TAPS_, PK_, NA_, S_>),   \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
     hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_, MFR_, TAPS_, PK_, NA_, S_>), grid, dim3(64 * nw), lds, stream, p);   \
-  } while (0)
-#define SSDK_SMR2(DT, CS_)                                                                                                 \
-  do {                                                                                                                     \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_smallmap_kernel<DT, CS_, 4, 9, true, 2, 1, 1, 2>),       \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
-    hipLaunchKernelGGL((conv_smallmap_kernel<DT, CS_, 4, 9, true, 2, 1, 1, 2>), grid, dim3(64 * nw), lds, stream, p);      \
   } while (0)
 #define SSDK_SMK2(DT, CS_)                                                                                                 \
   do {                                                                                                                     \
@@ -403,7 +391,6 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
   do {                                           \
     if (s2) SSDK_SMS(DT, CS_, 4, 9, true, 2, 2); \
     else if (P == 1) SSDK_SM1(DT, CS_, 4, 1);    \
-    else if (na == 2 && ring2) SSDK_SMR2(DT, CS_);      \
     else if (na == 2 && kw == 2) SSDK_SMK2(DT, CS_);    \
     else if (na == 2) SSDK_SM0(DT, CS_, 4, 9, true, 2); \
     else if (mfr == 8) SSDK_SM1(DT, CS_, 8, 9);  \
@@ -422,7 +409,6 @@ int launch_conv_smallmap(const ConvParams& p, int dtype, hipStream_t stream) {
 #undef SSDK_SM1
 #undef SSDK_SM0
 #undef SSDK_SMK2
-#undef SSDK_SMR2
 #undef SSDK_SMS
   return 0;
 }
