@@ -463,6 +463,15 @@ int ssdk_dwconv_fwd(const void* x, const void* w, void* y, int N, int C, int H, 
  * y.  Per-workgroup partials through `workspace` (16-byte aligned), added in index order.  ssdk_dwconv_fwd_stats_workspace_bytes
  * returns 0 where the geometry runs on the tiled fallback kernels (rows too wide): call ssdk_dwconv_fwd there. */
 size_t ssdk_dwconv_fwd_stats_workspace_bytes(int N, int C, int H, int W, int stride, int dtype);
+/* (version 240) the depthwise convolution behind a DEFERRED BatchNorm: x is the BatchNorm's INPUT, coef [C][4] / act come from
+ * ssdk_bn_act_train_stats; the kernels stage act(a x + b) rounded to the dtype -- bit for bit what the BatchNorm's apply pass would
+ * have stored.  16 bit, whole-row kernels only: ssdk_dwconv_affine_supported tells (1 | 0).  sums (optional, with `workspace` of
+ * ssdk_dwconv_fwd_stats_workspace_bytes): the statistics of y for the NEXT BatchNorm. */
+int ssdk_dwconv_affine_supported(int N, int C, int H, int W, int stride, int dtype);
+int ssdk_dwconv_fwd_affine(const void* x, const float* coef, int act, const void* w, void* y, float* sums, void* workspace,
+                           size_t workspace_bytes, int N, int C, int H, int W, int stride, int dtype, void* stream);
+int ssdk_dwconv_bwd_weight_affine(const void* x, const float* coef, int act, const void* dy, float* dw, void* workspace,
+                                  size_t workspace_bytes, int N, int C, int H, int W, int stride, int dtype, void* stream);
 int ssdk_dwconv_fwd_stats(const void* x, const void* w, void* y, float* sums, void* workspace, size_t workspace_bytes, int N, int C,
                           int H, int W, int stride, int dtype, void* stream);
 int ssdk_dwconv_bwd_data(const void* dy, const void* w, void* dx, int N, int C, int H, int W, int stride, int dtype,
@@ -508,6 +517,13 @@ int ssdk_bn_act_train_fwd_sums(const void* x, const float* sums, const float* we
                                float* running_var, void* y, float* save_mean, float* save_invstd, void* workspace,
                                size_t workspace_bytes, int N, int C, int HW, float momentum, float eps, int act, int dtype,
                                void* stream);
+/* ... the forward pass WITHOUT its apply pass (version 240): statistics (from `sums`, or NULL: the reduction over x), running
+ * statistics, save_mean / save_invstd and coef_out [C][4] = (a, b, 0, 0) with y = act(a x + b).  The depthwise convolution behind the
+ * BatchNorm applies the coefficients while it stages x (ssdk_dwconv_fwd_affine / ssdk_dwconv_bwd_weight_affine below): the
+ * BatchNorm's output -- the 6 x expanded tensor of an inverted-residual block (mobilenet.py:56) -- is never written. */
+int ssdk_bn_act_train_stats(const void* x, const float* sums, const float* weight, const float* bias, float* running_mean,
+                            float* running_var, float* save_mean, float* save_invstd, float* coef_out, void* workspace,
+                            size_t workspace_bytes, int N, int C, int HW, float momentum, float eps, int dtype, void* stream);
 int ssdk_bn_act_train_bwd(const void* x, const void* dy, const float* weight, const float* bias, const float* save_mean,
                           const float* save_invstd, void* dx, float* dweight, float* dbias, void* workspace,
                           size_t workspace_bytes, int N, int C, int HW, int act, int dtype, void* stream);

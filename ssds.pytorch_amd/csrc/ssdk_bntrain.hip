@@ -32,6 +32,7 @@ struct BnParams {
   float* save_invstd;
   float* dweight;
   float* dbias;
+  int no_apply;            // forward: statistics + coefficients only (the consumer applies them on load: ssdk_dwconv_fwd_affine)
   const float* sums;       // optional: [C][2] = (sum x, sum x^2) over N * HW computed by the PRODUCER of x (ssdk_pw_forward_stats):
                            // the forward pass then has no reduction of its own
   float* partial;          // [C][SPLIT][2]
@@ -481,7 +482,8 @@ static void bn_launch(const BnParams& p, hipStream_t st) {
     else hipLaunchKernelGGL((bn_reduce_kernel<DT, MODE>), rgrid, dim3(256), 0, st, p);                      \
     if (MODE == 0) hipLaunchKernelGGL((bn_fwd_finalize_kernel<DT>), dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p); \
     else hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p);  \
-    if (flat && fgrid < (1l << 31)) hipLaunchKernelGGL((bn_apply_flat_kernel<DT, MODE>), dim3((unsigned)fgrid), dim3(256), 0, st, p, f); \
+    if (MODE == 0 && p.no_apply) {                                                                           \
+    } else if (flat && fgrid < (1l << 31)) hipLaunchKernelGGL((bn_apply_flat_kernel<DT, MODE>), dim3((unsigned)fgrid), dim3(256), 0, st, p, f); \
     else hipLaunchKernelGGL((bn_apply_kernel<DT, MODE>), agrid, dim3(256), 0, st, p);                        \
   } while (0)
   if (p.dtype == SSDK_F32) SSDK_BN(SSDK_F32);
@@ -581,6 +583,39 @@ extern "C" int ssdk_bn_act_train_fwd_sums(const void* x, const float* sums, cons
   p.act = act;
   bn_launch<0>(p, (hipStream_t)stream);
   return check_launch("bn_train_fwd_sums");
+}
+
+// The forward pass WITHOUT its apply pass: batch statistics (from `sums` when the producer provided them, else by the reduction
+// over x), running statistics, save_mean / save_invstd and coef_out [C][4] = (a, b, 0, 0) with y = act(a x + b).  The consumer of
+// the BatchNorm's output applies the coefficients when it loads x (ssdk_dwconv_fwd_affine): y is never written.
+extern "C" int ssdk_bn_act_train_stats(const void* x, const float* sums, const float* weight, const float* bias, float* running_mean,
+                                       float* running_var, float* save_mean, float* save_invstd, float* coef_out, void* workspace,
+                                       size_t workspace_bytes, int N, int C, int HW, float momentum, float eps, int dtype,
+                                       void* stream) {
+  if (!x || !save_mean || !save_invstd || !coef_out || ((uintptr_t)coef_out & 15) || (!running_mean) != (!running_var)) {
+    set_error("bn_train_stats: null / misaligned pointer");
+    return SSDK_E_BADARG;
+  }
+  BnParams p;
+  memset(&p, 0, sizeof(p));
+  const int rc = bn_common(p, "bn_train_stats", N, C, HW, dtype, workspace, workspace_bytes);
+  if (rc) return rc;
+  p.x = x;
+  p.dy = x;
+  p.out = nullptr;
+  p.sums = sums;
+  p.no_apply = 1;
+  p.coef = coef_out;
+  p.weight = weight;
+  p.bias = bias;
+  p.running_mean = running_mean;
+  p.running_var = running_var;
+  p.save_mean = save_mean;
+  p.save_invstd = save_invstd;
+  p.momentum = momentum;
+  p.eps = eps;
+  bn_launch<0>(p, (hipStream_t)stream);
+  return check_launch("bn_train_stats");
 }
 
 extern "C" int ssdk_bn_train_fwd(const void* x, const float* weight, const float* bias, float* running_mean,

@@ -33,6 +33,8 @@ struct DwpParams {
   const void* b;   // w [C][9] in the activation dtype (forward, input gradient) | dy (weight gradient)
   void* out;       // y | dx | partial sums [groups][C][9] fp32
   float* stats;    // forward only, optional: [groups][C][2] per-workgroup (sum y, sum y^2) of its outputs (fp32, before the store)
+  const float* coef;  // AFF instances (forward, weight gradient; 16 bit): [C][4] = (a, b, ., .) of the BatchNorm whose OUTPUT is the
+  int act;            // staged tensor: the kernel stages act(a x + b) rounded to the dtype from the BatchNorm's INPUT x (0 none | 1 ReLU6 | 2 ReLU)
   int N, C;
   int Hs, Ws;      // plane of the staged tensor
   int Ht, Wt;      // plane of the thread space: y (forward), dx (input gradient), dy (weight gradient)
@@ -178,10 +180,19 @@ __device__ __forceinline__ void dwp_stage_f32(float* lds, const DwpParams& p, in
 }
 // 16-bit: the tensor's own bits, pixel x at column x + 8, LD a multiple of 8: chunk k of a row = pixels 8k .. 8k + 7 =
 // the aligned 16 bytes at column 8k + 8; columns 0 .. 7 (of which the windows read column 7 = pixel -1) are zero
+// AFF (round 6): the staged tensor is the OUTPUT of a training-mode BatchNorm (+ ReLU6 / ReLU) that was never written: p.a is the
+// BatchNorm's input x, and a chunk becomes act(x a + b) rounded to the dtype -- bit for bit what bn_apply_kernel would have
+// stored -- before the padding masks (the padding is zero in the BatchNorm's output, not in its input).
+template <int DT, bool AFF>
 __device__ __forceinline__ void dwp_stage_h16(u16* lds, const DwpParams& p, int n0, int c, int ys0) {
   const int items = p.G * p.SR * p.CH;
   const size_t plane = (size_t)p.Hs * p.Ws;
   const u16* src = (const u16*)p.a;
+  float ca = 1.f, cb = 0.f;
+  if constexpr (AFF) {
+    ca = p.coef[c * 4 + 0];
+    cb = p.coef[c * 4 + 1];
+  }
   for (int it0 = (int)threadIdx.x; it0 < items; it0 += 4 * kDwpThreads) {
     u32x4 v[4];
     int lr[4], x0[4];
@@ -202,6 +213,21 @@ __device__ __forceinline__ void dwp_stage_h16(u16* lds, const DwpParams& p, int 
           for (int e = 0; e < 8; ++e)
             if (gi + e < p.total_a) v[j][e >> 1] |= (u32)src[gi + e] << (16 * (e & 1));
         }
+        if constexpr (AFF) {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            float lo = bits16_to_f32<DT>(v[j][d] & 0xffffu) * ca + cb, hi = bits16_to_f32<DT>(v[j][d] >> 16) * ca + cb;
+            if (p.act) {  // (the same operations, in the same order, as bn_apply_kernel's forward lambda)
+              lo = fmaxf(lo, 0.f);
+              hi = fmaxf(hi, 0.f);
+            }
+            if (p.act == 1) {
+              lo = fminf(lo, 6.f);
+              hi = fminf(hi, 6.f);
+            }
+            v[j][d] = pack2_16<DT>(lo, hi);
+          }
+        }
         const int valid = p.Ws - x0[j];  // pixels of this chunk inside the row
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -220,10 +246,11 @@ __device__ __forceinline__ void dwp_stage_h16(u16* lds, const DwpParams& p, int 
     }
   }
 }
-template <int DT>
+template <int DT, bool AFF = false>
 __device__ __forceinline__ void dwp_stage(float* lds, const DwpParams& p, int n0, int c, int ys0) {
+  static_assert(!AFF || DT != SSDK_F32, "the deferred BatchNorm is a 16-bit path");
   if constexpr (DT == SSDK_F32) dwp_stage_f32(lds, p, n0, c, ys0);
-  else dwp_stage_h16(reinterpret_cast<u16*>(lds), p, n0, c, ys0);
+  else dwp_stage_h16<DT, AFF>(reinterpret_cast<u16*>(lds), p, n0, c, ys0);
 }
 
 // one window row as fp32: a[j] = pixel x = first - 1 + j of staged row `row`, j = 0 .. NC-1, first = S * 8 * g
@@ -266,7 +293,7 @@ __device__ __forceinline__ bool dwp_unit(const DwpParams& p, const DwpWhere& w, 
 // tensor = dy):  out[r][8g + e] = sum w[ky][kx] * a[S r + ky - 1][S (8g + e) + kx - 1]
 // STATS (round 6, forward only): the workgroup owns ONE channel -- it also leaves (sum y, sum y^2) of its outputs for the
 // BatchNorm behind the convolution (ssdk_bn_act_train_fwd_sums): per thread in registers, then a fixed-order block sum.
-template <int DT, int S, bool FLIP, bool STATS = false>
+template <int DT, int S, bool FLIP, bool STATS = false, bool AFF = false>
 __global__ __launch_bounds__(kDwpThreads) void dwp_fwd_kernel(const DwpParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float sred[2][kDwpThreads / 64];
@@ -276,7 +303,7 @@ __global__ __launch_bounds__(kDwpThreads) void dwp_fwd_kernel(const DwpParams p)
   float w[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) w[t] = dwp_ld<DT>(p.b, (size_t)wh.c * 9 + (FLIP ? 8 - t : t));
-  dwp_stage<DT>(lds, p, wh.n0, wh.c, S * wh.r0 - 1);
+  dwp_stage<DT, AFF>(lds, p, wh.n0, wh.c, S * wh.r0 - 1);
   __syncthreads();
   // packed fp32 math: the two halves of a segment (pixels e and e + 4) share an instruction -- one v_pk_fma_f32 updates
   // the pair of sums from the pair of window columns j and j + 4S
@@ -417,7 +444,7 @@ __global__ __launch_bounds__(kDwpThreads) void dwp_dgrad2_kernel(const DwpParams
 }
 
 // weight gradient, stage 1: partial[grp][c][t] = sum over the workgroup's units of dy[r][8g + e] * x[S r + ky - 1][S (8g + e) + kx - 1]
-template <int DT, int S>
+template <int DT, int S, bool AFF = false>
 __global__ __launch_bounds__(kDwpThreads) void dwp_wgrad_kernel(const DwpParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[4][9];
@@ -446,7 +473,7 @@ __global__ __launch_bounds__(kDwpThreads) void dwp_wgrad_kernel(const DwpParams 
       }
     }
   }
-  dwp_stage<DT>(lds, p, wh.n0, wh.c, S * wh.r0 - 1);
+  dwp_stage<DT, AFF>(lds, p, wh.n0, wh.c, S * wh.r0 - 1);
   __syncthreads();
   constexpr int HP = 4 * S, NP = 3 * S + 3;  // packed fp32 pairs (pixels e, e + 4) as in the forward kernel
   f32x2 acc2[9];
@@ -616,7 +643,7 @@ static bool dwp_enabled() {
 
 // 0: launched; 1: not taken (the caller uses the tiled kernels of ssdk_dwtrain.hip)
 int launch_dwp_fwd(const void* x, const void* w, void* y, int N, int C, int H, int W, int stride, int dtype, hipStream_t stream,
-                   float* stats, int* groups_out) {
+                   float* stats, int* groups_out, const float* coef, int act) {
   if (!dwp_enabled()) return 1;
   DwpPlan pl = dwp_plan(DWP_FWD, N, C, H, W, stride, dtype != SSDK_F32);
   if (!pl.ok) return 1;
@@ -624,8 +651,25 @@ int launch_dwp_fwd(const void* x, const void* w, void* y, int N, int C, int H, i
   pl.p.b = w;
   pl.p.out = y;
   pl.p.stats = stats;
+  pl.p.coef = coef;
+  pl.p.act = act;
   if (groups_out) *groups_out = pl.groups;
   const dim3 grid((unsigned)(pl.p.nwg8 * 8));
+  if (coef) {  // the staged tensor is a deferred BatchNorm's output (16 bit only; statistics on or off)
+    if (dtype == SSDK_F32) return 1;
+#define SSDK_DWP_FWA(DT)                                                                                                     \
+  do {                                                                                                                       \
+    if (stats) {                                                                                                             \
+      if (stride == 1) hipLaunchKernelGGL((dwp_fwd_kernel<DT, 1, false, true, true>), grid, dim3(kDwpThreads), pl.lds, stream, pl.p); \
+      else hipLaunchKernelGGL((dwp_fwd_kernel<DT, 2, false, true, true>), grid, dim3(kDwpThreads), pl.lds, stream, pl.p);     \
+    } else if (stride == 1) hipLaunchKernelGGL((dwp_fwd_kernel<DT, 1, false, false, true>), grid, dim3(kDwpThreads), pl.lds, stream, pl.p); \
+    else hipLaunchKernelGGL((dwp_fwd_kernel<DT, 2, false, false, true>), grid, dim3(kDwpThreads), pl.lds, stream, pl.p);      \
+  } while (0)
+    if (dtype == SSDK_BF16) SSDK_DWP_FWA(SSDK_BF16);
+    else SSDK_DWP_FWA(SSDK_F16);
+#undef SSDK_DWP_FWA
+    return 0;
+  }
 #define SSDK_DWP_FWD(DT)                                                                                                 \
   do {                                                                                                                   \
     if (stats) {                                                                                                         \
@@ -637,6 +681,12 @@ int launch_dwp_fwd(const void* x, const void* w, void* y, int N, int C, int H, i
   SSDK_DWP_BY_DTYPE(SSDK_DWP_FWD);
 #undef SSDK_DWP_FWD
   return 0;
+}
+
+// 1 when the forward AND the weight-gradient pass of this geometry run on the whole-row kernels (what a deferred BatchNorm needs)
+int dwp_affine_ok(int N, int C, int H, int W, int stride, int dtype) {
+  if (!dwp_enabled() || dtype == SSDK_F32) return 0;
+  return dwp_plan(DWP_FWD, N, C, H, W, stride, true).ok && dwp_plan(DWP_WGRAD, N, C, H, W, stride, true).ok ? 1 : 0;
 }
 
 // partial-sum groups of the forward statistics (0: the whole-row kernels do not take the pass)
@@ -676,14 +726,29 @@ size_t dwp_wgrad_workspace_bytes(int N, int C, int H, int W, int stride) {
 }
 
 int launch_dwp_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int C, int H, int W,
-                     int stride, int dtype, hipStream_t stream) {
+                     int stride, int dtype, hipStream_t stream, const float* coef, int act) {
   if (!dwp_enabled()) return 1;
   DwpPlan pl = dwp_plan(DWP_WGRAD, N, C, H, W, stride, dtype != SSDK_F32);
   if (!pl.ok || workspace_bytes < (size_t)pl.groups * C * 9 * sizeof(float)) return 1;
   pl.p.a = x;
   pl.p.b = dy;
   pl.p.out = workspace;
+  pl.p.coef = coef;
+  pl.p.act = act;
   const dim3 grid((unsigned)(pl.p.nwg8 * 8));
+  if (coef) {
+    if (dtype == SSDK_F32) return 1;
+#define SSDK_DWP_WGA(DT)                                                                                               \
+  do {                                                                                                                 \
+    if (stride == 1) hipLaunchKernelGGL((dwp_wgrad_kernel<DT, 1, true>), grid, dim3(kDwpThreads), pl.lds, stream, pl.p); \
+    else hipLaunchKernelGGL((dwp_wgrad_kernel<DT, 2, true>), grid, dim3(kDwpThreads), pl.lds, stream, pl.p);            \
+  } while (0)
+    if (dtype == SSDK_BF16) SSDK_DWP_WGA(SSDK_BF16);
+    else SSDK_DWP_WGA(SSDK_F16);
+#undef SSDK_DWP_WGA
+    hipLaunchKernelGGL(dwp_wgrad_reduce_kernel, dim3((unsigned)C), dim3(64), 0, stream, (const float*)workspace, dw, pl.groups, C);
+    return 0;
+  }
 #define SSDK_DWP_WG(DT)                                                                                       \
   do {                                                                                                        \
     if (stride == 1) hipLaunchKernelGGL((dwp_wgrad_kernel<DT, 1>), grid, dim3(kDwpThreads), pl.lds, stream, pl.p); \

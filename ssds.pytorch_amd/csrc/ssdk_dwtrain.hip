@@ -320,13 +320,14 @@ static constexpr size_t dwt_lds_dy(int s) {  // tile of dy behind a DT_TH x DT_T
 
 // ssdk_dwplane.hip: the whole-row kernels (0: launched, 1: not taken)
 int launch_dwp_fwd(const void* x, const void* w, void* y, int N, int C, int H, int W, int stride, int dtype, hipStream_t stream,
-                   float* stats = nullptr, int* groups_out = nullptr);
+                   float* stats = nullptr, int* groups_out = nullptr, const float* coef = nullptr, int act = 0);
 int dwp_fwd_groups(int N, int C, int H, int W, int stride, int dtype);
 int reduce_rows_fixed_order(const float* src, float* mid, float* dst, unsigned n, unsigned rows, hipStream_t st);  // ssdk_pwtrain.hip
 int launch_dwp_dgrad(const void* dy, const void* w, void* dx, int N, int C, int H, int W, int stride, int dtype, hipStream_t stream);
 size_t dwp_wgrad_workspace_bytes(int N, int C, int H, int W, int stride);
+int dwp_affine_ok(int N, int C, int H, int W, int stride, int dtype);
 int launch_dwp_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int C, int H, int W,
-                     int stride, int dtype, hipStream_t stream);
+                     int stride, int dtype, hipStream_t stream, const float* coef = nullptr, int act = 0);
 
 }  // namespace ssdk
 
@@ -370,6 +371,60 @@ extern "C" int ssdk_dwconv_fwd_stats(const void* x, const void* w, void* y, floa
   const unsigned n = (unsigned)C * 2u;
   return reduce_rows_fixed_order((const float*)workspace, (float*)workspace + (size_t)groups * n, sums, n, (unsigned)groups,
                                  (hipStream_t)stream);
+}
+
+// The depthwise convolution behind a DEFERRED BatchNorm (round 6): x is the BatchNorm's INPUT, coef [C][4] its per-channel
+// (a, b, ., .) from ssdk_bn_act_train_stats, act its folded activation; the kernels stage act(a x + b) rounded to the dtype --
+// the tensor bn_apply would have written -- so the BatchNorm's output never exists in memory.  16 bit only.
+//   ssdk_dwconv_affine_supported   1 when forward AND weight gradient of this geometry run on the whole-row kernels
+//   ssdk_dwconv_fwd_affine         y (+ sums [C][2] for the next BatchNorm when sums != NULL: workspace as ssdk_dwconv_fwd_stats)
+//   ssdk_dwconv_bwd_weight_affine  dw from (x, coef, act) and dy
+extern "C" int ssdk_dwconv_affine_supported(int N, int C, int H, int W, int stride, int dtype) {
+  if (N < 1 || C < 1 || H < 1 || W < 1 || (stride != 1 && stride != 2) || (dtype != SSDK_BF16 && dtype != SSDK_F16)) return 0;
+  return dwp_affine_ok(N, C, H, W, stride, dtype);
+}
+
+extern "C" int ssdk_dwconv_fwd_affine(const void* x, const float* coef, int act, const void* w, void* y, float* sums, void* workspace,
+                                      size_t workspace_bytes, int N, int C, int H, int W, int stride, int dtype, void* stream) {
+  const int rc = dwt_check("dwconv_fwd_affine", x, w, y, N, C, H, W, stride, dtype);
+  if (rc) return rc;
+  if (!coef || act < 0 || act > 2 || !ssdk_dwconv_affine_supported(N, C, H, W, stride, dtype)) {
+    set_error("dwconv_fwd_affine: 16-bit tensors on the whole-row kernels only, act 0 | 1 | 2, coef must not be null");
+    return SSDK_E_BADARG;
+  }
+  int groups = 0;
+  if (sums) {
+    const size_t need = ssdk_dwconv_fwd_stats_workspace_bytes(N, C, H, W, stride, dtype);
+    if (!workspace || need == 0 || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
+      set_error("dwconv_fwd_affine: workspace too small or misaligned");
+      return SSDK_E_WORKSPACE;
+    }
+  }
+  if (launch_dwp_fwd(x, w, y, N, C, H, W, stride, dtype, (hipStream_t)stream, sums ? (float*)workspace : nullptr, &groups, coef, act) != 0) {
+    set_error("dwconv_fwd_affine: the whole-row kernels declined");
+    return SSDK_E_BADARG;
+  }
+  int rc2 = check_launch("dwp_fwd_kernel");
+  if (rc2 || !sums) return rc2;
+  const unsigned n = (unsigned)C * 2u;
+  return reduce_rows_fixed_order((const float*)workspace, (float*)workspace + (size_t)groups * n, sums, n, (unsigned)groups,
+                                 (hipStream_t)stream);
+}
+
+extern "C" int ssdk_dwconv_bwd_weight_affine(const void* x, const float* coef, int act, const void* dy, float* dw, void* workspace,
+                                             size_t workspace_bytes, int N, int C, int H, int W, int stride, int dtype, void* stream) {
+  const int rc = dwt_check("dwconv_bwd_weight_affine", x, dy, dw, N, C, H, W, stride, dtype);
+  if (rc) return rc;
+  if (!coef || act < 0 || act > 2 || !workspace || workspace_bytes < ssdk_dwconv_bwd_weight_workspace_bytes(N, C, H, W, stride) ||
+      !ssdk_dwconv_affine_supported(N, C, H, W, stride, dtype)) {
+    set_error("dwconv_bwd_weight_affine: bad argument / workspace too small / geometry not on the whole-row kernels");
+    return SSDK_E_BADARG;
+  }
+  if (launch_dwp_wgrad(x, dy, dw, workspace, workspace_bytes, N, C, H, W, stride, dtype, (hipStream_t)stream, coef, act) != 0) {
+    set_error("dwconv_bwd_weight_affine: the whole-row kernels declined");
+    return SSDK_E_BADARG;
+  }
+  return check_launch("dwp_wgrad_kernel");
 }
 
 extern "C" int ssdk_dwconv_bwd_data(const void* dy, const void* w, void* dx, int N, int C, int H, int W, int stride,

@@ -74,6 +74,37 @@ class _BatchNormTrain(torch.autograd.Function):
         return gx, gw.to(weight.dtype), gb.to(weight.dtype), None, None, None, None, None, None
 
 
+class _BatchNormDeferred(torch.autograd.Function):
+    """Training BatchNorm whose OUTPUT is never written: the forward runs the statistics + coefficients only
+    (ssdk_bn_act_train_stats) and returns an ALIAS of x together with coef [C, 4]; the depthwise convolution behind it applies
+    act(a x + b) while it stages its input (dwconv._DwConv3x3 with ``coef``).  The backward pass is _BatchNormTrain's."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, act, sums):
+        x = x.contiguous()
+        n, c = int(x.shape[0]), int(x.shape[1])
+        hw = int(x.shape[2]) * int(x.shape[3])
+        dev = x.device
+        mean = torch.empty(c, device=dev, dtype=torch.float32)
+        invstd = torch.empty(c, device=dev, dtype=torch.float32)
+        coef = torch.empty((c, 4), device=dev, dtype=torch.float32)
+        ws, need = _ws(dev, n, c)
+        wp = (ws.data_ptr() + 15) & ~15
+        with torch.cuda.device(dev):
+            N.check(N.lib.ssdk_bn_act_train_stats(x.data_ptr(), None if sums is None else sums.data_ptr(), weight.data_ptr(),
+                                                  bias.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), mean.data_ptr(),
+                                                  invstd.data_ptr(), coef.data_ptr(), wp, need, n, c, hw, float(momentum), float(eps),
+                                                  N.dtype_code(x), N.stream_ptr(dev)), "bn_train_stats")
+        ctx.save_for_backward(x, weight, bias, mean, invstd)
+        ctx.act = int(act)
+        ctx.mark_non_differentiable(coef)
+        return x.detach(), coef  # (an alias: what the consumer reads through it is x, NOT the BatchNorm's output)
+
+    @staticmethod
+    def backward(ctx, gy, _gcoef=None):
+        return _BatchNormTrain.backward(ctx, gy)
+
+
 class FastBatchNorm2d(nn.BatchNorm2d):
     _ssdk_act = 0  # 1 ReLU6 | 2 ReLU folded into the kernels (set per instance by fuse_bn_activations)
     _ssdk_counter_external = False  # True: somebody bumps num_batches_tracked for ALL layers in one launch (bump_counters)
@@ -88,6 +119,18 @@ class FastBatchNorm2d(nn.BatchNorm2d):
         sums = x.__dict__.pop("_ssdk_bn_sums", None) if hasattr(x, "__dict__") else None  # (from the producing 1x1 convolution)
         if sums is not None and (tuple(sums.shape) != (x.shape[1], 2) or not x.is_contiguous()):
             sums = None
+        dw = self.__dict__.get("_ssdk_defer_to")  # the depthwise convolution that reads this BatchNorm's output (fuse_bn_into_depthwise)
+        if (dw is not None and dw.training and self._ssdk_act and x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous()
+                and (not torch.is_autocast_enabled() or torch.get_autocast_dtype("cuda") == x.dtype)
+                and N.lib.ssdk_dwconv_affine_supported(int(x.shape[0]), int(x.shape[1]), int(x.shape[2]), int(x.shape[3]),
+                                                       int(dw.stride[0]), N.dtype_code(x))):
+            with torch.autocast("cuda", enabled=False):
+                y, coef = _BatchNormDeferred.apply(x, self.weight, self.bias, self.running_mean, self.running_var, momentum,
+                                                   self.eps, self._ssdk_act, sums)
+            y._ssdk_pending_bn = (coef, self._ssdk_act)  # consumed (and checked) by DepthwiseConv2d.forward
+            y._ssdk_act_applied = self._ssdk_act
+            dw._ssdk_expect_pending = True
+            return y
         with torch.autocast("cuda", enabled=False):
             y = _BatchNormTrain.apply(x, self.weight, self.bias, self.running_mean, self.running_var, momentum, self.eps,
                                       self._ssdk_act, sums)
@@ -142,6 +185,35 @@ class FusedAwayReLU6(_FusedAwayActivation, nn.ReLU6):
 
 class FusedAwayReLU(_FusedAwayActivation, nn.ReLU):
     _ssdk_act_code = 2
+
+
+def fuse_bn_into_depthwise(model):
+    """For every pair of neighbouring ``nn.Sequential`` blocks [..., FastBatchNorm2d (+ folded ReLU6 / ReLU), activation] ->
+    [DepthwiseConv2d, ...] inside one ``nn.Sequential`` (the expand and depthwise ConvBNReLU blocks of an inverted-residual
+    block, mobilenet.py:56): the BatchNorm's apply pass disappears -- it computes statistics and coefficients only, and the depthwise
+    forward / weight-gradient kernels normalise x while they stage it (the 6 x expanded tensor is written once, by the 1x1
+    convolution, instead of twice).  Call after use_fast_batchnorm + fuse_bn_activations; SSDK_BN_DEFER=0 keeps the apply pass.
+    -> pairs found."""
+    import os
+
+    from ssds.modeling.layers.dwconv import DepthwiseConv2d
+
+    n = 0
+    if os.environ.get("SSDK_BN_DEFER", "1") == "0":
+        return n
+    for seq in model.modules():
+        if not isinstance(seq, nn.Sequential):
+            continue
+        kids = list(seq.children())
+        for a, b in zip(kids, kids[1:]):
+            if not (isinstance(a, nn.Sequential) and isinstance(b, nn.Sequential)):
+                continue
+            ak, bk = list(a.children()), list(b.children())
+            if (len(ak) >= 2 and len(bk) >= 1 and type(ak[-2]) is FastBatchNorm2d and ak[-2]._ssdk_act
+                    and isinstance(ak[-1], _FusedAwayActivation) and type(bk[0]) is DepthwiseConv2d):
+                ak[-2].__dict__["_ssdk_defer_to"] = bk[0]  # (not a registered submodule: no second path to its parameters)
+                n += 1
+    return n
 
 
 def fuse_bn_activations(model):

@@ -19,7 +19,7 @@ def _launch(fn, *args):
 
 class _DwConv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, stride, want_sums=False):
+    def forward(ctx, x, w, stride, want_sums=False, coef=None, act=0):
         """``want_sums``: also return sums [C, 2] = per-channel (sum y, sum y^2) of the outputs -- the batch statistics of the
         BatchNorm that follows (ssdk_dwconv_fwd_stats: no pass over y); non-differentiable; None where the geometry runs on the
         tiled fallback kernels."""
@@ -31,7 +31,15 @@ class _DwConv3x3(torch.autograd.Function):
         sums = None
         with torch.cuda.device(x.device):
             need = int(N.lib.ssdk_dwconv_fwd_stats_workspace_bytes(n, c, h, wd, stride, N.dtype_code(x))) if want_sums else 0
-            if need:
+            if coef is not None:  # x is the INPUT of a deferred BatchNorm: the kernel stages act(a x + b) (batchnorm._BatchNormDeferred)
+                ws = torch.empty(need + 16, dtype=torch.uint8, device=x.device) if need else None
+                if need:
+                    sums = torch.empty((c, 2), device=x.device, dtype=torch.float32)
+                N.check(N.lib.ssdk_dwconv_fwd_affine(x.data_ptr(), coef.data_ptr(), int(act), w.data_ptr(), y.data_ptr(),
+                                                     None if sums is None else sums.data_ptr(),
+                                                     None if ws is None else (ws.data_ptr() + 15) & ~15, need, n, c, h, wd, stride,
+                                                     N.dtype_code(x), N.stream_ptr(x.device)), "dwconv_fwd_affine")
+            elif need:
                 ws = torch.empty(need + 16, dtype=torch.uint8, device=x.device)
                 sums = torch.empty((c, 2), device=x.device, dtype=torch.float32)
                 N.check(N.lib.ssdk_dwconv_fwd_stats(x.data_ptr(), w.data_ptr(), y.data_ptr(), sums.data_ptr(), (ws.data_ptr() + 15) & ~15,
@@ -39,8 +47,12 @@ class _DwConv3x3(torch.autograd.Function):
             else:
                 _launch(N.lib.ssdk_dwconv_fwd, x.data_ptr(), w.data_ptr(), y.data_ptr(), n, c, h, wd, stride, N.dtype_code(x),
                         N.stream_ptr(x.device))
-        ctx.save_for_backward(x, w)
+        if coef is not None:
+            ctx.save_for_backward(x, w, coef)
+        else:
+            ctx.save_for_backward(x, w)
         ctx.stride = stride
+        ctx.act = int(act)
         if want_sums:
             if sums is None:
                 sums = torch.empty(0, device=x.device)
@@ -50,7 +62,11 @@ class _DwConv3x3(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, _gsums=None):
-        x, w = ctx.saved_tensors
+        coef = None
+        if len(ctx.saved_tensors) == 3:
+            x, w, coef = ctx.saved_tensors
+        else:
+            x, w = ctx.saved_tensors
         stride = ctx.stride
         gy = gy.contiguous()
         if gy.dtype != x.dtype:
@@ -67,27 +83,34 @@ class _DwConv3x3(torch.autograd.Function):
                 need = int(N.lib.ssdk_dwconv_bwd_weight_workspace_bytes(n, c, h, wd, stride))
                 ws = torch.empty(need, dtype=torch.uint8, device=dev)
                 gw32 = torch.empty((c, 1, 3, 3), device=dev, dtype=torch.float32)
-                _launch(N.lib.ssdk_dwconv_bwd_weight, x.data_ptr(), gy.data_ptr(), gw32.data_ptr(), ws.data_ptr(), need,
-                        n, c, h, wd, stride, N.dtype_code(x), N.stream_ptr(dev))
+                if coef is not None:
+                    N.check(N.lib.ssdk_dwconv_bwd_weight_affine(x.data_ptr(), coef.data_ptr(), ctx.act, gy.data_ptr(), gw32.data_ptr(),
+                                                                ws.data_ptr(), need, n, c, h, wd, stride, N.dtype_code(x),
+                                                                N.stream_ptr(dev)), "dwconv_bwd_weight_affine")
+                else:
+                    _launch(N.lib.ssdk_dwconv_bwd_weight, x.data_ptr(), gy.data_ptr(), gw32.data_ptr(), ws.data_ptr(), need,
+                            n, c, h, wd, stride, N.dtype_code(x), N.stream_ptr(dev))
                 gw = gw32.to(w.dtype)
-        return gx, gw, None, None
+        return gx, gw, None, None, None, None
 
 
-def dwconv3x3(x, weight, stride, want_sums=False):
+def dwconv3x3(x, weight, stride, want_sums=False, pending=None):
     """Depthwise 3x3, pad 1, no bias: x [N,C,H,W], weight [C,1,3,3] (same floating dtype), differentiable.  ``want_sums``: the
     output carries ``_ssdk_bn_sums`` = [C, 2] for the kernel-backed BatchNorm behind it (see pointwise.pointwise_conv)."""
+    coef, act = pending if pending is not None else (None, 0)
     if want_sums:
-        y, sums = _DwConv3x3.apply(x, weight, stride, True)
+        y, sums = _DwConv3x3.apply(x, weight, stride, True, coef, act)
         if sums.numel():
             y._ssdk_bn_sums = sums
         return y
-    return _DwConv3x3.apply(x, weight, stride)
+    return _DwConv3x3.apply(x, weight, stride, False, coef, act)
 
 
 class DepthwiseConv2d(nn.Conv2d):
     """``nn.Conv2d(C, C, 3, stride, 1, groups=C, bias=False)`` whose HIP-device forward/backward run on the
     ssdk kernels; anything else falls through to ``nn.Conv2d.forward``."""
     _ssdk_bn_follows = False  # set by pointwise.fuse_conv_bn_statistics: the next module is a kernel-backed BatchNorm
+    _ssdk_expect_pending = False  # set by a deferred BatchNorm right before its (alias) output reaches this module
 
     def _native(self, x):
         return (x.is_cuda and x.dim() == 4 and self.kernel_size == (3, 3) and self.padding == (1, 1)
@@ -96,6 +119,12 @@ class DepthwiseConv2d(nn.Conv2d):
                 and self.padding_mode == "zeros")
 
     def forward(self, x):
+        pending = x.__dict__.pop("_ssdk_pending_bn", None) if hasattr(x, "__dict__") else None
+        expect, self._ssdk_expect_pending = self._ssdk_expect_pending, False
+        if expect and pending is None:  # (would be silently wrong: the tensor in hand is the BatchNorm's INPUT)
+            raise RuntimeError("DepthwiseConv2d: the deferred BatchNorm's coefficients did not arrive with its output")
+        if pending is not None and not (self._native(x) and x.dtype in (torch.bfloat16, torch.float16)):
+            raise RuntimeError("DepthwiseConv2d: a deferred BatchNorm output reached a path that cannot apply it")
         if not self._native(x):
             return super(DepthwiseConv2d, self).forward(x)
         w = self.weight
@@ -111,8 +140,10 @@ class DepthwiseConv2d(nn.Conv2d):
         ho, wo = (x.shape[2] - 1) // self.stride[0] + 1, (x.shape[3] - 1) // self.stride[0] + 1
         want = (self._ssdk_bn_follows and self.training and x.dtype != torch.float32
                 and x.shape[0] * x.shape[1] * ho * wo * 2 >= _pw.BN_STATS_MIN_BYTES)
+        if pending is not None and x.dtype != (torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype):
+            raise RuntimeError("DepthwiseConv2d: dtype changed behind a deferred BatchNorm")
         with torch.autocast("cuda", enabled=False):
-            return dwconv3x3(x, w, self.stride[0], want_sums=want)
+            return dwconv3x3(x, w, self.stride[0], want_sums=want, pending=pending)
 
 
 def make_conv2d(in_planes, out_planes, kernel_size, stride=1, padding=0, groups=1, bias=True):

@@ -44,6 +44,9 @@ class Solver(object):
                 from ssds.modeling.layers.batchnorm import fuse_bn_activations
 
                 fuse_bn_activations(self.model)  # Conv-BN-ReLU6: the clamp and its gradient mask ride on the BN passes
+                from ssds.modeling.layers.batchnorm import fuse_bn_into_depthwise
+
+                fuse_bn_into_depthwise(self.model)  # expand BN (+ ReLU6) applied by the depthwise kernels on load: no apply pass
         if os.environ.get("SSDK_PW_GEMM", "1") != "0":
             from ssds.modeling.layers.pointwise import use_pointwise_gemm
 

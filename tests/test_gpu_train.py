@@ -618,6 +618,61 @@ def test_depthwise_conv_hands_its_batchnorm_the_statistics(n, c, h, w, stride, d
             assert float(rel.max()) <= 8 * eps, "%s: %.3g" % (what, float(rel.max()))
 
 
+@pytest.mark.parametrize("dtype_name", ["bfloat16", "float16"])
+@pytest.mark.parametrize("n,cin,c,h,w,stride", [(4, 16, 96, 64, 64, 2), (3, 24, 144, 33, 31, 1), (2, 64, 384, 16, 16, 1), (5, 8, 48, 19, 19, 2)])
+def test_depthwise_conv_applies_the_deferred_batchnorm(n, cin, c, h, w, stride, dtype_name, monkeypatch):
+    """fuse_bn_into_depthwise (round 6): the expand block's BatchNorm + ReLU6 (mobilenet.py:56-60: ConvBNReLU 1x1 -> ConvBNReLU
+    depthwise) computes statistics and coefficients only, and the depthwise forward / weight-gradient kernels apply
+    act(a x + b), rounded to the tensor dtype, while they stage x.  The arithmetic is bn_apply's, so the block's output, every
+    gradient and the running statistics are those of the path that writes the BatchNorm output, bit for bit."""
+    import copy
+    import torch
+    import torch.nn as nn
+    from ssds import _native as N
+    from ssds.modeling.layers import pointwise as PW
+    from ssds.modeling.layers.batchnorm import fuse_bn_activations, fuse_bn_into_depthwise, use_fast_batchnorm
+    from ssds.modeling.layers.dwconv import DepthwiseConv2d
+
+    dtype = getattr(torch, dtype_name)
+    torch.manual_seed(n * 7 + c)
+    net = nn.Sequential(nn.Sequential(nn.Conv2d(cin, c, 1, bias=False), nn.BatchNorm2d(c), nn.ReLU6()),
+                        nn.Sequential(DepthwiseConv2d(c, c, 3, stride, 1, groups=c, bias=False), nn.BatchNorm2d(c), nn.ReLU6())).cuda()
+    with torch.no_grad():
+        for blk in net:
+            blk[1].weight.uniform_(0.5, 1.5)
+            blk[1].bias.normal_(0.5, 1.0)  # (outputs on both sides of 0 and of 6)
+    use_fast_batchnorm(net)
+    fuse_bn_activations(net)
+    PW.use_pointwise_gemm(net)
+    monkeypatch.setattr(PW, "BN_STATS_MIN_BYTES", 0)
+    PW.fuse_conv_bn_statistics(net)
+    plain = copy.deepcopy(net)
+    monkeypatch.delenv("SSDK_BN_DEFER", raising=False)
+    assert fuse_bn_into_depthwise(net) == 1 and "_ssdk_defer_to" not in plain[0][1].__dict__
+    assert N.lib.ssdk_dwconv_affine_supported(n, c, h, w, stride, 1 if dtype_name == "bfloat16" else 2)
+    x = torch.randn(n, cin, h, w, device="cuda")
+    g = torch.randn(n, c, (h - 1) // stride + 1, (w - 1) // stride + 1, device="cuda").to(dtype)
+    outs = []
+    for m in (net, plain):
+        m.train()
+        xi = x.clone().requires_grad_(True)
+        seen = []
+        hook = m[1][0].register_forward_pre_hook(lambda mod, args: seen.append("_ssdk_pending_bn" in args[0].__dict__))
+        with torch.autocast("cuda", dtype=dtype):
+            o = m(xi)
+        hook.remove()
+        o.backward(g)
+        assert seen == [m is net]  # the deferred path ran on the first module and only there
+        outs.append([o.detach(), xi.grad] + [p.grad for p in m.parameters()] + [b.clone() for b in m.buffers()])
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert torch.equal(a, b), "tensor %d of (output, dx, parameter gradients, buffers) differs: %.3g" % (
+            k, float((a.double() - b.double()).abs().max()))
+    net.eval()  # eval: nothing is deferred (the BatchNorm runs torch's own forward on its running statistics)
+    plain.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+        assert torch.equal(net(x), plain(x))
+
+
 @pytest.mark.parametrize("dtype_name,tol", [("bfloat16", 2e-2), ("float16", 4e-3)])
 @pytest.mark.parametrize("n,cin,cout,h,w,stride,bias", [
     (2, 96, 24, 32, 32, 1, True), (2, 96, 480, 32, 32, 1, True),    # the heads of level 0 (ssd.py:100-103)
@@ -1029,11 +1084,12 @@ def _device_step(model, anchors, images, targets, cfg, autocast, ssdk=True, ddp=
 
     m = copy.deepcopy(model)
     if ssdk:
-        from ssds.modeling.layers.batchnorm import fuse_bn_activations, use_fast_batchnorm
+        from ssds.modeling.layers.batchnorm import fuse_bn_activations, fuse_bn_into_depthwise, use_fast_batchnorm
         from ssds.modeling.layers.pointwise import fuse_conv_bn_statistics, use_native_conv3x3, use_pointwise_gemm
 
         use_fast_batchnorm(m)
         assert fuse_bn_activations(m) > 30
+        assert fuse_bn_into_depthwise(m) == 16  # (every inverted-residual block with an expansion; SSDK_BN_DEFER unset in the suite)
         use_pointwise_gemm(m)
         assert fuse_conv_bn_statistics(m) > 30
         if conv3:  # (optional in the product too: SSDK_CONV3_NATIVE=1, ssds/utils/train_ddp.py)
