@@ -1252,6 +1252,10 @@ extern "C" int ssdk_conv(const ssdk_conv_desc* d, void* workspace, size_t worksp
     }
   }
   if (launch_conv_smallmap(p, d->dtype, stream) == 0) return check_launch("conv_smallmap_kernel");  // maps of <= 64 pixels
+  {
+    const int rc = launch_conv_gemmp(p, d->dtype, stream);  // 1x1, long K, enough tiles: persistent GEMM
+    if (rc != 1) return rc;
+  }
   if (launch_conv_pwflow(p, d->dtype, stream) == 0) return check_launch("pwflow_kernel");  // 1x1, short K, large maps: streaming
   // Side-lane ops (small heads running next to the extras chain) prefer the halo kernel however few tiles they have:
   // an underfilled grid is free there, and unlike the split-K kernels it has no agent-scope fences, which slow down

@@ -48,6 +48,9 @@ struct HaloParams {
   unsigned mg_ks;            // (grids too small to fill the chip: few pixels, long K -- the 8x8 ... 4x4 head levels)
   float* slabs;              // [tile][slice][16 fragments][512 lanes][4] fp32 partial accumulators
   unsigned* counters;        // [tile] arrival tickets, zero on entry, re-armed by the last arriver
+  unsigned y_bytes, y2_bytes, res_bytes;  // persistent form: ranges of the output / residual descriptors (0: tensor absent)
+  unsigned mg_wo;            // ceil(2^32 / Wo)
+  unsigned tq, tr;           // persistent form: workgroup g owns tiles [g*tq + min(g, tr), +tq + (g < tr)) of the launch's tiles
   long long* dbg;             // SSDK_H3_DBG=1: cycle stamps of one workgroup / wave 0 (4 per k-step)
   unsigned dbg_wg;            // which workgroup is stamped (SSDK_H3_DBG_WG: 0 = the first, cold one; -1 = the last to start)
 };
@@ -448,6 +451,377 @@ __global__ __launch_bounds__(H3_THREADS) void conv3x3_halo_kernel(const HaloPara
   H3_MARK(5);
 }
 
+// ---- persistent form (round 6) -----------------------------------------------------------------------------------------------
+// One workgroup per CU walks a contiguous range of the launch's tiles (the n-tiles of a patch are neighbours: the second one
+// finds the halo in L2).  Per tile the first form pays 2.5 k cycles of set-up, ~2 k of first-load latency, 7.5 k of epilogue
+// arithmetic + LDS staging and 4.6 k of stores + drain around a 51 k loop (256 -> 256 tower tile, stamps of round 5), all of it
+// serial because 160 KiB of LDS admit one workgroup per CU.  Here
+//   * the epilogue goes from the accumulator registers straight to global memory: NCHW -- a lane holds four consecutive pixels
+//     of a channel = 8 contiguous bytes of a plane; NHWC -- the LOADER places weight row n0 + (q & 64) + (q & 15) * 4 + ((q >> 4) & 3)
+//     at LDS row q, so that the four accumulator columns of a lane are four CONSECUTIVE channels: 8 contiguous bytes of a pixel,
+//     16 lanes = 128 bytes (the permutation costs nothing: it is a different voffset per loader lane).  No LDS image, no
+//     barrier, no 2-byte staging writes;
+//   * the next tile's halo slab 0 and first two weight stages are requested BEFORE the epilogue arithmetic of the current tile
+//     and land behind it; the set-up (roles, descriptors, fragment addresses) happens once per workgroup.
+// Takes ksplits == 1, patches with tw % 4 == 0, NCHW with Wo % 4 == 0, NHWC with Cout % 4 == 0; everything else stays on the first form.
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+// epilogue4 (ssdk_conv_common.h) with the per-lane activation choice as bit selects: the ternaries of the shared helper compile to
+// an exec-masked branch per VALUE on split heads (64 per tile), which a workgroup that is alone on its CU pays in full
+template <int DT, bool SIG>
+__device__ __forceinline__ uint2 epilogue4_flat(const f32x4 acc, float sc, float bi, float lo, float hi, u32 m_sig, u32 m_silu,
+                                                bool any_clamp) {
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = acc[r] * sc + bi;
+  if constexpr (SIG) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.442695041f * v[r]));
+      const u32 vb = __builtin_bit_cast(u32, v[r]), sb = __builtin_bit_cast(u32, sg), pb = __builtin_bit_cast(u32, v[r] * sg);
+      const u32 t = (pb & m_silu) | (vb & ~m_silu);
+      v[r] = __builtin_bit_cast(float, (sb & m_sig) | (t & ~m_sig));
+    }
+  }
+  if (any_clamp) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = __builtin_fminf(__builtin_fmaxf(v[r], lo), hi);
+  }
+  return make_uint2(pack2_16<DT>(v[0], v[1]), pack2_16<DT>(v[2], v[3]));
+}
+
+template <int DT, bool NHWC>
+__global__ __launch_bounds__(H3_THREADS) void conv3x3_halop_kernel(const HaloParams hp) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const ConvParams& p = hp.c;
+  const u32 tid = threadIdx.x, lane = tid & 63u;
+  const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const u32 wm = wave >> 1, wn = wave & 1u;
+
+  const u32 nwg = gridDim.x, id = blockIdx.x;
+  const u32 q8 = nwg >> 3, r8 = nwg & 7u, xcd = id & 7u;
+  const u32 lin = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + (id >> 3);  // neighbours in lin share an XCD
+  const u32 t_begin = lin * hp.tq + (lin < hp.tr ? lin : hp.tr);
+  const u32 t_cnt = hp.tq + (lin < hp.tr ? 1u : 0u);
+#define H3P_STAMP(idx)                                                                                        \
+  do {                                                                                                        \
+    if (hp.dbg && lin == hp.dbg_wg && tid == 0 && (idx) < 256) hp.dbg[(idx)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+  H3P_STAMP(240);
+
+  const int Cin = p.Cin, H = p.H, W = p.W;
+  const int HW2 = hp.tw + 2, HH2 = hp.th + 2;
+  const int Ktot = 9 * Cin;
+  const int cchunks = (Cin + H3_BK - 1) / H3_BK;
+
+  const u32 lrow = lane >> 3;
+  const u32 lchunk = ((lane & 7u) - (lane >> 3)) & 7u;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, hp.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, hp.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, hp.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc(p.y2 ? p.y2 : p.y, 0, hp.y2_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.x), 0, hp.res_bytes, 0x00020000);
+  constexpr u32 OOB = 0xfffffff0u;
+  const int lci = (int)lchunk * 8;
+  const int tail = Cin - (cchunks - 1) * H3_BK;
+  const u32 tailmask = lci < tail ? 0u : OOB;
+
+  const u32 fr = lane & 15u, fg = lane >> 4;
+  const int npix = hp.imgs * hp.th * hp.tw;
+  const int ppi = hp.th * hp.tw;
+  u32 a_ad[9][4];
+  {
+    int a_hr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int ml = (int)(wm * 64u + i * 16 + fr);
+      if (ml >= npix) ml = 0;
+      const int img = (int)fdiv((u32)ml, (u32)ppi, hp.mg_ppi), rr = ml - img * ppi;
+      const int y = (int)fdiv((u32)rr, (u32)hp.tw, hp.mg_tw), x = rr - y * hp.tw;
+      a_hr[i] = (img * HH2 + y) * HW2 + x;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32 hr = (u32)(a_hr[i] + (tap / 3) * HW2 + (tap % 3));
+        a_ad[tap][i] = hr * 128u + (((fg + hr) & 7u) << 4);
+      }
+  }
+  const u32 b_ad0 = 2u * H3_A_BYTES + (wn * 64u + fr) * 128u + (((fg + fr) & 7u) << 4);
+  const u32 b_ad1 = b_ad0 ^ 64u;
+
+  // ---- per-tile state ------------------------------------------------------------------------------------------------------
+  int b0 = 0, y0 = 0, x0 = 0;
+  u32 n0 = 0;
+  u32 a_vo[H3_NPIECE], b_vo[2];
+  u32 cur_pt = 0xffffffffu;
+  auto set_tile = [&](u32 tile) {
+    const u32 pt = fdiv(tile, (u32)hp.n_tiles, hp.mg_ntiles);
+    const u32 nt = tile - pt * (u32)hp.n_tiles;
+    n0 = nt * H3_BN;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const u32 q = ((u32)j * 8u + wave) * 8u + lrow;  // LDS row of this lane's chunk
+      const u32 n = n0 + (NHWC ? (q & 64u) + (q & 15u) * 4u + ((q >> 4) & 3u) : q);
+      b_vo[j] = n < (u32)p.Cout ? (u32)(((long)n * Ktot + lci) * 2) : OOB;
+    }
+    if (pt == cur_pt) return;  // the next n-tile of the same patch: the halo offsets stand
+    cur_pt = pt;
+    const u32 pq = fdiv(pt, (u32)hp.tiles_x, hp.mg_tx);
+    const u32 tx = pt - pq * (u32)hp.tiles_x;
+    const u32 grp = fdiv(pq, (u32)hp.tiles_y, hp.mg_ty);
+    const u32 ty = pq - grp * (u32)hp.tiles_y;
+    b0 = (int)grp * hp.imgs;
+    y0 = (int)ty * hp.th;
+    x0 = (int)tx * hp.tw;
+#pragma unroll
+    for (int t = 0; t < H3_NPIECE; ++t) {
+      const int hr = (t * 8 + (int)wave) * 8 + (int)lrow;
+      const int img = (int)fdiv((u32)hr, (u32)(HH2 * HW2), hp.mg_halo), rr = hr - img * (HH2 * HW2);
+      const int hy = (int)fdiv((u32)rr, (u32)HW2, hp.mg_hw2), hx = rr - hy * HW2;
+      const int b = b0 + img, iy = y0 + hy - 1, ix = x0 + hx - 1;
+      const bool inside = hr < hp.hrows && b < p.N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const u32 pix = ((u32)b * (u32)H + (u32)iy) * (u32)W + (u32)ix;
+      a_vo[t] = inside ? (pix * (u32)Cin + (u32)lci) * 2u : OOB;
+    }
+  };
+  auto load_b = [&](int stage, int cc, int tap) {
+    const bool live = cc < cchunks;
+    const u32 tm = (live && cc == cchunks - 1) ? tailmask : 0u;
+    const int soff = live ? (tap * Cin + cc * H3_BK) * 2 : 0;
+    lds_u8* dst = (lds_u8*)(smem + 2 * H3_A_BYTES + stage * H3_B_BYTES + wave * 1024u);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, dst, 16, b_vo[0] | tm, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, dst + 8192, 16, b_vo[1] | tm, soff, 0, 0);
+  };
+  auto load_a = [&](int t, int cc) {
+    const bool live = cc < cchunks;
+    const u32 tm = (live && cc == cchunks - 1) ? tailmask : 0u;
+    const int soff = live ? cc * H3_BK * 2 : 0;
+    lds_u8* dst = (lds_u8*)(smem + (cc & 1) * H3_A_BYTES + (t * 8 + (int)wave) * 1024);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, dst, 16, a_vo[t] | tm, soff, 0, 0);
+  };
+  auto issue_prologue = [&]() {  // 7 halo pieces, then the weights of steps 0 and 1: eleven LDS-DMA instructions, in this order
+#pragma unroll
+    for (int t = 0; t < H3_NPIECE; ++t) load_a(t, 0);
+    load_b(0, 0, 0);
+    load_b(1, 0, 1);
+  };
+  // the four accumulator columns of this lane: channels col_n(j)
+  auto col_n = [&](u32 tn0, int j) -> u32 { return tn0 + wn * 64u + (NHWC ? fr * 4u + (u32)j : (u32)j * 16u + fr); };
+  float ld_sc[4], ld_bi[4];
+  auto load_scbi = [&]() {  // (unconditional loads from clamped indices: see the first form)
+    const float* scp = p.scale ? p.scale : p.bias;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u32 n = col_n(n0, j);
+      n = n < (u32)p.Cout ? n : (u32)p.Cout - 1u;
+      ld_sc[j] = scp[n];
+      ld_bi[j] = p.bias[n];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const bool tail_half = tail <= 32;
+  const bool g1 = wave >= 4u;
+  const bool any_sig = act_is_sig(p.act) || act_is_sig(p.act2);
+  const bool any_clamp = act_is_clamp(p.act) || act_is_clamp(p.act2);
+  const u32 hw = (u32)(p.Ho * p.Wo);
+  const bool has_res = p.res != nullptr, two_out = p.split < p.Cout;
+  const u32 rsh = (u32)(p.res_mode & 1);
+  const float post_lo = (p.post == SSDK_ACT_RELU || p.post == SSDK_ACT_RELU6) ? 0.f : -__builtin_inff();
+  const float post_hi = p.post == SSDK_ACT_RELU6 ? 6.f : __builtin_inff();
+
+  set_tile(t_begin);
+  issue_prologue();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  H3_WAIT(2);  // everything but the weights of step 1
+  load_scbi();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  H3P_STAMP(241);
+
+  for (u32 it = 0; it < t_cnt; ++it) {
+    H3P_STAMP(it * 8u + 0u);
+    // ---- main loop: exactly the first form's (two phases per k-step, the wave groups one phase apart) -------------------------
+    u32 abuf = 0;
+    if (g1) __builtin_amdgcn_s_barrier();
+    for (int cc = 0; cc < cchunks; ++cc) {
+      const bool half = tail_half && cc == cchunks - 1;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 2 < 9) load_b((tap + 2) % 3, cc, tap + 2);
+        else load_b((tap + 2) % 3, cc + 1, tap + 2 - 9);
+        if (tap < H3_NPIECE) load_a(tap, cc + 1);
+        const u32 sboff = (u32)((tap % 3) * H3_B_BYTES);
+        u32x4 fa0[4], fb0[4], fa1[4], fb1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb0[j] = *reinterpret_cast<const u32x4*>(smem + b_ad0 + sboff + j * 2048);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa0[i] = *reinterpret_cast<const u32x4*>(smem + (a_ad[tap][i] + abuf));
+        if (!half) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fb1[j] = *reinterpret_cast<const u32x4*>(smem + b_ad1 + sboff + j * 2048);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fa1[i] = *reinterpret_cast<const u32x4*>(smem + ((a_ad[tap][i] + abuf) ^ 64u));
+        }
+        if (tap < H3_NPIECE) H3_WAIT(3);
+        else H3_WAIT(2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<DT>(fa0[i], fb0[j], acc[i][j]);
+        if (!half) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<DT>(fa1[i], fb1[j], acc[i][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      abuf ^= (u32)H3_A_BYTES;
+    }
+    if (!g1) __builtin_amdgcn_s_barrier();  // re-align the groups
+    H3P_STAMP(it * 8u + 1u);
+    H3_WAIT(0);                             // (the loop's harmless loads past the end; the scale / bias loads of this tile)
+    __builtin_amdgcn_s_barrier();
+    H3P_STAMP(it * 8u + 2u);
+
+    // ---- tile boundary -----------------------------------------------------------------------------------------------------------
+    // this tile's epilogue constants and coordinates, before the per-tile state moves on
+    float e_sc[4], e_bi[4], e_lo[4], e_hi[4];
+    u32 e_m1[4], e_m2[4], e_n[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 n = col_n(n0, j);
+      e_n[j] = n;
+      e_sc[j] = (n < (u32)p.Cout && p.scale) ? ld_sc[j] : 1.f;
+      e_bi[j] = n < (u32)p.Cout ? ld_bi[j] : 0.f;
+      {  // (act_sel without its if-chain: the activation differs per lane on split heads)
+        const int a = (int)n >= p.split ? p.act2 : p.act;
+        e_lo[j] = (a == SSDK_ACT_RELU || a == SSDK_ACT_RELU6) ? 0.f : -__builtin_inff();
+        e_hi[j] = a == SSDK_ACT_RELU6 ? 6.f : __builtin_inff();
+        e_m1[j] = (u32)-(int)(a == SSDK_ACT_SIGMOID);
+        e_m2[j] = (u32)-(int)(a == SSDK_ACT_SILU);
+      }
+      asm volatile("" : "+v"(e_sc[j]), "+v"(e_bi[j]));  // the loads are consumed HERE: no compiler wait behind the LDS-DMA requests below
+    }
+    const int cb0 = b0, cy0 = y0, cx0 = x0;
+    const bool more = it + 1u < t_cnt;
+    if (more) {
+      set_tile(t_begin + it + 1u);
+      issue_prologue();  // lands behind the arithmetic below; the buffers are free: every wave is past its last fragment read
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    H3P_STAMP(it * 8u + 3u);
+    // (branch-free: an element that must not be stored carries an out-of-range buffer offset -- the set-up of the first form
+    //  taught that ~60 short branches cost a workgroup 5 k cycles)
+    // tile row -> (image, oy, ox) of THIS tile; false: not a pixel of the output (the four rows ml .. ml+3 of an accumulator
+    // fragment are consecutive x of one map row: tw % 4 == 0)
+    auto pixel_of = [&](int ml, u32* b_out, u32* oy_out, u32* ox_out) -> bool {
+      const int img = (int)fdiv((u32)ml, (u32)ppi, hp.mg_ppi), rr = ml - img * ppi;
+      const int yy = (int)fdiv((u32)rr, (u32)hp.tw, hp.mg_tw);
+      const int oy = cy0 + yy, ox = cx0 + (rr - yy * hp.tw), b = cb0 + img;
+      *b_out = (u32)b;
+      *oy_out = (u32)oy;
+      *ox_out = (u32)ox;
+      return (ml < npix) & (b < p.N) & (oy < p.Ho) & (ox < p.Wo);
+    };
+    // one accumulator row fragment (16 pixels x the lane's four columns) at a time: arithmetic, then its stores
+    auto fragments = [&](auto SIG, auto FLAG) {  // FLAG: NHWC -- a residual is added; NCHW -- two output tensors (split heads)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint2 h[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        h[j] = epilogue4_flat<DT, decltype(SIG)::value>(acc[i][j], e_sc[j], e_bi[j], e_lo[j], e_hi[j], e_m1[j], e_m2[j], any_clamp);
+        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const int ml = (int)(wm * 64u + i * 16 + fg * 4);
+      if constexpr (NHWC) {
+        const u32 nb = e_n[0];  // four consecutive channels from here (Cout % 4 == 0: all inside or all outside)
+        uint2 o[4];             // row r: channels nb .. nb+3
+        o[0] = make_uint2(__builtin_amdgcn_perm(h[1].x, h[0].x, 0x05040100u), __builtin_amdgcn_perm(h[3].x, h[2].x, 0x05040100u));
+        o[1] = make_uint2(__builtin_amdgcn_perm(h[1].x, h[0].x, 0x07060302u), __builtin_amdgcn_perm(h[3].x, h[2].x, 0x07060302u));
+        o[2] = make_uint2(__builtin_amdgcn_perm(h[1].y, h[0].y, 0x05040100u), __builtin_amdgcn_perm(h[3].y, h[2].y, 0x05040100u));
+        o[3] = make_uint2(__builtin_amdgcn_perm(h[1].y, h[0].y, 0x07060302u), __builtin_amdgcn_perm(h[3].y, h[2].y, 0x07060302u));
+        u32 pb, oy, ox0;
+        const bool okb = pixel_of(ml, &pb, &oy, &ox0) & (nb < (u32)p.Cout);
+        const u32 m0 = (pb * (u32)p.Ho + oy) * (u32)p.Wo + ox0;
+        const u32 rrow = (pb * ((u32)p.Ho >> rsh) + (oy >> rsh)) * ((u32)p.Wo >> rsh);  // rsh = 1: half-resolution residual
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = okb & (ox0 + (u32)r < (u32)p.Wo);
+          const u32 m = m0 + (u32)r;
+          uint2 v = o[r];
+          if constexpr (decltype(FLAG)::value) {  // (values already rounded to 16 bit, like the framework's tensor add)
+            const u32 rpix = rrow + ((ox0 + (u32)r) >> rsh);
+            const v2u rv = __builtin_amdgcn_raw_buffer_load_b64(rr_, (int)(ok ? (rpix * (u32)p.Cout + nb) * 2u : OOB), 0, 0);
+            auto addc = [&](u32 a, u32 b) { return __builtin_fminf(__builtin_fmaxf(bits16_to_f32<DT>(a) + bits16_to_f32<DT>(b), post_lo), post_hi); };
+            v.x = pack2_16<DT>(addc(v.x & 0xffffu, rv.x & 0xffffu), addc(v.x >> 16, rv.x >> 16));
+            v.y = pack2_16<DT>(addc(v.y & 0xffffu, rv.y & 0xffffu), addc(v.y >> 16, rv.y >> 16));
+          }
+          __builtin_amdgcn_raw_buffer_store_b64(v2u{v.x, v.y}, yr, (int)(ok ? (m * (u32)p.Cout + nb) * 2u : OOB), 0, 0);
+        }
+      } else {
+        // four consecutive pixels (tw % 4 == 0, Wo % 4 == 0: same map row, 8-byte aligned) of channel e_n[j]
+        u32 pb, oy, ox0;
+        const bool okp = pixel_of(ml, &pb, &oy, &ox0);
+        const u32 pp = oy * (u32)p.Wo + ox0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32 n = e_n[j];
+          const bool first = (int)n < p.split;
+          const u32 ch = first ? n : n - (u32)p.split;
+          const u32 cy = first ? (u32)p.split : (u32)(p.Cout - p.split);
+          const u32 off = (okp & (n < (u32)p.Cout)) ? ((pb * cy + ch) * hw + pp) * 2u : OOB;
+          // (two descriptors, one store each: the invalid one is out of range)
+          __builtin_amdgcn_raw_buffer_store_b64(v2u{h[j].x, h[j].y}, yr, (int)(first ? off : OOB), 0, 0);
+          if constexpr (decltype(FLAG)::value) __builtin_amdgcn_raw_buffer_store_b64(v2u{h[j].x, h[j].y}, y2r, (int)(first ? OOB : off), 0, 0);
+        }
+      }
+    }
+    };
+    const bool flag = NHWC ? has_res : two_out;
+    if (any_sig) {
+      if (flag) fragments(std::true_type{}, std::true_type{});
+      else fragments(std::true_type{}, std::false_type{});
+    } else {
+      if (flag) fragments(std::false_type{}, std::true_type{});
+      else fragments(std::false_type{}, std::false_type{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // loads complete in order among loads: <= 2 operations outstanding means the next tile's halo and step-0 weights have landed
+    // (and all but two of the stores above are acknowledged -- the first k-step's counted wait would ask for that anyway)
+    H3P_STAMP(it * 8u + 4u);
+    if (more) H3_WAIT(2);
+    __builtin_amdgcn_sched_barrier(0);
+    H3P_STAMP(it * 8u + 5u);
+    if (more) load_scbi();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();  // every wave's pieces of the next tile have landed (each waited for its own above)
+    H3P_STAMP(it * 8u + 6u);
+  }
+  if (hp.dbg) {  // (debug only) the store acknowledgements a workgroup waits for before it retires
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    H3P_STAMP(242);
+  }
+}
+
 // Patch shape for an (N, Ho, Wo) output: maximise the fraction of the 256 tile rows that are real pixels.
 static bool plan_patch(int N, int Ho, int Wo, bool nchw, HaloParams* hp) {
   int best_imgs = 0, best_th = 0, best_tw = 0;
@@ -559,6 +933,7 @@ int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool
   hp.mg_hw2 = magic(hp.tw + 2);
   hp.mg_halo = magic((hp.th + 2) * (hp.tw + 2));
   hp.mg_ks = magic(hp.ksplits);
+  hp.mg_wo = magic(p.Wo);
   const long xb = (long)p.N * p.H * p.W * p.Cin * 2, wb = (long)p.Cout * 9 * p.Cin * 2;
   if (xb >= 0xfffffff0l || wb >= 0xfffffff0l) return 1;  // 32-bit buffer offsets
   hp.x_bytes = (unsigned)xb;
@@ -580,6 +955,70 @@ int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool
   static const int dbg = getenv("SSDK_H3_DBG") ? atoi(getenv("SSDK_H3_DBG")) : 0;
   hp.dbg = nullptr;
   hp.dbg_wg = 0;
+  hp.tq = hp.tr = 0;
+  // persistent form: one workgroup per CU walks tiles / CUs tiles, epilogue from registers (SSDK_HALO_PERSIST=0: first form)
+  static const int persist = getenv("SSDK_HALO_PERSIST") ? atoi(getenv("SSDK_HALO_PERSIST")) : 1;
+  const bool nchw_out = p.out_layout == LAYOUT_NCHW;
+  const long hw_out = (long)p.Ho * p.Wo;
+  const long yb = nchw_out ? (long)p.N * p.split * hw_out * 2 : (long)p.N * hw_out * p.Cout * 2;
+  const long y2b = nchw_out ? (long)p.N * (p.Cout - p.split) * hw_out * 2 : 0;
+  const long rb = !p.res ? 0 : ((p.res_mode & 1) ? (long)p.N * (p.Ho >> 1) * (p.Wo >> 1) * p.Cout * 2 : (long)p.N * hw_out * p.Cout * 2);
+  if (persist && hp.ksplits == 1 && (nchw_out ? (hp.tw % 4 == 0 && p.Wo % 4 == 0) : (hp.tw % 4 == 0 && p.Cout % 4 == 0)) &&
+      yb < 0xfffffff0l && y2b < 0xfffffff0l && rb < 0xfffffff0l && (!nchw_out || !p.res) && (p.split == p.Cout || p.y2)) {
+    hp.y_bytes = (unsigned)yb;
+    hp.y2_bytes = (unsigned)y2b;
+    hp.res_bytes = (unsigned)rb;
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    // persist = tiles per workgroup at most (1: only the register epilogue; large: one workgroup per CU walks tiles / CUs tiles)
+    long want = (tiles + persist - 1) / persist;
+    if (want < cus) want = tiles < cus ? tiles : cus;
+    const unsigned grid = (unsigned)(want < 1 ? 1 : (want > tiles ? tiles : want));
+    hp.tq = (unsigned)(tiles / grid);
+    hp.tr = (unsigned)(tiles % grid);
+    static bool attr2_done = false;
+    if (!attr2_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halop_kernel<SSDK_BF16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halop_kernel<SSDK_BF16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halop_kernel<SSDK_F16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halop_kernel<SSDK_F16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, H3_LDS);
+      attr2_done = true;
+    }
+    if (dbg) {
+      static const int dbg_wg = getenv("SSDK_H3_DBG_WG") ? atoi(getenv("SSDK_H3_DBG_WG")) : 0;
+      hp.dbg_wg = dbg_wg < 0 ? grid - 1u : (unsigned)dbg_wg;
+      (void)hipMalloc((void**)&hp.dbg, 64 * 4 * sizeof(long long));
+      (void)hipMemsetAsync(hp.dbg, 0, 64 * 4 * sizeof(long long), stream);
+    }
+    if (di == 0) {
+      if (nchw_out) hipLaunchKernelGGL((conv3x3_halop_kernel<SSDK_BF16, false>), dim3(grid), dim3(H3_THREADS), H3_LDS, stream, hp);
+      else hipLaunchKernelGGL((conv3x3_halop_kernel<SSDK_BF16, true>), dim3(grid), dim3(H3_THREADS), H3_LDS, stream, hp);
+    } else {
+      if (nchw_out) hipLaunchKernelGGL((conv3x3_halop_kernel<SSDK_F16, false>), dim3(grid), dim3(H3_THREADS), H3_LDS, stream, hp);
+      else hipLaunchKernelGGL((conv3x3_halop_kernel<SSDK_F16, true>), dim3(grid), dim3(H3_THREADS), H3_LDS, stream, hp);
+    }
+    if (dbg) {  // debug only: synchronises and prints the phase times of one workgroup (lane 0 of wave 0)
+      long long h[64 * 4];
+      (void)hipStreamSynchronize(stream);
+      (void)hipMemcpy(h, hp.dbg, sizeof(h), hipMemcpyDeviceToHost);
+      (void)hipFree(hp.dbg);
+      static int printed = 0;
+      if (printed++ < dbg) {
+        fprintf(stderr, "[h3p dbg] %s Cin %d Cout %d %dx%d grid %u tiles %ld: set-up + first loads %lld\n", nchw_out ? "nchw" : "nhwc", p.Cin,
+                p.Cout, p.Ho, p.Wo, grid, tiles, h[241] - h[240]);
+        for (int i = 0; i < 30 && h[i * 8]; ++i)
+          fprintf(stderr, "[h3p dbg] tile %2d: loop %6lld | drain+barrier %5lld | consts+next prologue %5lld | math+stores %5lld | wait %5lld | scale/bias+barrier %5lld\n",
+                  i, h[i * 8 + 1] - h[i * 8], h[i * 8 + 2] - h[i * 8 + 1], h[i * 8 + 3] - h[i * 8 + 2], h[i * 8 + 4] - h[i * 8 + 3],
+                  h[i * 8 + 5] - h[i * 8 + 4], h[i * 8 + 6] - h[i * 8 + 5]);
+        fprintf(stderr, "[h3p dbg] store acknowledgements after the last tile: %lld\n", h[242] - h[(hp.tq + (hp.dbg_wg < hp.tr ? 1 : 0) - 1) * 8 + 6]);
+      }
+    }
+    return check_launch("conv3x3_halo_kernel");
+  }
   if (dbg) {
     static const int dbg_wg = getenv("SSDK_H3_DBG_WG") ? atoi(getenv("SSDK_H3_DBG_WG")) : 0;
     hp.dbg_wg = dbg_wg < 0 ? (unsigned)(tiles - 1) : (unsigned)dbg_wg;

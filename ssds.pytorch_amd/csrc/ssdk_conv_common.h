@@ -183,6 +183,8 @@ size_t halo_ws_bytes(int N, int Cin, int Ho, int Wo, int Cout, bool nchw, int ks
 int launch_conv3x3_halo(const ConvParams& p, int dtype, hipStream_t stream, bool allow_underfill);
 int launch_conv3x3_short(const ConvParams& p, int dtype, hipStream_t stream);
 int launch_conv_pwflow(const ConvParams& p, int dtype, hipStream_t stream);  // ssdk_pwflow.hip: 1x1, Cin <= 256, streaming
+// 1x1, long K (Cin >= 256), NHWC: persistent NT GEMM (ssdk_gemmp.hip); 1: not taken
+int launch_conv_gemmp(const ConvParams& p, int dtype, hipStream_t stream);
 constexpr int kSmallmapGroupMax = 4;
 int launch_conv_smallmap_group(const ConvParams* ps, int n, int dtype, hipStream_t stream);  // ssdk_smallmap.hip  // ssdk_conv3x3s.hip: Cin <= 128, needs p.w_frag
 

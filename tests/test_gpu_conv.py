@@ -7,6 +7,63 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+GP = [  # cin, cout, stride, h, w, n, act, residual mode (None | "same" | "half" | "post")
+    (256, 1024, 1, 40, 40, 8, "none", "post"),   # ResNet-50 layer3 expansion + block tail: eight n-tiles per pixel tile, four k-steps
+    (1024, 256, 1, 40, 40, 8, "relu", None),      # the reduction: sixteen k-steps, two n-tiles
+    (512, 256, 1, 48, 56, 6, "none", "half"),    # FPN lateral + nearest x2 top-down add; ragged last pixel tile
+    (256, 512, 2, 80, 80, 4, "none", None),      # downsample branch: every second pixel of every second row
+    (288, 132, 1, 64, 50, 4, "relu6", "same"),   # K tail of 32 (one k-substep), channel tail (132 = 128 + 4), plain residual
+    (264, 128, 1, 100, 64, 4, "silu", None),     # K tail of 8, sigmoid-type activation
+    (2048, 512, 1, 20, 20, 16, "relu", None),     # 32 k-steps, fewer tiles than CUs
+]
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "f16"])
+@pytest.mark.parametrize("cin,cout,stride,h,w,n,act,rmode", GP)
+def test_pointwise_persistent_gemm_kernel(cin, cout, stride, h, w, n, act, rmode, dtype_name):
+    """ssdk_gemmp.hip (round 6): 1x1 convolutions with Cin >= 256 as a persistent NT GEMM (256 x 128 x 64 tiles, three LDS
+    stages by LDS-DMA, epilogue from the accumulator registers through a row permutation of the weights) against the fp32
+    layer: every residual mode of ssdk_conv, both strides, K / channel / pixel tails, one and several tiles per workgroup."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from ssds import _native as N
+    from ssds.modeling.layers import fused_conv as FC
+
+    dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float16
+    torch.manual_seed(cin + cout + h + stride)
+    conv = nn.Conv2d(cin, cout, 1, stride, 0, bias=False).cuda()
+    bn = nn.BatchNorm2d(cout).cuda()
+    bn.running_mean.normal_(0, 0.2)
+    bn.running_var.uniform_(0.5, 1.5)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.normal_(0, 0.2)
+    conv.weight.data = conv.weight.data.to(dtype).float()
+    x = torch.randn(n, cin, h, w).to(dtype)
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    pack = FC.ConvPack(conv, bn, act, dtype)
+    if rmode is None:
+        want = _ref(x, conv, bn, act)
+        y = FC.conv_native(x.cuda(), pack)
+    elif rmode == "post":
+        res = torch.randn(n, cout, ho, wo).to(dtype)
+        lin = _ref(x, conv, bn, "none").to(dtype).float() + res.float()
+        want = lin.clamp(min=0)
+        y = FC.conv_native(x.cuda(), FC.ConvPack(conv, bn, "relu", dtype), residual=res.cuda(), res_mode=2)
+    elif rmode == "same":
+        res = torch.randn(n, cout, ho, wo).to(dtype)
+        want = _ref(x, conv, bn, act, residual=res)
+        y = FC.conv_native(x.cuda(), pack, residual=res.cuda())
+    else:
+        res = torch.randn(n, cout, ho // 2, wo // 2).to(dtype)
+        want = _ref(x, conv, bn, act).to(dtype).float() + F.interpolate(res.float(), scale_factor=2, mode="nearest")
+        y = FC.conv_native(x.cuda(), pack, residual=res.cuda(), res_mode=1)
+    assert N.last_kernel() == "conv_gemmp_kernel", N.last_kernel()
+    _check(y, want, dtype, "gemmp %d->%d s%d %s" % (cin, cout, stride, rmode), floor=1.0 if rmode else 0.125)
+    y2 = FC.conv_native(x.cuda(), pack) if rmode is None else None  # (bit-reproducible: no atomics, fixed k order)
+    assert y2 is None or torch.equal(y, y2)
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

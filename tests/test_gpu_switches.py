@@ -18,7 +18,7 @@ SWITCHES = {
     "SSDK_CONV_SMALLMAP": ("0", "conv_smallmap"), "SSDK_CONV_SMALLMAP_GROUP": ("0", "conv_smallmap_group"),
     "SSDK_CONV_SMALLMAP_KW": ("1", None), "SSDK_S3_WIDE": ("0", None), "SSDK_WFRAG": ("0", None), "SSDK_XPAIR": ("0", "xpair"),
     "SSDK_FUSED_BLOCK": ("0", "mb"), "SSDK_HEAD_BALANCE": ("0", "conv_smallmap_group"), "SSDK_SPLITK": ("0", None),
-    "SSDK_CONV_WAVE": ("0", None),
+    "SSDK_CONV_WAVE": ("0", None), "SSDK_HALO_PERSIST": ("0", None),
 }
 CHILD = r'''
 import os, sys

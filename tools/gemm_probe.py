@@ -38,6 +38,10 @@ def run(name, reps=20, check=True):
     with torch.no_grad():
         conv.weight.mul_(0.5)
     x = torch.randn(B, Cin, H, W, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    if os.environ.get("SSDK_PROBE_ZERO") == "1":  # zero operands: what the schedule gives when the power budget does not bind
+        x.zero_()
+        with torch.no_grad():
+            conv.weight.zero_()
     pack = FC.ConvPack(conv, None, "none", torch.bfloat16)
     pack.w, pack.bias = pack.w.cuda(), pack.bias.cuda()
     if mode == "head":
