@@ -27,6 +27,13 @@ python tools/pmc_to_csv.py $OUT/pmc_write_size.csv $OUT/write/*/*counter_collect
 python tools/pmc_to_csv.py $OUT/pmc_sq.csv $OUT/sq1/*/*counter_collection.csv $OUT/sq2/*/*counter_collection.csv
 rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/sq1 $OUT/sq2
 head -8 $OUT/kernel_stats.csv | cut -c1-150
+# the bench lines below quote the rocprof figures of THIS command: put the summaries where bench.py looks for them
+# (profiles/r06_bench[_<cfg>]_kernel_stats_v<N>.csv, profiles/r06_pmc_fetch_size[_<cfg>]_v<N>.csv; PROF_CFG / PROF_V from the caller)
+V=${PROF_V:-1}
+if [ -n "$PROF_CFG" ]; then SFX="_$PROF_CFG"; else SFX=""; fi
+cp $OUT/kernel_stats.csv profiles/r06_bench${SFX}_kernel_stats_v$V.csv
+cp $OUT/pmc_fetch_size.csv profiles/r06_pmc_fetch_size${SFX}_v$V.csv
+cp profiles/r06_bench${SFX}_kernel_stats_v$V.csv profiles/r06_pmc_fetch_size${SFX}_v$V.csv $OUT/
 [ -n "$PROFILE_ONLY" ] && exit 0
 if [ -z "$ARGS" ]; then CPU=""; else CPU="--cpu-sample 4"; fi
 timeout 600 python bench.py $ARGS $CPU > $OUT/bench.json 2> $OUT/bench.err
