@@ -326,7 +326,8 @@ def test_halo_kernel_residual_and_split_heads():
 
 @pytest.mark.parametrize("cin,cout,k,h,w,n,kernel", [
     (64, 256, 1, 16, 20, 2, "conv_gemm_kernel"),       # FPN lateral + top-down add, tiled kernel
-    (1024, 256, 1, 64, 64, 16, G256),                  # same on the 256x256 kernel (K >= 1024)
+    (1024, 256, 1, 40, 60, 16, G256),                  # same on the 256x256 kernel (K >= 1024; 300 tiles of 256 x 128: the persistent GEMM declines a launch of 1.2 rounds)
+    (1024, 256, 1, 64, 64, 16, "conv_gemmp_kernel"),   # same on the persistent GEMM (round 6)
     (64, 64, 1, 2, 2, 8, "conv_wave_kernel"),          # same on the wave kernel
 ])
 def test_conv_half_resolution_residual(cin, cout, k, h, w, n, kernel):
@@ -352,7 +353,8 @@ def test_conv_half_resolution_residual(cin, cout, k, h, w, n, kernel):
 @pytest.mark.parametrize("cin,cout,k,h,w,n,act,kernel", [
     (64, 64, 3, 14, 14, 2, "relu", "conv_gemm_kernel"),
     (128, 256, 3, 16, 16, 48, "relu", HALO),
-    (1024, 512, 1, 64, 32, 16, "relu", G256),
+    (1024, 512, 1, 40, 32, 16, "relu", G256),
+    (1024, 512, 1, 64, 32, 16, "relu", "conv_gemmp_kernel"),
     (64, 64, 3, 2, 2, 8, "relu6", "conv_wave_kernel"),
 ])
 def test_conv_activation_after_residual(cin, cout, k, h, w, n, act, kernel):
