@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 240 /* 0.2.4: ssdk_abi_check, ssdk_pw_* (1x1 convolutions of the training step: forward / input gradient / weight gradient on NCHW tensors); 0.2.3: ssdk_struct_size; 0.2.2: ssdk_mbconv_desc.image_nw / w_image / w_image_bytes (ssdk_mbk.hip), larger ssdk_match_multibox_loss workspace; 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
+#define SSDK_VERSION 241 /* 0.2.4.1: ssdk_pack_conv3x3; 0.2.4: ssdk_abi_check, ssdk_pw_* (1x1 convolutions of the training step: forward / input gradient / weight gradient on NCHW tensors); 0.2.3: ssdk_struct_size; 0.2.2: ssdk_mbconv_desc.image_nw / w_image / w_image_bytes (ssdk_mbk.hip), larger ssdk_match_multibox_loss workspace; 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
 
 #define SSDK_MAX_LEVELS 8    /* feature-map levels per decode_nms call            */
 #define SSDK_MAX_ANCHORS 16  /* anchors per location (A)                          */
@@ -437,6 +437,14 @@ int ssdk_pw_wgrad(const void* dy, const void* x, float* dw, void* workspace, siz
  *   ssdk_col2im3x3   dcol [B, Kp, Ho * Wo] -> dx [B, C, H, W]  (per input pixel a gather of <= 9 terms, fp32 sum in tap order) */
 int ssdk_im2col3x3(const void* x, void* col, int B, int C, int H, int W, int stride, int dtype, void* stream);
 int ssdk_col2im3x3(const void* dcol, void* dx, int B, int C, int H, int W, int stride, int dtype, void* stream);
+
+/* Weights of a 3x3 layer -- or of the loc | conf PAIR of an SSD level (reference ssd.py:100-103), w2 / b2 / n2 = NULL / NULL / 0
+ * for a single layer -- from the fp32 master tensors [n, Cin, 3, 3] into the layouts ssdk_conv reads, in one launch (the head
+ * convolutions of the TRAINING step run on the inference kernels: weights change every step): krsc = 16-bit [n1 + n2][3][3][Cin];
+ * frag (may be NULL) = the fragment-major image of ssdk_weight_frag_bytes(n1 + n2, 9 * Cin), rows past the last channel zero;
+ * bias = fp32 [n1 + n2] (a NULL b1 / b2 contributes zeros).  Cin % 8 == 0; frag needs (9 * Cin) % 32 == 0. */
+int ssdk_pack_conv3x3(const float* w1, const float* b1, int n1, const float* w2, const float* b2, int n2, int cin, void* krsc, void* frag,
+                      float* bias, int dtype, void* stream);
 
 /* SGD with momentum / weight decay / Nesterov over ALL parameter tensors of a model (version 240; csrc/ssdk_sgd.hip): the
  * optimizer.step() of the reference's loop (pipeline_anchor_apex.py:128-130 on core/optimizer.py:73-134's torch.optim.SGD) with

@@ -964,3 +964,64 @@ extern "C" int ssdk_col2im3x3(const void* dcol, void* dx, int B, int C, int H, i
   else hipLaunchKernelGGL(col2im3x3_kernel<SSDK_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("col2im3x3_kernel");
 }
+
+// ---- weights of a 3x3 layer (or of the loc | conf PAIR of an SSD level) from the fp32 master tensors into the inference kernels'
+//      layouts, one launch per step: KRSC 16-bit rows [n1 + n2][9 * Cin] (k = (ky*3 + kx)*Cin + ci), the fragment-major image
+//      [ceil(rows / 16)][K / 32][4][16][8] of ssdk_weight_frag_bytes (zero rows past the last channel), and the fp32 biases
+//      (ssds/modeling/layers/headconv.py: the head convolutions of the training step run on conv3x3_short / halo / smallmap) ----
+namespace ssdk {
+struct PackParams {
+  const float *w1, *w2, *b1, *b2;
+  unsigned short *krsc, *frag;
+  float* bias;
+  int n1, n2, cin, rows_pad, dt;
+};
+template <int DT>
+__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const PackParams p) {
+  const u32 K = 9u * (u32)p.cin, kch = K / 8u;
+  const u32 rows = (u32)(p.n1 + p.n2);
+  const u32 total = (u32)p.rows_pad * kch;
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const u32 row = i / kch, k0 = (i - row * kch) * 8u;
+    const u32 tap = k0 / (u32)p.cin, ci0 = k0 - tap * (u32)p.cin;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < rows) {
+      const float* src = row < (u32)p.n1 ? p.w1 + ((size_t)row * p.cin + ci0) * 9 + tap
+                                        : p.w2 + ((size_t)(row - (u32)p.n1) * p.cin + ci0) * 9 + tap;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = pack2_16<DT>(src[(2 * e) * 9], src[(2 * e + 1) * 9]);
+      *reinterpret_cast<u32x4*>(p.krsc + (size_t)row * K + k0) = v;
+    }
+    if (p.frag) *reinterpret_cast<u32x4*>(p.frag + ((((size_t)(row >> 4) * (K / 32u) + (k0 >> 5)) * 4u + ((k0 >> 3) & 3u)) * 16u + (row & 15u)) * 8u) = v;
+    if (k0 == 0 && row < rows) p.bias[row] = row < (u32)p.n1 ? (p.b1 ? p.b1[row] : 0.f) : (p.b2 ? p.b2[row - (u32)p.n1] : 0.f);
+  }
+}
+}  // namespace ssdk
+
+extern "C" int ssdk_pack_conv3x3(const float* w1, const float* b1, int n1, const float* w2, const float* b2, int n2, int cin, void* krsc,
+                                 void* frag, float* bias, int dtype, void* stream) {
+  using namespace ssdk;
+  if (!w1 || !krsc || !bias || n1 <= 0 || n2 < 0 || (n2 > 0 && !w2) || cin <= 0 || (cin % 8)) {
+    set_error("ssdk_pack_conv3x3: bad arguments (Cin must be a multiple of 8)");
+    return SSDK_E_BADARG;
+  }
+  if (dtype != SSDK_BF16 && dtype != SSDK_F16) {
+    set_error("ssdk_pack_conv3x3: 16-bit weights only");
+    return SSDK_E_BADARG;
+  }
+  if (frag && ((9 * cin) % 32)) {
+    set_error("ssdk_pack_conv3x3: a fragment-major image needs 9 * Cin to be a multiple of 32");
+    return SSDK_E_BADARG;
+  }
+  PackParams p;
+  p.w1 = w1; p.w2 = w2; p.b1 = b1; p.b2 = b2;
+  p.krsc = (unsigned short*)krsc; p.frag = (unsigned short*)frag; p.bias = bias;
+  p.n1 = n1; p.n2 = n2; p.cin = cin; p.dt = dtype;
+  p.rows_pad = frag ? (n1 + n2 + 15) / 16 * 16 : n1 + n2;
+  const size_t total = (size_t)p.rows_pad * (9 * cin / 8);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == SSDK_BF16) hipLaunchKernelGGL(pack_conv3x3_kernel<SSDK_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(pack_conv3x3_kernel<SSDK_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("pack_conv3x3_kernel");
+}

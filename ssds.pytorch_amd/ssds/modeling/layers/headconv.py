@@ -1,0 +1,127 @@
+"""The 3x3 loc | conf convolutions of an SSD level (reference ssds/modeling/ssds/ssd.py:100-103, called at :67-70) inside the
+TRAINING step: forward on the inference kernels (one split-output GEMM per level: csrc/ssdk_conv3x3s.hip, ssdk_conv3x3.hip,
+ssdk_smallmap.hip -- the kernels the eval plan uses), backward on the framework's convolution backward, per module as before.  Rounds 2-6 left these twelve
+convolutions to MIOpen: ~1 ms of implicit-GEMM forward kernels + layout transposes per step at SSD-MobileNetV2@512, batch 64
+(profiles/r06_train_kernel_split_final_v1.txt).
+
+The weights change every step, so the kernels' layouts (KRSC 16-bit rows, the fragment-major image, fp32 biases) are rebuilt per
+call from the fp32 master tensors by ONE launch (ssdk_pack_conv3x3).  HIP tensors in a 16-bit autocast dtype only; everything else
+goes through the modules' own forward."""
+import os
+
+import torch
+
+from ssds import _native as N
+from ssds.modeling.layers import fused_conv as FC
+
+
+def enabled():
+    return os.environ.get("SSDK_HEAD_PAIR", "1") != "0"
+
+
+def supported(x, loc, conf):
+    """x: the level's feature map as the heads see it; loc / conf: the two nn.Conv2d."""
+    if not (x.is_cuda and x.dim() == 4 and torch.is_autocast_enabled()):
+        return False
+    dt = torch.get_autocast_dtype("cuda")
+    if dt not in (torch.bfloat16, torch.float16):
+        return False
+    for m in (loc, conf):
+        if not (type(m) is torch.nn.Conv2d and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
+                and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros" and m.weight.dtype == torch.float32
+                and m.weight.is_cuda):
+            return False
+    return loc.in_channels == conf.in_channels == int(x.shape[1]) and loc.in_channels % 8 == 0 and (loc.bias is None) == (conf.bias is None)
+
+
+class _Pack(object):
+    """The part of fused_conv.ConvPack that fill_desc / wants_frag read."""
+
+    __slots__ = ("kind", "w", "scale", "bias", "cin", "cout", "k", "stride", "groups", "act", "_img")
+
+    def frag(self):
+        return self._img
+
+
+class _HeadPair3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wl, bl, wc, bc):
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+        if x.dtype != dt:
+            x = x.to(dt)
+        n, cin, h, w = (int(v) for v in x.shape)
+        nl, nc = int(wl.shape[0]), int(wc.shape[0])
+        rows, kel = nl + nc, 9 * cin
+        dev = x.device
+        xcl = x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+        krsc = torch.empty((rows, 3, 3, cin), device=dev, dtype=dt)
+        bias = torch.empty(rows, device=dev, dtype=torch.float32)
+        pk = _Pack()
+        pk.kind, pk.w, pk.scale, pk.bias, pk.cin, pk.cout, pk.k, pk.stride, pk.groups, pk.act = "dense", krsc, None, bias, cin, rows, 3, 1, 1, "none"
+        pk._img = None
+        want_img = FC.USE_WFRAG and kel % 32 == 0 and cin % 32 == 0 and FC.wants_frag(pk, h, w, False)
+        img = torch.empty(int(N.lib.ssdk_weight_frag_bytes(rows, kel)) // 2, device=dev, dtype=dt) if want_img else None
+        pk._img = img
+        y = torch.empty((n, nl, h, w), device=dev, dtype=dt)
+        y2 = torch.empty((n, nc, h, w), device=dev, dtype=dt)
+        with torch.cuda.device(dev):
+            sp = N.stream_ptr(dev)
+            N.check(N.lib.ssdk_pack_conv3x3(wl.data_ptr(), None if bl is None else bl.data_ptr(), nl, wc.data_ptr(),
+                                            None if bc is None else bc.data_ptr(), nc, cin, krsc.data_ptr(),
+                                            None if img is None else img.data_ptr(), bias.data_ptr(), N.dtype_code(x), sp), "pack_conv3x3")
+            d = FC.fill_desc(N.ConvDesc(), xcl.data_ptr(), n, h, w, pk, N.dtype_code(x), "none", y.data_ptr(), N.NHWC, N.NCHW, None,
+                             y2.data_ptr(), nl, "none")
+            need = int(N.lib.ssdk_conv_workspace_bytes(n, cin, h, w, rows, 3, 1, N.dtype_code(x)))
+            if need:
+                ws = FC._splitk_ws(dev, need)
+                wptr = (ws.data_ptr() + 255) & ~255
+                rc = N.lib.ssdk_conv(ctypes_byref(d), wptr, ws.numel() - (wptr - ws.data_ptr()), sp)
+            else:
+                rc = N.lib.ssdk_conv(ctypes_byref(d), None, 0, sp)
+            N.check(rc, "conv (head pair)")
+        ctx.save_for_backward(x, wl, wc)
+        ctx.has_bias = bl is not None
+        return y, y2
+
+    @staticmethod
+    def backward(ctx, gl, gc):
+        x, wl, wc = ctx.saved_tensors
+        dt = x.dtype
+        # two calls, as autograd would make them for the two modules: ONE call on the concatenated 504 channels was measured and
+        # is 2 ms per step slower (the library picks k-tile-8 kernels for it; tools/run/r06_s23.sh)
+        out = []
+        for g, w in ((gl, wl), (gc, wc)):
+            out.append(torch.ops.aten.convolution_backward(g.to(dt), x, w.to(dt), [int(w.shape[0])], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                           [ctx.needs_input_grad[0], True, ctx.has_bias]))
+        (gx1, gwl, gbl), (gx2, gwc, gbc) = out
+        gx = gx1 + gx2 if ctx.needs_input_grad[0] else None
+        if not ctx.has_bias:
+            gbl = gbc = None
+        else:
+            gbl, gbc = gbl.to(wl.dtype), gbc.to(wc.dtype)
+        return gx, gwl.to(wl.dtype), gbl, gwc.to(wc.dtype), gbc
+
+
+def ctypes_byref(d):
+    import ctypes
+
+    return ctypes.byref(d)
+
+
+def head_pair(x, loc, conf):
+    """(loc(x), conf(x)) for the two 3x3 convolutions of one level; differentiable in x and the four parameters."""
+    with torch.autocast("cuda", enabled=False):
+        return _HeadPair3x3.apply(x, loc.weight, loc.bias, conf.weight, conf.bias)
+
+
+def use_head_pairs(model):
+    """Mark every SSD head of ``model`` (modules with ``loc`` / ``conf`` lists of bare 3x3 convolutions, ssd.py) so that its
+    TRAINING forward runs each level's loc | conf pair through ``head_pair``.  SSDK_HEAD_PAIR=0: no effect.  -> heads marked."""
+    n = 0
+    if not enabled():
+        return n
+    for m in model.modules():
+        if type(m).__name__ == "SSD" and hasattr(m, "loc") and hasattr(m, "conf"):
+            m.__dict__["_ssdk_head_pair"] = True
+            n += 1
+    return n

@@ -8,12 +8,14 @@ conf = logits in training mode, sigmoid probabilities in eval mode (reference ss
 MI355X execution: in eval mode on a HIP device the two bare 3x3 head convs of a level
 (reference ssd.py:100-103) run on the MFMA implicit-GEMM kernel with the bias and the sigmoid fused into
 the epilogue (``ssdk_conv_bn_act``); the extras (1x1 + 3x3/s2 Conv-BN-ReLU pairs) run on the same kernel
-with folded BatchNorm.  Training mode is ordinary autograd (MIOpen)."""
+with folded BatchNorm.  Training mode is ordinary autograd; with ``headconv.use_head_pairs`` (ssds/utils/train_ddp.py) the
+forward of the twelve head convolutions runs on the same kernels, one split-output launch per level."""
 import torch.nn as nn
 
 import torch
 
 from ssds.modeling.layers import fused_conv as FC
+from ssds.modeling.layers import headconv as HC
 from ssds.modeling.layers.layers_parser import parse_feature_layer
 from ssds.modeling.layers.planner import PlanUnsupported, build_ssd_plan
 
@@ -108,7 +110,13 @@ class SSD(SSDSBase):
             features.append(v(features[-1]))
         if self._native_ok(x) and all(FC.conv_kind(m) == "dense" for m in list(self.loc) + list(self.conf)):
             return self._heads_native(features)  # backbone without a planner: fused heads only
+        pair = self.training and self.__dict__.get("_ssdk_head_pair", False)
         for f, l, c in zip(features, self.loc, self.conf):
+            if pair and HC.supported(f, l, c):  # training step on a HIP device: loc | conf of the level as one kernel-backed layer
+                y, y2 = HC.head_pair(f, l, c)
+                loc.append(y)
+                conf.append(y2)
+                continue
             loc.append(l(f))
             conf.append(c(f))
         if not self.training:

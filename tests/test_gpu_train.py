@@ -674,6 +674,64 @@ def test_depthwise_conv_applies_the_deferred_batchnorm(n, cin, c, h, w, stride, 
 
 
 @pytest.mark.parametrize("dtype_name,tol", [("bfloat16", 2e-2), ("float16", 4e-3)])
+@pytest.mark.parametrize("n,cin,h,w,kernel", [
+    (64, 96, 32, 32, "conv3x3_short_kernel"),   # level 0 of SSD-MobileNetV2@512 at the bench batch (ssd.py:100-103: 24 | 480 channels)
+    (8, 96, 32, 32, "conv3x3_halo_kernel"),     # the same level at batch 8: 16x16 patches on the halo kernel
+    (32, 320, 16, 16, "conv3x3_halo_kernel"),   # level 1 (>= 96 tiles: the halo kernel)
+    (3, 320, 16, 16, None),                     # the same level at a small batch: whatever ssdk_conv picks
+    (5, 512, 8, 8, "conv_smallmap_kernel"), (6, 256, 4, 4, "conv_smallmap_kernel"), (7, 256, 2, 2, "conv_smallmap_kernel"),
+    (9, 128, 1, 1, "conv_smallmap_kernel"),
+    (2, 40, 19, 19, None)])                     # Cin not a multiple of 32 (no fragment-major image), odd map
+def test_head_pair_conv_matches_the_two_modules(n, cin, h, w, kernel, dtype_name, tol):
+    """headconv.head_pair (round 6): loc | conf of one SSD level in the TRAINING step -- forward on the inference kernels from
+    weights packed per call by ssdk_pack_conv3x3, backward as ONE convolution -- against the two nn.Conv2d modules in fp32 on the
+    same 16-bit operands: outputs and the input gradient per element, all four parameter gradients."""
+    import torch
+    import torch.nn as nn
+    from ssds import _native as N
+    from ssds.modeling.layers import headconv as HC
+
+    dtype = getattr(torch, dtype_name)
+    torch.manual_seed(n + cin + h)
+    loc = nn.Conv2d(cin, 24, 3, padding=1).cuda()
+    conf = nn.Conv2d(cin, 480, 3, padding=1).cuda()
+    with torch.no_grad():
+        for m in (loc, conf):  # (parameters a 16-bit cast does not change: the fp32 reference sees the same operands)
+            m.weight.copy_((m.weight * 3).to(dtype).float())
+            m.bias.normal_(0, 0.5)
+    x = torch.randn(n, cin, h, w, device="cuda").to(dtype)
+    xr = x.detach().float().clone().requires_grad_(True)
+    lr, cr = loc(xr), conf(xr)
+    gl, gc = torch.randn_like(lr).to(dtype), torch.randn_like(cr).to(dtype)
+    (lr * gl.float()).sum().add((cr * gc.float()).sum()).backward()
+    want = [lr.detach(), cr.detach(), xr.grad.clone()] + [p.grad.clone() for m in (loc, conf) for p in (m.weight, m.bias)]
+    for m in (loc, conf):
+        m.zero_grad()
+    xp = x.detach().clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=dtype):
+        assert HC.supported(xp, loc, conf)
+        lp, cp = HC.head_pair(xp, loc, conf)
+    if kernel is not None:
+        assert N.last_kernel() == kernel, N.last_kernel()
+    assert lp.dtype == dtype and cp.dtype == dtype and lp.is_contiguous() and cp.is_contiguous()
+    torch.autograd.backward([lp, cp], [gl, gc])
+    got = [lp.detach(), cp.detach(), xp.grad] + [p.grad for m in (loc, conf) for p in (m.weight, m.bias)]
+    names = ["loc", "conf", "dx", "dweight(loc)", "dbias(loc)", "dweight(conf)", "dbias(conf)"]
+    for a, b, what in zip(got, want, names):
+        assert a.shape == b.shape, what
+        err = float((a.float() - b.float()).abs().max()) / max(float(b.abs().max()), 1e-6)
+        assert err < tol, "%s: rel err %.3g" % (what, err)
+    eps = 2.0 ** -8 if dtype_name == "bfloat16" else 2.0 ** -10
+    for a, b, what in zip(got[:2], want[:2], names[:2]):  # outputs per element: the rounding of one 16-bit store
+        err = (a.float() - b).abs()
+        bar = eps * b.abs() + 4 * eps * float(b.pow(2).mean().sqrt())
+        assert bool((err <= bar).all()), "%s: %d elements outside the rounding bar" % (what, int((err > bar).sum()))
+    with torch.autocast("cuda", dtype=dtype):  # bit-reproducible forward
+        l2, c2 = HC.head_pair(x, loc, conf)
+    assert torch.equal(l2, lp) and torch.equal(c2, cp)
+
+
+@pytest.mark.parametrize("dtype_name,tol", [("bfloat16", 2e-2), ("float16", 4e-3)])
 @pytest.mark.parametrize("n,cin,cout,h,w,stride,bias", [
     (2, 96, 24, 32, 32, 1, True), (2, 96, 480, 32, 32, 1, True),    # the heads of level 0 (ssd.py:100-103)
     (3, 320, 24, 10, 10, 1, True), (1, 256, 504, 19, 19, 1, True),  # rows that are not a multiple of 8 pixels (300 px configuration)
@@ -1092,6 +1150,9 @@ def _device_step(model, anchors, images, targets, cfg, autocast, ssdk=True, ddp=
         assert fuse_bn_into_depthwise(m) == 16  # (every inverted-residual block with an expansion; SSDK_BN_DEFER unset in the suite)
         use_pointwise_gemm(m)
         assert fuse_conv_bn_statistics(m) > 30
+        from ssds.modeling.layers.headconv import use_head_pairs
+
+        assert use_head_pairs(m) == 1  # (the twelve head convolutions: forward on the inference kernels, as ssds/utils/train_ddp.py)
         if conv3:  # (optional in the product too: SSDK_CONV3_NATIVE=1, ssds/utils/train_ddp.py)
             use_native_conv3x3(m)
     else:
