@@ -445,6 +445,11 @@ int ssdk_col2im3x3(const void* dcol, void* dx, int B, int C, int H, int W, int s
  * bias = fp32 [n1 + n2] (a NULL b1 / b2 contributes zeros).  Cin % 8 == 0; frag needs (9 * Cin) % 32 == 0. */
 int ssdk_pack_conv3x3(const float* w1, const float* b1, int n1, const float* w2, const float* b2, int n2, int cin, void* krsc, void* frag,
                       float* bias, int dtype, void* stream);
+/* The same layer (pair) as the weights of its INPUT-GRADIENT convolution (stride 1, pad 1): dx = conv3x3(dy, W'),
+ * W'[ci][ky][kx][o] = W[o][ci][2 - ky][2 - kx], o zero-padded to opad >= n1 + n2 channels (opad % 8 == 0; dy is handed to ssdk_conv
+ * with opad channels).  krsc = 16-bit [Cin][3][3][opad]; frag (may be NULL; opad % 32 == 0) = its fragment-major image. */
+int ssdk_pack_conv3x3_dgrad(const float* w1, int n1, const float* w2, int n2, int cin, int opad, void* krsc, void* frag, int dtype,
+                            void* stream);
 
 /* SGD with momentum / weight decay / Nesterov over ALL parameter tensors of a model (version 240; csrc/ssdk_sgd.hip): the
  * optimizer.step() of the reference's loop (pipeline_anchor_apex.py:128-130 on core/optimizer.py:73-134's torch.optim.SGD) with

@@ -1025,3 +1025,66 @@ extern "C" int ssdk_pack_conv3x3(const float* w1, const float* b1, int n1, const
   else hipLaunchKernelGGL(pack_conv3x3_kernel<SSDK_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("pack_conv3x3_kernel");
 }
+
+// ---- the same pair as the weights of its INPUT-GRADIENT convolution: dx = conv3x3(dy, W') with W'[ci][ky][kx][o] = W[o][ci][2 - ky][2 - kx]
+//      (stride 1, pad 1), o zero-padded to opad channels (dy is handed over with opad channels: 504 -> 512 puts the small levels
+//      on conv_smallmap_kernel); KRSC rows [Cin][9 * opad] + the fragment-major image ----
+namespace ssdk {
+struct PackDgradParams {
+  const float *w1, *w2;
+  unsigned short *krsc, *frag;
+  int n1, n2, cin, opad, rows_pad;
+};
+template <int DT>
+__global__ __launch_bounds__(256) void pack_conv3x3_dgrad_kernel(const PackDgradParams p) {
+  const u32 K = 9u * (u32)p.opad, kch = K / 8u;
+  const u32 total = (u32)p.rows_pad * kch;
+  const u32 n12 = (u32)(p.n1 + p.n2);
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const u32 ci = i / kch, k0 = (i - ci * kch) * 8u;
+    const u32 tap = k0 / (u32)p.opad, o0 = k0 - tap * (u32)p.opad;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (ci < (u32)p.cin) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const u32 o = o0 + (u32)e;
+        f[e] = o < (u32)p.n1 ? p.w1[((size_t)o * p.cin + ci) * 9 + (8u - tap)]
+                             : (o < n12 ? p.w2[((size_t)(o - (u32)p.n1) * p.cin + ci) * 9 + (8u - tap)] : 0.f);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = pack2_16<DT>(f[2 * e], f[2 * e + 1]);
+      *reinterpret_cast<u32x4*>(p.krsc + (size_t)ci * K + k0) = v;
+    }
+    if (p.frag) *reinterpret_cast<u32x4*>(p.frag + ((((size_t)(ci >> 4) * (K / 32u) + (k0 >> 5)) * 4u + ((k0 >> 3) & 3u)) * 16u + (ci & 15u)) * 8u) = v;
+  }
+}
+}  // namespace ssdk
+
+extern "C" int ssdk_pack_conv3x3_dgrad(const float* w1, int n1, const float* w2, int n2, int cin, int opad, void* krsc, void* frag, int dtype,
+                                       void* stream) {
+  using namespace ssdk;
+  if (!w1 || !krsc || n1 <= 0 || n2 < 0 || (n2 > 0 && !w2) || cin <= 0 || opad < n1 + n2 || (opad % 8)) {
+    set_error("ssdk_pack_conv3x3_dgrad: bad arguments (opad >= n1 + n2, a multiple of 8)");
+    return SSDK_E_BADARG;
+  }
+  if (dtype != SSDK_BF16 && dtype != SSDK_F16) {
+    set_error("ssdk_pack_conv3x3_dgrad: 16-bit weights only");
+    return SSDK_E_BADARG;
+  }
+  if (frag && (opad % 32)) {
+    set_error("ssdk_pack_conv3x3_dgrad: a fragment-major image needs opad to be a multiple of 32");
+    return SSDK_E_BADARG;
+  }
+  PackDgradParams p;
+  p.w1 = w1; p.w2 = w2;
+  p.krsc = (unsigned short*)krsc; p.frag = (unsigned short*)frag;
+  p.n1 = n1; p.n2 = n2; p.cin = cin; p.opad = opad;
+  p.rows_pad = frag ? (cin + 15) / 16 * 16 : cin;
+  const size_t total = (size_t)p.rows_pad * (9 * opad / 8);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (dtype == SSDK_BF16) hipLaunchKernelGGL(pack_conv3x3_dgrad_kernel<SSDK_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(pack_conv3x3_dgrad_kernel<SSDK_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("pack_conv3x3_dgrad_kernel");
+}

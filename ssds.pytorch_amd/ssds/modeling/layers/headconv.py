@@ -1,6 +1,8 @@
 """The 3x3 loc | conf convolutions of an SSD level (reference ssds/modeling/ssds/ssd.py:100-103, called at :67-70) inside the
 TRAINING step: forward on the inference kernels (one split-output GEMM per level: csrc/ssdk_conv3x3s.hip, ssdk_conv3x3.hip,
-ssdk_smallmap.hip -- the kernels the eval plan uses), backward on the framework's convolution backward, per module as before.  Rounds 2-6 left these twelve
+ssdk_smallmap.hip -- the kernels the eval plan uses); the INPUT gradient of the pair is one more such convolution (of the
+concatenated output gradient with the transposed, flipped weights); the weight / bias gradients stay on the framework's
+convolution backward, per module as before.  Rounds 2-6 left these twelve
 convolutions to MIOpen: ~1 ms of implicit-GEMM forward kernels + layout transposes per step at SSD-MobileNetV2@512, batch 64
 (profiles/r06_train_kernel_split_final_v1.txt).
 
@@ -87,19 +89,74 @@ class _HeadPair3x3(torch.autograd.Function):
     def backward(ctx, gl, gc):
         x, wl, wc = ctx.saved_tensors
         dt = x.dtype
-        # two calls, as autograd would make them for the two modules: ONE call on the concatenated 504 channels was measured and
-        # is 2 ms per step slower (the library picks k-tile-8 kernels for it; tools/run/r06_s23.sh)
+        want_gx = ctx.needs_input_grad[0]
+        native_gx = want_gx and dgrad_enabled()
+        # weight / bias gradients: two calls, as autograd would make them for the two modules (ONE call on the concatenated 504
+        # channels was measured and is 2 ms per step slower: the library picks k-tile-8 kernels for it; tools/run/r06_s23.sh)
         out = []
         for g, w in ((gl, wl), (gc, wc)):
             out.append(torch.ops.aten.convolution_backward(g.to(dt), x, w.to(dt), [int(w.shape[0])], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                           [ctx.needs_input_grad[0], True, ctx.has_bias]))
+                                                           [want_gx and not native_gx, True, ctx.has_bias]))
         (gx1, gwl, gbl), (gx2, gwc, gbc) = out
-        gx = gx1 + gx2 if ctx.needs_input_grad[0] else None
+        gx = None
+        if native_gx:
+            gx = _input_gradient(gl, gc, wl, wc, x)
+        elif want_gx:
+            gx = gx1 + gx2
         if not ctx.has_bias:
             gbl = gbc = None
         else:
             gbl, gbc = gbl.to(wl.dtype), gbc.to(wc.dtype)
         return gx, gwl.to(wl.dtype), gbl, gwc.to(wc.dtype), gbc
+
+
+def dgrad_enabled():
+    return os.environ.get("SSDK_HEAD_PAIR_DGRAD", "1") != "0"
+
+
+_ZERO_BIAS = {}
+
+
+def _input_gradient(gl, gc, wl, wc, x):
+    """dx of the pair as ONE 3x3 convolution of the concatenated output gradient with the transposed, flipped weights
+    (ssdk_pack_conv3x3_dgrad) on the inference kernels: dy [N, opad, H, W] in channels_last memory (the 504 channels zero-padded to
+    512: conv_smallmap_kernel has instances for 128 / 256 / 512 input channels), dx [N, Cin, H, W] contiguous."""
+    dt = x.dtype
+    n, cin, h, w = (int(v) for v in x.shape)
+    nl, nc = int(wl.shape[0]), int(wc.shape[0])
+    rows = nl + nc
+    opad = next((c for c in (128, 256, 512) if c >= rows), (rows + 31) // 32 * 32)
+    dev = x.device
+    g = torch.empty((n, opad, h, w), device=dev, dtype=dt, memory_format=torch.channels_last)
+    g[:, :nl].copy_(gl)
+    g[:, nl:rows].copy_(gc)
+    if opad > rows:
+        g[:, rows:].zero_()
+    krsc = torch.empty((cin, 3, 3, opad), device=dev, dtype=dt)
+    zb = _ZERO_BIAS.get((dev.index, cin))
+    if zb is None:
+        zb = _ZERO_BIAS[(dev.index, cin)] = torch.zeros(cin, device=dev, dtype=torch.float32)
+    pk = _Pack()
+    pk.kind, pk.w, pk.scale, pk.bias, pk.cin, pk.cout, pk.k, pk.stride, pk.groups, pk.act = "dense", krsc, None, zb, opad, cin, 3, 1, 1, "none"
+    pk._img = None
+    want_img = FC.USE_WFRAG and opad % 32 == 0 and FC.wants_frag(pk, h, w, False)
+    img = torch.empty(int(N.lib.ssdk_weight_frag_bytes(cin, 9 * opad)) // 2, device=dev, dtype=dt) if want_img else None
+    pk._img = img
+    gx = torch.empty((n, cin, h, w), device=dev, dtype=dt)
+    with torch.cuda.device(dev):
+        sp = N.stream_ptr(dev)
+        N.check(N.lib.ssdk_pack_conv3x3_dgrad(wl.data_ptr(), nl, wc.data_ptr(), nc, cin, opad, krsc.data_ptr(),
+                                              None if img is None else img.data_ptr(), N.dtype_code(x), sp), "pack_conv3x3_dgrad")
+        d = FC.fill_desc(N.ConvDesc(), g.data_ptr(), n, h, w, pk, N.dtype_code(x), "none", gx.data_ptr(), N.NHWC, N.NCHW)
+        need = int(N.lib.ssdk_conv_workspace_bytes(n, opad, h, w, cin, 3, 1, N.dtype_code(x)))
+        if need:
+            ws = FC._splitk_ws(dev, need)
+            wptr = (ws.data_ptr() + 255) & ~255
+            rc = N.lib.ssdk_conv(ctypes_byref(d), wptr, ws.numel() - (wptr - ws.data_ptr()), sp)
+        else:
+            rc = N.lib.ssdk_conv(ctypes_byref(d), None, 0, sp)
+        N.check(rc, "conv (head pair, input gradient)")
+    return gx
 
 
 def ctypes_byref(d):
