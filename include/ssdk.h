@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 241 /* 0.2.4.1: ssdk_pack_conv3x3; 0.2.4: ssdk_abi_check, ssdk_pw_* (1x1 convolutions of the training step: forward / input gradient / weight gradient on NCHW tensors); 0.2.3: ssdk_struct_size; 0.2.2: ssdk_mbconv_desc.image_nw / w_image / w_image_bytes (ssdk_mbk.hip), larger ssdk_match_multibox_loss workspace; 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
+#define SSDK_VERSION 242 /* 0.2.4.2: ssdk_concat_nchw_to_nhwc; 0.2.4.1: ssdk_pack_conv3x3[_dgrad]; 0.2.4: ssdk_abi_check, ssdk_pw_* (1x1 convolutions of the training step: forward / input gradient / weight gradient on NCHW tensors); 0.2.3: ssdk_struct_size; 0.2.2: ssdk_mbconv_desc.image_nw / w_image / w_image_bytes (ssdk_mbk.hip), larger ssdk_match_multibox_loss workspace; 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
 
 #define SSDK_MAX_LEVELS 8    /* feature-map levels per decode_nms call            */
 #define SSDK_MAX_ANCHORS 16  /* anchors per location (A)                          */
@@ -450,6 +450,9 @@ int ssdk_pack_conv3x3(const float* w1, const float* b1, int n1, const float* w2,
  * with opad channels).  krsc = 16-bit [Cin][3][3][opad]; frag (may be NULL; opad % 32 == 0) = its fragment-major image. */
 int ssdk_pack_conv3x3_dgrad(const float* w1, int n1, const float* w2, int n2, int cin, int opad, void* krsc, void* frag, int dtype,
                             void* stream);
+/* a [N, c1, HW] | b [N, c2, HW] (16-bit NCHW planes; b / c2 may be NULL / 0) -> out [N, HW, cpad] (NHWC), channels past c1 + c2
+ * zero; cpad even.  The concatenated output gradient of a pair in the layout ssdk_conv reads. */
+int ssdk_concat_nchw_to_nhwc(const void* a, int c1, const void* b, int c2, void* out, int cpad, int N, int HW, int dtype, void* stream);
 
 /* SGD with momentum / weight decay / Nesterov over ALL parameter tensors of a model (version 240; csrc/ssdk_sgd.hip): the
  * optimizer.step() of the reference's loop (pipeline_anchor_apex.py:128-130 on core/optimizer.py:73-134's torch.optim.SGD) with

@@ -1088,3 +1088,72 @@ extern "C" int ssdk_pack_conv3x3_dgrad(const float* w1, int n1, const float* w2,
   else hipLaunchKernelGGL(pack_conv3x3_dgrad_kernel<SSDK_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("pack_conv3x3_dgrad_kernel");
 }
+
+// ---- [N, c1, HW] | [N, c2, HW] (NCHW, 16 bit) -> [N, HW, cpad] (NHWC), channels c1 + c2 .. cpad - 1 zero: the concatenated output
+//      gradient of an SSD level's loc | conf pair in the layout the inference kernels read (headconv._input_gradient; the framework's
+//      strided copy_ into a channels_last buffer ran at 0.3 TB/s: 0.31 ms per step for 180 MB).  64 x 64 tiles through LDS. ----
+namespace ssdk {
+struct CatParams {
+  const unsigned short *a, *b;
+  unsigned short* out;
+  int n, c1, c2, cpad, hw;
+  int ptiles, ctiles;
+};
+__global__ __launch_bounds__(256) void concat_nchw_to_nhwc_kernel(const CatParams p) {
+  __shared__ unsigned short tile[64][66];
+  const int per = p.ptiles * p.ctiles;
+  for (int t = blockIdx.x; t < p.n * per; t += gridDim.x) {
+    const int img = t / per, r = t - img * per, ct = r / p.ptiles, pt = r - ct * p.ptiles;
+    const int c0 = ct * 64, p0 = pt * 64;
+    // read: thread (cl = tid / 4, four 16-pixel pieces per channel row)
+    {
+      const int cl = threadIdx.x >> 2, q = (threadIdx.x & 3) * 16;
+      const int c = c0 + cl;
+      const unsigned short* src = c < p.c1 ? p.a + ((size_t)img * p.c1 + c) * p.hw : (c < p.c1 + p.c2 ? p.b + ((size_t)img * p.c2 + (c - p.c1)) * p.hw : nullptr);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int px = p0 + q + e;
+        tile[cl][q + e] = (src && px < p.hw) ? src[px] : (unsigned short)0;
+      }
+    }
+    __syncthreads();
+    // write: thread (pl = tid / 4, four 16-channel pieces per pixel)
+    {
+      const int pl = threadIdx.x >> 2, q = (threadIdx.x & 3) * 16;
+      const int px = p0 + pl;
+      if (px < p.hw) {
+        unsigned short* dst = p.out + ((size_t)img * p.hw + px) * p.cpad + c0 + q;
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          if (c0 + q + e < p.cpad)  // (cpad is even)
+            *reinterpret_cast<u32*>(dst + e) = (u32)tile[q + e][pl] | ((u32)tile[q + e + 1][pl] << 16);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+}  // namespace ssdk
+
+extern "C" int ssdk_concat_nchw_to_nhwc(const void* a, int c1, const void* b, int c2, void* out, int cpad, int N, int HW, int dtype,
+                                        void* stream) {
+  using namespace ssdk;
+  if (!a || !out || N < 1 || HW < 1 || c1 < 1 || c2 < 0 || (c2 > 0 && !b) || cpad < c1 + c2 || (cpad & 1) ||
+      (dtype != SSDK_BF16 && dtype != SSDK_F16)) {
+    set_error("ssdk_concat_nchw_to_nhwc: bad arguments (16-bit tensors, cpad >= c1 + c2 and even)");
+    return SSDK_E_BADARG;
+  }
+  CatParams p;
+  p.a = (const unsigned short*)a; p.b = (const unsigned short*)b; p.out = (unsigned short*)out;
+  p.n = N; p.c1 = c1; p.c2 = c2; p.cpad = cpad; p.hw = HW;
+  p.ptiles = (HW + 63) / 64;
+  p.ctiles = (cpad + 63) / 64;
+  long tiles = (long)N * p.ptiles * p.ctiles;
+  if (tiles > 2000000000l) {
+    set_error("ssdk_concat_nchw_to_nhwc: tensor too large");
+    return SSDK_E_BADARG;
+  }
+  const unsigned grid = (unsigned)(tiles < 256 * 16 ? tiles : 256 * 16);
+  hipLaunchKernelGGL(concat_nchw_to_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("concat_nchw_to_nhwc_kernel");
+}

@@ -128,10 +128,10 @@ def _input_gradient(gl, gc, wl, wc, x):
     opad = next((c for c in (128, 256, 512) if c >= rows), (rows + 31) // 32 * 32)
     dev = x.device
     g = torch.empty((n, opad, h, w), device=dev, dtype=dt, memory_format=torch.channels_last)
-    g[:, :nl].copy_(gl)
-    g[:, nl:rows].copy_(gc)
-    if opad > rows:
-        g[:, rows:].zero_()
+    gl, gc = gl.to(dt).contiguous(), gc.to(dt).contiguous()
+    with torch.cuda.device(dev):
+        N.check(N.lib.ssdk_concat_nchw_to_nhwc(gl.data_ptr(), nl, gc.data_ptr(), nc, g.data_ptr(), opad, n, h * w, N.dtype_code(x),
+                                               N.stream_ptr(dev)), "concat_nchw_to_nhwc")
     krsc = torch.empty((cin, 3, 3, opad), device=dev, dtype=dt)
     zb = _ZERO_BIAS.get((dev.index, cin))
     if zb is None:
