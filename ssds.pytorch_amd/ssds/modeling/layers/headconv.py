@@ -91,13 +91,25 @@ class _HeadPair3x3(torch.autograd.Function):
         dt = x.dtype
         want_gx = ctx.needs_input_grad[0]
         native_gx = want_gx and dgrad_enabled()
-        # weight / bias gradients: two calls, as autograd would make them for the two modules (ONE call on the concatenated 504
-        # channels was measured and is 2 ms per step slower: the library picks k-tile-8 kernels for it; tools/run/r06_s23.sh)
-        out = []
-        for g, w in ((gl, wl), (gc, wc)):
-            out.append(torch.ops.aten.convolution_backward(g.to(dt), x, w.to(dt), [int(w.shape[0])], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                           [want_gx and not native_gx, True, ctx.has_bias]))
-        (gx1, gwl, gbl), (gx2, gwc, gbc) = out
+        # weight / bias gradients.  Levels of >= 64 pixels: im2col + ssdk_pw_wgrad per module (tools/head_wgrad_probe.py: 198 / 146 /
+        # 160 us against the library's 369 / 208 / 217 on the 32^2 / 16^2 / 8^2 levels; the smaller levels are faster there).  Library:
+        # two calls, as autograd would make them for the two modules (ONE call on the concatenated 504 channels was measured and is
+        # 2 ms per step slower: the library picks k-tile-8 kernels for it; tools/run/r06_s23.sh)
+        n, cin, h, w_ = (int(v) for v in x.shape)
+        native_gw = wgrad_enabled() and h * w_ >= WGRAD_MIN_PIXELS and x.is_contiguous()
+        if native_gw:
+            (gwl, gbl), (gwc, gbc) = _weight_gradients(x, ((gl, wl), (gc, wc)), ctx.has_bias)
+            gx1 = gx2 = None
+            if want_gx and not native_gx:
+                gx1 = sum(torch.ops.aten.convolution_backward(g.to(dt), x, w.to(dt), [int(w.shape[0])], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                              [True, False, False])[0] for g, w in ((gl, wl), (gc, wc)))
+                gx2 = 0
+        else:
+            out = []
+            for g, w in ((gl, wl), (gc, wc)):
+                out.append(torch.ops.aten.convolution_backward(g.to(dt), x, w.to(dt), [int(w.shape[0])], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                               [want_gx and not native_gx, True, ctx.has_bias]))
+            (gx1, gwl, gbl), (gx2, gwc, gbc) = out
         gx = None
         if native_gx:
             gx = _input_gradient(gl, gc, wl, wc, x)
@@ -108,6 +120,40 @@ class _HeadPair3x3(torch.autograd.Function):
         else:
             gbl, gbc = gbl.to(wl.dtype), gbc.to(wc.dtype)
         return gx, gwl.to(wl.dtype), gbl, gwc.to(wc.dtype), gbc
+
+
+WGRAD_MIN_PIXELS = 64
+
+
+def wgrad_enabled():
+    return os.environ.get("SSDK_HEAD_PAIR_WGRAD", "1") != "0"
+
+
+def _weight_gradients(x, pairs, has_bias):
+    """[(dweight, dbias)] of 3x3 / stride 1 / pad 1 convolutions that share the input x [N, Cin, H, W] (contiguous, 16 bit): ONE
+    im2col of x, then ssdk_pw_wgrad per (dy, weight) pair -- dW = dy col^T contracts over pixels (csrc/ssdk_pwtrain.hip)."""
+    from ssds.modeling.layers import pointwise as PW
+
+    n, cin, h, w = (int(v) for v in x.shape)
+    dev, dt, hw = x.device, x.dtype, h * w
+    out = []
+    with torch.cuda.device(dev):
+        sp = N.stream_ptr(dev)
+        col = PW._im2col(x.detach(), 1)
+        kp = int(col.shape[1])
+        for g, wt in pairs:
+            g = g.to(dt).contiguous()
+            cout = int(wt.shape[0])
+            need = int(N.lib.ssdk_pw_wgrad_workspace_bytes(n, cout, kp, hw))
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            gw32 = torch.empty((cout, kp), device=dev, dtype=torch.float32)
+            N.check(N.lib.ssdk_pw_wgrad(g.data_ptr(), col.data_ptr(), gw32.data_ptr(), ws.data_ptr(), need, n, cout, kp, hw, N.dtype_code(x), sp),
+                    "pw_wgrad (head pair)")
+            gw = gw32[:, : cin * 9].reshape(cout, cin, 3, 3)
+            gb = g.sum((0, 2, 3), dtype=torch.float32) if has_bias else None
+            out.append((gw, gb))
+    PW.release_col_cache()
+    return out
 
 
 def dgrad_enabled():
