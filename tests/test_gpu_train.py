@@ -673,6 +673,68 @@ def test_depthwise_conv_applies_the_deferred_batchnorm(n, cin, c, h, w, stride, 
         assert torch.equal(net(x), plain(x))
 
 
+@pytest.mark.parametrize("dtype_name", ["bfloat16", "float16"])
+@pytest.mark.parametrize("n1,n2,cin", [(24, 480, 96), (24, 480, 40), (16, 0, 64), (5, 11, 8)])
+def test_head_weight_pack_kernels_against_the_layout_they_document(n1, n2, cin, dtype_name):
+    """ssdk_pack_conv3x3 / ssdk_pack_conv3x3_dgrad / ssdk_concat_nchw_to_nhwc (round 6; include/ssdk.h) against torch expressions of
+    the documented layouts, bit for bit: KRSC rows of the pair, its fragment-major image ([rows/16][K/32][4][16][8], zero rows past
+    the last channel), the fp32 biases; the transposed + flipped rows of the input-gradient convolution with the output channels
+    padded; the pair's output gradients as one channels-last tensor with zero padding channels."""
+    import torch
+    from ssds import _native as N
+
+    dtype = getattr(torch, dtype_name)
+    code = 1 if dtype_name == "bfloat16" else 2
+    torch.manual_seed(n1 + n2 + cin)
+    dev = torch.device("cuda", 0)
+    w1 = torch.randn(n1, cin, 3, 3, device=dev)
+    w2 = torch.randn(n2, cin, 3, 3, device=dev) if n2 else None
+    b1 = torch.randn(n1, device=dev)
+    b2 = torch.randn(n2, device=dev) if n2 else None
+    rows, kel = n1 + n2, 9 * cin
+    sp = N.stream_ptr(dev)
+    wcat = torch.cat([w1, w2], 0) if n2 else w1
+    # forward layouts
+    krsc = torch.empty((rows, 3, 3, cin), device=dev, dtype=dtype)
+    bias = torch.empty(rows, device=dev)
+    has_img = kel % 32 == 0
+    img = torch.full((int(N.lib.ssdk_weight_frag_bytes(rows, kel)) // 2,), 7.0, device=dev, dtype=dtype) if has_img else None
+    N.check(N.lib.ssdk_pack_conv3x3(w1.data_ptr(), b1.data_ptr(), n1, w2.data_ptr() if n2 else None, b2.data_ptr() if n2 else None, n2, cin,
+                                    krsc.data_ptr(), img.data_ptr() if has_img else None, bias.data_ptr(), code, sp), "pack")
+    want = wcat.permute(0, 2, 3, 1).contiguous().to(dtype)
+    assert torch.equal(krsc, want) and torch.equal(bias, torch.cat([b1, b2]) if n2 else b1)
+    if has_img:
+        g = (rows + 15) // 16
+        w2d = torch.cat([want.reshape(rows, kel), want.new_zeros((g * 16 - rows, kel))], 0)
+        assert torch.equal(img, w2d.view(g, 16, kel // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(-1))
+    # input-gradient layouts: W'[ci][ky][kx][o] = W[o][ci][2 - ky][2 - kx], o padded
+    opad = (rows + 31) // 32 * 32
+    kd = torch.empty((cin, 3, 3, opad), device=dev, dtype=dtype)
+    imgd = torch.full((int(N.lib.ssdk_weight_frag_bytes(cin, 9 * opad)) // 2,), 7.0, device=dev, dtype=dtype)
+    N.check(N.lib.ssdk_pack_conv3x3_dgrad(w1.data_ptr(), n1, w2.data_ptr() if n2 else None, n2, cin, opad, kd.data_ptr(), imgd.data_ptr(), code,
+                                          sp), "pack dgrad")
+    wd = torch.zeros((cin, 3, 3, opad), device=dev)
+    wd[..., :rows] = wcat.flip(2, 3).permute(1, 2, 3, 0)
+    wd = wd.to(dtype)
+    assert torch.equal(kd, wd)
+    g = (cin + 15) // 16
+    w2d = torch.cat([wd.reshape(cin, 9 * opad), wd.new_zeros((g * 16 - cin, 9 * opad))], 0)
+    assert torch.equal(imgd, w2d.view(g, 16, 9 * opad // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(-1))
+    # the pair's output gradients as one channels-last tensor
+    for nb, h, w in ((3, 5, 7), (2, 16, 16), (1, 1, 1), (4, 9, 8)):
+        ga = torch.randn(nb, n1, h, w, device=dev).to(dtype)
+        gb = torch.randn(nb, n2, h, w, device=dev).to(dtype) if n2 else None
+        cpad = (rows + 7) // 8 * 8 + 8
+        out = torch.full((nb, cpad, h, w), 3.0, device=dev, dtype=dtype).contiguous(memory_format=torch.channels_last)
+        N.check(N.lib.ssdk_concat_nchw_to_nhwc(ga.data_ptr(), n1, gb.data_ptr() if n2 else None, n2, out.data_ptr(), cpad, nb, h * w, code, sp),
+                "concat")
+        wantg = torch.zeros((nb, cpad, h, w), device=dev, dtype=dtype)
+        wantg[:, :n1] = ga
+        if n2:
+            wantg[:, n1:rows] = gb
+        assert out.is_contiguous(memory_format=torch.channels_last) and torch.equal(out, wantg)
+
+
 @pytest.mark.parametrize("dtype_name,tol", [("bfloat16", 2e-2), ("float16", 4e-3)])
 @pytest.mark.parametrize("n,cin,h,w,kernel", [
     (64, 96, 32, 32, "conv3x3_short_kernel"),   # level 0 of SSD-MobileNetV2@512 at the bench batch (ssd.py:100-103: 24 | 480 channels)
