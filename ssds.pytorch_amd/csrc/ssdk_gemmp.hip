@@ -356,7 +356,9 @@ int launch_conv_gemmp(const ConvParams& p, int dtype, hipStream_t stream) {
   if (!env || p.k != 1 || p.pad != 0 || (p.stride != 1 && p.stride != 2)) return 1;
   if (p.in_layout != LAYOUT_NHWC || p.out_layout != LAYOUT_NHWC || p.split != p.Cout || p.ksplits != 1) return 1;
   // long K, channels for at least one full tile column, pixels for at least half the chip (fewer: the split-K kernels)
-  static const int min_cin = getenv("SSDK_GEMMP_MIN_CIN") ? atoi(getenv("SSDK_GEMMP_MIN_CIN")) : 256;
+  // (measured with Cin >= 128 and >= 64 admitted, tools/run/r06_s21.sh: 128 -> 512 @80x80 146 us against pwflow's 140, 64 -> 256 @160x160
+  //  235 against 180 -- one or two k-steps per tile leave the tile boundary alone: the short-K layers stay on pwflow_kernel)
+  constexpr int min_cin = 256;
   if ((p.Cin % 8) || p.Cin < min_cin || (p.Cout % 4) || p.Cout < 128) return 1;
   if ((p.res_mode & 1) && ((p.Ho | p.Wo) & 1)) return 1;
   if (((uintptr_t)p.x | (uintptr_t)p.w | (uintptr_t)p.y | (uintptr_t)p.res) & 15) return 1;
@@ -391,11 +393,9 @@ int launch_conv_gemmp(const ConvParams& p, int dtype, hipStream_t stream) {
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   }
-  // tiles per workgroup at most (SSDK_GEMMP_TILES; large: one workgroup per CU walks tiles / CUs tiles)
-  static const int per = getenv("SSDK_GEMMP_TILES") ? atoi(getenv("SSDK_GEMMP_TILES")) : 9999;
-  long want = (tiles + per - 1) / (per < 1 ? 1 : per);
-  if (want < cus) want = tiles < cus ? tiles : cus;
-  const unsigned grid = (unsigned)(want > tiles ? tiles : want);
+  // one workgroup per CU walks tiles / CUs tiles (measured against at most 4 / 2 / 1 tiles per workgroup under the level lanes of the
+  // FPN / BiFPN plans, tools/run/r06_s30.sh: 3 417 - 3 430 vs 3 374 / 3 372 - 3 385 / 3 387 and 2 400 - 2 405 vs 2 403 / 2 351 - 2 371 / 2 393 img/s)
+  const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
   gp.tq = (unsigned)(tiles / grid);
   gp.tr = (unsigned)(tiles % grid);
   static bool attr_done = false;
