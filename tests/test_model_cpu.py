@@ -440,6 +440,66 @@ def test_xpair_ops_are_only_recorded_on_maps_the_c_entry_accepts(px):
         assert all(L["h"] != 7 for L in xp)
 
 
+def test_training_switches_of_round_6_pair_what_they_should_and_change_nothing_on_cpu():
+    """fuse_bn_into_depthwise / use_head_pairs (round 6; ssds/utils/train_ddp.py calls both) only MARK modules: the sixteen expand
+    BatchNorms of SSD-MobileNetV2 get a (non-registered) reference to the depthwise convolution behind them, the SSD head gets its
+    pair flag; no parameter, buffer or state_dict key appears, and on CPU tensors -- where no kernel exists -- training and eval
+    forwards are the unmarked model's, bit for bit (headconv.supported refuses CPU tensors, a deferred BatchNorm needs a HIP
+    tensor)."""
+    import copy
+    import os
+    import torch
+    import torch.nn as nn
+    from ssds.core import config
+    from ssds.modeling import model_builder
+    from ssds.modeling.layers import headconv as HC
+    from ssds.modeling.layers.batchnorm import FastBatchNorm2d, fuse_bn_activations, fuse_bn_into_depthwise, use_fast_batchnorm
+    from ssds.modeling.layers.dwconv import DepthwiseConv2d
+
+    cfg = config.cfg_from_file(os.path.join(os.path.dirname(__file__), "..", "experiments", "cfgs", "ssd_mobilenetv2_512.yml"))
+    torch.manual_seed(0)
+    model = model_builder.create_model(cfg.MODEL)
+    use_fast_batchnorm(model)
+    fuse_bn_activations(model)
+    plain = copy.deepcopy(model)
+    keys = list(model.state_dict().keys())
+    n_modules = len(list(model.modules()))
+    os.environ.pop("SSDK_BN_DEFER", None)
+    os.environ.pop("SSDK_HEAD_PAIR", None)
+    assert fuse_bn_into_depthwise(model) == 16  # every inverted-residual block with an expansion (the first block has none)
+    assert HC.use_head_pairs(model) == 1 and model.__dict__.get("_ssdk_head_pair") is True
+    assert list(model.state_dict().keys()) == keys and len(list(model.modules())) == n_modules
+    linked = [m for m in model.modules() if type(m) is FastBatchNorm2d and "_ssdk_defer_to" in m.__dict__]
+    assert len(linked) == 16 and all(type(m.__dict__["_ssdk_defer_to"]) is DepthwiseConv2d and m._ssdk_act == 1 for m in linked)
+    for bn in linked:  # the BatchNorm's channel count is the depthwise convolution's: the pair really is (expand BN -> depthwise)
+        assert bn.num_features == bn.__dict__["_ssdk_defer_to"].in_channels
+    os.environ["SSDK_BN_DEFER"] = "0"
+    os.environ["SSDK_HEAD_PAIR"] = "0"
+    try:
+        other = copy.deepcopy(plain)
+        assert fuse_bn_into_depthwise(other) == 0 and HC.use_head_pairs(other) == 0
+    finally:
+        del os.environ["SSDK_BN_DEFER"], os.environ["SSDK_HEAD_PAIR"]
+    x = torch.randn(2, 3, 128, 128)
+    for m in (model, plain):
+        m.train()
+    torch.manual_seed(1)
+    a = model(x)
+    torch.manual_seed(1)
+    b = plain(x)
+    assert all(torch.equal(u, v) for u, v in zip(a[0] + a[1], b[0] + b[1]))
+    for m in (model, plain):
+        m.eval()
+    with torch.no_grad():
+        a, b = model(x), plain(x)
+    assert all(torch.equal(u, v) for u, v in zip(a[0] + a[1], b[0] + b[1]))
+    # the head pair's admission test
+    loc, conf = model.loc[0], model.conf[0]
+    f = torch.randn(2, loc.in_channels, 8, 8)
+    assert not HC.supported(f, loc, conf)  # CPU tensor
+    assert not HC.supported(f, nn.Conv2d(loc.in_channels, 24, 1), conf)
+
+
 def test_a_model_that_went_through_the_training_solver_still_records_its_eval_plan():
     """fuse_bn_activations swaps activation classes to FusedAway* subclasses; the eval planner has to recognise them (it
     used to match activations by exact type and silently fell back to torch for the whole network)."""
