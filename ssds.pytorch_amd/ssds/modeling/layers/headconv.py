@@ -126,7 +126,7 @@ WGRAD_MIN_PIXELS = 64
 
 
 def wgrad_enabled():
-    return os.environ.get("SSDK_HEAD_PAIR_WGRAD", "1") != "0"
+    return True  # (round 6: the SSDK_HEAD_PAIR_WGRAD switch is gone, its A/B is settled -- tools/run/r06_s29.sh: 17.7 vs 17.9 ms per step)
 
 
 def _weight_gradients(x, pairs, has_bias):
@@ -157,7 +157,7 @@ def _weight_gradients(x, pairs, has_bias):
 
 
 def dgrad_enabled():
-    return os.environ.get("SSDK_HEAD_PAIR_DGRAD", "1") != "0"
+    return True  # (round 6: the SSDK_HEAD_PAIR_DGRAD switch is gone, its A/B is settled -- tools/run/r06_s25.sh: 17.8 vs 18.4 ms per step)
 
 
 _ZERO_BIAS = {}
