@@ -16,6 +16,8 @@
 // hardtanh_backward launches and one read + one write of every activation tensor in each direction.
 // A workgroup of a reduction pass owns (channel c, slice s): the planes n = s, s + SPLIT, ... of that channel, read
 // with 16-byte vectors; partials are combined by one thread per channel in index order (bit-reproducible).
+#include <atomic>
+
 #include "ssdk_conv_common.h"
 
 namespace ssdk {
@@ -40,6 +42,8 @@ struct BnParams {
   int N, C, HW, split, dtype;
   float momentum, eps;
   int act;                 // 0 none | 1 ReLU6 | 2 ReLU fused behind the normalisation
+  u32* tickets;            // [C] arrival counters of the reduction's workgroups (zero between launches): the LAST workgroup of a
+                           // channel does the finalize arithmetic itself and there is no finalize launch; nullptr: the launch
 };
 
 // the activation's pass-through mask on the pre-activation value as the forward pass stored it (rounded to DT)
@@ -86,6 +90,8 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float (*red)[2]) 
   a = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
   b = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
 }
+
+template <int DT, int MODE> __device__ __forceinline__ void bn_fold_finalize(const BnParams& p, int c, int s, float a, float b);  // (below the finalize kernels)
 
 // MODE 0: sums of (x - pivot), (x - pivot)^2.  MODE 1: sums of dy, dy * (x - mean) * invstd.
 template <int DT, int MODE>
@@ -139,27 +145,17 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const BnParams p) {
     }
   }
   block_sum2(a, b, red);
-  if (threadIdx.x == 0) {
+  if (p.tickets) {  // (workgroup-uniform)
+    bn_fold_finalize<DT, MODE>(p, c, s, a, b);
+  } else if (threadIdx.x == 0) {
     p.partial[((size_t)c * p.split + s) * 2 + 0] = a;
     p.partial[((size_t)c * p.split + s) * 2 + 1] = b;
   }
 }
 
-// forward statistics -> mean, invstd, running stats, apply coefficients (a, b)
+// forward statistics -> mean, invstd, running stats, apply coefficients (a, b) of channel c from its sums (s1, s2)
 template <int DT>
-__global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const BnParams p) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= p.C) return;
-  float s1 = 0.f, s2 = 0.f;
-  if (p.sums) {  // raw sums from the producing convolution: pivot 0
-    s1 = p.sums[2 * c + 0];
-    s2 = p.sums[2 * c + 1];
-  } else {
-    for (int s = 0; s < p.split; ++s) {
-      s1 += p.partial[((size_t)c * p.split + s) * 2 + 0];
-      s2 += p.partial[((size_t)c * p.split + s) * 2 + 1];
-    }
-  }
+__device__ __forceinline__ void bn_fwd_finish(const BnParams& p, int c, float s1, float s2) {
   const float M = (float)p.N * (float)p.HW;
   const float pivot = p.sums ? 0.f : bn_ld1<DT>(p.x, (size_t)c * p.HW);
   const float m1 = s1 / M;
@@ -180,16 +176,25 @@ __global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const BnParams p) {
   p.coef[c * 4 + 1] = bt - mean * a;
   p.coef[c * 4 + 2] = 0.f;
 }
-
-// backward sums -> dgamma, dbeta, coefficients of dx = a*dy + k1*x + k0
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const BnParams p) {
+template <int DT>
+__global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const BnParams p) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= p.C) return;
-  float sg = 0.f, sgx = 0.f;
-  for (int s = 0; s < p.split; ++s) {
-    sg += p.partial[((size_t)c * p.split + s) * 2 + 0];
-    sgx += p.partial[((size_t)c * p.split + s) * 2 + 1];
+  float s1 = 0.f, s2 = 0.f;
+  if (p.sums) {  // raw sums from the producing convolution: pivot 0
+    s1 = p.sums[2 * c + 0];
+    s2 = p.sums[2 * c + 1];
+  } else {
+    for (int s = 0; s < p.split; ++s) {
+      s1 += p.partial[((size_t)c * p.split + s) * 2 + 0];
+      s2 += p.partial[((size_t)c * p.split + s) * 2 + 1];
+    }
   }
+  bn_fwd_finish<DT>(p, c, s1, s2);
+}
+
+// backward sums -> dgamma, dbeta, coefficients of dx = a*dy + k1*x + k0
+__device__ __forceinline__ void bn_bwd_finish(const BnParams& p, int c, float sg, float sgx) {
   if (p.dweight) p.dweight[c] = sgx;
   if (p.dbias) p.dbias[c] = sg;
   const float M = (float)p.N * (float)p.HW;
@@ -201,6 +206,55 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const BnParams p) {
   p.coef[c * 4 + 1] = -a * sg / M - k1 * mean;  // k0
   p.coef[c * 4 + 2] = k1;
   p.coef[c * 4 + 3] = (p.bias ? p.bias[c] : 0.f) - mean * a;  // forward offset (activation mask of the apply pass)
+}
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const BnParams p) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= p.C) return;
+  float sg = 0.f, sgx = 0.f;
+  for (int s = 0; s < p.split; ++s) {
+    sg += p.partial[((size_t)c * p.split + s) * 2 + 0];
+    sgx += p.partial[((size_t)c * p.split + s) * 2 + 1];
+  }
+  bn_bwd_finish(p, c, sg, sgx);
+}
+
+// The finalize arithmetic WITHOUT its launch (round 6: 90 finalize launches of ~5 us per training step).  Every workgroup of
+// a reduction publishes its partial sums (a, b) and draws a ticket of its channel; the one that draws the last ticket reads
+// the channel's partials back, adds them in INDEX order -- the order of the finalize kernels, so the statistics keep their
+// bits -- and does what the finalize kernel's thread of that channel does.  It leaves the ticket at zero for the next launch.
+// The partials travel between CUs of different XCDs (one L2 each) as agent-scope relaxed atomics: the store goes through to
+// memory, the load does not take a line from the reader's L2.  (NOT fences: an agent-scope release is a write-back of the
+// whole L2, full of the neighbouring passes' dirty lines -- measured, 17.6 -> 22-29 ms per step.)  split <= 64 (bn_split).
+template <int DT, int MODE>
+__device__ __forceinline__ void bn_fold_finalize(const BnParams& p, int c, int s, float a, float b) {
+  __shared__ u32 s_last;
+  __shared__ float s_part[64][2];
+  const u32 tid = threadIdx.x;
+  if (tid == 0) {
+    float* q = p.partial + ((size_t)c * p.split + s) * 2;
+    __hip_atomic_store(q + 0, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // both stores have been acknowledged before the ticket is drawn
+    s_last = __hip_atomic_fetch_add(p.tickets + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (u32)p.split - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last == 0u) return;
+  if (tid < (u32)p.split) {
+    const float* q = p.partial + ((size_t)c * p.split + tid) * 2;
+    s_part[tid][0] = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_part[tid][1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_store(p.tickets + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < p.split; ++j) {
+      s1 += s_part[j][0];
+      s2 += s_part[j][1];
+    }
+    if constexpr (MODE == 0) bn_fwd_finish<DT>(p, c, s1, s2);
+    else bn_bwd_finish(p, c, s1, s2);
+  }
 }
 
 // MODE 0: out = x*a + b.  MODE 1: out = dy*a + x*k1 + k0.   grid (chunks of a plane, N*C planes)
@@ -359,7 +413,9 @@ __global__ __launch_bounds__(256) void bn_reduce_flat_kernel(const BnParams p) {
     }
   }
   block_sum2(a, b, red);
-  if (threadIdx.x == 0) {
+  if (p.tickets) {  // (workgroup-uniform)
+    bn_fold_finalize<DT, MODE>(p, c, s, a, b);
+  } else if (threadIdx.x == 0) {
     p.partial[((size_t)c * p.split + s) * 2 + 0] = a;
     p.partial[((size_t)c * p.split + s) * 2 + 1] = b;
   }
@@ -453,8 +509,31 @@ static int bn_split(int N, int C) {
   return s < 1 ? 1 : s;
 }
 
+// Ticket words of the folded finalize: kBnTicketRegions regions of kBnTicketC channels in device memory, zero when the module
+// is loaded and left at zero by every launch that uses them.  Consecutive launches take consecutive regions, so BatchNorms
+// that run concurrently on two streams do not share counters unless more than kBnTicketRegions of them are in flight.
+constexpr int kBnTicketC = 2048, kBnTicketRegions = 16;
+__device__ u32 g_bn_tickets[kBnTicketRegions * kBnTicketC];
+
+static u32* bn_tickets(int C) {
+  if (C > kBnTicketC) return nullptr;  // (A/B on the 512 px training step, tools/run/r06_s34.sh: 17.43 / 17.44 ms folded, 17.56 / 17.62 ms with the launch)
+  static u32* base[16] = {};  // per device (the symbol has one address per device)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!base[dev]) {
+    void* a = nullptr;
+    if (hipGetSymbolAddress(&a, HIP_SYMBOL(g_bn_tickets)) != hipSuccess || !a) return nullptr;
+    base[dev] = (u32*)a;
+  }
+  static std::atomic<unsigned> turn{0};
+  return base[dev] + (size_t)(turn.fetch_add(1u) % (unsigned)kBnTicketRegions) * kBnTicketC;
+}
+
 template <int MODE>
-static void bn_launch(const BnParams& p, hipStream_t st) {
+static void bn_launch(const BnParams& p0, hipStream_t st) {
+  BnParams p = p0;
+  const bool has_reduce = !(MODE == 0 && p.sums);
+  p.tickets = has_reduce ? bn_tickets(p.C) : nullptr;  // the reduction finalizes (no finalize launch)
   // 0: the per-plane kernels, 1: the flat kernels, 2 (default): the flat reduction always, the flat apply pass only where
   // the per-plane one cannot use vectors (plane size not a multiple of the vector width, or a misaligned tensor: there it
   // works element by element).  Per launch on the 512 px step, bf16 (profiles/r02_train_kernel_split_v2.txt against a trace
@@ -480,7 +559,8 @@ static void bn_launch(const BnParams& p, hipStream_t st) {
     if (MODE == 0 && p.sums) {                                                                              \
     } else if (flat_r) hipLaunchKernelGGL((bn_reduce_flat_kernel<DT, MODE>), rgrid, dim3(256), 0, st, p);   \
     else hipLaunchKernelGGL((bn_reduce_kernel<DT, MODE>), rgrid, dim3(256), 0, st, p);                      \
-    if (MODE == 0) hipLaunchKernelGGL((bn_fwd_finalize_kernel<DT>), dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p); \
+    if (p.tickets) {                                                                                        \
+    } else if (MODE == 0) hipLaunchKernelGGL((bn_fwd_finalize_kernel<DT>), dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p); \
     else hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((p.C + 63) / 64)), dim3(64), 0, st, p);  \
     if (MODE == 0 && p.no_apply) {                                                                           \
     } else if (flat && fgrid < (1l << 31)) hipLaunchKernelGGL((bn_apply_flat_kernel<DT, MODE>), dim3((unsigned)fgrid), dim3(256), 0, st, p, f); \
