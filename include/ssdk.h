@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 242 /* 0.2.4.2: ssdk_concat_nchw_to_nhwc; 0.2.4.1: ssdk_pack_conv3x3[_dgrad]; 0.2.4: ssdk_abi_check, ssdk_pw_* (1x1 convolutions of the training step: forward / input gradient / weight gradient on NCHW tensors); 0.2.3: ssdk_struct_size; 0.2.2: ssdk_mbconv_desc.image_nw / w_image / w_image_bytes (ssdk_mbk.hip), larger ssdk_match_multibox_loss workspace; 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
+#define SSDK_VERSION 243 /* 0.2.4.3: ssdk_stem3x3s2_fwd / _wgrad (the first convolution of the training step); 0.2.4.2: ssdk_concat_nchw_to_nhwc; 0.2.4.1: ssdk_pack_conv3x3[_dgrad]; 0.2.4: ssdk_abi_check, ssdk_pw_* (1x1 convolutions of the training step: forward / input gradient / weight gradient on NCHW tensors); 0.2.3: ssdk_struct_size; 0.2.2: ssdk_mbconv_desc.image_nw / w_image / w_image_bytes (ssdk_mbk.hip), larger ssdk_match_multibox_loss workspace; 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
 
 #define SSDK_MAX_LEVELS 8    /* feature-map levels per decode_nms call            */
 #define SSDK_MAX_ANCHORS 16  /* anchors per location (A)                          */
@@ -437,6 +437,19 @@ int ssdk_pw_wgrad(const void* dy, const void* x, float* dw, void* workspace, siz
  *   ssdk_col2im3x3   dcol [B, Kp, Ho * Wo] -> dx [B, C, H, W]  (per input pixel a gather of <= 9 terms, fp32 sum in tap order) */
 int ssdk_im2col3x3(const void* x, void* col, int B, int C, int H, int W, int stride, int dtype, void* stream);
 int ssdk_col2im3x3(const void* dcol, void* dx, int B, int C, int H, int W, int stride, int dtype, void* stream);
+
+/* The network's FIRST convolution inside the training step (3x3 / stride 2 / pad 1, Cin <= 3 image channels, Cout <= 32, bias-free:
+ * torchvision MobileNetV2 features[0][0] behind /root/reference/ssds/modeling/nets/mobilenet.py:180-192; the reference trains it
+ * through cuDNN, pipeline_anchor_apex.py:37-72) on its own kernels (csrc/ssdk_stemtrain.hip) -- an image has no input gradient:
+ *   ssdk_stem3x3s2_fwd     x [N, Cin, H, W] 16 bit, w [Cout, Cin, 3, 3] fp32 master weights (rounded to the tensor dtype inside,
+ *                          like autocast's cast) -> y [N, Cout, Ho, Wo] 16 bit, fp32 accumulation in tap order; Ho = (H - 1) / 2 + 1
+ *   ssdk_stem3x3s2_wgrad   x, dy [N, Cout, Ho, Wo] 16 bit -> dw [Cout, Cin, 3, 3] fp32 (matrix cores over pixels, workgroup partials
+ *                          added in index order: bit-reproducible)
+ * workspace of the weight gradient: ssdk_stem3x3s2_wgrad_workspace_bytes(N, H) bytes, 16-byte aligned. */
+size_t ssdk_stem3x3s2_wgrad_workspace_bytes(int N, int H);
+int ssdk_stem3x3s2_fwd(const void* x, const float* w, void* y, int N, int Cin, int H, int W, int Cout, int dtype, void* stream);
+int ssdk_stem3x3s2_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int Cin, int H, int W,
+                         int Cout, int dtype, void* stream);
 
 /* Weights of a 3x3 layer -- or of the loc | conf PAIR of an SSD level (reference ssd.py:100-103), w2 / b2 / n2 = NULL / NULL / 0
  * for a single layer -- from the fp32 master tensors [n, Cin, 3, 3] into the layouts ssdk_conv reads, in one launch (the head

@@ -122,7 +122,7 @@ class _HeadPair3x3(torch.autograd.Function):
         return gx, gwl.to(wl.dtype), gbl, gwc.to(wc.dtype), gbc
 
 
-WGRAD_MIN_PIXELS = 64
+WGRAD_MIN_PIXELS = int(os.environ.get("SSDK_HEAD_WGRAD_MIN", "64"))  # (A/B)
 
 
 def wgrad_enabled():

@@ -332,10 +332,90 @@ class NativeConv3x3(nn.Conv2d):
             return _Conv3x3Native.apply(x, w, bias, self.stride[0])
 
 
-def use_native_conv3x3(model):
-    """Switch every dense 3x3 / pad 1 / stride 1 | 2 ``nn.Conv2d`` of ``model`` to the kernel-backed subclass (in place)."""
+def use_native_conv3x3(model, min_in_channels=0):
+    """Switch every dense 3x3 / pad 1 / stride 1 | 2 ``nn.Conv2d`` of ``model`` with at least ``min_in_channels`` input channels
+    to the kernel-backed subclass (in place)."""
     for m in model.modules():
         if (type(m) is nn.Conv2d and m.kernel_size == (3, 3) and m.padding == (1, 1) and m.stride in ((1, 1), (2, 2))
-                and m.groups == 1 and m.dilation == (1, 1) and m.padding_mode == "zeros"):
+                and m.groups == 1 and m.dilation == (1, 1) and m.padding_mode == "zeros" and m.in_channels >= min_in_channels):
             m.__class__ = NativeConv3x3
     return model
+
+
+# ---- the network's first convolution (3x3 / stride 2 / pad 1 on the image) on its own kernels (csrc/ssdk_stemtrain.hip) ------------
+class _StemConv3x3s2(torch.autograd.Function):
+    """x [N, Cin <= 3, H, W] 16 bit (contiguous), w [Cout <= 32, Cin, 3, 3] fp32 master parameter -> y [N, Cout, Ho, Wo] 16 bit.
+    Backward: the weight gradient (fp32, matrix cores over pixels, fixed-order partial sums); the image's gradient, if anybody
+    asks for it, comes from the framework's convolution backward."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        n, cin, h, wd = (int(v) for v in x.shape)
+        cout, dev = int(w.shape[0]), x.device
+        ho, wo = (h - 1) // 2 + 1, (wd - 1) // 2 + 1
+        x = x.detach()
+        y = torch.empty((n, cout, ho, wo), device=dev, dtype=x.dtype)
+        with torch.cuda.device(dev):
+            N.check(N.lib.ssdk_stem3x3s2_fwd(x.data_ptr(), w.detach().contiguous().data_ptr(), y.data_ptr(), n, cin, h, wd, cout,
+                                             N.dtype_code(x), N.stream_ptr(dev)), "stem3x3s2_fwd")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        n, cin, h, wd = (int(v) for v in x.shape)
+        cout, dev = int(w.shape[0]), x.device
+        gy = gy.contiguous()
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        gx = gw = None
+        if ctx.needs_input_grad[1]:
+            need = int(N.lib.ssdk_stem3x3s2_wgrad_workspace_bytes(n, h))
+            ws = torch.empty(need + 16, dtype=torch.uint8, device=dev)
+            wp = (ws.data_ptr() + 15) & ~15
+            gw = torch.empty((cout, cin, 3, 3), device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                N.check(N.lib.ssdk_stem3x3s2_wgrad(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), wp, need, n, cin, h, wd, cout,
+                                                   N.dtype_code(x), N.stream_ptr(dev)), "stem3x3s2_wgrad")
+            gw = gw if w.dtype == torch.float32 else gw.to(w.dtype)
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, w.to(x.dtype), None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        return gx, gw
+
+
+class StemConv3x3s2(nn.Conv2d):
+    """``nn.Conv2d(Cin <= 3, Cout <= 32, k = 3, stride 2, pad 1, bias = False)`` -- the first layer of the MobileNet backbones --
+    whose 16-bit HIP-device forward / weight gradient run on ``csrc/ssdk_stemtrain.hip`` (same parameter, ``state_dict`` key and
+    initialisation); everything else is ``nn.Conv2d.forward``."""
+
+    def _native(self, x):
+        return (x.is_cuda and x.dim() == 4 and self.kernel_size == (3, 3) and self.padding == (1, 1) and self.dilation == (1, 1)
+                and self.stride == (2, 2) and self.groups == 1 and self.padding_mode == "zeros" and self.bias is None
+                and self.in_channels <= 3 and self.out_channels <= 32 and int(x.shape[1]) == self.in_channels
+                and os.environ.get("SSDK_STEM_NATIVE", "1") != "0")
+
+    def forward(self, x):
+        if not self._native(x):
+            return super(StemConv3x3s2, self).forward(x)
+        w = self.weight
+        if torch.is_autocast_enabled():
+            x = x.to(torch.get_autocast_dtype("cuda"))
+        if x.dtype not in (torch.bfloat16, torch.float16) or w.dtype != torch.float32:
+            return super(StemConv3x3s2, self).forward(x)
+        with torch.autocast("cuda", enabled=False):
+            return _StemConv3x3s2.apply(x.contiguous(), w)
+
+
+def use_native_stem(model):
+    """Switch the image-side 3x3 / stride-2 convolutions of ``model`` (<= 3 input channels, <= 32 filters, no bias) to the
+    kernel-backed subclass (in place).  -> layers switched."""
+    n = 0
+    for m in model.modules():
+        if (type(m) is nn.Conv2d and m.kernel_size == (3, 3) and m.padding == (1, 1) and m.stride == (2, 2) and m.groups == 1
+                and m.dilation == (1, 1) and m.padding_mode == "zeros" and m.bias is None and m.in_channels <= 3
+                and m.out_channels <= 32):
+            m.__class__ = StemConv3x3s2
+            n += 1
+    return n

@@ -55,9 +55,16 @@ class Solver(object):
                 from ssds.modeling.layers.pointwise import fuse_conv_bn_statistics
 
                 fuse_conv_bn_statistics(self.model)  # the 1x1 kernels hand their BatchNorm the batch statistics
+        from ssds.modeling.layers.pointwise import use_native_stem
+
+        use_native_stem(self.model)  # the image-side 3x3 / stride-2 convolution: forward + weight gradient on csrc/ssdk_stemtrain.hip (SSDK_STEM_NATIVE=0: library)
         from ssds.modeling.layers.headconv import use_head_pairs
 
         use_head_pairs(self.model)  # SSD heads: forward of each level's loc | conf pair on the inference kernels (SSDK_HEAD_PAIR=0: MIOpen)
+        if os.environ.get("SSDK_CONV3_NATIVE", "0") == "2":  # (A/B) every 3x3 layer but the 3-channel stem
+            from ssds.modeling.layers.pointwise import use_native_conv3x3
+
+            use_native_conv3x3(self.model.extras)
         if os.environ.get("SSDK_CONV3_NATIVE", "0") == "1":
             # stem / extras / head 3x3 convolutions as im2col + the same kernels.  Correct (tests/test_gpu_train.py) and OFF by
             # default: measured 23.2 vs 20.8 ms per step against MIOpen's implicit-GEMM kernels (round 6, session 4: the streaming

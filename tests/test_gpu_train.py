@@ -853,6 +853,60 @@ def test_native_conv3x3_matches_torch(n, cin, cout, h, w, stride, bias, dtype_na
     assert y32.dtype == torch.float32
 
 
+@pytest.mark.parametrize("dtype_name", ["bfloat16", "float16"])
+@pytest.mark.parametrize("n,cin,cout,h,w", [
+    (2, 3, 32, 64, 64),      # every fast path (widths that are multiples of 16)
+    (3, 3, 32, 128, 256),    # several output rows per wave, several workgroups
+    (2, 3, 32, 300, 300),    # the 300 px configuration: 150 output columns (not a multiple of 8), rows not 16-byte aligned
+    (2, 3, 24, 37, 45),      # odd sizes: the last output row / column reads the padding below / right of the image
+    (1, 1, 16, 33, 18), (2, 2, 32, 20, 24), (1, 3, 8, 2, 2), (1, 3, 32, 1, 1)])
+def test_stem_conv_kernels_match_torch(n, cin, cout, h, w, dtype_name):
+    """The first convolution of the training step (3x3 / stride 2 / pad 1 on the image; csrc/ssdk_stemtrain.hip behind
+    ssds/modeling/layers/pointwise.py::StemConv3x3s2) against nn.Conv2d in fp32 on the same 16-bit operands: the output per ELEMENT
+    within one rounding of its 16-bit store (a wrong tap, column parity or border is O(1)), the weight gradient per element
+    against the fp32 sum; bit-reproducible; fp32 master weights under autocast; fp32 tensors fall through to nn.Conv2d."""
+    import torch
+    import torch.nn as nn
+    from ssds import _native as N
+    from ssds.modeling.layers.pointwise import StemConv3x3s2, use_native_stem
+
+    dtype = getattr(torch, dtype_name)
+    torch.manual_seed(n + cin + cout + h + w)
+    cv = nn.Sequential(nn.Conv2d(cin, cout, 3, 2, 1, bias=False)).cuda()
+    assert use_native_stem(cv) == 1 and type(cv[0]) is StemConv3x3s2
+    w16 = cv[0].weight.detach().to(dtype).float()
+    ref = nn.Conv2d(cin, cout, 3, 2, 1, bias=False).cuda()
+    ref.weight.data.copy_(w16)
+    x = torch.randn(n, cin, h, w, device="cuda").to(dtype)
+    yr = ref(x.float())
+    g = torch.randn_like(yr).to(dtype)
+    yr.backward(g.float())
+    with torch.autocast("cuda", dtype=dtype):
+        yp = cv(x.float() if n % 2 else x)  # (an fp32 image is cast by the module, like autocast would)
+    assert N.last_kernel() == ("stem_fwd_mfma_kernel" if w % 2 == 0 and w >= 4 else "stem_fwd_kernel"), N.last_kernel()
+    assert yp.dtype == dtype and yp.shape == yr.shape and yp.is_contiguous()
+    yp.backward(g)  # (autograd's thread: ssdk_last_kernel is per thread)
+    eps = 2.0 ** -8 if dtype_name == "bfloat16" else 2.0 ** -10
+    err = (yp.detach().float() - yr.detach()).abs()
+    bar = eps * yr.detach().abs() + 2 * eps * float(yr.detach().pow(2).mean().sqrt())
+    assert bool((err <= bar).all()), "output: %d elements outside the rounding bar, worst %.3g" % (int((err > bar).sum()), float((err - bar).max()))
+    gw, gr = cv[0].weight.grad, ref.weight.grad
+    assert gw.dtype == torch.float32 and gw.shape == gr.shape
+    # fp32 accumulation of exact 16-bit products in another order: a few fp32 roundings of the largest partial sums
+    scale = float(gr.abs().max()) + float((g.float().abs().sum() * x.float().abs().max()).item()) * 1e-7
+    assert float((gw - gr).abs().max()) <= 2e-5 * scale + 1e-6, "dweight: %.3g vs scale %.3g" % (float((gw - gr).abs().max()), scale)
+    # bit-reproducible
+    cv[0].weight.grad = None
+    with torch.autocast("cuda", dtype=dtype):
+        y2 = cv(x)
+    y2.backward(g)
+    assert torch.equal(y2, yp) and torch.equal(cv[0].weight.grad, gw)
+    # fp32 tensors without autocast: nn.Conv2d.forward
+    assert cv(x.float()).dtype == torch.float32
+    # a convolution with a bias or more channels is not a stem
+    assert use_native_stem(nn.Sequential(nn.Conv2d(3, 32, 3, 2, 1, bias=True), nn.Conv2d(8, 32, 3, 2, 1, bias=False), nn.Conv2d(3, 64, 3, 2, 1, bias=False))) == 0
+
+
 @pytest.mark.parametrize("mode,dtype_name,gamma,loc_loss", [
     ("iou", "float32", 2.0, "smoothl1"), ("iou", "bfloat16", 2.0, "smoothl1"), ("iou_radius", "float32", 1.5, "smoothl1"),
     ("scale", "float32", 2.0, "smoothl1"), ("scale_center", "float16", 2.0, "smoothl1"),
@@ -1215,6 +1269,9 @@ def _device_step(model, anchors, images, targets, cfg, autocast, ssdk=True, ddp=
         from ssds.modeling.layers.headconv import use_head_pairs
 
         assert use_head_pairs(m) == 1  # (the twelve head convolutions: forward on the inference kernels, as ssds/utils/train_ddp.py)
+        from ssds.modeling.layers.pointwise import use_native_stem
+
+        assert use_native_stem(m) == 1  # (the image-side convolution on csrc/ssdk_stemtrain.hip, as ssds/utils/train_ddp.py)
         if conv3:  # (optional in the product too: SSDK_CONV3_NATIVE=1, ssds/utils/train_ddp.py)
             use_native_conv3x3(m)
     else:

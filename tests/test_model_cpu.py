@@ -468,6 +468,10 @@ def test_training_switches_of_round_6_pair_what_they_should_and_change_nothing_o
     os.environ.pop("SSDK_HEAD_PAIR", None)
     assert fuse_bn_into_depthwise(model) == 16  # every inverted-residual block with an expansion (the first block has none)
     assert HC.use_head_pairs(model) == 1 and model.__dict__.get("_ssdk_head_pair") is True
+    from ssds.modeling.layers.pointwise import StemConv3x3s2, use_native_stem
+
+    assert use_native_stem(model) == 1 and use_native_stem(model) == 0  # the image-side 3x3 / stride-2 convolution, once
+    assert sum(1 for m in model.modules() if type(m) is StemConv3x3s2) == 1
     assert list(model.state_dict().keys()) == keys and len(list(model.modules())) == n_modules
     linked = [m for m in model.modules() if type(m) is FastBatchNorm2d and "_ssdk_defer_to" in m.__dict__]
     assert len(linked) == 16 and all(type(m.__dict__["_ssdk_defer_to"]) is DepthwiseConv2d and m._ssdk_act == 1 for m in linked)

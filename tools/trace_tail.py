@@ -2,6 +2,7 @@
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 ms = float(sys.argv[2])
+top = int(sys.argv[3]) if len(sys.argv) > 3 else 45  # kernels listed
 end = max(int(r["End_Timestamp"]) for r in rows)
 acc = collections.defaultdict(lambda: [0, 0.0])
 tot = 0.0
@@ -12,6 +13,6 @@ for r in rows:
         acc[k][0] += 1
         acc[k][1] += (e - s) / 1e3
         tot += (e - s) / 1e3
-for k, (n, us) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:45]:
+for k, (n, us) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:top]:
     print("%8.1f us %5.1f%% x%-4d %s" % (us, 100 * us / tot, n, k))
 print("kernel time in window: %.1f ms" % (tot / 1e3))
