@@ -122,7 +122,7 @@ class _HeadPair3x3(torch.autograd.Function):
         return gx, gwl.to(wl.dtype), gbl, gwc.to(wc.dtype), gbc
 
 
-WGRAD_MIN_PIXELS = int(os.environ.get("SSDK_HEAD_WGRAD_MIN", "64"))  # (A/B)
+WGRAD_MIN_PIXELS = 64  # (0 -- ssds/utils/train_ddp.py with SSDK_CONV3_NATIVE=2 -- : every level, +0.1 ms per step, tools/run/r06_s39.sh)
 
 
 def wgrad_enabled():

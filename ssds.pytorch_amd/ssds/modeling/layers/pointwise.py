@@ -370,7 +370,12 @@ class _StemConv3x3s2(torch.autograd.Function):
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
         gx = gw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and wd % 16 != 0:
+            # rows that are not whole 16-byte groups (the 300 px configuration): the kernel's element-wise operand path is slower
+            # than the library's weight gradient (tools/run/r06_s43.sh) -- only the forward is ours there
+            gw = torch.ops.aten.convolution_backward(gy, x, w.to(x.dtype), None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1].to(w.dtype)
+        elif ctx.needs_input_grad[1]:
             need = int(N.lib.ssdk_stem3x3s2_wgrad_workspace_bytes(n, h))
             ws = torch.empty(need + 16, dtype=torch.uint8, device=dev)
             wp = (ws.data_ptr() + 15) & ~15
@@ -393,8 +398,7 @@ class StemConv3x3s2(nn.Conv2d):
     def _native(self, x):
         return (x.is_cuda and x.dim() == 4 and self.kernel_size == (3, 3) and self.padding == (1, 1) and self.dilation == (1, 1)
                 and self.stride == (2, 2) and self.groups == 1 and self.padding_mode == "zeros" and self.bias is None
-                and self.in_channels <= 3 and self.out_channels <= 32 and int(x.shape[1]) == self.in_channels
-                and os.environ.get("SSDK_STEM_NATIVE", "1") != "0")
+                and self.in_channels <= 3 and self.out_channels <= 32 and int(x.shape[1]) == self.in_channels)
 
     def forward(self, x):
         if not self._native(x):

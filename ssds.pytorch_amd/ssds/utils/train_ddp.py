@@ -57,14 +57,19 @@ class Solver(object):
                 fuse_conv_bn_statistics(self.model)  # the 1x1 kernels hand their BatchNorm the batch statistics
         from ssds.modeling.layers.pointwise import use_native_stem
 
-        use_native_stem(self.model)  # the image-side 3x3 / stride-2 convolution: forward + weight gradient on csrc/ssdk_stemtrain.hip (SSDK_STEM_NATIVE=0: library)
+        use_native_stem(self.model)  # the image-side 3x3 / stride-2 convolution: forward + weight gradient on csrc/ssdk_stemtrain.hip (A/B tools/run/r06_s42.sh: 17.0 vs 17.5 ms per step)
         from ssds.modeling.layers.headconv import use_head_pairs
 
         use_head_pairs(self.model)  # SSD heads: forward of each level's loc | conf pair on the inference kernels (SSDK_HEAD_PAIR=0: MIOpen)
-        if os.environ.get("SSDK_CONV3_NATIVE", "0") == "2":  # (A/B) every 3x3 layer but the 3-channel stem
+        if os.environ.get("SSDK_CONV3_NATIVE", "0") == "2" and hasattr(self.model, "extras"):
+            # NO library convolution left in the step: the extras' four 3x3 / stride-2 layers as im2col + ssdk_pw_* + col2im and the
+            # weight gradients of the small head levels on ssdk_pw_wgrad too.  Correct and OFF by default: 17.6 vs 17.0 ms per step
+            # (tools/run/r06_s39.sh, r06_s40.sh: the library's implicit-GEMM kernels are faster on these K = 576 ... 2304 layers)
+            from ssds.modeling.layers import headconv
             from ssds.modeling.layers.pointwise import use_native_conv3x3
 
             use_native_conv3x3(self.model.extras)
+            headconv.WGRAD_MIN_PIXELS = 0
         if os.environ.get("SSDK_CONV3_NATIVE", "0") == "1":
             # stem / extras / head 3x3 convolutions as im2col + the same kernels.  Correct (tests/test_gpu_train.py) and OFF by
             # default: measured 23.2 vs 20.8 ms per step against MIOpen's implicit-GEMM kernels (round 6, session 4: the streaming
