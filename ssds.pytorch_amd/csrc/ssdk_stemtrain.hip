@@ -188,10 +188,9 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const StemTrainParam
       xrow[q] = p.x + (((size_t)n * p.Cin + (xok[q] ? ci : 0)) * p.H + (xok[q] ? iy : 0)) * p.W;
     }
     u16* yrow = p.y + (size_t)n * p.Cout * plane + (size_t)oy * p.Wo;
-    for (int ox0 = 0; ox0 < p.Wo; ox0 += 32) {
-      uint2 raw[2][3];  // [tile: even / odd pixel][row]
+    // the loads of a tile: [tile: even / odd pixel][row]; the NEXT tile of the row is requested before this one is multiplied
+    auto load_tile = [&](int ox0, uint2 (&raw)[2][3]) {
       int cA = 2 * (ox0 + 2 * fr) - 2, cB = cA + 2;  // first column of the even / odd pixel's window
-      const bool edge = cA < 0;                      // pixel 0: columns -2, -1 are the zero padding
       cA = cA < 0 ? 0 : (cA > p.W - 4 ? p.W - 4 : cA);
       cB = cB > p.W - 4 ? p.W - 4 : cB;
 #pragma unroll
@@ -203,6 +202,12 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const StemTrainParam
           raw[0][q] = raw[1][q] = make_uint2(0u, 0u);
         }
       }
+    };
+    uint2 raw[2][3], nxt[2][3] = {};
+    load_tile(0, raw);
+    for (int ox0 = 0; ox0 < p.Wo; ox0 += 32) {
+      const bool edge = ox0 == 0 && fr == 0;  // pixel 0: columns -2, -1 are the zero padding
+      if (ox0 + 32 < p.Wo) load_tile(ox0 + 32, nxt);  // (uniform)
       f32x4 acc[2][2];  // [tile][co tile]
 #pragma unroll
       for (int T = 0; T < 2; ++T) {
@@ -239,6 +244,10 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const StemTrainParam
             }
           }
       }
+#pragma unroll
+      for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) raw[T][q] = nxt[T][q];
     }
   }
 }
@@ -249,8 +258,8 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const StemTrainParam
 // the nine dwords that cover columns 2 ox - 2 .. 2 ox + 15.  Loads are unconditional on clamped addresses, masked afterwards.
 // FAST (W a multiple of 16, 16-byte aligned tensor): an eight-pixel group lies inside the row or completely outside it.
 template <int DT, bool FAST>
-__device__ __forceinline__ u32x4 stem_patch(const u16* row, bool ok, int ox, int kx, int W, int Wo) {
-  u32 d[9];  // d[0] = columns (cb - 2, cb - 1), d[1 + i] = columns (cb + 2i, cb + 2i + 1), cb = 2 ox
+__device__ __forceinline__ void stem_patch_load(const u16* row, int ox, int W, int Wo, u32 (&d)[9]) {
+  // d[0] = columns (cb - 2, cb - 1), d[1 + i] = columns (cb + 2i, cb + 2i + 1), cb = 2 ox
   if constexpr (FAST) {
     const int oxc = ox < Wo ? ox : Wo - 8, cb = 2 * oxc;
     const u32x4 q0 = *reinterpret_cast<const u32x4*>(row + cb), q1 = *reinterpret_cast<const u32x4*>(row + cb + 8);
@@ -264,7 +273,6 @@ __device__ __forceinline__ u32x4 stem_patch(const u16* row, bool ok, int ox, int
     d[6] = q1[1];
     d[7] = q1[2];
     d[8] = q1[3];
-    ok = ok && ox < Wo;
   } else {
     const int cb = 2 * ox, last = W - 1;
     u32 e[17];  // columns cb - 1 .. cb + 15
@@ -278,6 +286,8 @@ __device__ __forceinline__ u32x4 stem_patch(const u16* row, bool ok, int ox, int
 #pragma unroll
     for (int i = 0; i < 8; ++i) d[1 + i] = e[1 + 2 * i] | (e[2 + 2 * i] << 16);
   }
+}
+__device__ __forceinline__ u32x4 stem_patch_pick(const u32 (&d)[9], bool ok, int kx) {
   u32x4 out;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -290,11 +300,10 @@ __device__ __forceinline__ u32x4 stem_patch(const u16* row, bool ok, int ox, int
 }
 
 template <int DT, bool FAST>
-__device__ __forceinline__ u32x4 stem_dy(const u16* row, bool ok, int ox, int Wo) {  // eight pixels ox .. ox + 7 of one channel row
+__device__ __forceinline__ u32x4 stem_dy_load(const u16* row, int ox, int Wo) {  // eight pixels ox .. ox + 7 of one channel row
   u32x4 out;
   if constexpr (FAST) {
     out = *reinterpret_cast<const u32x4*>(row + (ox < Wo ? ox : Wo - 8));
-    ok = ok && ox < Wo;
   } else {
     const int last = Wo - 1;
 #pragma unroll
@@ -304,8 +313,6 @@ __device__ __forceinline__ u32x4 stem_dy(const u16* row, bool ok, int ox, int Wo
       out[i] = (c < Wo ? e0 : 0u) | ((c + 1 < Wo ? e1 : 0u) << 16);
     }
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) out[i] = ok ? out[i] : 0u;
   return out;
 }
 
@@ -350,17 +357,40 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemTrainParams p
     const u16* grow[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) grow[a] = p.dy + ((size_t)n * p.Cout + (c_ok[a] ? a * 16 + (int)fr : 0)) * plane + (size_t)oy * p.Wo;
-    for (int ox0 = 0; ox0 < p.Wo; ox0 += 32) {  // a k-step = 32 output pixels: lane group fg holds pixels ox0 + 8 fg .. + 7
+    // a k-step = 32 output pixels: lane group fg holds pixels ox0 + 8 fg .. + 7; the NEXT k-step's operands are requested before
+    // this one's are multiplied
+    u32x4 A[2], An[2] = {};
+    u32 D[2][9], Dn[2][9] = {};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) A[a] = stem_dy_load<DT, FAST>(grow[a], 8 * (int)fg, p.Wo);
+#pragma unroll
+    for (int f = 0; f < 2; ++f) stem_patch_load<DT, FAST>(xrow[f], 8 * (int)fg, p.W, p.Wo, D[f]);
+    for (int ox0 = 0; ox0 < p.Wo; ox0 += 32) {
       const int ox = ox0 + 8 * (int)fg;
-      u32x4 A[2], B[2];
+      if (ox0 + 32 < p.Wo) {  // (uniform)
 #pragma unroll
-      for (int a = 0; a < 2; ++a) A[a] = stem_dy<DT, FAST>(grow[a], c_ok[a], ox, p.Wo);
+        for (int a = 0; a < 2; ++a) An[a] = stem_dy_load<DT, FAST>(grow[a], ox + 32, p.Wo);
 #pragma unroll
-      for (int f = 0; f < 2; ++f) B[f] = stem_patch<DT, FAST>(xrow[f], xok[f], ox, t_kx[f], p.W, p.Wo);
+        for (int f = 0; f < 2; ++f) stem_patch_load<DT, FAST>(xrow[f], ox + 32, p.W, p.Wo, Dn[f]);
+      }
+      const bool in = ox < p.Wo;
+      u32x4 B[2];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int f = 0; f < 2; ++f) B[f] = stem_patch_pick(D[f], xok[f] && in, t_kx[f]);
 #pragma unroll
-        for (int f = 0; f < 2; ++f) acc[a][f] = mfma16<DT>(A[a], B[f], acc[a][f]);
+      for (int a = 0; a < 2; ++a) {
+        u32x4 Aa = A[a];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Aa[i] = (c_ok[a] && in) ? Aa[i] : 0u;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[a][f] = mfma16<DT>(Aa, B[f], acc[a][f]);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) A[a] = An[a];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) D[f][i] = Dn[f][i];
     }
   }
   // D[m = 4 fg + j][n = fr] of tile (a, f) = dW[co = 16 a + 4 fg + j][tap = 16 f + fr]
