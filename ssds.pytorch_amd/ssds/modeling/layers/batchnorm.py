@@ -98,10 +98,13 @@ class _BatchNormDeferred(torch.autograd.Function):
         ctx.save_for_backward(x, weight, bias, mean, invstd)
         ctx.act = int(act)
         ctx.mark_non_differentiable(coef)
+        ctx.set_materialize_grads(False)  # (no zero-filled gradient tensor for coef: a fill launch per layer and step)
         return x.detach(), coef  # (an alias: what the consumer reads through it is x, NOT the BatchNorm's output)
 
     @staticmethod
     def backward(ctx, gy, _gcoef=None):
+        if gy is None:
+            return (None,) * 9
         return _BatchNormTrain.backward(ctx, gy)
 
 

@@ -24,7 +24,10 @@ class _DwConv3x3(torch.autograd.Function):
         BatchNorm that follows (ssdk_dwconv_fwd_stats: no pass over y); non-differentiable; None where the geometry runs on the
         tiled fallback kernels."""
         x = x.contiguous()
-        w = w.contiguous()
+        ctx.wdt = w.dtype
+        # an fp32 master weight next to a 16-bit tensor (autocast): cast here, outside autograd -- the fp32 weight gradient then
+        # reaches the parameter as it is, without autocast's bf16 round trip and its two cast launches per layer and step
+        w = w.detach().to(x.dtype).contiguous()
         n, c, h, wd = (int(v) for v in x.shape)
         ho, wo = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
         y = torch.empty((n, c, ho, wo), device=x.device, dtype=x.dtype)
@@ -57,6 +60,7 @@ class _DwConv3x3(torch.autograd.Function):
             if sums is None:
                 sums = torch.empty(0, device=x.device)
             ctx.mark_non_differentiable(sums)
+            ctx.set_materialize_grads(False)  # (no zero-filled gradient tensor for sums: a fill launch per layer and step)
             return y, sums
         return y
 
@@ -68,6 +72,8 @@ class _DwConv3x3(torch.autograd.Function):
         else:
             x, w = ctx.saved_tensors
         stride = ctx.stride
+        if gy is None:  # (only the non-differentiable statistics were used)
+            return None, None, None, None, None, None
         gy = gy.contiguous()
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
@@ -90,7 +96,7 @@ class _DwConv3x3(torch.autograd.Function):
                 else:
                     _launch(N.lib.ssdk_dwconv_bwd_weight, x.data_ptr(), gy.data_ptr(), gw32.data_ptr(), ws.data_ptr(), need,
                             n, c, h, wd, stride, N.dtype_code(x), N.stream_ptr(dev))
-                gw = gw32.to(w.dtype)
+                gw = gw32.to(ctx.wdt)
         return gx, gw, None, None, None, None
 
 
@@ -129,8 +135,9 @@ class DepthwiseConv2d(nn.Conv2d):
             return super(DepthwiseConv2d, self).forward(x)
         w = self.weight
         if torch.is_autocast_enabled():
-            dt = torch.get_autocast_dtype("cuda")
-            x, w = x.to(dt), w.to(dt)
+            x = x.to(torch.get_autocast_dtype("cuda"))
+            if not (w.dtype == torch.float32 and x.dtype in (torch.bfloat16, torch.float16)):
+                w = w.to(x.dtype)  # (fp32 master weights go in as they are: _DwConv3x3 casts outside autograd)
         elif w.dtype != x.dtype:
             w = w.to(x.dtype)
         if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):

@@ -107,6 +107,7 @@ class _PointwiseNative(torch.autograd.Function):
         ctx.meta = (w.dtype, None if bias is None else bias.dtype)
         if want_sums:
             ctx.mark_non_differentiable(sums)
+            ctx.set_materialize_grads(False)  # (no zero-filled gradient tensor for sums: a fill launch per layer and step)
             return y, sums
         return y
 
@@ -116,6 +117,8 @@ class _PointwiseNative(torch.autograd.Function):
         wdt, bdt = ctx.meta
         b, cin, h, wd = (int(v) for v in x.shape)
         cout, hw, dev = int(wt16.shape[1]), h * wd, x.device
+        if gy is None:  # (only the non-differentiable statistics were used)
+            return None, None, None, None
         gy = gy.contiguous()
         if gy.dtype != x.dtype:
             gy = gy.to(x.dtype)
