@@ -8,10 +8,11 @@
 // zero passes at SSD-MobileNetV2@512, batch 64 (profiles/r06_train_kernel_split_final_v3.txt).  The layer is a STREAM: 27 taps,
 // 100 MB of image in, 268 MB out (forward), the same two tensors in (weight gradient): ~60 us of HBM time each.
 //
-//   forward      a thread owns two neighbouring output pixels and all Cout channels: the 3 x 5 input window of every channel is
-//                one aligned 8-byte load + one 2-byte load per row, the weights (rounded to the tensor dtype like autocast does,
-//                kept as fp32) are staged in LDS once per workgroup and read as broadcasts, v_pk_fma_f32 over channel pairs,
-//                fp32 accumulation in tap order (ci, ky, kx), one 4-byte store per channel (a wave writes 256 contiguous bytes).
+//   forward      stem_fwd_mfma_kernel (even widths): the layer as a GEMM on the matrix cores with k = 4 r + j -- r one of the
+//                <= 9 (channel, kernel row) pairs, j the columns 2 ox - 2 .. 2 ox + 1 -- so that a lane's eight consecutive k are
+//                two 8-byte loads of an image row (no gather), the weights a loop-invariant A operand in 16 VGPRs; see the
+//                kernel.  Odd widths: stem_fwd_kernel, a thread per output pixel pair with the weights read from LDS (slow:
+//                kept as the fallback only).
 //   weight grad  dW[co][tap] = sum over pixels dy[co][p] patch[tap][p] contracts over PIXELS, which are contiguous in dy
 //                (NCHW) and stride-2 in x: v_mfma_f32_16x16x32 with A = dy (16 channels x 32 pixels: one 16-byte load per
 //                lane) and B = patch (16 taps x 32 pixels: 32 + 4 bytes of an image row per lane, the even / odd columns
