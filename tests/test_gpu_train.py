@@ -744,7 +744,8 @@ def test_head_weight_pack_kernels_against_the_layout_they_document(n1, n2, cin, 
     (5, 512, 8, 8, "conv_smallmap_kernel"), (6, 256, 4, 4, "conv_smallmap_kernel"), (7, 256, 2, 2, "conv_smallmap_kernel"),
     (9, 128, 1, 1, "conv_smallmap_kernel"),
     (2, 40, 19, 19, None)])                     # Cin not a multiple of 32 (no fragment-major image), odd map
-def test_head_pair_conv_matches_the_two_modules(n, cin, h, w, kernel, dtype_name, tol):
+@pytest.mark.parametrize("wgrad_min", [64, 0])  # 0: the < 64-pixel levels' weight gradients on ssdk_pw_wgrad too (SSDK_CONV3_NATIVE=2)
+def test_head_pair_conv_matches_the_two_modules(n, cin, h, w, kernel, dtype_name, tol, wgrad_min, monkeypatch):
     """headconv.head_pair (round 6): loc | conf of one SSD level in the TRAINING step -- forward on the inference kernels from
     weights packed per call by ssdk_pack_conv3x3, backward as ONE convolution -- against the two nn.Conv2d modules in fp32 on the
     same 16-bit operands: outputs and the input gradient per element, all four parameter gradients."""
@@ -753,6 +754,9 @@ def test_head_pair_conv_matches_the_two_modules(n, cin, h, w, kernel, dtype_name
     from ssds import _native as N
     from ssds.modeling.layers import headconv as HC
 
+    if wgrad_min == 0 and h * w >= 64:
+        pytest.skip("the large levels take the kernels' weight gradient either way")
+    monkeypatch.setattr(HC, "WGRAD_MIN_PIXELS", wgrad_min)
     dtype = getattr(torch, dtype_name)
     torch.manual_seed(n + cin + h)
     loc = nn.Conv2d(cin, 24, 3, padding=1).cuda()
