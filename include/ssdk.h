@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define SSDK_VERSION 243 /* 0.2.4.3: ssdk_stem3x3s2_fwd / _wgrad (the first convolution of the training step); 0.2.4.2: ssdk_concat_nchw_to_nhwc; 0.2.4.1: ssdk_pack_conv3x3[_dgrad]; 0.2.4: ssdk_abi_check, ssdk_pw_* (1x1 convolutions of the training step: forward / input gradient / weight gradient on NCHW tensors); 0.2.3: ssdk_struct_size; 0.2.2: ssdk_mbconv_desc.image_nw / w_image / w_image_bytes (ssdk_mbk.hip), larger ssdk_match_multibox_loss workspace; 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
+#define SSDK_VERSION 244 /* 0.2.4.4: ssdk_im2col3x3_folded / ssdk_col2im3x3_folded; 0.2.4.3: ssdk_stem3x3s2_fwd / _wgrad (the first convolution of the training step); 0.2.4.2: ssdk_concat_nchw_to_nhwc; 0.2.4.1: ssdk_pack_conv3x3[_dgrad]; 0.2.4: ssdk_abi_check, ssdk_pw_* (1x1 convolutions of the training step: forward / input gradient / weight gradient on NCHW tensors); 0.2.3: ssdk_struct_size; 0.2.2: ssdk_mbconv_desc.image_nw / w_image / w_image_bytes (ssdk_mbk.hip), larger ssdk_match_multibox_loss workspace; 0.2.1: ssdk_match_multibox_loss, ssdk_op.lane == 2; fields appended to descriptors since 200 (zero = old behaviour) */
 
 #define SSDK_MAX_LEVELS 8    /* feature-map levels per decode_nms call            */
 #define SSDK_MAX_ANCHORS 16  /* anchors per location (A)                          */
@@ -437,6 +437,11 @@ int ssdk_pw_wgrad(const void* dy, const void* x, float* dw, void* workspace, siz
  *   ssdk_col2im3x3   dcol [B, Kp, Ho * Wo] -> dx [B, C, H, W]  (per input pixel a gather of <= 9 terms, fp32 sum in tap order) */
 int ssdk_im2col3x3(const void* x, void* col, int B, int C, int H, int W, int stride, int dtype, void* stream);
 int ssdk_col2im3x3(const void* dcol, void* dx, int B, int C, int H, int W, int stride, int dtype, void* stream);
+/* The same two with the batch folded into the pixel dimension: col / dcol are [Kp, B, Ho * Wo], i.e. ONE image of B * Ho * Wo pixels
+ * for ssdk_pw_forward / ssdk_pw_wgrad (called with B = 1, HW = B * Ho * Wo), which tile the pixels of one image in groups of 128:
+ * the layers with few pixels per image (the extras of /root/reference/ssds/modeling/ssds/ssd.py:63-65: 64 / 16 / 4 / 1). */
+int ssdk_im2col3x3_folded(const void* x, void* col, int B, int C, int H, int W, int stride, int dtype, void* stream);
+int ssdk_col2im3x3_folded(const void* dcol, void* dx, int B, int C, int H, int W, int stride, int dtype, void* stream);
 
 /* The network's FIRST convolution inside the training step (3x3 / stride 2 / pad 1, Cin <= 3 image channels, Cout <= 32, bias-free:
  * torchvision MobileNetV2 features[0][0] behind /root/reference/ssds/modeling/nets/mobilenet.py:180-192; the reference trains it

@@ -832,6 +832,7 @@ struct ColParams {
   const u16* x;
   u16* col;
   int B, C, H, W, Ho, Wo, stride, Kp;
+  size_t kstride, bstride;  // elements between two k rows of an image / between two images: [B][Kp][HWo], or FOLDED [Kp][B][HWo]
 };
 
 __global__ __launch_bounds__(256) void im2col3x3_kernel(const ColParams p) {
@@ -841,7 +842,7 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const ColParams p) {
     const u32 v = (u32)(i % vpr), k = (u32)((i / vpr) % (u32)p.Kp), b = (u32)(i / ((size_t)vpr * p.Kp));
     const u32 p0 = v * 8u;
     const int nvalid = (int)HWo - (int)p0;
-    u16* dst = p.col + ((size_t)b * p.Kp + k) * HWo + p0;
+    u16* dst = p.col + (size_t)b * p.bstride + (size_t)k * p.kstride + p0;
     u32 h[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     if (k < (u32)(p.C * 9)) {
       const u32 c = k / 9u, t = k - c * 9u, ky = t / 3u, kx = t - ky * 3u;
@@ -868,21 +869,21 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const ColParams p) {
 
 template <int DT>
 __global__ __launch_bounds__(256) void col2im3x3_kernel(const ColParams p) {  // p.col = dcol (read), p.x = dx (written)
-  const u32 HW = (u32)(p.H * p.W), HWo = (u32)(p.Ho * p.Wo), vpr = (HW + 7u) / 8u;
+  const u32 HW = (u32)(p.H * p.W), vpr = (HW + 7u) / 8u;
   const size_t total = (size_t)p.B * p.C * vpr;
   u16* dx = const_cast<u16*>(p.x);
   for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < total; i += (size_t)gridDim.x * 256u) {
     const u32 v = (u32)(i % vpr), c = (u32)((i / vpr) % (u32)p.C), b = (u32)(i / ((size_t)vpr * p.C));
     const u32 p0 = v * 8u;
     const int nvalid = (int)HW - (int)p0;
-    const u16* rows = p.col + ((size_t)b * p.Kp + (size_t)c * 9u) * HWo;
+    const u16* rows = p.col + (size_t)b * p.bstride + (size_t)c * 9u * p.kstride;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const u32 iy0 = p0 / (u32)p.W, ix0 = p0 - iy0 * (u32)p.W;
     const bool one_row = p.stride == 1 && ix0 + 7u < (u32)p.W && nvalid >= 8;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int ky = t / 3, kx = t % 3;
-      const u16* row = rows + (size_t)t * HWo;
+      const u16* row = rows + (size_t)t * p.kstride;
       if (one_row) {  // stride 1: the 8 input pixels of a row meet 8 consecutive output pixels of row iy + 1 - ky
         const int oy = (int)iy0 + 1 - ky, ox = (int)ix0 + 1 - kx;
         if ((unsigned)oy >= (unsigned)p.Ho) continue;
@@ -927,7 +928,7 @@ static int col_check(const void* a, const void* b, int B, int C, int H, int W, i
   return SSDK_OK;
 }
 
-static ColParams col_params(const void* x, void* col, int B, int C, int H, int W, int stride) {
+static ColParams col_params(const void* x, void* col, int B, int C, int H, int W, int stride, int fold = 0) {
   ColParams p;
   p.x = (const u16*)x;
   p.col = (u16*)col;
@@ -939,6 +940,9 @@ static ColParams col_params(const void* x, void* col, int B, int C, int H, int W
   p.Ho = (H + 2 - 3) / stride + 1;
   p.Wo = (W + 2 - 3) / stride + 1;
   p.Kp = (C * 9 + 7) / 8 * 8;
+  const size_t hwo = (size_t)p.Ho * p.Wo;
+  p.kstride = fold ? (size_t)B * hwo : hwo;
+  p.bstride = fold ? hwo : (size_t)p.Kp * hwo;
   return p;
 }
 
@@ -957,6 +961,32 @@ extern "C" int ssdk_col2im3x3(const void* dcol, void* dx, int B, int C, int H, i
   int rc = col_check(dcol, dx, B, C, H, W, stride, dtype, "ssdk_col2im3x3");
   if (rc) return rc;
   ColParams p = col_params(dx, const_cast<void*>(dcol), B, C, H, W, stride);
+  const size_t total = (size_t)B * C * (((size_t)H * W + 7) / 8);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  if (dtype == SSDK_BF16) hipLaunchKernelGGL(col2im3x3_kernel<SSDK_BF16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(col2im3x3_kernel<SSDK_F16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("col2im3x3_kernel");
+}
+
+// The same two with the batch FOLDED into the pixel dimension: col / dcol are [Kp][B][Ho * Wo] = one "image" of B * Ho * Wo pixels
+// for the 1x1 kernels, which tile the pixels of ONE image in groups of 128 -- layers with a few pixels per image (the SSD extras:
+// 64 / 16 / 4 / 1) would fill those groups to 50 ... 0.8 %.
+extern "C" int ssdk_im2col3x3_folded(const void* x, void* col, int B, int C, int H, int W, int stride, int dtype, void* stream) {
+  int rc = col_check(x, col, B, C, H, W, stride, dtype, "ssdk_im2col3x3_folded");
+  if (rc) return rc;
+  const ColParams p = col_params(x, col, B, C, H, W, stride, 1);
+  const size_t total = (size_t)B * p.Kp * (((size_t)p.Ho * p.Wo + 7) / 8);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("im2col3x3_kernel");
+}
+
+extern "C" int ssdk_col2im3x3_folded(const void* dcol, void* dx, int B, int C, int H, int W, int stride, int dtype, void* stream) {
+  int rc = col_check(dcol, dx, B, C, H, W, stride, dtype, "ssdk_col2im3x3_folded");
+  if (rc) return rc;
+  ColParams p = col_params(dx, const_cast<void*>(dcol), B, C, H, W, stride, 1);
   const size_t total = (size_t)B * C * (((size_t)H * W + 7) / 8);
   size_t blocks = (total + 255) / 256;
   if (blocks > 256 * 64) blocks = 256 * 64;

@@ -96,7 +96,7 @@ FUSE_SAME, FUSE_UP2, FUSE_POOL2 = 0, 1, 2
 NCHW, NHWC = 0, 1
 
 
-ABI_VERSION = 243  # include/ssdk.h SSDK_VERSION this module's ctypes mirrors and prototypes are written for
+ABI_VERSION = 244  # include/ssdk.h SSDK_VERSION this module's ctypes mirrors and prototypes are written for
 
 
 def _load():
@@ -151,6 +151,8 @@ def _load():
     lib.ssdk_sgd_step.restype = i32
     lib.ssdk_im2col3x3.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.ssdk_col2im3x3.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.ssdk_im2col3x3_folded.argtypes = lib.ssdk_col2im3x3_folded.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.ssdk_im2col3x3_folded.restype = lib.ssdk_col2im3x3_folded.restype = i32
     lib.ssdk_stem3x3s2_wgrad_workspace_bytes.argtypes = [i32, i32]
     lib.ssdk_stem3x3s2_wgrad_workspace_bytes.restype = sz
     lib.ssdk_stem3x3s2_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
@@ -284,7 +286,7 @@ EXPORTS = ("ssdk_version", "ssdk_struct_size", "ssdk_abi_check", "ssdk_last_erro
            "ssdk_ctx_create", "ssdk_ctx_destroy", "ssdk_ctx_set_tail_stream", "ssdk_ctx_set_side_lane", "ssdk_ctx_set_profiling",
            "ssdk_ctx_get_timings", "ssdk_ctx_set_op_profiling", "ssdk_ctx_get_op_timings", "ssdk_ctx_get_tail_stamps",
            "ssdk_run_ops_ctx", "ssdk_decode_nms_ctx",
-           "ssdk_weight_frag_bytes", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_mbk_image_bytes", "ssdk_xpair", "ssdk_fuse", "ssdk_preprocess", "ssdk_dwconv_fwd_stats_workspace_bytes", "ssdk_dwconv_fwd_stats", "ssdk_dwconv_affine_supported", "ssdk_dwconv_fwd_affine", "ssdk_dwconv_bwd_weight_affine", "ssdk_bn_act_train_stats", "ssdk_pw_prepare", "ssdk_pw_forward", "ssdk_pw_stats_workspace_bytes", "ssdk_pw_forward_stats", "ssdk_bn_act_train_fwd_sums", "ssdk_pw_wgrad_workspace_bytes", "ssdk_pw_wgrad", "ssdk_im2col3x3", "ssdk_col2im3x3", "ssdk_stem3x3s2_wgrad_workspace_bytes", "ssdk_stem3x3s2_fwd", "ssdk_stem3x3s2_wgrad", "ssdk_pack_conv3x3", "ssdk_pack_conv3x3_dgrad", "ssdk_concat_nchw_to_nhwc", "ssdk_sgd_step", "ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data",
+           "ssdk_weight_frag_bytes", "ssdk_conv_workspace_bytes", "ssdk_conv", "ssdk_conv_sequence", "ssdk_mbconv", "ssdk_mbk_image_bytes", "ssdk_xpair", "ssdk_fuse", "ssdk_preprocess", "ssdk_dwconv_fwd_stats_workspace_bytes", "ssdk_dwconv_fwd_stats", "ssdk_dwconv_affine_supported", "ssdk_dwconv_fwd_affine", "ssdk_dwconv_bwd_weight_affine", "ssdk_bn_act_train_stats", "ssdk_pw_prepare", "ssdk_pw_forward", "ssdk_pw_stats_workspace_bytes", "ssdk_pw_forward_stats", "ssdk_bn_act_train_fwd_sums", "ssdk_pw_wgrad_workspace_bytes", "ssdk_pw_wgrad", "ssdk_im2col3x3", "ssdk_col2im3x3", "ssdk_im2col3x3_folded", "ssdk_col2im3x3_folded", "ssdk_stem3x3s2_wgrad_workspace_bytes", "ssdk_stem3x3s2_fwd", "ssdk_stem3x3s2_wgrad", "ssdk_pack_conv3x3", "ssdk_pack_conv3x3_dgrad", "ssdk_concat_nchw_to_nhwc", "ssdk_sgd_step", "ssdk_dwconv_fwd", "ssdk_dwconv_bwd_data",
            "ssdk_dwconv_bwd_weight_workspace_bytes", "ssdk_dwconv_bwd_weight", "ssdk_dwconv_plan", "ssdk_bn_workspace_bytes",
            "ssdk_bn_train_fwd", "ssdk_bn_train_bwd", "ssdk_bn_act_train_fwd", "ssdk_bn_act_train_bwd", "ssdk_conv_stem7", "ssdk_maxpool3x3s2", "ssdk_run_ops", "ssdk_conv_bn_act", "ssdk_set_profiling", "ssdk_get_timings")
 

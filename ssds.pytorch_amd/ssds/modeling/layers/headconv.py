@@ -91,8 +91,9 @@ class _HeadPair3x3(torch.autograd.Function):
         dt = x.dtype
         want_gx = ctx.needs_input_grad[0]
         native_gx = want_gx and dgrad_enabled()
-        # weight / bias gradients.  Levels of >= 64 pixels: im2col + ssdk_pw_wgrad per module (tools/head_wgrad_probe.py: 198 / 146 /
-        # 160 us against the library's 369 / 208 / 217 on the 32^2 / 16^2 / 8^2 levels; the smaller levels are faster there).  Library:
+        # weight / bias gradients: im2col + ssdk_pw_wgrad per module (tools/head_wgrad_probe.py: 198 / 146 / 160 us against the
+        # library's 369 / 208 / 217 on the 32^2 / 16^2 / 8^2 levels; the smaller levels with the batch folded into the pixel
+        # dimension, pointwise.FOLD_BELOW -- per image they were slower than the library).  Library (WGRAD_MIN_PIXELS):
         # two calls, as autograd would make them for the two modules (ONE call on the concatenated 504 channels was measured and is
         # 2 ms per step slower: the library picks k-tile-8 kernels for it; tools/run/r06_s23.sh)
         n, cin, h, w_ = (int(v) for v in x.shape)
@@ -122,7 +123,7 @@ class _HeadPair3x3(torch.autograd.Function):
         return gx, gwl.to(wl.dtype), gbl, gwc.to(wc.dtype), gbc
 
 
-WGRAD_MIN_PIXELS = 64  # (0 -- ssds/utils/train_ddp.py with SSDK_CONV3_NATIVE=2 -- : every level, +0.1 ms per step, tools/run/r06_s39.sh)
+WGRAD_MIN_PIXELS = 0  # (64 -- ssds/utils/train_ddp.py with SSDK_CONV3_NATIVE=0 --: the levels below 64 pixels on the library's weight gradient)
 
 
 def wgrad_enabled():
@@ -139,15 +140,18 @@ def _weight_gradients(x, pairs, has_bias):
     out = []
     with torch.cuda.device(dev):
         sp = N.stream_ptr(dev)
-        col = PW._im2col(x.detach(), 1)
+        fold = n > 1 and hw < PW.FOLD_BELOW and (n * hw) % 8 == 0  # small levels: the batch as ONE image of n * hw pixels (PW._fold)
+        col = PW._im2col(x.detach(), 1, fold)
         kp = int(col.shape[1])
+        gn, ghw = (1, n * hw) if fold else (n, hw)
         for g, wt in pairs:
             g = g.to(dt).contiguous()
             cout = int(wt.shape[0])
-            need = int(N.lib.ssdk_pw_wgrad_workspace_bytes(n, cout, kp, hw))
+            g2 = PW._fold(g.view(n, cout, hw)) if fold else g
+            need = int(N.lib.ssdk_pw_wgrad_workspace_bytes(gn, cout, kp, ghw))
             ws = torch.empty(need, dtype=torch.uint8, device=dev)
             gw32 = torch.empty((cout, kp), device=dev, dtype=torch.float32)
-            N.check(N.lib.ssdk_pw_wgrad(g.data_ptr(), col.data_ptr(), gw32.data_ptr(), ws.data_ptr(), need, n, cout, kp, hw, N.dtype_code(x), sp),
+            N.check(N.lib.ssdk_pw_wgrad(g2.data_ptr(), col.data_ptr(), gw32.data_ptr(), ws.data_ptr(), need, gn, cout, kp, ghw, N.dtype_code(x), sp),
                     "pw_wgrad (head pair)")
             gw = gw32[:, : cin * 9].reshape(cout, cin, 3, 3)
             gb = g.sum((0, 2, 3), dtype=torch.float32) if has_bias else None

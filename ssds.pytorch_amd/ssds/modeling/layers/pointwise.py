@@ -228,16 +228,18 @@ def use_pointwise_gemm(model):
 _COL_CACHE = {"x": None, "stride": 0, "col": None, "ver": -1}  # the loc and conf heads of a level read the SAME feature map (ssd.py:100-103)
 
 
-def _im2col(x, stride):
+def _im2col(x, stride, fold=False):
+    """-> col [B, Kp, Ho * Wo], or FOLDED [1, Kp, B * Ho * Wo] (pixel index b * Ho * Wo + p: see ``FOLD_BELOW``)."""
     c = _COL_CACHE
-    if c["x"] is x and c["stride"] == stride and c["ver"] == x._version:
+    if c["x"] is x and c["stride"] == (stride, fold) and c["ver"] == x._version:
         return c["col"]
     b, cin, h, w = (int(v) for v in x.shape)
     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
     kp = (cin * 9 + 7) // 8 * 8
-    col = torch.empty((b, kp, ho * wo), device=x.device, dtype=x.dtype)
-    N.check(N.lib.ssdk_im2col3x3(x.data_ptr(), col.data_ptr(), b, cin, h, w, stride, N.dtype_code(x), N.stream_ptr(x.device)), "im2col3x3")
-    c.update(x=x, stride=stride, col=col, ver=x._version)
+    col = torch.empty((1, kp, b * ho * wo) if fold else (b, kp, ho * wo), device=x.device, dtype=x.dtype)
+    fn = N.lib.ssdk_im2col3x3_folded if fold else N.lib.ssdk_im2col3x3
+    N.check(fn(x.data_ptr(), col.data_ptr(), b, cin, h, w, stride, N.dtype_code(x), N.stream_ptr(x.device)), "im2col3x3")
+    c.update(x=x, stride=(stride, fold), col=col, ver=x._version)
     return col
 
 
@@ -246,9 +248,26 @@ def release_col_cache():
     _COL_CACHE.update(x=None, col=None, stride=0, ver=-1)
 
 
+FOLD_BELOW = 128  # output pixels per image below which a 3x3 layer's batch is folded into the GEMM's pixel dimension
+
+
+def _fold(t):
+    """[B, C, P] -> [1, C, B * P] (pixel index b * P + p): the 1x1 kernels tile PIXELS of one image in groups of 128; an extras
+    layer has 64 / 16 / 4 / 1 pixels per image, i.e. groups that are 50 ... 0.8 % full, image by image."""
+    b, c, p_ = (int(v) for v in t.shape)
+    return t.permute(1, 0, 2).reshape(1, c, b * p_).contiguous()
+
+
+def _unfold(t, b):
+    """[1, C, B * P] -> [B, C, P]"""
+    c, bp = int(t.shape[1]), int(t.shape[2])
+    return t.view(c, b, bp // b).permute(1, 0, 2).contiguous()
+
+
 class _Conv3x3Native(torch.autograd.Function):
     """3x3 / pad 1 / stride 1 | 2 on a 16-bit NCHW tensor: im2col + the 1x1 kernels (see csrc/ssdk_pwtrain.hip).  weight
-    [Cout, Cin, 3, 3] fp32 (master parameter under autocast) or 16-bit; bias or None."""
+    [Cout, Cin, 3, 3] fp32 (master parameter under autocast) or 16-bit; bias or None.  Small maps (< FOLD_BELOW output pixels per
+    image: the extras) run as ONE image of B * Ho * Wo pixels (``_fold``)."""
 
     @staticmethod
     def forward(ctx, x, w, bias, stride):
@@ -257,10 +276,12 @@ class _Conv3x3Native(torch.autograd.Function):
         ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
         code = N.dtype_code(x)
         x = x.detach()
+        fold = b > 1 and ho * wo < FOLD_BELOW and (b * ho * wo) % 8 == 0
         with torch.cuda.device(dev):
             sp = N.stream_ptr(dev)
-            col = _im2col(x, stride)
+            col = _im2col(x, stride, fold)
             kp = int(col.shape[1])
+            gb, ghw = (1, b * ho * wo) if fold else (b, ho * wo)
             w2 = w.detach().reshape(cout, cin * 9)
             if kp != cin * 9:
                 w2 = torch.nn.functional.pad(w2, (0, kp - cin * 9))
@@ -272,46 +293,50 @@ class _Conv3x3Native(torch.autograd.Function):
                 w16 = w2.contiguous()
                 wt16 = w16.t().contiguous()
             b32 = None if bias is None else bias.detach().float().contiguous()
-            y = torch.empty((b, cout, ho, wo), device=dev, dtype=dt)
+            y = torch.empty((gb, cout, ghw), device=dev, dtype=dt)
             N.check(N.lib.ssdk_pw_forward(col.data_ptr(), w16.data_ptr(), None if b32 is None else b32.data_ptr(), y.data_ptr(),
-                                          b, kp, cout, ho * wo, code, sp), "pw_forward (3x3)")
+                                          gb, kp, cout, ghw, code, sp), "pw_forward (3x3)")
+            y = (_unfold(y, b) if fold else y).view(b, cout, ho, wo)
         ctx.save_for_backward(col, wt16)
-        ctx.meta = (w.dtype, None if bias is None else bias.dtype, (b, cin, h, wd), stride)
+        ctx.meta = (w.dtype, None if bias is None else bias.dtype, (b, cin, h, wd), stride, fold)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         col, wt16 = ctx.saved_tensors
-        wdt, bdt, (b, cin, h, wd), stride = ctx.meta
+        wdt, bdt, (b, cin, h, wd), stride, fold = ctx.meta
         kp, cout = (int(v) for v in wt16.shape)
-        hwo, dev, dt = int(col.shape[2]), col.device, col.dtype
+        gb, ghw, dev, dt = int(col.shape[0]), int(col.shape[2]), col.device, col.dtype
         gy = gy.contiguous()
         if gy.dtype != dt:
             gy = gy.to(dt)
+        g3 = gy.view(b, cout, -1)
+        gf = _fold(g3) if fold else g3  # [gb, cout, ghw]
         code = N.dtype_code(col)
-        gx = gw = gb = None
+        gx = gw = gbias = None
         with torch.cuda.device(dev):
             sp = N.stream_ptr(dev)
             if ctx.needs_input_grad[0]:
                 if cout % 8 == 0:
                     dcol = torch.empty_like(col)
-                    N.check(N.lib.ssdk_pw_forward(gy.data_ptr(), wt16.data_ptr(), None, dcol.data_ptr(), b, cout, kp, hwo, code, sp),
+                    N.check(N.lib.ssdk_pw_forward(gf.data_ptr(), wt16.data_ptr(), None, dcol.data_ptr(), gb, cout, kp, ghw, code, sp),
                             "pw_forward (3x3 input gradient)")
                 else:
-                    dcol = torch.matmul(wt16, gy.view(b, cout, hwo)).contiguous()
+                    dcol = torch.matmul(wt16, gf).contiguous()
                 gx = torch.empty((b, cin, h, wd), device=dev, dtype=dt)
-                N.check(N.lib.ssdk_col2im3x3(dcol.data_ptr(), gx.data_ptr(), b, cin, h, wd, stride, code, sp), "col2im3x3")
+                fn = N.lib.ssdk_col2im3x3_folded if fold else N.lib.ssdk_col2im3x3
+                N.check(fn(dcol.data_ptr(), gx.data_ptr(), b, cin, h, wd, stride, code, sp), "col2im3x3")
             if ctx.needs_input_grad[1]:
-                need = int(N.lib.ssdk_pw_wgrad_workspace_bytes(b, cout, kp, hwo))
+                need = int(N.lib.ssdk_pw_wgrad_workspace_bytes(gb, cout, kp, ghw))
                 ws = torch.empty(need, dtype=torch.uint8, device=dev)
                 gw32 = torch.empty((cout, kp), device=dev, dtype=torch.float32)
-                N.check(N.lib.ssdk_pw_wgrad(gy.data_ptr(), col.data_ptr(), gw32.data_ptr(), ws.data_ptr(), need, b, cout, kp, hwo, code, sp),
+                N.check(N.lib.ssdk_pw_wgrad(gf.data_ptr(), col.data_ptr(), gw32.data_ptr(), ws.data_ptr(), need, gb, cout, kp, ghw, code, sp),
                         "pw_wgrad (3x3)")
                 gw = gw32[:, : cin * 9].reshape(cout, cin, 3, 3)
                 gw = gw if wdt == torch.float32 else gw.to(wdt)
         if bdt is not None and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2, 3), dtype=torch.float32).to(bdt)
-        return gx, gw, gb, None
+            gbias = gy.sum((0, 2, 3), dtype=torch.float32).to(bdt)
+        return gx, gw, gbias, None
 
 
 class NativeConv3x3(nn.Conv2d):

@@ -61,19 +61,22 @@ class Solver(object):
         from ssds.modeling.layers.headconv import use_head_pairs
 
         use_head_pairs(self.model)  # SSD heads: forward of each level's loc | conf pair on the inference kernels (SSDK_HEAD_PAIR=0: MIOpen)
-        if os.environ.get("SSDK_CONV3_NATIVE", "0") == "2" and hasattr(self.model, "extras"):
-            # NO library convolution left in the step: the extras' four 3x3 / stride-2 layers as im2col + ssdk_pw_* + col2im and the
-            # weight gradients of the small head levels on ssdk_pw_wgrad too.  Correct and OFF by default: 17.6 vs 17.0 ms per step
-            # (tools/run/r06_s39.sh, r06_s40.sh: the library's implicit-GEMM kernels are faster on these K = 576 ... 2304 layers)
-            from ssds.modeling.layers import headconv
+        conv3 = os.environ.get("SSDK_CONV3_NATIVE", "2")
+        from ssds.modeling.layers import headconv
+
+        headconv.WGRAD_MIN_PIXELS = 64 if conv3 == "0" else 0
+        if conv3 == "2" and hasattr(self.model, "extras"):
+            # (default) NO library convolution in the step: the extras' 3x3 / stride-2 layers as im2col + ssdk_pw_* + col2im with the
+            # batch folded into the GEMM's pixel dimension (64 / 16 / 4 / 1 pixels per image: pointwise.FOLD_BELOW), and the weight
+            # gradients of the small head levels on ssdk_pw_wgrad the same way.  tools/run/r06_s53.sh: 16.7 vs 17.0 ms per step
+            # against the library (SSDK_CONV3_NATIVE=0); before the fold the same path was 0.6 ms SLOWER than the library
             from ssds.modeling.layers.pointwise import use_native_conv3x3
 
             use_native_conv3x3(self.model.extras)
-            headconv.WGRAD_MIN_PIXELS = 0
-        if os.environ.get("SSDK_CONV3_NATIVE", "0") == "1":
-            # stem / extras / head 3x3 convolutions as im2col + the same kernels.  Correct (tests/test_gpu_train.py) and OFF by
-            # default: measured 23.2 vs 20.8 ms per step against MIOpen's implicit-GEMM kernels (round 6, session 4: the streaming
-            # 1x1 kernels are the wrong shape for K = 864 ... 4608 at 480 output channels)
+        if conv3 == "1":
+            # EVERY 3x3 layer (the heads too) as im2col + the 1x1 kernels.  Correct (tests/test_gpu_train.py) and slow: 23.2 vs
+            # 20.8 ms per step when it was measured (round 6, session 4: the streaming 1x1 kernels are the wrong shape for
+            # K = 864 ... 4608 at 480 output channels; the heads run on the inference kernels instead: headconv.py)
             from ssds.modeling.layers.pointwise import use_native_conv3x3
 
             use_native_conv3x3(self.model)

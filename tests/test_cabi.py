@@ -21,7 +21,7 @@ def test_header_symbols_exported():
     assert declared == set(N.EXPORTS), declared ^ set(N.EXPORTS)
     for name in declared:
         assert hasattr(N.lib, name), name
-    assert N.lib.ssdk_version() == 243 == N.ABI_VERSION
+    assert N.lib.ssdk_version() == 244 == N.ABI_VERSION
 
 
 def test_descriptor_layouts_are_the_ones_the_library_was_built_with():

@@ -1286,8 +1286,8 @@ def _device_step(model, anchors, images, targets, cfg, autocast, ssdk=True, ddp=
         from ssds.modeling.layers.pointwise import use_native_stem
 
         assert use_native_stem(m) == 1  # (the image-side convolution on csrc/ssdk_stemtrain.hip, as ssds/utils/train_ddp.py)
-        if conv3:  # (optional in the product too: SSDK_CONV3_NATIVE=1, ssds/utils/train_ddp.py)
-            use_native_conv3x3(m)
+        # (the product, ssds/utils/train_ddp.py: the extras' 3x3 layers on the kernels by default; SSDK_CONV3_NATIVE=1: every 3x3 layer)
+        use_native_conv3x3(m if conv3 else m.extras)
     else:
         for mod in m.modules():
             if type(mod) is DepthwiseConv2d:
