@@ -7,6 +7,6 @@ timeout 400 python tools/bench_train.py --steps 30 --warmup 10 --size 300 > $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/tr
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT/tr -- python $GRAFT_REPO_ROOT/tools/bench_train.py --steps 6 --warmup 3 > $OUT/prof_log.txt 2>&1
-python $GRAFT_REPO_ROOT/tools/trace_tail.py $(ls $OUT/tr/*/*kernel_trace.csv | head -1) 100 > $OUT/train_kernel_split.txt
+python $GRAFT_REPO_ROOT/tools/trace_tail.py $(ls $OUT/tr/*/*kernel_trace.csv | head -1) 100 400 > $OUT/train_kernel_split.txt
 head -12 $OUT/train_kernel_split.txt; grep -c Cijk $OUT/train_kernel_split.txt
 rm -rf $OUT/tr
