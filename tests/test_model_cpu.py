@@ -555,3 +555,24 @@ def test_fragment_major_weight_image_layout_and_size():
     assert dw.frag() is None                                           # depthwise: no MFMA operand stream
     odd = FC.ConvPack(nn.Conv2d(24, 64, 3, 1, 1, bias=False), nn.BatchNorm2d(64), "relu", torch.bfloat16)
     assert odd.frag() is None                                          # Cin % 32 != 0
+
+
+def test_batch_fold_of_the_small_map_layers_is_a_pure_permutation():
+    """pointwise._fold / _unfold (round 6): [B, C, P] <-> [1, C, B * P] with pixel index b * P + p -- the layout
+    ssdk_im2col3x3_folded writes and ssdk_col2im3x3_folded reads, so that the 1x1 kernels see ONE image of B * P pixels where a
+    layer has only 64 / 16 / 4 / 1 pixels per image (the SSD extras).  A round trip is the identity, column b * P + p of the
+    folded tensor is pixel p of image b, and a GEMM on the folded operand equals the per-image GEMMs."""
+    import torch
+    from ssds.modeling.layers import pointwise as PW
+
+    torch.manual_seed(0)
+    for b, c, p_ in ((4, 5, 16), (3, 2, 1), (2, 7, 100)):
+        t = torch.randn(b, c, p_)
+        f = PW._fold(t)
+        assert f.shape == (1, c, b * p_) and f.is_contiguous()
+        assert torch.equal(PW._unfold(f, b), t)
+        for bi in range(b):
+            assert torch.equal(f[0, :, bi * p_:(bi + 1) * p_], t[bi])
+        w = torch.randn(6, c)
+        assert torch.allclose(PW._unfold(torch.matmul(w, f), b), torch.matmul(w, t), atol=1e-6)
+    assert PW.FOLD_BELOW == 128  # (the 1x1 kernels' pixel group)
